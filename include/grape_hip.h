@@ -1,0 +1,165 @@
+/*
+ * grape_hip.h -- C ABI of libgrape_hip.so, the MI355X (gfx950) GRAPE propagator/gradient
+ * engine that replaces the body of the (F, G, x) closure QuOptimalControl.jl hands to Optim.
+ *
+ * The reference has no FFI of its own (pure Julia); the seam is the closure `topt` built in
+ *   solve(::Problem, ::GRAPE)          /root/reference/src/solve.jl:63-143  (closure :75-100)
+ *   solve(::EnsembleProblem, ::GRAPE)  /root/reference/src/solve.jl:145-250 (closure :164-196)
+ * whose body is  _fom_and_gradient_GRAPE!  (src/GRAPE.jl:25-96)  looped over the ensemble.
+ * Each entry point below names the reference code it stands in for.  INTEGRATION.md shows the
+ * Julia `ccall` glue (julia/GrapeHIP.jl) and the Python ctypes binding that mirror it.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types.  Every function returns a grape_status
+ *     (0 = OK, negative = error); grape_last_error() gives the message.  No exceptions cross.
+ *   - complex numbers are interleaved {re, im} doubles == Julia ComplexF64 == double _Complex.
+ *   - matrices are column-major (Julia): element (i,j) of an n x n matrix at i + j*n.
+ *   - x and G are (K, N) column-major Float64: x[j,i] at j + i*K  (what Optim hands in/out).
+ *   - host-pointer arguments are only read/written during the call; the library keeps no
+ *     caller pointer after return (Julia: GC.@preserve for the duration of the ccall).
+ *   - one evaluation in flight per context (like the reference's closure, which shares one
+ *     evolve_store, src/solve.jl:162); distinct contexts are independent.
+ */
+#ifndef GRAPE_HIP_H
+#define GRAPE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRAPE_ABI_VERSION 1
+
+typedef enum grape_status {
+    GRAPE_OK = 0,
+    GRAPE_ERR_INVALID_ARG = -1,   /* null pointer, non-positive size, bad enum           */
+    GRAPE_ERR_UNSUPPORTED = -2,   /* operator dimension / option this build has no kernel for */
+    GRAPE_ERR_NO_DEVICE = -3,     /* no HIP device / wrong architecture                 */
+    GRAPE_ERR_HIP = -4,           /* a HIP runtime call failed (message has the detail) */
+    GRAPE_ERR_NOT_READY = -5,     /* grape_eval before grape_set_operators              */
+    GRAPE_ERR_ALLOC = -6          /* host or device allocation failed                   */
+} grape_status;
+
+/* src/problems.jl:8-10.  CoherenceTransfer dispatches exactly like StateTransfer
+ * (src/GRAPE.jl:197,236,276,294; src/cost_functions.jl:104). */
+typedef enum grape_sys_type {
+    GRAPE_UNITARY_GATE = 0,
+    GRAPE_STATE_TRANSFER = 1,
+    GRAPE_COHERENCE_TRANSFER = 2
+} grape_sys_type;
+
+/* GRAPE(isinplace=true)  -> _fom_and_gradient_GRAPE!  (src/GRAPE.jl:25-96):   H = (sum_j B_j x_j) + A,
+ *                           UnitaryGate gradient sign +i (src/GRAPE.jl:272)
+ * GRAPE(isinplace=false) -> _fom_and_gradient_sGRAPE  (src/GRAPE.jl:103-166): H = A + sum_j B_j x_j,
+ *                           UnitaryGate gradient sign -i (src/GRAPE.jl:290) */
+typedef enum grape_variant {
+    GRAPE_VARIANT_INPLACE = 0,
+    GRAPE_VARIANT_STATIC = 1
+} grape_variant;
+
+enum {
+    GRAPE_FLAG_KEEP_COSTATES = 1 << 0,  /* debug: also store every costate L_t so that
+                                           grape_get_trajectory can return them         */
+    GRAPE_FLAG_TIME_KERNELS = 1 << 1    /* record HIP events around the sweep kernel of every
+                                           evaluation (see grape_get_kernel_time)       */
+};
+
+/* Mirrors what solve() unpacks: Problem fields (src/problems.jl:19-28: sys_type, T,
+ * n_controls), the integrator's n_slices (src/timeevolution.jl:11-14), EnsembleProblem.n_ens
+ * (src/problems.jl:33-41) -- here: the members THIS context owns (a shard of the ensemble). */
+typedef struct grape_config {
+    int32_t sys_type;          /* grape_sys_type                                     */
+    int32_t variant;           /* grape_variant                                      */
+    int32_t n;                 /* operator dimension (d, or d*d for Liouvillians)    */
+    int32_t n_controls;        /* K                                                  */
+    int32_t n_slices;          /* N                                                  */
+    int32_t n_ensemble;        /* E owned by this context (1 for a plain Problem)    */
+    double  duration;          /* T                                                  */
+    int32_t device;            /* HIP device ordinal, -1 = current device            */
+    int32_t flags;             /* GRAPE_FLAG_*                                       */
+    /* tuning; 0 = choose automatically */
+    int32_t slices_per_lane;   /* S: consecutive time slices one lane owns           */
+    int32_t waves_per_member;  /* W: wavefronts that share one member's time axis    */
+    int32_t expm_squarings;    /* <0 = per slice from the generator norm; >=0 forces s */
+    int32_t reserved;
+} grape_config;
+
+typedef struct grape_info {
+    int32_t abi_version;
+    int32_t device;
+    int32_t compute_units;
+    int32_t slices_per_lane;       /* S in use                                          */
+    int32_t waves_per_member;      /* W in use                                          */
+    int32_t expm_squarings;        /* forced s, or -1 = per slice from the generator norm */
+    int32_t kernel_family;         /* 0 = register-resident small-n, 1 = LDS/MFMA tile  */
+    int32_t reserved;
+    double  expm_theta;            /* norm threshold below which no scaling/squaring is done */
+    uint64_t workspace_bytes;      /* device bytes owned by the context                 */
+    char    arch[32];              /* gcnArchName of the device                         */
+} grape_info;
+
+typedef struct grape_ctx grape_ctx;
+
+/* ABI version of the loaded library (== GRAPE_ABI_VERSION of the header it was built from). */
+int grape_abi_version(void);
+
+/* Replaces init_GRAPE (src/grape_tools.jl:4-16) + init_ensemble's allocation
+ * (src/tools.jl:42-53): creates the device workspace (propagators, forward states,
+ * per-member gradients) for the given shape.  *out is NULL on failure. */
+int grape_create(const grape_config *cfg, grape_ctx **out);
+
+/* Frees everything the context owns (Julia: finalizer). NULL is accepted. */
+int grape_destroy(grape_ctx *ctx);
+
+/* Uploads the per-member operators once -- what init_ensemble (src/tools.jl:42-53) produces by
+ * calling A_g(k), B_g(k), XiG(k), XtG(k), packed contiguously by the glue:
+ *   A  c128 (n,n,E)     B  c128 (n,n,K,E)     Xi, Xt  c128 (n,n,E)     wts  f64 (E)
+ * (wts: EnsembleProblem.wts, src/problems.jl:40; pass {1.0} for a plain Problem). */
+int grape_set_operators(grape_ctx *ctx, const double *A, const double *B, const double *Xi,
+                        const double *Xt, const double *wts);
+
+/* The closure body, src/solve.jl:164-196 (E>1) / :75-100 (E=1):
+ *   F = sum_k w_k F_k ,  G[c,t] = sum_k w_k g_k[c,t]   with (F_k, g_k) = _fom_and_gradient_GRAPE!.
+ * x: host (K,N) f64.  F (nullable): host f64.  G (nullable): host (K,N) f64 -- Optim passes
+ * `nothing` for the one it does not need (src/solve.jl:189-195).  Blocks until F/G are written.
+ * Non-finite x propagates NaN like the reference (no trapping). */
+int grape_eval(grape_ctx *ctx, const double *x, double *F, double *G);
+
+/* Same evaluation with device-resident input/output, asynchronous on `stream`
+ * (a hipStream_t; NULL = the default stream):
+ *   d_x   device (K,N) f64            d_fg  device f64[K*N + 1] = { G (K,N col-major), F }
+ * This is the entry point the multi-GPU host layer uses: each rank evaluates its member shard
+ * and a single all-reduce(sum) of d_fg over ranks completes src/solve.jl:171-191.
+ * Nothing is synchronised; errors detectable at enqueue time are returned. */
+int grape_eval_device(grape_ctx *ctx, const double *d_x, double *d_fg, void *stream);
+
+/* Debug/parity accessors (valid after an evaluation):
+ * per-member unweighted results, as the reference's `gradient[k,:,:]` and the F_k summands:
+ *   foms  host f64[E] (nullable)      grads  host f64 (K,N,E) (nullable) */
+int grape_get_member_results(grape_ctx *ctx, double *foms, double *grads);
+
+/* The stores the reference keeps per member (src/grape_tools.jl:4-16), for parity tests:
+ *   props     c128 (n,n,N)     propagators[t],  t = 0..N-1
+ *   states    c128 (n,n,N+1)   fwd_state_store[t], t = 0..N   (states[0] = Xi)
+ *   costates  c128 (n,n,N+1)   bwd_costate_store[t], t = 0..N (costates[N] = Xt);
+ *                              needs GRAPE_FLAG_KEEP_COSTATES, else GRAPE_ERR_NOT_READY.
+ * Any of the three may be NULL. */
+int grape_get_trajectory(grape_ctx *ctx, int32_t member, double *props, double *states,
+                         double *costates);
+
+/* Sum and count of the sweep kernel's HIP-event durations recorded since the last reset
+ * (GRAPE_FLAG_TIME_KERNELS).  Synchronises the recorded events.  reset != 0 clears them. */
+int grape_get_kernel_time(grape_ctx *ctx, double *total_ms, int64_t *launches, int32_t reset);
+
+int grape_get_info(const grape_ctx *ctx, grape_info *info);
+
+/* Message of the last error on this context (ctx == NULL: of the last failed grape_create
+ * on the calling thread).  Never NULL. */
+const char *grape_last_error(const grape_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPE_HIP_H */

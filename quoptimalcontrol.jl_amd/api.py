@@ -1,0 +1,188 @@
+"""Host-side mirror of the reference's user surface for the GRAPE path.
+
+Names, fields and argument meaning follow /root/reference so that the parity tests read like
+the reference's own tests (test/state_transfer_tests.jl, test/unitary_gate_tests.jl):
+
+  Problem(B, A, Xi, Xt, T, n_controls, guess, sys_type)        src/problems.jl:19-28
+  EnsembleProblem(prob, n_ens, A_g, B_g, XiG, XtG, wts)        src/problems.jl:33-41
+  StateTransfer() / UnitaryGate() / CoherenceTransfer()        src/problems.jl:8-10
+  GRAPE(n_slices=..., isinplace=True, optim_options=...)       src/solve.jl:33-42
+  solve(prob, alg) -> SolutionResult / EnsembleSolutionResult  src/solve.jl:63-143, :145-250
+  init_ensemble(ens)                                           src/tools.jl:42-53
+  C1(KT, KN)                                                   src/cost_functions.jl:13-17
+
+What differs, on purpose: the body of the (F, G, x) closure is one call into libgrape_hip.so
+(engine.GrapeEngine) instead of _fom_and_gradient_GRAPE!, and the L-BFGS driver is SciPy's
+(the optimiser is outside the hot path; Optim.jl is a third-party dependency of the
+reference).  Generator callables A_g/B_g/XiG/XtG receive the 1-based member index k, as in
+Julia.
+"""
+from dataclasses import dataclass, field
+from typing import Any, Callable, Optional
+
+import numpy as np
+
+from .engine import GrapeEngine
+
+
+class _SysType:
+    name = ""
+
+    def __repr__(self):
+        return f"{self.name}()"
+
+    def __eq__(self, other):
+        return type(self) is type(other)
+
+    def __hash__(self):
+        return hash(self.name)
+
+
+class StateTransfer(_SysType):
+    name = "StateTransfer"
+
+
+class UnitaryGate(_SysType):
+    name = "UnitaryGate"
+
+
+class CoherenceTransfer(_SysType):
+    name = "CoherenceTransfer"
+
+
+@dataclass
+class Problem:
+    B: Any                 # list of K control operators (n x n)
+    A: Any                 # drift operator (n x n)
+    Xi: Any                # initial state / operator
+    Xt: Any                # target state / operator
+    T: float               # pulse duration
+    n_controls: int
+    guess: Any             # (K, N) initial controls
+    sys_type: _SysType
+
+
+@dataclass
+class EnsembleProblem:
+    prob: Problem
+    n_ens: int
+    A_g: Callable[[int], Any]
+    B_g: Callable[[int], Any]
+    XiG: Callable[[int], Any]
+    XtG: Callable[[int], Any]
+    wts: Any
+
+
+@dataclass
+class GRAPE:
+    n_slices: int
+    expm_method: str = "fast"      # stored and never read, like the reference (src/solve.jl:39-41,66)
+    isinplace: bool = True
+    optim_options: dict = field(default_factory=dict)
+    device: int = -1               # HIP device ordinal (new: the reference has no devices)
+
+
+@dataclass
+class SolutionResult:
+    result: Any
+    fidelity: float
+    opti_pulses: Any
+    problem: Problem
+    alg: GRAPE
+
+
+@dataclass
+class EnsembleSolutionResult:
+    result: Any
+    fidelity: float
+    opti_pulses: Any
+    problem: EnsembleProblem
+    alg: GRAPE
+
+
+def C1(KT, KN):
+    """Density-matrix infidelity, src/cost_functions.jl:13-17."""
+    KT = np.asarray(KT, complex)
+    KN = np.asarray(KN, complex)
+    D = KT.shape[0]
+    return 1.0 - abs(np.trace(KT.conj().T @ KN) / D) ** 2
+
+
+def init_ensemble(ens):
+    """src/tools.jl:42-53: one Problem per member with A, B, Xi, Xt from the generators."""
+    out = []
+    for k in range(1, ens.n_ens + 1):
+        p = ens.prob
+        out.append(Problem(B=ens.B_g(k), A=ens.A_g(k), Xi=ens.XiG(k), Xt=ens.XtG(k), T=p.T,
+                           n_controls=p.n_controls, guess=p.guess, sys_type=p.sys_type))
+    return out
+
+
+def _pack(problems):
+    A = np.array([np.asarray(p.A, complex) for p in problems])
+    B = np.array([[np.asarray(b, complex) for b in p.B] for p in problems])
+    Xi = np.array([np.asarray(p.Xi, complex) for p in problems])
+    Xt = np.array([np.asarray(p.Xt, complex) for p in problems])
+    return A, B, Xi, Xt
+
+
+def make_engine(prob, alg, **engine_kw):
+    """Build the device context for a Problem (E = 1) or an EnsembleProblem."""
+    if isinstance(prob, EnsembleProblem):
+        members = init_ensemble(prob)
+        wts = np.asarray(prob.wts, dtype=np.float64)
+    else:
+        members = [prob]
+        wts = np.ones(1)
+    first = members[0]
+    if len(first.B) != first.n_controls:
+        raise ValueError("n_controls does not match the number of control operators")
+    A, B, Xi, Xt = _pack(members)
+    return GrapeEngine(first.sys_type.name, A, B, Xi, Xt, wts, first.T, alg.n_slices,
+                       variant=0 if alg.isinplace else 1, device=alg.device, **engine_kw)
+
+
+def fom_and_gradient(prob, alg, x, engine=None):
+    """One call of the closure `topt(F, G, x)` (src/solve.jl:75-100 / :164-196)."""
+    own = engine is None
+    eng = engine or make_engine(prob, alg)
+    try:
+        return eng.eval(x)
+    finally:
+        if own:
+            eng.close()
+
+
+def _lbfgs(topt, x0, options):
+    """Stand-in for Optim.optimize(Optim.only_fg!(topt), x0, LBFGS(), opts) (src/solve.jl:138)."""
+    from scipy.optimize import minimize
+
+    shape = x0.shape
+    opts = {"maxiter": int(options.get("iterations", 1000)), "gtol": float(options.get("g_tol", 1e-8)),
+            "ftol": float(options.get("f_tol", 0.0)) or 1e-15, "maxls": 40}
+
+    def fun(xflat):
+        F, G = topt(xflat.reshape(shape))
+        return F, G.reshape(-1)
+
+    res = minimize(fun, np.asarray(x0, float).reshape(-1), jac=True, method="L-BFGS-B", options=opts)
+    res.minimum = float(res.fun)
+    res.minimizer = res.x.reshape(shape)
+    return res
+
+
+def solve(prob, alg: Optional[GRAPE] = None, engine=None):
+    """solve(::Problem, ::GRAPE) / solve(::EnsembleProblem, ::GRAPE)."""
+    if alg is None:
+        raise TypeError("solve(prob) without an algorithm has no integrator in the reference either "
+                        "(src/solve.jl:57,66); pass GRAPE(n_slices=...)")
+    own = engine is None
+    eng = engine or make_engine(prob, alg)
+    try:
+        guess = np.asarray((prob.prob if isinstance(prob, EnsembleProblem) else prob).guess, float)
+        res = _lbfgs(lambda x: eng.eval(x), guess, alg.optim_options)
+    finally:
+        if own:
+            eng.close()
+    cls = EnsembleSolutionResult if isinstance(prob, EnsembleProblem) else SolutionResult
+    return cls(res, res.minimum, res.minimizer, prob, alg)

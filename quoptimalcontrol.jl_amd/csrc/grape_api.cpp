@@ -1,0 +1,408 @@
+// grape_api.cpp -- C-ABI host layer of libgrape_hip.so (include/grape_hip.h).
+//
+// Owns the device workspace (what init_GRAPE allocates on the Julia heap,
+// /root/reference/src/grape_tools.jl:4-16), uploads the operators once, and turns one call of
+// the reference's (F, G, x) closure (src/solve.jl:164-196) into: sweep kernel -> 2 reduce
+// launches, all asynchronous on one HIP stream.  There is NO CPU fallback: without a gfx950
+// device every entry point fails with GRAPE_ERR_NO_DEVICE.
+#include "../../include/grape_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "grape_kernels.hpp"
+
+using grape::SweepParams;
+typedef std::complex<double> cplx;
+
+struct grape_ctx {
+    grape_config cfg{};
+    int device = 0;
+    int compute_units = 0;
+    char arch[32] = {0};
+    int S = 0, W = 0, LT = 0;
+    int ksplit = 1;
+    size_t ws_elems = 0;          // double2 elements per workspace array
+    uint64_t bytes = 0;
+    // device
+    double2 *d_ops = nullptr;
+    double *d_wts = nullptr;
+    double *d_x = nullptr;
+    double *d_fg = nullptr;
+    double2 *d_props = nullptr, *d_states = nullptr, *d_costates = nullptr;
+    double *d_member_out = nullptr;
+    double *d_partial = nullptr;
+    // host
+    double *h_stage = nullptr;    // pinned, K*N + 1 doubles (x in, fg out)
+    hipStream_t stream = nullptr;
+    bool ops_set = false, evaluated = false;
+    std::vector<hipEvent_t> ev;   // start/stop pairs of the sweep kernel
+    size_t ev_used = 0;
+    double ev_total_ms = 0.0;
+    int64_t ev_count = 0;
+    mutable std::string err;
+};
+
+static thread_local std::string g_create_err = "";
+
+static int fail(const grape_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                     \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return fail(ctx, e__ == hipErrorOutOfMemory ? GRAPE_ERR_ALLOC : GRAPE_ERR_HIP,     \
+                        std::string(#call) + ": " + hipGetErrorString(e__));                   \
+    } while (0)
+
+static size_t KN(const grape_ctx *c) { return (size_t)c->cfg.n_controls * c->cfg.n_slices; }
+
+static void free_all(grape_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    (void)hipFree(c->d_ops); (void)hipFree(c->d_wts); (void)hipFree(c->d_x); (void)hipFree(c->d_fg);
+    (void)hipFree(c->d_props); (void)hipFree(c->d_states); (void)hipFree(c->d_costates);
+    (void)hipFree(c->d_member_out); (void)hipFree(c->d_partial);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    delete c;
+}
+
+extern "C" int grape_abi_version(void) { return GRAPE_ABI_VERSION; }
+
+extern "C" const char *grape_last_error(const grape_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
+{
+    if (out) *out = nullptr;
+    if (!cfg || !out) return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: null argument");
+    if (cfg->sys_type < GRAPE_UNITARY_GATE || cfg->sys_type > GRAPE_COHERENCE_TRANSFER)
+        return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: bad sys_type");
+    if (cfg->variant != GRAPE_VARIANT_INPLACE && cfg->variant != GRAPE_VARIANT_STATIC)
+        return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: bad variant");
+    if (cfg->n < 1 || cfg->n_controls < 1 || cfg->n_slices < 1 || cfg->n_ensemble < 1)
+        return fail(nullptr, GRAPE_ERR_INVALID_ARG,
+                    "grape_create: n, n_controls, n_slices, n_ensemble must be positive");
+    if (!(cfg->duration == cfg->duration))
+        return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: duration is NaN");
+    const int wmax = grape::sweep_small_max_waves(cfg->n);
+    if (wmax == 0)
+        return fail(nullptr, GRAPE_ERR_UNSUPPORTED,
+                    "grape_create: operator dimension n=" + std::to_string(cfg->n) +
+                        " has no kernel in this build (supported: 2, 3, 4)");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, GRAPE_ERR_NO_DEVICE, "grape_create: no HIP device visible");
+    int dev = cfg->device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= ndev)
+        return fail(nullptr, GRAPE_ERR_NO_DEVICE, "grape_create: device ordinal out of range");
+    HIP_TRY(nullptr, hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("GRAPE_HIP_ANY_ARCH"))
+        return fail(nullptr, GRAPE_ERR_NO_DEVICE,
+                    std::string("grape_create: device is ") + prop.gcnArchName +
+                        ", this library carries gfx950 code only");
+
+    grape_ctx *c = new (std::nothrow) grape_ctx();
+    if (!c) return fail(nullptr, GRAPE_ERR_ALLOC, "grape_create: out of host memory");
+    c->cfg = *cfg;
+    c->device = dev;
+    c->compute_units = prop.multiProcessorCount;
+    std::snprintf(c->arch, sizeof(c->arch), "%s", prop.gcnArchName);
+
+    // time-axis decomposition: W waves per member, S slices per lane, S * 64 * W >= N.
+    // Aim for one wave per SIMD across the chip; more waves per member only when the
+    // ensemble alone cannot fill it.
+    const int N = cfg->n_slices, E = cfg->n_ensemble;
+    int W = cfg->waves_per_member;
+    if (W <= 0) {
+        const long simds = 4L * c->compute_units;
+        W = (int)((simds + E - 1) / E);
+        const int wneed = (N + 63) / 64;
+        if (W > wneed) W = wneed;
+    }
+    if (W > wmax) W = wmax;
+    if (W < 1) W = 1;
+    int S = cfg->slices_per_lane;
+    const int smin = (N + 64 * W - 1) / (64 * W);
+    if (S < smin) S = smin;
+    c->W = W; c->S = S; c->LT = 64 * W;
+    c->ksplit = grape::reduce_ksplit(E);
+
+    const size_t nn = (size_t)cfg->n * cfg->n, K = cfg->n_controls;
+    const size_t Q = KN(c) + 1;
+    c->ws_elems = (size_t)E * S * nn * c->LT;
+    const bool keepl = (cfg->flags & GRAPE_FLAG_KEEP_COSTATES) != 0;
+
+    auto alloc = [&](void **p, size_t bytes) -> hipError_t {
+        c->bytes += bytes;
+        return hipMalloc(p, bytes);
+    };
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = alloc((void **)&c->d_ops, sizeof(double2) * E * (K + 3) * nn);
+    if (e == hipSuccess) e = alloc((void **)&c->d_wts, sizeof(double) * E);
+    if (e == hipSuccess) e = alloc((void **)&c->d_x, sizeof(double) * KN(c));
+    if (e == hipSuccess) e = alloc((void **)&c->d_fg, sizeof(double) * Q);
+    if (e == hipSuccess) e = alloc((void **)&c->d_props, sizeof(double2) * c->ws_elems);
+    if (e == hipSuccess) e = alloc((void **)&c->d_states, sizeof(double2) * c->ws_elems);
+    if (e == hipSuccess && keepl) e = alloc((void **)&c->d_costates, sizeof(double2) * c->ws_elems);
+    if (e == hipSuccess) e = alloc((void **)&c->d_member_out, sizeof(double) * E * Q);
+    if (e == hipSuccess) e = alloc((void **)&c->d_partial, sizeof(double) * c->ksplit * Q);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, sizeof(double) * Q, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        std::string msg = std::string("grape_create: device allocation failed: ") + hipGetErrorString(e);
+        free_all(c);
+        return fail(nullptr, e == hipErrorOutOfMemory ? GRAPE_ERR_ALLOC : GRAPE_ERR_HIP, msg);
+    }
+    *out = c;
+    return GRAPE_OK;
+}
+
+extern "C" int grape_destroy(grape_ctx *ctx)
+{
+    if (!ctx) return GRAPE_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    free_all(ctx);
+    return GRAPE_OK;
+}
+
+extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *B, const double *Xi,
+                                   const double *Xt, const double *wts)
+{
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (!A || !B || !Xi || !Xt || !wts)
+        return fail(c, GRAPE_ERR_INVALID_ARG, "grape_set_operators: null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nn = (size_t)c->cfg.n * c->cfg.n, K = c->cfg.n_controls, E = c->cfg.n_ensemble;
+    // interleave per member: [A | B_0..B_{K-1} | Xi | Xt]
+    std::vector<double> packed;
+    try {
+        packed.resize(2 * E * (K + 3) * nn);
+    } catch (...) {
+        return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: out of host memory");
+    }
+    for (size_t k = 0; k < E; ++k) {
+        double *dst = packed.data() + 2 * k * (K + 3) * nn;
+        std::memcpy(dst, A + 2 * k * nn, sizeof(double) * 2 * nn);
+        std::memcpy(dst + 2 * nn, B + 2 * k * K * nn, sizeof(double) * 2 * K * nn);
+        std::memcpy(dst + 2 * (1 + K) * nn, Xi + 2 * k * nn, sizeof(double) * 2 * nn);
+        std::memcpy(dst + 2 * (2 + K) * nn, Xt + 2 * k * nn, sizeof(double) * 2 * nn);
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->d_ops, packed.data(), sizeof(double) * packed.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_wts, wts, sizeof(double) * E, hipMemcpyHostToDevice));
+    c->ops_set = true;
+    c->evaluated = false;
+    return GRAPE_OK;
+}
+
+static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream_t stream)
+{
+    SweepParams p{};
+    p.ops = c->d_ops;
+    p.x = d_x;
+    p.props = c->d_props;
+    p.states = c->d_states;
+    p.costates = c->d_costates;
+    p.member_out = c->d_member_out;
+    p.K = c->cfg.n_controls;
+    p.N = c->cfg.n_slices;
+    p.E = c->cfg.n_ensemble;
+    p.S = c->S;
+    p.LT = c->LT;
+    p.s_forced = c->cfg.expm_squarings;
+    p.variant = c->cfg.variant;
+    p.dt = c->cfg.duration / c->cfg.n_slices;                 // src/GRAPE.jl:42
+    const bool timed = (c->cfg.flags & GRAPE_FLAG_TIME_KERNELS) != 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        if (c->ev_used + 2 > c->ev.size()) {
+            for (int i = 0; i < 2; ++i) {
+                hipEvent_t e;
+                HIP_TRY(c, hipEventCreate(&e));
+                c->ev.push_back(e);
+            }
+        }
+        e0 = c->ev[c->ev_used];
+        e1 = c->ev[c->ev_used + 1];
+        c->ev_used += 2;
+        HIP_TRY(c, hipEventRecord(e0, stream));
+    }
+    HIP_TRY(c, grape::launch_sweep_small(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE,
+                                         c->d_costates != nullptr, p, stream));
+    if (timed) HIP_TRY(c, hipEventRecord(e1, stream));
+    HIP_TRY(c, grape::launch_reduce(c->d_member_out, c->d_wts, c->d_partial, d_fg, p.E,
+                                    (int)(KN(c) + 1), c->ksplit, stream));
+    c->evaluated = true;
+    return GRAPE_OK;
+}
+
+extern "C" int grape_eval_device(grape_ctx *c, const double *d_x, double *d_fg, void *stream)
+{
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (!d_x || !d_fg) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval_device: null argument");
+    if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, "grape_eval_device: operators not set");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return enqueue_eval(c, d_x, d_fg, (hipStream_t)stream);
+}
+
+extern "C" int grape_eval(grape_ctx *c, const double *x, double *F, double *G)
+{
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (!x) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval: x is null");
+    if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, "grape_eval: operators not set");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t kn = KN(c);
+    std::memcpy(c->h_stage, x, sizeof(double) * kn);
+    HIP_TRY(c, hipMemcpyAsync(c->d_x, c->h_stage, sizeof(double) * kn, hipMemcpyHostToDevice, c->stream));
+    int rc = enqueue_eval(c, c->d_x, c->d_fg, c->stream);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_fg, sizeof(double) * (kn + 1), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (G) std::memcpy(G, c->h_stage, sizeof(double) * kn);
+    if (F) *F = c->h_stage[kn];
+    return GRAPE_OK;
+}
+
+extern "C" int grape_get_member_results(grape_ctx *c, double *foms, double *grads)
+{
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (!c->evaluated) return fail(c, GRAPE_ERR_NOT_READY, "grape_get_member_results: no evaluation yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    const size_t kn = KN(c), Q = kn + 1, E = c->cfg.n_ensemble;
+    std::vector<double> h(E * Q);
+    HIP_TRY(c, hipMemcpy(h.data(), c->d_member_out, sizeof(double) * E * Q, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < E; ++k) {
+        if (foms) foms[k] = h[k * Q + kn];
+        if (grads) std::memcpy(grads + k * kn, h.data() + k * Q, sizeof(double) * kn);
+    }
+    return GRAPE_OK;
+}
+
+// gathers one member's slab from the lane-major workspace layout into (n,n,count) col-major
+static int fetch_slab(grape_ctx *c, const double2 *d_ws, int member, cplx *out)
+{
+    const size_t nn = (size_t)c->cfg.n * c->cfg.n, S = c->S, LT = c->LT, N = c->cfg.n_slices;
+    std::vector<cplx> h(S * nn * LT);
+    HIP_TRY(c, hipMemcpy(h.data(), d_ws + (size_t)member * S * nn * LT, sizeof(cplx) * h.size(),
+                         hipMemcpyDeviceToHost));
+    for (size_t t = 0; t < N; ++t) {
+        const size_t L = t / S, j = t % S;
+        for (size_t e = 0; e < nn; ++e)
+            out[t * nn + e] = h[(j * nn + e) * LT + L];
+    }
+    return GRAPE_OK;
+}
+
+extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props, double *states,
+                                    double *costates)
+{
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (!c->evaluated) return fail(c, GRAPE_ERR_NOT_READY, "grape_get_trajectory: no evaluation yet");
+    if (member < 0 || member >= c->cfg.n_ensemble)
+        return fail(c, GRAPE_ERR_INVALID_ARG, "grape_get_trajectory: member out of range");
+    if (costates && !c->d_costates)
+        return fail(c, GRAPE_ERR_NOT_READY,
+                    "grape_get_trajectory: costates need GRAPE_FLAG_KEEP_COSTATES at grape_create");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    const int n = c->cfg.n;
+    const size_t nn = (size_t)n * n, N = c->cfg.n_slices, K = c->cfg.n_controls;
+    std::vector<cplx> P(N * nn);
+    int rc = fetch_slab(c, c->d_props, member, P.data());
+    if (rc) return rc;
+    if (props) std::memcpy(props, P.data(), sizeof(cplx) * N * nn);
+    if (states) {
+        cplx *X = reinterpret_cast<cplx *>(states);
+        rc = fetch_slab(c, c->d_states, member, X);
+        if (rc) return rc;
+        // the final state X_N is never needed by the gradient, so the kernel does not form
+        // it; complete the reference's fwd_state_store[N+1] here (debug accessor only).
+        const cplx *Pl = P.data() + (N - 1) * nn, *Xl = X + (N - 1) * nn;
+        cplx *Xn = X + N * nn;
+        std::vector<cplx> tmp(nn);
+        const bool sand = c->cfg.sys_type != GRAPE_UNITARY_GATE;
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) {
+                cplx s = 0.0;
+                for (int k = 0; k < n; ++k)
+                    s += sand ? Xl[i + k * n] * std::conj(Pl[j + k * n]) : Pl[i + k * n] * Xl[k + j * n];
+                (sand ? tmp[i + j * n] : Xn[i + j * n]) = s;
+            }
+        if (sand)
+            for (int j = 0; j < n; ++j)
+                for (int i = 0; i < n; ++i) {
+                    cplx s = 0.0;
+                    for (int k = 0; k < n; ++k) s += Pl[i + k * n] * tmp[k + j * n];
+                    Xn[i + j * n] = s;
+                }
+    }
+    if (costates) {
+        cplx *Lc = reinterpret_cast<cplx *>(costates);
+        rc = fetch_slab(c, c->d_costates, member, Lc);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpy(Lc + N * nn, c->d_ops + (size_t)member * (K + 3) * nn + (K + 2) * nn,
+                             sizeof(cplx) * nn, hipMemcpyDeviceToHost));
+    }
+    return GRAPE_OK;
+}
+
+extern "C" int grape_get_kernel_time(grape_ctx *c, double *total_ms, int64_t *launches, int32_t reset)
+{
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        HIP_TRY(c, hipEventSynchronize(c->ev[i + 1]));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        c->ev_total_ms += ms;
+        c->ev_count += 1;
+    }
+    c->ev_used = 0;
+    if (total_ms) *total_ms = c->ev_total_ms;
+    if (launches) *launches = c->ev_count;
+    if (reset) { c->ev_total_ms = 0.0; c->ev_count = 0; }
+    return GRAPE_OK;
+}
+
+extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
+{
+    if (!c || !info) return GRAPE_ERR_INVALID_ARG;
+    std::memset(info, 0, sizeof(*info));
+    info->abi_version = GRAPE_ABI_VERSION;
+    info->device = c->device;
+    info->compute_units = c->compute_units;
+    info->slices_per_lane = c->S;
+    info->waves_per_member = c->W;
+    info->expm_squarings = c->cfg.expm_squarings;
+    info->kernel_family = 0;
+    info->expm_theta = 0.05;
+    info->workspace_bytes = c->bytes;
+    std::snprintf(info->arch, sizeof(info->arch), "%s", c->arch);
+    return GRAPE_OK;
+}

@@ -1,0 +1,42 @@
+// grape_kernels.hpp -- launch interface between the C-ABI host layer (grape_api.cpp) and the
+// gfx950 kernels (sweep_small.hip, reduce.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace grape {
+
+// Device-side view of one context.  All complex data is interleaved double2 {re, im}.
+struct SweepParams {
+    // inputs
+    const double2 *ops;   // per member: [A | B_0..B_{K-1} | Xi | Xt], each n*n col-major  (E blocks)
+    const double *x;      // (K, N) col-major controls, shared by all members
+    // workspace (lane-major "chunk" layout):
+    //   element e of slice t = L*S + j of member k at  ((k*S + j)*n*n + e)*LT + L
+    double2 *props;       // P_t
+    double2 *states;      // X_t (state BEFORE slice t), t = 0..N-1
+    double2 *costates;    // L_t (debug only, GRAPE_FLAG_KEEP_COSTATES), same layout
+    // outputs
+    double *member_out;   // (K*N + 1) per member: unweighted g_k (K,N col-major), then F_k
+    int32_t K, N, E;
+    int32_t S;            // slices per lane
+    int32_t LT;           // lanes per member = 64 * W
+    int32_t s_forced;     // expm squarings, -1 = per slice from the norm
+    int32_t variant;      // 0 in-place, 1 static
+    double dt;
+};
+
+// which == 0: UnitaryGate chain; 1: State/CoherenceTransfer sandwich chain.
+// Returns hipSuccess or the launch error.  n must be 2, 3 or 4.
+hipError_t launch_sweep_small(int n, int sandwich, bool keep_costates, const SweepParams &p,
+                              hipStream_t stream);
+int sweep_small_max_waves(int n);   // W limit of the register-resident kernel for this n
+
+// G[q] = sum_k w_k member_out[k][q]  for q in [0, Q)  (Q = K*N + 1; the last entry is F).
+// partial: scratch of ksplit*Q doubles.  Deterministic (fixed summation tree).
+hipError_t launch_reduce(const double *member_out, const double *wts, double *partial, double *fg,
+                         int E, int Q, int ksplit, hipStream_t stream);
+int reduce_ksplit(int E);
+
+}  // namespace grape

@@ -1,0 +1,206 @@
+"""ctypes binding of libgrape_hip.so (include/grape_hip.h) -- the only compute path.
+
+There is deliberately no CPU fallback here: if the HIP library is missing or no gfx950
+device is visible, construction raises GrapeError.  (The CPU restatement under oracle/ is
+test infrastructure and is never imported from this package.)
+
+This is the Python twin of julia/GrapeHIP.jl: both pack the operators once
+(what init_ensemble produces, /root/reference/src/tools.jl:42-53), create a context
+(init_GRAPE, src/grape_tools.jl:4-16) and then forward every call of the (F, G, x) closure
+(src/solve.jl:164-196) to grape_eval.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SYS_TYPE_CODES = {"UnitaryGate": 0, "StateTransfer": 1, "CoherenceTransfer": 2}
+FLAG_KEEP_COSTATES = 1
+FLAG_TIME_KERNELS = 2
+
+STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID_ARG", -2: "GRAPE_ERR_UNSUPPORTED",
+          -3: "GRAPE_ERR_NO_DEVICE", -4: "GRAPE_ERR_HIP", -5: "GRAPE_ERR_NOT_READY",
+          -6: "GRAPE_ERR_ALLOC"}
+
+# every symbol include/grape_hip.h declares
+EXPORTS = ["grape_abi_version", "grape_create", "grape_destroy", "grape_set_operators",
+           "grape_eval", "grape_eval_device", "grape_get_member_results", "grape_get_trajectory",
+           "grape_get_kernel_time", "grape_get_info", "grape_last_error"]
+
+
+class GrapeError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS.get(status, status)}: {message}")
+        self.status = status
+
+
+class GrapeConfig(C.Structure):
+    _fields_ = [("sys_type", C.c_int32), ("variant", C.c_int32), ("n", C.c_int32),
+                ("n_controls", C.c_int32), ("n_slices", C.c_int32), ("n_ensemble", C.c_int32),
+                ("duration", C.c_double), ("device", C.c_int32), ("flags", C.c_int32),
+                ("slices_per_lane", C.c_int32), ("waves_per_member", C.c_int32),
+                ("expm_squarings", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GrapeInfo(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("compute_units", C.c_int32),
+                ("slices_per_lane", C.c_int32), ("waves_per_member", C.c_int32),
+                ("expm_squarings", C.c_int32), ("kernel_family", C.c_int32), ("reserved", C.c_int32),
+                ("expm_theta", C.c_double), ("workspace_bytes", C.c_uint64), ("arch", C.c_char * 32)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libgrape_hip.so")
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 build of csrc/ into libgrape_hip.so (in-tree)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return library_path()
+
+
+def load_library():
+    """dlopen libgrape_hip.so and declare the prototypes of include/grape_hip.h."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise GrapeError(-3, f"{path} not built (run __graft_entry__.build())")
+    L = C.CDLL(path)
+    vp, dp, i32 = C.c_void_p, C.POINTER(C.c_double), C.c_int32
+    L.grape_abi_version.restype = C.c_int
+    L.grape_create.argtypes = [C.POINTER(GrapeConfig), C.POINTER(vp)]
+    L.grape_destroy.argtypes = [vp]
+    L.grape_set_operators.argtypes = [vp] * 6
+    L.grape_eval.argtypes = [vp, vp, dp, vp]
+    L.grape_eval_device.argtypes = [vp, vp, vp, vp]
+    L.grape_get_member_results.argtypes = [vp, vp, vp]
+    L.grape_get_trajectory.argtypes = [vp, i32, vp, vp, vp]
+    L.grape_get_kernel_time.argtypes = [vp, dp, C.POINTER(C.c_int64), i32]
+    L.grape_get_info.argtypes = [vp, C.POINTER(GrapeInfo)]
+    L.grape_last_error.argtypes = [vp]
+    L.grape_last_error.restype = C.c_char_p
+    for name in EXPORTS:
+        if name not in ("grape_last_error",):
+            getattr(L, name).restype = C.c_int
+    _LIB = L
+    return L
+
+
+def _cm(M):
+    """[..., i, j] complex -> contiguous buffer with each matrix column-major (Julia layout)."""
+    return np.ascontiguousarray(np.swapaxes(np.asarray(M, dtype=np.complex128), -1, -2))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class GrapeEngine:
+    """One context = one device + one shard of the ensemble.
+
+    A (E,n,n), B (E,K,n,n), Xi/Xt (E,n,n), wts (E,) -- natural numpy matrices A[k][i,j].
+    eval(x) -> (F, G) with x, G of shape (K, N) (x[j, i] as in the reference)."""
+
+    def __init__(self, sys_type, A, B, Xi, Xt, wts, T, n_slices, variant=0, device=-1, flags=0,
+                 slices_per_lane=0, waves_per_member=0, expm_squarings=-1):
+        self._h = None
+        self._lib = load_library()
+        A = np.asarray(A, dtype=np.complex128)
+        B = np.asarray(B, dtype=np.complex128)
+        if A.ndim != 3 or B.ndim != 4 or A.shape[1] != A.shape[2]:
+            raise ValueError("A must be (E,n,n) and B (E,K,n,n)")
+        E, n = A.shape[0], A.shape[1]
+        K = B.shape[1]
+        Xi = np.asarray(Xi, dtype=np.complex128)
+        Xt = np.asarray(Xt, dtype=np.complex128)
+        if B.shape != (E, K, n, n) or Xi.shape != (E, n, n) or Xt.shape != (E, n, n):
+            raise ValueError("operator shapes disagree (Xi/Xt must be n x n like A)")
+        wts = np.ascontiguousarray(wts, dtype=np.float64)
+        if wts.shape != (E,):
+            raise ValueError("wts must have one weight per member")
+        code = SYS_TYPE_CODES[sys_type] if isinstance(sys_type, str) else int(sys_type)
+        self.sys_type, self.n, self.K, self.N, self.E, self.T = sys_type, n, K, int(n_slices), E, float(T)
+        cfg = GrapeConfig(code, int(variant), n, K, int(n_slices), E, float(T), int(device), int(flags),
+                          int(slices_per_lane), int(waves_per_member), int(expm_squarings), 0)
+        h = C.c_void_p()
+        rc = self._lib.grape_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise GrapeError(rc, self._lib.grape_last_error(None).decode())
+        self._h = h
+        self._check(self._lib.grape_set_operators(h, _p(_cm(A)), _p(_cm(B)), _p(_cm(Xi)), _p(_cm(Xt)),
+                                                  _p(wts)))
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc:
+            raise GrapeError(rc, self._lib.grape_last_error(self._h).decode())
+
+    def close(self):
+        if self._h is not None:
+            self._lib.grape_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def info(self):
+        inf = GrapeInfo()
+        self._check(self._lib.grape_get_info(self._h, C.byref(inf)))
+        return {f: (getattr(inf, f).decode() if f == "arch" else getattr(inf, f)) for f, _ in inf._fields_}
+
+    # ------------------------------------------------------------------ evaluation
+    def eval(self, x, want_F=True, want_G=True):
+        """grape_eval: host x (K,N) -> (F, G); either may be skipped like Optim's only_fg!."""
+        x = np.asarray(x, dtype=np.float64)
+        if x.shape != (self.K, self.N):
+            raise ValueError(f"x must be ({self.K},{self.N})")
+        xf = np.ascontiguousarray(x.T)
+        F = C.c_double()
+        G = np.empty((self.N, self.K)) if want_G else None
+        self._check(self._lib.grape_eval(self._h, _p(xf), C.byref(F) if want_F else None, _p(G)))
+        return (F.value if want_F else None), (np.ascontiguousarray(G.T) if want_G else None)
+
+    def eval_device(self, d_x_ptr, d_fg_ptr, stream=0):
+        """grape_eval_device with raw device pointers (e.g. torch tensor .data_ptr())."""
+        self._check(self._lib.grape_eval_device(self._h, C.c_void_p(d_x_ptr), C.c_void_p(d_fg_ptr),
+                                                C.c_void_p(stream)))
+
+    def member_results(self):
+        foms = np.empty(self.E)
+        grads = np.empty((self.E, self.N, self.K))
+        self._check(self._lib.grape_get_member_results(self._h, _p(foms), _p(grads)))
+        return foms, np.ascontiguousarray(np.swapaxes(grads, 1, 2))
+
+    def trajectory(self, member, costates=False):
+        n, N = self.n, self.N
+        P = np.empty((N, n, n), np.complex128)
+        X = np.empty((N + 1, n, n), np.complex128)
+        Lc = np.empty((N + 1, n, n), np.complex128) if costates else None
+        self._check(self._lib.grape_get_trajectory(self._h, int(member), _p(P), _p(X), _p(Lc)))
+        sw = lambda a: np.ascontiguousarray(np.swapaxes(a, -1, -2))
+        return (sw(P), sw(X), sw(Lc)) if costates else (sw(P), sw(X))
+
+    def kernel_time(self, reset=False):
+        ms = C.c_double()
+        cnt = C.c_int64()
+        self._check(self._lib.grape_get_kernel_time(self._h, C.byref(ms), C.byref(cnt), int(reset)))
+        return ms.value, cnt.value

@@ -1,0 +1,237 @@
+"""Deterministic synthetic workloads for the BASELINE.json configs.
+
+Inputs are generated from a counter-based splitmix64 stream so that any language can
+regenerate them bit for bit:  u(s, i) = (splitmix64(s * 2**32 + i) >> 11) * 2**-53,
+stream ids: controls x -> 1, targets -> 2, detunings -> 3.
+
+Operators follow the reference's own fixtures: S = sigma/2 (test/setup_tests.jl:10-12),
+ensemble detuning generalising A_gens (test/setup_tests.jl:31), weights 1/E
+(test/state_transfer_tests.jl:63), the 4x4 / 500-slice / T=2 system of
+test/time_evol_tests.jl:5-32, and the Liouville-space superoperator of test/liou.jl:8-11.
+
+Array conventions (shared with the oracle's Python wrapper):
+  A (E,n,n)  B (E,K,n,n)  Xi,Xt (E,n,n)  wts (E,)  x (K,N)
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_M64 = (1 << 64) - 1
+
+
+def splitmix64(z):
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def uniform(stream, count, offset=0):
+    """count doubles in [0,1): u(stream, offset + i)."""
+    idx = (np.uint64(stream) << np.uint64(32)) + np.arange(offset, offset + count, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = idx + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+
+
+# spin-1/2 operators, test/setup_tests.jl:10-12
+Sx = np.array([[0, 1], [1, 0]], complex) / 2
+Sy = np.array([[0, -1j], [1j, 0]], complex) / 2
+Sz = np.array([[1, 0], [0, -1]], complex) / 2
+I2 = np.eye(2, dtype=complex)
+rho_init = np.array([[1, 0], [0, 0]], complex)      # test/setup_tests.jl:4
+rho_fin = np.array([[0, 0], [0, 1]], complex)       # test/setup_tests.jl:5
+U_init = np.eye(2, dtype=complex)                   # test/setup_tests.jl:21
+U_fin = np.array([[0, 1], [1, 0]], complex)         # test/setup_tests.jl:22
+
+
+def kron_all(*ops):
+    out = np.array([[1.0 + 0j]])
+    for o in ops:
+        out = np.kron(out, o)
+    return out
+
+
+def site_op(op, q, nq):
+    """op acting on qubit q (0-based) of nq qubits."""
+    return kron_all(*[op if i == q else I2 for i in range(nq)])
+
+
+def to_superoperator(H):
+    """test/liou.jl:8-11: kron(I, H) - kron(H', I)."""
+    D = H.shape[0]
+    return np.kron(np.eye(D), H) - np.kron(H.conj().T, np.eye(D))
+
+
+def dissipator(c):
+    """Column-stacking Lindblad dissipator of one collapse operator c:
+    vec(c rho c' - (c'c rho + rho c'c)/2) = D vec(rho)."""
+    D = c.shape[0]
+    cdc = c.conj().T @ c
+    return (np.kron(c.conj(), c) - 0.5 * np.kron(np.eye(D), cdc) - 0.5 * np.kron(cdc.T, np.eye(D)))
+
+
+def detunings(E):
+    if E == 1:
+        return np.zeros(1)
+    k = np.arange(E, dtype=np.float64)
+    return 5.0 * (2.0 * k / (E - 1) - 1.0)
+
+
+@dataclass
+class Workload:
+    name: str
+    sys_type: str
+    n: int
+    K: int
+    N: int
+    E: int
+    T: float
+    A: np.ndarray
+    B: np.ndarray
+    Xi: np.ndarray
+    Xt: np.ndarray
+    wts: np.ndarray
+    x: np.ndarray
+    note: str = ""
+    meta: dict = field(default_factory=dict)
+
+    def members(self, lo, hi):
+        """contiguous member shard [lo, hi) -- the multi-GPU partition."""
+        return Workload(self.name, self.sys_type, self.n, self.K, self.N, hi - lo, self.T,
+                        self.A[lo:hi], self.B[lo:hi], self.Xi[lo:hi], self.Xt[lo:hi],
+                        self.wts[lo:hi], self.x, self.note, dict(self.meta))
+
+    @property
+    def algorithmic_bytes(self):
+        """model S, BASELINE.md section 2: bytes per ensemble evaluation."""
+        n, K, N, E = self.n, self.K, self.N, self.E
+        return E * (64 * n * n * N + 16 * K * N + 16 * (K + 3) * n * n)
+
+    @property
+    def algorithmic_flops(self):
+        n, K, N, E = self.n, self.K, self.N, self.E
+        q = 3 if self.sys_type == "UnitaryGate" else 6
+        p = (2 + 4 / 3) if n <= 4 else (3 + 4 / 3)
+        return E * N * (8 * n ** 3 * (p + q) + 12 * K * n * n)
+
+
+def controls(K, N):
+    """x[j, i] = u(1, i*K + j)  (0-based i, j)"""
+    return np.ascontiguousarray(uniform(1, K * N).reshape(N, K).T)
+
+
+def _bcast(M, E):
+    return np.ascontiguousarray(np.broadcast_to(M, (E,) + M.shape))
+
+
+def single_qubit_state_transfer(N, T, name):
+    """C1 / C2: test/state_transfer_tests.jl:4-19 shape (A=Sz, B=[Sx,Sy], rho_init -> rho_fin)."""
+    K = 2
+    return Workload(name, "StateTransfer", 2, K, N, 1, T, Sz[None], np.array([[Sx, Sy]]),
+                    rho_init[None], rho_fin[None], np.ones(1), controls(K, N))
+
+
+def two_qubit_unitary(E=1024, N=500, T=2.0):
+    """C3 (headline): 4x4 UnitaryGate, K=4, drift of test/time_evol_tests.jl:11 plus detuning."""
+    K = 4
+    d = detunings(E)
+    H0 = np.kron(Sx, Sz)
+    Hz = np.kron(Sz, I2) + np.kron(I2, Sz)
+    A = H0[None] + d[:, None, None] * Hz[None]
+    Bs = np.array([np.kron(Sx, I2), np.kron(Sy, I2), np.kron(I2, Sx), np.kron(I2, Sy)])
+    cnot = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], complex)
+    return Workload("C3", "UnitaryGate", 4, K, N, E, T, A, _bcast(Bs, E),
+                    _bcast(np.eye(4, dtype=complex), E), _bcast(cnot, E),
+                    np.full(E, 1.0 / E), controls(K, N))
+
+
+def two_qubit_liouvillian(E=1024, N=1000, T=5.0, gamma1=0.02, gamma_phi=0.05):
+    """C4: CoherenceTransfer on 16x16 Liouvillian superoperators (non-Hermitian generator)."""
+    K = 4
+    d = detunings(E)
+    H0 = np.kron(Sx, Sz)
+    Hz = np.kron(Sz, I2) + np.kron(I2, Sz)
+    sm = np.array([[0, 1], [0, 0]], complex)            # sigma_minus
+    Dis = np.zeros((16, 16), complex)
+    for q in range(2):
+        Dis += dissipator(np.sqrt(gamma1) * site_op(sm, q, 2))
+        Dis += dissipator(np.sqrt(gamma_phi) * site_op(Sz, q, 2))
+    L0, Lz = to_superoperator(H0), to_superoperator(Hz)
+    A = (L0 + 1j * Dis)[None] + d[:, None, None] * Lz[None]
+    Hc = [np.kron(Sx, I2), np.kron(Sy, I2), np.kron(I2, Sx), np.kron(I2, Sy)]
+    Bs = np.array([to_superoperator(h) for h in Hc])
+    psi0 = np.zeros(4, complex); psi0[0] = 1
+    psiT = np.zeros(4, complex); psiT[3] = 1
+    v0 = np.outer(psi0, psi0.conj()).reshape(16, order="F")
+    vT = np.outer(psiT, psiT.conj()).reshape(16, order="F")
+    Xi = np.outer(v0, v0.conj())
+    Xt = np.outer(vT, vT.conj())
+    return Workload("C4", "CoherenceTransfer", 16, K, N, E, T, A, _bcast(Bs, E), _bcast(Xi, E),
+                    _bcast(Xt, E), np.full(E, 1.0 / E), controls(K, N))
+
+
+def _haar_unitary(n):
+    u = uniform(2, 2 * n * n * 2)
+    r = np.sqrt(-2.0 * np.log(1.0 - u[0::2])) * np.exp(2j * np.pi * u[1::2])   # Box-Muller
+    g = (r.real[: n * n] + 1j * r.imag[: n * n]).reshape(n, n)
+    q, rr = np.linalg.qr(g)
+    ph = np.diag(rr) / np.abs(np.diag(rr))
+    return q * ph[None, :]
+
+
+def five_qubit_unitary(E=4096, N=2000, T=10.0):
+    """C5: 32x32 UnitaryGate, K=6."""
+    nq, K = 5, 6
+    d = detunings(E)
+    Z, X, Y = 2 * Sz, 2 * Sx, 2 * Sy
+    H0 = sum(0.25 * site_op(Z, q, nq) @ site_op(Z, q + 1, nq) for q in range(nq - 1))
+    Hz = sum(0.5 * site_op(Z, q, nq) for q in range(nq))
+    A = H0[None] + d[:, None, None] * Hz[None]
+    Bs = []
+    for q in (0, 2, 4):
+        Bs += [0.5 * site_op(X, q, nq), 0.5 * site_op(Y, q, nq)]
+    Bs = np.array(Bs)
+    return Workload("C5", "UnitaryGate", 32, K, N, E, T, A, _bcast(Bs, E),
+                    _bcast(np.eye(32, dtype=complex), E), _bcast(_haar_unitary(32), E),
+                    np.full(E, 1.0 / E), controls(K, N))
+
+
+def config(name, E=None, N=None):
+    """BASELINE.json configs by name; E/N override for bounded samples and parity sizes."""
+    kw = {}
+    if E is not None:
+        kw["E"] = E
+    if N is not None:
+        kw["N"] = N
+    if name == "C1":
+        return single_qubit_state_transfer(N or 10, 1.0, "C1")
+    if name == "C2":
+        return single_qubit_state_transfer(N or 1000, 5.0, "C2")
+    if name == "C3":
+        return two_qubit_unitary(**kw)
+    if name == "C4":
+        return two_qubit_liouvillian(**kw)
+    if name == "C5":
+        return five_qubit_unitary(**kw)
+    raise KeyError(name)
+
+
+def reference_ensemble(sys_type, n_ens=5, N=25, T=5.0):
+    """The n_ens=5 ensembles of test/state_transfer_tests.jl:42-68 and
+    test/unitary_gate_tests.jl:41-74 (A_gens/B_gens/odd_switch, test/setup_tests.jl:31-66)."""
+    K = 2
+    k = np.arange(1, n_ens + 1, dtype=np.float64)
+    A = ((k - 2.5) / 2.5)[:, None, None] * Sz[None] * 5
+    B = _bcast(np.array([Sx, Sy]), n_ens)
+    if sys_type == "UnitaryGate":
+        Xi = _bcast(U_init, n_ens)
+        Xt = np.array([U_fin if int(kk) % 2 else U_init for kk in k])
+    else:
+        Xi = _bcast(rho_init, n_ens)
+        Xt = np.array([rho_fin if int(kk) % 2 else rho_init for kk in k])
+    return Workload("ref-ens", sys_type, 2, K, N, n_ens, T, A, B, Xi, Xt,
+                    np.ones(n_ens) / n_ens, controls(K, N))
