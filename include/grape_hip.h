@@ -62,8 +62,11 @@ typedef enum grape_variant {
 enum {
     GRAPE_FLAG_KEEP_COSTATES = 1 << 0,  /* debug: also store every costate L_t so that
                                            grape_get_trajectory can return them         */
-    GRAPE_FLAG_TIME_KERNELS = 1 << 1    /* record HIP events around the sweep kernel of every
+    GRAPE_FLAG_TIME_KERNELS = 1 << 1,   /* record HIP events around the sweep kernel of every
                                            evaluation (see grape_get_kernel_time)       */
+    GRAPE_FLAG_PHASE_STAMPS = 1 << 2    /* diagnostic build of the sweep: every wave stamps the
+                                           shader clock at its phase boundaries
+                                           (see grape_get_phase_stamps); never for timing runs */
 };
 
 /* Mirrors what solve() unpacks: Problem fields (src/problems.jl:19-28: sys_type, T,
@@ -152,6 +155,12 @@ int grape_get_trajectory(grape_ctx *ctx, int32_t member, double *props, double *
 /* Sum and count of the sweep kernel's HIP-event durations recorded since the last reset
  * (GRAPE_FLAG_TIME_KERNELS).  Synchronises the recorded events.  reset != 0 clears them. */
 int grape_get_kernel_time(grape_ctx *ctx, double *total_ms, int64_t *launches, int32_t reset);
+
+/* Diagnostic (GRAPE_FLAG_PHASE_STAMPS): the stamps of the last evaluation, 8 uint64 per wave,
+ * waves ordered (member, wave-in-member): [0..4] shader clock at start / after propagators /
+ * after scan / after forward sweep / end, [5],[6] 100 MHz real-time counter at start / end.
+ * out: host uint64[capacity]; *count receives the number of values available. */
+int grape_get_phase_stamps(grape_ctx *ctx, uint64_t *out, int64_t capacity, int64_t *count);
 
 int grape_get_info(const grape_ctx *ctx, grape_info *info);
 

@@ -40,6 +40,7 @@ struct grape_ctx {
     double2 *d_props = nullptr, *d_states = nullptr, *d_costates = nullptr;
     double *d_member_out = nullptr;
     double *d_partial = nullptr;
+    unsigned long long *d_stamps = nullptr;
     // host
     double *h_stage = nullptr;    // pinned, K*N + 1 doubles (x in, fg out)
     hipStream_t stream = nullptr;
@@ -77,7 +78,7 @@ static void free_all(grape_ctx *c)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     (void)hipFree(c->d_ops); (void)hipFree(c->d_wts); (void)hipFree(c->d_x); (void)hipFree(c->d_fg);
     (void)hipFree(c->d_props); (void)hipFree(c->d_states); (void)hipFree(c->d_costates);
-    (void)hipFree(c->d_member_out); (void)hipFree(c->d_partial);
+    (void)hipFree(c->d_member_out); (void)hipFree(c->d_partial); (void)hipFree(c->d_stamps);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     delete c;
 }
@@ -170,6 +171,8 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     if (e == hipSuccess && keepl) e = alloc((void **)&c->d_costates, sizeof(double2) * c->ws_elems);
     if (e == hipSuccess) e = alloc((void **)&c->d_member_out, sizeof(double) * E * Q);
     if (e == hipSuccess) e = alloc((void **)&c->d_partial, sizeof(double) * c->ksplit * Q);
+    if (e == hipSuccess && (cfg->flags & GRAPE_FLAG_PHASE_STAMPS))
+        e = alloc((void **)&c->d_stamps, sizeof(unsigned long long) * E * W * grape::kStampSlots);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, sizeof(double) * Q, hipHostMallocDefault);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -229,6 +232,7 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     p.states = c->d_states;
     p.costates = c->d_costates;
     p.member_out = c->d_member_out;
+    p.stamps = c->d_stamps;
     p.K = c->cfg.n_controls;
     p.N = c->cfg.n_slices;
     p.E = c->cfg.n_ensemble;
@@ -387,6 +391,22 @@ extern "C" int grape_get_kernel_time(grape_ctx *c, double *total_ms, int64_t *la
     if (total_ms) *total_ms = c->ev_total_ms;
     if (launches) *launches = c->ev_count;
     if (reset) { c->ev_total_ms = 0.0; c->ev_count = 0; }
+    return GRAPE_OK;
+}
+
+extern "C" int grape_get_phase_stamps(grape_ctx *c, uint64_t *out, int64_t capacity, int64_t *count)
+{
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (!c->d_stamps || !c->evaluated)
+        return fail(c, GRAPE_ERR_NOT_READY, "grape_get_phase_stamps: needs GRAPE_FLAG_PHASE_STAMPS and an evaluation");
+    const int64_t total = (int64_t)c->cfg.n_ensemble * c->W * grape::kStampSlots;
+    if (count) *count = total;
+    if (out && capacity > 0) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipDeviceSynchronize());
+        const int64_t nget = capacity < total ? capacity : total;
+        HIP_TRY(c, hipMemcpy(out, c->d_stamps, sizeof(uint64_t) * nget, hipMemcpyDeviceToHost));
+    }
     return GRAPE_OK;
 }
 

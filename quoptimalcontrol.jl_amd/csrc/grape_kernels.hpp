@@ -7,6 +7,8 @@
 
 namespace grape {
 
+constexpr int kStampSlots = 8;   // [0..4] shader clock at phase boundaries, [5],[6] 100 MHz real time
+
 // Device-side view of one context.  All complex data is interleaved double2 {re, im}.
 struct SweepParams {
     // inputs
@@ -19,6 +21,7 @@ struct SweepParams {
     double2 *costates;    // L_t (debug only, GRAPE_FLAG_KEEP_COSTATES), same layout
     // outputs
     double *member_out;   // (K*N + 1) per member: unweighted g_k (K,N col-major), then F_k
+    unsigned long long *stamps;   // diagnostic (NULL in production): kStampSlots per (member, wave)
     int32_t K, N, E;
     int32_t S;            // slices per lane
     int32_t LT;           // lanes per member = 64 * W

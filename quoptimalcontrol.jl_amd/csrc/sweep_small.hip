@@ -52,6 +52,18 @@ GRAPE_DEV void load_ws(CMat<N> &m, const double2 *__restrict__ base, size_t stri
     }
 }
 
+// diagnostic phase stamps (GRAPE_FLAG_PHASE_STAMPS): lane 0 of every wave stores the shader
+// clock at the phase boundaries into a buffer nothing else reads.  p.stamps is NULL in
+// production, so no stamp executes there.
+GRAPE_DEV void stamp(unsigned long long *__restrict__ st, int slot)
+{
+    if (st) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if ((threadIdx.x & 63) == 0)
+            st[slot] = t;
+    }
+}
+
 template <int N, int SAND, bool KEEPL, int MAXT>
 __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
 {
@@ -76,6 +88,11 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
     double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * Nsl + 1);
     const int t0 = L * S;
     const double dt = p.dt;
+    unsigned long long *__restrict__ st =
+        p.stamps ? p.stamps + ((size_t)k * W + wave) * kStampSlots : nullptr;
+    if (st && lane == 0)
+        st[5] = __builtin_amdgcn_s_memrealtime();
+    stamp(st, 0);
 
     // ---------------------------------------------------------------- phase A
     CMat<N> Q;
@@ -124,6 +141,7 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
         }
     }
 
+    stamp(st, 1);
     // ---------------------------------------------------------------- phase B
     CMat<N> Xs, Le;
     {
@@ -201,6 +219,7 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
         }
     }
 
+    stamp(st, 2);
     // ---------------------------------------------------------------- phase C
     {
         CMat<N> X = Xs, P, tmp;
@@ -222,6 +241,7 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
         }
     }
 
+    stamp(st, 3);
     // ---------------------------------------------------------------- phase D
     {
         CMat<N> Lc = Le, P, X, M, tmp;
@@ -279,6 +299,9 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
             }
         }
     }
+    stamp(st, 4);
+    if (st && lane == 0)
+        st[6] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <int N>

@@ -21,6 +21,7 @@ _LIB = None
 SYS_TYPE_CODES = {"UnitaryGate": 0, "StateTransfer": 1, "CoherenceTransfer": 2}
 FLAG_KEEP_COSTATES = 1
 FLAG_TIME_KERNELS = 2
+FLAG_PHASE_STAMPS = 4
 
 STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID_ARG", -2: "GRAPE_ERR_UNSUPPORTED",
           -3: "GRAPE_ERR_NO_DEVICE", -4: "GRAPE_ERR_HIP", -5: "GRAPE_ERR_NOT_READY",
@@ -29,7 +30,7 @@ STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID_ARG", -2: "GRAPE_ERR_UNSUPPORTED
 # every symbol include/grape_hip.h declares
 EXPORTS = ["grape_abi_version", "grape_create", "grape_destroy", "grape_set_operators",
            "grape_eval", "grape_eval_device", "grape_get_member_results", "grape_get_trajectory",
-           "grape_get_kernel_time", "grape_get_info", "grape_last_error"]
+           "grape_get_kernel_time", "grape_get_phase_stamps", "grape_get_info", "grape_last_error"]
 
 
 class GrapeError(RuntimeError):
@@ -85,6 +86,7 @@ def load_library():
     L.grape_get_member_results.argtypes = [vp, vp, vp]
     L.grape_get_trajectory.argtypes = [vp, i32, vp, vp, vp]
     L.grape_get_kernel_time.argtypes = [vp, dp, C.POINTER(C.c_int64), i32]
+    L.grape_get_phase_stamps.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.grape_get_info.argtypes = [vp, C.POINTER(GrapeInfo)]
     L.grape_last_error.argtypes = [vp]
     L.grape_last_error.restype = C.c_char_p
@@ -198,6 +200,14 @@ class GrapeEngine:
         self._check(self._lib.grape_get_trajectory(self._h, int(member), _p(P), _p(X), _p(Lc)))
         sw = lambda a: np.ascontiguousarray(np.swapaxes(a, -1, -2))
         return (sw(P), sw(X), sw(Lc)) if costates else (sw(P), sw(X))
+
+    def phase_stamps(self):
+        """(E*W, 8) uint64 stamps of the last evaluation (FLAG_PHASE_STAMPS)."""
+        cnt = C.c_int64()
+        self._check(self._lib.grape_get_phase_stamps(self._h, None, 0, C.byref(cnt)))
+        out = np.empty(cnt.value, dtype=np.uint64)
+        self._check(self._lib.grape_get_phase_stamps(self._h, _p(out), cnt.value, C.byref(cnt)))
+        return out.reshape(-1, 8)
 
     def kernel_time(self, reset=False):
         ms = C.c_double()
