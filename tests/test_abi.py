@@ -1,0 +1,83 @@
+"""The C-ABI library: loads, exports every symbol include/grape_hip.h declares, validates
+arguments, and FAILS LOUDLY without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import HAS_GPU, ROOT
+
+
+def declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "grape_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(grape_[a-z_]+)\s*\(", hdr)))
+
+
+def test_header_and_binding_agree(qoc):
+    assert declared_functions() == sorted(qoc.engine.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(qoc):
+    lib = qoc.load_library()
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    assert lib.grape_abi_version() == 1
+    out = subprocess.check_output(["nm", "-D", "--defined-only", qoc.library_path()]).decode()
+    exported = set(re.findall(r" T (grape_\w+)", out))
+    assert exported == set(declared_functions())
+
+
+def test_library_carries_gfx950_code_only(qoc):
+    blob = open(qoc.library_path(), "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx90a", b"gfx942", b"sm_80", b"nvptx"):
+        assert other not in blob
+
+
+def test_header_is_plain_c():
+    src = '#include "grape_hip.h"\nint main(void){grape_config c; (void)c; return GRAPE_ABI_VERSION - 1;}\n'
+    p = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                        "-x", "c", "-", "-fsyntax-only"], input=src.encode(), capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+
+
+def test_argument_validation(qoc):
+    lib = qoc.load_library()
+    h = C.c_void_p()
+    assert lib.grape_create(None, C.byref(h)) == -1
+    cfg = qoc.engine.GrapeConfig(7, 0, 2, 2, 10, 1, 1.0, -1, 0, 0, 0, -1, 0)
+    assert lib.grape_create(C.byref(cfg), C.byref(h)) == -1 and not h.value        # bad sys_type
+    assert b"sys_type" in lib.grape_last_error(None)
+    cfg = qoc.engine.GrapeConfig(0, 0, 2, 0, 10, 1, 1.0, -1, 0, 0, 0, -1, 0)
+    assert lib.grape_create(C.byref(cfg), C.byref(h)) == -1                        # K = 0
+    cfg = qoc.engine.GrapeConfig(0, 0, 7, 2, 10, 1, 1.0, -1, 0, 0, 0, -1, 0)
+    assert lib.grape_create(C.byref(cfg), C.byref(h)) == -2                        # n = 7 unsupported
+    assert b"n=7" in lib.grape_last_error(None)
+    assert lib.grape_destroy(None) == 0
+    assert lib.grape_eval(None, None, None, None) == -1
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU behaviour")
+def test_no_gpu_means_error_not_fallback(qoc):
+    wl = qoc.workloads
+    w = wl.config("C1")
+    with pytest.raises(qoc.GrapeError) as ei:
+        qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N)
+    assert ei.value.status == -3                                                   # GRAPE_ERR_NO_DEVICE
+
+
+def test_product_never_touches_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    pkg = os.path.join(ROOT, "quoptimalcontrol.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                for line in txt.splitlines():
+                    s = line.strip()
+                    if s.startswith(("#", "//", "*", '"""')) or "oracle/" in s and ("test" in s or "never" in s):
+                        continue
+                    assert not re.search(r"(import|from)\s+oracle|grape_oracle|libgrape_oracle", s), (f, s)

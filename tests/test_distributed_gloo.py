@@ -1,0 +1,57 @@
+"""The N>1 path on CPU: world_size=2 gloo processes run the product's ShardedGrape
+(shard partition + ONE all-reduce of [G, F]) with the oracle standing in for each rank's local
+evaluator, and the result must equal the unsharded oracle evaluation."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, assert_parity
+
+
+class OracleLocal:
+    """local evaluator with the GrapeEngine.eval_device signature, CPU tensors + the C oracle."""
+
+    def __init__(self, w, lo, hi, K, N):
+        self.w, self.lo, self.hi, self.K, self.N = w, lo, hi, K, N
+
+    def eval_device(self, x_ptr, fg_ptr, stream):
+        import ctypes
+        from oracle import grape_oracle
+        w = self.w
+        x = np.ctypeslib.as_array(ctypes.cast(x_ptr, ctypes.POINTER(ctypes.c_double)), shape=(self.N, self.K)).T
+        s = slice(self.lo, self.hi)
+        F, G = grape_oracle.ensemble_eval(w.sys_type, w.A[s], w.B[s], w.Xi[s], w.Xt[s], w.wts[s], x, w.T)
+        fg = np.ctypeslib.as_array(ctypes.cast(fg_ptr, ctypes.POINTER(ctypes.c_double)), shape=(self.K * self.N + 1,))
+        fg[:-1] = G.T.reshape(-1)
+        fg[-1] = F
+
+
+def _worker(rank, world, port, E, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import quoptimalcontrol_jl_amd as qoc
+    from quoptimalcontrol_jl_amd.distributed import ShardedGrape
+    w = qoc.workloads.config("C3", E=E, N=30)
+    sg = ShardedGrape(w.E, w.K, w.N, lambda lo, hi: OracleLocal(w, lo, hi, w.K, w.N), torch.device("cpu"))
+    F, G = sg.eval(w.x)
+    if rank == 0:
+        np.save(out, np.concatenate([G.reshape(-1), [F], [sg.lo, sg.hi]]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("E,world", [(6, 2), (5, 2), (1, 2)])
+def test_sharded_allreduce_matches_unsharded(tmp_path, oracle, qoc, E, world):
+    out = str(tmp_path / "r0.npy")
+    port = 29600 + (os.getpid() + 7 * E) % 300
+    mp.spawn(_worker, args=(world, port, E, out), nprocs=world, join=True)
+    got = np.load(out)
+    w = qoc.workloads.config("C3", E=E, N=30)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    assert_parity(got[-3], got[:-3].reshape(w.K, w.N), F_ref, G_ref, w.n, what=f"E={E} world={world}")
+    assert (got[-2], got[-1]) == (0, -(-E // world))

@@ -1,0 +1,144 @@
+"""GPU: the HIP path against the committed mpmath fixtures, the reference's convergence
+testsets driven through solve() on the device, the device-pointer entry point, error
+behaviour and size-independent properties at the full BASELINE size."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+from test_oracle_golden import GOLDEN, load_case
+
+pytestmark = pytest.mark.gpu
+tol = 1e-6
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-5] for p in GOLDEN])
+def test_hip_matches_golden(qoc, path):
+    c, A, B, Xi, Xt, wts, x, exp, traj = load_case(path)
+    with qoc.GrapeEngine(c["sys_type"], A, B, Xi, Xt, wts, c["T"], c["N"], variant=c["variant"],
+                         flags=qoc.engine.FLAG_KEEP_COSTATES) as eng:
+        F, G = eng.eval(x)
+        foms, grads = eng.member_results()
+        P, X, L = eng.trajectory(0, costates=True)
+    assert_parity(F, G, exp["F"], np.array(exp["G"]), c["n"], what="ensemble")
+    for k in range(c["E"]):
+        assert_parity(foms[k], grads[k], exp["member_F"][k], np.array(exp["member_g"][k]), c["n"], what=f"member {k}")
+    for got, want in zip((P, X, L), traj):
+        assert np.abs(got - want).max() < 1e-13
+
+
+def _problem(qoc, sys_type, N, T):
+    wl = qoc.workloads
+    ug = sys_type == "UnitaryGate"
+    return qoc.Problem(B=[wl.Sx, wl.Sy], A=wl.Sz, Xi=wl.U_init if ug else wl.rho_init,
+                       Xt=wl.U_fin if ug else wl.rho_fin, T=T, n_controls=2, guess=wl.controls(2, N),
+                       sys_type=qoc.UnitaryGate() if ug else qoc.StateTransfer())
+
+
+@pytest.mark.parametrize("sys_type,floor", [("StateTransfer", 0.75), ("UnitaryGate", 0.0)])
+@pytest.mark.parametrize("isinplace", [True, False])
+def test_reference_single_problem_testsets(qoc, sys_type, floor, isinplace):
+    """test/state_transfer_tests.jl:4-37, test/unitary_gate_tests.jl:3-37 through the device."""
+    prob = _problem(qoc, sys_type, 10, 1.0)
+    sol = qoc.solve(prob, qoc.GRAPE(n_slices=10, isinplace=isinplace))
+    assert isinstance(sol, qoc.SolutionResult)
+    assert sol.result.minimum - floor < tol
+    assert sol.opti_pulses.shape == (2, 10) and sol.fidelity == sol.result.minimum
+
+
+@pytest.mark.parametrize("sys_type,N,opts", [("StateTransfer", 25, {}), ("UnitaryGate", 100, {"f_tol": 1e-3})])
+def test_reference_ensemble_testsets(qoc, sys_type, N, opts):
+    """test/state_transfer_tests.jl:42-68, test/unitary_gate_tests.jl:41-74 (n_ens = 5)."""
+    wl = qoc.workloads
+    ug = sys_type == "UnitaryGate"
+    prob = _problem(qoc, sys_type, N, 5.0)
+    tgt = (wl.U_fin, wl.U_init) if ug else (wl.rho_fin, wl.rho_init)
+    ens = qoc.EnsembleProblem(prob=prob, n_ens=5, A_g=lambda k: (k - 2.5) / 2.5 * wl.Sz * 5,
+                              B_g=lambda k: [wl.Sx, wl.Sy], XiG=lambda k: prob.Xi,
+                              XtG=lambda k: tgt[0] if k % 2 else tgt[1], wts=np.ones(5) / 5)
+    sol = qoc.solve(ens, qoc.GRAPE(n_slices=N, isinplace=True, optim_options=opts))
+    assert isinstance(sol, qoc.EnsembleSolutionResult)
+    assert sol.result.minimum - 0.75 < tol * 10
+
+
+def test_only_f_or_only_g(qoc):
+    w = qoc.workloads.config("C1")
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        F, G = eng.eval(w.x)
+        F2, none = eng.eval(w.x, want_G=False)
+        none2, G2 = eng.eval(w.x, want_F=False)
+    assert none is None and none2 is None and F2 == F and np.array_equal(G2, G)
+
+
+def test_not_ready_and_bad_shapes(qoc):
+    import ctypes as C
+    lib = qoc.load_library()
+    cfg = qoc.engine.GrapeConfig(1, 0, 2, 2, 10, 1, 1.0, -1, 0, 0, 0, -1, 0)
+    h = C.c_void_p()
+    assert lib.grape_create(C.byref(cfg), C.byref(h)) == 0
+    x = np.zeros(20)
+    F = C.c_double()
+    assert lib.grape_eval(h, x.ctypes.data_as(C.c_void_p), C.byref(F), None) == -5     # operators not set
+    assert b"operators" in lib.grape_last_error(h)
+    assert lib.grape_get_member_results(h, None, None) == -5
+    assert lib.grape_destroy(h) == 0
+    w = qoc.workloads.config("C1")
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        with pytest.raises(ValueError):
+            eng.eval(np.zeros((2, 11)))
+        eng.eval(w.x)
+        with pytest.raises(qoc.GrapeError):
+            eng.trajectory(0, costates=True)                     # needs FLAG_KEEP_COSTATES
+
+
+def test_nan_controls_propagate(qoc):
+    """the reference does not trap non-finite controls; neither does the device path."""
+    w = qoc.workloads.config("C1")
+    x = w.x.copy()
+    x[0, 3] = np.nan
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        F, G = eng.eval(x)
+    assert np.isnan(F) and np.isnan(G).any()
+
+
+def test_large_norm_takes_the_squaring_path(qoc, oracle):
+    """dt*|H| far above theta8 (T = 40 over 10 slices): expm scaling + squarings, per lane."""
+    w = qoc.workloads.config("C3", E=4, N=10)
+    w.T = 40.0
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        F, G = eng.eval(w.x)
+    assert_parity(F, G, F_ref, G_ref, w.n, rtol=1e-9, what="squaring path")
+
+
+def test_eval_device_with_torch_buffers(qoc, oracle):
+    import torch
+    from quoptimalcontrol_jl_amd.distributed import sharded_engine
+    w = qoc.workloads.config("C3", E=16, N=100)
+    sg = sharded_engine(w, torch.device("cuda", 0))
+    F, G = sg.eval(w.x)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    assert_parity(F, G, F_ref, G_ref, w.n, what="eval_device")
+    sg.close()
+
+
+def test_full_size_properties(qoc, oracle):
+    """BASELINE size (4x4, K=4, N=500, E=1024): spot members against the oracle, bitwise
+    run-to-run reproducibility, and linearity of the ensemble reduction in the weights."""
+    w = qoc.workloads.config("C3")
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+        F2, G2 = eng.eval(w.x)
+    assert F == F2 and np.array_equal(G, G2)                              # deterministic reduction
+    assert abs(F - foms @ w.wts) <= 1e-12 and np.abs(G - np.tensordot(w.wts, grads, 1)).max() <= 1e-14
+    for k in (0, 1, 511, 777, 1023):
+        f_ref, g_ref = oracle.member_eval(w.sys_type, w.A[k], w.B[k], w.Xi[k], w.Xt[k], w.x, w.T)
+        assert_parity(foms[k], grads[k], f_ref, g_ref, w.n, what=f"member {k}")
+    w2 = w.members(0, w.E)
+    w2.wts = w.wts * np.linspace(0.5, 1.5, w.E)
+    with qoc.GrapeEngine(w2.sys_type, w2.A, w2.B, w2.Xi, w2.Xt, w2.wts, w2.T, w2.N) as eng:
+        Fw, Gw = eng.eval(w.x)
+    assert abs(Fw - foms @ w2.wts) <= 1e-12 and np.abs(Gw - np.tensordot(w2.wts, grads, 1)).max() <= 1e-14

@@ -1,0 +1,84 @@
+"""Host-side logic that needs no GPU: the synthetic workload generator, operator packing,
+the Problem/EnsembleProblem mirror and the shard partition."""
+import numpy as np
+import pytest
+
+
+def test_splitmix64_known_values(qoc):
+    wl = qoc.workloads
+    # reference values of the public-domain splitmix64 (seed 0 -> first outputs)
+    assert wl.splitmix64(0) == 0xE220A8397B1DCDAF
+    assert wl.splitmix64(0x9E3779B97F4A7C15) == 0x6E789E6AA1B965F4
+    u = wl.uniform(1, 5)
+    want = [(wl.splitmix64((1 << 32) + i) >> 11) * 2.0 ** -53 for i in range(5)]
+    assert np.array_equal(u, np.array(want))
+    assert ((0 <= u) & (u < 1)).all()
+
+
+def test_controls_layout(qoc):
+    x = qoc.workloads.controls(4, 6)
+    u = qoc.workloads.uniform(1, 24)
+    assert x.shape == (4, 6)
+    assert x[2, 3] == u[3 * 4 + 2]            # x[j,i] = u(1, i*K + j)
+
+
+def test_configs_have_baseline_shapes(qoc):
+    wl = qoc.workloads
+    for name, (st, n, K, N, E, T) in {"C1": ("StateTransfer", 2, 2, 10, 1, 1.0),
+                                      "C2": ("StateTransfer", 2, 2, 1000, 1, 5.0),
+                                      "C3": ("UnitaryGate", 4, 4, 500, 1024, 2.0)}.items():
+        w = wl.config(name)
+        assert (w.sys_type, w.n, w.K, w.N, w.E, w.T) == (st, n, K, N, E, T)
+        assert w.A.shape == (E, n, n) and w.B.shape == (E, K, n, n) and w.x.shape == (K, N)
+        assert np.allclose(w.A, np.swapaxes(w.A.conj(), -1, -2))       # Hermitian drift
+    w = wl.config("C3")
+    assert w.algorithmic_bytes == 558891008                              # 558.9 MB
+    assert abs(w.wts.sum() - 1) < 1e-12
+    assert w.A[0, 0, 0].real == pytest.approx(-5.0) and w.A[-1, 0, 0].real == pytest.approx(5.0)
+
+
+def test_liouvillian_config_is_trace_preserving(qoc):
+    w = qoc.workloads.config("C4", E=2, N=4)
+    assert w.n == 16 and w.sys_type == "CoherenceTransfer"
+    vecI = np.eye(4).reshape(16, order="F")
+    # d/dt tr(rho) = vec(I)' (-i A) vec(rho) = 0 for every rho
+    assert np.abs(vecI @ (-1j * w.A[0])).max() < 1e-14
+    assert np.abs(w.A[0] - w.A[0].conj().T).max() > 1e-3                 # non-Hermitian generator
+
+
+def test_shard_bounds_partition(qoc):
+    from quoptimalcontrol_jl_amd.distributed import shard_bounds
+    for E in (1, 5, 1024, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(E, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == E
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b
+            assert max(b - a for a, b in spans) == -(-E // world)
+
+
+def test_init_ensemble_mirrors_reference(qoc):
+    wl = qoc.workloads
+    prob = qoc.Problem(B=[wl.Sx, wl.Sy], A=wl.Sz, Xi=wl.rho_init, Xt=wl.rho_fin, T=5.0, n_controls=2,
+                       guess=np.zeros((2, 25)), sys_type=qoc.StateTransfer())
+    ens = qoc.EnsembleProblem(prob=prob, n_ens=5, A_g=lambda k: (k - 2.5) / 2.5 * wl.Sz * 5,
+                              B_g=lambda k: [wl.Sx, wl.Sy], XiG=lambda k: wl.rho_init,
+                              XtG=lambda k: wl.rho_fin if k % 2 else wl.rho_init, wts=np.ones(5) / 5)
+    members = qoc.init_ensemble(ens)
+    assert len(members) == 5
+    assert np.allclose(members[0].A, (1 - 2.5) / 2.5 * wl.Sz * 5)        # 1-based k, test/setup_tests.jl:31
+    assert np.array_equal(members[0].Xt, wl.rho_fin) and np.array_equal(members[1].Xt, wl.rho_init)
+    ref = wl.reference_ensemble("StateTransfer", 5, 25, 5.0)
+    assert np.allclose(np.array([m.A for m in members]), ref.A)
+    assert np.allclose(np.array([m.Xt for m in members]), ref.Xt)
+    assert qoc.C1(wl.rho_fin, wl.rho_fin) == pytest.approx(0.75)
+    assert qoc.UnitaryGate() == qoc.UnitaryGate() and qoc.UnitaryGate() != qoc.StateTransfer()
+    with pytest.raises(TypeError):
+        qoc.solve(prob)                                                 # reference: GRAPE() has no integrator
+
+
+def test_column_major_packing(qoc):
+    M = np.arange(8).reshape(2, 2, 2) + 0j
+    buf = qoc.engine._cm(M)
+    assert buf.flags["C_CONTIGUOUS"]
+    assert buf.reshape(-1)[1] == M[0, 1, 0]          # element (i=1, j=0) second in memory
