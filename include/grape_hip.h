@@ -64,9 +64,13 @@ enum {
                                            grape_get_trajectory can return them         */
     GRAPE_FLAG_TIME_KERNELS = 1 << 1,   /* record HIP events around the sweep kernel of every
                                            evaluation (see grape_get_kernel_time)       */
-    GRAPE_FLAG_PHASE_STAMPS = 1 << 2    /* diagnostic build of the sweep: every wave stamps the
+    GRAPE_FLAG_PHASE_STAMPS = 1 << 2,   /* diagnostic build of the sweep: every wave stamps the
                                            shader clock at its phase boundaries
                                            (see grape_get_phase_stamps); never for timing runs */
+    GRAPE_FLAG_FORCE_GENERAL = 1 << 3   /* always use the general data flow (forward states stored
+                                           in HBM, as the reference does), even when every
+                                           generator is Hermitian and the cheaper unitary flow
+                                           applies.  KEEP_COSTATES implies it.          */
 };
 
 /* Mirrors what solve() unpacks: Problem fields (src/problems.jl:19-28: sys_type, T,
@@ -97,7 +101,8 @@ typedef struct grape_info {
     int32_t waves_per_member;      /* W in use                                          */
     int32_t expm_squarings;        /* forced s, or -1 = per slice from the generator norm */
     int32_t kernel_family;         /* 0 = register-resident small-n, 1 = LDS/MFMA tile  */
-    int32_t reserved;
+    int32_t unitary_flow;          /* 1 after grape_set_operators found every A_k, B_jk Hermitian
+                                      (propagators unitary): no forward-state round trip  */
     double  expm_theta;            /* norm threshold below which no scaling/squaring is done */
     uint64_t workspace_bytes;      /* device bytes owned by the context                 */
     char    arch[32];              /* gcnArchName of the device                         */
@@ -145,7 +150,9 @@ int grape_get_member_results(grape_ctx *ctx, double *foms, double *grads);
 
 /* The stores the reference keeps per member (src/grape_tools.jl:4-16), for parity tests:
  *   props     c128 (n,n,N)     propagators[t],  t = 0..N-1
- *   states    c128 (n,n,N+1)   fwd_state_store[t], t = 0..N   (states[0] = Xi)
+ *   states    c128 (n,n,N+1)   fwd_state_store[t], t = 0..N   (states[0] = Xi); only the general
+ *                              flow stores them (GRAPE_FLAG_FORCE_GENERAL / KEEP_COSTATES or a
+ *                              non-Hermitian generator), else GRAPE_ERR_NOT_READY.
  *   costates  c128 (n,n,N+1)   bwd_costate_store[t], t = 0..N (costates[N] = Xt);
  *                              needs GRAPE_FLAG_KEEP_COSTATES, else GRAPE_ERR_NOT_READY.
  * Any of the three may be NULL. */

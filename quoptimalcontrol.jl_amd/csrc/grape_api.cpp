@@ -45,6 +45,7 @@ struct grape_ctx {
     double *h_stage = nullptr;    // pinned, K*N + 1 doubles (x in, fg out)
     hipStream_t stream = nullptr;
     bool ops_set = false, evaluated = false;
+    bool unitary = false;         // all generators Hermitian -> unitary data flow
     std::vector<hipEvent_t> ev;   // start/stop pairs of the sweep kernel
     size_t ev_used = 0;
     double ev_total_ms = 0.0;
@@ -167,7 +168,6 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     if (e == hipSuccess) e = alloc((void **)&c->d_x, sizeof(double) * KN(c));
     if (e == hipSuccess) e = alloc((void **)&c->d_fg, sizeof(double) * Q);
     if (e == hipSuccess) e = alloc((void **)&c->d_props, sizeof(double2) * c->ws_elems);
-    if (e == hipSuccess) e = alloc((void **)&c->d_states, sizeof(double2) * c->ws_elems);
     if (e == hipSuccess && keepl) e = alloc((void **)&c->d_costates, sizeof(double2) * c->ws_elems);
     if (e == hipSuccess) e = alloc((void **)&c->d_member_out, sizeof(double) * E * Q);
     if (e == hipSuccess) e = alloc((void **)&c->d_partial, sizeof(double) * c->ksplit * Q);
@@ -215,6 +215,29 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         std::memcpy(dst + 2 * (1 + K) * nn, Xi + 2 * k * nn, sizeof(double) * 2 * nn);
         std::memcpy(dst + 2 * (2 + K) * nn, Xt + 2 * k * nn, sizeof(double) * 2 * nn);
     }
+    // Data-flow choice: if every generator is Hermitian to rounding, every propagator is
+    // unitary and the sweep can carry M_t = P_t' M_{t+1} P_t instead of storing X_t.
+    bool herm = !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES));
+    const int n = c->cfg.n;
+    for (size_t k = 0; k < E && herm; ++k) {
+        for (size_t m = 0; m < K + 1 && herm; ++m) {
+            const double *M = (m == 0) ? A + 2 * k * nn : B + 2 * (k * K + (m - 1)) * nn;
+            double scale = 0.0, dev = 0.0;
+            for (int j = 0; j < n; ++j)
+                for (int i = 0; i < n; ++i) {
+                    const double re = M[2 * (i + j * n)], im = M[2 * (i + j * n) + 1];
+                    const double tr = M[2 * (j + i * n)], ti = M[2 * (j + i * n) + 1];
+                    scale = std::fmax(scale, std::fmax(std::fabs(re), std::fabs(im)));
+                    dev = std::fmax(dev, std::fmax(std::fabs(re - tr), std::fabs(im + ti)));
+                }
+            if (!(dev <= 4e-16 * scale)) herm = false;      // also false on NaN
+        }
+    }
+    c->unitary = herm;
+    if (!herm && !c->d_states) {
+        c->bytes += sizeof(double2) * c->ws_elems;
+        HIP_TRY(c, hipMalloc((void **)&c->d_states, sizeof(double2) * c->ws_elems));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->d_ops, packed.data(), sizeof(double) * packed.size(), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_wts, wts, sizeof(double) * E, hipMemcpyHostToDevice));
@@ -256,8 +279,8 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
         c->ev_used += 2;
         HIP_TRY(c, hipEventRecord(e0, stream));
     }
-    HIP_TRY(c, grape::launch_sweep_small(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE,
-                                         c->d_costates != nullptr, p, stream));
+    const int mode = c->unitary ? 2 : (c->d_costates ? 1 : 0);
+    HIP_TRY(c, grape::launch_sweep_small(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, mode, p, stream));
     if (timed) HIP_TRY(c, hipEventRecord(e1, stream));
     HIP_TRY(c, grape::launch_reduce(c->d_member_out, c->d_wts, c->d_partial, d_fg, p.E,
                                     (int)(KN(c) + 1), c->ksplit, stream));
@@ -333,6 +356,10 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
     if (costates && !c->d_costates)
         return fail(c, GRAPE_ERR_NOT_READY,
                     "grape_get_trajectory: costates need GRAPE_FLAG_KEEP_COSTATES at grape_create");
+    if (states && c->unitary)
+        return fail(c, GRAPE_ERR_NOT_READY,
+                    "grape_get_trajectory: the unitary flow stores no forward states; create the context "
+                    "with GRAPE_FLAG_FORCE_GENERAL or GRAPE_FLAG_KEEP_COSTATES");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
     const int n = c->cfg.n;
@@ -421,6 +448,7 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
     info->waves_per_member = c->W;
     info->expm_squarings = c->cfg.expm_squarings;
     info->kernel_family = 0;
+    info->unitary_flow = c->unitary ? 1 : 0;
     info->expm_theta = 0.05;
     info->workspace_bytes = c->bytes;
     std::snprintf(info->arch, sizeof(info->arch), "%s", c->arch);

@@ -30,10 +30,10 @@ struct SweepParams {
     double dt;
 };
 
-// which == 0: UnitaryGate chain; 1: State/CoherenceTransfer sandwich chain.
-// Returns hipSuccess or the launch error.  n must be 2, 3 or 4.
-hipError_t launch_sweep_small(int n, int sandwich, bool keep_costates, const SweepParams &p,
-                              hipStream_t stream);
+// sandwich == 0: UnitaryGate chain; 1: State/CoherenceTransfer sandwich chain.
+// mode: 0 general flow, 1 general flow + costates stored (debug), 2 unitary flow (all
+// generators Hermitian).  Returns hipSuccess or the launch error.  n must be 2, 3 or 4.
+hipError_t launch_sweep_small(int n, int sandwich, int mode, const SweepParams &p, hipStream_t stream);
 int sweep_small_max_waves(int n);   // W limit of the register-resident kernel for this n
 
 // G[q] = sum_k w_k member_out[k][q]  for q in [0, Q)  (Q = K*N + 1; the last entry is F).

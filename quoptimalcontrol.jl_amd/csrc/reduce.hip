@@ -36,21 +36,23 @@ __global__ __launch_bounds__(kTileQ *kSubK) void reduce_stage1(const double *__r
 #pragma unroll
         for (int i = 1; i < kSubK; ++i)
             s += s_acc[i][tq];
-        partial[(size_t)ks * Q + q] = s;
+        partial[(size_t)q * gridDim.y + ks] = s;      // [q][ks]: stage 2 reads it lane-contiguously
     }
 }
 
-// stage 2: fg[q] = sum_ks partial[ks][q]
+// stage 2: fg[q] = sum_ks partial[q][ks]; 32 lanes per output, fixed xor-shuffle tree.
+constexpr int kMaxSplit = 32;
 __global__ __launch_bounds__(256) void reduce_stage2(const double *__restrict__ partial,
                                                      double *__restrict__ fg, int Q, int ksplit)
 {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q)
-        return;
-    double s = 0.0;
-    for (int ks = 0; ks < ksplit; ++ks)
-        s += partial[(size_t)ks * Q + q];
-    fg[q] = s;
+    const int ks = threadIdx.x & (kMaxSplit - 1);
+    const int q = blockIdx.x * (256 / kMaxSplit) + threadIdx.x / kMaxSplit;
+    double v = (q < Q && ks < ksplit) ? partial[(size_t)q * ksplit + ks] : 0.0;
+#pragma unroll
+    for (int d = kMaxSplit / 2; d >= 1; d >>= 1)
+        v += __shfl_xor(v, d, 64);
+    if (ks == 0 && q < Q)
+        fg[q] = v;
 }
 
 int reduce_ksplit(int E)
@@ -71,8 +73,9 @@ hipError_t launch_reduce(const double *member_out, const double *wts, double *pa
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(reduce_stage2, dim3((Q + 255) / 256), dim3(256), 0, stream, partial, fg, Q,
-                       ksplit);
+    const int per_block = 256 / kMaxSplit;
+    hipLaunchKernelGGL(reduce_stage2, dim3((Q + per_block - 1) / per_block), dim3(256), 0, stream, partial,
+                       fg, Q, ksplit);
     return hipGetLastError();
 }
 

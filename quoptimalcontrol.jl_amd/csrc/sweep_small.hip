@@ -15,8 +15,18 @@
 //            tr(L' B_c X) = sum_ij B_c[i,j] (X L')[j,i]  (the trace_matmul identity,
 //            src/grape_tools.jl:66-68), so one product per slice serves all K controls.
 //
-// HBM traffic = "model S" of BASELINE.md: P_t and X_t make one round trip, 64 n^2 N bytes per
-// member, written and read with lane-contiguous 16-byte accesses (1 KiB per wave instruction).
+// Two data flows share phases A and B:
+//   MODE_GENERAL (any generator, e.g. non-Hermitian Liouvillians): exactly the reference's
+//     flow -- X_t stored forward, L_t pulled back, M_t = X_t L_t' per slice.  HBM traffic =
+//     "model S" of BASELINE.md: P_t and X_t make one round trip (64 n^2 N bytes per member).
+//   MODE_UNITARY (every A_k, B_jk Hermitian, checked on the host, so every P_t is unitary):
+//     M_t = X_t L_t' (UnitaryGate) or [X_t, L_t'] (State/CoherenceTransfer) obeys
+//     M_t = P_t' M_{t+1} P_t, so the backward sweep carries ONE matrix, no forward state is
+//     stored and phase C disappears: only P_t makes the HBM round trip (32 n^2 N bytes per
+//     member) and the sweep needs 2 products per slice instead of 3-6.  tr(X_t' L_t), which
+//     the UnitaryGate gradient and both figures of merit use, is conj(tr M_t) (UnitaryGate) or
+//     t-invariant (taken at the chunk end that owns slice N).
+// All workspace accesses are lane-contiguous 16-byte accesses (1 KiB per wave instruction).
 #include "cmat.hpp"
 #include "grape_kernels.hpp"
 
@@ -64,12 +74,59 @@ GRAPE_DEV void stamp(unsigned long long *__restrict__ st, int slot)
     }
 }
 
-template <int N, int SAND, bool KEEPL, int MAXT>
+enum { MODE_GENERAL = 0, MODE_GENERAL_KEEPL = 1, MODE_UNITARY = 2 };
+
+// sum_ij B[i,j] M[j,i] for the K control operators of this member -> gradient entries
+template <int N, int SAND>
+GRAPE_DEV void write_gradient(double *out, const double2 *opB, int K, const CMat<N> &M, double zr,
+                              double zi, double gs)
+{
+    constexpr int NN = N * N;
+    for (int c = 0; c < K; ++c) {
+        double wr = 0.0, wi = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < N; ++jj)
+#pragma unroll
+            for (int ii = 0; ii < N; ++ii) {
+                const double2 b = opB[c * NN + ii + jj * N];
+                const double mr = M.re[jj + ii * N], mi = M.im[jj + ii * N];
+                wr = fma(b.x, mr, wr);
+                wr = fma(-b.y, mi, wr);
+                wi = fma(b.x, mi, wi);
+                wi = fma(b.y, mr, wi);
+            }
+        const double im = SAND ? wi : fma(wr, zi, wi * zr);   // Im(w) | Im(w z)
+        out[c] = gs * im;
+    }
+}
+
+template <int N, int SAND>
+GRAPE_DEV double figure_of_merit(double zr, double zi)
+{
+    if (SAND) {                                  // 1 - |tr(L'X)/D|^2, cost_functions.jl:13-17
+        const double inv = 1.0 / (double)N;
+        const double ar = zr * inv, ai = zi * inv;
+        return 1.0 - (ar * ar + ai * ai);
+    }
+    return zr * zr - zi * zi;                    // Re(z^2), cost_functions.jl:99-101
+}
+
+template <int N, int SAND, int MODE, int MAXT>
 __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
 {
     constexpr int NN = N * N;
     constexpr int MAXW = MAXT / 64;
-    __shared__ double2 s_tot[2][MAXW][NN];
+    constexpr bool UNI = (MODE == MODE_UNITARY);
+    constexpr bool KEEPL = (MODE == MODE_GENERAL_KEEPL);
+    // One dynamic LDS array (16-byte aligned carve, nothing static in front of it):
+    //   s_tot  2*MAXW*NN double2   wave totals of the two scans
+    //   s_ops  (K+3)*NN double2    this member's A, B_1..B_K, Xi, Xt (broadcast reads)
+    //   s_xg   LT*(S*K+1) double   controls x[., t] of this member's slices on the way in, the
+    //                              gradient g[., t] on the way out; lane stride S*K+1 is odd, so
+    //                              the per-lane reads/writes are bank-conflict free
+    extern __shared__ double2 s_dyn[];
+    double2(*s_tot)[MAXW][NN] = reinterpret_cast<double2(*)[MAXW][NN]>(s_dyn);
+    double2 *s_ops = s_dyn + 2 * MAXW * NN;
 
     const int k = blockIdx.x;
     const int L = threadIdx.x;
@@ -78,10 +135,23 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
     const int K = p.K, Nsl = p.N, S = p.S;
     const size_t stride = (size_t)LT;
 
-    const double2 *__restrict__ ops = p.ops + (size_t)k * (K + 3) * NN;
-    const double2 *__restrict__ opB = ops + NN;
-    const double2 *__restrict__ opXi = ops + (size_t)(1 + K) * NN;
-    const double2 *__restrict__ opXt = opXi + NN;
+    double *s_xg = reinterpret_cast<double *>(s_ops + (K + 3) * NN);
+    const int SK = S * K;
+    {
+        const double2 *__restrict__ gops = p.ops + (size_t)k * (K + 3) * NN;
+        for (int i = L; i < (K + 3) * NN; i += LT)
+            s_ops[i] = gops[i];
+        for (int q = L; q < K * Nsl; q += LT) {
+            const int lq = q / SK;
+            s_xg[lq * (SK + 1) + (q - lq * SK)] = p.x[q];
+        }
+        __syncthreads();
+    }
+    const double2 *ops = s_ops;
+    const double2 *opB = ops + NN;
+    const double2 *opXi = ops + (1 + K) * NN;
+    const double2 *opXt = opXi + NN;
+    double *xg = s_xg + L * (SK + 1);            // this lane's x / g slots: [j*K + c]
     const size_t wbase = (size_t)k * S * NN * stride + L;
     double2 *__restrict__ Pw = p.props + wbase;
     double2 *__restrict__ Xw = p.states + wbase;
@@ -95,9 +165,11 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
     stamp(st, 0);
 
     // ---------------------------------------------------------------- phase A
-    CMat<N> Q;
+    // Q accumulates the chunk product P_last ... P_first; two buffers alternate so that the
+    // product never needs a register copy (Qout = P * Qin).
+    CMat<N> Q, Q2;
     set_identity(Q);
-    for (int j = 0; j < S; ++j) {
+    auto slice = [&](int j, const CMat<N> &Qin, CMat<N> &Qout) {
         const int t = t0 + j;
         if (t < Nsl) {
             CMat<N> G, P;
@@ -108,7 +180,7 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
                 load_uniform(G, ops);
             }
             for (int c = 0; c < K; ++c) {
-                const double xv = p.x[c + (size_t)t * K];
+                const double xv = xg[j * K + c];
 #pragma unroll
                 for (int e = 0; e < NN; ++e) {
                     const double2 b = opB[c * NN + e];
@@ -132,18 +204,33 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
             }
             expm_t8(P, G, p.s_forced);
             store_ws(Pw + (size_t)j * NN * stride, stride, P);
-            if (j == 0) {
-                Q = P;
-            } else {
-                mul(G, P, Q);
-                Q = G;
-            }
+            mul(Qout, P, Qin);
+        } else {
+            Qout = Qin;
+        }
+    };
+    {
+        int j = 0;
+        for (; j + 1 < S; j += 2) {
+            slice(j, Q, Q2);
+            slice(j + 1, Q2, Q);
+        }
+        if (j < S) {
+            slice(j, Q, Q2);
+            Q = Q2;
         }
     }
 
     stamp(st, 1);
     // ---------------------------------------------------------------- phase B
+    // General flow: Xs = state at the chunk start, Le = costate at the chunk end.
+    // Unitary flow: M = M at the chunk end, from the forward scan alone: with U the inclusive
+    // prefix product of this lane and T the product of ALL propagators of the member, the
+    // exclusive suffix is V = T U' (U unitary), hence
+    //   UnitaryGate:  M_end = X L' = U (Xi Xt' T) U'
+    //   sandwich:     M_end = [X, L'] = U [Xi, E'] U',  E = T' Xt T,  tr(X' L) = tr(Xi' E).
     CMat<N> Xs, Le;
+    double zr = 0.0, zi = 0.0;
     {
         CMat<N> inc = Q, oth, tmp;
         for (int d = 1; d < 64; d <<= 1) {
@@ -153,9 +240,11 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
                 inc = tmp;
             }
         }
-        shfl_up(oth, inc, 1);
-        if (lane == 0)
-            set_identity(oth);
+        if (!UNI) {                                  // exclusive prefix
+            shfl_up(oth, inc, 1);
+            if (lane == 0)
+                set_identity(oth);
+        }
         if (W > 1) {
             if (lane == 63) {
 #pragma unroll
@@ -163,25 +252,61 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
                     s_tot[0][wave][e] = make_double2(inc.re[e], inc.im[e]);
             }
             __syncthreads();
-            CMat<N> pre;
+            CMat<N> pre, wt;
             set_identity(pre);
             for (int w = 0; w < wave; ++w) {
-                load_uniform(inc, &s_tot[0][w][0]);
-                mul(tmp, inc, pre);
+                load_uniform(wt, &s_tot[0][w][0]);
+                mul(tmp, wt, pre);
                 pre = tmp;
             }
-            mul(tmp, oth, pre);
-            oth = tmp;
+            if (UNI) {
+                mul(tmp, inc, pre);
+                inc = tmp;
+            } else {
+                mul(tmp, oth, pre);
+                oth = tmp;
+            }
         }
-        load_uniform(inc, opXi);
-        if (SAND) {
-            mul(tmp, oth, inc);
-            mul_a_bh(Xs, tmp, oth);
+        if (UNI) {
+            if (L == LT - 1) {
+#pragma unroll
+                for (int e = 0; e < NN; ++e)
+                    s_tot[1][0][e] = make_double2(inc.re[e], inc.im[e]);
+            }
+            __syncthreads();
+            CMat<N> T, C0, xi, xt;
+            load_uniform(T, &s_tot[1][0][0]);
+            load_uniform(xi, opXi);
+            load_uniform(xt, opXt);
+            if (SAND) {
+                mul(tmp, xt, T);
+                mul_ah_b(oth, T, tmp);               // E = T' Xt T
+                trace_ah_b(zr, zi, xi, oth);         // tr(Xi' E) = tr(X_t' L_t) for every t
+                mul_a_bh(C0, xi, oth);               // Xi E'
+                mul_ah_b(tmp, oth, xi);              // E' Xi
+#pragma unroll
+                for (int e = 0; e < NN; ++e) {
+                    C0.re[e] -= tmp.re[e];
+                    C0.im[e] -= tmp.im[e];
+                }
+            } else {
+                mul_a_bh(tmp, xi, xt);               // Xi Xt'
+                mul(C0, tmp, T);
+            }
+            mul(tmp, inc, C0);
+            mul_a_bh(Xs, tmp, inc);                  // Xs := M at the chunk end
         } else {
-            mul(Xs, oth, inc);
+            CMat<N> xi;
+            load_uniform(xi, opXi);
+            if (SAND) {
+                mul(tmp, oth, xi);
+                mul_a_bh(Xs, tmp, oth);
+            } else {
+                mul(Xs, oth, xi);
+            }
         }
     }
-    {
+    if (!UNI) {
         CMat<N> inc = Q, oth, tmp;
         for (int d = 1; d < 64; d <<= 1) {
             shfl_down(oth, inc, d);
@@ -219,33 +344,72 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
         }
     }
 
-    stamp(st, 2);
-    // ---------------------------------------------------------------- phase C
-    {
-        CMat<N> X = Xs, P, tmp;
-        for (int j = 0; j < S; ++j) {
+    const double gs = SAND ? -dt : (p.variant == 0 ? -2.0 * dt : 2.0 * dt);
+
+    if (UNI) {
+        stamp(st, 2);
+        stamp(st, 3);
+        // ------------------------------------------------------------ phase D, unitary flow
+        CMat<N> M = Xs, tmp;
+        CMat<N> P0, P1;
+        // software pipeline: P of slice j-1 is in flight while slice j is processed
+        auto step = [&](int j, const CMat<N> &P) {
             const int t = t0 + j;
             if (t < Nsl) {
-                store_ws(Xw + (size_t)j * NN * stride, stride, X);
-                if (j + 1 < S) {                       // the chunk's last state is never read
-                    load_ws(P, Pw + (size_t)j * NN * stride, stride);
-                    if (SAND) {
-                        mul_a_bh(tmp, X, P);
-                        mul(X, P, tmp);
-                    } else {
-                        mul(tmp, P, X);
-                        X = tmp;
+                mul(tmp, M, P);
+                mul_ah_b(M, P, tmp);                 // M_t = P' M_{t+1} P
+                if (!SAND) {                         // z_t = tr(X_t' L_t) = conj(tr M_t)
+                    double tr_r = 0.0, tr_i = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        tr_r += M.re[i + i * N];
+                        tr_i += M.im[i + i * N];
+                    }
+                    zr = tr_r;
+                    zi = -tr_i;
+                }
+                write_gradient<N, SAND>(xg + j * K, opB, K, M, zr, zi, gs);
+                if (t == Nsl - 1)
+                    out[(size_t)K * Nsl] = figure_of_merit<N, SAND>(zr, zi);
+            }
+        };
+        int j = S - 1;
+        load_ws(P0, Pw + (size_t)j * NN * stride, stride);
+        for (; j >= 1; j -= 2) {
+            load_ws(P1, Pw + (size_t)(j - 1) * NN * stride, stride);
+            step(j, P0);
+            if (j >= 2)
+                load_ws(P0, Pw + (size_t)(j - 2) * NN * stride, stride);
+            step(j - 1, P1);
+        }
+        if (j == 0)
+            step(0, P0);
+    } else {
+        stamp(st, 2);
+        // ------------------------------------------------------------ phase C
+        {
+            CMat<N> X = Xs, P, tmp;
+            for (int j = 0; j < S; ++j) {
+                const int t = t0 + j;
+                if (t < Nsl) {
+                    store_ws(Xw + (size_t)j * NN * stride, stride, X);
+                    if (j + 1 < S) {                   // the chunk's last state is never read
+                        load_ws(P, Pw + (size_t)j * NN * stride, stride);
+                        if (SAND) {
+                            mul_a_bh(tmp, X, P);
+                            mul(X, P, tmp);
+                        } else {
+                            mul(tmp, P, X);
+                            X = tmp;
+                        }
                     }
                 }
             }
         }
-    }
 
-    stamp(st, 3);
-    // ---------------------------------------------------------------- phase D
-    {
+        stamp(st, 3);
+        // ------------------------------------------------------------ phase D, general flow
         CMat<N> Lc = Le, P, X, M, tmp;
-        const double gs = SAND ? -dt : (p.variant == 0 ? -2.0 * dt : 2.0 * dt);
         for (int j = S - 1; j >= 0; --j) {
             const int t = t0 + j;
             if (t < Nsl) {
@@ -271,33 +435,17 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
                         M.im[e] -= tmp.im[e];
                     }
                 }
-                for (int c = 0; c < K; ++c) {
-                    double wr = 0.0, wi = 0.0;
-#pragma unroll
-                    for (int jj = 0; jj < N; ++jj)
-#pragma unroll
-                        for (int ii = 0; ii < N; ++ii) {
-                            const double2 b = opB[c * NN + ii + jj * N];
-                            const double mr = M.re[jj + ii * N], mi = M.im[jj + ii * N];
-                            wr = fma(b.x, mr, wr);
-                            wr = fma(-b.y, mi, wr);
-                            wi = fma(b.x, mi, wi);
-                            wi = fma(b.y, mr, wi);
-                        }
-                    const double im = SAND ? wi : fma(wr, zi, wi * zr);   // Im(w) | Im(w z)
-                    out[c + (size_t)t * K] = gs * im;
-                }
-                if (t == Nsl - 1) {
-                    if (SAND) {
-                        const double inv = 1.0 / (double)N;
-                        const double ar = zr * inv, ai = zi * inv;
-                        out[(size_t)K * Nsl] = 1.0 - (ar * ar + ai * ai);
-                    } else {
-                        out[(size_t)K * Nsl] = zr * zr - zi * zi;
-                    }
-                }
+                write_gradient<N, SAND>(xg + j * K, opB, K, M, zr, zi, gs);
+                if (t == Nsl - 1)
+                    out[(size_t)K * Nsl] = figure_of_merit<N, SAND>(zr, zi);
             }
         }
+    }
+    // gradient: LDS -> HBM, lane-contiguous
+    __syncthreads();
+    for (int q = L; q < K * Nsl; q += LT) {
+        const int lq = q / SK;
+        out[q] = s_xg[lq * (SK + 1) + (q - lq * SK)];
     }
     stamp(st, 4);
     if (st && lane == 0)
@@ -320,30 +468,50 @@ int sweep_small_max_waves(int n)
     }
 }
 
-template <int N>
-static hipError_t launch_n(int sandwich, bool keepl, const SweepParams &p, hipStream_t stream)
+template <int N, int SAND>
+static hipError_t launch_ns(int mode, const SweepParams &p, hipStream_t stream)
 {
     constexpr int MAXT = SmallTraits<N>::MAXT;
     const dim3 grid(p.E), block(p.LT);
     if (p.LT > MAXT || (p.LT & 63) || (long long)p.S * p.LT < p.N)
         return hipErrorInvalidConfiguration;
-    if (sandwich) {
-        if (keepl) hipLaunchKernelGGL((sweep_small_kernel<N, 1, true, MAXT>), grid, block, 0, stream, p);
-        else       hipLaunchKernelGGL((sweep_small_kernel<N, 1, false, MAXT>), grid, block, 0, stream, p);
-    } else {
-        if (keepl) hipLaunchKernelGGL((sweep_small_kernel<N, 0, true, MAXT>), grid, block, 0, stream, p);
-        else       hipLaunchKernelGGL((sweep_small_kernel<N, 0, false, MAXT>), grid, block, 0, stream, p);
+    const size_t lds = sizeof(double2) * (2 * (MAXT / 64) * N * N + (size_t)(p.K + 3) * N * N) +
+                       sizeof(double) * (size_t)p.LT * ((size_t)p.S * p.K + 1);
+    if (lds > 160 * 1024)
+        return hipErrorInvalidConfiguration;
+    if (lds > 64 * 1024) {                       // above the default dynamic-LDS cap: opt in
+        const void *fn = mode == MODE_GENERAL ? (const void *)sweep_small_kernel<N, SAND, MODE_GENERAL, MAXT>
+                       : mode == MODE_GENERAL_KEEPL ? (const void *)sweep_small_kernel<N, SAND, MODE_GENERAL_KEEPL, MAXT>
+                                                    : (const void *)sweep_small_kernel<N, SAND, MODE_UNITARY, MAXT>;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
+    switch (mode) {
+    case MODE_GENERAL:
+        hipLaunchKernelGGL((sweep_small_kernel<N, SAND, MODE_GENERAL, MAXT>), grid, block, lds, stream, p);
+        break;
+    case MODE_GENERAL_KEEPL:
+        hipLaunchKernelGGL((sweep_small_kernel<N, SAND, MODE_GENERAL_KEEPL, MAXT>), grid, block, lds, stream, p);
+        break;
+    case MODE_UNITARY:
+        hipLaunchKernelGGL((sweep_small_kernel<N, SAND, MODE_UNITARY, MAXT>), grid, block, lds, stream, p);
+        break;
+    default:
+        return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_sweep_small(int n, int sandwich, bool keep_costates, const SweepParams &p,
-                              hipStream_t stream)
+hipError_t launch_sweep_small(int n, int sandwich, int mode, const SweepParams &p, hipStream_t stream)
 {
-    switch (n) {
-    case 2: return launch_n<2>(sandwich, keep_costates, p, stream);
-    case 3: return launch_n<3>(sandwich, keep_costates, p, stream);
-    case 4: return launch_n<4>(sandwich, keep_costates, p, stream);
+    switch (n * 2 + (sandwich ? 1 : 0)) {
+    case 4: return launch_ns<2, 0>(mode, p, stream);
+    case 5: return launch_ns<2, 1>(mode, p, stream);
+    case 6: return launch_ns<3, 0>(mode, p, stream);
+    case 7: return launch_ns<3, 1>(mode, p, stream);
+    case 8: return launch_ns<4, 0>(mode, p, stream);
+    case 9: return launch_ns<4, 1>(mode, p, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -22,6 +22,7 @@ SYS_TYPE_CODES = {"UnitaryGate": 0, "StateTransfer": 1, "CoherenceTransfer": 2}
 FLAG_KEEP_COSTATES = 1
 FLAG_TIME_KERNELS = 2
 FLAG_PHASE_STAMPS = 4
+FLAG_FORCE_GENERAL = 8
 
 STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID_ARG", -2: "GRAPE_ERR_UNSUPPORTED",
           -3: "GRAPE_ERR_NO_DEVICE", -4: "GRAPE_ERR_HIP", -5: "GRAPE_ERR_NOT_READY",
@@ -50,7 +51,7 @@ class GrapeConfig(C.Structure):
 class GrapeInfo(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("compute_units", C.c_int32),
                 ("slices_per_lane", C.c_int32), ("waves_per_member", C.c_int32),
-                ("expm_squarings", C.c_int32), ("kernel_family", C.c_int32), ("reserved", C.c_int32),
+                ("expm_squarings", C.c_int32), ("kernel_family", C.c_int32), ("unitary_flow", C.c_int32),
                 ("expm_theta", C.c_double), ("workspace_bytes", C.c_uint64), ("arch", C.c_char * 32)]
 
 
@@ -192,13 +193,13 @@ class GrapeEngine:
         self._check(self._lib.grape_get_member_results(self._h, _p(foms), _p(grads)))
         return foms, np.ascontiguousarray(np.swapaxes(grads, 1, 2))
 
-    def trajectory(self, member, costates=False):
+    def trajectory(self, member, costates=False, states=True):
         n, N = self.n, self.N
         P = np.empty((N, n, n), np.complex128)
-        X = np.empty((N + 1, n, n), np.complex128)
+        X = np.empty((N + 1, n, n), np.complex128) if states else None
         Lc = np.empty((N + 1, n, n), np.complex128) if costates else None
         self._check(self._lib.grape_get_trajectory(self._h, int(member), _p(P), _p(X), _p(Lc)))
-        sw = lambda a: np.ascontiguousarray(np.swapaxes(a, -1, -2))
+        sw = lambda a: None if a is None else np.ascontiguousarray(np.swapaxes(a, -1, -2))
         return (sw(P), sw(X), sw(Lc)) if costates else (sw(P), sw(X))
 
     def phase_stamps(self):

@@ -15,17 +15,23 @@ tol = 1e-6
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-5] for p in GOLDEN])
-def test_hip_matches_golden(qoc, path):
+@pytest.mark.parametrize("flow", ["unitary", "general"])
+def test_hip_matches_golden(qoc, path, flow):
     c, A, B, Xi, Xt, wts, x, exp, traj = load_case(path)
-    with qoc.GrapeEngine(c["sys_type"], A, B, Xi, Xt, wts, c["T"], c["N"], variant=c["variant"],
-                         flags=qoc.engine.FLAG_KEEP_COSTATES) as eng:
+    flags = 0 if flow == "unitary" else qoc.engine.FLAG_KEEP_COSTATES
+    with qoc.GrapeEngine(c["sys_type"], A, B, Xi, Xt, wts, c["T"], c["N"], variant=c["variant"], flags=flags) as eng:
         F, G = eng.eval(x)
         foms, grads = eng.member_results()
-        P, X, L = eng.trajectory(0, costates=True)
+        if flow == "general":
+            got_traj = eng.trajectory(0, costates=True)
+        else:
+            got_traj = (eng.trajectory(0, states=False)[0],)
+            with pytest.raises(qoc.GrapeError):
+                eng.trajectory(0)                                # the unitary flow stores no states
     assert_parity(F, G, exp["F"], np.array(exp["G"]), c["n"], what="ensemble")
     for k in range(c["E"]):
         assert_parity(foms[k], grads[k], exp["member_F"][k], np.array(exp["member_g"][k]), c["n"], what=f"member {k}")
-    for got, want in zip((P, X, L), traj):
+    for got, want in zip(got_traj, traj):
         assert np.abs(got - want).max() < 1e-13
 
 
