@@ -15,12 +15,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <string>
 #include <vector>
 
 #include "grape_kernels.hpp"
 
 using grape::SweepParams;
+using grape::TileParams;
 typedef std::complex<double> cplx;
 
 struct grape_ctx {
@@ -28,6 +30,9 @@ struct grape_ctx {
     int device = 0;
     int compute_units = 0;
     char arch[32] = {0};
+    int family = 0;               // 0: register-resident small-n kernels, 1: MFMA tile kernels
+    int NT = 0;                   // tile family: tiles per dimension (padded n = 16 NT)
+    size_t TSZ = 0;               // tile family: double2 per matrix dump
     int S = 0, W = 0, LT = 0;
     int ksplit = 1;
     size_t ws_elems = 0;          // double2 elements per workspace array
@@ -105,10 +110,11 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     if (!(cfg->duration == cfg->duration))
         return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: duration is NaN");
     const int wmax = grape::sweep_small_max_waves(cfg->n);
-    if (wmax == 0)
+    const int nt = grape::tile_count(cfg->n);
+    if (wmax == 0 && nt == 0)
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED,
                     "grape_create: operator dimension n=" + std::to_string(cfg->n) +
-                        " has no kernel in this build (supported: 2, 3, 4)");
+                        " has no kernel in this build (supported: 2..32)");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -138,6 +144,9 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     // Aim for one wave per SIMD across the chip; more waves per member only when the
     // ensemble alone cannot fill it.
     const int N = cfg->n_slices, E = cfg->n_ensemble;
+    c->family = wmax > 0 ? 0 : 1;
+    c->NT = nt;
+    c->TSZ = (size_t)nt * nt * 256;
     int W = cfg->waves_per_member;
     if (W <= 0) {
         const long simds = 4L * c->compute_units;
@@ -145,8 +154,8 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
         const int wneed = (N + 63) / 64;
         if (W > wneed) W = wneed;
     }
-    if (W > wmax) W = wmax;
-    if (W < 1) W = 1;
+    if (wmax > 0 && W > wmax) W = wmax;
+    if (W < 1 || c->family == 1) W = 1;
     int S = cfg->slices_per_lane;
     const int smin = (N + 64 * W - 1) / (64 * W);
     if (S < smin) S = smin;
@@ -155,7 +164,8 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
 
     const size_t nn = (size_t)cfg->n * cfg->n, K = cfg->n_controls;
     const size_t Q = KN(c) + 1;
-    c->ws_elems = (size_t)E * S * nn * c->LT;
+    c->ws_elems = c->family == 0 ? (size_t)E * S * nn * c->LT : (size_t)E * N * c->TSZ;
+    const size_t ops_elems = c->family == 0 ? (size_t)E * (K + 3) * nn : (size_t)E * (2 * K + 3) * c->TSZ;
     const bool keepl = (cfg->flags & GRAPE_FLAG_KEEP_COSTATES) != 0;
 
     auto alloc = [&](void **p, size_t bytes) -> hipError_t {
@@ -163,7 +173,7 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
         return hipMalloc(p, bytes);
     };
     hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = alloc((void **)&c->d_ops, sizeof(double2) * E * (K + 3) * nn);
+    if (e == hipSuccess) e = alloc((void **)&c->d_ops, sizeof(double2) * ops_elems);
     if (e == hipSuccess) e = alloc((void **)&c->d_wts, sizeof(double) * E);
     if (e == hipSuccess) e = alloc((void **)&c->d_x, sizeof(double) * KN(c));
     if (e == hipSuccess) e = alloc((void **)&c->d_fg, sizeof(double) * Q);
@@ -201,23 +211,51 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         return fail(c, GRAPE_ERR_INVALID_ARG, "grape_set_operators: null argument");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t nn = (size_t)c->cfg.n * c->cfg.n, K = c->cfg.n_controls, E = c->cfg.n_ensemble;
-    // interleave per member: [A | B_0..B_{K-1} | Xi | Xt]
     std::vector<double> packed;
     try {
-        packed.resize(2 * E * (K + 3) * nn);
+        packed.assign(c->family == 0 ? 2 * E * (K + 3) * nn : 2 * E * (2 * K + 3) * c->TSZ, 0.0);
     } catch (...) {
         return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: out of host memory");
     }
-    for (size_t k = 0; k < E; ++k) {
-        double *dst = packed.data() + 2 * k * (K + 3) * nn;
-        std::memcpy(dst, A + 2 * k * nn, sizeof(double) * 2 * nn);
-        std::memcpy(dst + 2 * nn, B + 2 * k * K * nn, sizeof(double) * 2 * K * nn);
-        std::memcpy(dst + 2 * (1 + K) * nn, Xi + 2 * k * nn, sizeof(double) * 2 * nn);
-        std::memcpy(dst + 2 * (2 + K) * nn, Xt + 2 * k * nn, sizeof(double) * 2 * nn);
+    if (c->family == 0) {
+        // per member: [A | B_0..B_{K-1} | Xi | Xt], column-major as given
+        for (size_t k = 0; k < E; ++k) {
+            double *dst = packed.data() + 2 * k * (K + 3) * nn;
+            std::memcpy(dst, A + 2 * k * nn, sizeof(double) * 2 * nn);
+            std::memcpy(dst + 2 * nn, B + 2 * k * K * nn, sizeof(double) * 2 * K * nn);
+            std::memcpy(dst + 2 * (1 + K) * nn, Xi + 2 * k * nn, sizeof(double) * 2 * nn);
+            std::memcpy(dst + 2 * (2 + K) * nn, Xt + 2 * k * nn, sizeof(double) * 2 * nn);
+        }
+    } else {
+        // per member: [A | B_c | B_c^T | Xi | Xt] as zero-padded D-layout dumps (tile.hpp)
+        const int nd = c->cfg.n, NT = c->NT;
+        auto dump = [&](double *dst, const double *M, bool transpose) {
+            for (int I = 0; I < NT; ++I)
+                for (int J = 0; J < NT; ++J)
+                    for (int r = 0; r < 4; ++r)
+                        for (int l = 0; l < 64; ++l) {
+                            int row = 16 * I + 4 * r + (l >> 4), col = 16 * J + (l & 15);
+                            if (row >= nd || col >= nd) continue;
+                            if (transpose) std::swap(row, col);
+                            const size_t o = 2 * ((size_t)((I * NT + J) * 4 + r) * 64 + l);
+                            dst[o] = M[2 * (row + (size_t)nd * col)];
+                            dst[o + 1] = M[2 * (row + (size_t)nd * col) + 1];
+                        }
+        };
+        for (size_t k = 0; k < E; ++k) {
+            double *dst = packed.data() + 2 * k * (2 * K + 3) * c->TSZ;
+            dump(dst, A + 2 * k * nn, false);
+            for (size_t j = 0; j < K; ++j) {
+                dump(dst + 2 * (1 + j) * c->TSZ, B + 2 * (k * K + j) * nn, false);
+                dump(dst + 2 * (1 + K + j) * c->TSZ, B + 2 * (k * K + j) * nn, true);
+            }
+            dump(dst + 2 * (1 + 2 * K) * c->TSZ, Xi + 2 * k * nn, false);
+            dump(dst + 2 * (2 + 2 * K) * c->TSZ, Xt + 2 * k * nn, false);
+        }
     }
     // Data-flow choice: if every generator is Hermitian to rounding, every propagator is
     // unitary and the sweep can carry M_t = P_t' M_{t+1} P_t instead of storing X_t.
-    bool herm = !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES));
+    bool herm = c->family == 0 && !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES));
     const int n = c->cfg.n;
     for (size_t k = 0; k < E && herm; ++k) {
         for (size_t m = 0; m < K + 1 && herm; ++m) {
@@ -243,6 +281,27 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     HIP_TRY(c, hipMemcpy(c->d_wts, wts, sizeof(double) * E, hipMemcpyHostToDevice));
     c->ops_set = true;
     c->evaluated = false;
+    return GRAPE_OK;
+}
+
+static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream)
+{
+    TileParams p{};
+    p.ops = c->d_ops;
+    p.x = d_x;
+    p.props = c->d_props;
+    p.states = c->d_states;
+    p.costates = c->d_costates;
+    p.member_out = c->d_member_out;
+    p.K = c->cfg.n_controls;
+    p.N = c->cfg.n_slices;
+    p.E = c->cfg.n_ensemble;
+    p.n = c->cfg.n;
+    p.s_forced = c->cfg.expm_squarings;
+    p.variant = c->cfg.variant;
+    p.dt = c->cfg.duration / c->cfg.n_slices;
+    HIP_TRY(c, grape::launch_sweep_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, c->d_costates != nullptr,
+                                        p, stream));
     return GRAPE_OK;
 }
 
@@ -279,8 +338,13 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
         c->ev_used += 2;
         HIP_TRY(c, hipEventRecord(e0, stream));
     }
-    const int mode = c->unitary ? 2 : (c->d_costates ? 1 : 0);
-    HIP_TRY(c, grape::launch_sweep_small(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, mode, p, stream));
+    if (c->family == 0) {
+        const int mode = c->unitary ? 2 : (c->d_costates ? 1 : 0);
+        HIP_TRY(c, grape::launch_sweep_small(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, mode, p, stream));
+    } else {
+        int rc = enqueue_tile(c, d_x, stream);
+        if (rc) return rc;
+    }
     if (timed) HIP_TRY(c, hipEventRecord(e1, stream));
     HIP_TRY(c, grape::launch_reduce(c->d_member_out, c->d_wts, c->d_partial, d_fg, p.E,
                                     (int)(KN(c) + 1), c->ksplit, stream));
@@ -334,6 +398,24 @@ extern "C" int grape_get_member_results(grape_ctx *c, double *foms, double *grad
 // gathers one member's slab from the lane-major workspace layout into (n,n,count) col-major
 static int fetch_slab(grape_ctx *c, const double2 *d_ws, int member, cplx *out)
 {
+    if (c->family == 1) {
+        const size_t N = c->cfg.n_slices, TSZ = c->TSZ;
+        const int n = c->cfg.n, NT = c->NT;
+        std::vector<cplx> h(N * TSZ);
+        HIP_TRY(c, hipMemcpy(h.data(), d_ws + (size_t)member * N * TSZ, sizeof(cplx) * h.size(),
+                             hipMemcpyDeviceToHost));
+        for (size_t t = 0; t < N; ++t)
+            for (int I = 0; I < NT; ++I)
+                for (int J = 0; J < NT; ++J)
+                    for (int r = 0; r < 4; ++r)
+                        for (int l = 0; l < 64; ++l) {
+                            const int row = 16 * I + 4 * r + (l >> 4), col = 16 * J + (l & 15);
+                            if (row < n && col < n)
+                                out[t * n * n + row + (size_t)n * col] =
+                                    h[t * TSZ + (size_t)((I * NT + J) * 4 + r) * 64 + l];
+                        }
+        return GRAPE_OK;
+    }
     const size_t nn = (size_t)c->cfg.n * c->cfg.n, S = c->S, LT = c->LT, N = c->cfg.n_slices;
     std::vector<cplx> h(S * nn * LT);
     HIP_TRY(c, hipMemcpy(h.data(), d_ws + (size_t)member * S * nn * LT, sizeof(cplx) * h.size(),
@@ -397,8 +479,22 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
         cplx *Lc = reinterpret_cast<cplx *>(costates);
         rc = fetch_slab(c, c->d_costates, member, Lc);
         if (rc) return rc;
-        HIP_TRY(c, hipMemcpy(Lc + N * nn, c->d_ops + (size_t)member * (K + 3) * nn + (K + 2) * nn,
-                             sizeof(cplx) * nn, hipMemcpyDeviceToHost));
+        if (c->family == 0) {
+            HIP_TRY(c, hipMemcpy(Lc + N * nn, c->d_ops + (size_t)member * (K + 3) * nn + (K + 2) * nn,
+                                 sizeof(cplx) * nn, hipMemcpyDeviceToHost));
+        } else {
+            std::vector<cplx> h(c->TSZ);
+            HIP_TRY(c, hipMemcpy(h.data(), c->d_ops + ((size_t)member * (2 * K + 3) + 2 * K + 2) * c->TSZ,
+                                 sizeof(cplx) * c->TSZ, hipMemcpyDeviceToHost));
+            for (int I = 0; I < c->NT; ++I)
+                for (int J = 0; J < c->NT; ++J)
+                    for (int r = 0; r < 4; ++r)
+                        for (int l = 0; l < 64; ++l) {
+                            const int row = 16 * I + 4 * r + (l >> 4), col = 16 * J + (l & 15);
+                            if (row < n && col < n)
+                                Lc[N * nn + row + (size_t)n * col] = h[(size_t)((I * c->NT + J) * 4 + r) * 64 + l];
+                        }
+        }
     }
     return GRAPE_OK;
 }
@@ -447,7 +543,7 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
     info->slices_per_lane = c->S;
     info->waves_per_member = c->W;
     info->expm_squarings = c->cfg.expm_squarings;
-    info->kernel_family = 0;
+    info->kernel_family = c->family;
     info->unitary_flow = c->unitary ? 1 : 0;
     info->expm_theta = 0.05;
     info->workspace_bytes = c->bytes;

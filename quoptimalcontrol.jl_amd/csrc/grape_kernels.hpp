@@ -36,6 +36,22 @@ struct SweepParams {
 hipError_t launch_sweep_small(int n, int sandwich, int mode, const SweepParams &p, hipStream_t stream);
 int sweep_small_max_waves(int n);   // W limit of the register-resident kernel for this n
 
+// ---- tile (MFMA) family, n = 5..32, zero-padded to 16*NT ------------------------------------
+// All matrices are "D-layout dumps" (tile.hpp): (16 NT)^2 double2 each, TSZ = NT*NT*256.
+struct TileParams {
+    const double2 *ops;   // per member: [A | B_1..B_K | B_1^T..B_K^T | Xi | Xt]  ((2K+3) dumps)
+    const double *x;      // (K, N) col-major controls
+    double2 *props;       // P_t dump at (k*N + t)*TSZ
+    double2 *states;      // X_t dump, same indexing
+    double2 *costates;    // L_t dump (debug, GRAPE_FLAG_KEEP_COSTATES)
+    double *member_out;   // as in SweepParams
+    int32_t K, N, E, n;
+    int32_t s_forced, variant;
+    double dt;
+};
+int tile_count(int n);    // NT for this n (0: not a tile-family size)
+hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
+
 // G[q] = sum_k w_k member_out[k][q]  for q in [0, Q)  (Q = K*N + 1; the last entry is F).
 // partial: scratch of ksplit*Q doubles.  Deterministic (fixed summation tree).
 hipError_t launch_reduce(const double *member_out, const double *wts, double *partial, double *fg,

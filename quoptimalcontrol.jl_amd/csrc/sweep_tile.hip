@@ -1,0 +1,279 @@
+// sweep_tile.hip -- the GRAPE hot path for operators of dimension 5..32 on the FP64 matrix
+// cores (tile.hpp): one wavefront owns a whole zero-padded (16 NT)^2 complex matrix.
+//
+//   prop_tile_kernel   pw_prop_save!  (src/timeevolution.jl:98-110): one wave per (member, slice):
+//                      H = sum_j B_j x[j,t] + A in D layout straight from the pre-tiled operators,
+//                      G = -i dt H, expm_t8 with MFMA products, P_t dumped in D layout.
+//   chain_tile_kernel  evolve_func! forward and backward + grad_func! + fom_func
+//                      (src/GRAPE.jl:216-287, src/cost_functions.jl:99-111): one wave per member
+//                      walks the time axis serially; with E >= #SIMDs the ensemble alone fills the
+//                      chip, so no time-parallel scan is needed at these sizes.  The reference's
+//                      data flow is kept (forward states stored, costates pulled back in registers).
+//
+// Products are arranged so that every operand is either a lane-contiguous dump load or the D
+// registers of the running matrix (tile.hpp):
+//   forward  UG:  X' = P X                 = tmul_an(P_A, X)
+//            ST:  X' = P X P'  ->  Y^T = X^T P^T = tmul_tb(X, P_A);  X' = Y P' = tmul_tb<conj B>(Y^T, P_A)
+//   backward UG:  L' = P' L                = tmul_tn<conj Z>(P, L)      (P^H as A operand: free)
+//            ST:  Y^T = L^T conj(P) = tmul_tn<., conj W>(L, P);  L' = Y P = tmul_tn(Y^T, P)
+//   gradient:     R = X L' (one A-layout conversion each of X and L), sandwich: minus L' X
+//                 = tmul_tn<conj Z>(L, X);  tr(L' B_c X) = sum R .* (B_c^T in D layout).
+#include "cmat.hpp"          // Taylor-8 coefficients, squarings_for
+#include "grape_kernels.hpp"
+#include "tile.hpp"
+
+namespace grape {
+
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void prop_tile_kernel(const TileParams p)
+{
+    constexpr int TSZ = NT * NT * 256;                     // double2 per matrix dump
+    __shared__ double2 s_img[4][kTileImage];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.y;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= p.N)
+        return;
+    const int K = p.K;
+    const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;   // [A | B_c | B_c^T | Xi | Xt]
+    double2 *img = s_img[wave];
+
+    TMat<NT> G;
+    if (p.variant == 0)
+        tzero(G);
+    else
+        tload(G, ops, lane);
+    for (int c = 0; c < K; ++c) {
+        const double xv = p.x[c + (size_t)t * K];
+        TMat<NT> B;
+        tload(B, ops + (size_t)(1 + c) * TSZ, lane);
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    G.re[I][J][r] = fma(B.re[I][J][r], xv, G.re[I][J][r]);
+                    G.im[I][J][r] = fma(B.im[I][J][r], xv, G.im[I][J][r]);
+                }
+    }
+    if (p.variant == 0) {
+        TMat<NT> A;
+        tload(A, ops, lane);
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                G.re[I][J] += A.re[I][J];
+                G.im[I][J] += A.im[I][J];
+            }
+    }
+    // G = (-i dt) H ; column sums of |re|+|im| bound the 1-norm
+    const double dt = p.dt;
+    double colmax = 0.0;
+#pragma unroll
+    for (int J = 0; J < NT; ++J) {
+        double cs = 0.0;
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double hr = G.re[I][J][r], hi = G.im[I][J][r];
+                G.re[I][J][r] = dt * hi;
+                G.im[I][J][r] = -dt * hr;
+                cs += fabs(G.re[I][J][r]) + fabs(G.im[I][J][r]);
+            }
+        cs += __shfl_xor(cs, 16, 64);                      // rows live on lane>>4 and r
+        cs += __shfl_xor(cs, 32, 64);
+        colmax = fmax(colmax, cs);
+    }
+    colmax = wave_max(colmax);
+    const int s = p.s_forced >= 0 ? p.s_forced : squarings_for(colmax);
+    if (s > 0) {
+        const double sc = ldexp(1.0, -s);
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                G.re[I][J] *= sc;
+                G.im[I][J] *= sc;
+            }
+    }
+
+    // expm_t8 (cmat.hpp) with MFMA products; every matrix is a polynomial in G
+    TOp<NT> opa;
+    TMat<NT> A2, A4, U, T;
+    to_a_layout(opa, G, img, lane);
+    tmul_an<NT, false, false>(A2, opa, G);                 // A2 = G G
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J) {
+            T.re[I][J] = kX1 * G.re[I][J] + kX2 * A2.re[I][J];
+            T.im[I][J] = kX1 * G.im[I][J] + kX2 * A2.im[I][J];
+        }
+    to_a_layout(opa, A2, img, lane);
+    tmul_an<NT, false, false>(A4, opa, T);                 // A4 = A2 (x1 G + x2 A2)
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J) {
+            U.re[I][J] = kX3 * A2.re[I][J] + A4.re[I][J];
+            U.im[I][J] = kX3 * A2.im[I][J] + A4.im[I][J];
+            T.re[I][J] = kX5 * G.re[I][J] + kX6 * A2.re[I][J] + kX7 * A4.re[I][J];
+            T.im[I][J] = kX5 * G.im[I][J] + kX6 * A2.im[I][J] + kX7 * A4.im[I][J];
+        }
+    // identity: element (row, col) with row == col  <=>  I == J and 4r + (lane>>4) == lane&15
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * r + (lane >> 4) == (lane & 15))
+                T.re[I][I][r] += kX4;
+    to_a_layout(opa, U, img, lane);
+    TMat<NT> P;
+    tmul_an<NT, false, false>(P, opa, T);                  // A8
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J) {
+            P.re[I][J] += G.re[I][J] + kY2 * A2.re[I][J];
+            P.im[I][J] += G.im[I][J] + kY2 * A2.im[I][J];
+        }
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * r + (lane >> 4) == (lane & 15))
+                P.re[I][I][r] += 1.0;
+    for (int i = 0; i < s; ++i) {
+        to_a_layout(opa, P, img, lane);
+        tmul_an<NT, false, false>(T, opa, P);
+        P = T;
+    }
+    tstore(p.props + ((size_t)k * p.N + t) * TSZ, P, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NT, int SAND, bool KEEPL>
+__global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
+{
+    constexpr int TSZ = NT * NT * 256;
+    __shared__ double2 s_img[kTileImage];
+    const int lane = threadIdx.x;
+    const int k = blockIdx.x;
+    const int K = p.K, N = p.N;
+    const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
+    const double2 *__restrict__ opBT = ops + (size_t)(1 + K) * TSZ;
+    const double2 *__restrict__ Pk = p.props + (size_t)k * N * TSZ;
+    double2 *__restrict__ Xk = p.states + (size_t)k * N * TSZ;
+    double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * N + 1);
+
+    // ------------------------------------------------------------ forward sweep
+    {
+        TMat<NT> X, Pm, Y;
+        TOp<NT> PA;
+        tload(X, ops + (size_t)(1 + 2 * K) * TSZ, lane);           // Xi
+        for (int t = 0; t < N; ++t) {
+            tstore(Xk + (size_t)t * TSZ, X, lane);
+            if (t + 1 < N) {                                       // X_N is never read
+                tload(Pm, Pk + (size_t)t * TSZ, lane);
+                to_a_layout(PA, Pm, s_img, lane);
+                if (SAND) {
+                    tmul_tb<NT, false, false>(Y, X, PA);           // (P X)^T
+                    tmul_tb<NT, false, true>(X, Y, PA);            // (P X) P'
+                } else {
+                    tmul_an<NT, false, false>(Y, PA, X);
+                    X = Y;
+                }
+            }
+        }
+    }
+
+    // ------------------------------------------------------------ backward sweep + gradient
+    TMat<NT> L, Pm, X, Y, R;
+    TOp<NT> XA, LA;
+    tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);               // Xt
+    const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
+    for (int t = N - 1; t >= 0; --t) {
+        tload(Pm, Pk + (size_t)t * TSZ, lane);
+        tload(X, Xk + (size_t)t * TSZ, lane);
+        if (SAND) {
+            tmul_tn<NT, false, true>(Y, L, Pm);                    // (P' L)^T
+            tmul_tn<NT, false, false>(L, Y, Pm);                   // P' L P
+        } else {
+            tmul_tn<NT, true, false>(Y, Pm, L);                    // P' L
+            L = Y;
+        }
+        if (KEEPL)
+            tstore(p.costates + ((size_t)k * N + t) * TSZ, L, lane);
+        double zr, zi;
+        tdot<NT, true>(zr, zi, X, L);                              // tr(X' L)
+        // R = X L' : A layout of X, B layout of L' = conj(A layout of L)
+        to_a_layout(XA, X, s_img, lane);
+        to_a_layout(LA, L, s_img, lane);
+        tprod<NT, false, true>(
+            R, [&](int I, int Kt, int kb, double &r, double &i) { r = XA.re[I][Kt][kb]; i = XA.im[I][Kt][kb]; },
+            [&](int Kt, int J, int kb, double &r, double &i) { r = LA.re[J][Kt][kb]; i = LA.im[J][Kt][kb]; });
+        if (SAND) {
+            tmul_tn<NT, true, false>(Y, L, X);                     // L' X
+#pragma unroll
+            for (int I = 0; I < NT; ++I)
+#pragma unroll
+                for (int J = 0; J < NT; ++J) {
+                    R.re[I][J] -= Y.re[I][J];
+                    R.im[I][J] -= Y.im[I][J];
+                }
+        }
+        for (int c = 0; c < K; ++c) {
+            TMat<NT> BT;
+            tload(BT, opBT + (size_t)c * TSZ, lane);
+            double wr, wi;
+            tdot<NT, false>(wr, wi, BT, R);                        // sum_ij B[i,j] R[j,i]
+            const double im = SAND ? wi : fma(wr, zi, wi * zr);
+            if (lane == 0)
+                out[c + (size_t)t * K] = gs * im;
+        }
+        if (t == N - 1 && lane == 0) {
+            if (SAND) {
+                const double inv = 1.0 / (double)p.n;
+                const double ar = zr * inv, ai = zi * inv;
+                out[(size_t)K * N] = 1.0 - (ar * ar + ai * ai);
+            } else {
+                out[(size_t)K * N] = zr * zr - zi * zi;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+int tile_count(int n) { return n <= 4 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : 0)); }
+
+template <int NT>
+static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipStream_t stream)
+{
+    hipLaunchKernelGGL(prop_tile_kernel<NT>, dim3((p.N + 3) / 4, p.E), dim3(256), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return e;
+    if (sandwich) {
+        if (keepl) hipLaunchKernelGGL((chain_tile_kernel<NT, 1, true>), dim3(p.E), dim3(64), 0, stream, p);
+        else       hipLaunchKernelGGL((chain_tile_kernel<NT, 1, false>), dim3(p.E), dim3(64), 0, stream, p);
+    } else {
+        if (keepl) hipLaunchKernelGGL((chain_tile_kernel<NT, 0, true>), dim3(p.E), dim3(64), 0, stream, p);
+        else       hipLaunchKernelGGL((chain_tile_kernel<NT, 0, false>), dim3(p.E), dim3(64), 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream)
+{
+    switch (tile_count(n)) {
+    case 1: return launch_nt<1>(sandwich, keep_costates, p, stream);
+    case 2: return launch_nt<2>(sandwich, keep_costates, p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace grape

@@ -1,0 +1,204 @@
+// tile.hpp -- wave-level complex matrices on the FP64 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// A wave owns whole (16*NT) x (16*NT) ComplexF64 matrices, NT = 1 (n <= 16) or 2 (n <= 32),
+// zero-padded; this is the dense-contraction path the north star reserves for MFMA (the
+// d^2 x d^2 Liouvillian products of config C4 and the 32 x 32 products of C5).
+//
+// "D layout" (the MFMA accumulator layout, MI355X guide section 3): for tile (I, J), register
+// r in 0..3, lane l:   element (row 16I + 4r + (l>>4),  col 16J + (l&15)).
+// Facts this file is built on (verified on gfx950 by tests/test_gpu_tile.py):
+//   * D layout == the B-operand layout: register r of a D tile is the b-operand of k-block r.
+//   * used as the A operand, the D registers of tile (Kt, I) present the TRANSPOSE: so a product
+//     Z^T * B needs no data movement at all, and
+//   * the A-operand layout of Z itself (lane l, k-block kb: Z[16I + (l&15)][16Kt + 4kb + (l>>4)])
+//     is obtained from the D registers through a small LDS image (to_a_layout), padded so the
+//     transposing 16-byte reads are at most 2-way bank-conflicted.
+// A dump of the D registers to memory ((tile*4 + r)*64 + lane, double2) is therefore lane
+// contiguous (1 KiB per wave access) and is the workspace format of this kernel family.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace grape {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define GRAPE_DEV __device__ __forceinline__
+
+template <int NT>
+struct TMat {                     // D layout
+    d4 re[NT][NT];
+    d4 im[NT][NT];
+};
+
+template <int NT>
+struct TOp {                      // an MFMA operand set: one f64 per lane per (tile, tile, k-block)
+    double re[NT][NT][4];
+    double im[NT][NT][4];
+};
+
+constexpr int kTileImage = 68 * 3 + 17 * 3 + 16;      // double2 slots of one padded LDS tile image
+
+template <int NT>
+GRAPE_DEV void tzero(TMat<NT> &m)
+{
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            m.re[i][j] = (d4){0, 0, 0, 0};
+            m.im[i][j] = (d4){0, 0, 0, 0};
+        }
+}
+
+// out (+)= op(A) * op(B), operands given per (tile, tile, k-block).  NEGI_A / NEGI_B conjugate.
+// a(I, Kt, kb) -> {re, im} of the A operand, b(Kt, J, kb) likewise.
+template <int NT, bool CONJ_A, bool CONJ_B, typename FA, typename FB>
+GRAPE_DEV void tprod(TMat<NT> &out, FA a, FB b)
+{
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J) {
+            d4 cr = (d4){0, 0, 0, 0}, ci = (d4){0, 0, 0, 0};
+#pragma unroll
+            for (int Kt = 0; Kt < NT; ++Kt)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    double ar, ai, br, bi;
+                    a(I, Kt, kb, ar, ai);
+                    b(Kt, J, kb, br, bi);
+                    if (CONJ_A) ai = -ai;
+                    if (CONJ_B) bi = -bi;
+                    cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cr, 0, 0, 0);
+                    cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cr, 0, 0, 0);
+                    ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, ci, 0, 0, 0);
+                    ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci, 0, 0, 0);
+                }
+            out.re[I][J] = cr;
+            out.im[I][J] = ci;
+        }
+}
+
+// out = op(Z)^T * op(W)   (both in D layout, no data movement)
+template <int NT, bool CONJ_Z, bool CONJ_W>
+GRAPE_DEV void tmul_tn(TMat<NT> &out, const TMat<NT> &z, const TMat<NT> &w)
+{
+    tprod<NT, CONJ_Z, CONJ_W>(
+        out, [&](int I, int Kt, int kb, double &r, double &i) { r = z.re[Kt][I][kb]; i = z.im[Kt][I][kb]; },
+        [&](int Kt, int J, int kb, double &r, double &i) { r = w.re[Kt][J][kb]; i = w.im[Kt][J][kb]; });
+}
+
+// out = op(A) * op(W),  A given in A-operand layout (TOp), W in D layout
+template <int NT, bool CONJ_A, bool CONJ_W>
+GRAPE_DEV void tmul_an(TMat<NT> &out, const TOp<NT> &a, const TMat<NT> &w)
+{
+    tprod<NT, CONJ_A, CONJ_W>(
+        out, [&](int I, int Kt, int kb, double &r, double &i) { r = a.re[I][Kt][kb]; i = a.im[I][Kt][kb]; },
+        [&](int Kt, int J, int kb, double &r, double &i) { r = w.re[Kt][J][kb]; i = w.im[Kt][J][kb]; });
+}
+
+// out = op(Z)^T * op(B),  Z in D layout, B an operand set whose registers are the B layout
+// of the wanted right factor (e.g. the A layout of P is the B layout of P^T)
+template <int NT, bool CONJ_Z, bool CONJ_B>
+GRAPE_DEV void tmul_tb(TMat<NT> &out, const TMat<NT> &z, const TOp<NT> &b)
+{
+    tprod<NT, CONJ_Z, CONJ_B>(
+        out, [&](int I, int Kt, int kb, double &r, double &i) { r = z.re[Kt][I][kb]; i = z.im[Kt][I][kb]; },
+        [&](int Kt, int J, int kb, double &r, double &i) { r = b.re[J][Kt][kb]; i = b.im[J][Kt][kb]; });
+}
+
+// A-operand layout of Z from its D registers, through the wave's private LDS image.
+// a.re[I][Kt][kb] (lane l) = Z[16I + (l&15)][16Kt + 4kb + (l>>4)].
+template <int NT>
+GRAPE_DEV void to_a_layout(TOp<NT> &a, const TMat<NT> &z, double2 *__restrict__ img, int lane)
+{
+    const int rho = lane & 15, q = lane >> 4;
+    const int wr = 17 * (lane >> 4) + (lane & 15);               // write slot of (r, lane) minus 68 r
+    const int rd = 68 * (rho >> 2) + 17 * (rho & 3) + q;         // read slot of (rho, 4kb + q) minus 4 kb
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int Kt = 0; Kt < NT; ++Kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                img[68 * r + wr] = make_double2(z.re[I][Kt][r], z.im[I][Kt][r]);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the wave's own writes
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const double2 v = img[rd + 4 * kb];
+                a.re[I][Kt][kb] = v.x;
+                a.im[I][Kt][kb] = v.y;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
+// memory dump <-> D registers: element (tile, r, lane) at ((I*NT + J)*4 + r)*64 + lane
+template <int NT>
+GRAPE_DEV void tload(TMat<NT> &m, const double2 *__restrict__ src, int lane)
+{
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double2 v = src[((I * NT + J) * 4 + r) * 64 + lane];
+                m.re[I][J][r] = v.x;
+                m.im[I][J][r] = v.y;
+            }
+}
+
+template <int NT>
+GRAPE_DEV void tstore(double2 *__restrict__ dst, const TMat<NT> &m, int lane)
+{
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                dst[((I * NT + J) * 4 + r) * 64 + lane] = make_double2(m.re[I][J][r], m.im[I][J][r]);
+}
+
+GRAPE_DEV double wave_sum(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+GRAPE_DEV double wave_max(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v = fmax(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+// sum over all elements of conj?(A) .* B  (elementwise, both D layout) -> wave-uniform complex
+template <int NT, bool CONJ_A>
+GRAPE_DEV void tdot(double &zr, double &zi, const TMat<NT> &a, const TMat<NT> &b)
+{
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double ar = a.re[I][J][r], ai = CONJ_A ? -a.im[I][J][r] : a.im[I][J][r];
+                const double br = b.re[I][J][r], bi = b.im[I][J][r];
+                sr = fma(ar, br, sr);
+                sr = fma(-ai, bi, sr);
+                si = fma(ar, bi, si);
+                si = fma(ai, br, si);
+            }
+    zr = wave_sum(sr);
+    zi = wave_sum(si);
+}
+
+}  // namespace grape

@@ -53,9 +53,9 @@ def test_argument_validation(qoc):
     assert b"sys_type" in lib.grape_last_error(None)
     cfg = qoc.engine.GrapeConfig(0, 0, 2, 0, 10, 1, 1.0, -1, 0, 0, 0, -1, 0)
     assert lib.grape_create(C.byref(cfg), C.byref(h)) == -1                        # K = 0
-    cfg = qoc.engine.GrapeConfig(0, 0, 7, 2, 10, 1, 1.0, -1, 0, 0, 0, -1, 0)
-    assert lib.grape_create(C.byref(cfg), C.byref(h)) == -2                        # n = 7 unsupported
-    assert b"n=7" in lib.grape_last_error(None)
+    cfg = qoc.engine.GrapeConfig(0, 0, 40, 2, 10, 1, 1.0, -1, 0, 0, 0, -1, 0)
+    assert lib.grape_create(C.byref(cfg), C.byref(h)) == -2                        # n = 40 unsupported
+    assert b"n=40" in lib.grape_last_error(None)
     assert lib.grape_destroy(None) == 0
     assert lib.grape_eval(None, None, None, None) == -1
 

@@ -1,0 +1,81 @@
+"""GPU: the MFMA tile-kernel family (operator dimension 5..32, zero-padded to 16 or 32) against
+the oracle: the configs BASELINE.json names C4 (16x16 Liouvillian, CoherenceTransfer, non-Hermitian
+generator) and C5 (32x32 UnitaryGate) at parity-test sizes, plus odd sizes that exercise padding."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(qoc, w, **kw):
+    return qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, **kw)
+
+
+def _random_problem(qoc, n, K, N, E, sys_type, seed, hermitian=True):
+    rng = np.random.default_rng(seed)
+
+    def rnd():
+        M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        return (M + M.conj().T) / 2 if hermitian else M
+    A = np.array([rnd() for _ in range(E)]) * 0.7
+    B = np.array([[rnd() for _ in range(K)] for _ in range(E)]) * 0.5
+    if sys_type == "UnitaryGate":
+        Xi = np.array([np.eye(n, dtype=complex)] * E)
+        Xt = np.array([np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))[0] for _ in range(E)])
+    else:
+        def rho():
+            v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+            v /= np.linalg.norm(v)
+            return np.outer(v, v.conj())
+        Xi = np.array([rho() for _ in range(E)])
+        Xt = np.array([rho() for _ in range(E)])
+    w = qoc.workloads.Workload("rnd", sys_type, n, K, N, E, 1.0, A, B, Xi, Xt, np.full(E, 1.0 / E),
+                               rng.uniform(0, 1, (K, N)))
+    return w
+
+
+@pytest.mark.parametrize("n,sys_type,herm", [(5, "UnitaryGate", True), (8, "StateTransfer", True),
+                                             (16, "UnitaryGate", True), (16, "CoherenceTransfer", False),
+                                             (17, "StateTransfer", True), (27, "UnitaryGate", False),
+                                             (32, "UnitaryGate", True), (32, "StateTransfer", True)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_tile_family_random(qoc, oracle, n, sys_type, herm, variant):
+    w = _random_problem(qoc, n, 3, 12, 3, sys_type, seed=100 + n, hermitian=herm)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
+                                                            variant=variant, per_member=True)
+    with _engine(qoc, w, variant=variant, flags=qoc.engine.FLAG_KEEP_COSTATES) as eng:
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+        assert eng.info["kernel_family"] == 1
+        P, X, L = eng.trajectory(1, costates=True)
+    _, _, Pr, Xr, Lr = oracle.member_eval(w.sys_type, w.A[1], w.B[1], w.Xi[1], w.Xt[1], w.x, w.T, variant=variant,
+                                          trajectory=True)
+    for got, want, what in ((P, Pr, "propagators"), (X, Xr, "states"), (L, Lr, "costates")):
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), what
+    for k in range(w.E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], w.n, what=f"n={n} member {k}")
+    assert_parity(F, G, F_ref, G_ref, w.n, what=f"n={n}")
+
+
+def test_c4_liouvillian_parity(qoc, oracle):
+    """BASELINE config 4 at parity size: 16x16 Liouvillian superoperators, CoherenceTransfer, K=4, N=1000."""
+    w = qoc.workloads.config("C4", E=6)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
+                                                            per_member=True)
+    with _engine(qoc, w) as eng:
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+    for k in range(w.E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], w.n, what=f"C4 member {k}")
+    assert_parity(F, G, F_ref, G_ref, w.n, what="C4")
+
+
+def test_c5_five_qubit_parity(qoc, oracle):
+    """BASELINE config 5 at parity size: 32x32 UnitaryGate, K=6, N=2000 (2 members)."""
+    w = qoc.workloads.config("C5", E=2)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    with _engine(qoc, w) as eng:
+        F, G = eng.eval(w.x)
+    assert_parity(F, G, F_ref, G_ref, w.n, what="C5")
