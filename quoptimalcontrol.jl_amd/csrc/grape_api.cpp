@@ -34,6 +34,8 @@ struct grape_ctx {
     int NT = 0;                   // tile family: tiles per dimension (padded n = 16 NT)
     size_t TSZ = 0;               // tile family: double2 per matrix dump
     int S = 0, W = 0, LT = 0;
+    int MPB = 1, NB = 0;          // small family: members per workgroup, number of workgroups
+    double *d_block_out = nullptr;
     int ksplit = 1;
     size_t ws_elems = 0;          // double2 elements per workspace array
     uint64_t bytes = 0;
@@ -84,7 +86,7 @@ static void free_all(grape_ctx *c)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     (void)hipFree(c->d_ops); (void)hipFree(c->d_wts); (void)hipFree(c->d_x); (void)hipFree(c->d_fg);
     (void)hipFree(c->d_props); (void)hipFree(c->d_states); (void)hipFree(c->d_costates);
-    (void)hipFree(c->d_member_out); (void)hipFree(c->d_partial); (void)hipFree(c->d_stamps);
+    (void)hipFree(c->d_member_out); (void)hipFree(c->d_partial); (void)hipFree(c->d_stamps); (void)hipFree(c->d_block_out);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     delete c;
 }
@@ -160,6 +162,13 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     const int smin = (N + 64 * W - 1) / (64 * W);
     if (S < smin) S = smin;
     c->W = W; c->S = S; c->LT = 64 * W;
+    if (c->family == 0 && (uint64_t)cfg->n_controls * N * S * cfg->n_controls >= (1ull << 32)) {
+        delete c;
+        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: n_controls^2 * n_slices^2 too large for the LDS index arithmetic");
+    }
+    c->MPB = (c->family == 0 && W <= 4) ? 4 / W : 1;         // fill the 4 SIMDs of a CU per workgroup
+    if (c->MPB > E) c->MPB = E;
+    c->NB = (E + c->MPB - 1) / c->MPB;
     c->ksplit = grape::reduce_ksplit(E);
 
     const size_t nn = (size_t)cfg->n * cfg->n, K = cfg->n_controls;
@@ -181,6 +190,7 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     if (e == hipSuccess && keepl) e = alloc((void **)&c->d_costates, sizeof(double2) * c->ws_elems);
     if (e == hipSuccess) e = alloc((void **)&c->d_member_out, sizeof(double) * E * Q);
     if (e == hipSuccess) e = alloc((void **)&c->d_partial, sizeof(double) * c->ksplit * Q);
+    if (e == hipSuccess && c->family == 0) e = alloc((void **)&c->d_block_out, sizeof(double) * c->NB * Q);
     if (e == hipSuccess && (cfg->flags & GRAPE_FLAG_PHASE_STAMPS))
         e = alloc((void **)&c->d_stamps, sizeof(unsigned long long) * E * W * grape::kStampSlots);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, sizeof(double) * Q, hipHostMallocDefault);
@@ -314,6 +324,10 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     p.states = c->d_states;
     p.costates = c->d_costates;
     p.member_out = c->d_member_out;
+    p.wts = c->d_wts;
+    p.block_out = c->d_block_out;
+    p.MPB = c->MPB;
+    p.sk_magic = (uint32_t)((1ull << 32) / ((uint64_t)c->S * c->cfg.n_controls)) + 1u;
     p.stamps = c->d_stamps;
     p.K = c->cfg.n_controls;
     p.N = c->cfg.n_slices;
@@ -346,8 +360,11 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
         if (rc) return rc;
     }
     if (timed) HIP_TRY(c, hipEventRecord(e1, stream));
-    HIP_TRY(c, grape::launch_reduce(c->d_member_out, c->d_wts, c->d_partial, d_fg, p.E,
-                                    (int)(KN(c) + 1), c->ksplit, stream));
+    if (c->family == 0)
+        HIP_TRY(c, grape::launch_reduce_rows(c->d_block_out, d_fg, c->NB, (int)(KN(c) + 1), stream));
+    else
+        HIP_TRY(c, grape::launch_reduce(c->d_member_out, c->d_wts, c->d_partial, d_fg, p.E,
+                                        (int)(KN(c) + 1), c->ksplit, stream));
     c->evaluated = true;
     return GRAPE_OK;
 }

@@ -21,10 +21,14 @@ struct SweepParams {
     double2 *costates;    // L_t (debug only, GRAPE_FLAG_KEEP_COSTATES), same layout
     // outputs
     double *member_out;   // (K*N + 1) per member: unweighted g_k (K,N col-major), then F_k
+    const double *wts;    // ensemble weights w_k
+    double *block_out;    // (K*N + 1) per workgroup: sum over its members of w_k * [g_k, F_k]
     unsigned long long *stamps;   // diagnostic (NULL in production): kStampSlots per (member, wave)
     int32_t K, N, E;
     int32_t S;            // slices per lane
     int32_t LT;           // lanes per member = 64 * W
+    int32_t MPB;          // members per workgroup (MPB * LT threads)
+    uint32_t sk_magic;    // floor(2^32 / (S*K)) + 1: q / (S*K) == __umulhi(q, sk_magic)
     int32_t s_forced;     // expm squarings, -1 = per slice from the norm
     int32_t variant;      // 0 in-place, 1 static
     double dt;
@@ -57,5 +61,7 @@ hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const Tile
 hipError_t launch_reduce(const double *member_out, const double *wts, double *partial, double *fg,
                          int E, int Q, int ksplit, hipStream_t stream);
 int reduce_ksplit(int E);
+// fg[q] = sum_b rows[b][q] over NB already-weighted rows (one launch, fixed summation tree).
+hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, hipStream_t stream);
 
 }  // namespace grape

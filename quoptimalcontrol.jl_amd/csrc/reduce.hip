@@ -55,6 +55,37 @@ __global__ __launch_bounds__(256) void reduce_stage2(const double *__restrict__ 
         fg[q] = v;
 }
 
+// single-stage reduction of NB already-weighted rows (the sweep kernel's workgroup partials):
+// a block owns 8 consecutive outputs x 32 row-lanes; every thread walks its rows with stride 32,
+// then the 32 partial sums of an output are added in a fixed order through LDS.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restrict__ rows,
+                                                          double *__restrict__ fg, int NB, int Q)
+{
+    __shared__ double s_acc[32][9];
+    const int ql = threadIdx.x & 7, bl = threadIdx.x >> 3;
+    const int q = blockIdx.x * 8 + ql;
+    double acc = 0.0;
+    if (q < Q) {
+        for (int b = bl; b < NB; b += 32)
+            acc += rows[(size_t)b * Q + q];
+    }
+    s_acc[bl][ql] = acc;
+    __syncthreads();
+    if (bl == 0 && q < Q) {
+        double s = s_acc[0][ql];
+#pragma unroll
+        for (int i = 1; i < 32; ++i)
+            s += s_acc[i][ql];
+        fg[q] = s;
+    }
+}
+
+hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, hipStream_t stream)
+{
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((Q + 7) / 8), dim3(256), 0, stream, rows, fg, NB, Q);
+    return hipGetLastError();
+}
+
 int reduce_ksplit(int E)
 {
     // enough blocks to cover the chip (32 q-tiles at C3) without making stage 2 long

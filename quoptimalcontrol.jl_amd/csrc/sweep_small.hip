@@ -78,7 +78,7 @@ enum { MODE_GENERAL = 0, MODE_GENERAL_KEEPL = 1, MODE_UNITARY = 2 };
 
 // sum_ij B[i,j] M[j,i] for the K control operators of this member -> gradient entries
 template <int N, int SAND>
-GRAPE_DEV void write_gradient(double *out, const double2 *opB, int K, const CMat<N> &M, double zr,
+GRAPE_DEV void write_gradient(double *out, const double2 *__restrict__ opB, int K, const CMat<N> &M, double zr,
                               double zi, double gs)
 {
     constexpr int NN = N * N;
@@ -111,8 +111,14 @@ GRAPE_DEV double figure_of_merit(double zr, double zi)
     return zr * zr - zi * zi;                    // Re(z^2), cost_functions.jl:99-101
 }
 
+// ops_all / x_all are separate `const __restrict__` kernel arguments (not members of the
+// parameter struct) so that the compiler can prove them read-only and fetch the wave-uniform
+// operator entries with scalar loads (s_load_dwordx16 -> SGPR operands of v_fma_f64).
 template <int N, int SAND, int MODE, int MAXT>
-__global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
+__global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__restrict__ ops_all,
+                                                           const double *__restrict__ x_all,
+                                                           const double *__restrict__ wts_all,
+                                                           const SweepParams p)
 {
     constexpr int NN = N * N;
     constexpr int MAXW = MAXT / 64;
@@ -120,37 +126,42 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
     constexpr bool KEEPL = (MODE == MODE_GENERAL_KEEPL);
     // One dynamic LDS array (16-byte aligned carve, nothing static in front of it):
     //   s_tot  2*MAXW*NN double2   wave totals of the two scans
-    //   s_ops  (K+3)*NN double2    this member's A, B_1..B_K, Xi, Xt (broadcast reads)
-    //   s_xg   LT*(S*K+1) double   controls x[., t] of this member's slices on the way in, the
-    //                              gradient g[., t] on the way out; lane stride S*K+1 is odd, so
-    //                              the per-lane reads/writes are bank-conflict free
+    //   s_xg   MPB*LT*(S*K+1) double  per member: controls x[., t] of its slices on the way in,
+    //                              the gradient g[., t] on the way out; lane stride S*K+1 is odd,
+    //                              so the per-lane reads/writes are bank-conflict free
+    //   s_F    MPB double          figures of merit of the block's members
+    // A workgroup holds MPB members (W waves each): their weighted results are summed in LDS
+    // before leaving the chip (first level of src/solve.jl:171-191), so the ensemble reduction
+    // that follows reads E/MPB rows instead of E.
     extern __shared__ double2 s_dyn[];
     double2(*s_tot)[MAXW][NN] = reinterpret_cast<double2(*)[MAXW][NN]>(s_dyn);
-    double2 *s_ops = s_dyn + 2 * MAXW * NN;
 
-    const int k = blockIdx.x;
-    const int L = threadIdx.x;
-    const int lane = L & 63, wave = L >> 6;
     const int LT = p.LT, W = LT >> 6;
+    // LT is a multiple of 64, so mb is the same in every lane of a wave: say so, or the
+    // operator loads below stop being scalar loads
+    const int mb = __builtin_amdgcn_readfirstlane(threadIdx.x / LT);   // member within the block
+    const int L = threadIdx.x - mb * LT;             // lane within the member
+    const int lane = L & 63, wave = L >> 6;
+    const int wbase_tot = mb * W;                    // this member's rows of s_tot
+    int k = blockIdx.x * p.MPB + mb;
+    if (k >= p.E)
+        k = p.E - 1;                                 // surplus waves repeat the last member (never stored)
     const int K = p.K, Nsl = p.N, S = p.S;
     const size_t stride = (size_t)LT;
 
-    double *s_xg = reinterpret_cast<double *>(s_ops + (K + 3) * NN);
     const int SK = S * K;
-    {
-        const double2 *__restrict__ gops = p.ops + (size_t)k * (K + 3) * NN;
-        for (int i = L; i < (K + 3) * NN; i += LT)
-            s_ops[i] = gops[i];
-        for (int q = L; q < K * Nsl; q += LT) {
-            const int lq = q / SK;
-            s_xg[lq * (SK + 1) + (q - lq * SK)] = p.x[q];
-        }
-        __syncthreads();
-    }
-    const double2 *ops = s_ops;
-    const double2 *opB = ops + NN;
-    const double2 *opXi = ops + (1 + K) * NN;
-    const double2 *opXt = opXi + NN;
+    double *s_xg_all = reinterpret_cast<double *>(s_dyn + 2 * MAXW * NN);
+    double *s_xg = s_xg_all + (size_t)mb * LT * (SK + 1);
+    double *s_F = s_xg_all + (size_t)p.MPB * LT * (SK + 1);
+    const unsigned magic = p.sk_magic;               // q / SK == __umulhi(q, magic) for q * SK < 2^32
+    auto chunk_of = [&](int q) { return SK == 1 ? q : (int)__umulhi((unsigned)q, magic); };
+    for (int q = L; q < K * Nsl; q += LT)
+        s_xg[q + chunk_of(q)] = x_all[q];            // lq*(SK+1) + (q - lq*SK) = q + lq
+    __syncthreads();
+    const double2 *__restrict__ ops = ops_all + (size_t)k * (K + 3) * NN;
+    const double2 *__restrict__ opB = ops + NN;
+    const double2 *__restrict__ opXi = ops + (size_t)(1 + K) * NN;
+    const double2 *__restrict__ opXt = opXi + NN;
     double *xg = s_xg + L * (SK + 1);            // this lane's x / g slots: [j*K + c]
     const size_t wbase = (size_t)k * S * NN * stride + L;
     double2 *__restrict__ Pw = p.props + wbase;
@@ -221,6 +232,12 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
         }
     }
 
+    // unitary flow: the first propagator the backward sweep needs (the chunk's last slice) is
+    // requested now, so its latency hides under the scan
+    CMat<N> P0;
+    if (UNI)
+        load_ws(P0, Pw + (size_t)(S - 1) * NN * stride, stride);
+
     stamp(st, 1);
     // ---------------------------------------------------------------- phase B
     // General flow: Xs = state at the chunk start, Le = costate at the chunk end.
@@ -249,13 +266,13 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
             if (lane == 63) {
 #pragma unroll
                 for (int e = 0; e < NN; ++e)
-                    s_tot[0][wave][e] = make_double2(inc.re[e], inc.im[e]);
+                    s_tot[0][wbase_tot + wave][e] = make_double2(inc.re[e], inc.im[e]);
             }
             __syncthreads();
             CMat<N> pre, wt;
             set_identity(pre);
             for (int w = 0; w < wave; ++w) {
-                load_uniform(wt, &s_tot[0][w][0]);
+                load_uniform(wt, &s_tot[0][wbase_tot + w][0]);
                 mul(tmp, wt, pre);
                 pre = tmp;
             }
@@ -271,11 +288,11 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
             if (L == LT - 1) {
 #pragma unroll
                 for (int e = 0; e < NN; ++e)
-                    s_tot[1][0][e] = make_double2(inc.re[e], inc.im[e]);
+                    s_tot[1][wbase_tot][e] = make_double2(inc.re[e], inc.im[e]);
             }
             __syncthreads();
             CMat<N> T, C0, xi, xt;
-            load_uniform(T, &s_tot[1][0][0]);
+            load_uniform(T, &s_tot[1][wbase_tot][0]);
             load_uniform(xi, opXi);
             load_uniform(xt, opXt);
             if (SAND) {
@@ -322,13 +339,13 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
             if (lane == 0) {
 #pragma unroll
                 for (int e = 0; e < NN; ++e)
-                    s_tot[1][wave][e] = make_double2(inc.re[e], inc.im[e]);
+                    s_tot[1][wbase_tot + wave][e] = make_double2(inc.re[e], inc.im[e]);
             }
             __syncthreads();
             CMat<N> post;
             set_identity(post);
             for (int w = wave + 1; w < W; ++w) {
-                load_uniform(inc, &s_tot[1][w][0]);
+                load_uniform(inc, &s_tot[1][wbase_tot + w][0]);
                 mul(tmp, inc, post);
                 post = tmp;
             }
@@ -351,7 +368,7 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
         stamp(st, 3);
         // ------------------------------------------------------------ phase D, unitary flow
         CMat<N> M = Xs, tmp;
-        CMat<N> P0, P1;
+        CMat<N> P1;
         // software pipeline: P of slice j-1 is in flight while slice j is processed
         auto step = [&](int j, const CMat<N> &P) {
             const int t = t0 + j;
@@ -370,11 +387,10 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
                 }
                 write_gradient<N, SAND>(xg + j * K, opB, K, M, zr, zi, gs);
                 if (t == Nsl - 1)
-                    out[(size_t)K * Nsl] = figure_of_merit<N, SAND>(zr, zi);
+                    s_F[mb] = figure_of_merit<N, SAND>(zr, zi);
             }
         };
         int j = S - 1;
-        load_ws(P0, Pw + (size_t)j * NN * stride, stride);
         for (; j >= 1; j -= 2) {
             load_ws(P1, Pw + (size_t)(j - 1) * NN * stride, stride);
             step(j, P0);
@@ -437,15 +453,34 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const SweepParams p)
                 }
                 write_gradient<N, SAND>(xg + j * K, opB, K, M, zr, zi, gs);
                 if (t == Nsl - 1)
-                    out[(size_t)K * Nsl] = figure_of_merit<N, SAND>(zr, zi);
+                    s_F[mb] = figure_of_merit<N, SAND>(zr, zi);
             }
         }
     }
-    // gradient: LDS -> HBM, lane-contiguous
+    // results: LDS -> HBM, lane-contiguous.  (1) this member's unweighted row (the reference's
+    // gradient[k,:,:] and F_k: parity/debug accessor), (2) the block's weighted partial sum.
     __syncthreads();
-    for (int q = L; q < K * Nsl; q += LT) {
-        const int lq = q / SK;
-        out[q] = s_xg[lq * (SK + 1) + (q - lq * SK)];
+    const int KN = K * Nsl;
+    if (blockIdx.x * p.MPB + mb < p.E) {
+        for (int q = L; q < KN; q += LT)
+            out[q] = s_xg[q + chunk_of(q)];
+        if (L == 0)
+            out[KN] = s_F[mb];
+    }
+    {
+        const int nmem = min(p.MPB, p.E - (int)blockIdx.x * p.MPB);
+        const double *__restrict__ wb = wts_all + (size_t)blockIdx.x * p.MPB;
+        double *__restrict__ bout = p.block_out + (size_t)blockIdx.x * (KN + 1);
+        const int mstride = LT * (SK + 1);
+        for (int q = threadIdx.x; q <= KN; q += blockDim.x) {
+            const int off = q + chunk_of(q);
+            double acc = 0.0;
+            for (int m = 0; m < nmem; ++m) {
+                const double v = (q < KN) ? s_xg_all[m * mstride + off] : s_F[m];
+                acc = fma(v, wb[m], acc);
+            }
+            bout[q] = acc;
+        }
     }
     stamp(st, 4);
     if (st && lane == 0)
@@ -472,11 +507,11 @@ template <int N, int SAND>
 static hipError_t launch_ns(int mode, const SweepParams &p, hipStream_t stream)
 {
     constexpr int MAXT = SmallTraits<N>::MAXT;
-    const dim3 grid(p.E), block(p.LT);
-    if (p.LT > MAXT || (p.LT & 63) || (long long)p.S * p.LT < p.N)
+    const dim3 grid((p.E + p.MPB - 1) / p.MPB), block(p.LT * p.MPB);
+    if (p.MPB < 1 || p.LT * p.MPB > MAXT || (p.LT & 63) || (long long)p.S * p.LT < p.N)
         return hipErrorInvalidConfiguration;
-    const size_t lds = sizeof(double2) * (2 * (MAXT / 64) * N * N + (size_t)(p.K + 3) * N * N) +
-                       sizeof(double) * (size_t)p.LT * ((size_t)p.S * p.K + 1);
+    const size_t lds = sizeof(double2) * (2 * (MAXT / 64) * N * N) +
+                       sizeof(double) * ((size_t)p.MPB * p.LT * ((size_t)p.S * p.K + 1) + p.MPB);
     if (lds > 160 * 1024)
         return hipErrorInvalidConfiguration;
     if (lds > 64 * 1024) {                       // above the default dynamic-LDS cap: opt in
@@ -489,13 +524,13 @@ static hipError_t launch_ns(int mode, const SweepParams &p, hipStream_t stream)
     }
     switch (mode) {
     case MODE_GENERAL:
-        hipLaunchKernelGGL((sweep_small_kernel<N, SAND, MODE_GENERAL, MAXT>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((sweep_small_kernel<N, SAND, MODE_GENERAL, MAXT>), grid, block, lds, stream, p.ops, p.x, p.wts, p);
         break;
     case MODE_GENERAL_KEEPL:
-        hipLaunchKernelGGL((sweep_small_kernel<N, SAND, MODE_GENERAL_KEEPL, MAXT>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((sweep_small_kernel<N, SAND, MODE_GENERAL_KEEPL, MAXT>), grid, block, lds, stream, p.ops, p.x, p.wts, p);
         break;
     case MODE_UNITARY:
-        hipLaunchKernelGGL((sweep_small_kernel<N, SAND, MODE_UNITARY, MAXT>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((sweep_small_kernel<N, SAND, MODE_UNITARY, MAXT>), grid, block, lds, stream, p.ops, p.x, p.wts, p);
         break;
     default:
         return hipErrorInvalidValue;

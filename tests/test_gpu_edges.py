@@ -1,0 +1,67 @@
+"""GPU: edge shapes of the hot path -- single slice, ragged slice counts around the 64-lane
+chunking, one control / many controls, 3x3 operators, single member, forced decompositions,
+weights that are not normalised -- all against the oracle at the 1e-10 parity bar."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(qoc, n, K, N, E, sys_type, seed):
+    rng = np.random.default_rng(seed)
+
+    def herm():
+        M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        return (M + M.conj().T) / 2
+    A = np.array([herm() for _ in range(E)])
+    B = np.array([[herm() for _ in range(K)] for _ in range(E)]) * 0.5
+    if sys_type == "UnitaryGate":
+        Xi = np.array([np.eye(n, dtype=complex)] * E)
+        Xt = np.array([np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))[0] for _ in range(E)])
+    else:
+        def rho():
+            v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+            v /= np.linalg.norm(v)
+            return np.outer(v, v.conj())
+        Xi = np.array([rho() for _ in range(E)])
+        Xt = np.array([rho() for _ in range(E)])
+    return qoc.workloads.Workload("edge", sys_type, n, K, N, E, 1.3, A, B, Xi, Xt, rng.uniform(0.2, 1.7, E),
+                                  rng.uniform(-1, 1, (K, N)))
+
+
+SHAPES = [  # n, K, N, E, engine kwargs
+    (2, 1, 1, 1, {}), (2, 2, 63, 2, {}), (2, 2, 64, 2, {}), (2, 2, 65, 2, {}), (2, 3, 1000, 1, {}),
+    (2, 2, 1025, 1, {}), (3, 2, 50, 3, {}), (3, 5, 200, 2, {"waves_per_member": 3}), (4, 1, 7, 5, {}),
+    (4, 7, 129, 3, {}), (4, 4, 500, 2, {"waves_per_member": 4}), (4, 2, 300, 2, {"slices_per_lane": 9}),
+    (4, 3, 64, 70, {}),
+]
+
+
+@pytest.mark.parametrize("n,K,N,E,ekw", SHAPES)
+@pytest.mark.parametrize("sys_type", ["UnitaryGate", "StateTransfer"])
+@pytest.mark.parametrize("flow", ["auto", "general"])
+def test_edge_shapes(qoc, oracle, n, K, N, E, ekw, sys_type, flow):
+    w = _problem(qoc, n, K, N, E, sys_type, seed=n * 1000 + K * 100 + N + E)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
+                                                            per_member=True)
+    flags = 0 if flow == "auto" else qoc.engine.FLAG_FORCE_GENERAL
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, flags=flags, **ekw) as eng:
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k}")
+    assert_parity(F, G, F_ref, G_ref, n, what="ensemble")
+
+
+def test_repeated_evaluations_and_new_controls(qoc, oracle):
+    """the context is reused across evaluations like the reference's closure across optimiser steps."""
+    w = qoc.workloads.config("C3", E=8, N=120)
+    rng = np.random.default_rng(3)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        for _ in range(4):
+            x = rng.uniform(-2, 2, w.x.shape)
+            F, G = eng.eval(x)
+            F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, x, w.T)
+            assert_parity(F, G, F_ref, G_ref, w.n)

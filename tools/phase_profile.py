@@ -35,4 +35,10 @@ out = {"config": a.config, "E": w.E, "S": info["slices_per_lane"], "W": info["wa
        "kernel_span_ns": float((st[:, 6].max() - st[:, 5].min()) * 10.0),
        "phases": {n: {"cycles_median": float(np.median(d[:, i])), "share": float(np.median(d[:, i]) / np.median(tot))}
                   for i, n in enumerate(names)}}
+pc = lambda a: [float(np.percentile(a, q)) for q in (0, 10, 50, 90, 100)]
+out["percentiles_0_10_50_90_100"] = {
+    "wave_start_ns_after_first": pc((st[:, 5] - st[:, 5].min()) * 10.0),
+    "wave_end_ns_after_first_start": pc((st[:, 6] - st[:, 5].min()) * 10.0),
+    "wave_real_ns": pc(real), "wave_total_cycles": pc(tot),
+    **{n: pc(d[:, i]) for i, n in enumerate(names)}}
 print(json.dumps(out, indent=1))
