@@ -164,8 +164,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cb, (foms_ref, grads_ref) = cpu_baseline(w, args.cpu_seconds, args.cpu_sample)
             out["cpu_baseline"] = cb
-            foms, grads = sg.local.member_results()
             m = len(foms_ref)
+            ws = w.members(0, m)                       # same members through the HIP path, rows kept
+            with qoc.GrapeEngine(ws.sys_type, ws.A, ws.B, ws.Xi, ws.Xt, ws.wts, ws.T, ws.N, device=local_rank,
+                                 member_results=True) as chk:
+                chk.eval(ws.x)
+                foms, grads = chk.member_results()
             gerr = float(np.abs(grads[:m] - grads_ref).max() / np.abs(grads_ref).max())
             ftol = 1e-10 * np.maximum(np.abs(foms_ref), 1e-3 * w.n * w.n)
             ferr = float((np.abs(foms[:m] - foms_ref) / ftol).max())

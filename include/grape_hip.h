@@ -67,6 +67,10 @@ enum {
     GRAPE_FLAG_PHASE_STAMPS = 1 << 2,   /* diagnostic build of the sweep: every wave stamps the
                                            shader clock at its phase boundaries
                                            (see grape_get_phase_stamps); never for timing runs */
+    GRAPE_FLAG_MEMBER_RESULTS = 1 << 4, /* also leave every member's unweighted (F_k, g_k) in HBM for
+                                           grape_get_member_results (the reference's
+                                           gradient[k,:,:] intermediate); off by default: F and G
+                                           do not need it and it costs E*(K*N+1) doubles of writes */
     GRAPE_FLAG_FORCE_GENERAL = 1 << 3   /* always use the general data flow (forward states stored
                                            in HBM, as the reference does), even when every
                                            generator is Hermitian and the cheaper unitary flow
@@ -143,7 +147,7 @@ int grape_eval(grape_ctx *ctx, const double *x, double *F, double *G);
  * Nothing is synchronised; errors detectable at enqueue time are returned. */
 int grape_eval_device(grape_ctx *ctx, const double *d_x, double *d_fg, void *stream);
 
-/* Debug/parity accessors (valid after an evaluation):
+/* Debug/parity accessors (valid after an evaluation; needs GRAPE_FLAG_MEMBER_RESULTS):
  * per-member unweighted results, as the reference's `gradient[k,:,:]` and the F_k summands:
  *   foms  host f64[E] (nullable)      grads  host f64 (K,N,E) (nullable) */
 int grape_get_member_results(grape_ctx *ctx, double *foms, double *grads);

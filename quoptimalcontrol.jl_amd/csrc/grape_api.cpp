@@ -188,7 +188,8 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     if (e == hipSuccess) e = alloc((void **)&c->d_fg, sizeof(double) * Q);
     if (e == hipSuccess) e = alloc((void **)&c->d_props, sizeof(double2) * c->ws_elems);
     if (e == hipSuccess && keepl) e = alloc((void **)&c->d_costates, sizeof(double2) * c->ws_elems);
-    if (e == hipSuccess) e = alloc((void **)&c->d_member_out, sizeof(double) * E * Q);
+    const bool want_rows = c->family == 1 || (cfg->flags & GRAPE_FLAG_MEMBER_RESULTS);
+    if (e == hipSuccess && want_rows) e = alloc((void **)&c->d_member_out, sizeof(double) * E * Q);
     if (e == hipSuccess) e = alloc((void **)&c->d_partial, sizeof(double) * c->ksplit * Q);
     if (e == hipSuccess && c->family == 0) e = alloc((void **)&c->d_block_out, sizeof(double) * c->NB * Q);
     if (e == hipSuccess && (cfg->flags & GRAPE_FLAG_PHASE_STAMPS))
@@ -400,6 +401,8 @@ extern "C" int grape_get_member_results(grape_ctx *c, double *foms, double *grad
 {
     if (!c) return GRAPE_ERR_INVALID_ARG;
     if (!c->evaluated) return fail(c, GRAPE_ERR_NOT_READY, "grape_get_member_results: no evaluation yet");
+    if (!c->d_member_out)
+        return fail(c, GRAPE_ERR_NOT_READY, "grape_get_member_results: create the context with GRAPE_FLAG_MEMBER_RESULTS");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
     const size_t kn = KN(c), Q = kn + 1, E = c->cfg.n_ensemble;

@@ -20,7 +20,7 @@ struct SweepParams {
     double2 *states;      // X_t (state BEFORE slice t), t = 0..N-1
     double2 *costates;    // L_t (debug only, GRAPE_FLAG_KEEP_COSTATES), same layout
     // outputs
-    double *member_out;   // (K*N + 1) per member: unweighted g_k (K,N col-major), then F_k
+    double *member_out;   // (K*N + 1) per member: unweighted g_k (K,N col-major), then F_k; may be NULL
     const double *wts;    // ensemble weights w_k
     double *block_out;    // (K*N + 1) per workgroup: sum over its members of w_k * [g_k, F_k]
     unsigned long long *stamps;   // diagnostic (NULL in production): kStampSlots per (member, wave)

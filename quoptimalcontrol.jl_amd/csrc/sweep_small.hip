@@ -461,7 +461,7 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__rest
     // gradient[k,:,:] and F_k: parity/debug accessor), (2) the block's weighted partial sum.
     __syncthreads();
     const int KN = K * Nsl;
-    if (blockIdx.x * p.MPB + mb < p.E) {
+    if (p.member_out && blockIdx.x * p.MPB + mb < p.E) {
         for (int q = L; q < KN; q += LT)
             out[q] = s_xg[q + chunk_of(q)];
         if (L == 0)

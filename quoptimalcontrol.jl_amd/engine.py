@@ -23,6 +23,7 @@ FLAG_KEEP_COSTATES = 1
 FLAG_TIME_KERNELS = 2
 FLAG_PHASE_STAMPS = 4
 FLAG_FORCE_GENERAL = 8
+FLAG_MEMBER_RESULTS = 16
 
 STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID_ARG", -2: "GRAPE_ERR_UNSUPPORTED",
           -3: "GRAPE_ERR_NO_DEVICE", -4: "GRAPE_ERR_HIP", -5: "GRAPE_ERR_NOT_READY",
@@ -114,7 +115,7 @@ class GrapeEngine:
     eval(x) -> (F, G) with x, G of shape (K, N) (x[j, i] as in the reference)."""
 
     def __init__(self, sys_type, A, B, Xi, Xt, wts, T, n_slices, variant=0, device=-1, flags=0,
-                 slices_per_lane=0, waves_per_member=0, expm_squarings=-1):
+                 slices_per_lane=0, waves_per_member=0, expm_squarings=-1, member_results=False):
         self._h = None
         self._lib = load_library()
         A = np.asarray(A, dtype=np.complex128)
@@ -130,6 +131,8 @@ class GrapeEngine:
         wts = np.ascontiguousarray(wts, dtype=np.float64)
         if wts.shape != (E,):
             raise ValueError("wts must have one weight per member")
+        if member_results:
+            flags |= FLAG_MEMBER_RESULTS
         code = SYS_TYPE_CODES[sys_type] if isinstance(sys_type, str) else int(sys_type)
         self.sys_type, self.n, self.K, self.N, self.E, self.T = sys_type, n, K, int(n_slices), E, float(T)
         cfg = GrapeConfig(code, int(variant), n, K, int(n_slices), E, float(T), int(device), int(flags),

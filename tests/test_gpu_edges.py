@@ -47,7 +47,7 @@ def test_edge_shapes(qoc, oracle, n, K, N, E, ekw, sys_type, flow):
     F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
                                                             per_member=True)
     flags = 0 if flow == "auto" else qoc.engine.FLAG_FORCE_GENERAL
-    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, flags=flags, **ekw) as eng:
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, flags=flags, member_results=True, **ekw) as eng:
         F, G = eng.eval(w.x)
         foms, grads = eng.member_results()
     for k in range(E):

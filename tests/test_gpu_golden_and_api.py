@@ -19,7 +19,8 @@ tol = 1e-6
 def test_hip_matches_golden(qoc, path, flow):
     c, A, B, Xi, Xt, wts, x, exp, traj = load_case(path)
     flags = 0 if flow == "unitary" else qoc.engine.FLAG_KEEP_COSTATES
-    with qoc.GrapeEngine(c["sys_type"], A, B, Xi, Xt, wts, c["T"], c["N"], variant=c["variant"], flags=flags) as eng:
+    with qoc.GrapeEngine(c["sys_type"], A, B, Xi, Xt, wts, c["T"], c["N"], variant=c["variant"], flags=flags,
+                         member_results=True) as eng:
         F, G = eng.eval(x)
         foms, grads = eng.member_results()
         if flow == "general":
@@ -90,6 +91,11 @@ def test_not_ready_and_bad_shapes(qoc):
     assert b"operators" in lib.grape_last_error(h)
     assert lib.grape_get_member_results(h, None, None) == -5
     assert lib.grape_destroy(h) == 0
+    w0 = qoc.workloads.config("C1")
+    with qoc.GrapeEngine(w0.sys_type, w0.A, w0.B, w0.Xi, w0.Xt, w0.wts, w0.T, w0.N) as eng:
+        eng.eval(w0.x)
+        with pytest.raises(qoc.GrapeError):
+            eng.member_results()                                 # needs FLAG_MEMBER_RESULTS
     w = qoc.workloads.config("C1")
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
         with pytest.raises(ValueError):
@@ -134,7 +140,7 @@ def test_full_size_properties(qoc, oracle):
     """BASELINE size (4x4, K=4, N=500, E=1024): spot members against the oracle, bitwise
     run-to-run reproducibility, and linearity of the ensemble reduction in the weights."""
     w = qoc.workloads.config("C3")
-    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, member_results=True) as eng:
         F, G = eng.eval(w.x)
         foms, grads = eng.member_results()
         F2, G2 = eng.eval(w.x)

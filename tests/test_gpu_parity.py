@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _engine(qoc, w, **kw):
-    return qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, **kw)
+    return qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, member_results=True, **kw)
 
 
 CASES = [

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _engine(qoc, w, **kw):
-    return qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, **kw)
+    return qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, member_results=True, **kw)
 
 
 def _random_problem(qoc, n, K, N, E, sys_type, seed, hermitian=True):
