@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 vector = matrix spec; 72 measured (tools/ubench)
 
 
 def cpu_baseline(workload, seconds, sample_members):
@@ -142,11 +143,22 @@ def main():
                 traffic = json.load(open(tpath)).get(f"{args.config}_E{local.E}")
             except Exception:
                 traffic = None
+        if info.get("kernel_family") == 1:            # n > 4: FP64 matrix-core kernels, compute-bound
+            tf = local.algorithmic_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            roof = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic,
+                    "kernel": "prop_tile_kernel + chain_tile_kernel", "kernel_avg_us": 1e3 * avg_ms,
+                    "kernel_launches": kern_n, "algorithmic_flops_per_launch": local.algorithmic_flops}
+        else:
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "kernel": "sweep_small_kernel", "kernel_avg_us": 1e3 * avg_ms,
+                    "kernel_launches": kern_n, "algorithmic_bytes_per_launch": alg_bytes}
         out = {
             "metric": "GRAPE gradient-evals/sec", "value": value, "unit": "gradient-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64 (ComplexF64)", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {w.sys_type} {w.n}x{w.n}, K={w.K}, N={w.N} slices, "
                                    f"ensemble E={E_total} ({'sharded' if world > 1 else 'one GPU'}, "
                                    f"{local.E} members/GPU), T={w.T}",
@@ -155,10 +167,7 @@ def main():
                        "slices_per_lane": info.get("slices_per_lane"),
                        "waves_per_member": info.get("waves_per_member")},
             "member_evals_per_s": evals_per_s * E_total,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "sweep_small_kernel", "kernel_avg_us": 1e3 * avg_ms,
-                         "kernel_launches": kern_n, "algorithmic_bytes_per_launch": alg_bytes},
+            "roofline": roof,
             "F": float(fg[-1]),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -180,8 +180,44 @@ GRAPE_DEV int squarings_for(double theta)
     return s > 60 ? 60 : s;
 }
 
-// p = exp(g); g is destroyed.  s_forced < 0: choose s from the norm of g.
+// C = G * G for an anti-Hermitian G (G = -i dt H, H Hermitian): the square is Hermitian, so only
+// the upper triangle is computed (diagonal: -sum_k |g_ik|^2, real) and mirrored -- half the FMAs.
 template <int N>
+GRAPE_DEV void square_antihermitian(CMat<N> &c, const CMat<N> &g)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double d = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            d = fma(g.re[i + k * N], g.re[i + k * N], d);
+            d = fma(g.im[i + k * N], g.im[i + k * N], d);
+        }
+        c.re[i + i * N] = -d;
+        c.im[i + i * N] = 0.0;
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) {
+            double sr = 0.0, si = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const double ar = g.re[i + k * N], ai = g.im[i + k * N];
+                const double br = g.re[k + j * N], bi = g.im[k + j * N];
+                sr = fma(ar, br, sr);
+                sr = fma(-ai, bi, sr);
+                si = fma(ar, bi, si);
+                si = fma(ai, br, si);
+            }
+            c.re[i + j * N] = sr;
+            c.im[i + j * N] = si;
+            c.re[j + i * N] = sr;
+            c.im[j + i * N] = -si;
+        }
+    }
+}
+
+// p = exp(g); g is destroyed.  s_forced < 0: choose s from the norm of g.
+// ANTIHERM: g is known to be anti-Hermitian (unitary data flow).
+template <int N, bool ANTIHERM = false>
 GRAPE_DEV void expm_t8(CMat<N> &p, CMat<N> &g, int s_forced)
 {
     const int s = s_forced >= 0 ? s_forced : squarings_for(norm1_bound(g));
@@ -194,7 +230,10 @@ GRAPE_DEV void expm_t8(CMat<N> &p, CMat<N> &g, int s_forced)
         }
     }
     CMat<N> a2, a4, t;
-    mul(a2, g, g);
+    if (ANTIHERM)
+        square_antihermitian(a2, g);
+    else
+        mul(a2, g, g);
 #pragma unroll
     for (int e = 0; e < N * N; ++e) {
         t.re[e] = fma(kX1, g.re[e], kX2 * a2.re[e]);

@@ -229,11 +229,20 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: out of host memory");
     }
     if (c->family == 0) {
-        // per member: [A | B_0..B_{K-1} | Xi | Xt], column-major as given
+        // per member: [A' | B'_0..B'_{K-1} | Xi | Xt], column-major, with the generators already
+        // multiplied by (-i dt): the kernel builds G = -i dt H directly and its gradient traces use
+        // dt Im(tr(B M)) = Re(tr(B' M))
+        const double dt = c->cfg.duration / c->cfg.n_slices;
+        auto scaled = [&](double *dst, const double *src, size_t count) {
+            for (size_t e = 0; e < count; ++e) {
+                dst[2 * e] = dt * src[2 * e + 1];
+                dst[2 * e + 1] = -dt * src[2 * e];
+            }
+        };
         for (size_t k = 0; k < E; ++k) {
             double *dst = packed.data() + 2 * k * (K + 3) * nn;
-            std::memcpy(dst, A + 2 * k * nn, sizeof(double) * 2 * nn);
-            std::memcpy(dst + 2 * nn, B + 2 * k * K * nn, sizeof(double) * 2 * K * nn);
+            scaled(dst, A + 2 * k * nn, nn);
+            scaled(dst + 2 * nn, B + 2 * k * K * nn, K * nn);
             std::memcpy(dst + 2 * (1 + K) * nn, Xi + 2 * k * nn, sizeof(double) * 2 * nn);
             std::memcpy(dst + 2 * (2 + K) * nn, Xt + 2 * k * nn, sizeof(double) * 2 * nn);
         }

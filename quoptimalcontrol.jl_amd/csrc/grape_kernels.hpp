@@ -51,6 +51,7 @@ struct TileParams {
     double *member_out;   // as in SweepParams
     int32_t K, N, E, n;
     int32_t s_forced, variant;
+    int32_t bt_in_lds;    // set by the launcher: the K transposed control operators are cached in LDS
     double dt;
 };
 int tile_count(int n);    // NT for this n (0: not a tile-family size)

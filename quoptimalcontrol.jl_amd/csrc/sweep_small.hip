@@ -95,8 +95,9 @@ GRAPE_DEV void write_gradient(double *out, const double2 *__restrict__ opB, int 
                 wi = fma(b.x, mi, wi);
                 wi = fma(b.y, mr, wi);
             }
-        const double im = SAND ? wi : fma(wr, zi, wi * zr);   // Im(w) | Im(w z)
-        out[c] = gs * im;
+        // opB holds B' = -i dt B, so w' = -i dt w and  dt Im(w) = Re(w'),  dt Im(w z) = Re(w' z)
+        const double re = SAND ? wr : fma(wr, zr, -wi * zi);
+        out[c] = gs * re;
     }
 }
 
@@ -207,13 +208,8 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__rest
                     G.im[e] += a.y;
                 }
             }
-#pragma unroll
-            for (int e = 0; e < NN; ++e) {          // (-i dt) * H
-                const double hr = G.re[e], hi = G.im[e];
-                G.re[e] = dt * hi;
-                G.im[e] = -dt * hr;
-            }
-            expm_t8(P, G, p.s_forced);
+            // (the operators were multiplied by -i dt on the host: this already is G = -i dt H)
+            expm_t8<N, UNI>(P, G, p.s_forced);
             store_ws(Pw + (size_t)j * NN * stride, stride, P);
             mul(Qout, P, Qin);
         } else {
@@ -361,7 +357,7 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__rest
         }
     }
 
-    const double gs = SAND ? -dt : (p.variant == 0 ? -2.0 * dt : 2.0 * dt);
+    const double gs = SAND ? -1.0 : (p.variant == 0 ? -2.0 : 2.0);
 
     if (UNI) {
         stamp(st, 2);

@@ -160,12 +160,23 @@ template <int NT, int SAND, bool KEEPL>
 __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
 {
     constexpr int TSZ = NT * NT * 256;
-    __shared__ double2 s_img[kTileImage];
+    // LDS: the layout-conversion image, then (when it was given room at launch) this member's
+    // K transposed control operators, read K times per slice by the gradient traces
+    extern __shared__ double2 s_dynt[];
+    double2 *s_img = s_dynt;
+    double2 *s_bt = s_dynt + kTileImage + 1;
     const int lane = threadIdx.x;
     const int k = blockIdx.x;
     const int K = p.K, N = p.N;
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
     const double2 *__restrict__ opBT = ops + (size_t)(1 + K) * TSZ;
+    const bool bt_lds = p.bt_in_lds != 0;
+    if (bt_lds) {
+        for (int i = lane; i < K * TSZ; i += 64)
+            s_bt[i] = opBT[i];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
     const double2 *__restrict__ Pk = p.props + (size_t)k * N * TSZ;
     double2 *__restrict__ Xk = p.states + (size_t)k * N * TSZ;
     double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * N + 1);
@@ -174,11 +185,14 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
     {
         TMat<NT> X, Pm, Y;
         TOp<NT> PA;
+        TMat<NT> Pn;
         tload(X, ops + (size_t)(1 + 2 * K) * TSZ, lane);           // Xi
+        tload(Pm, Pk, lane);
         for (int t = 0; t < N; ++t) {
             tstore(Xk + (size_t)t * TSZ, X, lane);
+            if (t + 2 < N)
+                tload(Pn, Pk + (size_t)(t + 1) * TSZ, lane);       // next slice's P in flight
             if (t + 1 < N) {                                       // X_N is never read
-                tload(Pm, Pk + (size_t)t * TSZ, lane);
                 to_a_layout(PA, Pm, s_img, lane);
                 if (SAND) {
                     tmul_tb<NT, false, false>(Y, X, PA);           // (P X)^T
@@ -188,17 +202,22 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
                     X = Y;
                 }
             }
+            Pm = Pn;
         }
     }
 
     // ------------------------------------------------------------ backward sweep + gradient
-    TMat<NT> L, Pm, X, Y, R;
+    TMat<NT> L, Pm, X, Y, R, Pn, Xn;
     TOp<NT> XA, LA;
     tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);               // Xt
     const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
+    tload(Pm, Pk + (size_t)(N - 1) * TSZ, lane);
+    tload(X, Xk + (size_t)(N - 1) * TSZ, lane);
     for (int t = N - 1; t >= 0; --t) {
-        tload(Pm, Pk + (size_t)t * TSZ, lane);
-        tload(X, Xk + (size_t)t * TSZ, lane);
+        if (t > 0) {                                               // next slice's P, X in flight
+            tload(Pn, Pk + (size_t)(t - 1) * TSZ, lane);
+            tload(Xn, Xk + (size_t)(t - 1) * TSZ, lane);
+        }
         if (SAND) {
             tmul_tn<NT, false, true>(Y, L, Pm);                    // (P' L)^T
             tmul_tn<NT, false, false>(L, Y, Pm);                   // P' L P
@@ -228,7 +247,10 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
         }
         for (int c = 0; c < K; ++c) {
             TMat<NT> BT;
-            tload(BT, opBT + (size_t)c * TSZ, lane);
+            if (bt_lds)
+                tload(BT, s_bt + (size_t)c * TSZ, lane);
+            else
+                tload(BT, opBT + (size_t)c * TSZ, lane);
             double wr, wi;
             tdot<NT, false>(wr, wi, BT, R);                        // sum_ij B[i,j] R[j,i]
             const double im = SAND ? wi : fma(wr, zi, wi * zr);
@@ -244,6 +266,8 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
                 out[(size_t)K * N] = zr * zr - zi * zi;
             }
         }
+        Pm = Pn;
+        X = Xn;
     }
 }
 
@@ -257,12 +281,16 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
+    TileParams q = p;
+    const size_t bt_bytes = sizeof(double2) * (size_t)p.K * NT * NT * 256;
+    q.bt_in_lds = bt_bytes <= 36 * 1024 ? 1 : 0;                   // 4 waves per CU must still fit
+    const size_t lds = sizeof(double2) * (kTileImage + 1) + (q.bt_in_lds ? bt_bytes : 0);
     if (sandwich) {
-        if (keepl) hipLaunchKernelGGL((chain_tile_kernel<NT, 1, true>), dim3(p.E), dim3(64), 0, stream, p);
-        else       hipLaunchKernelGGL((chain_tile_kernel<NT, 1, false>), dim3(p.E), dim3(64), 0, stream, p);
+        if (keepl) hipLaunchKernelGGL((chain_tile_kernel<NT, 1, true>), dim3(p.E), dim3(64), lds, stream, q);
+        else       hipLaunchKernelGGL((chain_tile_kernel<NT, 1, false>), dim3(p.E), dim3(64), lds, stream, q);
     } else {
-        if (keepl) hipLaunchKernelGGL((chain_tile_kernel<NT, 0, true>), dim3(p.E), dim3(64), 0, stream, p);
-        else       hipLaunchKernelGGL((chain_tile_kernel<NT, 0, false>), dim3(p.E), dim3(64), 0, stream, p);
+        if (keepl) hipLaunchKernelGGL((chain_tile_kernel<NT, 0, true>), dim3(p.E), dim3(64), lds, stream, q);
+        else       hipLaunchKernelGGL((chain_tile_kernel<NT, 0, false>), dim3(p.E), dim3(64), lds, stream, q);
     }
     return hipGetLastError();
 }
