@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl) and run the all-reduce even with one rank")
     ap.add_argument("--slices-per-lane", type=int, default=0)
     ap.add_argument("--waves-per-member", type=int, default=0)
     args = ap.parse_args()
@@ -90,8 +92,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     base = qoc.workloads.config(args.config)
@@ -99,7 +104,7 @@ def main():
     E_total = E_cfg * (world if args.scaling == "weak" else 1)
     w = qoc.workloads.config(args.config, E=E_total) if E_total != base.E else base
 
-    sg = sharded_engine(w, device, flags=qoc.engine.FLAG_TIME_KERNELS,
+    sg = sharded_engine(w, device, force_collective=args.force_dist, flags=qoc.engine.FLAG_TIME_KERNELS,
                         slices_per_lane=args.slices_per_lane, waves_per_member=args.waves_per_member)
     x_dev = torch.as_tensor(np.ascontiguousarray(w.x.T), device=device)     # (K,N) col-major in HBM
 
@@ -184,11 +189,15 @@ def main():
             ferr = float((np.abs(foms[:m] - foms_ref) / ftol).max())
             out["parity"] = {"members_checked": m, "max_rel_G": gerr, "max_F_err_over_tol": ferr,
                              "tol": 1e-10, "ok": bool(gerr <= 1e-10 and ferr <= 1.0)}
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
 
     sg.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+    if out is not None:                       # the JSON line is the last thing on stdout
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

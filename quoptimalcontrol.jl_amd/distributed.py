@@ -28,12 +28,13 @@ class ShardedGrape:
     make_local(lo, hi) -> object with eval_device(d_x_ptr, d_fg_ptr, stream) for members [lo, hi)
     (or None when the shard is empty).  `device` is a torch.device."""
 
-    def __init__(self, E, K, N, make_local, device, group=None):
+    def __init__(self, E, K, N, make_local, device, group=None, force_collective=False):
         import torch
         import torch.distributed as dist
 
         self.torch, self.dist = torch, dist
         self.group = group
+        self.force_collective = force_collective      # run the all-reduce even with one rank (testing)
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
@@ -52,7 +53,7 @@ class ShardedGrape:
             self.local.eval_device(x_dev.data_ptr(), self.fg.data_ptr(), stream)
         else:
             self.fg.zero_()
-        if self.world > 1:
+        if self.world > 1 or self.force_collective:
             self.dist.all_reduce(self.fg, op=self.dist.ReduceOp.SUM, group=self.group)
         return self.fg
 
@@ -72,7 +73,7 @@ class ShardedGrape:
             self.local = None
 
 
-def sharded_engine(workload, device, group=None, **engine_kw):
+def sharded_engine(workload, device, group=None, force_collective=False, **engine_kw):
     """The product wiring: every rank builds a GrapeEngine for its block of `workload`."""
     from .engine import GrapeEngine
 
@@ -83,4 +84,4 @@ def sharded_engine(workload, device, group=None, **engine_kw):
         return GrapeEngine(w.sys_type, w.A[lo:hi], w.B[lo:hi], w.Xi[lo:hi], w.Xt[lo:hi], w.wts[lo:hi],
                            w.T, w.N, device=dev_index, **engine_kw)
 
-    return ShardedGrape(w.E, w.K, w.N, make_local, device, group)
+    return ShardedGrape(w.E, w.K, w.N, make_local, device, group, force_collective)
