@@ -320,8 +320,15 @@ static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream)
     p.s_forced = c->cfg.expm_squarings;
     p.variant = c->cfg.variant;
     p.dt = c->cfg.duration / c->cfg.n_slices;
-    HIP_TRY(c, grape::launch_sweep_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, c->d_costates != nullptr,
-                                        p, stream));
+    // default: the v_mfma_f64_16x16x4 kernels (sweep_tile.hip).  GRAPE_TILE_MFMA4=1 selects the
+    // v_mfma_f64_4x4x4_4b variant (sweep_tile4.hip): correct, but measured 15-50 % slower so far.
+    static const bool mfma4 = std::getenv("GRAPE_TILE_MFMA4") != nullptr;
+    if (!mfma4)
+        HIP_TRY(c, grape::launch_sweep_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE,
+                                            c->d_costates != nullptr, p, stream));
+    else
+        HIP_TRY(c, grape::launch_sweep_tile4(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE,
+                                             c->d_costates != nullptr, p, stream));
     return GRAPE_OK;
 }
 

@@ -56,6 +56,8 @@ struct TileParams {
 };
 int tile_count(int n);    // NT for this n (0: not a tile-family size)
 hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
+// same contract on v_mfma_f64_4x4x4_4b (sweep_tile4.hip): the default for the tile family
+hipError_t launch_sweep_tile4(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
 
 // G[q] = sum_k w_k member_out[k][q]  for q in [0, Q)  (Q = K*N + 1; the last entry is F).
 // partial: scratch of ksplit*Q doubles.  Deterministic (fixed summation tree).

@@ -227,8 +227,6 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
         }
         if (KEEPL)
             tstore(p.costates + ((size_t)k * N + t) * TSZ, L, lane);
-        double zr, zi;
-        tdot<NT, true>(zr, zi, X, L);                              // tr(X' L)
         // R = X L' : A layout of X, B layout of L' = conj(A layout of L)
         to_a_layout(XA, X, s_img, lane);
         to_a_layout(LA, L, s_img, lane);
@@ -245,17 +243,37 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
                     R.im[I][J] -= Y.im[I][J];
                 }
         }
-        for (int c = 0; c < K; ++c) {
-            TMat<NT> BT;
-            if (bt_lds)
-                tload(BT, s_bt + (size_t)c * TSZ, lane);
-            else
-                tload(BT, opBT + (size_t)c * TSZ, lane);
-            double wr, wi;
-            tdot<NT, false>(wr, wi, BT, R);                        // sum_ij B[i,j] R[j,i]
-            const double im = SAND ? wi : fma(wr, zi, wi * zr);
-            if (lane == 0)
-                out[c + (size_t)t * K] = gs * im;
+        // all cross-lane sums of this slice are taken together (wave_sum_n): tr(X' L) and, per
+        // control, sum R .* B^T
+        double zr = 0.0, zi = 0.0;
+        for (int c0 = 0; c0 < K; c0 += 4) {
+            double v[2 + 8];
+            tdot_partial<NT, true>(v[0], v[1], X, L);              // tr(X' L)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int c = c0 + cc;
+                v[2 + 2 * cc] = 0.0;
+                v[3 + 2 * cc] = 0.0;
+                if (c < K) {
+                    TMat<NT> BT;
+                    if (bt_lds)
+                        tload(BT, s_bt + (size_t)c * TSZ, lane);
+                    else
+                        tload(BT, opBT + (size_t)c * TSZ, lane);
+                    tdot_partial<NT, false>(v[2 + 2 * cc], v[3 + 2 * cc], BT, R);   // sum_ij B[i,j] R[j,i]
+                }
+            }
+            wave_sum_n(v);
+            zr = v[0];
+            zi = v[1];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int c = c0 + cc;
+                const double wr = v[2 + 2 * cc], wi = v[3 + 2 * cc];
+                const double im = SAND ? wi : fma(wr, zi, wi * zr);
+                if (c < K && lane == 0)
+                    out[c + (size_t)t * K] = gs * im;
+            }
         }
         if (t == N - 1 && lane == 0) {
             if (SAND) {

@@ -171,6 +171,44 @@ GRAPE_DEV double wave_sum(double v)
     return v;
 }
 
+// butterfly sum of M independent values at once: the M shuffle/add chains interleave, so the
+// ~100-cycle latency of each cross-lane step is paid once per step instead of once per value
+template <int M>
+GRAPE_DEV void wave_sum_n(double (&v)[M])
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        double o[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+            o[m] = __shfl_xor(v[m], d, 64);
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+            v[m] += o[m];
+    }
+}
+
+// per-lane partial of sum over all elements of conj?(A) .* B (no cross-lane step)
+template <int NT, bool CONJ_A>
+GRAPE_DEV void tdot_partial(double &sr, double &si, const TMat<NT> &a, const TMat<NT> &b)
+{
+    sr = 0.0;
+    si = 0.0;
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double ar = a.re[I][J][r], ai = CONJ_A ? -a.im[I][J][r] : a.im[I][J][r];
+                const double br = b.re[I][J][r], bi = b.im[I][J][r];
+                sr = fma(ar, br, sr);
+                sr = fma(-ai, bi, sr);
+                si = fma(ar, bi, si);
+                si = fma(ai, br, si);
+            }
+}
+
 GRAPE_DEV double wave_max(double v)
 {
 #pragma unroll

@@ -12,9 +12,10 @@ for f in glob.glob(os.path.join(sys.argv[1], "pass*", "**", "*counter_collection
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "?")
-            k = "sweep" if "sweep" in k else ("reduce1" if "stage1" in k else ("reduce2" if "stage2" in k else None))
-            if k is None:
+            if "grape::" not in k:
                 continue
+            k = k.split("grape::")[1].split("(")[0].split("<")[0]
+            k = {"sweep_small_kernel": "sweep", "reduce_stage1": "reduce1", "reduce_stage2": "reduce2"}.get(k, k)
             out[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {k: {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in cs.items()} for k, cs in out.items()}
 print(json.dumps(res, indent=1))
