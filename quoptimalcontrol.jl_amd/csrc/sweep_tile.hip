@@ -25,29 +25,45 @@
 namespace grape {
 
 // ---------------------------------------------------------------------------------------------
+// slices per workgroup: for NT = 1 the member's K+1 generator tiles are staged in LDS once per
+// workgroup and every wave walks kPropSlices/4 slices with them (read from L2 once per 64 slices
+// instead of once per slice -- the kernel was L2-bandwidth bound: 24 KB of operators per 4 KB of P)
+constexpr int kPropSlices = 64;
+
 template <int NT>
 __global__ __launch_bounds__(256) void prop_tile_kernel(const TileParams p)
 {
     constexpr int TSZ = NT * NT * 256;                     // double2 per matrix dump
-    __shared__ double2 s_img[4][kTileImage];
+    constexpr bool STAGE = (NT == 1);
+    extern __shared__ double2 s_prop[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = blockIdx.y;
-    const int t = blockIdx.x * 4 + wave;
-    if (t >= p.N)
-        return;
     const int K = p.K;
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;   // [A | B_c | B_c^T | Xi | Xt]
-    double2 *img = s_img[wave];
-
+    double2 *img = s_prop + (size_t)wave * kTileImage;
+    double2 *s_ops = s_prop + 4 * kTileImage;              // STAGE: [A | B_1..B_K]
+    if (STAGE) {
+        for (int i = threadIdx.x; i < (K + 1) * TSZ; i += 256)
+            s_ops[i] = ops[i];
+        __syncthreads();
+    }
+    const int t_lo = blockIdx.x * (STAGE ? kPropSlices : 4);
+    const int t_hi = min(p.N, t_lo + (STAGE ? kPropSlices : 4));
+  for (int t = t_lo + wave; t < t_hi; t += 4) {
     TMat<NT> G;
     if (p.variant == 0)
         tzero(G);
+    else if (STAGE)
+        tload(G, s_ops, lane);
     else
         tload(G, ops, lane);
     for (int c = 0; c < K; ++c) {
         const double xv = p.x[c + (size_t)t * K];
         TMat<NT> B;
-        tload(B, ops + (size_t)(1 + c) * TSZ, lane);
+        if (STAGE)
+            tload(B, s_ops + (size_t)(1 + c) * TSZ, lane);
+        else
+            tload(B, ops + (size_t)(1 + c) * TSZ, lane);
 #pragma unroll
         for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -60,7 +76,10 @@ __global__ __launch_bounds__(256) void prop_tile_kernel(const TileParams p)
     }
     if (p.variant == 0) {
         TMat<NT> A;
-        tload(A, ops, lane);
+        if (STAGE)
+            tload(A, s_ops, lane);
+        else
+            tload(A, ops, lane);
 #pragma unroll
         for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -153,6 +172,7 @@ __global__ __launch_bounds__(256) void prop_tile_kernel(const TileParams p)
         P = T;
     }
     tstore(p.props + ((size_t)k * p.N + t) * TSZ, P, lane);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -295,7 +315,15 @@ int tile_count(int n) { return n <= 4 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : 0)); }
 template <int NT>
 static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipStream_t stream)
 {
-    hipLaunchKernelGGL(prop_tile_kernel<NT>, dim3((p.N + 3) / 4, p.E), dim3(256), 0, stream, p);
+    {
+        const bool stage = (NT == 1);
+        const int per_block = stage ? kPropSlices : 4;
+        const size_t lds = sizeof(double2) * (4 * (size_t)kTileImage + (stage ? (size_t)(p.K + 1) * NT * NT * 256 : 0));
+        if (lds > 64 * 1024)
+            return hipErrorInvalidConfiguration;           // K > 14 at n <= 16: not supported by this build
+        hipLaunchKernelGGL(prop_tile_kernel<NT>, dim3((p.N + per_block - 1) / per_block, p.E), dim3(256), lds,
+                           stream, p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
