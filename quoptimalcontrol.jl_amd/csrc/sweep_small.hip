@@ -181,34 +181,42 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__rest
     // product never needs a register copy (Qout = P * Qin).
     CMat<N> Q, Q2;
     set_identity(Q);
-    auto slice = [&](int j, const CMat<N> &Qin, CMat<N> &Qout) {
-        const int t = t0 + j;
-        if (t < Nsl) {
-            CMat<N> G, P;
-            if (p.variant == 0) {
+    // generators of TWO consecutive slices are assembled in one pass over the member's operators:
+    // every scalar-loaded operator entry feeds both slices, halving the scalar-load round trips
+    auto build2 = [&](int j, int j1, CMat<N> &G0, CMat<N> &G1) {
+        if (p.variant == 0) {
 #pragma unroll
-                for (int e = 0; e < NN; ++e) { G.re[e] = 0.0; G.im[e] = 0.0; }
-            } else {
-                load_uniform(G, ops);
-            }
-            for (int c = 0; c < K; ++c) {
-                const double xv = xg[j * K + c];
+            for (int e = 0; e < NN; ++e) { G0.re[e] = 0.0; G0.im[e] = 0.0; G1.re[e] = 0.0; G1.im[e] = 0.0; }
+        } else {
+            load_uniform(G0, ops);
+            G1 = G0;
+        }
+        for (int c = 0; c < K; ++c) {
+            const double x0 = xg[j * K + c], x1 = xg[j1 * K + c];
 #pragma unroll
-                for (int e = 0; e < NN; ++e) {
-                    const double2 b = opB[c * NN + e];
-                    G.re[e] = fma(b.x, xv, G.re[e]);
-                    G.im[e] = fma(b.y, xv, G.im[e]);
-                }
+            for (int e = 0; e < NN; ++e) {
+                const double2 b = opB[c * NN + e];
+                G0.re[e] = fma(b.x, x0, G0.re[e]);
+                G0.im[e] = fma(b.y, x0, G0.im[e]);
+                G1.re[e] = fma(b.x, x1, G1.re[e]);
+                G1.im[e] = fma(b.y, x1, G1.im[e]);
             }
-            if (p.variant == 0) {
+        }
+        if (p.variant == 0) {
 #pragma unroll
-                for (int e = 0; e < NN; ++e) {
-                    const double2 a = ops[e];
-                    G.re[e] += a.x;
-                    G.im[e] += a.y;
-                }
+            for (int e = 0; e < NN; ++e) {
+                const double2 a = ops[e];
+                G0.re[e] += a.x;
+                G0.im[e] += a.y;
+                G1.re[e] += a.x;
+                G1.im[e] += a.y;
             }
-            // (the operators were multiplied by -i dt on the host: this already is G = -i dt H)
+        }
+    };
+    // (the operators were multiplied by -i dt on the host: G already is -i dt H)
+    auto finish = [&](int j, CMat<N> &G, const CMat<N> &Qin, CMat<N> &Qout) {
+        if (t0 + j < Nsl) {
+            CMat<N> P;
             expm_t8<N, UNI>(P, G, p.s_forced);
             store_ws(Pw + (size_t)j * NN * stride, stride, P);
             mul(Qout, P, Qin);
@@ -217,13 +225,16 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__rest
         }
     };
     {
+        CMat<N> G0, G1;
         int j = 0;
         for (; j + 1 < S; j += 2) {
-            slice(j, Q, Q2);
-            slice(j + 1, Q2, Q);
+            build2(j, j + 1, G0, G1);
+            finish(j, G0, Q, Q2);
+            finish(j + 1, G1, Q2, Q);
         }
-        if (j < S) {
-            slice(j, Q, Q2);
+        if (j < S) {                                // odd S: the last slice alone
+            build2(j, j, G0, G1);
+            finish(j, G0, Q, Q2);
             Q = Q2;
         }
     }
