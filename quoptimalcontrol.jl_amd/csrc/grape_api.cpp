@@ -49,7 +49,9 @@ struct grape_ctx {
     double *d_partial = nullptr;
     unsigned long long *d_stamps = nullptr;
     // host
-    double *h_stage = nullptr;    // pinned, K*N + 1 doubles (x in, fg out)
+    double *h_stage = nullptr;    // pinned, K*N + 1 doubles: x on the way in
+    double *h_fg = nullptr;       // pinned + device-mapped, K*N + 1 doubles: the reduce kernel writes [G, F] here
+    double *d_h_fg = nullptr;     // device address of h_fg
     hipStream_t stream = nullptr;
     bool ops_set = false, evaluated = false;
     bool unitary = false;         // all generators Hermitian -> unitary data flow
@@ -88,6 +90,7 @@ static void free_all(grape_ctx *c)
     (void)hipFree(c->d_props); (void)hipFree(c->d_states); (void)hipFree(c->d_costates);
     (void)hipFree(c->d_member_out); (void)hipFree(c->d_partial); (void)hipFree(c->d_stamps); (void)hipFree(c->d_block_out);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_fg) (void)hipHostFree(c->h_fg);
     delete c;
 }
 
@@ -167,6 +170,10 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: n_controls^2 * n_slices^2 too large for the LDS index arithmetic");
     }
     c->MPB = (c->family == 0 && W <= 4) ? 4 / W : 1;         // fill the 4 SIMDs of a CU per workgroup
+    if (const char *ev = std::getenv("GRAPE_MPB")) {           // tuning experiment: members per workgroup
+        const int v = std::atoi(ev);
+        if (c->family == 0 && v >= 1 && v * W <= wmax) c->MPB = v;
+    }
     if (c->MPB > E) c->MPB = E;
     c->NB = (E + c->MPB - 1) / c->MPB;
     c->ksplit = grape::reduce_ksplit(E);
@@ -195,6 +202,8 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     if (e == hipSuccess && (cfg->flags & GRAPE_FLAG_PHASE_STAMPS))
         e = alloc((void **)&c->d_stamps, sizeof(unsigned long long) * E * W * grape::kStampSlots);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, sizeof(double) * Q, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_fg, sizeof(double) * Q, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->d_h_fg, c->h_fg, 0);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         std::string msg = std::string("grape_create: device allocation failed: ") + hipGetErrorString(e);
@@ -404,12 +413,18 @@ extern "C" int grape_eval(grape_ctx *c, const double *x, double *F, double *G)
     const size_t kn = KN(c);
     std::memcpy(c->h_stage, x, sizeof(double) * kn);
     HIP_TRY(c, hipMemcpyAsync(c->d_x, c->h_stage, sizeof(double) * kn, hipMemcpyHostToDevice, c->stream));
-    int rc = enqueue_eval(c, c->d_x, c->d_fg, c->stream);
+    // the final reduce kernel writes its 16 KB result straight into mapped pinned host memory (no
+    // D2H copy node), and the host polls the stream instead of sleeping on an interrupt: the
+    // optimiser is sequential, so per-call latency is what the Julia side sees
+    int rc = enqueue_eval(c, c->d_x, c->d_h_fg, c->stream);
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_fg, sizeof(double) * (kn + 1), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (G) std::memcpy(G, c->h_stage, sizeof(double) * kn);
-    if (F) *F = c->h_stage[kn];
+    for (;;) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) HIP_TRY(c, q);
+    }
+    if (G) std::memcpy(G, c->h_fg, sizeof(double) * kn);
+    if (F) *F = c->h_fg[kn];
     return GRAPE_OK;
 }
 
