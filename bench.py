@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl) and run the all-reduce even with one rank")
+    ap.add_argument("--force-general", action="store_true",
+                    help="use the general data flow (forward states stored) even for Hermitian generators")
     ap.add_argument("--slices-per-lane", type=int, default=0)
     ap.add_argument("--waves-per-member", type=int, default=0)
     args = ap.parse_args()
@@ -104,7 +106,8 @@ def main():
     E_total = E_cfg * (world if args.scaling == "weak" else 1)
     w = qoc.workloads.config(args.config, E=E_total) if E_total != base.E else base
 
-    sg = sharded_engine(w, device, force_collective=args.force_dist, flags=qoc.engine.FLAG_TIME_KERNELS,
+    sg = sharded_engine(w, device, force_collective=args.force_dist,
+                        flags=qoc.engine.FLAG_TIME_KERNELS | (qoc.engine.FLAG_FORCE_GENERAL if args.force_general else 0),
                         slices_per_lane=args.slices_per_lane, waves_per_member=args.waves_per_member)
     x_dev = torch.as_tensor(np.ascontiguousarray(w.x.T), device=device)     # (K,N) col-major in HBM
 

@@ -489,10 +489,10 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
     if (costates && !c->d_costates)
         return fail(c, GRAPE_ERR_NOT_READY,
                     "grape_get_trajectory: costates need GRAPE_FLAG_KEEP_COSTATES at grape_create");
-    if (states && c->unitary)
+    if (states && c->family == 0 && !c->d_costates)
         return fail(c, GRAPE_ERR_NOT_READY,
-                    "grape_get_trajectory: the unitary flow stores no forward states; create the context "
-                    "with GRAPE_FLAG_FORCE_GENERAL or GRAPE_FLAG_KEEP_COSTATES");
+                    "grape_get_trajectory: forward states are stored only by the debug flow; create the "
+                    "context with GRAPE_FLAG_KEEP_COSTATES");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
     const int n = c->cfg.n;

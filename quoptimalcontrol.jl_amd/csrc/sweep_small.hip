@@ -16,9 +16,14 @@
 //            src/grape_tools.jl:66-68), so one product per slice serves all K controls.
 //
 // Two data flows share phases A and B:
-//   MODE_GENERAL (any generator, e.g. non-Hermitian Liouvillians): exactly the reference's
-//     flow -- X_t stored forward, L_t pulled back, M_t = X_t L_t' per slice.  HBM traffic =
-//     "model S" of BASELINE.md: P_t and X_t make one round trip (64 n^2 N bytes per member).
+//   MODE_GENERAL (any generator, e.g. non-Hermitian Liouvillians): the reference's flow -- forward
+//     states X_t, costates L_t pulled back, M_t = X_t L_t' per slice -- with one change of
+//     bookkeeping: phase A also stores the running in-chunk product Q_j = P_j ... P_first, and the
+//     backward sweep rebuilds X_t = Q_{j-1} Xs [Q_{j-1}'] from it, so there is no separate forward
+//     sweep (no phase C) and P_t is read once instead of twice.  HBM traffic = "model S" of
+//     two matrices per slice make one round trip (64 n^2 N bytes per member).
+//   MODE_GENERAL_KEEPL (debug, GRAPE_FLAG_KEEP_COSTATES): the literal reference flow with the
+//     forward sweep (phase C) storing X_t and every L_t stored, for grape_get_trajectory.
 //   MODE_UNITARY (every A_k, B_jk Hermitian, checked on the host, so every P_t is unitary):
 //     M_t = X_t L_t' (UnitaryGate) or [X_t, L_t'] (State/CoherenceTransfer) obeys
 //     M_t = P_t' M_{t+1} P_t, so the backward sweep carries ONE matrix, no forward state is
@@ -220,6 +225,8 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__rest
             expm_t8<N, UNI>(P, G, p.s_forced);
             store_ws(Pw + (size_t)j * NN * stride, stride, P);
             mul(Qout, P, Qin);
+            if (MODE == MODE_GENERAL)                // in-chunk prefix product, read back in phase D
+                store_ws(Xw + (size_t)j * NN * stride, stride, Qout);
         } else {
             Qout = Qin;
         }
@@ -409,8 +416,8 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__rest
             step(0, P0);
     } else {
         stamp(st, 2);
-        // ------------------------------------------------------------ phase C
-        {
+        // ------------------------------------------------------------ phase C (debug flow only)
+        if (KEEPL) {
             CMat<N> X = Xs, P, tmp;
             for (int j = 0; j < S; ++j) {
                 const int t = t0 + j;
@@ -437,13 +444,29 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__rest
             const int t = t0 + j;
             if (t < Nsl) {
                 load_ws(P, Pw + (size_t)j * NN * stride, stride);
-                load_ws(X, Xw + (size_t)j * NN * stride, stride);
+                if (KEEPL) {
+                    load_ws(X, Xw + (size_t)j * NN * stride, stride);
+                } else if (j > 0) {
+                    load_ws(M, Xw + (size_t)(j - 1) * NN * stride, stride);   // Q_{j-1}
+                }
                 if (SAND) {
                     mul(tmp, Lc, P);
                     mul_ah_b(Lc, P, tmp);
                 } else {
                     mul_ah_b(tmp, P, Lc);
                     Lc = tmp;
+                }
+                if (!KEEPL) {                        // X_t = Q_{j-1} Xs [Q_{j-1}'] ; X at the chunk start is Xs
+                    if (j > 0) {
+                        if (SAND) {
+                            mul(tmp, M, Xs);
+                            mul_a_bh(X, tmp, M);
+                        } else {
+                            mul(X, M, Xs);
+                        }
+                    } else {
+                        X = Xs;
+                    }
                 }
                 if (KEEPL)
                     store_ws(p.costates + wbase + (size_t)j * NN * stride, stride, Lc);

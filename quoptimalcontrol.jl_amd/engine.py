@@ -76,7 +76,10 @@ def load_library():
         return _LIB
     path = library_path()
     if not os.path.exists(path):
-        raise GrapeError(-3, f"{path} not built (run __graft_entry__.build())")
+        try:                                   # a fresh checkout: build in-tree once (hipcc, gfx950)
+            build_library()
+        except Exception as exc:               # no hipcc / build failure: fail loudly, no fallback
+            raise GrapeError(-3, f"{path} is not built and building it failed: {exc}") from exc
     L = C.CDLL(path)
     vp, dp, i32 = C.c_void_p, C.POINTER(C.c_double), C.c_int32
     L.grape_abi_version.restype = C.c_int

@@ -16,9 +16,10 @@ ap.add_argument("--config", default="C3")
 ap.add_argument("--ensemble", type=int, default=0)
 ap.add_argument("--slices-per-lane", type=int, default=0)
 ap.add_argument("--waves-per-member", type=int, default=0)
+ap.add_argument("--force-general", action="store_true")
 a = ap.parse_args()
 w = qoc.workloads.config(a.config, E=a.ensemble or None)
-with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, flags=qoc.engine.FLAG_PHASE_STAMPS,
+with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, flags=qoc.engine.FLAG_PHASE_STAMPS | (qoc.engine.FLAG_FORCE_GENERAL if a.force_general else 0),
                      slices_per_lane=a.slices_per_lane, waves_per_member=a.waves_per_member) as eng:
     for _ in range(3):
         eng.eval(w.x)
