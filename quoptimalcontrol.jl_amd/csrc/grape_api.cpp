@@ -36,6 +36,7 @@ struct grape_ctx {
     int S = 0, W = 0, LT = 0;
     int MPB = 1, NB = 0;          // small family: members per workgroup, number of workgroups
     double *d_block_out = nullptr;
+    double *d_xg_scratch = nullptr;   // only when K*N is too long for the LDS staging buffer
     int ksplit = 1;
     size_t ws_elems = 0;          // double2 elements per workspace array
     uint64_t bytes = 0;
@@ -88,7 +89,7 @@ static void free_all(grape_ctx *c)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     (void)hipFree(c->d_ops); (void)hipFree(c->d_wts); (void)hipFree(c->d_x); (void)hipFree(c->d_fg);
     (void)hipFree(c->d_props); (void)hipFree(c->d_states); (void)hipFree(c->d_costates);
-    (void)hipFree(c->d_member_out); (void)hipFree(c->d_partial); (void)hipFree(c->d_stamps); (void)hipFree(c->d_block_out);
+    (void)hipFree(c->d_member_out); (void)hipFree(c->d_partial); (void)hipFree(c->d_stamps); (void)hipFree(c->d_block_out); (void)hipFree(c->d_xg_scratch);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_fg) (void)hipHostFree(c->h_fg);
     delete c;
@@ -175,6 +176,13 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
         if (c->family == 0 && v >= 1 && v * W <= wmax) c->MPB = v;
     }
     if (c->MPB > E) c->MPB = E;
+    bool xg_in_lds = true;
+    if (c->family == 0) {                                    // fit the x/g staging buffer into LDS
+        const size_t cap = 150 * 1024;
+        while (c->MPB > 1 && grape::sweep_small_lds_bytes(cfg->n, c->MPB, c->LT, S, cfg->n_controls, true) > cap)
+            c->MPB /= 2;
+        xg_in_lds = grape::sweep_small_lds_bytes(cfg->n, c->MPB, c->LT, S, cfg->n_controls, true) <= cap;
+    }
     c->NB = (E + c->MPB - 1) / c->MPB;
     c->ksplit = grape::reduce_ksplit(E);
 
@@ -199,6 +207,9 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     if (e == hipSuccess && want_rows) e = alloc((void **)&c->d_member_out, sizeof(double) * E * Q);
     if (e == hipSuccess) e = alloc((void **)&c->d_partial, sizeof(double) * c->ksplit * Q);
     if (e == hipSuccess && c->family == 0) e = alloc((void **)&c->d_block_out, sizeof(double) * c->NB * Q);
+    if (e == hipSuccess && c->family == 0 && !xg_in_lds)
+        e = alloc((void **)&c->d_xg_scratch,
+                  sizeof(double) * c->NB * ((size_t)c->MPB * c->LT * ((size_t)S * K + 1) + c->MPB));
     if (e == hipSuccess && (cfg->flags & GRAPE_FLAG_PHASE_STAMPS))
         e = alloc((void **)&c->d_stamps, sizeof(unsigned long long) * E * W * grape::kStampSlots);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, sizeof(double) * Q, hipHostMallocDefault);
@@ -355,6 +366,7 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     p.MPB = c->MPB;
     p.sk_magic = (uint32_t)((1ull << 32) / ((uint64_t)c->S * c->cfg.n_controls)) + 1u;
     p.stamps = c->d_stamps;
+    p.xg_scratch = c->d_xg_scratch;
     p.K = c->cfg.n_controls;
     p.N = c->cfg.n_slices;
     p.E = c->cfg.n_ensemble;

@@ -24,6 +24,7 @@ struct SweepParams {
     const double *wts;    // ensemble weights w_k
     double *block_out;    // (K*N + 1) per workgroup: sum over its members of w_k * [g_k, F_k]
     unsigned long long *stamps;   // diagnostic (NULL in production): kStampSlots per (member, wave)
+    double *xg_scratch;   // NULL: controls/gradient staged in LDS; else per-workgroup global scratch
     int32_t K, N, E;
     int32_t S;            // slices per lane
     int32_t LT;           // lanes per member = 64 * W
@@ -39,6 +40,8 @@ struct SweepParams {
 // generators Hermitian).  Returns hipSuccess or the launch error.  n must be 2, 3 or 4.
 hipError_t launch_sweep_small(int n, int sandwich, int mode, const SweepParams &p, hipStream_t stream);
 int sweep_small_max_waves(int n);   // W limit of the register-resident kernel for this n
+// dynamic LDS a workgroup of the small-n sweep needs for this decomposition
+size_t sweep_small_lds_bytes(int n, int MPB, int LT, int S, int K, bool xg_in_lds);
 
 // ---- tile (MFMA) family, n = 5..32, zero-padded to 16*NT ------------------------------------
 // All matrices are "D-layout dumps" (tile.hpp): (16 NT)^2 double2 each, TSZ = NT*NT*256.

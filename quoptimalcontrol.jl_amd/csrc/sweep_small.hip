@@ -120,7 +120,9 @@ GRAPE_DEV double figure_of_merit(double zr, double zi)
 // ops_all / x_all are separate `const __restrict__` kernel arguments (not members of the
 // parameter struct) so that the compiler can prove them read-only and fetch the wave-uniform
 // operator entries with scalar loads (s_load_dwordx16 -> SGPR operands of v_fma_f64).
-template <int N, int SAND, int MODE, int MAXT>
+// XGLDS: the controls/gradient staging buffer lives in LDS (normal case); false: it lives in a
+// global scratch buffer (very long pulses, where K*N doubles per member no longer fit in LDS).
+template <int N, int SAND, int MODE, int MAXT, bool XGLDS>
 __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__restrict__ ops_all,
                                                            const double *__restrict__ x_all,
                                                            const double *__restrict__ wts_all,
@@ -156,7 +158,8 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__rest
     const size_t stride = (size_t)LT;
 
     const int SK = S * K;
-    double *s_xg_all = reinterpret_cast<double *>(s_dyn + 2 * MAXW * NN);
+    double *s_xg_all = XGLDS ? reinterpret_cast<double *>(s_dyn + 2 * MAXW * NN)
+                             : p.xg_scratch + (size_t)blockIdx.x * ((size_t)p.MPB * LT * (SK + 1) + p.MPB);
     double *s_xg = s_xg_all + (size_t)mb * LT * (SK + 1);
     double *s_F = s_xg_all + (size_t)p.MPB * LT * (SK + 1);
     const unsigned magic = p.sk_magic;               // q / SK == __umulhi(q, magic) for q * SK < 2^32
@@ -533,39 +536,51 @@ int sweep_small_max_waves(int n)
     }
 }
 
+size_t sweep_small_lds_bytes(int n, int MPB, int LT, int S, int K, bool xg_in_lds)
+{
+    const int maxt = n == 2 ? SmallTraits<2>::MAXT : (n == 3 ? SmallTraits<3>::MAXT : SmallTraits<4>::MAXT);
+    size_t b = sizeof(double2) * (2 * (size_t)(maxt / 64) * n * n);
+    if (xg_in_lds)
+        b += sizeof(double) * ((size_t)MPB * LT * ((size_t)S * K + 1) + MPB);
+    return b;
+}
+
+template <int N, int SAND, int MODE, bool XGLDS>
+static hipError_t launch_one(const SweepParams &p, hipStream_t stream)
+{
+    constexpr int MAXT = SmallTraits<N>::MAXT;
+    const dim3 grid((p.E + p.MPB - 1) / p.MPB), block(p.LT * p.MPB);
+    const size_t lds = sweep_small_lds_bytes(N, p.MPB, p.LT, p.S, p.K, XGLDS);
+    if (lds > 160 * 1024)
+        return hipErrorInvalidConfiguration;
+    auto kern = sweep_small_kernel<N, SAND, MODE, MAXT, XGLDS>;
+    if (lds > 64 * 1024) {                       // above the default dynamic-LDS cap: opt in
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, p.ops, p.x, p.wts, p);
+    return hipGetLastError();
+}
+
 template <int N, int SAND>
 static hipError_t launch_ns(int mode, const SweepParams &p, hipStream_t stream)
 {
     constexpr int MAXT = SmallTraits<N>::MAXT;
-    const dim3 grid((p.E + p.MPB - 1) / p.MPB), block(p.LT * p.MPB);
     if (p.MPB < 1 || p.LT * p.MPB > MAXT || (p.LT & 63) || (long long)p.S * p.LT < p.N)
         return hipErrorInvalidConfiguration;
-    const size_t lds = sizeof(double2) * (2 * (MAXT / 64) * N * N) +
-                       sizeof(double) * ((size_t)p.MPB * p.LT * ((size_t)p.S * p.K + 1) + p.MPB);
-    if (lds > 160 * 1024)
-        return hipErrorInvalidConfiguration;
-    if (lds > 64 * 1024) {                       // above the default dynamic-LDS cap: opt in
-        const void *fn = mode == MODE_GENERAL ? (const void *)sweep_small_kernel<N, SAND, MODE_GENERAL, MAXT>
-                       : mode == MODE_GENERAL_KEEPL ? (const void *)sweep_small_kernel<N, SAND, MODE_GENERAL_KEEPL, MAXT>
-                                                    : (const void *)sweep_small_kernel<N, SAND, MODE_UNITARY, MAXT>;
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
-    }
+    const bool lds = p.xg_scratch == nullptr;
     switch (mode) {
     case MODE_GENERAL:
-        hipLaunchKernelGGL((sweep_small_kernel<N, SAND, MODE_GENERAL, MAXT>), grid, block, lds, stream, p.ops, p.x, p.wts, p);
-        break;
+        return lds ? launch_one<N, SAND, MODE_GENERAL, true>(p, stream) : launch_one<N, SAND, MODE_GENERAL, false>(p, stream);
     case MODE_GENERAL_KEEPL:
-        hipLaunchKernelGGL((sweep_small_kernel<N, SAND, MODE_GENERAL_KEEPL, MAXT>), grid, block, lds, stream, p.ops, p.x, p.wts, p);
-        break;
+        return lds ? launch_one<N, SAND, MODE_GENERAL_KEEPL, true>(p, stream)
+                   : launch_one<N, SAND, MODE_GENERAL_KEEPL, false>(p, stream);
     case MODE_UNITARY:
-        hipLaunchKernelGGL((sweep_small_kernel<N, SAND, MODE_UNITARY, MAXT>), grid, block, lds, stream, p.ops, p.x, p.wts, p);
-        break;
+        return lds ? launch_one<N, SAND, MODE_UNITARY, true>(p, stream) : launch_one<N, SAND, MODE_UNITARY, false>(p, stream);
     default:
         return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 hipError_t launch_sweep_small(int n, int sandwich, int mode, const SweepParams &p, hipStream_t stream)

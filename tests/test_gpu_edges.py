@@ -36,6 +36,9 @@ SHAPES = [  # n, K, N, E, engine kwargs
     (2, 2, 1025, 1, {}), (3, 2, 50, 3, {}), (3, 5, 200, 2, {"waves_per_member": 3}), (4, 1, 7, 5, {}),
     (4, 7, 129, 3, {}), (4, 4, 500, 2, {"waves_per_member": 4}), (4, 2, 300, 2, {"slices_per_lane": 9}),
     (4, 3, 64, 70, {}),
+    # long pulses: the LDS staging buffer of controls/gradient no longer fits 4 members (fewer
+    # members per workgroup), then not even one (global-scratch fallback)
+    (4, 4, 1500, 8, {"waves_per_member": 1}), (2, 2, 20000, 1, {}), (4, 3, 9000, 2, {"waves_per_member": 1}),
 ]
 
 
