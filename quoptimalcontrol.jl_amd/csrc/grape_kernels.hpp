@@ -55,6 +55,7 @@ struct TileParams {
     int32_t K, N, E, n;
     int32_t s_forced, variant;
     int32_t bt_in_lds;    // set by the launcher: the K transposed control operators are cached in LDS
+    int32_t stage_ops;    // set by the launcher: prop kernel stages the generators in LDS
     double dt;
 };
 int tile_count(int n);    // NT for this n (0: not a tile-family size)

@@ -34,7 +34,7 @@ template <int NT>
 __global__ __launch_bounds__(256) void prop_tile_kernel(const TileParams p)
 {
     constexpr int TSZ = NT * NT * 256;                     // double2 per matrix dump
-    constexpr bool STAGE = (NT == 1);
+    const bool STAGE = (NT == 1) && p.stage_ops;           // set by the launcher when the tiles fit in LDS
     extern __shared__ double2 s_prop[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = blockIdx.y;
@@ -316,13 +316,14 @@ template <int NT>
 static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipStream_t stream)
 {
     {
-        const bool stage = (NT == 1);
-        const int per_block = stage ? kPropSlices : 4;
-        const size_t lds = sizeof(double2) * (4 * (size_t)kTileImage + (stage ? (size_t)(p.K + 1) * NT * NT * 256 : 0));
-        if (lds > 64 * 1024)
-            return hipErrorInvalidConfiguration;           // K > 14 at n <= 16: not supported by this build
+        TileParams q = p;
+        const size_t ops_bytes = sizeof(double2) * (size_t)(p.K + 1) * NT * NT * 256;
+        const size_t img_bytes = sizeof(double2) * 4 * (size_t)kTileImage;
+        q.stage_ops = (NT == 1 && img_bytes + ops_bytes <= 64 * 1024) ? 1 : 0;
+        const int per_block = q.stage_ops ? kPropSlices : 4;
+        const size_t lds = img_bytes + (q.stage_ops ? ops_bytes : 0);
         hipLaunchKernelGGL(prop_tile_kernel<NT>, dim3((p.N + per_block - 1) / per_block, p.E), dim3(256), lds,
-                           stream, p);
+                           stream, q);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)

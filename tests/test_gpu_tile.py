@@ -59,6 +59,16 @@ def test_tile_family_random(qoc, oracle, n, sys_type, herm, variant):
     assert_parity(F, G, F_ref, G_ref, w.n, what=f"n={n}")
 
 
+def test_many_controls(qoc, oracle):
+    """K = 17 controls at n = 12: neither the generator tiles nor the transposed operators fit
+    their LDS caches, so both kernels take their global-memory paths."""
+    w = _random_problem(qoc, 12, 17, 9, 2, "StateTransfer", seed=5)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    with _engine(qoc, w) as eng:
+        F, G = eng.eval(w.x)
+    assert_parity(F, G, F_ref, G_ref, w.n, what="K=17")
+
+
 def test_c4_liouvillian_parity(qoc, oracle):
     """BASELINE config 4 at parity size: 16x16 Liouvillian superoperators, CoherenceTransfer, K=4, N=1000."""
     w = qoc.workloads.config("C4", E=6)
