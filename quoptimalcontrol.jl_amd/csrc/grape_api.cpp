@@ -295,7 +295,8 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     }
     // Data-flow choice: if every generator is Hermitian to rounding, every propagator is
     // unitary and the sweep can carry M_t = P_t' M_{t+1} P_t instead of storing X_t.
-    bool herm = c->family == 0 && !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES));
+    bool herm = !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) &&
+                !(c->family == 1 && std::getenv("GRAPE_TILE_MFMA4"));     // the 4x4x4 experiment has no unitary flow
     const int n = c->cfg.n;
     for (size_t k = 0; k < E && herm; ++k) {
         for (size_t m = 0; m < K + 1 && herm; ++m) {
@@ -340,6 +341,7 @@ static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream)
     p.s_forced = c->cfg.expm_squarings;
     p.variant = c->cfg.variant;
     p.dt = c->cfg.duration / c->cfg.n_slices;
+    p.unitary = c->unitary ? 1 : 0;
     // default: the v_mfma_f64_16x16x4 kernels (sweep_tile.hip).  GRAPE_TILE_MFMA4=1 selects the
     // v_mfma_f64_4x4x4_4b variant (sweep_tile4.hip): correct, but measured 15-50 % slower so far.
     static const bool mfma4 = std::getenv("GRAPE_TILE_MFMA4") != nullptr;
@@ -501,7 +503,7 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
     if (costates && !c->d_costates)
         return fail(c, GRAPE_ERR_NOT_READY,
                     "grape_get_trajectory: costates need GRAPE_FLAG_KEEP_COSTATES at grape_create");
-    if (states && c->family == 0 && !c->d_costates)
+    if (states && !c->d_costates && (c->family == 0 || c->unitary))
         return fail(c, GRAPE_ERR_NOT_READY,
                     "grape_get_trajectory: forward states are stored only by the debug flow; create the "
                     "context with GRAPE_FLAG_KEEP_COSTATES");

@@ -56,6 +56,7 @@ struct TileParams {
     int32_t s_forced, variant;
     int32_t bt_in_lds;    // set by the launcher: the K transposed control operators are cached in LDS
     int32_t stage_ops;    // set by the launcher: prop kernel stages the generators in LDS
+    int32_t unitary;      // every generator Hermitian: chain kernel carries M_t = P' M P, no stored states
     double dt;
 };
 int tile_count(int n);    // NT for this n (0: not a tile-family size)

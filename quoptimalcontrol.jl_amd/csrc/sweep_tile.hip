@@ -310,6 +310,152 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Unitary flow (every generator Hermitian, so every P_t is unitary; same idea as sweep_small.hip):
+// the gradient matrix M_t = X_t L_t' (UnitaryGate) or [X_t, L_t'] (sandwich) obeys
+// M_t = P_t' M_{t+1} P_t, so no forward state is stored or re-read.  The forward pass only
+// accumulates X_N = P_{N-1} ... P_0 Xi (UnitaryGate) or the total product T (sandwich:
+// X_N = T Xi T'), 1 product per slice; the backward pass carries M with 2 products per slice.
+// tr(X_t' L_t) is conj(tr M_t) (UnitaryGate) or t-invariant (sandwich, taken at t = N).
+template <int NT, int SAND>
+__global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams p)
+{
+    constexpr int TSZ = NT * NT * 256;
+    extern __shared__ double2 s_dynt[];
+    double2 *s_img = s_dynt;
+    double2 *s_bt = s_dynt + kTileImage + 1;
+    const int lane = threadIdx.x;
+    const int k = blockIdx.x;
+    const int K = p.K, N = p.N;
+    const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
+    const double2 *__restrict__ opBT = ops + (size_t)(1 + K) * TSZ;
+    const bool bt_lds = p.bt_in_lds != 0;
+    if (bt_lds) {
+        for (int i = lane; i < K * TSZ; i += 64)
+            s_bt[i] = opBT[i];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+    const double2 *__restrict__ Pk = p.props + (size_t)k * N * TSZ;
+    double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * N + 1);
+
+    TMat<NT> M, L, Y, Pm, Pn;
+    double zr = 0.0, zi = 0.0;
+    // ------------------------------------------------------------ forward: X_N (or T)
+    {
+        TMat<NT> X;
+        TOp<NT> PA;
+        if (SAND) {                                                // T starts as the identity
+            tzero(X);
+#pragma unroll
+            for (int I = 0; I < NT; ++I)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * r + (lane >> 4) == (lane & 15))
+                        X.re[I][I][r] = 1.0;
+        } else {
+            tload(X, ops + (size_t)(1 + 2 * K) * TSZ, lane);       // Xi
+        }
+        tload(Pm, Pk, lane);
+        for (int t = 0; t < N; ++t) {
+            if (t + 1 < N)
+                tload(Pn, Pk + (size_t)(t + 1) * TSZ, lane);       // next slice's P in flight
+            to_a_layout(PA, Pm, s_img, lane);
+            tmul_an<NT, false, false>(Y, PA, X);                   // P X
+            X = Y;
+            Pm = Pn;
+        }
+        if (SAND) {                                                // X_N = T Xi T'
+            TMat<NT> Xi;
+            tload(Xi, ops + (size_t)(1 + 2 * K) * TSZ, lane);
+            to_a_layout(PA, X, s_img, lane);
+            tmul_tb<NT, false, false>(Y, Xi, PA);                  // (T Xi)^T
+            tmul_tb<NT, false, true>(X, Y, PA);                    // (T Xi) T'
+        }
+        tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);           // L_N = Xt
+        // M_N = X_N L_N'  [ - L_N' X_N ]
+        TOp<NT> XA, LA;
+        to_a_layout(XA, X, s_img, lane);
+        to_a_layout(LA, L, s_img, lane);
+        tprod<NT, false, true>(
+            M, [&](int I, int Kt, int kb, double &r, double &i) { r = XA.re[I][Kt][kb]; i = XA.im[I][Kt][kb]; },
+            [&](int Kt, int J, int kb, double &r, double &i) { r = LA.re[J][Kt][kb]; i = LA.im[J][Kt][kb]; });
+        if (SAND) {
+            tmul_tn<NT, true, false>(Y, L, X);                     // L' X
+#pragma unroll
+            for (int I = 0; I < NT; ++I)
+#pragma unroll
+                for (int J = 0; J < NT; ++J) {
+                    M.re[I][J] -= Y.re[I][J];
+                    M.im[I][J] -= Y.im[I][J];
+                }
+            tdot<NT, true>(zr, zi, X, L);                          // tr(X' L), the same for every t
+        }
+    }
+
+    // ------------------------------------------------------------ backward: M_t = P_t' M_{t+1} P_t
+    const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
+    tload(Pm, Pk + (size_t)(N - 1) * TSZ, lane);
+    for (int t = N - 1; t >= 0; --t) {
+        if (t > 0)
+            tload(Pn, Pk + (size_t)(t - 1) * TSZ, lane);
+        tmul_tn<NT, false, true>(Y, M, Pm);                        // (P' M)^T
+        tmul_tn<NT, false, false>(M, Y, Pm);                       // P' M P
+        for (int c0 = 0; c0 < K; c0 += 4) {
+            double v[2 + 8];
+            v[0] = 0.0;
+            v[1] = 0.0;
+            if (!SAND) {                                           // tr(M): z_t = conj(tr M_t)
+#pragma unroll
+                for (int I = 0; I < NT; ++I)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * r + (lane >> 4) == (lane & 15)) {
+                            v[0] += M.re[I][I][r];
+                            v[1] += M.im[I][I][r];
+                        }
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int c = c0 + cc;
+                v[2 + 2 * cc] = 0.0;
+                v[3 + 2 * cc] = 0.0;
+                if (c < K) {
+                    TMat<NT> BT;
+                    if (bt_lds)
+                        tload(BT, s_bt + (size_t)c * TSZ, lane);
+                    else
+                        tload(BT, opBT + (size_t)c * TSZ, lane);
+                    tdot_partial<NT, false>(v[2 + 2 * cc], v[3 + 2 * cc], BT, M);   // sum_ij B[i,j] M[j,i]
+                }
+            }
+            wave_sum_n(v);
+            if (!SAND) {
+                zr = v[0];
+                zi = -v[1];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int c = c0 + cc;
+                const double wr = v[2 + 2 * cc], wi = v[3 + 2 * cc];
+                const double im = SAND ? wi : fma(wr, zi, wi * zr);
+                if (c < K && lane == 0)
+                    out[c + (size_t)t * K] = gs * im;
+            }
+        }
+        if (t == N - 1 && lane == 0) {
+            if (SAND) {
+                const double inv = 1.0 / (double)p.n;
+                const double ar = zr * inv, ai = zi * inv;
+                out[(size_t)K * N] = 1.0 - (ar * ar + ai * ai);
+            } else {
+                out[(size_t)K * N] = zr * zr - zi * zi;
+            }
+        }
+        Pm = Pn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 int tile_count(int n) { return n <= 4 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : 0)); }
 
 template <int NT>
@@ -332,7 +478,10 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     const size_t bt_bytes = sizeof(double2) * (size_t)p.K * NT * NT * 256;
     q.bt_in_lds = bt_bytes <= 36 * 1024 ? 1 : 0;                   // 4 waves per CU must still fit
     const size_t lds = sizeof(double2) * (kTileImage + 1) + (q.bt_in_lds ? bt_bytes : 0);
-    if (sandwich) {
+    if (p.unitary && !keepl) {
+        if (sandwich) hipLaunchKernelGGL((chain_tile_unitary_kernel<NT, 1>), dim3(p.E), dim3(64), lds, stream, q);
+        else          hipLaunchKernelGGL((chain_tile_unitary_kernel<NT, 0>), dim3(p.E), dim3(64), lds, stream, q);
+    } else if (sandwich) {
         if (keepl) hipLaunchKernelGGL((chain_tile_kernel<NT, 1, true>), dim3(p.E), dim3(64), lds, stream, q);
         else       hipLaunchKernelGGL((chain_tile_kernel<NT, 1, false>), dim3(p.E), dim3(64), lds, stream, q);
     } else {

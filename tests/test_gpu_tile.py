@@ -59,6 +59,26 @@ def test_tile_family_random(qoc, oracle, n, sys_type, herm, variant):
     assert_parity(F, G, F_ref, G_ref, w.n, what=f"n={n}")
 
 
+@pytest.mark.parametrize("n,sys_type", [(6, "UnitaryGate"), (8, "StateTransfer"), (16, "UnitaryGate"),
+                                        (16, "StateTransfer"), (23, "StateTransfer"), (32, "UnitaryGate"),
+                                        (32, "StateTransfer")])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_tile_family_unitary_flow(qoc, oracle, n, sys_type, variant):
+    """Hermitian generators: the chain kernel carries M_t = P' M P and stores no forward states."""
+    w = _random_problem(qoc, n, 3, 14, 3, sys_type, seed=300 + n, hermitian=True)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
+                                                            variant=variant, per_member=True)
+    with _engine(qoc, w, variant=variant) as eng:
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+        assert eng.info["kernel_family"] == 1 and eng.info["unitary_flow"] == 1
+        with pytest.raises(qoc.GrapeError):
+            eng.trajectory(0)                               # no stored states in this flow
+    for k in range(w.E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], w.n, what=f"n={n} member {k}")
+    assert_parity(F, G, F_ref, G_ref, w.n, what=f"n={n}")
+
+
 def test_many_controls(qoc, oracle):
     """K = 17 controls at n = 12: neither the generator tiles nor the transposed operators fit
     their LDS caches, so both kernels take their global-memory paths."""
