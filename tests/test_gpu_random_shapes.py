@@ -1,0 +1,44 @@
+"""GPU: seeded random sweep over shapes, decompositions, system types, variants and data flows of
+the small-operator kernels against the oracle (1e-10 parity bar)."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+from test_gpu_edges import _problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        n = int(rng.choice([2, 3, 4]))
+        K = int(rng.integers(1, 7))
+        N = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 100, 129, 257, 300, 511]))
+        E = int(rng.choice([1, 2, 3, 5, 8, 13, 33]))
+        wmax = {2: 16, 3: 8, 4: 4}[n]
+        ekw = {}
+        if rng.random() < 0.5:
+            ekw["waves_per_member"] = int(rng.integers(1, wmax + 1))
+        if rng.random() < 0.3:
+            ekw["slices_per_lane"] = int(rng.integers(1, 12))
+        out.append((i, n, K, N, E, str(rng.choice(["UnitaryGate", "StateTransfer", "CoherenceTransfer"])),
+                    int(rng.integers(0, 2)), str(rng.choice(["auto", "general", "debug"])), ekw))
+    return out
+
+
+@pytest.mark.parametrize("i,n,K,N,E,sys_type,variant,flow,ekw", _cases(60, 2026))
+def test_random_shape(qoc, oracle, i, n, K, N, E, sys_type, variant, flow, ekw):
+    w = _problem(qoc, n, K, N, E, "UnitaryGate" if sys_type == "UnitaryGate" else "StateTransfer", seed=9000 + i)
+    w.sys_type = sys_type
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
+                                                            variant=variant, per_member=True)
+    flags = {"auto": 0, "general": qoc.engine.FLAG_FORCE_GENERAL, "debug": qoc.engine.FLAG_KEEP_COSTATES}[flow]
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, variant=variant, flags=flags,
+                         member_results=True, **ekw) as eng:
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"case {i} member {k}")
+    assert_parity(F, G, F_ref, G_ref, n, what=f"case {i}")
