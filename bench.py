@@ -49,11 +49,25 @@ def cpu_baseline(workload, seconds, sample_members):
         if el >= seconds:
             break
     member_evals_per_s = n * w.E / el
+    # B2 of BASELINE.md: the same port with OpenMP over members on every host core (bounded, ~1/3 of the time)
+    cores = os.cpu_count() or 1
+    wide = workload.members(0, min(max(sample_members, 16 * cores), workload.E))
+    wargs = (wide.sys_type, wide.A, wide.B, wide.Xi, wide.Xt, wide.wts, wide.x, wide.T)
+    grape_oracle.ensemble_eval(*wargs, n_threads=cores)
+    n2, t1 = 0, time.perf_counter()
+    while True:
+        grape_oracle.ensemble_eval(*wargs, n_threads=cores)
+        n2 += 1
+        el2 = time.perf_counter() - t1
+        if el2 >= seconds / 3:
+            break
     return {
         "value": member_evals_per_s / workload.E, "unit": "gradient-evals/s", "cores": 1, "kind": "port",
         "sample": f"{n} x {w.E} of {workload.E} members, {el:.1f} s of oracle/grape_oracle.c (serial, like the "
                   f"reference's member loop); scaled by members",
         "member_evals_per_s": member_evals_per_s,
+        "all_cores": {"value": n2 * wide.E / el2 / workload.E, "cores": cores,
+                      "sample": f"{n2} x {wide.E} members, OpenMP over members"},
     }, (foms, grads)
 
 
