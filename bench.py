@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for plumbing tests)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl) and run the all-reduce even with one rank")
     ap.add_argument("--force-general", action="store_true",
@@ -106,14 +107,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()      # (> 1 rank per GPU only in plumbing tests)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     base = qoc.workloads.config(args.config)
     E_cfg = args.ensemble or base.E
@@ -197,7 +202,7 @@ def main():
             out["cpu_baseline"] = cb
             m = len(foms_ref)
             ws = w.members(0, m)                       # same members through the HIP path, rows kept
-            with qoc.GrapeEngine(ws.sys_type, ws.A, ws.B, ws.Xi, ws.Xt, ws.wts, ws.T, ws.N, device=local_rank,
+            with qoc.GrapeEngine(ws.sys_type, ws.A, ws.B, ws.Xi, ws.Xt, ws.wts, ws.T, ws.N, device=dev_index,
                                  member_results=True) as chk:
                 chk.eval(ws.x)
                 foms, grads = chk.member_results()
