@@ -33,6 +33,8 @@ struct grape_ctx {
     int family = 0;               // 0: register-resident small-n kernels, 1: MFMA tile kernels
     int NT = 0;                   // tile family: tiles per dimension (padded n = 16 NT)
     size_t TSZ = 0;               // tile family: double2 per matrix dump
+    bool pack2 = false;           // tile family, n <= 8: two members per 16x16 tile (block diagonal)
+    int EU = 0;                   // tile family: wavefront-level units = members, or member pairs when pack2
     int S = 0, W = 0, LT = 0;
     int MPB = 1, NB = 0;          // small family: members per workgroup, number of workgroups
     double *d_block_out = nullptr;
@@ -153,6 +155,8 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     c->family = wmax > 0 ? 0 : 1;
     c->NT = nt;
     c->TSZ = (size_t)nt * nt * 256;
+    c->pack2 = (c->family == 1 && cfg->n <= 8 && !std::getenv("GRAPE_TILE_NOPACK") && !std::getenv("GRAPE_TILE_MFMA4"));
+    c->EU = c->pack2 ? (E + 1) / 2 : E;
     int W = cfg->waves_per_member;
     if (W <= 0) {
         const long simds = 4L * c->compute_units;
@@ -188,8 +192,8 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
 
     const size_t nn = (size_t)cfg->n * cfg->n, K = cfg->n_controls;
     const size_t Q = KN(c) + 1;
-    c->ws_elems = c->family == 0 ? (size_t)E * S * nn * c->LT : (size_t)E * N * c->TSZ;
-    const size_t ops_elems = c->family == 0 ? (size_t)E * (K + 3) * nn : (size_t)E * (2 * K + 3) * c->TSZ;
+    c->ws_elems = c->family == 0 ? (size_t)E * S * nn * c->LT : (size_t)c->EU * N * c->TSZ;
+    const size_t ops_elems = c->family == 0 ? (size_t)E * (K + 3) * nn : (size_t)c->EU * (2 * K + 3) * c->TSZ;
     const bool keepl = (cfg->flags & GRAPE_FLAG_KEEP_COSTATES) != 0;
 
     auto alloc = [&](void **p, size_t bytes) -> hipError_t {
@@ -244,7 +248,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     const size_t nn = (size_t)c->cfg.n * c->cfg.n, K = c->cfg.n_controls, E = c->cfg.n_ensemble;
     std::vector<double> packed;
     try {
-        packed.assign(c->family == 0 ? 2 * E * (K + 3) * nn : 2 * E * (2 * K + 3) * c->TSZ, 0.0);
+        packed.assign(c->family == 0 ? 2 * E * (K + 3) * nn : 2 * (size_t)c->EU * (2 * K + 3) * c->TSZ, 0.0);
     } catch (...) {
         return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: out of host memory");
     }
@@ -269,13 +273,14 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     } else {
         // per member: [A | B_c | B_c^T | Xi | Xt] as zero-padded D-layout dumps (tile.hpp)
         const int nd = c->cfg.n, NT = c->NT;
-        auto dump = [&](double *dst, const double *M, bool transpose) {
+        // off: 0, or 8 for the second member of a block-diagonal pair (pack2, n <= 8)
+        auto dump = [&](double *dst, const double *M, bool transpose, int off) {
             for (int I = 0; I < NT; ++I)
                 for (int J = 0; J < NT; ++J)
                     for (int r = 0; r < 4; ++r)
                         for (int l = 0; l < 64; ++l) {
-                            int row = 16 * I + 4 * r + (l >> 4), col = 16 * J + (l & 15);
-                            if (row >= nd || col >= nd) continue;
+                            int row = 16 * I + 4 * r + (l >> 4) - off, col = 16 * J + (l & 15) - off;
+                            if (row < 0 || col < 0 || row >= nd || col >= nd) continue;
                             if (transpose) std::swap(row, col);
                             const size_t o = 2 * ((size_t)((I * NT + J) * 4 + r) * 64 + l);
                             dst[o] = M[2 * (row + (size_t)nd * col)];
@@ -283,14 +288,16 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                         }
         };
         for (size_t k = 0; k < E; ++k) {
-            double *dst = packed.data() + 2 * k * (2 * K + 3) * c->TSZ;
-            dump(dst, A + 2 * k * nn, false);
+            const size_t unit = c->pack2 ? k / 2 : k;
+            const int off = c->pack2 ? 8 * (int)(k & 1) : 0;
+            double *dst = packed.data() + 2 * unit * (2 * K + 3) * c->TSZ;
+            dump(dst, A + 2 * k * nn, false, off);
             for (size_t j = 0; j < K; ++j) {
-                dump(dst + 2 * (1 + j) * c->TSZ, B + 2 * (k * K + j) * nn, false);
-                dump(dst + 2 * (1 + K + j) * c->TSZ, B + 2 * (k * K + j) * nn, true);
+                dump(dst + 2 * (1 + j) * c->TSZ, B + 2 * (k * K + j) * nn, false, off);
+                dump(dst + 2 * (1 + K + j) * c->TSZ, B + 2 * (k * K + j) * nn, true, off);
             }
-            dump(dst + 2 * (1 + 2 * K) * c->TSZ, Xi + 2 * k * nn, false);
-            dump(dst + 2 * (2 + 2 * K) * c->TSZ, Xt + 2 * k * nn, false);
+            dump(dst + 2 * (1 + 2 * K) * c->TSZ, Xi + 2 * k * nn, false, off);
+            dump(dst + 2 * (2 + 2 * K) * c->TSZ, Xt + 2 * k * nn, false, off);
         }
     }
     // Data-flow choice: if every generator is Hermitian to rounding, every propagator is
@@ -336,7 +343,9 @@ static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream)
     p.member_out = c->d_member_out;
     p.K = c->cfg.n_controls;
     p.N = c->cfg.n_slices;
-    p.E = c->cfg.n_ensemble;
+    p.E = c->EU;
+    p.E_members = c->cfg.n_ensemble;
+    p.pack2 = c->pack2 ? 1 : 0;
     p.n = c->cfg.n;
     p.s_forced = c->cfg.expm_squarings;
     p.variant = c->cfg.variant;
@@ -466,16 +475,17 @@ static int fetch_slab(grape_ctx *c, const double2 *d_ws, int member, cplx *out)
     if (c->family == 1) {
         const size_t N = c->cfg.n_slices, TSZ = c->TSZ;
         const int n = c->cfg.n, NT = c->NT;
+        const int unit = c->pack2 ? member / 2 : member, off = c->pack2 ? 8 * (member & 1) : 0;
         std::vector<cplx> h(N * TSZ);
-        HIP_TRY(c, hipMemcpy(h.data(), d_ws + (size_t)member * N * TSZ, sizeof(cplx) * h.size(),
+        HIP_TRY(c, hipMemcpy(h.data(), d_ws + (size_t)unit * N * TSZ, sizeof(cplx) * h.size(),
                              hipMemcpyDeviceToHost));
         for (size_t t = 0; t < N; ++t)
             for (int I = 0; I < NT; ++I)
                 for (int J = 0; J < NT; ++J)
                     for (int r = 0; r < 4; ++r)
                         for (int l = 0; l < 64; ++l) {
-                            const int row = 16 * I + 4 * r + (l >> 4), col = 16 * J + (l & 15);
-                            if (row < n && col < n)
+                            const int row = 16 * I + 4 * r + (l >> 4) - off, col = 16 * J + (l & 15) - off;
+                            if (row >= 0 && col >= 0 && row < n && col < n)
                                 out[t * n * n + row + (size_t)n * col] =
                                     h[t * TSZ + (size_t)((I * NT + J) * 4 + r) * 64 + l];
                         }
@@ -549,14 +559,15 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
                                  sizeof(cplx) * nn, hipMemcpyDeviceToHost));
         } else {
             std::vector<cplx> h(c->TSZ);
-            HIP_TRY(c, hipMemcpy(h.data(), c->d_ops + ((size_t)member * (2 * K + 3) + 2 * K + 2) * c->TSZ,
+            const int unit = c->pack2 ? member / 2 : member, off = c->pack2 ? 8 * (member & 1) : 0;
+            HIP_TRY(c, hipMemcpy(h.data(), c->d_ops + ((size_t)unit * (2 * K + 3) + 2 * K + 2) * c->TSZ,
                                  sizeof(cplx) * c->TSZ, hipMemcpyDeviceToHost));
             for (int I = 0; I < c->NT; ++I)
                 for (int J = 0; J < c->NT; ++J)
                     for (int r = 0; r < 4; ++r)
                         for (int l = 0; l < 64; ++l) {
-                            const int row = 16 * I + 4 * r + (l >> 4), col = 16 * J + (l & 15);
-                            if (row < n && col < n)
+                            const int row = 16 * I + 4 * r + (l >> 4) - off, col = 16 * J + (l & 15) - off;
+                            if (row >= 0 && col >= 0 && row < n && col < n)
                                 Lc[N * nn + row + (size_t)n * col] = h[(size_t)((I * c->NT + J) * 4 + r) * 64 + l];
                         }
         }

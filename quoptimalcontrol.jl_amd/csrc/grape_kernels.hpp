@@ -52,7 +52,9 @@ struct TileParams {
     double2 *states;      // X_t dump, same indexing
     double2 *costates;    // L_t dump (debug, GRAPE_FLAG_KEEP_COSTATES)
     double *member_out;   // as in SweepParams
-    int32_t K, N, E, n;
+    int32_t K, N, E, n;   // E = wavefront-level units: members, or member PAIRS when pack2
+    int32_t pack2;        // n <= 8: two members share one 16x16 tile as a block-diagonal pair
+    int32_t E_members;    // true member count (rows of member_out)
     int32_t s_forced, variant;
     int32_t bt_in_lds;    // set by the launcher: the K transposed control operators are cached in LDS
     int32_t stage_ops;    // set by the launcher: prop kernel stages the generators in LDS

@@ -199,7 +199,12 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
     }
     const double2 *__restrict__ Pk = p.props + (size_t)k * N * TSZ;
     double2 *__restrict__ Xk = p.states + (size_t)k * N * TSZ;
-    double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * N + 1);
+    // pack2: this wave carries members 2k (tile rows/cols 0..7) and 2k+1 (8..15); after the
+    // cross-lane sums lane 0 holds the first member's values and lane 8 the second's
+    const bool pack2 = p.pack2 != 0;
+    const int member = pack2 ? 2 * k + ((lane >> 3) & 1) : k;
+    const bool writer = (pack2 ? (lane == 0 || lane == 8) : lane == 0) && member < p.E_members;
+    double *__restrict__ out = p.member_out + (size_t)member * ((size_t)K * N + 1);
 
     // ------------------------------------------------------------ forward sweep
     {
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
                     tdot_partial<NT, false>(v[2 + 2 * cc], v[3 + 2 * cc], BT, R);   // sum_ij B[i,j] R[j,i]
                 }
             }
-            wave_sum_n(v);
+            wave_sum_n(v, pack2);
             zr = v[0];
             zi = v[1];
 #pragma unroll
@@ -291,11 +296,11 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
                 const int c = c0 + cc;
                 const double wr = v[2 + 2 * cc], wi = v[3 + 2 * cc];
                 const double im = SAND ? wi : fma(wr, zi, wi * zr);
-                if (c < K && lane == 0)
+                if (c < K && writer)
                     out[c + (size_t)t * K] = gs * im;
             }
         }
-        if (t == N - 1 && lane == 0) {
+        if (t == N - 1 && writer) {
             if (SAND) {
                 const double inv = 1.0 / (double)p.n;
                 const double ar = zr * inv, ai = zi * inv;
@@ -336,7 +341,10 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
         __builtin_amdgcn_wave_barrier();
     }
     const double2 *__restrict__ Pk = p.props + (size_t)k * N * TSZ;
-    double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * N + 1);
+    const bool pack2 = p.pack2 != 0;
+    const int member = pack2 ? 2 * k + ((lane >> 3) & 1) : k;
+    const bool writer = (pack2 ? (lane == 0 || lane == 8) : lane == 0) && member < p.E_members;
+    double *__restrict__ out = p.member_out + (size_t)member * ((size_t)K * N + 1);
 
     TMat<NT> M, L, Y, Pm, Pn;
     double zr = 0.0, zi = 0.0;
@@ -388,7 +396,11 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
                     M.re[I][J] -= Y.re[I][J];
                     M.im[I][J] -= Y.im[I][J];
                 }
-            tdot<NT, true>(zr, zi, X, L);                          // tr(X' L), the same for every t
+            double zz[2];
+            tdot_partial<NT, true>(zz[0], zz[1], X, L);            // tr(X' L), the same for every t
+            wave_sum_n(zz, pack2);
+            zr = zz[0];
+            zi = zz[1];
         }
     }
 
@@ -428,7 +440,7 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
                     tdot_partial<NT, false>(v[2 + 2 * cc], v[3 + 2 * cc], BT, M);   // sum_ij B[i,j] M[j,i]
                 }
             }
-            wave_sum_n(v);
+            wave_sum_n(v, pack2);
             if (!SAND) {
                 zr = v[0];
                 zi = -v[1];
@@ -438,11 +450,11 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
                 const int c = c0 + cc;
                 const double wr = v[2 + 2 * cc], wi = v[3 + 2 * cc];
                 const double im = SAND ? wi : fma(wr, zi, wi * zr);
-                if (c < K && lane == 0)
+                if (c < K && writer)
                     out[c + (size_t)t * K] = gs * im;
             }
         }
-        if (t == N - 1 && lane == 0) {
+        if (t == N - 1 && writer) {
             if (SAND) {
                 const double inv = 1.0 / (double)p.n;
                 const double ar = zr * inv, ai = zi * inv;

@@ -173,11 +173,15 @@ GRAPE_DEV double wave_sum(double v)
 
 // butterfly sum of M independent values at once: the M shuffle/add chains interleave, so the
 // ~100-cycle latency of each cross-lane step is paid once per step instead of once per value
+// `halves`: leave out the xor-8 step, so lanes with bit 3 clear / set end up with the sums over
+// columns 0..7 / 8..15 of a tile -- the two members of a block-diagonally packed pair.
 template <int M>
-GRAPE_DEV void wave_sum_n(double (&v)[M])
+GRAPE_DEV void wave_sum_n(double (&v)[M], bool halves = false)
 {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
+        if (halves && d == 8)
+            continue;
         double o[M];
 #pragma unroll
         for (int m = 0; m < M; ++m)
