@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void prop_tile_kernel(const TileParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NT, int SAND, bool KEEPL>
+template <int NT, int SAND, bool KEEPL, bool PACK2>
 __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
 {
     constexpr int TSZ = NT * NT * 256;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
     double2 *__restrict__ Xk = p.states + (size_t)k * N * TSZ;
     // pack2: this wave carries members 2k (tile rows/cols 0..7) and 2k+1 (8..15); after the
     // cross-lane sums lane 0 holds the first member's values and lane 8 the second's
-    const bool pack2 = p.pack2 != 0;
+    constexpr bool pack2 = PACK2;
     const int member = pack2 ? 2 * k + ((lane >> 3) & 1) : k;
     const bool writer = (pack2 ? (lane == 0 || lane == 8) : lane == 0) && member < p.E_members;
     double *__restrict__ out = p.member_out + (size_t)member * ((size_t)K * N + 1);
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
 // accumulates X_N = P_{N-1} ... P_0 Xi (UnitaryGate) or the total product T (sandwich:
 // X_N = T Xi T'), 1 product per slice; the backward pass carries M with 2 products per slice.
 // tr(X_t' L_t) is conj(tr M_t) (UnitaryGate) or t-invariant (sandwich, taken at t = N).
-template <int NT, int SAND>
+template <int NT, int SAND, bool PACK2>
 __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams p)
 {
     constexpr int TSZ = NT * NT * 256;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
         __builtin_amdgcn_wave_barrier();
     }
     const double2 *__restrict__ Pk = p.props + (size_t)k * N * TSZ;
-    const bool pack2 = p.pack2 != 0;
+    constexpr bool pack2 = PACK2;
     const int member = pack2 ? 2 * k + ((lane >> 3) & 1) : k;
     const bool writer = (pack2 ? (lane == 0 || lane == 8) : lane == 0) && member < p.E_members;
     double *__restrict__ out = p.member_out + (size_t)member * ((size_t)K * N + 1);
@@ -490,16 +490,20 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     const size_t bt_bytes = sizeof(double2) * (size_t)p.K * NT * NT * 256;
     q.bt_in_lds = bt_bytes <= 36 * 1024 ? 1 : 0;                   // 4 waves per CU must still fit
     const size_t lds = sizeof(double2) * (kTileImage + 1) + (q.bt_in_lds ? bt_bytes : 0);
+    const dim3 grid(p.E), block(64);
+    const bool pk = (NT == 1) && p.pack2;
+#define GRAPE_LAUNCH_CHAIN(KERNEL) hipLaunchKernelGGL(KERNEL, grid, block, lds, stream, q)
     if (p.unitary && !keepl) {
-        if (sandwich) hipLaunchKernelGGL((chain_tile_unitary_kernel<NT, 1>), dim3(p.E), dim3(64), lds, stream, q);
-        else          hipLaunchKernelGGL((chain_tile_unitary_kernel<NT, 0>), dim3(p.E), dim3(64), lds, stream, q);
+        if (sandwich) { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 1, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 1, false>)); }
+        else          { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 0, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 0, false>)); }
     } else if (sandwich) {
-        if (keepl) hipLaunchKernelGGL((chain_tile_kernel<NT, 1, true>), dim3(p.E), dim3(64), lds, stream, q);
-        else       hipLaunchKernelGGL((chain_tile_kernel<NT, 1, false>), dim3(p.E), dim3(64), lds, stream, q);
+        if (keepl) { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_kernel<NT, 1, true, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_kernel<NT, 1, true, false>)); }
+        else       { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_kernel<NT, 1, false, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_kernel<NT, 1, false, false>)); }
     } else {
-        if (keepl) hipLaunchKernelGGL((chain_tile_kernel<NT, 0, true>), dim3(p.E), dim3(64), lds, stream, q);
-        else       hipLaunchKernelGGL((chain_tile_kernel<NT, 0, false>), dim3(p.E), dim3(64), lds, stream, q);
+        if (keepl) { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_kernel<NT, 0, true, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_kernel<NT, 0, true, false>)); }
+        else       { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_kernel<NT, 0, false, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_kernel<NT, 0, false, false>)); }
     }
+#undef GRAPE_LAUNCH_CHAIN
     return hipGetLastError();
 }
 
