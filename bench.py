@@ -50,7 +50,17 @@ def cpu_baseline(workload, seconds, sample_members):
             break
     member_evals_per_s = n * w.E / el
     # B2 of BASELINE.md: the same port with OpenMP over members on every host core (bounded, ~1/3 of the time)
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))          # cores this process may actually use
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:                                              # a cgroup CPU quota caps what affinity shows
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = min(cores, max(1, int(-(-int(q) // int(per)))))
+    except Exception:
+        pass
+    cores = max(1, min(cores, 64))
     wide = workload.members(0, min(max(sample_members, 16 * cores), workload.E))
     wargs = (wide.sys_type, wide.A, wide.B, wide.Xi, wide.Xt, wide.wts, wide.x, wide.T)
     grape_oracle.ensemble_eval(*wargs, n_threads=cores)
