@@ -94,7 +94,7 @@ typedef struct grape_config {
     int32_t slices_per_lane;   /* S: consecutive time slices one lane owns           */
     int32_t waves_per_member;  /* W: wavefronts that share one member's time axis    */
     int32_t expm_squarings;    /* <0 = per slice from the generator norm; >=0 forces s */
-    int32_t reserved;
+    int32_t max_batch;         /* control arrays one grape_eval_batch call may carry; 0 or 1 = no batching */
 } grape_config;
 
 typedef struct grape_info {
@@ -147,7 +147,18 @@ int grape_eval(grape_ctx *ctx, const double *x, double *F, double *G);
  * Nothing is synchronised; errors detectable at enqueue time are returned. */
 int grape_eval_device(grape_ctx *ctx, const double *d_x, double *d_fg, void *stream);
 
-/* Debug/parity accessors (valid after an evaluation; needs GRAPE_FLAG_MEMBER_RESULTS):
+/* Extension beyond the reference (multi-start optimisation / line-search batches):
+ * n_x <= max_batch independent control arrays evaluated against the same ensemble in ONE launch.
+ *   x  host f64 (K,N,n_x)      F  host f64[n_x] (nullable)      G  host f64 (K,N,n_x) (nullable)
+ * Entry b is exactly what grape_eval(ctx, x[:,:,b]) returns; with n_x = 1 the two calls are the same.
+ * Needs grape_config.max_batch >= n_x; operator dimension n <= 4 in this build. */
+int grape_eval_batch(grape_ctx *ctx, int32_t n_x, const double *x, double *F, double *G);
+
+/* Device-pointer form: d_x (K,N,n_x), d_fg f64[(K*N + 1) * n_x] = n_x blocks of { G, F }. */
+int grape_eval_batch_device(grape_ctx *ctx, int32_t n_x, const double *d_x, double *d_fg, void *stream);
+
+/* Debug/parity accessors (valid after an evaluation; needs GRAPE_FLAG_MEMBER_RESULTS; after a batched
+ * evaluation they refer to control array 0):
  * per-member unweighted results, as the reference's `gradient[k,:,:]` and the F_k summands:
  *   foms  host f64[E] (nullable)      grads  host f64 (K,N,E) (nullable) */
 int grape_get_member_results(grape_ctx *ctx, double *foms, double *grads);

@@ -40,7 +40,7 @@ struct GrapeConfig
     slices_per_lane::Int32
     waves_per_member::Int32
     expm_squarings::Int32
-    reserved::Int32
+    max_batch::Int32
 end
 
 sys_code(::UnitaryGate) = Int32(0)

@@ -36,7 +36,8 @@ struct grape_ctx {
     bool pack2 = false;           // tile family, n <= 8: two members per 16x16 tile (block diagonal)
     int EU = 0;                   // tile family: wavefront-level units = members, or member pairs when pack2
     int S = 0, W = 0, LT = 0;
-    int MPB = 1, NB = 0;          // small family: members per workgroup, number of workgroups
+    int MPB = 1, NB = 0;          // small family: members per workgroup, workgroups per control array
+    int B = 1;                    // batch capacity: control arrays per grape_eval_batch call
     double *d_block_out = nullptr;
     double *d_xg_scratch = nullptr;   // only when K*N is too long for the LDS staging buffer
     int ksplit = 1;
@@ -153,6 +154,11 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     // ensemble alone cannot fill it.
     const int N = cfg->n_slices, E = cfg->n_ensemble;
     c->family = wmax > 0 ? 0 : 1;
+    c->B = cfg->max_batch > 1 ? cfg->max_batch : 1;
+    if (c->B > 1 && c->family != 0) {
+        delete c;
+        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: max_batch > 1 needs operator dimension n <= 4 in this build");
+    }
     c->NT = nt;
     c->TSZ = (size_t)nt * nt * 256;
     c->pack2 = (c->family == 1 && cfg->n <= 8 && !std::getenv("GRAPE_TILE_NOPACK") && !std::getenv("GRAPE_TILE_MFMA4"));
@@ -160,7 +166,8 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     int W = cfg->waves_per_member;
     if (W <= 0) {
         const long simds = 4L * c->compute_units;
-        W = (int)((simds + E - 1) / E);
+        const long units = (long)E * c->B;                       // a batch fills the chip like a larger ensemble
+        W = (int)((simds + units - 1) / units);
         const int wneed = (N + 63) / 64;
         if (W > wneed) W = wneed;
     }
@@ -203,21 +210,22 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = alloc((void **)&c->d_ops, sizeof(double2) * ops_elems);
     if (e == hipSuccess) e = alloc((void **)&c->d_wts, sizeof(double) * E);
-    if (e == hipSuccess) e = alloc((void **)&c->d_x, sizeof(double) * KN(c));
-    if (e == hipSuccess) e = alloc((void **)&c->d_fg, sizeof(double) * Q);
-    if (e == hipSuccess) e = alloc((void **)&c->d_props, sizeof(double2) * c->ws_elems);
-    if (e == hipSuccess && keepl) e = alloc((void **)&c->d_costates, sizeof(double2) * c->ws_elems);
+    const size_t Bn = (size_t)c->B;
+    if (e == hipSuccess) e = alloc((void **)&c->d_x, sizeof(double) * KN(c) * Bn);
+    if (e == hipSuccess) e = alloc((void **)&c->d_fg, sizeof(double) * Q * Bn);
+    if (e == hipSuccess) e = alloc((void **)&c->d_props, sizeof(double2) * c->ws_elems * Bn);
+    if (e == hipSuccess && keepl) e = alloc((void **)&c->d_costates, sizeof(double2) * c->ws_elems * Bn);
     const bool want_rows = c->family == 1 || (cfg->flags & GRAPE_FLAG_MEMBER_RESULTS);
-    if (e == hipSuccess && want_rows) e = alloc((void **)&c->d_member_out, sizeof(double) * E * Q);
+    if (e == hipSuccess && want_rows) e = alloc((void **)&c->d_member_out, sizeof(double) * E * Q * Bn);
     if (e == hipSuccess) e = alloc((void **)&c->d_partial, sizeof(double) * c->ksplit * Q);
-    if (e == hipSuccess && c->family == 0) e = alloc((void **)&c->d_block_out, sizeof(double) * c->NB * Q);
+    if (e == hipSuccess && c->family == 0) e = alloc((void **)&c->d_block_out, sizeof(double) * c->NB * Q * Bn);
     if (e == hipSuccess && c->family == 0 && !xg_in_lds)
         e = alloc((void **)&c->d_xg_scratch,
-                  sizeof(double) * c->NB * ((size_t)c->MPB * c->LT * ((size_t)S * K + 1) + c->MPB));
+                  sizeof(double) * Bn * c->NB * ((size_t)c->MPB * c->LT * ((size_t)S * K + 1) + c->MPB));
     if (e == hipSuccess && (cfg->flags & GRAPE_FLAG_PHASE_STAMPS))
-        e = alloc((void **)&c->d_stamps, sizeof(unsigned long long) * E * W * grape::kStampSlots);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, sizeof(double) * Q, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_fg, sizeof(double) * Q, hipHostMallocMapped);
+        e = alloc((void **)&c->d_stamps, sizeof(unsigned long long) * Bn * E * W * grape::kStampSlots);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, sizeof(double) * Q * Bn, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_fg, sizeof(double) * Q * Bn, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->d_h_fg, c->h_fg, 0);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -321,8 +329,8 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     }
     c->unitary = herm;
     if (!herm && !c->d_states) {
-        c->bytes += sizeof(double2) * c->ws_elems;
-        HIP_TRY(c, hipMalloc((void **)&c->d_states, sizeof(double2) * c->ws_elems));
+        c->bytes += sizeof(double2) * c->ws_elems * c->B;
+        HIP_TRY(c, hipMalloc((void **)&c->d_states, sizeof(double2) * c->ws_elems * c->B));
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->d_ops, packed.data(), sizeof(double) * packed.size(), hipMemcpyHostToDevice));
@@ -363,7 +371,7 @@ static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream)
     return GRAPE_OK;
 }
 
-static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream_t stream)
+static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream_t stream, int n_x = 1)
 {
     SweepParams p{};
     p.ops = c->d_ops;
@@ -375,6 +383,8 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     p.wts = c->d_wts;
     p.block_out = c->d_block_out;
     p.MPB = c->MPB;
+    p.BPX = c->NB;
+    p.n_x = n_x;
     p.sk_magic = (uint32_t)((1ull << 32) / ((uint64_t)c->S * c->cfg.n_controls)) + 1u;
     p.stamps = c->d_stamps;
     p.xg_scratch = c->d_xg_scratch;
@@ -410,7 +420,7 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     }
     if (timed) HIP_TRY(c, hipEventRecord(e1, stream));
     if (c->family == 0)
-        HIP_TRY(c, grape::launch_reduce_rows(c->d_block_out, d_fg, c->NB, (int)(KN(c) + 1), stream));
+        HIP_TRY(c, grape::launch_reduce_rows(c->d_block_out, d_fg, c->NB, (int)(KN(c) + 1), n_x, stream));
     else
         HIP_TRY(c, grape::launch_reduce(c->d_member_out, c->d_wts, c->d_partial, d_fg, p.E,
                                         (int)(KN(c) + 1), c->ksplit, stream));
@@ -448,6 +458,42 @@ extern "C" int grape_eval(grape_ctx *c, const double *x, double *F, double *G)
     }
     if (G) std::memcpy(G, c->h_fg, sizeof(double) * kn);
     if (F) *F = c->h_fg[kn];
+    return GRAPE_OK;
+}
+
+extern "C" int grape_eval_batch_device(grape_ctx *c, int32_t n_x, const double *d_x, double *d_fg, void *stream)
+{
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (!d_x || !d_fg) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval_batch_device: null argument");
+    if (n_x < 1 || n_x > c->B)
+        return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval_batch_device: n_x must be in 1..grape_config.max_batch");
+    if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, "grape_eval_batch_device: operators not set");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return enqueue_eval(c, d_x, d_fg, (hipStream_t)stream, n_x);
+}
+
+extern "C" int grape_eval_batch(grape_ctx *c, int32_t n_x, const double *x, double *F, double *G)
+{
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (!x) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval_batch: x is null");
+    if (n_x < 1 || n_x > c->B)
+        return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval_batch: n_x must be in 1..grape_config.max_batch");
+    if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, "grape_eval_batch: operators not set");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t kn = KN(c), Q = kn + 1;
+    std::memcpy(c->h_stage, x, sizeof(double) * kn * n_x);
+    HIP_TRY(c, hipMemcpyAsync(c->d_x, c->h_stage, sizeof(double) * kn * n_x, hipMemcpyHostToDevice, c->stream));
+    int rc = enqueue_eval(c, c->d_x, c->d_h_fg, c->stream, n_x);
+    if (rc) return rc;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) HIP_TRY(c, q);
+    }
+    for (int b = 0; b < n_x; ++b) {
+        if (G) std::memcpy(G + (size_t)b * kn, c->h_fg + (size_t)b * Q, sizeof(double) * kn);
+        if (F) F[b] = c->h_fg[(size_t)b * Q + kn];
+    }
     return GRAPE_OK;
 }
 

@@ -29,6 +29,8 @@ struct SweepParams {
     int32_t S;            // slices per lane
     int32_t LT;           // lanes per member = 64 * W
     int32_t MPB;          // members per workgroup (MPB * LT threads)
+    int32_t BPX;          // workgroups per control array = ceil(E / MPB)
+    int32_t n_x;          // control arrays evaluated by this launch (grid = BPX * n_x workgroups)
     uint32_t sk_magic;    // floor(2^32 / (S*K)) + 1: q / (S*K) == __umulhi(q, sk_magic)
     int32_t s_forced;     // expm squarings, -1 = per slice from the norm
     int32_t variant;      // 0 in-place, 1 static
@@ -72,6 +74,7 @@ hipError_t launch_reduce(const double *member_out, const double *wts, double *pa
                          int E, int Q, int ksplit, hipStream_t stream);
 int reduce_ksplit(int E);
 // fg[q] = sum_b rows[b][q] over NB already-weighted rows (one launch, fixed summation tree).
-hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, hipStream_t stream);
+// n_x > 1: independent reductions, rows [x*NB, (x+1)*NB) -> fg + x*Q
+hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, int n_x, hipStream_t stream);
 
 }  // namespace grape

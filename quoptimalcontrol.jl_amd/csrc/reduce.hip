@@ -64,6 +64,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restri
     __shared__ double s_acc[32][9];
     const int ql = threadIdx.x & 7, bl = threadIdx.x >> 3;
     const int q = blockIdx.x * 8 + ql;
+    rows += (size_t)blockIdx.y * NB * Q;             // batched evaluation: one reduction per control array
+    fg += (size_t)blockIdx.y * Q;
     double acc = 0.0;
     if (q < Q) {
         for (int b = bl; b < NB; b += 32)
@@ -80,9 +82,9 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restri
     }
 }
 
-hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, hipStream_t stream)
+hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, int n_x, hipStream_t stream)
 {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((Q + 7) / 8), dim3(256), 0, stream, rows, fg, NB, Q);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((Q + 7) / 8, n_x), dim3(256), 0, stream, rows, fg, NB, Q);
     return hipGetLastError();
 }
 

@@ -151,9 +151,15 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__rest
     const int L = threadIdx.x - mb * LT;             // lane within the member
     const int lane = L & 63, wave = L >> 6;
     const int wbase_tot = mb * W;                    // this member's rows of s_tot
-    int k = blockIdx.x * p.MPB + mb;
-    if (k >= p.E)
-        k = p.E - 1;                                 // surplus waves repeat the last member (never stored)
+    // batched evaluation (grape_eval_batch): the grid is n_x copies of the ensemble's BPX
+    // workgroups, copy xi evaluates control array xi; a workgroup never straddles two copies
+    const int xi = blockIdx.x / p.BPX;               // which control array
+    const int bi = blockIdx.x - xi * p.BPX;          // workgroup within the ensemble
+    int kl = bi * p.MPB + mb;                        // member within the ensemble
+    const bool valid = kl < p.E;
+    if (!valid)
+        kl = p.E - 1;                                // surplus waves repeat the last member (never stored)
+    const int k = xi * p.E + kl;                     // row of the workspace / per-member output
     const int K = p.K, Nsl = p.N, S = p.S;
     const size_t stride = (size_t)LT;
 
@@ -164,10 +170,13 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__rest
     double *s_F = s_xg_all + (size_t)p.MPB * LT * (SK + 1);
     const unsigned magic = p.sk_magic;               // q / SK == __umulhi(q, magic) for q * SK < 2^32
     auto chunk_of = [&](int q) { return SK == 1 ? q : (int)__umulhi((unsigned)q, magic); };
-    for (int q = L; q < K * Nsl; q += LT)
-        s_xg[q + chunk_of(q)] = x_all[q];            // lq*(SK+1) + (q - lq*SK) = q + lq
+    {
+        const double *__restrict__ xsrc = x_all + (size_t)xi * K * Nsl;
+        for (int q = L; q < K * Nsl; q += LT)
+            s_xg[q + chunk_of(q)] = xsrc[q];         // lq*(SK+1) + (q - lq*SK) = q + lq
+    }
     __syncthreads();
-    const double2 *__restrict__ ops = ops_all + (size_t)k * (K + 3) * NN;
+    const double2 *__restrict__ ops = ops_all + (size_t)kl * (K + 3) * NN;
     const double2 *__restrict__ opB = ops + NN;
     const double2 *__restrict__ opXi = ops + (size_t)(1 + K) * NN;
     const double2 *__restrict__ opXt = opXi + NN;
@@ -494,15 +503,15 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__rest
     // gradient[k,:,:] and F_k: parity/debug accessor), (2) the block's weighted partial sum.
     __syncthreads();
     const int KN = K * Nsl;
-    if (p.member_out && blockIdx.x * p.MPB + mb < p.E) {
+    if (p.member_out && valid) {
         for (int q = L; q < KN; q += LT)
             out[q] = s_xg[q + chunk_of(q)];
         if (L == 0)
             out[KN] = s_F[mb];
     }
     {
-        const int nmem = min(p.MPB, p.E - (int)blockIdx.x * p.MPB);
-        const double *__restrict__ wb = wts_all + (size_t)blockIdx.x * p.MPB;
+        const int nmem = min(p.MPB, p.E - bi * p.MPB);
+        const double *__restrict__ wb = wts_all + (size_t)bi * p.MPB;
         double *__restrict__ bout = p.block_out + (size_t)blockIdx.x * (KN + 1);
         const int mstride = LT * (SK + 1);
         for (int q = threadIdx.x; q <= KN; q += blockDim.x) {
@@ -549,7 +558,7 @@ template <int N, int SAND, int MODE, bool XGLDS>
 static hipError_t launch_one(const SweepParams &p, hipStream_t stream)
 {
     constexpr int MAXT = SmallTraits<N>::MAXT;
-    const dim3 grid((p.E + p.MPB - 1) / p.MPB), block(p.LT * p.MPB);
+    const dim3 grid(p.BPX * p.n_x), block(p.LT * p.MPB);
     const size_t lds = sweep_small_lds_bytes(N, p.MPB, p.LT, p.S, p.K, XGLDS);
     if (lds > 160 * 1024)
         return hipErrorInvalidConfiguration;

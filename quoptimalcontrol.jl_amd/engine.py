@@ -31,7 +31,8 @@ STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID_ARG", -2: "GRAPE_ERR_UNSUPPORTED
 
 # every symbol include/grape_hip.h declares
 EXPORTS = ["grape_abi_version", "grape_create", "grape_destroy", "grape_set_operators",
-           "grape_eval", "grape_eval_device", "grape_get_member_results", "grape_get_trajectory",
+           "grape_eval", "grape_eval_device", "grape_eval_batch", "grape_eval_batch_device",
+           "grape_get_member_results", "grape_get_trajectory",
            "grape_get_kernel_time", "grape_get_phase_stamps", "grape_get_info", "grape_last_error"]
 
 
@@ -46,7 +47,7 @@ class GrapeConfig(C.Structure):
                 ("n_controls", C.c_int32), ("n_slices", C.c_int32), ("n_ensemble", C.c_int32),
                 ("duration", C.c_double), ("device", C.c_int32), ("flags", C.c_int32),
                 ("slices_per_lane", C.c_int32), ("waves_per_member", C.c_int32),
-                ("expm_squarings", C.c_int32), ("reserved", C.c_int32)]
+                ("expm_squarings", C.c_int32), ("max_batch", C.c_int32)]
 
 
 class GrapeInfo(C.Structure):
@@ -88,6 +89,8 @@ def load_library():
     L.grape_set_operators.argtypes = [vp] * 6
     L.grape_eval.argtypes = [vp, vp, dp, vp]
     L.grape_eval_device.argtypes = [vp, vp, vp, vp]
+    L.grape_eval_batch.argtypes = [vp, i32, vp, vp, vp]
+    L.grape_eval_batch_device.argtypes = [vp, i32, vp, vp, vp]
     L.grape_get_member_results.argtypes = [vp, vp, vp]
     L.grape_get_trajectory.argtypes = [vp, i32, vp, vp, vp]
     L.grape_get_kernel_time.argtypes = [vp, dp, C.POINTER(C.c_int64), i32]
@@ -118,7 +121,7 @@ class GrapeEngine:
     eval(x) -> (F, G) with x, G of shape (K, N) (x[j, i] as in the reference)."""
 
     def __init__(self, sys_type, A, B, Xi, Xt, wts, T, n_slices, variant=0, device=-1, flags=0,
-                 slices_per_lane=0, waves_per_member=0, expm_squarings=-1, member_results=False):
+                 slices_per_lane=0, waves_per_member=0, expm_squarings=-1, member_results=False, max_batch=1):
         self._h = None
         self._lib = load_library()
         A = np.asarray(A, dtype=np.complex128)
@@ -139,7 +142,8 @@ class GrapeEngine:
         code = SYS_TYPE_CODES[sys_type] if isinstance(sys_type, str) else int(sys_type)
         self.sys_type, self.n, self.K, self.N, self.E, self.T = sys_type, n, K, int(n_slices), E, float(T)
         cfg = GrapeConfig(code, int(variant), n, K, int(n_slices), E, float(T), int(device), int(flags),
-                          int(slices_per_lane), int(waves_per_member), int(expm_squarings), 0)
+                          int(slices_per_lane), int(waves_per_member), int(expm_squarings), int(max_batch))
+        self.max_batch = max(1, int(max_batch))
         h = C.c_void_p()
         rc = self._lib.grape_create(C.byref(cfg), C.byref(h))
         if rc:
@@ -188,10 +192,28 @@ class GrapeEngine:
         self._check(self._lib.grape_eval(self._h, _p(xf), C.byref(F) if want_F else None, _p(G)))
         return (F.value if want_F else None), (np.ascontiguousarray(G.T) if want_G else None)
 
+    def eval_batch(self, X):
+        """grape_eval_batch: X (n_x, K, N) control arrays -> (F (n_x,), G (n_x, K, N)); entry b equals
+        eval(X[b]).  An extension for multi-start optimisation; needs max_batch >= n_x."""
+        X = np.asarray(X, dtype=np.float64)
+        if X.ndim != 3 or X.shape[1:] != (self.K, self.N):
+            raise ValueError(f"X must be (n_x, {self.K}, {self.N})")
+        n_x = X.shape[0]
+        xf = np.ascontiguousarray(np.swapaxes(X, 1, 2))            # each (K,N) column-major
+        F = np.empty(n_x)
+        G = np.empty((n_x, self.N, self.K))
+        self._check(self._lib.grape_eval_batch(self._h, n_x, _p(xf), _p(F), _p(G)))
+        return F, np.ascontiguousarray(np.swapaxes(G, 1, 2))
+
     def eval_device(self, d_x_ptr, d_fg_ptr, stream=0):
         """grape_eval_device with raw device pointers (e.g. torch tensor .data_ptr())."""
         self._check(self._lib.grape_eval_device(self._h, C.c_void_p(d_x_ptr), C.c_void_p(d_fg_ptr),
                                                 C.c_void_p(stream)))
+
+    def eval_batch_device(self, n_x, d_x_ptr, d_fg_ptr, stream=0):
+        """grape_eval_batch_device with raw device pointers: d_x (K,N,n_x) f64, d_fg n_x blocks of (K*N+1) f64."""
+        self._check(self._lib.grape_eval_batch_device(self._h, int(n_x), C.c_void_p(d_x_ptr), C.c_void_p(d_fg_ptr),
+                                                      C.c_void_p(stream)))
 
     def member_results(self):
         foms = np.empty(self.E)

@@ -154,3 +154,23 @@ def test_full_size_properties(qoc, oracle):
     with qoc.GrapeEngine(w2.sys_type, w2.A, w2.B, w2.Xi, w2.Xt, w2.wts, w2.T, w2.N) as eng:
         Fw, Gw = eng.eval(w.x)
     assert abs(Fw - foms @ w2.wts) <= 1e-12 and np.abs(Gw - np.tensordot(w2.wts, grads, 1)).max() <= 1e-14
+
+
+@pytest.mark.parametrize("name,wkw,n_x", [("C2", {"N": 200}, 7), ("C3", {"E": 5, "N": 60}, 4), ("C3", {"E": 40, "N": 130}, 3)])
+@pytest.mark.parametrize("flow", ["auto", "general"])
+def test_batched_evaluation(qoc, oracle, name, wkw, n_x, flow):
+    """grape_eval_batch (SURVEY.md 8f-2): n_x control arrays against one ensemble in a single launch;
+    every entry must equal the oracle's evaluation of that control array."""
+    w = qoc.workloads.config(name, **wkw)
+    rng = np.random.default_rng(11)
+    X = rng.uniform(-1, 1, (n_x,) + w.x.shape)
+    flags = 0 if flow == "auto" else qoc.engine.FLAG_FORCE_GENERAL
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, max_batch=8, flags=flags) as eng:
+        F, G = eng.eval_batch(X)
+        F1, G1 = eng.eval(X[1])                                  # the single-x entry point on the same context
+        with pytest.raises(qoc.GrapeError):
+            eng.eval_batch(np.zeros((9,) + w.x.shape))           # beyond max_batch
+    for b in range(n_x):
+        F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, X[b], w.T)
+        assert_parity(F[b], G[b], F_ref, G_ref, w.n, what=f"batch entry {b}")
+    assert F1 == F[1] and np.array_equal(G1, G[1])
