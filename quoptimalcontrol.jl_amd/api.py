@@ -153,6 +153,29 @@ def fom_and_gradient(prob, alg, x, engine=None):
             eng.close()
 
 
+def pulse_to_file(pulse, file_path, duration=None):
+    """src/tools.jl:90-104: write a (K, N) pulse as delimited text with time going down the file
+    (`writedlm(io, pulse')`, tab separated); with `duration`, a leading time column
+    `range(0, duration, length=N)` like the reference's 3-argument method (which takes N = length(pulse),
+    i.e. a single-control pulse)."""
+    P = np.atleast_2d(np.asarray(pulse, dtype=np.float64))
+    rows = P.T
+    if duration is not None:
+        t = np.linspace(0.0, float(duration), rows.shape[0])
+        rows = np.column_stack([t, rows])
+    with open(file_path, "w") as io:
+        for r in rows:
+            io.write("\t".join(repr(float(v)) for v in r) + "\n")
+
+
+def pulse_from_file(file_path, has_time_column=False):
+    """inverse of pulse_to_file: returns the (K, N) pulse (and the time column if present)."""
+    data = np.loadtxt(file_path, delimiter="\t", ndmin=2)
+    if has_time_column:
+        return np.ascontiguousarray(data[:, 1:].T), data[:, 0].copy()
+    return np.ascontiguousarray(data.T)
+
+
 def _lbfgs(topt, x0, options):
     """Stand-in for Optim.optimize(Optim.only_fg!(topt), x0, LBFGS(), opts) (src/solve.jl:138)."""
     from scipy.optimize import minimize

@@ -82,3 +82,16 @@ def test_column_major_packing(qoc):
     buf = qoc.engine._cm(M)
     assert buf.flags["C_CONTIGUOUS"]
     assert buf.reshape(-1)[1] == M[0, 1, 0]          # element (i=1, j=0) second in memory
+
+
+def test_pulse_file_round_trip(qoc, tmp_path):
+    """src/tools.jl:90-104: time goes down the file, controls across, tab separated."""
+    x = qoc.workloads.controls(3, 7)
+    f = tmp_path / "pulse.txt"
+    qoc.pulse_to_file(x, f)
+    lines = f.read_text().splitlines()
+    assert len(lines) == 7 and all(len(l.split("\t")) == 3 for l in lines)
+    assert np.array_equal(qoc.pulse_from_file(f), x)                   # repr() round-trips float64 exactly
+    qoc.pulse_to_file(x[:1], f, duration=2.0)
+    back, t = qoc.pulse_from_file(f, has_time_column=True)
+    assert np.array_equal(back, x[:1]) and t[0] == 0.0 and t[-1] == 2.0
