@@ -147,16 +147,41 @@ def main():
         ("ug_2x2_ens", wl.reference_ensemble("UnitaryGate", 3, 8, 5.0)),
         ("ug_4x4_ens", wl.config("C3", E=3, N=12)),
         ("st_4x4_ens", None),
+        ("st_8x8_pairs", "rand8"),                    # tile kernels, two members per 16x16 tile
+        ("ct_16x16_nonherm", "rand16"),               # tile kernels, non-Hermitian generator
     ]
     for name, w in cases:
-        if w is None:                                  # 4x4 StateTransfer: C3 operators, rho targets
+        if isinstance(w, str):                         # seeded random problems for the MFMA tile kernels
+            n = 8 if w == "rand8" else 16
+            rng = np.random.default_rng(n)
+            E, K, N = (3, 2, 5) if n == 8 else (2, 2, 4)
+
+            def rnd(herm):
+                M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+                return (M + M.conj().T) / 2 if herm else M
+            herm = n == 8
+            A = np.array([rnd(herm) for _ in range(E)]) * 0.6
+            B = np.array([[rnd(herm) for _ in range(K)] for _ in range(E)]) * 0.4
+
+            def rho():
+                v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+                v /= np.linalg.norm(v)
+                return np.outer(v, v.conj())
+            w = wl.Workload(name, "StateTransfer" if n == 8 else "CoherenceTransfer", n, K, N, E, 1.0, A, B,
+                            np.array([rho() for _ in range(E)]), np.array([rho() for _ in range(E)]),
+                            rng.uniform(0.3, 1.2, E), rng.uniform(-1, 1, (K, N)))
+            variants = (0,)
+        elif w is None:                                # 4x4 StateTransfer: C3 operators, rho targets
             w = wl.config("C3", E=2, N=10)
             rho0 = np.zeros((4, 4), complex); rho0[0, 0] = 1
             psi = np.array([1, 1j, -1, 0.5]) / np.linalg.norm([1, 1j, -1, 0.5])
             rhoT = np.outer(psi, psi.conj())
             w.sys_type = "StateTransfer"
             w.Xi = np.array([rho0, rho0]); w.Xt = np.array([rhoT, rhoT])
-        for variant in (0, 1):
+            variants = (0, 1)
+        else:
+            variants = (0, 1)
+        for variant in variants:
             case = make_case(f"{name}_v{variant}", w, variant)
             path = os.path.join(out, f"{name}_v{variant}.json")
             with open(path, "w") as fh:

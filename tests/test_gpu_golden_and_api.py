@@ -26,14 +26,18 @@ def test_hip_matches_golden(qoc, path, flow):
         if flow == "general":
             got_traj = eng.trajectory(0, costates=True)
         else:
-            got_traj = (eng.trajectory(0, states=False)[0],)
-            with pytest.raises(qoc.GrapeError):
-                eng.trajectory(0)                                # the unitary flow stores no states
+            inf = eng.info
+            if inf["kernel_family"] == 1 and not inf["unitary_flow"]:
+                got_traj = eng.trajectory(0)                     # tile kernels, non-Hermitian: states are stored
+            else:
+                got_traj = (eng.trajectory(0, states=False)[0],)
+                with pytest.raises(qoc.GrapeError):
+                    eng.trajectory(0)                            # the fast n <= 4 / unitary flows store no states
     assert_parity(F, G, exp["F"], np.array(exp["G"]), c["n"], what="ensemble")
     for k in range(c["E"]):
         assert_parity(foms[k], grads[k], exp["member_F"][k], np.array(exp["member_g"][k]), c["n"], what=f"member {k}")
     for got, want in zip(got_traj, traj):
-        assert np.abs(got - want).max() < 1e-13
+        assert np.abs(got - want).max() <= 2e-13 * max(1.0, np.abs(want).max())
 
 
 def _problem(qoc, sys_type, N, T):
@@ -146,9 +150,10 @@ def test_full_size_properties(qoc, oracle):
         F2, G2 = eng.eval(w.x)
     assert F == F2 and np.array_equal(G, G2)                              # deterministic reduction
     assert abs(F - foms @ w.wts) <= 1e-12 and np.abs(G - np.tensordot(w.wts, grads, 1)).max() <= 1e-14
-    for k in (0, 1, 511, 777, 1023):
-        f_ref, g_ref = oracle.member_eval(w.sys_type, w.A[k], w.B[k], w.Xi[k], w.Xt[k], w.x, w.T)
-        assert_parity(foms[k], grads[k], f_ref, g_ref, w.n, what=f"member {k}")
+    _, _, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
+                                                     per_member=True, n_threads=8)
+    for k in range(w.E):                                                  # every one of the 1024 members
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], w.n, what=f"member {k}")
     w2 = w.members(0, w.E)
     w2.wts = w.wts * np.linspace(0.5, 1.5, w.E)
     with qoc.GrapeEngine(w2.sys_type, w2.A, w2.B, w2.Xi, w2.Xt, w2.wts, w2.T, w2.N) as eng:
