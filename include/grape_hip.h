@@ -180,7 +180,8 @@ int grape_get_kernel_time(grape_ctx *ctx, double *total_ms, int64_t *launches, i
 
 /* Diagnostic (GRAPE_FLAG_PHASE_STAMPS): the stamps of the last evaluation, 8 uint64 per wave,
  * waves ordered (member, wave-in-member): [0..4] shader clock at start / after propagators /
- * after scan / after forward sweep / end, [5],[6] 100 MHz real-time counter at start / end.
+ * after scan / after forward sweep / end, [5],[6] 100 MHz real-time counter at start / end,
+ * [7] where the wave ran: HW_REG_XCC_ID << 32 | HW_REG_HW_ID.
  * out: host uint64[capacity]; *count receives the number of values available. */
 int grape_get_phase_stamps(grape_ctx *ctx, uint64_t *out, int64_t capacity, int64_t *count);
 

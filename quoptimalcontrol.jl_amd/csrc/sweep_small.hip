@@ -535,8 +535,12 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__rest
         }
     }
     stamp(st, 4);
-    if (st && lane == 0)
+    if (st && lane == 0) {
         st[6] = __builtin_amdgcn_s_memrealtime();
+        // where the wave ran: HW_REG_XCC_ID (hwreg 20) in the high word, HW_REG_HW_ID (hwreg 4) in the low
+        st[7] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) |
+                (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+    }
 }
 
 template <int N>

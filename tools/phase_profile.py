@@ -23,7 +23,8 @@ with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, flags=qo
                      slices_per_lane=a.slices_per_lane, waves_per_member=a.waves_per_member) as eng:
     for _ in range(3):
         eng.eval(w.x)
-    st = eng.phase_stamps().astype(np.int64)
+    eng_stamps_raw = eng.phase_stamps()
+    st = eng_stamps_raw.astype(np.int64)
     info = eng.info
 d = np.diff(st[:, :5], axis=1)                      # cycles per phase per wave
 real = (st[:, 6] - st[:, 5]) * 10.0                 # ns (100 MHz counter)
@@ -42,4 +43,7 @@ out["percentiles_0_10_50_90_100"] = {
     "wave_end_ns_after_first_start": pc((st[:, 6] - st[:, 5].min()) * 10.0),
     "wave_real_ns": pc(real), "wave_total_cycles": pc(tot),
     **{n: pc(d[:, i]) for i, n in enumerate(names)}}
+hw = eng_stamps_raw[:, 7]
+xcc = ((hw >> np.uint64(32)) & np.uint64(0xF)).astype(int)
+out["per_xcc_wave_total_cycles_median"] = {int(x): float(np.median(tot[xcc == x])) for x in sorted(set(xcc.tolist()))}
 print(json.dumps(out, indent=1))
