@@ -2,25 +2,40 @@
 """bench.py -- GRAPE gradient-evals/sec on the headline config (BASELINE.json):
 2-qubit UnitaryGate, 4x4, 4 controls, 500 slices, 1024-member ensemble (SURVEY.md 8d "C3").
 
-One step = one call of the reference's ensemble closure topt(F, G, x) (src/solve.jl:164-196):
-all member evaluations + the weighted reduction, with x already resident in HBM and [G, F]
-left in HBM (grape_eval_device).  N > 1 GPUs: one process per GPU (torchrun), the ensemble is
-sharded in contiguous member blocks and ONE all-reduce of K*N+1 doubles per step completes it.
+One step = one call of the reference's ensemble closure topt(F, G, x) (src/solve.jl:164-196) exactly
+as the Julia glue makes it: grape_eval(ctx, x_host, &F, G_host) -- x in host memory -> all member
+evaluations + the weighted reduction -> F, G back in host memory, blocking (SURVEY.md 8d,
+BASELINE.md section 2).  An L-BFGS can run nothing faster than this, because x_{k+1} depends on G_k.
+N > 1 GPUs: one process per GPU, the ensemble is sharded in contiguous member blocks and every
+step ends in ONE all-reduce of K*N+1 doubles, issued inside libgrape_hip.so (RCCL, grape_comm_attach);
+every rank makes the same host -> host call.
 
-  python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus 1 --steps 300 --warmup 30
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-         --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 20
+         --master-port 29500 bench.py --gpus 8 --steps 300 --warmup 30
+  python bench.py --gpus 8         # no torchrun around it: spawns the 8 ranks itself (fresh children)
+
+Timing: W warm-up steps, then --blocks (default 3) blocks of EXACTLY K steps, each bracketed by a
+barrier + torch.cuda.synchronize(); per block the MAX over ranks; `value` comes from the MEDIAN block
+(so a 20-step run is not a single 2 ms sample); all block times are in the line.
 
 Prints ONE JSON line on rank 0 (contract: see the task statement), including
-  roofline      dominant kernel (sweep) priced against the 8 TB/s HBM peak with the
-                ALGORITHMIC bytes of BASELINE.md's model S, duration from HIP events recorded
-                around every sweep launch inside the timed region (on the launch stream);
+  roofline      dominant kernel (sweep) against the 8 TB/s HBM peak with the ALGORITHMIC bytes of
+                BASELINE.md's model S; duration from HIP events recorded around every sweep launch
+                inside the timed region (on the launch stream).  Also: the bytes/flops of the data
+                flow actually run (`flow`), the FP64 fraction, and the end-to-end fraction
+                (model S x value / peak, BASELINE.md section 2 formula);
   cpu_baseline  the C oracle (a port of the reference's serial algorithm) timed on this
-                host on a bounded member sample, rank 0 / N = 1 only.
+                host on a bounded member sample, rank 0 / N = 1 only;
+  extra         the device-resident pipelined loop (grape_eval_device back to back, what round 1
+                reported) for comparison;
+  extra_configs C2, C4 (E=1024), C5 (E=4096) host->host value + roofline on one GPU (N = 1 only).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -35,7 +50,6 @@ FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 vector = matrix spec
 def cpu_baseline(workload, seconds, sample_members):
     """Time the oracle (kind 'port', 1 core) on `sample_members` members of the same workload
     and scale to whole-ensemble evaluations per second."""
-    import numpy as np
     from oracle import grape_oracle
 
     w = workload.members(0, min(sample_members, workload.E))
@@ -81,12 +95,97 @@ def cpu_baseline(workload, seconds, sample_members):
     }, (foms, grads)
 
 
+def roofline(local, info, kern_ms, kern_n, evals_per_s, n_gpus, traffic):
+    """The dominant kernel of one shard (`local` = the members this rank owns) against its roof."""
+    avg_ms = kern_ms / max(kern_n, 1)
+    sec = avg_ms * 1e-3
+    uni = bool(info.get("unitary_flow"))
+    alg_bytes, alg_flops = local.algorithmic_bytes, local.algorithmic_flops
+    flow_bytes, flow_flops = local.flow_bytes(uni), local.flow_flops(uni)
+    gbs = alg_bytes / sec / 1e9 if sec > 0 else 0.0
+    tfs = alg_flops / sec / 1e12 if sec > 0 else 0.0
+    flow = {"name": "unitary (P_t only)" if uni else "general (model S)", "bytes_per_launch": flow_bytes,
+            "achieved_GBs": flow_bytes / sec / 1e9 if sec > 0 else 0.0,
+            "frac_hbm": flow_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else 0.0,
+            "flops_per_launch": flow_flops,
+            "achieved_TFLOPs": flow_flops / sec / 1e12 if sec > 0 else 0.0,
+            "frac_fp64": flow_flops / sec / 1e12 / FP64_PEAK_TFLOPS if sec > 0 else 0.0}
+    if info.get("kernel_family") == 1:            # n > 4: FP64 matrix-core kernels, compute-bound
+        roof = {"bound": "mfma", "achieved": tfs, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tfs / FP64_PEAK_TFLOPS, "traffic": traffic,
+                "kernel": "prop_tile_kernel + chain_tile*_kernel", "algorithmic_flops_per_launch": alg_flops,
+                "end_to_end_frac": alg_flops * evals_per_s / 1e12 / FP64_PEAK_TFLOPS}
+    else:
+        roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "sweep_small_kernel", "algorithmic_bytes_per_launch": alg_bytes,
+                "end_to_end_frac": alg_bytes * evals_per_s / 1e9 / HBM_PEAK_GBS}
+    roof.update({"kernel_avg_us": 1e3 * avg_ms, "kernel_launches": kern_n, "flow": flow,
+                 "note": "achieved/frac price the sweep kernel with the ALGORITHMIC work of SURVEY.md 8d "
+                         "(model S); `flow` prices the same launches with the bytes/flops of the data flow "
+                         "actually run; end_to_end_frac = algorithmic work x this rank's evals/s / peak"})
+    if isinstance(traffic, dict):
+        roof["traffic_source"] = "rocprofv3 PMC passes of this command, committed under profiles/ (not re-measured in this run)"
+    return roof
+
+
+def time_blocks(step, steps, blocks, barrier, reduce_max):
+    out = []
+    for _ in range(blocks):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        out.append(reduce_max(time.perf_counter() - t0))
+    return out
+
+
+def run_extra_config(qoc, name, dev_index, steps, warmup):
+    """One more BASELINE config on this GPU, host -> host, with its own roofline (N = 1 only)."""
+    w = qoc.workloads.config(name)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, device=dev_index,
+                         flags=qoc.engine.FLAG_TIME_KERNELS) as eng:
+        for _ in range(warmup):
+            eng.eval(w.x)
+        eng.kernel_time(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            F, _ = eng.eval(w.x)
+        el = time.perf_counter() - t0
+        kern_ms, kern_n = eng.kernel_time()
+        info = eng.info
+    evals = steps / el
+    return {"workload": f"{name}: {w.sys_type} {w.n}x{w.n}, K={w.K}, N={w.N}, E={w.E}, host->host grape_eval",
+            "value": evals, "unit": "gradient-evals/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+            "member_evals_per_s": evals * w.E, "F": F,
+            "roofline": roofline(w, info, kern_ms, kern_n, evals, 1, None)}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as fresh child
+    processes (nothing in THIS process has touched the GPU yet), relay their output, exit with
+    their code.  Never re-exec a process that initialised HIP."""
+    import torch                                   # device_count() does not initialise the GPU on this image
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) are visible; refusing to "
+                         f"report a {args.gpus}-GPU number from fewer GPUs")
+    port = 29500 + os.getpid() % 400
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--config", default="C3", help="workload (C2, C3; others once their kernels exist)")
+    ap.add_argument("--blocks", type=int, default=3, help="timed blocks of --steps calls; value = median block")
+    ap.add_argument("--config", default="C3", help="workload: C2, C3 (headline), C4, C5")
     ap.add_argument("--ensemble", type=int, default=0, help="override E (default: the config's)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong: the config's ensemble is split over the GPUs (north star); "
@@ -94,14 +193,27 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for plumbing tests)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the device-resident loop and the extra configs")
+    ap.add_argument("--extra-configs", default="C2,C4,C5")
+    ap.add_argument("--backend", default="cpu:gloo,cuda:nccl",
+                    help="torch.distributed control plane (the data-path collective is RCCL inside the library)")
+    ap.add_argument("--collective", choices=["lib", "torch"], default="lib",
+                    help="lib: ncclAllReduce inside libgrape_hip.so (grape_comm_attach); torch: torch.distributed.all_reduce")
     ap.add_argument("--force-dist", action="store_true",
-                    help="initialise torch.distributed (nccl) and run the all-reduce even with one rank")
+                    help="run the collective even with one rank (a 1-rank RCCL communicator)")
     ap.add_argument("--force-general", action="store_true",
                     help="use the general data flow (forward states stored) even for Hermitian generators")
     ap.add_argument("--slices-per-lane", type=int, default=0)
     ap.add_argument("--waves-per-member", type=int, default=0)
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                          # does not return
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; refusing to mislabel the run")
 
     import numpy as np
     import torch
@@ -110,59 +222,67 @@ def main():
     import quoptimalcontrol_jl_amd as qoc
     from quoptimalcontrol_jl_amd.distributed import sharded_engine
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    dev_index = local_rank % torch.cuda.device_count()      # (> 1 rank per GPU only in plumbing tests)
+    if world > torch.cuda.device_count() and not os.environ.get("GRAPE_BENCH_SHARE_GPU"):
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s): one rank per GPU is the contract")
+    dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1 or args.force_dist:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(args.backend)
+        dist.init_process_group(args.backend)
 
     base = qoc.workloads.config(args.config)
     E_cfg = args.ensemble or base.E
     E_total = E_cfg * (world if args.scaling == "weak" else 1)
     w = qoc.workloads.config(args.config, E=E_total) if E_total != base.E else base
 
-    sg = sharded_engine(w, device, force_collective=args.force_dist,
+    sg = sharded_engine(w, device, force_collective=args.force_dist, collective=args.collective,
                         flags=qoc.engine.FLAG_TIME_KERNELS | (qoc.engine.FLAG_FORCE_GENERAL if args.force_general else 0),
                         slices_per_lane=args.slices_per_lane, waves_per_member=args.waves_per_member)
-    x_dev = torch.as_tensor(np.ascontiguousarray(w.x.T), device=device)     # (K,N) col-major in HBM
+    x_host = np.ascontiguousarray(w.x)
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.all_reduce(torch.zeros(1))        # CPU tensor: the gloo half of the control plane
         torch.cuda.synchronize(device)
 
+    def reduce_max(seconds):
+        if world > 1:
+            t = torch.tensor([seconds], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return seconds
+
+    def step():
+        return sg.eval(x_host)                     # host -> GPUs -> host, all-reduce inside the library
+
     for _ in range(args.warmup):
-        sg.eval_device(x_dev)
+        step()
     barrier()
     if sg.local is not None:
         sg.local.kernel_time(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sg.eval_device(x_dev)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    block_s = time_blocks(step, args.steps, args.blocks, barrier, reduce_max)
     kern_ms, kern_n = sg.local.kernel_time() if sg.local is not None else (0.0, 0)
-    fg = sg.fg.cpu().numpy()
+    F_last, G_last = step()
     info = sg.local.info if sg.local is not None else {}
+    elapsed = statistics.median(block_s)
+
+    # ---- the device-resident pipelined loop round 1 reported (x and [G,F] stay in HBM, one sync at the end)
+    extra = None
+    if not args.no_extra:
+        x_dev = torch.as_tensor(np.ascontiguousarray(w.x.T), device=device)
+        for _ in range(min(args.warmup, 10)):
+            sg.eval_device(x_dev)
+        dev_s = time_blocks(lambda: sg.eval_device(x_dev), args.steps, 1, barrier, reduce_max)[0]
+        extra = {"device_resident_pipelined": {
+            "value": args.steps / dev_s * (E_total / E_cfg), "ms_per_step": 1e3 * dev_s / args.steps,
+            "what": "grape_eval_device back to back, x and [G,F] resident in HBM, one sync after all steps: "
+                    "kernel throughput, not a rate a sequential optimiser can reach"}}
 
     if rank == 0:
         evals_per_s = args.steps / elapsed
@@ -170,9 +290,6 @@ def main():
         # report in the metric's unit (evaluations of the CONFIG's E-member ensemble).
         value = evals_per_s * (E_total / E_cfg)
         local = w.members(sg.lo, sg.hi)
-        alg_bytes = local.algorithmic_bytes
-        avg_ms = kern_ms / max(kern_n, 1)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -180,33 +297,30 @@ def main():
                 traffic = json.load(open(tpath)).get(f"{args.config}_E{local.E}")
             except Exception:
                 traffic = None
-        if info.get("kernel_family") == 1:            # n > 4: FP64 matrix-core kernels, compute-bound
-            tf = local.algorithmic_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-            roof = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic,
-                    "kernel": "prop_tile_kernel + chain_tile_kernel", "kernel_avg_us": 1e3 * avg_ms,
-                    "kernel_launches": kern_n, "algorithmic_flops_per_launch": local.algorithmic_flops}
-        else:
-            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "kernel": "sweep_small_kernel", "kernel_avg_us": 1e3 * avg_ms,
-                    "kernel_launches": kern_n, "algorithmic_bytes_per_launch": alg_bytes}
+        roof = roofline(local, info, kern_ms, kern_n, evals_per_s, world, traffic)
+        n_joined = sg.comm_size if (world > 1 or args.force_dist) else 1
         out = {
             "metric": "GRAPE gradient-evals/sec", "value": value, "unit": "gradient-evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_joined, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {w.sys_type} {w.n}x{w.n}, K={w.K}, N={w.N} slices, "
                                    f"ensemble E={E_total} ({'sharded' if world > 1 else 'one GPU'}, "
-                                   f"{local.E} members/GPU), T={w.T}",
-                       "parallelism": f"ensemble-shard x{world}, one all-reduce of {w.K * w.N + 1} f64 per step"
+                                   f"{local.E} members/GPU), T={w.T}; step = host->host grape_eval "
+                                   f"(x in host memory -> F, G in host memory, blocking)",
+                       "parallelism": (f"ensemble-shard x{world}, one all-reduce of {w.K * w.N + 1} f64 per step "
+                                       f"({'ncclAllReduce inside libgrape_hip.so' if sg.collective == 'lib' else 'torch.distributed'})")
                                       if world > 1 else "single GPU",
+                       "collective": sg.collective if (world > 1 or args.force_dist) else None,
                        "slices_per_lane": info.get("slices_per_lane"),
                        "waves_per_member": info.get("waves_per_member")},
+            "blocks": {"count": args.blocks, "steps_each": args.steps, "seconds": block_s, "statistic": "median"},
             "member_evals_per_s": evals_per_s * E_total,
             "roofline": roof,
-            "F": float(fg[-1]),
+            "F": float(F_last),
         }
+        if extra is not None:
+            out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             cb, (foms_ref, grads_ref) = cpu_baseline(w, args.cpu_seconds, args.cpu_sample)
             out["cpu_baseline"] = cb
@@ -225,6 +339,15 @@ def main():
         out = None
 
     sg.close()
+    if rank == 0 and world == 1 and not args.no_extra and args.extra_configs:
+        out["extra_configs"] = []
+        for name in [s for s in args.extra_configs.split(",") if s and s != args.config]:
+            heavy = name in ("C4", "C5")
+            try:
+                out["extra_configs"].append(run_extra_config(qoc, name, dev_index, 3 if name == "C5" else (20 if heavy else 200),
+                                                             1 if name == "C5" else (3 if heavy else 20)))
+            except Exception as exc:               # noqa: BLE001 -- an extra line must not kill the headline
+                out["extra_configs"].append({"workload": name, "error": repr(exc)})
     if dist.is_initialized():
         dist.destroy_process_group()
     if out is not None:                       # the JSON line is the last thing on stdout

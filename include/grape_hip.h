@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GRAPE_ABI_VERSION 1
+#define GRAPE_ABI_VERSION 2
 
 typedef enum grape_status {
     GRAPE_OK = 0,
@@ -39,7 +39,10 @@ typedef enum grape_status {
     GRAPE_ERR_NO_DEVICE = -3,     /* no HIP device / wrong architecture                 */
     GRAPE_ERR_HIP = -4,           /* a HIP runtime call failed (message has the detail) */
     GRAPE_ERR_NOT_READY = -5,     /* grape_eval before grape_set_operators              */
-    GRAPE_ERR_ALLOC = -6          /* host or device allocation failed                   */
+    GRAPE_ERR_ALLOC = -6,         /* host or device allocation failed                   */
+    GRAPE_ERR_TIMEOUT = -7,       /* the device did not finish an evaluation within the time limit
+                                     (GRAPE_EVAL_TIMEOUT_S, default 600 s): device presumed hung */
+    GRAPE_ERR_COMM = -8           /* RCCL could not be loaded / a collective call failed */
 } grape_status;
 
 /* src/problems.jl:8-10.  CoherenceTransfer dispatches exactly like StateTransfer
@@ -71,15 +74,23 @@ enum {
                                            grape_get_member_results (the reference's
                                            gradient[k,:,:] intermediate); off by default: F and G
                                            do not need it and it costs E*(K*N+1) doubles of writes */
-    GRAPE_FLAG_FORCE_GENERAL = 1 << 3   /* always use the general data flow (forward states stored
+    GRAPE_FLAG_FORCE_GENERAL = 1 << 3,  /* always use the general data flow (forward states stored
                                            in HBM, as the reference does), even when every
                                            generator is Hermitian and the cheaper unitary flow
                                            applies.  KEEP_COSTATES implies it.          */
+    GRAPE_FLAG_FORCE_COLLECTIVE = 1 << 5 /* create the RCCL communicator and run the all-reduce of
+                                           [G, F] even when the context spans ONE device (a
+                                           1-rank collective: exercises the multi-GPU code path
+                                           on a single-GPU machine; testing/diagnostics)  */
 };
+
+#define GRAPE_MAX_DEVICES 8
 
 /* Mirrors what solve() unpacks: Problem fields (src/problems.jl:19-28: sys_type, T,
  * n_controls), the integrator's n_slices (src/timeevolution.jl:11-14), EnsembleProblem.n_ens
- * (src/problems.jl:33-41) -- here: the members THIS context owns (a shard of the ensemble). */
+ * (src/problems.jl:33-41) -- the members this context owns: the whole ensemble for a
+ * single-process caller (the library shards it over `n_devices` GPUs itself), or this rank's
+ * shard when one process per GPU is used with grape_comm_attach. */
 typedef struct grape_config {
     int32_t sys_type;          /* grape_sys_type                                     */
     int32_t variant;           /* grape_variant                                      */
@@ -95,6 +106,16 @@ typedef struct grape_config {
     int32_t waves_per_member;  /* W: wavefronts that share one member's time axis    */
     int32_t expm_squarings;    /* <0 = per slice from the generator norm; >=0 forces s */
     int32_t max_batch;         /* control arrays one grape_eval_batch call may carry; 0 or 1 = no batching */
+    /* ---- ABI v2 ---- */
+    int32_t n_state_cols;      /* m: Xi, Xt are n x m (src/problems.jl:23-24 puts no constraint on the
+                                  shape); 0 = n (square, every reference test).  m < n (e.g. m = 1,
+                                  vectorised density matrices as in test/liou.jl:38-48) needs UnitaryGate */
+    int32_t n_devices;         /* 0 or 1: one GPU (`device`).  2..8: the ensemble axis is sharded inside the
+                                  library over device_ids[0..n_devices) in contiguous blocks of ceil(E/G)
+                                  members (src/solve.jl:166-187 is the loop being split) and every
+                                  evaluation ends in ONE RCCL all-reduce of the K*N+1 doubles [G, F]
+                                  (src/solve.jl:171-186, :191) */
+    int32_t device_ids[GRAPE_MAX_DEVICES];   /* HIP ordinals, used when n_devices >= 2 */
 } grape_config;
 
 typedef struct grape_info {
@@ -110,7 +131,17 @@ typedef struct grape_info {
     double  expm_theta;            /* norm threshold below which no scaling/squaring is done */
     uint64_t workspace_bytes;      /* device bytes owned by the context                 */
     char    arch[32];              /* gcnArchName of the device                         */
+    /* ---- ABI v2 ---- */
+    int32_t n_devices;             /* GPUs this context spans (in-library sharding)      */
+    int32_t comm_size;             /* ranks of the RCCL communicator the all-reduce runs on (1 = none) */
+    int32_t comm_rank;
+    int32_t members_first_device;  /* members owned by device_ids[0] (the largest shard)  */
 } grape_info;
+
+/* Opaque RCCL bootstrap token (ncclUniqueId), see grape_comm_unique_id / grape_comm_attach. */
+typedef struct grape_comm_id {
+    char bytes[128];
+} grape_comm_id;
 
 typedef struct grape_ctx grape_ctx;
 
@@ -125,9 +156,20 @@ int grape_create(const grape_config *cfg, grape_ctx **out);
 /* Frees everything the context owns (Julia: finalizer). NULL is accepted. */
 int grape_destroy(grape_ctx *ctx);
 
+/* One process per GPU (the layout torch.distributed / MPI launchers produce): every rank creates a
+ * context for ITS contiguous member shard, rank 0 calls grape_comm_unique_id and ships the 128
+ * bytes to the other ranks by any means, then every rank calls grape_comm_attach.  From then on
+ * each grape_eval / grape_eval_device on that context ends in the one all-reduce(sum) of
+ * [G, F] over the ranks (RCCL over xGMI, enqueued on the evaluation's own stream) that completes
+ * src/solve.jl:171-191, so every rank returns the full-ensemble F and G.  Collective: all ranks
+ * must call grape_comm_attach, and later the evaluations, in the same order.
+ * librccl is loaded lazily (dlopen) by these two calls and by multi-device contexts only. */
+int grape_comm_unique_id(grape_comm_id *out);
+int grape_comm_attach(grape_ctx *ctx, const grape_comm_id *id, int32_t rank, int32_t n_ranks);
+
 /* Uploads the per-member operators once -- what init_ensemble (src/tools.jl:42-53) produces by
  * calling A_g(k), B_g(k), XiG(k), XtG(k), packed contiguously by the glue:
- *   A  c128 (n,n,E)     B  c128 (n,n,K,E)     Xi, Xt  c128 (n,n,E)     wts  f64 (E)
+ *   A  c128 (n,n,E)     B  c128 (n,n,K,E)     Xi, Xt  c128 (n,m,E)     wts  f64 (E)
  * (wts: EnsembleProblem.wts, src/problems.jl:40; pass {1.0} for a plain Problem). */
 int grape_set_operators(grape_ctx *ctx, const double *A, const double *B, const double *Xi,
                         const double *Xt, const double *wts);
@@ -144,7 +186,11 @@ int grape_eval(grape_ctx *ctx, const double *x, double *F, double *G);
  *   d_x   device (K,N) f64            d_fg  device f64[K*N + 1] = { G (K,N col-major), F }
  * This is the entry point the multi-GPU host layer uses: each rank evaluates its member shard
  * and a single all-reduce(sum) of d_fg over ranks completes src/solve.jl:171-191.
- * Nothing is synchronised; errors detectable at enqueue time are returned. */
+ * Nothing is synchronised; errors detectable at enqueue time are returned.
+ * Stream ordering: the context has ONE workspace.  The library orders a later grape_eval /
+ * grape_set_operators behind the last grape_eval_device (event wait), but two grape_eval_device
+ * calls on DIFFERENT streams must be ordered by the caller.  Multi-device contexts: d_x and d_fg
+ * live on device_ids[0]; the library fans x out to the other devices (peer copies). */
 int grape_eval_device(grape_ctx *ctx, const double *d_x, double *d_fg, void *stream);
 
 /* Extension beyond the reference (multi-start optimisation / line-search batches):

@@ -41,6 +41,9 @@ struct GrapeConfig
     waves_per_member::Int32
     expm_squarings::Int32
     max_batch::Int32
+    n_state_cols::Int32              # ABI v2: 0 = square states
+    n_devices::Int32                 # ABI v2: 0/1 = one GPU; 2..8 = in-library sharding + RCCL all-reduce
+    device_ids::NTuple{8,Int32}
 end
 
 sys_code(::UnitaryGate) = Int32(0)
@@ -52,6 +55,7 @@ Base.@kwdef struct GRAPE_HIP{OPTS}
     n_slices::Int
     isinplace::Bool = true           # selects the in-place / static formula variant (sign, sum order)
     device::Int = -1
+    devices::Vector{Int} = Int[]     # 2..8 HIP ordinals: the ensemble is sharded over them inside the library
     optim_options::OPTS = Optim.Options()
 end
 
@@ -63,8 +67,10 @@ mutable struct GrapeContext
         p1 = members[1]
         n = size(p1.A, 1)
         K, N, E = p1.n_controls, alg.n_slices, length(members)
+        nd = length(alg.devices)
+        ids = ntuple(i -> i <= nd ? Int32(alg.devices[i]) : Int32(0), 8)
         cfg = GrapeConfig(sys_code(p1.sys_type), alg.isinplace ? 0 : 1, n, K, N, E, Float64(p1.T),
-                          alg.device, 0, 0, 0, -1, 0)
+                          nd == 1 ? alg.devices[1] : alg.device, 0, 0, 0, -1, 0, 0, nd > 1 ? nd : 0, ids)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:grape_create, libgrape), Cint, (Ref{GrapeConfig}, Ref{Ptr{Cvoid}}), cfg, h)
         rc == 0 || error("grape_create: ", unsafe_string(ccall((:grape_last_error, libgrape), Cstring, (Ptr{Cvoid},), C_NULL)))

@@ -2,18 +2,32 @@
 //
 // Owns the device workspace (what init_GRAPE allocates on the Julia heap,
 // /root/reference/src/grape_tools.jl:4-16), uploads the operators once, and turns one call of
-// the reference's (F, G, x) closure (src/solve.jl:164-196) into: sweep kernel -> 2 reduce
-// launches, all asynchronous on one HIP stream.  There is NO CPU fallback: without a gfx950
-// device every entry point fails with GRAPE_ERR_NO_DEVICE.
+// the reference's (F, G, x) closure (src/solve.jl:164-196) into: sweep kernel -> reduce launch
+// [-> one RCCL all-reduce when the ensemble spans several GPUs], all asynchronous on one HIP
+// stream per device.  There is NO CPU fallback: without a gfx950 device every entry point fails
+// with GRAPE_ERR_NO_DEVICE.
+//
+// Multi-GPU lives here, behind the C ABI, in two shapes:
+//   * one process, n_devices GPUs (grape_config.n_devices/device_ids): the context is a GROUP of
+//     per-device shard contexts (contiguous blocks of ceil(E/G) members); ncclCommInitAll once,
+//     one grouped ncclAllReduce of K*N+1 doubles per evaluation;
+//   * one process per GPU (grape_comm_attach): the context is this rank's shard and joins a
+//     communicator built from a unique id the caller distributes (ncclCommInitRank).
+// librccl is dlopen'ed on first use, so single-GPU users never pay for loading it.
 #include "../../include/grape_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library itself is dlopen'ed
+
+#include <dlfcn.h>
+#include <time.h>
 
 #include <cmath>
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <utility>
 #include <string>
@@ -59,12 +73,27 @@ struct grape_ctx {
     hipStream_t stream = nullptr;
     bool ops_set = false, evaluated = false;
     bool unitary = false;         // all generators Hermitian -> unitary data flow
-    std::vector<hipEvent_t> ev;   // start/stop pairs of the sweep kernel
-    size_t ev_used = 0;
+    // GRAPE_FLAG_TIME_KERNELS: a fixed ring of start/stop event pairs around the sweep launches,
+    // created at grape_create; when the ring wraps, the oldest pair is folded into ev_total_ms
+    std::vector<hipEvent_t> ev;
+    uint64_t ev_issued = 0, ev_folded = 0;    // pairs
     double ev_total_ms = 0.0;
     int64_t ev_count = 0;
+    hipEvent_t ev_dev = nullptr;  // recorded after every grape_eval_device: orders the private stream behind it
+    bool dev_pending = false;
+    // collective: one all-reduce(sum) of [G, F] per evaluation (src/solve.jl:171-191 across GPUs)
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_size = 1;
+    // group context (n_devices >= 2, or GRAPE_FLAG_FORCE_COLLECTIVE): owns no workspace itself,
+    // only the per-device shard contexts
+    bool is_group = false;
+    std::vector<grape_ctx *> sub;
+    std::vector<int> sub_lo;      // first member of every shard
+    double timeout_s = 600.0;
     mutable std::string err;
 };
+
+static constexpr size_t kEventRing = 256;      // start/stop pairs kept before folding
 
 static thread_local std::string g_create_err = "";
 
@@ -82,13 +111,77 @@ static int fail(const grape_ctx *ctx, int code, const std::string &msg)
                         std::string(#call) + ": " + hipGetErrorString(e__));                   \
     } while (0)
 
+// ------------------------------------------------------------------------------------------
+// RCCL, loaded on demand (573 MB shared object: single-GPU users never touch it)
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+static RcclApi g_rccl;
+
+static RcclApi *rccl()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        RcclApi &api = g_rccl;
+        // a librccl already mapped into the process (e.g. the one a host framework bundles) is
+        // found by SONAME and reused
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *nm : names) {
+            api.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (!api.handle) {
+            const char *e = dlerror();
+            api.err = std::string("cannot load librccl: ") + (e ? e : "?");
+            return;
+        }
+        bool ok = true;
+        auto sym = [&](const char *name) -> void * {
+            void *p = dlsym(api.handle, name);
+            if (!p && ok) { ok = false; api.err = std::string("librccl lacks ") + name; }
+            return p;
+        };
+        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+        api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        if (!ok) api.handle = nullptr;
+    });
+    return g_rccl.handle ? &g_rccl : nullptr;
+}
+
+#define NCCL_TRY(ctx, call)                                                                    \
+    do {                                                                                       \
+        ncclResult_t r__ = (call);                                                             \
+        if (r__ != ncclSuccess)                                                                \
+            return fail(ctx, GRAPE_ERR_COMM, std::string(#call) + ": " + g_rccl.GetErrorString(r__)); \
+    } while (0)
+
 static size_t KN(const grape_ctx *c) { return (size_t)c->cfg.n_controls * c->cfg.n_slices; }
 
 static void free_all(grape_ctx *c)
 {
     if (!c) return;
+    for (grape_ctx *s : c->sub) free_all(s);
+    c->sub.clear();
+    if (c->is_group) { delete c; return; }
     (void)hipSetDevice(c->device);
+    if (c->comm && g_rccl.handle) (void)g_rccl.CommDestroy(c->comm);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->ev_dev) (void)hipEventDestroy(c->ev_dev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     (void)hipFree(c->d_ops); (void)hipFree(c->d_wts); (void)hipFree(c->d_x); (void)hipFree(c->d_fg);
     (void)hipFree(c->d_props); (void)hipFree(c->d_states); (void)hipFree(c->d_costates);
@@ -105,10 +198,8 @@ extern "C" const char *grape_last_error(const grape_ctx *ctx)
     return ctx ? ctx->err.c_str() : g_create_err.c_str();
 }
 
-extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
+static int validate_config(const grape_config *cfg)
 {
-    if (out) *out = nullptr;
-    if (!cfg || !out) return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: null argument");
     if (cfg->sys_type < GRAPE_UNITARY_GATE || cfg->sys_type > GRAPE_COHERENCE_TRANSFER)
         return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: bad sys_type");
     if (cfg->variant != GRAPE_VARIANT_INPLACE && cfg->variant != GRAPE_VARIANT_STATIC)
@@ -118,26 +209,42 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
                     "grape_create: n, n_controls, n_slices, n_ensemble must be positive");
     if (!(cfg->duration == cfg->duration))
         return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: duration is NaN");
+    if (cfg->n_state_cols < 0 || cfg->n_state_cols > cfg->n)
+        return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: n_state_cols must be in 0..n");
+    if (cfg->n_devices < 0 || cfg->n_devices > GRAPE_MAX_DEVICES)
+        return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: n_devices must be in 0..8");
+    if (cfg->max_batch < 0)
+        return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: max_batch is negative");
+    if ((uint64_t)cfg->n_controls * (uint64_t)cfg->n_slices >= (1ull << 31))
+        return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: n_controls * n_slices overflows int32");
     const int wmax = grape::sweep_small_max_waves(cfg->n);
     const int nt = grape::tile_count(cfg->n);
     if (wmax == 0 && nt == 0)
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED,
                     "grape_create: operator dimension n=" + std::to_string(cfg->n) +
                         " has no kernel in this build (supported: 2..32)");
+    const int m = cfg->n_state_cols ? cfg->n_state_cols : cfg->n;
+    if (m != cfg->n && cfg->sys_type != GRAPE_UNITARY_GATE)
+        return fail(nullptr, GRAPE_ERR_INVALID_ARG,
+                    "grape_create: n x m states with m < n need UnitaryGate (the sandwich X P' is not defined)");
+    if (m != cfg->n)
+        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: n_state_cols != n has no kernel in this build");
+    if (cfg->max_batch > 1 && wmax == 0)
+        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: max_batch > 1 needs operator dimension n <= 4 in this build");
+    if ((cfg->flags & GRAPE_FLAG_PHASE_STAMPS) && wmax == 0)
+        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: GRAPE_FLAG_PHASE_STAMPS exists for n <= 4 only (the tile kernels write no stamps)");
+    return GRAPE_OK;
+}
 
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
-        return fail(nullptr, GRAPE_ERR_NO_DEVICE, "grape_create: no HIP device visible");
-    int dev = cfg->device;
-    if (dev < 0) {
-        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    }
-    if (dev >= ndev)
-        return fail(nullptr, GRAPE_ERR_NO_DEVICE, "grape_create: device ordinal out of range");
+// one device, one contiguous shard of members: the workspace init_GRAPE allocates
+static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
+{
+    const int wmax = grape::sweep_small_max_waves(cfg->n);
+    const int nt = grape::tile_count(cfg->n);
     HIP_TRY(nullptr, hipSetDevice(dev));
     hipDeviceProp_t prop;
     HIP_TRY(nullptr, hipGetDeviceProperties(&prop, dev));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("GRAPE_HIP_ANY_ARCH"))
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, GRAPE_ERR_NO_DEVICE,
                     std::string("grape_create: device is ") + prop.gcnArchName +
                         ", this library carries gfx950 code only");
@@ -148,6 +255,10 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     c->device = dev;
     c->compute_units = prop.multiProcessorCount;
     std::snprintf(c->arch, sizeof(c->arch), "%s", prop.gcnArchName);
+    if (const char *ts = std::getenv("GRAPE_EVAL_TIMEOUT_S")) {
+        const double v = std::atof(ts);
+        if (v > 0) c->timeout_s = v;
+    }
 
     // time-axis decomposition: W waves per member, S slices per lane, S * 64 * W >= N.
     // Aim for one wave per SIMD across the chip; more waves per member only when the
@@ -155,13 +266,9 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     const int N = cfg->n_slices, E = cfg->n_ensemble;
     c->family = wmax > 0 ? 0 : 1;
     c->B = cfg->max_batch > 1 ? cfg->max_batch : 1;
-    if (c->B > 1 && c->family != 0) {
-        delete c;
-        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: max_batch > 1 needs operator dimension n <= 4 in this build");
-    }
     c->NT = nt;
     c->TSZ = (size_t)nt * nt * 256;
-    c->pack2 = (c->family == 1 && cfg->n <= 8 && !std::getenv("GRAPE_TILE_NOPACK") && !std::getenv("GRAPE_TILE_MFMA4"));
+    c->pack2 = (c->family == 1 && cfg->n <= 8 && !std::getenv("GRAPE_TILE_NOPACK"));
     c->EU = c->pack2 ? (E + 1) / 2 : E;
     int W = cfg->waves_per_member;
     if (W <= 0) {
@@ -222,12 +329,24 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     if (e == hipSuccess && c->family == 0 && !xg_in_lds)
         e = alloc((void **)&c->d_xg_scratch,
                   sizeof(double) * Bn * c->NB * ((size_t)c->MPB * c->LT * ((size_t)S * K + 1) + c->MPB));
-    if (e == hipSuccess && (cfg->flags & GRAPE_FLAG_PHASE_STAMPS))
-        e = alloc((void **)&c->d_stamps, sizeof(unsigned long long) * Bn * E * W * grape::kStampSlots);
+    if (e == hipSuccess && (cfg->flags & GRAPE_FLAG_PHASE_STAMPS)) {
+        const size_t sb = sizeof(unsigned long long) * Bn * E * W * grape::kStampSlots;
+        e = alloc((void **)&c->d_stamps, sb);
+        if (e == hipSuccess) e = hipMemset(c->d_stamps, 0, sb);
+    }
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, sizeof(double) * Q * Bn, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_fg, sizeof(double) * Q * Bn, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->d_h_fg, c->h_fg, 0);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_dev, hipEventDisableTiming);
+    if (e == hipSuccess && (cfg->flags & GRAPE_FLAG_TIME_KERNELS)) {
+        c->ev.reserve(2 * kEventRing);
+        for (size_t i = 0; i < 2 * kEventRing && e == hipSuccess; ++i) {
+            hipEvent_t evn = nullptr;
+            e = hipEventCreate(&evn);
+            if (e == hipSuccess) c->ev.push_back(evn);
+        }
+    }
     if (e != hipSuccess) {
         std::string msg = std::string("grape_create: device allocation failed: ") + hipGetErrorString(e);
         free_all(c);
@@ -237,12 +356,143 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     return GRAPE_OK;
 }
 
+// contiguous blocks of ceil(E / G) members; trailing devices may stay unused
+static void shard_plan(int E, int G, std::vector<int> &lo)
+{
+    const int per = (E + G - 1) / G;
+    lo.clear();
+    for (int s = 0; s < E; s += per) lo.push_back(s);
+    lo.push_back(E);
+}
+
+extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
+{
+    if (out) *out = nullptr;
+    if (!cfg || !out) return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: null argument");
+    int rc = validate_config(cfg);
+    if (rc) return rc;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, GRAPE_ERR_NO_DEVICE, "grape_create: no HIP device visible");
+    const bool group = cfg->n_devices >= 2 || (cfg->flags & GRAPE_FLAG_FORCE_COLLECTIVE);
+    std::vector<int> devs;
+    if (cfg->n_devices >= 2) {
+        for (int i = 0; i < cfg->n_devices; ++i) {
+            const int d = cfg->device_ids[i];
+            if (d < 0 || d >= ndev)
+                return fail(nullptr, GRAPE_ERR_NO_DEVICE,
+                            "grape_create: device_ids[" + std::to_string(i) + "]=" + std::to_string(d) +
+                                " but " + std::to_string(ndev) + " HIP device(s) are visible");
+            for (int j = 0; j < i; ++j)
+                if (cfg->device_ids[j] == d)
+                    return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: device_ids holds a duplicate");
+            devs.push_back(d);
+        }
+    } else {
+        int dev = cfg->n_devices == 1 && cfg->device < 0 ? cfg->device_ids[0] : cfg->device;
+        if (dev < 0) {
+            if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        }
+        if (dev >= ndev)
+            return fail(nullptr, GRAPE_ERR_NO_DEVICE, "grape_create: device ordinal out of range");
+        devs.push_back(dev);
+    }
+    if (!group)
+        return create_shard(cfg, devs[0], out);
+
+    if (cfg->max_batch > 1)
+        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: max_batch > 1 is single-device in this build");
+    if (cfg->flags & GRAPE_FLAG_PHASE_STAMPS)
+        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: GRAPE_FLAG_PHASE_STAMPS is single-device");
+    RcclApi *api = rccl();
+    if (!api) return fail(nullptr, GRAPE_ERR_COMM, "grape_create: " + g_rccl.err);
+
+    grape_ctx *g = new (std::nothrow) grape_ctx();
+    if (!g) return fail(nullptr, GRAPE_ERR_ALLOC, "grape_create: out of host memory");
+    g->cfg = *cfg;
+    g->is_group = true;
+    shard_plan(cfg->n_ensemble, (int)devs.size(), g->sub_lo);
+    const int G = (int)g->sub_lo.size() - 1;
+    for (int i = 0; i < G; ++i) {
+        grape_config sc = *cfg;
+        sc.n_ensemble = g->sub_lo[i + 1] - g->sub_lo[i];
+        sc.device = devs[i];
+        sc.n_devices = 0;
+        sc.flags &= ~GRAPE_FLAG_FORCE_COLLECTIVE;
+        grape_ctx *s = nullptr;
+        rc = create_shard(&sc, devs[i], &s);
+        if (rc) { free_all(g); return rc; }
+        g->sub.push_back(s);
+    }
+    std::vector<ncclComm_t> comms(G);
+    std::vector<int> used(devs.begin(), devs.begin() + G);
+    const ncclResult_t nr = api->CommInitAll(comms.data(), G, used.data());
+    if (nr != ncclSuccess) {
+        free_all(g);
+        return fail(nullptr, GRAPE_ERR_COMM, std::string("grape_create: ncclCommInitAll: ") + api->GetErrorString(nr));
+    }
+    for (int i = 0; i < G; ++i) {
+        g->sub[i]->comm = comms[i];
+        g->sub[i]->comm_rank = i;
+        g->sub[i]->comm_size = G;
+    }
+    const grape_ctx *s0 = g->sub[0];
+    g->device = s0->device; g->compute_units = s0->compute_units; g->family = s0->family;
+    g->S = s0->S; g->W = s0->W; g->LT = s0->LT; g->comm_size = G; g->timeout_s = s0->timeout_s;
+    std::snprintf(g->arch, sizeof(g->arch), "%s", s0->arch);
+    for (const grape_ctx *s : g->sub) g->bytes += s->bytes;
+    *out = g;
+    return GRAPE_OK;
+}
+
 extern "C" int grape_destroy(grape_ctx *ctx)
 {
     if (!ctx) return GRAPE_OK;
-    (void)hipSetDevice(ctx->device);
-    (void)hipDeviceSynchronize();
+    if (ctx->is_group) {
+        for (grape_ctx *s : ctx->sub) {
+            (void)hipSetDevice(s->device);
+            (void)hipDeviceSynchronize();
+        }
+    } else {
+        (void)hipSetDevice(ctx->device);
+        (void)hipDeviceSynchronize();
+    }
     free_all(ctx);
+    return GRAPE_OK;
+}
+
+extern "C" int grape_comm_unique_id(grape_comm_id *out)
+{
+    if (!out) return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_comm_unique_id: null argument");
+    static_assert(sizeof(grape_comm_id) == sizeof(ncclUniqueId), "grape_comm_id must hold an ncclUniqueId");
+    RcclApi *api = rccl();
+    if (!api) return fail(nullptr, GRAPE_ERR_COMM, "grape_comm_unique_id: " + g_rccl.err);
+    ncclUniqueId id;
+    NCCL_TRY(nullptr, api->GetUniqueId(&id));
+    std::memcpy(out->bytes, &id, sizeof(id));
+    return GRAPE_OK;
+}
+
+extern "C" int grape_comm_attach(grape_ctx *c, const grape_comm_id *id, int32_t rank, int32_t n_ranks)
+{
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return fail(c, GRAPE_ERR_INVALID_ARG, "grape_comm_attach: bad rank / n_ranks / id");
+    if (c->is_group)
+        return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_comm_attach: the context already spans devices in-process");
+    if (c->comm)
+        return fail(c, GRAPE_ERR_INVALID_ARG, "grape_comm_attach: a communicator is already attached");
+    if (c->B > 1)
+        return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_comm_attach: max_batch > 1 is single-device in this build");
+    RcclApi *api = rccl();
+    if (!api) return fail(c, GRAPE_ERR_COMM, "grape_comm_attach: " + g_rccl.err);
+    HIP_TRY(c, hipSetDevice(c->device));
+    ncclUniqueId nid;
+    std::memcpy(&nid, id->bytes, sizeof(nid));
+    NCCL_TRY(c, api->CommInitRank(&c->comm, n_ranks, nid, rank));
+    c->comm_rank = rank;
+    c->comm_size = n_ranks;
     return GRAPE_OK;
 }
 
@@ -252,6 +502,18 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     if (!c) return GRAPE_ERR_INVALID_ARG;
     if (!A || !B || !Xi || !Xt || !wts)
         return fail(c, GRAPE_ERR_INVALID_ARG, "grape_set_operators: null argument");
+    if (c->is_group) {                                       // hand every device its contiguous member block
+        const size_t nn2 = 2 * (size_t)c->cfg.n * c->cfg.n, Kc = c->cfg.n_controls;
+        for (size_t i = 0; i < c->sub.size(); ++i) {
+            const size_t lo = (size_t)c->sub_lo[i];
+            const int rc = grape_set_operators(c->sub[i], A + lo * nn2, B + lo * Kc * nn2, Xi + lo * nn2,
+                                               Xt + lo * nn2, wts + lo);
+            if (rc) return fail(c, rc, c->sub[i]->err);
+        }
+        c->ops_set = true;
+        c->evaluated = false;
+        return GRAPE_OK;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t nn = (size_t)c->cfg.n * c->cfg.n, K = c->cfg.n_controls, E = c->cfg.n_ensemble;
     std::vector<double> packed;
@@ -310,8 +572,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     }
     // Data-flow choice: if every generator is Hermitian to rounding, every propagator is
     // unitary and the sweep can carry M_t = P_t' M_{t+1} P_t instead of storing X_t.
-    bool herm = !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) &&
-                !(c->family == 1 && std::getenv("GRAPE_TILE_MFMA4"));     // the 4x4x4 experiment has no unitary flow
+    bool herm = !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES));
     const int n = c->cfg.n;
     for (size_t k = 0; k < E && herm; ++k) {
         for (size_t m = 0; m < K + 1 && herm; ++m) {
@@ -331,6 +592,10 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     if (!herm && !c->d_states) {
         c->bytes += sizeof(double2) * c->ws_elems * c->B;
         HIP_TRY(c, hipMalloc((void **)&c->d_states, sizeof(double2) * c->ws_elems * c->B));
+    }
+    if (c->dev_pending) {                                    // an evaluation may still run on a caller's stream
+        HIP_TRY(c, hipEventSynchronize(c->ev_dev));
+        c->dev_pending = false;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->d_ops, packed.data(), sizeof(double) * packed.size(), hipMemcpyHostToDevice));
@@ -359,18 +624,27 @@ static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream)
     p.variant = c->cfg.variant;
     p.dt = c->cfg.duration / c->cfg.n_slices;
     p.unitary = c->unitary ? 1 : 0;
-    // default: the v_mfma_f64_16x16x4 kernels (sweep_tile.hip).  GRAPE_TILE_MFMA4=1 selects the
-    // v_mfma_f64_4x4x4_4b variant (sweep_tile4.hip): correct, but measured 15-50 % slower so far.
-    static const bool mfma4 = std::getenv("GRAPE_TILE_MFMA4") != nullptr;
-    if (!mfma4)
-        HIP_TRY(c, grape::launch_sweep_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE,
-                                            c->d_costates != nullptr, p, stream));
-    else
-        HIP_TRY(c, grape::launch_sweep_tile4(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE,
-                                             c->d_costates != nullptr, p, stream));
+    HIP_TRY(c, grape::launch_sweep_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE,
+                                        c->d_costates != nullptr, p, stream));
     return GRAPE_OK;
 }
 
+// folds the `count` oldest outstanding event pairs into ev_total_ms (synchronises their stop events)
+static int fold_events(grape_ctx *c, uint64_t count)
+{
+    for (uint64_t i = 0; i < count && c->ev_folded < c->ev_issued; ++i) {
+        const size_t slot = (size_t)(c->ev_folded % kEventRing);
+        HIP_TRY(c, hipEventSynchronize(c->ev[2 * slot + 1]));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2 * slot], c->ev[2 * slot + 1]));
+        c->ev_total_ms += ms;
+        c->ev_count += 1;
+        c->ev_folded += 1;
+    }
+    return GRAPE_OK;
+}
+
+// one shard: sweep kernel(s) + the on-device ensemble reduction into d_fg; nothing is synchronised
 static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream_t stream, int n_x = 1)
 {
     SweepParams p{};
@@ -399,16 +673,14 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     const bool timed = (c->cfg.flags & GRAPE_FLAG_TIME_KERNELS) != 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
-        if (c->ev_used + 2 > c->ev.size()) {
-            for (int i = 0; i < 2; ++i) {
-                hipEvent_t e;
-                HIP_TRY(c, hipEventCreate(&e));
-                c->ev.push_back(e);
-            }
+        if (c->ev_issued - c->ev_folded == kEventRing) {   // ring full: fold the oldest pair (long finished)
+            int rc = fold_events(c, 1);
+            if (rc) return rc;
         }
-        e0 = c->ev[c->ev_used];
-        e1 = c->ev[c->ev_used + 1];
-        c->ev_used += 2;
+        const size_t slot = (size_t)(c->ev_issued % kEventRing);
+        e0 = c->ev[2 * slot];
+        e1 = c->ev[2 * slot + 1];
+        c->ev_issued += 1;
         HIP_TRY(c, hipEventRecord(e0, stream));
     }
     if (c->family == 0) {
@@ -428,37 +700,174 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     return GRAPE_OK;
 }
 
+// in-place (or send -> recv) all-reduce of one shard's [G, F] on `stream`
+static int enqueue_allreduce(grape_ctx *c, const double *send, double *recv, hipStream_t stream)
+{
+    NCCL_TRY(c, g_rccl.AllReduce(send, recv, KN(c) + 1, ncclDouble, ncclSum, c->comm, stream));
+    return GRAPE_OK;
+}
+
+// Blocks until `stream` has drained: busy polls for a few hundred microseconds (the optimiser is
+// sequential, so per-call latency is what the caller sees), then sleeps between polls; gives up
+// after c->timeout_s (device presumed hung).
+static int wait_stream(grape_ctx *c, hipStream_t stream)
+{
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    auto elapsed = [&]() {
+        timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        return (double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec);
+    };
+    long nap_ns = 20000;
+    for (unsigned it = 0;; ++it) {
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) return GRAPE_OK;
+        if (q != hipErrorNotReady) HIP_TRY(c, q);
+        if ((it & 63) != 63) continue;
+        const double el = elapsed();
+        if (el < 500e-6) continue;                          // spin phase
+        if (el > c->timeout_s)
+            return fail(c, GRAPE_ERR_TIMEOUT, "evaluation did not finish within " + std::to_string(c->timeout_s) +
+                                                  " s (GRAPE_EVAL_TIMEOUT_S): device presumed hung");
+        timespec nap{0, nap_ns};
+        nanosleep(&nap, nullptr);
+        if (nap_ns < 1000000) nap_ns *= 2;
+    }
+}
+
+// x (host) -> this shard's d_x, evaluation into `target`, all on the shard's private stream
+static int shard_enqueue_host(grape_ctx *s, const double *x, int n_x, double *target)
+{
+    HIP_TRY(s, hipSetDevice(s->device));
+    if (s->dev_pending) {                                   // order behind the last grape_eval_device
+        HIP_TRY(s, hipStreamWaitEvent(s->stream, s->ev_dev, 0));
+        s->dev_pending = false;
+    }
+    const size_t kn = KN(s);
+    std::memcpy(s->h_stage, x, sizeof(double) * kn * n_x);
+    HIP_TRY(s, hipMemcpyAsync(s->d_x, s->h_stage, sizeof(double) * kn * n_x, hipMemcpyHostToDevice, s->stream));
+    return enqueue_eval(s, s->d_x, target, s->stream, n_x);
+}
+
+static int group_fail(grape_ctx *g, grape_ctx *s, int rc) { return fail(g, rc, s->err); }
+
 extern "C" int grape_eval_device(grape_ctx *c, const double *d_x, double *d_fg, void *stream)
 {
     if (!c) return GRAPE_ERR_INVALID_ARG;
     if (!d_x || !d_fg) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval_device: null argument");
     if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, "grape_eval_device: operators not set");
-    HIP_TRY(c, hipSetDevice(c->device));
-    return enqueue_eval(c, d_x, d_fg, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (!c->is_group) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        int rc = enqueue_eval(c, d_x, d_fg, st);
+        if (rc) return rc;
+        if (c->comm) {
+            rc = enqueue_allreduce(c, d_fg, d_fg, st);
+            if (rc) return rc;
+        }
+        HIP_TRY(c, hipEventRecord(c->ev_dev, st));
+        c->dev_pending = true;
+        return GRAPE_OK;
+    }
+    // group: d_x, d_fg live on the first device; fan x out, evaluate every shard, one grouped all-reduce
+    grape_ctx *s0 = c->sub[0];
+    const size_t bytes = sizeof(double) * KN(c);
+    HIP_TRY(c, hipSetDevice(s0->device));
+    if (c->sub.size() > 1) HIP_TRY(c, hipEventRecord(s0->ev_dev, st));       // x is ready at this point of `st`
+    int rc = enqueue_eval(s0, d_x, s0->d_fg, st);
+    if (rc) return group_fail(c, s0, rc);
+    for (size_t i = 1; i < c->sub.size(); ++i) {
+        grape_ctx *s = c->sub[i];
+        HIP_TRY(c, hipSetDevice(s->device));
+        HIP_TRY(c, hipStreamWaitEvent(s->stream, s0->ev_dev, 0));
+        HIP_TRY(c, hipMemcpyPeerAsync(s->d_x, s->device, d_x, s0->device, bytes, s->stream));
+        rc = enqueue_eval(s, s->d_x, s->d_fg, s->stream);
+        if (rc) return group_fail(c, s, rc);
+    }
+    NCCL_TRY(c, g_rccl.GroupStart());
+    for (size_t i = 0; i < c->sub.size(); ++i) {
+        grape_ctx *s = c->sub[i];
+        const ncclResult_t r = g_rccl.AllReduce(s->d_fg, i == 0 ? d_fg : s->d_fg, KN(c) + 1, ncclDouble, ncclSum,
+                                                s->comm, i == 0 ? st : s->stream);
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            return fail(c, GRAPE_ERR_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+        }
+    }
+    NCCL_TRY(c, g_rccl.GroupEnd());
+    HIP_TRY(c, hipSetDevice(s0->device));
+    HIP_TRY(c, hipEventRecord(s0->ev_dev, st));
+    s0->dev_pending = true;
+    c->evaluated = true;
+    return GRAPE_OK;
+}
+
+// host -> device(s) -> host: the (F, G, x) closure body.  n_x > 1: grape_eval_batch.
+static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *G, const char *who)
+{
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (!x) return fail(c, GRAPE_ERR_INVALID_ARG, std::string(who) + ": x is null");
+    if (n_x < 1 || n_x > c->B)
+        return fail(c, GRAPE_ERR_INVALID_ARG, std::string(who) + ": n_x must be in 1..grape_config.max_batch");
+    if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, std::string(who) + ": operators not set");
+    const size_t kn = KN(c), Q = kn + 1;
+    grape_ctx *lead = c->is_group ? c->sub[0] : c;
+    int rc;
+    if (!c->is_group && !c->comm) {
+        // single GPU: the final reduce kernel writes its result straight into mapped pinned host
+        // memory (no D2H copy node) and the host polls the stream
+        rc = shard_enqueue_host(c, x, n_x, c->d_h_fg);
+        if (rc) return rc;
+    } else {
+        if (c->is_group) {
+            for (grape_ctx *s : c->sub) {
+                rc = shard_enqueue_host(s, x, 1, s->d_fg);
+                if (rc) return group_fail(c, s, rc);
+            }
+            NCCL_TRY(c, g_rccl.GroupStart());
+            for (grape_ctx *s : c->sub) {
+                const ncclResult_t r = g_rccl.AllReduce(s->d_fg, s->d_fg, Q, ncclDouble, ncclSum, s->comm, s->stream);
+                if (r != ncclSuccess) {
+                    (void)g_rccl.GroupEnd();
+                    return fail(c, GRAPE_ERR_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+                }
+            }
+            NCCL_TRY(c, g_rccl.GroupEnd());
+        } else {
+            rc = shard_enqueue_host(c, x, 1, c->d_fg);
+            if (rc) return rc;
+            rc = enqueue_allreduce(c, c->d_fg, c->d_fg, c->stream);
+            if (rc) return rc;
+        }
+        HIP_TRY(c, hipSetDevice(lead->device));
+        HIP_TRY(c, grape::launch_copy(lead->d_fg, lead->d_h_fg, (int)Q, lead->stream));
+    }
+    if (c->is_group) {
+        for (grape_ctx *s : c->sub) {
+            rc = wait_stream(s, s->stream);
+            if (rc) return group_fail(c, s, rc);
+        }
+        c->evaluated = true;
+    } else {
+        rc = wait_stream(c, c->stream);
+        if (rc) return rc;
+    }
+    for (int b = 0; b < n_x; ++b) {
+        if (G) std::memcpy(G + (size_t)b * kn, lead->h_fg + (size_t)b * Q, sizeof(double) * kn);
+        if (F) F[b] = lead->h_fg[(size_t)b * Q + kn];
+    }
+    return GRAPE_OK;
 }
 
 extern "C" int grape_eval(grape_ctx *c, const double *x, double *F, double *G)
 {
-    if (!c) return GRAPE_ERR_INVALID_ARG;
-    if (!x) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval: x is null");
-    if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, "grape_eval: operators not set");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const size_t kn = KN(c);
-    std::memcpy(c->h_stage, x, sizeof(double) * kn);
-    HIP_TRY(c, hipMemcpyAsync(c->d_x, c->h_stage, sizeof(double) * kn, hipMemcpyHostToDevice, c->stream));
-    // the final reduce kernel writes its 16 KB result straight into mapped pinned host memory (no
-    // D2H copy node), and the host polls the stream instead of sleeping on an interrupt: the
-    // optimiser is sequential, so per-call latency is what the Julia side sees
-    int rc = enqueue_eval(c, c->d_x, c->d_h_fg, c->stream);
-    if (rc) return rc;
-    for (;;) {
-        const hipError_t q = hipStreamQuery(c->stream);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) HIP_TRY(c, q);
-    }
-    if (G) std::memcpy(G, c->h_fg, sizeof(double) * kn);
-    if (F) *F = c->h_fg[kn];
-    return GRAPE_OK;
+    return eval_host(c, 1, x, F, G, "grape_eval");
+}
+
+extern "C" int grape_eval_batch(grape_ctx *c, int32_t n_x, const double *x, double *F, double *G)
+{
+    return eval_host(c, n_x, x, F, G, "grape_eval_batch");
 }
 
 extern "C" int grape_eval_batch_device(grape_ctx *c, int32_t n_x, const double *d_x, double *d_fg, void *stream)
@@ -468,39 +877,39 @@ extern "C" int grape_eval_batch_device(grape_ctx *c, int32_t n_x, const double *
     if (n_x < 1 || n_x > c->B)
         return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval_batch_device: n_x must be in 1..grape_config.max_batch");
     if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, "grape_eval_batch_device: operators not set");
-    HIP_TRY(c, hipSetDevice(c->device));
-    return enqueue_eval(c, d_x, d_fg, (hipStream_t)stream, n_x);
+    if (n_x == 1) return grape_eval_device(c, d_x, d_fg, stream);
+    HIP_TRY(c, hipSetDevice(c->device));                    // n_x > 1 implies a single-device context
+    int rc = enqueue_eval(c, d_x, d_fg, (hipStream_t)stream, n_x);
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_dev, (hipStream_t)stream));
+    c->dev_pending = true;
+    return GRAPE_OK;
 }
 
-extern "C" int grape_eval_batch(grape_ctx *c, int32_t n_x, const double *x, double *F, double *G)
+// group accessors: the shard that owns `member`
+static grape_ctx *owner_of(grape_ctx *c, int member, int *local)
 {
-    if (!c) return GRAPE_ERR_INVALID_ARG;
-    if (!x) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval_batch: x is null");
-    if (n_x < 1 || n_x > c->B)
-        return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval_batch: n_x must be in 1..grape_config.max_batch");
-    if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, "grape_eval_batch: operators not set");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const size_t kn = KN(c), Q = kn + 1;
-    std::memcpy(c->h_stage, x, sizeof(double) * kn * n_x);
-    HIP_TRY(c, hipMemcpyAsync(c->d_x, c->h_stage, sizeof(double) * kn * n_x, hipMemcpyHostToDevice, c->stream));
-    int rc = enqueue_eval(c, c->d_x, c->d_h_fg, c->stream, n_x);
-    if (rc) return rc;
-    for (;;) {
-        const hipError_t q = hipStreamQuery(c->stream);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) HIP_TRY(c, q);
-    }
-    for (int b = 0; b < n_x; ++b) {
-        if (G) std::memcpy(G + (size_t)b * kn, c->h_fg + (size_t)b * Q, sizeof(double) * kn);
-        if (F) F[b] = c->h_fg[(size_t)b * Q + kn];
-    }
-    return GRAPE_OK;
+    for (size_t i = 0; i < c->sub.size(); ++i)
+        if (member >= c->sub_lo[i] && member < c->sub_lo[i + 1]) {
+            *local = member - c->sub_lo[i];
+            return c->sub[i];
+        }
+    return nullptr;
 }
 
 extern "C" int grape_get_member_results(grape_ctx *c, double *foms, double *grads)
 {
     if (!c) return GRAPE_ERR_INVALID_ARG;
     if (!c->evaluated) return fail(c, GRAPE_ERR_NOT_READY, "grape_get_member_results: no evaluation yet");
+    if (c->is_group) {
+        const size_t kn = KN(c);
+        for (size_t i = 0; i < c->sub.size(); ++i) {
+            const size_t lo = (size_t)c->sub_lo[i];
+            const int rc = grape_get_member_results(c->sub[i], foms ? foms + lo : nullptr, grads ? grads + lo * kn : nullptr);
+            if (rc) return group_fail(c, c->sub[i], rc);
+        }
+        return GRAPE_OK;
+    }
     if (!c->d_member_out)
         return fail(c, GRAPE_ERR_NOT_READY, "grape_get_member_results: create the context with GRAPE_FLAG_MEMBER_RESULTS");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -556,6 +965,12 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
     if (!c->evaluated) return fail(c, GRAPE_ERR_NOT_READY, "grape_get_trajectory: no evaluation yet");
     if (member < 0 || member >= c->cfg.n_ensemble)
         return fail(c, GRAPE_ERR_INVALID_ARG, "grape_get_trajectory: member out of range");
+    if (c->is_group) {
+        int local = 0;
+        grape_ctx *s = owner_of(c, member, &local);
+        const int rc = grape_get_trajectory(s, local, props, states, costates);
+        return rc ? group_fail(c, s, rc) : GRAPE_OK;
+    }
     if (costates && !c->d_costates)
         return fail(c, GRAPE_ERR_NOT_READY,
                     "grape_get_trajectory: costates need GRAPE_FLAG_KEEP_COSTATES at grape_create");
@@ -624,15 +1039,24 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
 extern "C" int grape_get_kernel_time(grape_ctx *c, double *total_ms, int64_t *launches, int32_t reset)
 {
     if (!c) return GRAPE_ERR_INVALID_ARG;
-    HIP_TRY(c, hipSetDevice(c->device));
-    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
-        HIP_TRY(c, hipEventSynchronize(c->ev[i + 1]));
-        float ms = 0.f;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
-        c->ev_total_ms += ms;
-        c->ev_count += 1;
+    if (c->is_group) {                                       // the shards run concurrently: report the slowest device
+        double worst = 0.0;
+        int64_t n = 0;
+        for (grape_ctx *s : c->sub) {
+            double ms = 0.0;
+            int64_t cnt = 0;
+            const int rc = grape_get_kernel_time(s, &ms, &cnt, reset);
+            if (rc) return group_fail(c, s, rc);
+            if (ms > worst) worst = ms;
+            n = cnt;
+        }
+        if (total_ms) *total_ms = worst;
+        if (launches) *launches = n;
+        return GRAPE_OK;
     }
-    c->ev_used = 0;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = fold_events(c, c->ev_issued - c->ev_folded);
+    if (rc) return rc;
     if (total_ms) *total_ms = c->ev_total_ms;
     if (launches) *launches = c->ev_count;
     if (reset) { c->ev_total_ms = 0.0; c->ev_count = 0; }
@@ -642,7 +1066,7 @@ extern "C" int grape_get_kernel_time(grape_ctx *c, double *total_ms, int64_t *la
 extern "C" int grape_get_phase_stamps(grape_ctx *c, uint64_t *out, int64_t capacity, int64_t *count)
 {
     if (!c) return GRAPE_ERR_INVALID_ARG;
-    if (!c->d_stamps || !c->evaluated)
+    if (c->is_group || !c->d_stamps || !c->evaluated)
         return fail(c, GRAPE_ERR_NOT_READY, "grape_get_phase_stamps: needs GRAPE_FLAG_PHASE_STAMPS and an evaluation");
     const int64_t total = (int64_t)c->cfg.n_ensemble * c->W * grape::kStampSlots;
     if (count) *count = total;
@@ -670,5 +1094,10 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
     info->expm_theta = 0.05;
     info->workspace_bytes = c->bytes;
     std::snprintf(info->arch, sizeof(info->arch), "%s", c->arch);
+    info->n_devices = c->is_group ? (int32_t)c->sub.size() : 1;
+    info->comm_size = c->comm_size;
+    info->comm_rank = c->comm_rank;
+    info->members_first_device = c->is_group ? c->sub[0]->cfg.n_ensemble : c->cfg.n_ensemble;
+    if (c->is_group) info->unitary_flow = c->sub[0]->unitary ? 1 : 0;
     return GRAPE_OK;
 }

@@ -65,8 +65,6 @@ struct TileParams {
 };
 int tile_count(int n);    // NT for this n (0: not a tile-family size)
 hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
-// same contract on v_mfma_f64_4x4x4_4b (sweep_tile4.hip): the default for the tile family
-hipError_t launch_sweep_tile4(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
 
 // G[q] = sum_k w_k member_out[k][q]  for q in [0, Q)  (Q = K*N + 1; the last entry is F).
 // partial: scratch of ksplit*Q doubles.  Deterministic (fixed summation tree).
@@ -76,5 +74,9 @@ int reduce_ksplit(int E);
 // fg[q] = sum_b rows[b][q] over NB already-weighted rows (one launch, fixed summation tree).
 // n_x > 1: independent reductions, rows [x*NB, (x+1)*NB) -> fg + x*Q
 hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, int n_x, hipStream_t stream);
+
+// dst[i] = src[i], i < n: moves the all-reduced [G, F] into mapped pinned host memory (one small launch
+// instead of a D2H copy node: the host polls the stream)
+hipError_t launch_copy(const double *src, double *dst, int n, hipStream_t stream);
 
 }  // namespace grape

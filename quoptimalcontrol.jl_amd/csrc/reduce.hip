@@ -88,6 +88,19 @@ hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, int
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void copy_kernel(const double *__restrict__ src, double *__restrict__ dst, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        dst[i] = src[i];
+}
+
+hipError_t launch_copy(const double *src, double *dst, int n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(copy_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, dst, n);
+    return hipGetLastError();
+}
+
 int reduce_ksplit(int E)
 {
     // enough blocks to cover the chip (32 q-tiles at C3) without making stage 2 long

@@ -3,14 +3,22 @@
 The ensemble members are independent given the shared controls x
 (/root/reference/src/solve.jl:166-187); the only coupling is the weighted sum of F and G
 (:171-186, :191).  Each rank owns a contiguous block of members, evaluates it with its own
-libgrape_hip context into a device buffer fg = [G (K*N), F], and a single
-all_reduce(SUM) of those K*N+1 doubles over RCCL/xGMI completes the closure.  16 KB at the
-headline config: latency-bound, one collective per optimiser step, nothing else crosses GPUs.
+libgrape_hip context, and a single all-reduce(SUM) of the K*N+1 doubles [G, F] over RCCL/xGMI
+completes the closure.  16 KB at the headline config: latency-bound, one collective per optimiser
+step, nothing else crosses GPUs.
+
+Where the collective runs (`collective=`):
+  "lib"    (product default) inside libgrape_hip.so: rank 0 creates an RCCL unique id
+           (grape_comm_unique_id), torch.distributed only carries those 128 bytes to the other ranks,
+           every rank calls grape_comm_attach, and from then on grape_eval / grape_eval_device end
+           in ncclAllReduce on the evaluation's own stream.  grape_eval(x) is then the complete
+           host -> N GPUs -> host closure on every rank.
+  "torch"  torch.distributed.all_reduce on the fg tensor (backend "nccl" == RCCL on ROCm; "gloo" in
+           the CPU tests, where a stand-in evaluator replaces the GPU).  Fallback when a rank cannot
+           join the library communicator (e.g. fewer members than ranks).
 
 torch is used for what it is here for: device buffers, the current HIP stream and
-torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).  The evaluator
-is injectable so the world_size=2 gloo tests can exercise the sharding/reduction logic on CPU
-tensors with a stand-in local evaluator; the product always passes GrapeEngine.
+torch.distributed as the control plane.
 """
 import numpy as np
 
@@ -22,13 +30,30 @@ def shard_bounds(E, world_size, rank):
     return lo, min(E, lo + per)
 
 
+def _bcast_bytes(dist, payload, nbytes, group):
+    """rank 0's `payload` (bytes) to every rank, as a CPU uint8 tensor (gloo) or a device tensor (nccl)."""
+    import torch
+
+    backend = dist.get_backend(group)
+    buf = torch.zeros(nbytes, dtype=torch.uint8)
+    if payload is not None:
+        buf[:] = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+    if "gloo" in backend:
+        dist.broadcast(buf, src=0, group=group)
+        return bytes(buf.numpy().tobytes())
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dbuf = buf.to(dev)
+    dist.broadcast(dbuf, src=0, group=group)
+    return bytes(dbuf.cpu().numpy().tobytes())
+
+
 class ShardedGrape:
     """Evaluate F, G of an ensemble split over the ranks of a torch.distributed group.
 
     make_local(lo, hi) -> object with eval_device(d_x_ptr, d_fg_ptr, stream) for members [lo, hi)
     (or None when the shard is empty).  `device` is a torch.device."""
 
-    def __init__(self, E, K, N, make_local, device, group=None, force_collective=False):
+    def __init__(self, E, K, N, make_local, device, group=None, force_collective=False, collective="torch"):
         import torch
         import torch.distributed as dist
 
@@ -43,6 +68,35 @@ class ShardedGrape:
         self.device = device
         self.local = make_local(self.lo, self.hi) if self.hi > self.lo else None
         self.fg = torch.zeros(K * N + 1, dtype=torch.float64, device=device)
+        self.collective = "torch"
+        self.comm_size = self.world
+        if collective == "lib" and (self.world > 1 or force_collective):
+            self._attach_library_communicator()
+
+    def _attach_library_communicator(self):
+        """Every rank joins an RCCL communicator owned by libgrape_hip.so; all ranks agree on the
+        outcome (one failed rank sends everybody to the torch.distributed fallback)."""
+        torch, dist = self.torch, self.dist
+        ok = 1
+        try:
+            if self.local is None or not hasattr(self.local, "comm_attach"):
+                raise RuntimeError("this rank owns no members (E < world size)")
+            token = self.local.comm_unique_id() if self.rank == 0 else None
+            if self.distributed and self.world > 1:
+                token = _bcast_bytes(dist, token, 128, self.group)
+            self.local.comm_attach(token, self.rank, self.world)
+        except Exception as exc:                      # noqa: BLE001 -- any failure means "fall back", consistently
+            self.attach_error = repr(exc)
+            ok = 0
+        if self.distributed and self.world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32)
+            if "gloo" not in dist.get_backend(self.group):
+                flag = flag.to(self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            ok = int(flag.item())
+        if ok:
+            self.collective = "lib"
+            self.comm_size = self.local.info["comm_size"]
 
     def eval_device(self, x_dev):
         """x_dev: float64 tensor holding x as (K,N) column-major, i.e. shape (N, K) contiguous.
@@ -53,12 +107,15 @@ class ShardedGrape:
             self.local.eval_device(x_dev.data_ptr(), self.fg.data_ptr(), stream)
         else:
             self.fg.zero_()
-        if self.world > 1 or self.force_collective:
+        if self.collective == "torch" and (self.world > 1 or self.force_collective):
             self.dist.all_reduce(self.fg, op=self.dist.ReduceOp.SUM, group=self.group)
         return self.fg
 
     def eval(self, x):
-        """Host convenience: x (K,N) numpy -> (F, G (K,N))."""
+        """Host -> GPUs -> host: x (K,N) numpy -> (F, G (K,N)), the full-ensemble closure on every rank."""
+        if self.collective == "lib" or (self.world == 1 and not self.force_collective and self.local is not None
+                                        and hasattr(self.local, "eval")):
+            return self.local.eval(x)                 # grape_eval: the all-reduce happens inside the library
         torch = self.torch
         xd = torch.as_tensor(np.ascontiguousarray(np.asarray(x, float).T), device=self.device)
         fg = self.eval_device(xd)
@@ -73,7 +130,7 @@ class ShardedGrape:
             self.local = None
 
 
-def sharded_engine(workload, device, group=None, force_collective=False, **engine_kw):
+def sharded_engine(workload, device, group=None, force_collective=False, collective="lib", **engine_kw):
     """The product wiring: every rank builds a GrapeEngine for its block of `workload`."""
     from .engine import GrapeEngine
 
@@ -84,4 +141,4 @@ def sharded_engine(workload, device, group=None, force_collective=False, **engin
         return GrapeEngine(w.sys_type, w.A[lo:hi], w.B[lo:hi], w.Xi[lo:hi], w.Xt[lo:hi], w.wts[lo:hi],
                            w.T, w.N, device=dev_index, **engine_kw)
 
-    return ShardedGrape(w.E, w.K, w.N, make_local, device, group, force_collective)
+    return ShardedGrape(w.E, w.K, w.N, make_local, device, group, force_collective, collective)

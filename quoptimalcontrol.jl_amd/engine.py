@@ -24,13 +24,17 @@ FLAG_TIME_KERNELS = 2
 FLAG_PHASE_STAMPS = 4
 FLAG_FORCE_GENERAL = 8
 FLAG_MEMBER_RESULTS = 16
+FLAG_FORCE_COLLECTIVE = 32
+MAX_DEVICES = 8
+ABI_VERSION = 2
 
 STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID_ARG", -2: "GRAPE_ERR_UNSUPPORTED",
           -3: "GRAPE_ERR_NO_DEVICE", -4: "GRAPE_ERR_HIP", -5: "GRAPE_ERR_NOT_READY",
-          -6: "GRAPE_ERR_ALLOC"}
+          -6: "GRAPE_ERR_ALLOC", -7: "GRAPE_ERR_TIMEOUT", -8: "GRAPE_ERR_COMM"}
 
 # every symbol include/grape_hip.h declares
 EXPORTS = ["grape_abi_version", "grape_create", "grape_destroy", "grape_set_operators",
+           "grape_comm_unique_id", "grape_comm_attach",
            "grape_eval", "grape_eval_device", "grape_eval_batch", "grape_eval_batch_device",
            "grape_get_member_results", "grape_get_trajectory",
            "grape_get_kernel_time", "grape_get_phase_stamps", "grape_get_info", "grape_last_error"]
@@ -47,14 +51,21 @@ class GrapeConfig(C.Structure):
                 ("n_controls", C.c_int32), ("n_slices", C.c_int32), ("n_ensemble", C.c_int32),
                 ("duration", C.c_double), ("device", C.c_int32), ("flags", C.c_int32),
                 ("slices_per_lane", C.c_int32), ("waves_per_member", C.c_int32),
-                ("expm_squarings", C.c_int32), ("max_batch", C.c_int32)]
+                ("expm_squarings", C.c_int32), ("max_batch", C.c_int32),
+                ("n_state_cols", C.c_int32), ("n_devices", C.c_int32), ("device_ids", C.c_int32 * MAX_DEVICES)]
 
 
 class GrapeInfo(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("compute_units", C.c_int32),
                 ("slices_per_lane", C.c_int32), ("waves_per_member", C.c_int32),
                 ("expm_squarings", C.c_int32), ("kernel_family", C.c_int32), ("unitary_flow", C.c_int32),
-                ("expm_theta", C.c_double), ("workspace_bytes", C.c_uint64), ("arch", C.c_char * 32)]
+                ("expm_theta", C.c_double), ("workspace_bytes", C.c_uint64), ("arch", C.c_char * 32),
+                ("n_devices", C.c_int32), ("comm_size", C.c_int32), ("comm_rank", C.c_int32),
+                ("members_first_device", C.c_int32)]
+
+
+class GrapeCommId(C.Structure):
+    _fields_ = [("bytes", C.c_char * 128)]
 
 
 def library_path():
@@ -87,6 +98,8 @@ def load_library():
     L.grape_create.argtypes = [C.POINTER(GrapeConfig), C.POINTER(vp)]
     L.grape_destroy.argtypes = [vp]
     L.grape_set_operators.argtypes = [vp] * 6
+    L.grape_comm_unique_id.argtypes = [C.POINTER(GrapeCommId)]
+    L.grape_comm_attach.argtypes = [vp, C.POINTER(GrapeCommId), i32, i32]
     L.grape_eval.argtypes = [vp, vp, dp, vp]
     L.grape_eval_device.argtypes = [vp, vp, vp, vp]
     L.grape_eval_batch.argtypes = [vp, i32, vp, vp, vp]
@@ -121,7 +134,10 @@ class GrapeEngine:
     eval(x) -> (F, G) with x, G of shape (K, N) (x[j, i] as in the reference)."""
 
     def __init__(self, sys_type, A, B, Xi, Xt, wts, T, n_slices, variant=0, device=-1, flags=0,
-                 slices_per_lane=0, waves_per_member=0, expm_squarings=-1, member_results=False, max_batch=1):
+                 slices_per_lane=0, waves_per_member=0, expm_squarings=-1, member_results=False, max_batch=1,
+                 devices=None, force_collective=False):
+        """devices: list of HIP ordinals -> the library shards the ensemble over them itself
+        (grape_config.n_devices / device_ids) and all-reduces [G, F] with RCCL once per evaluation."""
         self._h = None
         self._lib = load_library()
         A = np.asarray(A, dtype=np.complex128)
@@ -139,10 +155,19 @@ class GrapeEngine:
             raise ValueError("wts must have one weight per member")
         if member_results:
             flags |= FLAG_MEMBER_RESULTS
+        if force_collective:
+            flags |= FLAG_FORCE_COLLECTIVE
+        devices = list(devices) if devices is not None else []
+        if len(devices) > MAX_DEVICES:
+            raise ValueError(f"at most {MAX_DEVICES} devices")
         code = SYS_TYPE_CODES[sys_type] if isinstance(sys_type, str) else int(sys_type)
         self.sys_type, self.n, self.K, self.N, self.E, self.T = sys_type, n, K, int(n_slices), E, float(T)
+        ids = (C.c_int32 * MAX_DEVICES)(*(devices + [0] * (MAX_DEVICES - len(devices))))
+        if len(devices) == 1:
+            device = devices[0]
         cfg = GrapeConfig(code, int(variant), n, K, int(n_slices), E, float(T), int(device), int(flags),
-                          int(slices_per_lane), int(waves_per_member), int(expm_squarings), int(max_batch))
+                          int(slices_per_lane), int(waves_per_member), int(expm_squarings), int(max_batch),
+                          0, len(devices) if len(devices) > 1 else 0, ids)
         self.max_batch = max(1, int(max_batch))
         h = C.c_void_p()
         rc = self._lib.grape_create(C.byref(cfg), C.byref(h))
@@ -179,6 +204,23 @@ class GrapeEngine:
         inf = GrapeInfo()
         self._check(self._lib.grape_get_info(self._h, C.byref(inf)))
         return {f: (getattr(inf, f).decode() if f == "arch" else getattr(inf, f)) for f, _ in inf._fields_}
+
+    # ------------------------------------------------------------------ one process per GPU
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL bootstrap token (rank 0 creates it, every rank passes it to comm_attach)."""
+        lib = load_library()
+        cid = GrapeCommId()
+        rc = lib.grape_comm_unique_id(C.byref(cid))
+        if rc:
+            raise GrapeError(rc, lib.grape_last_error(None).decode())
+        return bytes(bytearray(cid)[:128])
+
+    def comm_attach(self, token, rank, n_ranks):
+        """Join the communicator: from now on every eval()/eval_device() of this context (this rank's
+        member shard) ends in the single all-reduce of [G, F] over the ranks, inside the library."""
+        cid = GrapeCommId.from_buffer_copy(bytes(token))
+        self._check(self._lib.grape_comm_attach(self._h, C.byref(cid), int(rank), int(n_ranks)))
 
     # ------------------------------------------------------------------ evaluation
     def eval(self, x, want_F=True, want_G=True):

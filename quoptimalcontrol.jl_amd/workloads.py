@@ -118,6 +118,22 @@ class Workload:
         p = (2 + 4 / 3) if n <= 4 else (3 + 4 / 3)
         return E * N * (8 * n ** 3 * (p + q) + 12 * K * n * n)
 
+    def flow_bytes(self, unitary_flow):
+        """HBM bytes of the data flow the kernels actually run, per ensemble
+        evaluation: the general flow is model S (P_t and one state-like matrix per slice make one
+        round trip); the unitary flow (all generators Hermitian) moves only P_t."""
+        n, K, N, E = self.n, self.K, self.N, self.E
+        per_slice = 32 if unitary_flow else 64
+        return E * (per_slice * n * n * N + 16 * K * N + 16 * (K + 3) * n * n)
+
+    def flow_flops(self, unitary_flow):
+        """FP64 flops of the flow in use: expm (Taylor-8: 3 products) + chain products per slice
+        (unitary flow: 3 = chunk/forward product + P'MP; general: 3 UnitaryGate / 6 sandwich) + H build
+        and the K traces."""
+        n, K, N, E = self.n, self.K, self.N, self.E
+        q = 3 if (unitary_flow or self.sys_type == "UnitaryGate") else 6
+        return E * N * (8 * n ** 3 * (3 + q) + 12 * K * n * n)
+
 
 def controls(K, N):
     """x[j, i] = u(1, i*K + j)  (0-based i, j)"""

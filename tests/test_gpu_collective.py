@@ -1,0 +1,102 @@
+"""GPU: the multi-GPU machinery behind the C ABI, exercised on ONE device (the metered box has one):
+a 1-device group context (ncclCommInitAll + grouped ncclAllReduce inside grape_eval), a 1-rank
+communicator attached to a plain context (grape_comm_unique_id / grape_comm_attach), the device-pointer
+entry point with the in-library all-reduce, shard planning, and the timed-event ring."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,kw", [("C3", {"E": 12, "N": 70}), ("C1", {}), ("C4", {"E": 3, "N": 40})])
+def test_group_context_one_device_runs_the_rccl_allreduce(qoc, oracle, name, kw):
+    w = qoc.workloads.config(name, **kw)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
+                                                             per_member=True)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, force_collective=True,
+                         member_results=True) as eng:
+        info = eng.info
+        assert info["n_devices"] == 1 and info["comm_size"] == 1
+        F, G = eng.eval(w.x)
+        F2, G2 = eng.eval(w.x)
+        foms, grads = eng.member_results()
+        P = eng.trajectory(w.E - 1, states=False)[0]
+    assert_parity(F, G, F_ref, G_ref, w.n, what="group eval")
+    assert F == F2 and np.array_equal(G, G2)
+    for k in range(w.E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], w.n, what=f"member {k}")
+    assert P.shape == (w.N, w.n, w.n)
+
+
+def test_group_context_device_pointers(qoc, oracle):
+    import torch
+    w = qoc.workloads.config("C3", E=9, N=64)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    dev = torch.device("cuda", 0)
+    xd = torch.as_tensor(np.ascontiguousarray(w.x.T), device=dev)
+    fg = torch.zeros(w.K * w.N + 1, dtype=torch.float64, device=dev)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, force_collective=True, device=0) as eng:
+        eng.eval_device(xd.data_ptr(), fg.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize(dev)
+        h = fg.cpu().numpy()
+        F1, G1 = eng.eval(w.x)                      # host path right after the device path (stream ordering)
+    assert_parity(h[-1], h[:-1].reshape(w.N, w.K).T, F_ref, G_ref, w.n, what="group eval_device")
+    assert_parity(F1, G1, F_ref, G_ref, w.n, what="group eval after eval_device")
+
+
+def test_comm_attach_single_rank(qoc, oracle):
+    """one process per GPU, world of one: unique id -> attach -> every evaluation all-reduces in-library."""
+    w = qoc.workloads.config("C3", E=10, N=50)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    token = qoc.GrapeEngine.comm_unique_id()
+    assert len(token) == 128
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        eng.comm_attach(token, 0, 1)
+        assert eng.info["comm_size"] == 1 and eng.info["comm_rank"] == 0
+        F, G = eng.eval(w.x)
+        with pytest.raises(qoc.GrapeError):
+            eng.comm_attach(token, 0, 1)            # already attached
+    assert_parity(F, G, F_ref, G_ref, w.n, what="comm_attach eval")
+
+
+def test_sharded_engine_library_collective(qoc, oracle):
+    """the product wiring bench.py uses: ShardedGrape with collective='lib' and a forced 1-rank communicator."""
+    import torch
+    from quoptimalcontrol_jl_amd.distributed import sharded_engine
+    w = qoc.workloads.config("C3", E=16, N=100)
+    sg = sharded_engine(w, torch.device("cuda", 0), force_collective=True, collective="lib")
+    assert sg.collective == "lib" and sg.comm_size == 1
+    F, G = sg.eval(w.x)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    assert_parity(F, G, F_ref, G_ref, w.n, what="lib collective")
+    sg.close()
+
+
+def test_two_devices_requested_on_a_one_gpu_box_fails_loudly(qoc):
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a single-GPU box")
+    w = qoc.workloads.config("C3", E=8, N=20)
+    with pytest.raises(qoc.GrapeError) as ei:
+        qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, devices=[0, 1])
+    assert ei.value.status == -3 and "device_ids[1]" in str(ei.value)
+    with pytest.raises(qoc.GrapeError) as ei:
+        qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, devices=[0, 0])
+    assert ei.value.status == -1
+
+
+def test_timed_event_ring_wraps(qoc):
+    """GRAPE_FLAG_TIME_KERNELS: more timed launches than the ring holds; the count and the sum survive."""
+    w = qoc.workloads.config("C1")
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, flags=qoc.engine.FLAG_TIME_KERNELS) as eng:
+        for _ in range(700):
+            eng.eval(w.x)
+        ms, n = eng.kernel_time(reset=True)
+        assert n == 700 and 0.0 < ms < 700 * 1.0
+        eng.eval(w.x)
+        ms2, n2 = eng.kernel_time()
+        assert n2 == 1 and ms2 < ms
