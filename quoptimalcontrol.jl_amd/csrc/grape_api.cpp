@@ -50,6 +50,8 @@ struct grape_ctx {
     bool pack2 = false;           // tile family, n <= 8: two members per 16x16 tile (block diagonal)
     int EU = 0;                   // tile family: wavefront-level units = members, or member pairs when pack2
     int S = 0, W = 0, LT = 0;
+    bool pair = false;            // small family: lane-pair kernel (sweep_pair.hip), a time chunk per two lanes
+    int CH = 0;                   // small family: time chunks per member = workspace stride (LT, or LT/2 when pair)
     int MPB = 1, NB = 0;          // small family: members per workgroup, workgroups per control array
     int B = 1;                    // batch capacity: control arrays per grape_eval_batch call
     double *d_block_out = nullptr;
@@ -239,8 +241,17 @@ static int validate_config(const grape_config *cfg)
 // one device, one contiguous shard of members: the workspace init_GRAPE allocates
 static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
 {
-    const int wmax = grape::sweep_small_max_waves(cfg->n);
+    int wmax = grape::sweep_small_max_waves(cfg->n);
     const int nt = grape::tile_count(cfg->n);
+    // n = 4 runs the lane-pair kernel (two waves per SIMD); n = 2, 3 the lane-per-chunk kernel.
+    // GRAPE_SMALL_KERNEL=pair|lane overrides (parity tests run both).
+    bool pair = cfg->n == 4;
+    if (const char *sk = std::getenv("GRAPE_SMALL_KERNEL")) {
+        if (!std::strcmp(sk, "pair")) pair = true;
+        if (!std::strcmp(sk, "lane")) pair = false;
+    }
+    if (grape::sweep_pair_max_waves(cfg->n) == 0 || wmax == 0) pair = false;
+    if (pair) wmax = grape::sweep_pair_max_waves(cfg->n);
     HIP_TRY(nullptr, hipSetDevice(dev));
     hipDeviceProp_t prop;
     HIP_TRY(nullptr, hipGetDeviceProperties(&prop, dev));
@@ -270,25 +281,30 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     c->TSZ = (size_t)nt * nt * 256;
     c->pack2 = (c->family == 1 && cfg->n <= 8 && !std::getenv("GRAPE_TILE_NOPACK"));
     c->EU = c->pack2 ? (E + 1) / 2 : E;
+    c->pair = pair && c->family == 0;
+    const int cpw = c->pair ? 32 : 64;                           // time chunks per wave
     int W = cfg->waves_per_member;
     if (W <= 0) {
-        const long simds = 4L * c->compute_units;
+        // lane kernel: one wave per SIMD; pair kernel: two (its registers allow it, and the FP64 pipe
+        // needs two waves to run near its peak)
+        const long slots = (c->pair ? 8L : 4L) * c->compute_units;
         const long units = (long)E * c->B;                       // a batch fills the chip like a larger ensemble
-        W = (int)((simds + units - 1) / units);
-        const int wneed = (N + 63) / 64;
+        W = (int)((slots + units - 1) / units);
+        const int wneed = (N + cpw - 1) / cpw;
         if (W > wneed) W = wneed;
     }
     if (wmax > 0 && W > wmax) W = wmax;
     if (W < 1 || c->family == 1) W = 1;
     int S = cfg->slices_per_lane;
-    const int smin = (N + 64 * W - 1) / (64 * W);
+    const int smin = (N + cpw * W - 1) / (cpw * W);
     if (S < smin) S = smin;
-    c->W = W; c->S = S; c->LT = 64 * W;
+    c->W = W; c->S = S; c->LT = 64 * W; c->CH = cpw * W;
     if (c->family == 0 && (uint64_t)cfg->n_controls * N * S * cfg->n_controls >= (1ull << 32)) {
         delete c;
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: n_controls^2 * n_slices^2 too large for the LDS index arithmetic");
     }
-    c->MPB = (c->family == 0 && W <= 4) ? 4 / W : 1;         // fill the 4 SIMDs of a CU per workgroup
+    const int wg_waves = c->pair ? 8 : 4;                    // a workgroup fills the CU's 4 SIMDs (x2 for the pair kernel)
+    c->MPB = (c->family == 0 && W <= wg_waves) ? wg_waves / W : 1;
     if (const char *ev = std::getenv("GRAPE_MPB")) {           // tuning experiment: members per workgroup
         const int v = std::atoi(ev);
         if (c->family == 0 && v >= 1 && v * W <= wmax) c->MPB = v;
@@ -297,16 +313,20 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     bool xg_in_lds = true;
     if (c->family == 0) {                                    // fit the x/g staging buffer into LDS
         const size_t cap = 150 * 1024;
-        while (c->MPB > 1 && grape::sweep_small_lds_bytes(cfg->n, c->MPB, c->LT, S, cfg->n_controls, true) > cap)
+        auto lds_need = [&](int mpb, bool in_lds) {
+            return c->pair ? grape::sweep_pair_lds_bytes(cfg->n, mpb, c->LT, S, cfg->n_controls, in_lds)
+                           : grape::sweep_small_lds_bytes(cfg->n, mpb, c->LT, S, cfg->n_controls, in_lds);
+        };
+        while (c->MPB > 1 && lds_need(c->MPB, true) > cap)
             c->MPB /= 2;
-        xg_in_lds = grape::sweep_small_lds_bytes(cfg->n, c->MPB, c->LT, S, cfg->n_controls, true) <= cap;
+        xg_in_lds = lds_need(c->MPB, true) <= cap;
     }
     c->NB = (E + c->MPB - 1) / c->MPB;
     c->ksplit = grape::reduce_ksplit(E);
 
     const size_t nn = (size_t)cfg->n * cfg->n, K = cfg->n_controls;
     const size_t Q = KN(c) + 1;
-    c->ws_elems = c->family == 0 ? (size_t)E * S * nn * c->LT : (size_t)c->EU * N * c->TSZ;
+    c->ws_elems = c->family == 0 ? (size_t)E * S * nn * c->CH : (size_t)c->EU * N * c->TSZ;
     const size_t ops_elems = c->family == 0 ? (size_t)E * (K + 3) * nn : (size_t)c->EU * (2 * K + 3) * c->TSZ;
     const bool keepl = (cfg->flags & GRAPE_FLAG_KEEP_COSTATES) != 0;
 
@@ -328,7 +348,7 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     if (e == hipSuccess && c->family == 0) e = alloc((void **)&c->d_block_out, sizeof(double) * c->NB * Q * Bn);
     if (e == hipSuccess && c->family == 0 && !xg_in_lds)
         e = alloc((void **)&c->d_xg_scratch,
-                  sizeof(double) * Bn * c->NB * ((size_t)c->MPB * c->LT * ((size_t)S * K + 1) + c->MPB));
+                  sizeof(double) * Bn * c->NB * ((size_t)c->MPB * c->CH * ((size_t)S * K + 1) + c->MPB));
     if (e == hipSuccess && (cfg->flags & GRAPE_FLAG_PHASE_STAMPS)) {
         const size_t sb = sizeof(unsigned long long) * Bn * E * W * grape::kStampSlots;
         e = alloc((void **)&c->d_stamps, sb);
@@ -685,7 +705,10 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     }
     if (c->family == 0) {
         const int mode = c->unitary ? 2 : (c->d_costates ? 1 : 0);
-        HIP_TRY(c, grape::launch_sweep_small(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, mode, p, stream));
+        if (c->pair)
+            HIP_TRY(c, grape::launch_sweep_pair(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, mode, p, stream));
+        else
+            HIP_TRY(c, grape::launch_sweep_small(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, mode, p, stream));
     } else {
         int rc = enqueue_tile(c, d_x, stream);
         if (rc) return rc;
@@ -946,7 +969,7 @@ static int fetch_slab(grape_ctx *c, const double2 *d_ws, int member, cplx *out)
                         }
         return GRAPE_OK;
     }
-    const size_t nn = (size_t)c->cfg.n * c->cfg.n, S = c->S, LT = c->LT, N = c->cfg.n_slices;
+    const size_t nn = (size_t)c->cfg.n * c->cfg.n, S = c->S, LT = c->CH, N = c->cfg.n_slices;   // LT: chunks per member
     std::vector<cplx> h(S * nn * LT);
     HIP_TRY(c, hipMemcpy(h.data(), d_ws + (size_t)member * S * nn * LT, sizeof(cplx) * h.size(),
                          hipMemcpyDeviceToHost));

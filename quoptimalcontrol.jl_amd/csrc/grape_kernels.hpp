@@ -45,6 +45,12 @@ int sweep_small_max_waves(int n);   // W limit of the register-resident kernel f
 // dynamic LDS a workgroup of the small-n sweep needs for this decomposition
 size_t sweep_small_lds_bytes(int n, int MPB, int LT, int S, int K, bool xg_in_lds);
 
+// lane-pair edition of the same kernel (sweep_pair.hip, n = 2, 4): a time chunk is shared by two adjacent
+// lanes, LT/2 chunks per member; same SweepParams, workspace stride LT/2 instead of LT
+hipError_t launch_sweep_pair(int n, int sandwich, int mode, const SweepParams &p, hipStream_t stream);
+int sweep_pair_max_waves(int n);    // 0: no pair kernel for this n
+size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool xg_in_lds);
+
 // ---- tile (MFMA) family, n = 5..32, zero-padded to 16*NT ------------------------------------
 // All matrices are "D-layout dumps" (tile.hpp): (16 NT)^2 double2 each, TSZ = NT*NT*256.
 struct TileParams {

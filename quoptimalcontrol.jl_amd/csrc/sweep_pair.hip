@@ -1,0 +1,725 @@
+// sweep_pair.hip -- the GRAPE hot path for even small operators (n = 2, 4), lane-PAIR edition.
+//
+// Same algorithm, phases and data flows as sweep_small.hip (read its header first: phase A propagators
+// + chunk product, phase B lane-chunk scan, phase D backward sweep fused with the gradient traces and the
+// figure of merit; MODE_GENERAL / MODE_GENERAL_KEEPL / MODE_UNITARY), with ONE change of decomposition:
+// a time chunk belongs to a PAIR of adjacent lanes, each owning half the columns of every matrix
+// (cmatp.hpp).  A 4 x 4 complex matrix is 32 VGPRs per lane instead of 64, the kernel needs < 256
+// registers instead of ~400 (256 VGPR + 150 AGPR of spill), so TWO waves share every SIMD: the FP64 pipe
+// goes from the ~60 % issue rate of a lone wave to ~80 %, LDS / HBM latency hides behind the other wave,
+// and the scan's products are shared by the pair.  At the headline config (E = 1024 members on 1024
+// SIMDs) a member is W = 2 waves = 64 chunks of 8 slices.
+//
+// Operators: the two lanes of a pair need DIFFERENT entries of the member's (wave-uniform) operators, so
+// the scalar-load trick of sweep_small.hip does not apply; instead the workgroup stages, per member, a
+// parity-relative image of [A' | B'_c | B'_c^T | Xi | Xt] in LDS once (2 x (2K+3) x n*n/2 double2 = 2.8 KB
+// at n = 4, K = 4) and every lane reads its entries with ds_read_b128 (two distinct addresses per wave
+// instruction: broadcast, conflict free).
+//
+// Workspace layout (chunk-major): element e = i + j n of slice t = c S + jj of member k at
+//   ((k S + jj) n^2 + e) CH + c ,   CH = chunks per member = 32 W ;
+// a lane stores its own columns (two 512-byte runs per wave instruction) and the backward sweep reads
+// the whole P_t per lane (both lanes of a pair read the same 16 bytes: one 512-byte run).
+#include "cmatp.hpp"
+#include "grape_kernels.hpp"
+
+#ifndef GRAPE_ABL
+#define GRAPE_ABL 0          // diagnostic ablation bitmask (tools/ablate.sh); 0 in the product build
+#endif
+
+namespace grape {
+
+enum { PMODE_GENERAL = 0, PMODE_GENERAL_KEEPL = 1, PMODE_UNITARY = 2 };
+
+// global element index i + j n of local element (r, jl) as seen by a lane of parity q
+template <int N>
+GRAPE_DEV int gelem(int q, int r, int jl)
+{
+    constexpr int NC = N / 2;
+    const int i = (((r / NC) ^ q) * NC) + (r % NC);
+    const int j = q * NC + jl;
+    return i + j * N;
+}
+
+// local half (parity-q view) <-> chunk-major workspace
+template <int N>
+GRAPE_DEV void pstore_ws(double2 *__restrict__ base, size_t stride, const PMat<N> &m, int q)
+{
+#pragma unroll
+    for (int jl = 0; jl < N / 2; ++jl)
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+            base[(size_t)gelem<N>(q, r, jl) * stride] = make_double2(m.re[r + jl * N], m.im[r + jl * N]);
+}
+
+template <int N>
+GRAPE_DEV void pload_ws(PMat<N> &m, const double2 *__restrict__ base, size_t stride, int q)
+{
+#pragma unroll
+    for (int jl = 0; jl < N / 2; ++jl)
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            const double2 v = base[(size_t)gelem<N>(q, r, jl) * stride];
+            m.re[r + jl * N] = v.x;
+            m.im[r + jl * N] = v.y;
+        }
+}
+
+// parity image of one matrix in LDS: NE = n*n/2 consecutive double2
+template <int N>
+GRAPE_DEV void pload_lds(PMat<N> &m, const double2 *s)
+{
+#pragma unroll
+    for (int e = 0; e < N * (N / 2); ++e) {
+        const double2 v = s[e];
+        m.re[e] = v.x;
+        m.im[e] = v.y;
+    }
+}
+
+template <int N>
+GRAPE_DEV void pstore_lds(double2 *s, const PMat<N> &m)
+{
+#pragma unroll
+    for (int e = 0; e < N * (N / 2); ++e)
+        s[e] = make_double2(m.re[e], m.im[e]);
+}
+
+GRAPE_DEV void pstamp(unsigned long long *__restrict__ st, int slot)
+{
+    if (st) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if ((threadIdx.x & 63) == 0)
+            st[slot] = t;
+    }
+}
+
+template <int N, int SAND>
+GRAPE_DEV double pfigure_of_merit(double zr, double zi)
+{
+    if (SAND) {                                  // 1 - |tr(L'X)/D|^2, cost_functions.jl:13-17
+        const double inv = 1.0 / (double)N;
+        const double ar = zr * inv, ai = zi * inv;
+        return 1.0 - (ar * ar + ai * ai);
+    }
+    return zr * zr - zi * zi;                    // Re(z^2), cost_functions.jl:99-101
+}
+
+// gradient entries of one slice: Re tr(B'_c (z M)) for the K controls, own half + pair sum.
+// s_bt: parity image of the transposed scaled controls, matrix c at s_bt + c*NE.
+template <int N, int SAND>
+GRAPE_DEV void pwrite_gradient(double *out, const double2 *s_bt, int K, const PMat<N> &M, double zr, double zi,
+                               double gs, int p)
+{
+    constexpr int NE = N * (N / 2);
+    PMat<N> Z;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        if (SAND) {
+            Z.re[e] = M.re[e];
+            Z.im[e] = M.im[e];
+        } else {
+            Z.re[e] = fma(M.re[e], zr, -M.im[e] * zi);
+            Z.im[e] = fma(M.re[e], zi, M.im[e] * zr);
+        }
+    }
+    // operand reads software-pipelined by hand: control c+1's entries are in flight during control c's FMAs
+    double2 b0[NE], b1[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+        b0[e] = s_bt[e];
+    for (int c = 0; c < K; c += 2) {
+        if (c + 1 < K) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                b1[e] = s_bt[(c + 1) * NE + e];
+        }
+        double re = 0.0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            re = fma(b0[e].x, Z.re[e], re);
+            re = fma(-b0[e].y, Z.im[e], re);
+        }
+        re += pair_swap(re);
+        if (p == 0)
+            out[c] = gs * re;
+        if (c + 1 < K) {
+            if (c + 2 < K) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    b0[e] = s_bt[(c + 2) * NE + e];
+            }
+            double r1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                r1 = fma(b1[e].x, Z.re[e], r1);
+                r1 = fma(-b1[e].y, Z.im[e], r1);
+            }
+            r1 += pair_swap(r1);
+            if (p == 0)
+                out[c + 1] = gs * r1;
+        }
+    }
+}
+
+template <int N, int SAND, int MODE, int MAXT, bool XGLDS>
+__global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restrict__ ops_all,
+                                                          const double *__restrict__ x_all,
+                                                          const double *__restrict__ wts_all,
+                                                          const SweepParams p)
+{
+    constexpr int NN = N * N, NC = N / 2, NE = N * NC;
+    constexpr int MAXW = MAXT / 64;
+    constexpr bool UNI = (MODE == PMODE_UNITARY);
+    constexpr bool KEEPL = (MODE == PMODE_GENERAL_KEEPL);
+    // dynamic LDS:  s_tot  2*MAXW*NN double2   wave totals of the two scans (both parity halves)
+    //               s_ops  MPB * 2 * NM * NE double2   parity images of the members' operators
+    //               s_xg   MPB*CH*(S*K+1) double      controls in / gradient out, chunk stride odd
+    //               s_F    MPB double
+    extern __shared__ double2 s_dyn[];
+    double2(*s_tot)[MAXW][NN] = reinterpret_cast<double2(*)[MAXW][NN]>(s_dyn);
+
+    const int LT = p.LT, W = LT >> 6, CH = LT >> 1;
+    const int mb = __builtin_amdgcn_readfirstlane(threadIdx.x / LT);   // member within the block
+    const int L = threadIdx.x - mb * LT;             // lane within the member
+    const int lane = L & 63, wave = L >> 6;
+    const int par = L & 1;                           // parity within the pair
+    const int ch = L >> 1;                           // time chunk of the pair
+    const int cw = lane >> 1;                        // chunk within the wave (0..31)
+    const int wbase_tot = mb * W;
+    const int xi = blockIdx.x / p.BPX;               // which control array (batched evaluation)
+    const int bi = blockIdx.x - xi * p.BPX;
+    int kl = bi * p.MPB + mb;
+    const bool valid = kl < p.E;
+    if (!valid)
+        kl = p.E - 1;
+    const int k = xi * p.E + kl;
+    const int K = p.K, Nsl = p.N, S = p.S;
+    const size_t stride = (size_t)CH;
+    const int NM = 2 * K + 3;
+
+    double2 *s_ops_all = s_dyn + 2 * MAXW * NN;
+    double2 *s_ops = s_ops_all + (size_t)mb * 2 * NM * NE;
+    const int SK = S * K;
+    const size_t nrm_d2 = ((size_t)p.MPB * (K + 1) + 1) / 2;        // double2 slots of the operator-norm table
+    double *s_xg_all = XGLDS ? reinterpret_cast<double *>(s_ops_all + (size_t)p.MPB * 2 * NM * NE + nrm_d2)
+                             : p.xg_scratch + (size_t)blockIdx.x * ((size_t)p.MPB * CH * (SK + 1) + p.MPB);
+    double *s_xg = s_xg_all + (size_t)mb * CH * (SK + 1);
+    double *s_F = s_xg_all + (size_t)p.MPB * CH * (SK + 1);
+    // 1-norm bounds (max column sum of |re| + |im|) of this member's A' and B'_c: |G_t|_1 <= nrm[0] + sum |x_c| nrm[1+c]
+    double *s_nrm = reinterpret_cast<double *>(s_ops_all + (size_t)p.MPB * 2 * NM * NE) + (size_t)mb * (K + 1);
+    const unsigned magic = p.sk_magic;
+    auto chunk_of = [&](int q) { return SK == 1 ? q : (int)__umulhi((unsigned)q, magic); };
+    {
+        const double *__restrict__ xsrc = x_all + (size_t)xi * K * Nsl;
+        const int KNs = K * Nsl;
+        for (int q0 = 0; q0 < KNs; q0 += 8 * LT) {           // 8 loads in flight per lane, then the LDS scatter
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u * LT + L;
+                v[u] = q < KNs ? xsrc[q] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u * LT + L;
+                if (q < KNs)
+                    s_xg[q + chunk_of(q)] = v[u];
+            }
+        }
+        // parity images of this member's operators: image element (q, mat, e = r + jl n)
+        const double2 *__restrict__ ops = ops_all + (size_t)kl * (K + 3) * NN;
+        for (int idx = L; idx < 2 * NM * NE; idx += LT) {
+            const int q = idx / (NM * NE), rem = idx - q * NM * NE;
+            const int mat = rem / NE, e = rem - mat * NE;
+            const int r = e % N, jl = e / N;
+            const int i = (((r / NC) ^ q) * NC) + (r % NC), j = q * NC + jl;
+            int src;
+            if (mat <= K)            src = mat * NN + i + j * N;                 // A', B'_c
+            else if (mat <= 2 * K)   src = (mat - K) * NN + j + i * N;           // B'_c transposed
+            else                     src = (mat - K) * NN + i + j * N;           // Xi, Xt
+            s_ops[idx] = ops[src];
+        }
+    }
+    __syncthreads();
+    if (L <= K) {                                    // one lane per generator: max column sum of |re| + |im|
+        double best = 0.0;
+        for (int q = 0; q < 2; ++q)
+            for (int jl = 0; jl < NC; ++jl) {
+                double cs = 0.0;
+                for (int r = 0; r < N; ++r) {
+                    const double2 v = s_ops[((size_t)q * NM + L) * NE + r + jl * N];
+                    cs += fabs(v.x) + fabs(v.y);
+                }
+                best = fmax(best, cs);
+            }
+        s_nrm[L] = best;
+    }
+    __syncthreads();
+    const double2 *sA = s_ops + (size_t)par * NM * NE;          // my parity's images
+    const double2 *sB = sA + NE;
+    const double2 *sBT = sA + (size_t)(1 + K) * NE;
+    const double2 *sXi = sA + (size_t)(1 + 2 * K) * NE;
+    const double2 *sXt = sXi + NE;
+    const double2 *sXi_o = s_ops + (size_t)(1 - par) * NM * NE + (size_t)(1 + 2 * K) * NE;   // the partner's images
+    const double2 *sXt_o = sXi_o + NE;
+    double *xg = s_xg + ch * (SK + 1);
+    const size_t wbase = (size_t)k * S * NN * stride + ch;
+    double2 *__restrict__ Pw = p.props + wbase;
+    double2 *__restrict__ Xw = p.states + wbase;
+    double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * Nsl + 1);
+    const int t0 = ch * S;
+    unsigned long long *__restrict__ st =
+        p.stamps ? p.stamps + ((size_t)k * W + wave) * kStampSlots : nullptr;
+    if (st && lane == 0)
+        st[5] = __builtin_amdgcn_s_memrealtime();
+    pstamp(st, 0);
+
+    // ---------------------------------------------------------------- phase A
+    PMat<N> Q, Q2;
+    pset_identity(Q);
+    // returns an upper bound of |G|_1 from the members' operator norms: |A'| + sum_c |x_c| |B'_c|
+    auto build = [&](int j, PMat<N> &G) -> double {
+        double nb = s_nrm[0];
+        if (p.variant == 0) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { G.re[e] = 0.0; G.im[e] = 0.0; }
+        } else {
+            pload_lds(G, sA);
+        }
+        double2 b0[NE], b1[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            b0[e] = sB[e];
+        for (int c = 0; c < K; c += 2) {
+            const double x0 = xg[j * K + c];
+            const double x1 = (c + 1 < K) ? xg[j * K + c + 1] : 0.0;
+            nb = fma(fabs(x0), s_nrm[1 + c], nb);
+            if (c + 1 < K)
+                nb = fma(fabs(x1), s_nrm[2 + c], nb);
+            if (c + 1 < K) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    b1[e] = sB[(c + 1) * NE + e];
+            }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                G.re[e] = fma(b0[e].x, x0, G.re[e]);
+                G.im[e] = fma(b0[e].y, x0, G.im[e]);
+            }
+            if (c + 1 < K) {
+                if (c + 2 < K) {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e)
+                        b0[e] = sB[(c + 2) * NE + e];
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    G.re[e] = fma(b1[e].x, x1, G.re[e]);
+                    G.im[e] = fma(b1[e].y, x1, G.im[e]);
+                }
+            }
+        }
+        if (p.variant == 0) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const double2 a = sA[e];
+                G.re[e] += a.x;
+                G.im[e] += a.y;
+            }
+        }
+        return nb;
+    };
+    auto finish = [&](int j, PMat<N> &G, double nb, const PMat<N> &Qin, PMat<N> &Qout) {
+        if (t0 + j < Nsl) {
+            PMat<N> P, Ppar;
+            if (GRAPE_ABL & 32) P = G; else
+            pexpm_t8<N, UNI>(P, G, p.s_forced, nb);
+            if (!(GRAPE_ABL & 2))
+            pstore_ws(Pw + (size_t)j * NN * stride, stride, P, par);
+            if (GRAPE_ABL & 4) { Qout = Qin; Qout.re[0] += P.re[1]; } else {
+            fetch_partner(Ppar, P);
+            pmul(Qout, P, Ppar, Qin); }
+            if (MODE == PMODE_GENERAL)                // in-chunk prefix product, read back in phase D
+                pstore_ws(Xw + (size_t)j * NN * stride, stride, Qout, par);
+        } else {
+            Qout = Qin;
+        }
+    };
+    {
+        PMat<N> G;
+        int j = 0;
+        for (; j + 1 < S; j += 2) {
+            double nb = build(j, G);
+            finish(j, G, nb, Q, Q2);
+            nb = build(j + 1, G);
+            finish(j + 1, G, nb, Q2, Q);
+        }
+        if (j < S) {
+            const double nb = build(j, G);
+            finish(j, G, nb, Q, Q2);
+            Q = Q2;
+        }
+    }
+
+    pstamp(st, 1);
+    // ---------------------------------------------------------------- phase B
+    // Kogge-Stone over the 32 chunks of a wave (shuffle distance 2d lanes keeps the parity), wave totals
+    // through LDS.  Unitary flow: M at the chunk end from the inclusive prefix U and the total T;
+    // general flow: state at the chunk start and costate at the chunk end from prefix and suffix.
+    PMat<N> Xs, Le;
+    double zr = 0.0, zi = 0.0;
+    {
+        PMat<N> inc = Q, oth, tmp, ipar;
+        for (int d = 1; d < 32; d <<= 1) {
+            pshfl_up(oth, inc, 2 * d);
+            if (cw >= d) {
+                fetch_partner(ipar, inc);
+                pmul(tmp, inc, ipar, oth);
+                inc = tmp;
+            }
+        }
+        if (!UNI) {                                  // exclusive prefix
+            pshfl_up(oth, inc, 2);
+            if (cw == 0)
+                pset_identity(oth);
+        }
+        if (W > 1) {
+            if (cw == 31)
+                pstore_lds(&s_tot[0][wbase_tot + wave][par * NE], inc);
+            __syncthreads();
+            PMat<N> pre, wt, wtp;
+            pset_identity(pre);
+            for (int w = 0; w < wave; ++w) {
+                pload_lds(wt, &s_tot[0][wbase_tot + w][par * NE]);
+                pload_lds(wtp, &s_tot[0][wbase_tot + w][(1 - par) * NE]);
+                pmul(tmp, wt, wtp, pre);
+                pre = tmp;
+            }
+            if (UNI) {
+                fetch_partner(ipar, inc);
+                pmul(tmp, inc, ipar, pre);
+                inc = tmp;
+            } else {
+                fetch_partner(ipar, oth);
+                pmul(tmp, oth, ipar, pre);
+                oth = tmp;
+            }
+        }
+        if (UNI) {
+            if (ch == CH - 1)
+                pstore_lds(&s_tot[1][wbase_tot][par * NE], inc);
+            __syncthreads();
+            PMat<N> T, Tp, C0, xi_m, xi_o, xt_m, xt_o;
+            pload_lds(T, &s_tot[1][wbase_tot][par * NE]);
+            pload_lds(Tp, &s_tot[1][wbase_tot][(1 - par) * NE]);
+            pload_lds(xi_m, sXi);
+            pload_lds(xi_o, sXi_o);
+            pload_lds(xt_m, sXt);
+            pload_lds(xt_o, sXt_o);
+            if (SAND) {
+                PMat<N> Em, Ep;
+                pmul(tmp, xt_m, xt_o, T);            // Xt T
+                pmul_ah_b(Em, T, Tp, tmp);           // E = T' Xt T
+                ptrace_ah_b(zr, zi, xi_m, Em);       // tr(Xi' E) = tr(X_t' L_t) for every t
+                fetch_partner(Ep, Em);
+                pmul_a_bh(C0, xi_m, xi_o, Em, Ep);   // Xi E'
+                pmul_ah_b(tmp, Em, Ep, xi_m);        // E' Xi
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    C0.re[e] -= tmp.re[e];
+                    C0.im[e] -= tmp.im[e];
+                }
+            } else {
+                pmul_a_bh(tmp, xi_m, xi_o, xt_m, xt_o);   // Xi Xt'
+                PMat<N> tp;
+                fetch_partner(tp, tmp);
+                pmul(C0, tmp, tp, T);
+            }
+            fetch_partner(ipar, inc);
+            pmul(tmp, inc, ipar, C0);
+            PMat<N> tp;
+            fetch_partner(tp, tmp);
+            pmul_a_bh(Xs, tmp, tp, inc, ipar);       // Xs := M at the chunk end = U C0 U'
+        } else {
+            PMat<N> xi_m;
+            pload_lds(xi_m, sXi);
+            fetch_partner(ipar, oth);
+            if (SAND) {
+                pmul(tmp, oth, ipar, xi_m);
+                PMat<N> tp;
+                fetch_partner(tp, tmp);
+                pmul_a_bh(Xs, tmp, tp, oth, ipar);
+            } else {
+                pmul(Xs, oth, ipar, xi_m);
+            }
+        }
+    }
+    if (!UNI) {
+        PMat<N> inc = Q, oth, tmp, opar;
+        for (int d = 1; d < 32; d <<= 1) {
+            pshfl_down(oth, inc, 2 * d);
+            if (cw + d < 32) {
+                fetch_partner(opar, oth);
+                pmul(tmp, oth, opar, inc);
+                inc = tmp;
+            }
+        }
+        pshfl_down(oth, inc, 2);
+        if (cw == 31)
+            pset_identity(oth);
+        if (W > 1) {
+            if (cw == 0)
+                pstore_lds(&s_tot[1][wbase_tot + wave][par * NE], inc);
+            __syncthreads();
+            PMat<N> post, wt, wtp;
+            pset_identity(post);
+            for (int w = wave + 1; w < W; ++w) {
+                pload_lds(wt, &s_tot[1][wbase_tot + w][par * NE]);
+                pload_lds(wtp, &s_tot[1][wbase_tot + w][(1 - par) * NE]);
+                pmul(tmp, wt, wtp, post);
+                post = tmp;
+            }
+            PMat<N> pp;
+            fetch_partner(pp, post);
+            pmul(tmp, post, pp, oth);
+            oth = tmp;
+        }
+        PMat<N> xt_m;
+        pload_lds(xt_m, sXt);
+        fetch_partner(opar, oth);
+        if (SAND) {
+            pmul_ah_b(tmp, oth, opar, xt_m);         // V' Xt
+            PMat<N> tp;
+            fetch_partner(tp, tmp);
+            pmul(Le, tmp, tp, oth);                  // V' Xt V
+        } else {
+            pmul_ah_b(Le, oth, opar, xt_m);
+        }
+    }
+
+    const double gs = SAND ? -1.0 : (p.variant == 0 ? -2.0 : 2.0);
+
+    if (UNI) {
+        pstamp(st, 2);
+        pstamp(st, 3);
+        // ------------------------------------------------------------ phase D, unitary flow
+        // Every lane loads only its own columns of P_t (8 x 16 B) and takes the other half from its
+        // partner by DPP; slice j-1's load is issued BEFORE slice j's products (two register buffers,
+        // loop unrolled by two), so the HBM latency hides under ~300 VALU instructions of both waves.
+        PMat<N> M = Xs, Mp, tmp, PA, PB, Pp;
+        auto step = [&](int j, const PMat<N> &P) {
+            const int t = t0 + j;
+            if (t < Nsl) {
+                fetch_partner(Pp, P);
+                fetch_partner(Mp, M);
+                pmul(tmp, M, Mp, P);
+                pmul_ah_b(M, P, Pp, tmp);            // M_t = P' M_{t+1} P
+                if (!SAND) {                         // z_t = tr(X_t' L_t) = conj(tr M_t)
+                    double tr_r, tr_i;
+                    ptrace(tr_r, tr_i, M);
+                    zr = tr_r;
+                    zi = -tr_i;
+                }
+                if (GRAPE_ABL & 16) { if (par == 0) xg[j * K] = M.re[0] + zr; } else
+                pwrite_gradient<N, SAND>(xg + j * K, sBT, K, M, zr, zi, gs, par);
+                if (t == Nsl - 1 && par == 0)
+                    s_F[mb] = pfigure_of_merit<N, SAND>(zr, zi);
+            }
+        };
+        pload_ws(PA, Pw + (size_t)(S - 1) * NN * stride, stride, par);
+        int j = S - 1;
+        for (; j >= 1; j -= 2) {
+            if (!(GRAPE_ABL & 8)) pload_ws(PB, Pw + (size_t)(j - 1) * NN * stride, stride, par);
+            step(j, PA);
+            if (j >= 2 && !(GRAPE_ABL & 8))
+                pload_ws(PA, Pw + (size_t)(j - 2) * NN * stride, stride, par);
+            step(j - 1, PB);
+        }
+        if (j == 0)
+            step(0, PA);
+    } else {
+        pstamp(st, 2);
+        // ------------------------------------------------------------ phase C (debug flow only)
+        if (KEEPL) {
+            PMat<N> X = Xs, Po, Pp, Xp, tmp;
+            for (int j = 0; j < S; ++j) {
+                const int t = t0 + j;
+                if (t < Nsl) {
+                    pstore_ws(Xw + (size_t)j * NN * stride, stride, X, par);
+                    if (j + 1 < S) {
+                        pload_ws(Po, Pw + (size_t)j * NN * stride, stride, par);
+                        pload_ws(Pp, Pw + (size_t)j * NN * stride, stride, 1 - par);
+                        if (SAND) {
+                            fetch_partner(Xp, X);
+                            pmul_a_bh(tmp, X, Xp, Po, Pp);       // X P'
+                            pmul(X, Po, Pp, tmp);                // P X P'
+                        } else {
+                            pmul(tmp, Po, Pp, X);
+                            X = tmp;
+                        }
+                    }
+                }
+            }
+        }
+
+        pstamp(st, 3);
+        // ------------------------------------------------------------ phase D, general flow
+        PMat<N> Lc = Le, Po, Pp, X, Xp, M, tmp, Lp;
+        for (int j = S - 1; j >= 0; --j) {
+            const int t = t0 + j;
+            if (t < Nsl) {
+                pload_ws(Po, Pw + (size_t)j * NN * stride, stride, par);
+                pload_ws(Pp, Pw + (size_t)j * NN * stride, stride, 1 - par);
+                if (SAND) {
+                    fetch_partner(Lp, Lc);
+                    pmul(tmp, Lc, Lp, Po);           // L P
+                    pmul_ah_b(Lc, Po, Pp, tmp);      // P' L P
+                } else {
+                    pmul_ah_b(tmp, Po, Pp, Lc);
+                    Lc = tmp;
+                }
+                if (KEEPL) {
+                    pload_ws(X, Xw + (size_t)j * NN * stride, stride, par);
+                } else if (j > 0) {                  // X_t = Q_{j-1} Xs [Q_{j-1}']
+                    PMat<N> Qo, Qp;
+                    pload_ws(Qo, Xw + (size_t)(j - 1) * NN * stride, stride, par);
+                    pload_ws(Qp, Xw + (size_t)(j - 1) * NN * stride, stride, 1 - par);
+                    if (SAND) {
+                        pmul(tmp, Qo, Qp, Xs);
+                        PMat<N> tp;
+                        fetch_partner(tp, tmp);
+                        pmul_a_bh(X, tmp, tp, Qo, Qp);
+                    } else {
+                        pmul(X, Qo, Qp, Xs);
+                    }
+                } else {
+                    X = Xs;
+                }
+                if (KEEPL)
+                    pstore_ws(p.costates + wbase + (size_t)j * NN * stride, stride, Lc, par);
+                double zr, zi;
+                ptrace_ah_b(zr, zi, X, Lc);          // tr(X' L)
+                fetch_partner(Xp, X);
+                fetch_partner(Lp, Lc);
+                pmul_a_bh(M, X, Xp, Lc, Lp);         // X L'
+                if (SAND) {
+                    pmul_ah_b(tmp, Lc, Lp, X);       // L' X
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        M.re[e] -= tmp.re[e];
+                        M.im[e] -= tmp.im[e];
+                    }
+                }
+                pwrite_gradient<N, SAND>(xg + j * K, sBT, K, M, zr, zi, gs, par);
+                if (t == Nsl - 1 && par == 0)
+                    s_F[mb] = pfigure_of_merit<N, SAND>(zr, zi);
+            }
+        }
+    }
+    // results: LDS -> HBM, lane-contiguous.  (1) this member's unweighted row, (2) the block's weighted partial sum
+    __syncthreads();
+    const int KN = K * Nsl;
+    if (p.member_out && valid) {
+        for (int q = L; q < KN; q += LT)
+            out[q] = s_xg[q + chunk_of(q)];
+        if (L == 0)
+            out[KN] = s_F[mb];
+    }
+    {
+        const int nmem = min(p.MPB, p.E - bi * p.MPB);
+        const double *__restrict__ wb = wts_all + (size_t)bi * p.MPB;
+        double *__restrict__ bout = p.block_out + (size_t)blockIdx.x * (KN + 1);
+        const int mstride = CH * (SK + 1);
+        for (int q = threadIdx.x; q <= KN; q += blockDim.x) {
+            const int off = q + chunk_of(q);
+            double acc = 0.0;
+            for (int m = 0; m < nmem; ++m) {
+                const double v = (q < KN) ? s_xg_all[m * mstride + off] : s_F[m];
+                acc = fma(v, wb[m], acc);
+            }
+            bout[q] = acc;
+        }
+    }
+    pstamp(st, 4);
+    if (st && lane == 0) {
+        st[6] = __builtin_amdgcn_s_memrealtime();
+        st[7] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) |
+                (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+    }
+}
+
+template <int N>
+struct PairTraits;
+template <> struct PairTraits<2> { static constexpr int MAXT = 1024; };
+template <> struct PairTraits<4> { static constexpr int MAXT = 512; };
+
+int sweep_pair_max_waves(int n)
+{
+    switch (n) {
+    case 2: return PairTraits<2>::MAXT / 64;
+    case 4: return PairTraits<4>::MAXT / 64;
+    default: return 0;
+    }
+}
+
+size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool xg_in_lds)
+{
+    const int maxt = n == 2 ? PairTraits<2>::MAXT : PairTraits<4>::MAXT;
+    size_t b = sizeof(double2) * (2 * (size_t)(maxt / 64) * n * n);
+    b += sizeof(double2) * ((size_t)MPB * 2 * (2 * K + 3) * (n * (n / 2)) + ((size_t)MPB * (K + 1) + 1) / 2);
+    if (xg_in_lds)
+        b += sizeof(double) * ((size_t)MPB * (LT / 2) * ((size_t)S * K + 1) + MPB);
+    return b;
+}
+
+template <int N, int SAND, int MODE, bool XGLDS>
+static hipError_t plaunch_one(const SweepParams &p, hipStream_t stream)
+{
+    constexpr int MAXT = PairTraits<N>::MAXT;
+    const dim3 grid(p.BPX * p.n_x), block(p.LT * p.MPB);
+    const size_t lds = sweep_pair_lds_bytes(N, p.MPB, p.LT, p.S, p.K, XGLDS);
+    if (lds > 160 * 1024)
+        return hipErrorInvalidConfiguration;
+    auto kern = sweep_pair_kernel<N, SAND, MODE, MAXT, XGLDS>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, p.ops, p.x, p.wts, p);
+    return hipGetLastError();
+}
+
+template <int N, int SAND>
+static hipError_t plaunch_ns(int mode, const SweepParams &p, hipStream_t stream)
+{
+    constexpr int MAXT = PairTraits<N>::MAXT;
+    if (p.MPB < 1 || p.LT * p.MPB > MAXT || (p.LT & 63) || (long long)p.S * (p.LT / 2) < p.N)
+        return hipErrorInvalidConfiguration;
+    const bool lds = p.xg_scratch == nullptr;
+    switch (mode) {
+    case PMODE_GENERAL:
+        return lds ? plaunch_one<N, SAND, PMODE_GENERAL, true>(p, stream) : plaunch_one<N, SAND, PMODE_GENERAL, false>(p, stream);
+    case PMODE_GENERAL_KEEPL:
+        return lds ? plaunch_one<N, SAND, PMODE_GENERAL_KEEPL, true>(p, stream)
+                   : plaunch_one<N, SAND, PMODE_GENERAL_KEEPL, false>(p, stream);
+    case PMODE_UNITARY:
+        return lds ? plaunch_one<N, SAND, PMODE_UNITARY, true>(p, stream) : plaunch_one<N, SAND, PMODE_UNITARY, false>(p, stream);
+    default:
+        return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_sweep_pair(int n, int sandwich, int mode, const SweepParams &p, hipStream_t stream)
+{
+    switch (n * 2 + (sandwich ? 1 : 0)) {
+    case 4: return plaunch_ns<2, 0>(mode, p, stream);
+    case 5: return plaunch_ns<2, 1>(mode, p, stream);
+    case 8: return plaunch_ns<4, 0>(mode, p, stream);
+    case 9: return plaunch_ns<4, 1>(mode, p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace grape

@@ -69,7 +69,8 @@ class GrapeCommId(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libgrape_hip.so")
+    """libgrape_hip.so next to this file; GRAPE_HIP_LIB points diagnostics (tools/ablate.sh) at another build."""
+    return os.environ.get("GRAPE_HIP_LIB") or os.path.join(_HERE, "libgrape_hip.so")
 
 
 def build_library(force=False):
