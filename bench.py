@@ -22,7 +22,8 @@ barrier + torch.cuda.synchronize(); per block the MAX over ranks; `value` comes 
 Prints ONE JSON line on rank 0 (contract: see the task statement), including
   roofline      dominant kernel (sweep) against the 8 TB/s HBM peak with the ALGORITHMIC bytes of
                 BASELINE.md's model S; duration from HIP events recorded around every sweep launch
-                inside the timed region (on the launch stream).  Also: the bytes/flops of the data
+                inside the timed region (on the launch stream; every 8th launch carries the event pair,
+                GRAPE_FLAG_TIME_SAMPLED, because a pair costs ~5 us of the ~90 us call).  Also: the bytes/flops of the data
                 flow actually run (`flow`), the FP64 fraction, and the end-to-end fraction
                 (model S x value / peak, BASELINE.md section 2 formula);
   cpu_baseline  the C oracle (a port of the reference's serial algorithm) timed on this
@@ -118,7 +119,8 @@ def roofline(local, info, kern_ms, kern_n, evals_per_s, n_gpus, traffic):
     else:
         roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "sweep_small_kernel", "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel": "sweep_pair_kernel" if info.get("lane_pair") else "sweep_small_kernel",
+                "algorithmic_bytes_per_launch": alg_bytes,
                 "end_to_end_frac": alg_bytes * evals_per_s / 1e9 / HBM_PEAK_GBS}
     roof.update({"kernel_avg_us": 1e3 * avg_ms, "kernel_launches": kern_n, "flow": flow,
                  "note": "achieved/frac price the sweep kernel with the ALGORITHMIC work of SURVEY.md 8d "
@@ -242,7 +244,8 @@ def main():
     w = qoc.workloads.config(args.config, E=E_total) if E_total != base.E else base
 
     sg = sharded_engine(w, device, force_collective=args.force_dist, collective=args.collective,
-                        flags=qoc.engine.FLAG_TIME_KERNELS | (qoc.engine.FLAG_FORCE_GENERAL if args.force_general else 0),
+                        flags=qoc.engine.FLAG_TIME_KERNELS | qoc.engine.FLAG_TIME_SAMPLED |
+                        (qoc.engine.FLAG_FORCE_GENERAL if args.force_general else 0),
                         slices_per_lane=args.slices_per_lane, waves_per_member=args.waves_per_member)
     x_host = np.ascontiguousarray(w.x)
 
@@ -258,8 +261,15 @@ def main():
             return float(t.item())
         return seconds
 
+    # the step, as a compiled caller makes it: buffers in the library's (K,N) column-major layout, allocated once
+    xf = np.ascontiguousarray(w.x.T)
+    Gf = np.empty_like(xf)
+    direct = sg.local is not None and (sg.collective == "lib" or (world == 1 and not args.force_dist))
+
     def step():
-        return sg.eval(x_host)                     # host -> GPUs -> host, all-reduce inside the library
+        if direct:
+            return sg.local.eval_cm(xf, Gf), Gf    # grape_eval: host -> GPUs -> host, all-reduce inside the library
+        return sg.eval(x_host)
 
     for _ in range(args.warmup):
         step()
@@ -268,7 +278,7 @@ def main():
         sg.local.kernel_time(reset=True)
     block_s = time_blocks(step, args.steps, args.blocks, barrier, reduce_max)
     kern_ms, kern_n = sg.local.kernel_time() if sg.local is not None else (0.0, 0)
-    F_last, G_last = step()
+    F_last, _ = step()
     info = sg.local.info if sg.local is not None else {}
     elapsed = statistics.median(block_s)
 

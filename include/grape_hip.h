@@ -78,6 +78,8 @@ enum {
                                            in HBM, as the reference does), even when every
                                            generator is Hermitian and the cheaper unitary flow
                                            applies.  KEEP_COSTATES implies it.          */
+    GRAPE_FLAG_TIME_SAMPLED = 1 << 6,   /* with TIME_KERNELS: record the event pair on every 8th evaluation only
+                                           (an event pair costs ~5 us of a ~90 us host->host call)  */
     GRAPE_FLAG_FORCE_COLLECTIVE = 1 << 5 /* create the RCCL communicator and run the all-reduce of
                                            [G, F] even when the context spans ONE device (a
                                            1-rank collective: exercises the multi-GPU code path
@@ -136,6 +138,7 @@ typedef struct grape_info {
     int32_t comm_size;             /* ranks of the RCCL communicator the all-reduce runs on (1 = none) */
     int32_t comm_rank;
     int32_t members_first_device;  /* members owned by device_ids[0] (the largest shard)  */
+    int32_t lane_pair;             /* 1: the lane-pair small-n kernel (two lanes per time chunk, two waves per SIMD) */
 } grape_info;
 
 /* Opaque RCCL bootstrap token (ncclUniqueId), see grape_comm_unique_id / grape_comm_attach. */

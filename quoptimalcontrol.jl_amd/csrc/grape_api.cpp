@@ -20,7 +20,9 @@
 #include <rccl/rccl.h>          // types and prototypes only: the library itself is dlopen'ed
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <time.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <complex>
@@ -69,9 +71,17 @@ struct grape_ctx {
     double *d_partial = nullptr;
     unsigned long long *d_stamps = nullptr;
     // host
-    double *h_stage = nullptr;    // pinned, K*N + 1 doubles: x on the way in
+    double *h_stage = nullptr;    // pinned + device-mapped, K*N + 1 doubles: x on the way in
+    double *d_h_stage = nullptr;  // device address of h_stage
     double *h_fg = nullptr;       // pinned + device-mapped, K*N + 1 doubles: the reduce kernel writes [G, F] here
     double *d_h_fg = nullptr;     // device address of h_fg
+    // host-visible completion of an evaluation: the final kernel's last workgroup publishes `seq` in h_flag
+    unsigned long long *h_flag = nullptr, *d_h_flag = nullptr;
+    unsigned *d_done_counter = nullptr;
+    unsigned long long seq = 0;
+    int x_upload = 1;             // 0: hipMemcpyAsync, 1: copy kernel reading the mapped staging buffer,
+                                  // 2: the host writes x straight into fine-grained device memory (large BAR)
+    double *d_x_bar = nullptr;    // mode 2: host-writable device buffer the sweep reads x from
     hipStream_t stream = nullptr;
     bool ops_set = false, evaluated = false;
     bool unitary = false;         // all generators Hermitian -> unitary data flow
@@ -79,6 +89,7 @@ struct grape_ctx {
     // created at grape_create; when the ring wraps, the oldest pair is folded into ev_total_ms
     std::vector<hipEvent_t> ev;
     uint64_t ev_issued = 0, ev_folded = 0;    // pairs
+    uint64_t launches = 0;                    // evaluations enqueued (GRAPE_FLAG_TIME_SAMPLED)
     double ev_total_ms = 0.0;
     int64_t ev_count = 0;
     hipEvent_t ev_dev = nullptr;  // recorded after every grape_eval_device: orders the private stream behind it
@@ -190,6 +201,9 @@ static void free_all(grape_ctx *c)
     (void)hipFree(c->d_member_out); (void)hipFree(c->d_partial); (void)hipFree(c->d_stamps); (void)hipFree(c->d_block_out); (void)hipFree(c->d_xg_scratch);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_fg) (void)hipHostFree(c->h_fg);
+    if (c->h_flag) (void)hipHostFree(c->h_flag);
+    (void)hipFree(c->d_done_counter);
+    (void)hipFree(c->d_x_bar);
     delete c;
 }
 
@@ -354,9 +368,49 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
         e = alloc((void **)&c->d_stamps, sb);
         if (e == hipSuccess) e = hipMemset(c->d_stamps, 0, sb);
     }
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, sizeof(double) * Q * Bn, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_fg, sizeof(double) * Q * Bn, hipHostMallocMapped);
+    const unsigned hflags = hipHostMallocMapped | hipHostMallocCoherent;
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, sizeof(double) * Q * Bn, hflags);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->d_h_stage, c->h_stage, 0);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_fg, sizeof(double) * Q * Bn, hflags);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->d_h_fg, c->h_fg, 0);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_flag, 64, hflags);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->d_h_flag, c->h_flag, 0);
+    if (e == hipSuccess) { *c->h_flag = 0; e = alloc((void **)&c->d_done_counter, 64); }
+    if (e == hipSuccess) e = hipMemset(c->d_done_counter, 0, 64);
+    {
+        // x upload path.  Default: if the device exposes its memory to the CPU (large BAR), the host
+        // writes x straight into a fine-grained device buffer -- no upload kernel, no kernel boundary;
+        // otherwise (or GRAPE_X_UPLOAD=kernel|memcpy) a copy kernel / hipMemcpyAsync moves the staged x.
+        const char *xu = std::getenv("GRAPE_X_UPLOAD");
+        int mode = 2;
+        if (xu) mode = !std::strcmp(xu, "memcpy") ? 0 : (!std::strcmp(xu, "kernel") ? 1 : 2);
+        int large_bar = 0;
+        if (mode == 2 && e == hipSuccess &&
+            (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess || !large_bar))
+            mode = 1;
+        if (mode == 2 && e == hipSuccess) {
+            void *p = nullptr;
+            if (hipExtMallocWithFlags(&p, sizeof(double) * KN(c) * Bn, hipDeviceMallocFinegrained) == hipSuccess && p) {
+                // is the buffer writable from the CPU?  read(2) into it fails with EFAULT instead of faulting
+                const int fd = open("/dev/zero", O_RDONLY);
+                const bool ok = fd >= 0 && read(fd, p, 64) == 64;
+                if (fd >= 0) close(fd);
+                if (ok) {
+                    c->d_x_bar = (double *)p;
+                    c->bytes += sizeof(double) * KN(c) * Bn;
+                } else {
+                    (void)hipFree(p);
+                    mode = 1;
+                }
+            } else {
+                (void)hipGetLastError();
+                mode = 1;
+            }
+        }
+        c->x_upload = mode;
+        if (std::getenv("GRAPE_DEBUG"))
+            std::fprintf(stderr, "[grape] x upload mode %d (large_bar=%d)\n", mode, large_bar);
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_dev, hipEventDisableTiming);
     if (e == hipSuccess && (cfg->flags & GRAPE_FLAG_TIME_KERNELS)) {
@@ -665,7 +719,8 @@ static int fold_events(grape_ctx *c, uint64_t count)
 }
 
 // one shard: sweep kernel(s) + the on-device ensemble reduction into d_fg; nothing is synchronised
-static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream_t stream, int n_x = 1)
+static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream_t stream, int n_x = 1,
+                        grape::DoneSignal done = grape::DoneSignal())
 {
     SweepParams p{};
     p.ops = c->d_ops;
@@ -690,7 +745,9 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     p.s_forced = c->cfg.expm_squarings;
     p.variant = c->cfg.variant;
     p.dt = c->cfg.duration / c->cfg.n_slices;                 // src/GRAPE.jl:42
-    const bool timed = (c->cfg.flags & GRAPE_FLAG_TIME_KERNELS) != 0;
+    bool timed = (c->cfg.flags & GRAPE_FLAG_TIME_KERNELS) != 0;
+    if (timed && (c->cfg.flags & GRAPE_FLAG_TIME_SAMPLED) && (c->launches++ & 7) != 0)
+        timed = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
         if (c->ev_issued - c->ev_folded == kEventRing) {   // ring full: fold the oldest pair (long finished)
@@ -715,10 +772,10 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     }
     if (timed) HIP_TRY(c, hipEventRecord(e1, stream));
     if (c->family == 0)
-        HIP_TRY(c, grape::launch_reduce_rows(c->d_block_out, d_fg, c->NB, (int)(KN(c) + 1), n_x, stream));
+        HIP_TRY(c, grape::launch_reduce_rows(c->d_block_out, d_fg, c->NB, (int)(KN(c) + 1), n_x, stream, done));
     else
         HIP_TRY(c, grape::launch_reduce(c->d_member_out, c->d_wts, c->d_partial, d_fg, p.E,
-                                        (int)(KN(c) + 1), c->ksplit, stream));
+                                        (int)(KN(c) + 1), c->ksplit, stream, done));
     c->evaluated = true;
     return GRAPE_OK;
 }
@@ -760,7 +817,7 @@ static int wait_stream(grape_ctx *c, hipStream_t stream)
 }
 
 // x (host) -> this shard's d_x, evaluation into `target`, all on the shard's private stream
-static int shard_enqueue_host(grape_ctx *s, const double *x, int n_x, double *target)
+static int shard_enqueue_host(grape_ctx *s, const double *x, int n_x, double *target, bool signal)
 {
     HIP_TRY(s, hipSetDevice(s->device));
     if (s->dev_pending) {                                   // order behind the last grape_eval_device
@@ -768,9 +825,63 @@ static int shard_enqueue_host(grape_ctx *s, const double *x, int n_x, double *ta
         s->dev_pending = false;
     }
     const size_t kn = KN(s);
-    std::memcpy(s->h_stage, x, sizeof(double) * kn * n_x);
-    HIP_TRY(s, hipMemcpyAsync(s->d_x, s->h_stage, sizeof(double) * kn * n_x, hipMemcpyHostToDevice, s->stream));
-    return enqueue_eval(s, s->d_x, target, s->stream, n_x);
+    const double *d_x = s->d_x;
+    if (s->x_upload == 2) {     // posted writes through the BAR; the doorbell of the launch below follows them
+        std::memcpy(s->d_x_bar, x, sizeof(double) * kn * n_x);
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#if defined(__x86_64__)
+        __builtin_ia32_sfence();
+#endif
+        d_x = s->d_x_bar;
+    } else {
+        std::memcpy(s->h_stage, x, sizeof(double) * kn * n_x);
+        if (s->x_upload == 1)   // a small kernel pulls x out of the coherent mapped staging buffer
+            HIP_TRY(s, grape::launch_copy(s->d_h_stage, s->d_x, (int)(kn * n_x), s->stream));
+        else
+            HIP_TRY(s, hipMemcpyAsync(s->d_x, s->h_stage, sizeof(double) * kn * n_x, hipMemcpyHostToDevice, s->stream));
+    }
+    grape::DoneSignal done;
+    if (signal) {                  // single GPU: the reduce kernel stages [G, F] in d_fg and its last workgroup
+        done.counter = s->d_done_counter;          // writes them to the mapped host buffer + the completion flag
+        done.flag = s->d_h_flag;
+        done.seq = ++s->seq;
+        done.host_out = target;
+        target = s->d_fg;
+    }
+    return enqueue_eval(s, d_x, target, s->stream, n_x, done);
+}
+
+// Blocks until the final kernel has published sequence number s->seq in the host flag (see
+// reduce.hip: signal_done): a plain load loop on coherent pinned memory, no runtime call on the fast
+// path.  Falls back to the stream for error detection and for the timeout.
+static int wait_flag(grape_ctx *s)
+{
+    volatile unsigned long long *flag = s->h_flag;
+    const unsigned long long want = s->seq;
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    long nap_ns = 20000;
+    for (unsigned it = 0;; ++it) {
+        if (*flag == want) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            return GRAPE_OK;
+        }
+        if ((it & 1023) != 1023) continue;
+        timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        const double el = (double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec);
+        if (el < 500e-6) continue;                          // spin phase
+        const hipError_t q = hipStreamQuery(s->stream);     // a failed kernel never publishes: ask the runtime
+        if (q != hipSuccess && q != hipErrorNotReady) HIP_TRY(s, q);
+        if (q == hipSuccess && *flag != want)
+            return fail(s, GRAPE_ERR_HIP, "evaluation finished without publishing its completion flag");
+        if (el > s->timeout_s)
+            return fail(s, GRAPE_ERR_TIMEOUT, "evaluation did not finish within " + std::to_string(s->timeout_s) +
+                                                  " s (GRAPE_EVAL_TIMEOUT_S): device presumed hung");
+        timespec nap{0, nap_ns};
+        nanosleep(&nap, nullptr);
+        if (nap_ns < 200000) nap_ns *= 2;
+    }
 }
 
 static int group_fail(grape_ctx *g, grape_ctx *s, int rc) { return fail(g, rc, s->err); }
@@ -840,12 +951,12 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
     if (!c->is_group && !c->comm) {
         // single GPU: the final reduce kernel writes its result straight into mapped pinned host
         // memory (no D2H copy node) and the host polls the stream
-        rc = shard_enqueue_host(c, x, n_x, c->d_h_fg);
+        rc = shard_enqueue_host(c, x, n_x, c->d_h_fg, true);
         if (rc) return rc;
     } else {
         if (c->is_group) {
             for (grape_ctx *s : c->sub) {
-                rc = shard_enqueue_host(s, x, 1, s->d_fg);
+                rc = shard_enqueue_host(s, x, 1, s->d_fg, false);
                 if (rc) return group_fail(c, s, rc);
             }
             NCCL_TRY(c, g_rccl.GroupStart());
@@ -858,23 +969,28 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
             }
             NCCL_TRY(c, g_rccl.GroupEnd());
         } else {
-            rc = shard_enqueue_host(c, x, 1, c->d_fg);
+            rc = shard_enqueue_host(c, x, 1, c->d_fg, false);
             if (rc) return rc;
             rc = enqueue_allreduce(c, c->d_fg, c->d_fg, c->stream);
             if (rc) return rc;
         }
         HIP_TRY(c, hipSetDevice(lead->device));
-        HIP_TRY(c, grape::launch_copy(lead->d_fg, lead->d_h_fg, (int)Q, lead->stream));
+        grape::DoneSignal done;
+        done.counter = lead->d_done_counter;
+        done.flag = lead->d_h_flag;
+        done.seq = ++lead->seq;
+        HIP_TRY(c, grape::launch_copy(lead->d_fg, lead->d_h_fg, (int)Q, lead->stream, done));
     }
+    rc = wait_flag(lead);                                    // [G, F] are in host memory
+    if (rc) return c->is_group ? group_fail(c, lead, rc) : rc;
     if (c->is_group) {
-        for (grape_ctx *s : c->sub) {
-            rc = wait_stream(s, s->stream);
-            if (rc) return group_fail(c, s, rc);
+        // the other shards' streams finish with the same all-reduce; drain them so that the next call
+        // (and the accessors) find every device idle -- they are done or microseconds from it
+        for (size_t i = 1; i < c->sub.size(); ++i) {
+            rc = wait_stream(c->sub[i], c->sub[i]->stream);
+            if (rc) return group_fail(c, c->sub[i], rc);
         }
         c->evaluated = true;
-    } else {
-        rc = wait_stream(c, c->stream);
-        if (rc) return rc;
     }
     for (int b = 0; b < n_x; ++b) {
         if (G) std::memcpy(G + (size_t)b * kn, lead->h_fg + (size_t)b * Q, sizeof(double) * kn);
@@ -1122,5 +1238,6 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
     info->comm_rank = c->comm_rank;
     info->members_first_device = c->is_group ? c->sub[0]->cfg.n_ensemble : c->cfg.n_ensemble;
     if (c->is_group) info->unitary_flow = c->sub[0]->unitary ? 1 : 0;
+    info->lane_pair = (c->is_group ? c->sub[0]->pair : c->pair) ? 1 : 0;
     return GRAPE_OK;
 }

@@ -7,6 +7,17 @@
 
 namespace grape {
 
+// optional host-visible completion signal of an evaluation's FINAL kernel (reduce.hip: signal_done);
+// flag == nullptr: none (device-pointer entry points, intermediate kernels)
+struct DoneSignal {
+    unsigned *counter = nullptr;               // device: workgroups of the final kernel that have finished
+    unsigned long long *flag = nullptr;        // coherent pinned host memory (device address)
+    unsigned long long seq = 0;                // value to publish
+    double *host_out = nullptr;                // reduce kernels: mapped host destination of [G, F]; the kernel's
+                                               // `fg` argument is then a DEVICE staging buffer that the last
+                                               // workgroup copies out in one coalesced burst before publishing
+};
+
 constexpr int kStampSlots = 8;   // [0..4] shader clock at phase boundaries, [5],[6] 100 MHz real time
 
 // Device-side view of one context.  All complex data is interleaved double2 {re, im}.
@@ -75,14 +86,15 @@ hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const Tile
 // G[q] = sum_k w_k member_out[k][q]  for q in [0, Q)  (Q = K*N + 1; the last entry is F).
 // partial: scratch of ksplit*Q doubles.  Deterministic (fixed summation tree).
 hipError_t launch_reduce(const double *member_out, const double *wts, double *partial, double *fg,
-                         int E, int Q, int ksplit, hipStream_t stream);
+                         int E, int Q, int ksplit, hipStream_t stream, DoneSignal done = DoneSignal());
 int reduce_ksplit(int E);
 // fg[q] = sum_b rows[b][q] over NB already-weighted rows (one launch, fixed summation tree).
 // n_x > 1: independent reductions, rows [x*NB, (x+1)*NB) -> fg + x*Q
-hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, int n_x, hipStream_t stream);
+hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, int n_x, hipStream_t stream,
+                              DoneSignal done = DoneSignal());
 
 // dst[i] = src[i], i < n: moves the all-reduced [G, F] into mapped pinned host memory (one small launch
 // instead of a D2H copy node: the host polls the stream)
-hipError_t launch_copy(const double *src, double *dst, int n, hipStream_t stream);
+hipError_t launch_copy(const double *src, double *dst, int n, hipStream_t stream, DoneSignal done = DoneSignal());
 
 }  // namespace grape

@@ -9,6 +9,68 @@
 
 namespace grape {
 
+// Host-visible completion without waiting for the kernel-end signal: the LAST workgroup of the final
+// kernel of an evaluation stores the evaluation's sequence number into coherent pinned host memory,
+// after every workgroup's result stores have been released at system scope.  Called by ONE thread per
+// workgroup whose own wave made (or, after a workgroup barrier + per-thread fence, covers) the stores.
+__device__ __forceinline__ void signal_done(DoneSignal d, unsigned nblocks)
+{
+    if (!d.flag)
+        return;
+    __threadfence_system();
+    const unsigned prev = atomicAdd(d.counter, 1u);
+    if (prev == nblocks - 1) {
+        __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch: behind this kernel
+        __threadfence_system();
+        __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Result stores of the reduce kernels when the evaluation ends in host memory.  251 workgroups each
+// pushing 64 bytes over PCIe and waiting for a system-scope fence cost ~10 us; instead every workgroup
+// stores its outputs into a DEVICE staging buffer with sc1 (write-through) stores, drains them
+// (s_waitcnt vmcnt(0)), and adds to an agent-scope counter; the workgroup whose add came last reads the
+// whole staging buffer with sc1 loads (MI355X guide, inter-workgroup hand-off table, row 1), writes it to
+// the mapped host buffer in one coalesced burst and publishes the sequence number.
+__device__ __forceinline__ void stage_store(double *stage, int i, double v)
+{
+    __hip_atomic_store(stage + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // global_store ... sc1
+}
+
+__device__ __forceinline__ void publish_via_last_block(DoneSignal d, const double *stage, int n_total, unsigned nblocks)
+{
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its own staging stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = atomicAdd(d.counter, 1u);
+        s_last = prev == nblocks - 1;
+        if (s_last)
+            __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last)
+        return;
+    for (int i0 = threadIdx.x; i0 < n_total; i0 += 8 * blockDim.x) {       // 8 sc1 loads in flight per thread
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            v[u] = i < n_total ? __hip_atomic_load(stage + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i < n_total)
+                d.host_out[i] = v[u];
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 constexpr int kTileQ = 64;    // outputs per block (one wave-width, coalesced)
 constexpr int kSubK = 4;      // member sub-lanes per block
 
@@ -43,7 +105,7 @@ __global__ __launch_bounds__(kTileQ *kSubK) void reduce_stage1(const double *__r
 // stage 2: fg[q] = sum_ks partial[q][ks]; 32 lanes per output, fixed xor-shuffle tree.
 constexpr int kMaxSplit = 32;
 __global__ __launch_bounds__(256) void reduce_stage2(const double *__restrict__ partial,
-                                                     double *__restrict__ fg, int Q, int ksplit)
+                                                     double *__restrict__ fg, int Q, int ksplit, DoneSignal done)
 {
     const int ks = threadIdx.x & (kMaxSplit - 1);
     const int q = blockIdx.x * (256 / kMaxSplit) + threadIdx.x / kMaxSplit;
@@ -51,15 +113,20 @@ __global__ __launch_bounds__(256) void reduce_stage2(const double *__restrict__ 
 #pragma unroll
     for (int d = kMaxSplit / 2; d >= 1; d >>= 1)
         v += __shfl_xor(v, d, 64);
-    if (ks == 0 && q < Q)
+    if (done.flag) {
+        if (ks == 0 && q < Q)
+            stage_store(fg, q, v);
+        publish_via_last_block(done, fg, Q, gridDim.x);
+    } else if (ks == 0 && q < Q) {
         fg[q] = v;
+    }
 }
 
 // single-stage reduction of NB already-weighted rows (the sweep kernel's workgroup partials):
 // a block owns 8 consecutive outputs x 32 row-lanes; every thread walks its rows with stride 32,
 // then the 32 partial sums of an output are added in a fixed order through LDS.
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restrict__ rows,
-                                                          double *__restrict__ fg, int NB, int Q)
+                                                          double *__restrict__ fg, int NB, int Q, DoneSignal done)
 {
     __shared__ double s_acc[32][9];
     const int ql = threadIdx.x & 7, bl = threadIdx.x >> 3;
@@ -68,8 +135,19 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restri
     fg += (size_t)blockIdx.y * Q;
     double acc = 0.0;
     if (q < Q) {
-        for (int b = bl; b < NB; b += 32)
-            acc += rows[(size_t)b * Q + q];
+        // 8 independent loads in flight per thread (a plain `acc += load` loop serialises the round trips);
+        // the additions keep the order b = bl, bl + 32, ...
+        for (int b0 = bl; b0 < NB; b0 += 256) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 32 * u;
+                v[u] = b < NB ? rows[(size_t)b * Q + q] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                acc += v[u];
+        }
     }
     s_acc[bl][ql] = acc;
     __syncthreads();
@@ -78,26 +156,38 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restri
 #pragma unroll
         for (int i = 1; i < 32; ++i)
             s += s_acc[i][ql];
-        fg[q] = s;
+        if (done.flag)
+            stage_store(fg, q, s);
+        else
+            fg[q] = s;
     }
+    if (done.flag)                                     // fg - blockIdx.y * Q: the staging buffer of all n_x reductions
+        publish_via_last_block(done, fg - (size_t)blockIdx.y * Q, Q * (int)gridDim.y, gridDim.x * gridDim.y);
 }
 
-hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, int n_x, hipStream_t stream)
+hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, int n_x, hipStream_t stream, DoneSignal done)
 {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((Q + 7) / 8, n_x), dim3(256), 0, stream, rows, fg, NB, Q);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((Q + 7) / 8, n_x), dim3(256), 0, stream, rows, fg, NB, Q, done);
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void copy_kernel(const double *__restrict__ src, double *__restrict__ dst, int n)
+__global__ __launch_bounds__(256) void copy_kernel(const double *__restrict__ src, double *__restrict__ dst, int n,
+                                                   DoneSignal done)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n)
         dst[i] = src[i];
+    if (done.flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0)
+            signal_done(done, gridDim.x);
+    }
 }
 
-hipError_t launch_copy(const double *src, double *dst, int n, hipStream_t stream)
+hipError_t launch_copy(const double *src, double *dst, int n, hipStream_t stream, DoneSignal done)
 {
-    hipLaunchKernelGGL(copy_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, dst, n);
+    hipLaunchKernelGGL(copy_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, dst, n, done);
     return hipGetLastError();
 }
 
@@ -111,7 +201,7 @@ int reduce_ksplit(int E)
 }
 
 hipError_t launch_reduce(const double *member_out, const double *wts, double *partial, double *fg,
-                         int E, int Q, int ksplit, hipStream_t stream)
+                         int E, int Q, int ksplit, hipStream_t stream, DoneSignal done)
 {
     const int per_split = (E + ksplit - 1) / ksplit;
     const dim3 g1((Q + kTileQ - 1) / kTileQ, ksplit), b1(kTileQ * kSubK);
@@ -121,7 +211,7 @@ hipError_t launch_reduce(const double *member_out, const double *wts, double *pa
         return e;
     const int per_block = 256 / kMaxSplit;
     hipLaunchKernelGGL(reduce_stage2, dim3((Q + per_block - 1) / per_block), dim3(256), 0, stream, partial,
-                       fg, Q, ksplit);
+                       fg, Q, ksplit, done);
     return hipGetLastError();
 }
 

@@ -25,6 +25,7 @@ FLAG_PHASE_STAMPS = 4
 FLAG_FORCE_GENERAL = 8
 FLAG_MEMBER_RESULTS = 16
 FLAG_FORCE_COLLECTIVE = 32
+FLAG_TIME_SAMPLED = 64
 MAX_DEVICES = 8
 ABI_VERSION = 2
 
@@ -61,7 +62,7 @@ class GrapeInfo(C.Structure):
                 ("expm_squarings", C.c_int32), ("kernel_family", C.c_int32), ("unitary_flow", C.c_int32),
                 ("expm_theta", C.c_double), ("workspace_bytes", C.c_uint64), ("arch", C.c_char * 32),
                 ("n_devices", C.c_int32), ("comm_size", C.c_int32), ("comm_rank", C.c_int32),
-                ("members_first_device", C.c_int32)]
+                ("members_first_device", C.c_int32), ("lane_pair", C.c_int32)]
 
 
 class GrapeCommId(C.Structure):
@@ -175,6 +176,7 @@ class GrapeEngine:
         if rc:
             raise GrapeError(rc, self._lib.grape_last_error(None).decode())
         self._h = h
+        self._F = C.c_double()
         self._check(self._lib.grape_set_operators(h, _p(_cm(A)), _p(_cm(B)), _p(_cm(Xi)), _p(_cm(Xt)),
                                                   _p(wts)))
 
@@ -234,6 +236,20 @@ class GrapeEngine:
         G = np.empty((self.N, self.K)) if want_G else None
         self._check(self._lib.grape_eval(self._h, _p(xf), C.byref(F) if want_F else None, _p(G)))
         return (F.value if want_F else None), (np.ascontiguousarray(G.T) if want_G else None)
+
+    def eval_cm(self, xf, G_out=None):
+        """grape_eval on caller-owned buffers in the library's own layout, no copies: xf is x as (K,N) COLUMN-major
+        memory, i.e. a C-contiguous float64 array of shape (N, K); G_out (same shape, or None to skip G) receives
+        the gradient in that layout.  Returns F.  This is what a compiled caller (the Julia ccall) does per
+        optimiser step; eval() is the convenience form with natural (K, N) arrays."""
+        if xf.dtype != np.float64 or not xf.flags.c_contiguous or xf.shape != (self.N, self.K):
+            raise ValueError(f"xf must be a C-contiguous float64 array of shape ({self.N},{self.K})")
+        if G_out is not None and (G_out.dtype != np.float64 or not G_out.flags.c_contiguous or G_out.shape != xf.shape):
+            raise ValueError("G_out must match xf")
+        rc = self._lib.grape_eval(self._h, xf.ctypes.data, C.byref(self._F), G_out.ctypes.data if G_out is not None else None)
+        if rc:
+            self._check(rc)
+        return self._F.value
 
     def eval_batch(self, X):
         """grape_eval_batch: X (n_x, K, N) control arrays -> (F (n_x,), G (n_x, K, N)); entry b equals
