@@ -137,7 +137,7 @@ def make_case(name, w, variant):
     }
 
 
-def main():
+def main(only=None):
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
     wl = qoc.workloads
@@ -147,11 +147,18 @@ def main():
         ("ug_2x2_ens", wl.reference_ensemble("UnitaryGate", 3, 8, 5.0)),
         ("ug_4x4_ens", wl.config("C3", E=3, N=12)),
         ("st_4x4_ens", None),
+        ("ug_4x4_bignorm", "bignorm"),                # dt |H| ~ 10-20: expm scaling + squaring path
         ("st_8x8_pairs", "rand8"),                    # tile kernels, two members per 16x16 tile
         ("ct_16x16_nonherm", "rand16"),               # tile kernels, non-Hermitian generator
     ]
     for name, w in cases:
-        if isinstance(w, str):                         # seeded random problems for the MFMA tile kernels
+        if only and name not in only:
+            continue
+        if w == "bignorm":                             # C3 operators, T = 40 over 10 slices
+            w = wl.config("C3", E=2, N=10)
+            w.T = 40.0
+            variants = (0,)
+        elif isinstance(w, str):                       # seeded random problems for the MFMA tile kernels
             n = 8 if w == "rand8" else 16
             rng = np.random.default_rng(n)
             E, K, N = (3, 2, 5) if n == 8 else (2, 2, 4)
@@ -190,4 +197,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(set(sys.argv[1:]))              # optional: names of the cases to (re)generate

@@ -165,8 +165,11 @@ def two_qubit_unitary(E=1024, N=500, T=2.0):
                     np.full(E, 1.0 / E), controls(K, N))
 
 
-def two_qubit_liouvillian(E=1024, N=1000, T=5.0, gamma1=0.02, gamma_phi=0.05):
-    """C4: CoherenceTransfer on 16x16 Liouvillian superoperators (non-Hermitian generator)."""
+def two_qubit_liouvillian(E=1024, N=1000, T=5.0, gamma1=0.02, gamma_phi=0.05, target="generic"):
+    """C4: CoherenceTransfer on 16x16 Liouvillian superoperators (non-Hermitian generator).
+    target="generic" (bench / per-member parity): |00> -> a generic superposition;
+    target="survey": SURVEY.md 8d's original |00> -> |11> transfer, whose far-detuned members have
+    gradients ~1e-10 of O(1) terms -- only the norm-wise ENSEMBLE parity metric is meaningful there."""
     K = 4
     d = detunings(E)
     H0 = np.kron(Sx, Sz)
@@ -183,7 +186,10 @@ def two_qubit_liouvillian(E=1024, N=1000, T=5.0, gamma1=0.02, gamma_phi=0.05):
     # |00> -> a generic superposition: with the |11> target the far-detuned members' gradients
     # are ~1e-10 of O(1) terms, which makes a relative parity metric meaningless for them
     psi0 = np.zeros(4, complex); psi0[0] = 1
-    psiT = np.array([1, 1j, -1, 0.5], complex); psiT /= np.linalg.norm(psiT)
+    if target == "survey":
+        psiT = np.zeros(4, complex); psiT[3] = 1
+    else:
+        psiT = np.array([1, 1j, -1, 0.5], complex); psiT /= np.linalg.norm(psiT)
     v0 = np.outer(psi0, psi0.conj()).reshape(16, order="F")
     vT = np.outer(psiT, psiT.conj()).reshape(16, order="F")
     Xi = np.outer(v0, v0.conj())
@@ -218,9 +224,9 @@ def five_qubit_unitary(E=4096, N=2000, T=10.0):
                     np.full(E, 1.0 / E), controls(K, N))
 
 
-def config(name, E=None, N=None):
+def config(name, E=None, N=None, **extra):
     """BASELINE.json configs by name; E/N override for bounded samples and parity sizes."""
-    kw = {}
+    kw = dict(extra)
     if E is not None:
         kw["E"] = E
     if N is not None:

@@ -1,0 +1,20 @@
+// Host-only stand-ins for the kernel launchers of libgrape_hip.so, for the CPU sanitizer build of the C-ABI
+// host layer (tests/test_sanitizers.py).  No device code exists in that build: every launcher reports
+// hipErrorNoDevice; the sizing helpers answer like the real ones so that grape_create's validation and
+// planning logic runs unchanged.  TEST INFRASTRUCTURE ONLY.
+#include "../../quoptimalcontrol.jl_amd/csrc/grape_kernels.hpp"
+
+namespace grape {
+hipError_t launch_sweep_small(int, int, int, const SweepParams &, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_sweep_pair(int, int, int, const SweepParams &, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_sweep_tile(int, int, bool, const TileParams &, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_reduce(const double *, const double *, double *, double *, int, int, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
+hipError_t launch_reduce_rows(const double *, double *, int, int, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
+hipError_t launch_copy(const double *, double *, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
+int sweep_small_max_waves(int n) { return n == 2 ? 16 : (n == 3 ? 8 : (n == 4 ? 4 : 0)); }
+int sweep_pair_max_waves(int n) { return n == 2 ? 16 : (n == 4 ? 8 : 0); }
+size_t sweep_small_lds_bytes(int n, int MPB, int LT, int S, int K, bool x) { return 16 * (size_t)n * n * 32 + (x ? 8 * ((size_t)MPB * LT * ((size_t)S * K + 1) + MPB) : 0); }
+size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool x) { return 16 * (size_t)n * n * 32 + 16 * (size_t)MPB * 2 * (2 * K + 3) * n * n / 2 + (x ? 8 * ((size_t)MPB * (LT / 2) * ((size_t)S * K + 1) + MPB) : 0); }
+int tile_count(int n) { return n <= 4 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : 0)); }
+int reduce_ksplit(int E) { int ks = (E + 31) / 32; return ks > 32 ? 32 : (ks < 1 ? 1 : ks); }
+}  // namespace grape

@@ -136,3 +136,32 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("name,E,members", [("C4", 1024, (0, 1, 511, 1023)), ("C5", 1024, (0, 1023))])
+def test_full_size_spot_members(qoc, oracle, name, E, members):
+    """Full BASELINE sizes (C4: E = 1024, N = 1000 -- the two-wave chain kernel the bench runs; C5: E = 1024 of
+    4096, N = 2000, the unitary tile flow): spot members against the oracle, the weighted sum, reproducibility.
+    The small-E parity tests above take different launch branches (E < 2048, pack2, LDS fit)."""
+    w = qoc.workloads.config(name, E=E)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+        F2, G2 = eng.eval(w.x)
+    assert F == F2 and np.array_equal(G, G2)
+    assert abs(F - foms @ w.wts) <= 1e-12 * max(1.0, abs(F))
+    assert np.abs(G - np.tensordot(w.wts, grads, 1)).max() <= 1e-13 * np.abs(G).max() + 1e-16
+    for k in members:
+        F_ref, g_ref = oracle.member_eval(w.sys_type, w.A[k], w.B[k], w.Xi[k], w.Xt[k], w.x, w.T)
+        assert_parity(foms[k], grads[k], F_ref, g_ref, w.n, what=f"{name} member {k}")
+
+
+def test_c4_survey_target_ensemble_metric(qoc, oracle):
+    """SURVEY.md 8d's original C4 target (|00> -> |11>): far-detuned members have gradients ~1e-10 of O(1)
+    terms, so only the norm-wise ENSEMBLE metric of the north star is applied (per-member parity is covered
+    by the generic-target case above)."""
+    w = qoc.workloads.config("C4", E=12, N=1000, target="survey")
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, n_threads=8)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        F, G = eng.eval(w.x)
+    assert_parity(F, G, F_ref, G_ref, w.n, what="C4 survey target, ensemble")
