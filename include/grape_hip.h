@@ -214,10 +214,10 @@ int grape_get_member_results(grape_ctx *ctx, double *foms, double *grads);
 
 /* The stores the reference keeps per member (src/grape_tools.jl:4-16), for parity tests:
  *   props     c128 (n,n,N)     propagators[t],  t = 0..N-1
- *   states    c128 (n,n,N+1)   fwd_state_store[t], t = 0..N   (states[0] = Xi); for n <= 4 they
+ *   states    c128 (n,m,N+1)   fwd_state_store[t], t = 0..N   (states[0] = Xi); for n <= 4 they
  *                              are stored only under GRAPE_FLAG_KEEP_COSTATES (the fast flows
  *                              rebuild them on the fly), else GRAPE_ERR_NOT_READY.
- *   costates  c128 (n,n,N+1)   bwd_costate_store[t], t = 0..N (costates[N] = Xt);
+ *   costates  c128 (n,m,N+1)   bwd_costate_store[t], t = 0..N (costates[N] = Xt);
  *                              needs GRAPE_FLAG_KEEP_COSTATES, else GRAPE_ERR_NOT_READY.
  * Any of the three may be NULL. */
 int grape_get_trajectory(grape_ctx *ctx, int32_t member, double *props, double *states,

@@ -414,6 +414,103 @@ int oracle_ensemble_eval(int sys_type, int variant, int n, int K, int N, int E, 
     return rc_all;
 }
 
+/* ---------------------------------------------------------------- n x m states (UnitaryGate dispatch)
+ *
+ * The reference's UnitaryGate methods (evolve_func! src/GRAPE.jl:216-230, grad_func! :261-273,
+ * fom_func src/cost_functions.jl:99-101) only ever left-multiply the states by n x n propagators and take
+ * traces of m x m products, and init_GRAPE allocates `similar(Xi)` (src/grape_tools.jl:6-8): nothing
+ * requires Xi, Xt to be square.  m = 1 is the vectorised density matrix evolved by Liouvillian
+ * superoperators that test/liou.jl:38-48 writes out by hand.  Same operation order as
+ * oracle_member_eval_ws with rectangular products.  Xi, Xt: (n, m) column-major. */
+static void mm_rect(int n, int m, const cplx *P, const cplx *X, cplx *out)          /* (n x n)(n x m) */
+{
+    for (int j = 0; j < m; ++j)
+        for (int i = 0; i < n; ++i) {
+            cplx s = 0.0;
+            for (int k = 0; k < n; ++k)
+                s += P[i + k * n] * X[k + j * n];
+            out[i + j * n] = s;
+        }
+}
+
+static void mm_ah_rect(int n, int m, const cplx *P, const cplx *L, cplx *out)       /* (n x n)' (n x m) */
+{
+    for (int j = 0; j < m; ++j)
+        for (int i = 0; i < n; ++i) {
+            cplx s = 0.0;
+            for (int k = 0; k < n; ++k)
+                s += conj(P[k + i * n]) * L[k + j * n];
+            out[i + j * n] = s;
+        }
+}
+
+static cplx trace_xh_y(int n, int m, const cplx *X, const cplx *Y)                  /* tr(X' Y), both n x m */
+{
+    cplx tr = 0.0;                                       /* diagonal of the m x m product, column by column */
+    for (int j = 0; j < m; ++j) {
+        cplx s = 0.0;
+        for (int k = 0; k < n; ++k)
+            s += conj(X[k + j * n]) * Y[k + j * n];
+        tr += s;
+    }
+    return tr;
+}
+
+int oracle_member_eval_rect(int variant, int n, int m, int K, int N, double T, const cplx *A, const cplx *B,
+                            const cplx *Xi, const cplx *Xt, const double *x, double *fom, double *grad,
+                            cplx *props_out, cplx *states_out, cplx *costates_out)
+{
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m;
+    cplx *props = (cplx *)malloc(sizeof(cplx) * (nn * N + 2 * nm * (N + 1) + 2 * nn + nm));
+    if (!props) return -2;
+    cplx *states = props + nn * N, *costates = states + nm * (N + 1);
+    cplx *H = costates + nm * (N + 1), *t1 = H + nn, *bx = t1 + nn;
+    const double dt = T / N;
+    memcpy(states, Xi, sizeof(cplx) * nm);
+    memcpy(costates + nm * N, Xt, sizeof(cplx) * nm);
+    const cplx mi_dt = CMPLX(-0.0, -1.0) * dt;
+    int rc = 0;
+    for (int i = 0; i < N && rc == 0; ++i) {
+        if (variant == 0) {
+            for (size_t e = 0; e < nn; ++e) H[e] = 0.0;
+            for (int j = 0; j < K; ++j)
+                for (size_t e = 0; e < nn; ++e)
+                    H[e] = H[e] + B[e + nn * j] * x[j + (size_t)i * K];
+            for (size_t e = 0; e < nn; ++e) t1[e] = mi_dt * (H[e] + A[e]);
+        } else {
+            for (size_t e = 0; e < nn; ++e) H[e] = A[e];
+            for (int j = 0; j < K; ++j)
+                for (size_t e = 0; e < nn; ++e)
+                    H[e] = H[e] + B[e + nn * j] * x[j + (size_t)i * K];
+            for (size_t e = 0; e < nn; ++e) t1[e] = mi_dt * H[e];
+        }
+        rc = oracle_expm(n, t1, props + nn * i);
+    }
+    if (rc) { free(props); return rc; }
+    for (int t = 0; t < N; ++t)                                   /* GRAPE.jl:226 */
+        mm_rect(n, m, props + nn * t, states + nm * t, states + nm * (t + 1));
+    for (int t = N - 1; t >= 0; --t)                              /* GRAPE.jl:228 */
+        mm_ah_rect(n, m, props + nn * t, costates + nm * (t + 1), costates + nm * t);
+    for (int c = 0; c < K; ++c)                                   /* GRAPE.jl:79-92, :261-273 */
+        for (int t = 0; t < N; ++t) {
+            const cplx *X = states + nm * t, *L = costates + nm * t;
+            mm_rect(n, m, B + nn * c, X, bx);                     /* B X ; tr(L' B X) = tr(L' (B X)) */
+            const cplx tr1 = trace_xh_y(n, m, L, bx);
+            const cplx tr2 = trace_xh_y(n, m, X, L);              /* tr(X' L) */
+            const cplx idt = (variant == 0 ? CMPLX(0.0, 1.0) : CMPLX(-0.0, -1.0)) * dt;
+            grad[c + (size_t)t * K] = 2.0 * creal(idt * tr1 * tr2);
+        }
+    {
+        const cplx z = trace_xh_y(n, m, states + nm * (N - 1), costates + nm * (N - 1));
+        *fom = creal(z * z);                                      /* cost_functions.jl:99-101 */
+    }
+    if (props_out) memcpy(props_out, props, sizeof(cplx) * nn * N);
+    if (states_out) memcpy(states_out, states, sizeof(cplx) * nm * (N + 1));
+    if (costates_out) memcpy(costates_out, costates, sizeof(cplx) * nm * (N + 1));
+    free(props);
+    return 0;
+}
+
 /* C1(KT, KN) = 1 - |tr(KT' KN)/D|^2   -- src/cost_functions.jl:13-17 */
 double oracle_C1(int n, const cplx *KT, const cplx *KN)
 {

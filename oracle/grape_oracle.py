@@ -45,6 +45,8 @@ def lib():
         L.oracle_member_eval.restype = C.c_int
         L.oracle_ensemble_eval.argtypes = [C.c_int] * 6 + [C.c_double] + [vp] * 6 + [dp, vp, vp, vp, C.c_int]
         L.oracle_ensemble_eval.restype = C.c_int
+        L.oracle_member_eval_rect.argtypes = [C.c_int] * 5 + [C.c_double] + [vp] * 4 + [vp, dp, vp, vp, vp, vp]
+        L.oracle_member_eval_rect.restype = C.c_int
         L.oracle_C1.argtypes = [C.c_int, vp, vp]
         L.oracle_C1.restype = C.c_double
         _LIB = L
@@ -86,6 +88,8 @@ def C1(KT, KN):
 def member_eval(sys_type, A, B, Xi, Xt, x, T, variant=0, trajectory=False):
     """One member: returns (F, G[K,N]) or (F, G, props[N,n,n], states[N+1,n,n], costates[N+1,n,n])."""
     st = SYS_TYPES[sys_type] if isinstance(sys_type, str) else int(sys_type)
+    if np.asarray(Xi).shape[-1] != np.asarray(A).shape[-1]:
+        return member_eval_rect(A, B, Xi, Xt, x, T, variant, trajectory, st)
     A = pack_cm(A)
     n = A.shape[0]
     B = pack_cm(B)
@@ -113,9 +117,47 @@ def member_eval(sys_type, A, B, Xi, Xt, x, T, variant=0, trajectory=False):
     return fom.value, G
 
 
+def member_eval_rect(A, B, Xi, Xt, x, T, variant=0, trajectory=False, st=0):
+    """n x m states (m < n), UnitaryGate dispatch only: (F, G) [+ props (N,n,n), states, costates (N+1,n,m)]."""
+    if st != 0:
+        raise ValueError("n x m states need UnitaryGate (the sandwich X P' is undefined for m != n)")
+    A, B, Xi, Xt = pack_cm(A), pack_cm(B), pack_cm(Xi), pack_cm(Xt)
+    n, K, m = A.shape[0], B.shape[0], Xi.shape[0]
+    x = np.asarray(x, dtype=np.float64)
+    N = x.shape[1]
+    xf = np.ascontiguousarray(x.T)
+    grad = np.empty((N, K))
+    fom = C.c_double()
+    props = np.empty((N, n, n), np.complex128) if trajectory else None
+    sts = np.empty((N + 1, m, n), np.complex128) if trajectory else None
+    cos = np.empty((N + 1, m, n), np.complex128) if trajectory else None
+    rc = lib().oracle_member_eval_rect(variant, n, m, K, N, float(T), _p(A), _p(B), _p(Xi), _p(Xt), _p(xf),
+                                       C.byref(fom), _p(grad), _p(props) if trajectory else None,
+                                       _p(sts) if trajectory else None, _p(cos) if trajectory else None)
+    if rc:
+        raise RuntimeError(f"oracle_member_eval_rect failed rc={rc}")
+    G = np.ascontiguousarray(grad.T)
+    if trajectory:
+        sw = lambda a: np.ascontiguousarray(np.swapaxes(a, -1, -2))
+        return fom.value, G, sw(props), sw(sts), sw(cos)
+    return fom.value, G
+
+
 def ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, T, variant=0, n_threads=1, per_member=False):
     """Ensemble closure (src/solve.jl:164-196): returns (F, G[K,N]) [+ foms[E], grads[E,K,N]]."""
     st = SYS_TYPES[sys_type] if isinstance(sys_type, str) else int(sys_type)
+    if np.asarray(Xi).shape[-1] != np.asarray(A).shape[-1]:         # n x m states: member loop in k order, then the weighted sums
+        res = [member_eval(sys_type, A[k], B[k], Xi[k], Xt[k], x, T, variant) for k in range(len(A))]
+        foms = np.array([r[0] for r in res])
+        grads = np.array([r[1] for r in res])
+        wts = np.asarray(wts, dtype=np.float64)
+        F = 0.0
+        for k in range(len(A)):
+            F += foms[k] * wts[k]
+        G = np.zeros_like(grads[0])
+        for k in range(len(A)):
+            G += grads[k] * wts[k]
+        return (F, G, foms, grads) if per_member else (F, G)
     A = pack_cm(A)
     E, n = A.shape[0], A.shape[1]
     B = pack_cm(B)

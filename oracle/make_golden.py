@@ -122,7 +122,8 @@ def make_case(name, w, variant):
     Gtot = [[sum(gs[k][c][t] * mpf(float(w.wts[k])) for k in range(w.E)) for t in range(w.N)]
             for c in range(w.K)]
     return {
-        "name": name, "sys_type": w.sys_type, "variant": variant, "n": w.n, "K": w.K, "N": w.N, "E": w.E,
+        "name": name, "sys_type": w.sys_type, "variant": variant, "n": w.n, "m": int(np.asarray(w.Xi).shape[-1]),
+        "K": w.K, "N": w.N, "E": w.E,
         "T": w.T, "digits": mp.dps,
         "layout": "matrices column-major [re, im]; x, G, g as [c][t]",
         "inputs": {"A": [np_cm(a) for a in w.A], "B": [[np_cm(b) for b in bk] for bk in w.B],
@@ -147,6 +148,8 @@ def main(only=None):
         ("ug_2x2_ens", wl.reference_ensemble("UnitaryGate", 3, 8, 5.0)),
         ("ug_4x4_ens", wl.config("C3", E=3, N=12)),
         ("st_4x4_ens", None),
+        ("vec_4x1_liou", wl.liouville_vec(1, 3, 9, 1.0)),                 # n x 1 states, Hermitian superoperators
+        ("vec_16x1_diss", wl.liouville_vec(2, 2, 4, 1.0, dissipative=True)),   # n x 1, non-Hermitian (tile kernels)
         ("ug_4x4_bignorm", "bignorm"),                # dt |H| ~ 10-20: expm scaling + squaring path
         ("st_8x8_pairs", "rand8"),                    # tile kernels, two members per 16x16 tile
         ("ct_16x16_nonherm", "rand16"),               # tile kernels, non-Hermitian generator
@@ -186,6 +189,8 @@ def main(only=None):
             w.sys_type = "StateTransfer"
             w.Xi = np.array([rho0, rho0]); w.Xt = np.array([rhoT, rhoT])
             variants = (0, 1)
+        elif name == "vec_16x1_diss":
+            variants = (0,)
         else:
             variants = (0, 1)
         for variant in variants:

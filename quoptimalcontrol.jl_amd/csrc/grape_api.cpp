@@ -46,6 +46,7 @@ struct grape_ctx {
     int device = 0;
     int compute_units = 0;
     char arch[32] = {0};
+    int m = 0;                    // state columns (Xi, Xt are n x m); m < n runs zero-padded to n x n
     int family = 0;               // 0: register-resident small-n kernels, 1: MFMA tile kernels
     int NT = 0;                   // tile family: tiles per dimension (padded n = 16 NT)
     size_t TSZ = 0;               // tile family: double2 per matrix dump
@@ -243,8 +244,6 @@ static int validate_config(const grape_config *cfg)
     if (m != cfg->n && cfg->sys_type != GRAPE_UNITARY_GATE)
         return fail(nullptr, GRAPE_ERR_INVALID_ARG,
                     "grape_create: n x m states with m < n need UnitaryGate (the sandwich X P' is not defined)");
-    if (m != cfg->n)
-        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: n_state_cols != n has no kernel in this build");
     if (cfg->max_batch > 1 && wmax == 0)
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: max_batch > 1 needs operator dimension n <= 4 in this build");
     if ((cfg->flags & GRAPE_FLAG_PHASE_STAMPS) && wmax == 0)
@@ -277,6 +276,7 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     grape_ctx *c = new (std::nothrow) grape_ctx();
     if (!c) return fail(nullptr, GRAPE_ERR_ALLOC, "grape_create: out of host memory");
     c->cfg = *cfg;
+    c->m = cfg->n_state_cols ? cfg->n_state_cols : cfg->n;
     c->device = dev;
     c->compute_units = prop.multiProcessorCount;
     std::snprintf(c->arch, sizeof(c->arch), "%s", prop.gcnArchName);
@@ -578,10 +578,11 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         return fail(c, GRAPE_ERR_INVALID_ARG, "grape_set_operators: null argument");
     if (c->is_group) {                                       // hand every device its contiguous member block
         const size_t nn2 = 2 * (size_t)c->cfg.n * c->cfg.n, Kc = c->cfg.n_controls;
+        const size_t nm2 = 2 * (size_t)c->cfg.n * (c->cfg.n_state_cols ? c->cfg.n_state_cols : c->cfg.n);
         for (size_t i = 0; i < c->sub.size(); ++i) {
             const size_t lo = (size_t)c->sub_lo[i];
-            const int rc = grape_set_operators(c->sub[i], A + lo * nn2, B + lo * Kc * nn2, Xi + lo * nn2,
-                                               Xt + lo * nn2, wts + lo);
+            const int rc = grape_set_operators(c->sub[i], A + lo * nn2, B + lo * Kc * nn2, Xi + lo * nm2,
+                                               Xt + lo * nm2, wts + lo);
             if (rc) return fail(c, rc, c->sub[i]->err);
         }
         c->ops_set = true;
@@ -590,6 +591,26 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     }
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t nn = (size_t)c->cfg.n * c->cfg.n, K = c->cfg.n_controls, E = c->cfg.n_ensemble;
+    // n x m states with m < n (UnitaryGate-style left multiplication of m column vectors, e.g. m = 1:
+    // a vectorised density matrix under Liouvillian superoperators, test/liou.jl:38-48): run zero-padded
+    // to n x n.  Every product keeps the padding columns zero and both traces only add zeros, so F and g
+    // are exactly those of the n x m problem (the kernels do n/m times the minimal chain work).
+    std::vector<double> xi_pad, xt_pad;
+    if (c->m != c->cfg.n) {
+        const size_t nm = (size_t)c->cfg.n * c->m;
+        try {
+            xi_pad.assign(2 * E * nn, 0.0);
+            xt_pad.assign(2 * E * nn, 0.0);
+        } catch (...) {
+            return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: out of host memory");
+        }
+        for (size_t k = 0; k < E; ++k) {
+            std::memcpy(xi_pad.data() + 2 * k * nn, Xi + 2 * k * nm, sizeof(double) * 2 * nm);
+            std::memcpy(xt_pad.data() + 2 * k * nn, Xt + 2 * k * nm, sizeof(double) * 2 * nm);
+        }
+        Xi = xi_pad.data();
+        Xt = xt_pad.data();
+    }
     std::vector<double> packed;
     try {
         packed.assign(c->family == 0 ? 2 * E * (K + 3) * nn : 2 * (size_t)c->EU * (2 * K + 3) * c->TSZ, 0.0);
@@ -1125,6 +1146,18 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
     int rc = fetch_slab(c, c->d_props, member, P.data());
     if (rc) return rc;
     if (props) std::memcpy(props, P.data(), sizeof(cplx) * N * nn);
+    // n x m states: the workspace holds them zero-padded to n x n; hand out the first m columns
+    std::vector<cplx> xs_full, ls_full;
+    double *states_user = states, *costates_user = costates;
+    if (c->m != n) {
+        if (states) { xs_full.resize((N + 1) * nn); states = reinterpret_cast<double *>(xs_full.data()); }
+        if (costates) { ls_full.resize((N + 1) * nn); costates = reinterpret_cast<double *>(ls_full.data()); }
+    }
+    auto narrow = [&](const std::vector<cplx> &full, double *user) {
+        const size_t nm = (size_t)n * c->m;
+        for (size_t t = 0; t <= N; ++t)
+            std::memcpy(reinterpret_cast<cplx *>(user) + t * nm, full.data() + t * nn, sizeof(cplx) * nm);
+    };
     if (states) {
         cplx *X = reinterpret_cast<cplx *>(states);
         rc = fetch_slab(c, c->d_states, member, X);
@@ -1171,6 +1204,10 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
                                 Lc[N * nn + row + (size_t)n * col] = h[(size_t)((I * c->NT + J) * 4 + r) * 64 + l];
                         }
         }
+    }
+    if (c->m != n) {
+        if (states_user) narrow(xs_full, states_user);
+        if (costates_user) narrow(ls_full, costates_user);
     }
     return GRAPE_OK;
 }

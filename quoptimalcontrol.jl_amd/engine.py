@@ -150,8 +150,9 @@ class GrapeEngine:
         K = B.shape[1]
         Xi = np.asarray(Xi, dtype=np.complex128)
         Xt = np.asarray(Xt, dtype=np.complex128)
-        if B.shape != (E, K, n, n) or Xi.shape != (E, n, n) or Xt.shape != (E, n, n):
-            raise ValueError("operator shapes disagree (Xi/Xt must be n x n like A)")
+        if Xi.ndim != 3 or Xi.shape[:2] != (E, n) or Xt.shape != Xi.shape or not 1 <= Xi.shape[2] <= n or B.shape != (E, K, n, n):
+            raise ValueError("operator shapes disagree (B (E,K,n,n); Xi, Xt (E,n,m) with 1 <= m <= n)")
+        m = Xi.shape[2]
         wts = np.ascontiguousarray(wts, dtype=np.float64)
         if wts.shape != (E,):
             raise ValueError("wts must have one weight per member")
@@ -164,12 +165,13 @@ class GrapeEngine:
             raise ValueError(f"at most {MAX_DEVICES} devices")
         code = SYS_TYPE_CODES[sys_type] if isinstance(sys_type, str) else int(sys_type)
         self.sys_type, self.n, self.K, self.N, self.E, self.T = sys_type, n, K, int(n_slices), E, float(T)
+        self.m = m
         ids = (C.c_int32 * MAX_DEVICES)(*(devices + [0] * (MAX_DEVICES - len(devices))))
         if len(devices) == 1:
             device = devices[0]
         cfg = GrapeConfig(code, int(variant), n, K, int(n_slices), E, float(T), int(device), int(flags),
                           int(slices_per_lane), int(waves_per_member), int(expm_squarings), int(max_batch),
-                          0, len(devices) if len(devices) > 1 else 0, ids)
+                          0 if m == n else m, len(devices) if len(devices) > 1 else 0, ids)
         self.max_batch = max(1, int(max_batch))
         h = C.c_void_p()
         rc = self._lib.grape_create(C.byref(cfg), C.byref(h))
@@ -281,10 +283,10 @@ class GrapeEngine:
         return foms, np.ascontiguousarray(np.swapaxes(grads, 1, 2))
 
     def trajectory(self, member, costates=False, states=True):
-        n, N = self.n, self.N
+        n, N, m = self.n, self.N, self.m
         P = np.empty((N, n, n), np.complex128)
-        X = np.empty((N + 1, n, n), np.complex128) if states else None
-        Lc = np.empty((N + 1, n, n), np.complex128) if costates else None
+        X = np.empty((N + 1, m, n), np.complex128) if states else None       # column-major n x m each
+        Lc = np.empty((N + 1, m, n), np.complex128) if costates else None
         self._check(self._lib.grape_get_trajectory(self._h, int(member), _p(P), _p(X), _p(Lc)))
         sw = lambda a: None if a is None else np.ascontiguousarray(np.swapaxes(a, -1, -2))
         return (sw(P), sw(X), sw(Lc)) if costates else (sw(P), sw(X))

@@ -198,6 +198,40 @@ def two_qubit_liouvillian(E=1024, N=1000, T=5.0, gamma1=0.02, gamma_phi=0.05, ta
                     _bcast(Xt, E), np.full(E, 1.0 / E), controls(K, N))
 
 
+def liouville_vec(nq=1, E=3, N=10, T=1.0, dissipative=False, gamma1=0.02, gamma_phi=0.05):
+    """Vectorised density matrices under Liouvillian superoperators, as test/liou.jl:8-48 writes out by hand
+    (SURVEY.md 8f-3): n = 4^nq / 2^nq ... i.e. n = d^2 with d = 2^nq, states n x 1 = vec(rho) (column stacking),
+    UnitaryGate-style left multiplication.  Drift to_superoperator(H0 + delta_k Hz) [+ i D for `dissipative`],
+    controls to_superoperator(pi sigma_x), to_superoperator(pi sigma_y) per qubit (test/liou.jl:5),
+    vec(|0..0><0..0|) -> vec(|1..1><1..1|)."""
+    d = 2 ** nq
+    n = d * d
+    sx, sy, sz = 2 * Sx, 2 * Sy, 2 * Sz
+    H0 = sum(site_op(sz, q, nq) for q in range(nq)) / nq
+    if nq > 1:
+        H0 = H0 + 0.5 * sum(site_op(sz, q, nq) @ site_op(sz, q + 1, nq) for q in range(nq - 1))
+    Hz = sum(site_op(Sz, q, nq) for q in range(nq))
+    dlt = detunings(E) * 0.2
+    Dis = np.zeros((n, n), complex)
+    if dissipative:
+        sm = np.array([[0, 1], [0, 0]], complex)
+        for q in range(nq):
+            Dis += dissipator(np.sqrt(gamma1) * site_op(sm, q, nq))
+            Dis += dissipator(np.sqrt(gamma_phi) * site_op(Sz, q, nq))
+    A = np.array([to_superoperator(H0 + dk * Hz) + 1j * Dis for dk in dlt])
+    Bs = []
+    for q in range(nq):
+        Bs += [to_superoperator(np.pi * site_op(sx, q, nq)), to_superoperator(np.pi * site_op(sy, q, nq))]
+    Bs = np.array(Bs)
+    K = len(Bs)
+    psi0 = np.zeros(d, complex); psi0[0] = 1
+    psiT = np.zeros(d, complex); psiT[-1] = 1
+    v0 = np.outer(psi0, psi0.conj()).reshape(n, 1, order="F")
+    vT = np.outer(psiT, psiT.conj()).reshape(n, 1, order="F")
+    return Workload(f"vec{n}x1", "UnitaryGate", n, K, N, E, T, A, _bcast(Bs, E), _bcast(v0, E), _bcast(vT, E),
+                    np.full(E, 1.0 / E), controls(K, N) * 0.3)
+
+
 def _haar_unitary(n):
     u = uniform(2, 2 * n * n * 2)
     r = np.sqrt(-2.0 * np.log(1.0 - u[0::2])) * np.exp(2j * np.pi * u[1::2])   # Box-Muller
