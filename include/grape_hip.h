@@ -139,6 +139,8 @@ typedef struct grape_info {
     int32_t comm_rank;
     int32_t members_first_device;  /* members owned by device_ids[0] (the largest shard)  */
     int32_t lane_pair;             /* 1: the lane-pair small-n kernel (two lanes per time chunk, two waves per SIMD) */
+    int32_t states_stored;         /* 1: grape_get_trajectory can return the forward states (after set_operators);
+                                      0: the flow in use rebuilds them on the fly -- ask for GRAPE_FLAG_KEEP_COSTATES */
 } grape_info;
 
 /* Opaque RCCL bootstrap token (ncclUniqueId), see grape_comm_unique_id / grape_comm_attach. */
@@ -214,9 +216,9 @@ int grape_get_member_results(grape_ctx *ctx, double *foms, double *grads);
 
 /* The stores the reference keeps per member (src/grape_tools.jl:4-16), for parity tests:
  *   props     c128 (n,n,N)     propagators[t],  t = 0..N-1
- *   states    c128 (n,m,N+1)   fwd_state_store[t], t = 0..N   (states[0] = Xi); for n <= 4 they
- *                              are stored only under GRAPE_FLAG_KEEP_COSTATES (the fast flows
- *                              rebuild them on the fly), else GRAPE_ERR_NOT_READY.
+ *   states    c128 (n,m,N+1)   fwd_state_store[t], t = 0..N   (states[0] = Xi); the fast flows rebuild
+ *                              them on the fly (grape_info.states_stored == 0): then only under
+ *                              GRAPE_FLAG_KEEP_COSTATES, else GRAPE_ERR_NOT_READY.
  *   costates  c128 (n,m,N+1)   bwd_costate_store[t], t = 0..N (costates[N] = Xt);
  *                              needs GRAPE_FLAG_KEEP_COSTATES, else GRAPE_ERR_NOT_READY.
  * Any of the three may be NULL. */

@@ -86,6 +86,7 @@ struct grape_ctx {
     hipStream_t stream = nullptr;
     bool ops_set = false, evaluated = false;
     bool unitary = false;         // all generators Hermitian -> unitary data flow
+    bool herm_states = false;     // all Xi, Xt Hermitian (tile family: one-product commutator)
     // GRAPE_FLAG_TIME_KERNELS: a fixed ring of start/stop event pairs around the sweep launches,
     // created at grape_create; when the ring wraps, the oldest pair is folded into ev_total_ms
     std::vector<hipEvent_t> ev;
@@ -684,6 +685,23 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         }
     }
     c->unitary = herm;
+    {                                                        // Hermitian initial / target operators (square states only)
+        bool hs = c->m == c->cfg.n;
+        for (size_t k = 0; k < E && hs; ++k)
+            for (int which = 0; which < 2 && hs; ++which) {
+                const double *M = (which ? Xt : Xi) + 2 * k * nn;
+                double scale = 0.0, dev = 0.0;
+                for (int j = 0; j < n; ++j)
+                    for (int i = 0; i < n; ++i) {
+                        const double re = M[2 * (i + j * n)], im = M[2 * (i + j * n) + 1];
+                        const double tr = M[2 * (j + i * n)], ti = M[2 * (j + i * n) + 1];
+                        scale = std::fmax(scale, std::fmax(std::fabs(re), std::fabs(im)));
+                        dev = std::fmax(dev, std::fmax(std::fabs(re - tr), std::fabs(im + ti)));
+                    }
+                if (!(dev <= 4e-16 * scale)) hs = false;
+            }
+        c->herm_states = hs;
+    }
     if (!herm && !c->d_states) {
         c->bytes += sizeof(double2) * c->ws_elems * c->B;
         HIP_TRY(c, hipMalloc((void **)&c->d_states, sizeof(double2) * c->ws_elems * c->B));
@@ -700,7 +718,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     return GRAPE_OK;
 }
 
-static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream)
+static TileParams tile_params(const grape_ctx *c, const double *d_x)
 {
     TileParams p{};
     p.ops = c->d_ops;
@@ -719,6 +737,21 @@ static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream)
     p.variant = c->cfg.variant;
     p.dt = c->cfg.duration / c->cfg.n_slices;
     p.unitary = c->unitary ? 1 : 0;
+    p.herm_states = c->herm_states ? 1 : 0;
+    return p;
+}
+
+// forward states X_t available to grape_get_trajectory without the debug flow?
+static bool states_stored(const grape_ctx *c)
+{
+    if (c->d_costates) return true;                          // debug flow stores everything
+    if (c->family == 0 || c->unitary) return false;          // fast small-n flows / unitary flows rebuild them
+    return !grape::tile_chain_is_split(tile_params(c, nullptr), false);
+}
+
+static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream)
+{
+    const TileParams p = tile_params(c, d_x);
     HIP_TRY(c, grape::launch_sweep_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE,
                                         c->d_costates != nullptr, p, stream));
     return GRAPE_OK;
@@ -1134,7 +1167,7 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
     if (costates && !c->d_costates)
         return fail(c, GRAPE_ERR_NOT_READY,
                     "grape_get_trajectory: costates need GRAPE_FLAG_KEEP_COSTATES at grape_create");
-    if (states && !c->d_costates && (c->family == 0 || c->unitary))
+    if (states && !states_stored(c))
         return fail(c, GRAPE_ERR_NOT_READY,
                     "grape_get_trajectory: forward states are stored only by the debug flow; create the "
                     "context with GRAPE_FLAG_KEEP_COSTATES");
@@ -1276,5 +1309,6 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
     info->members_first_device = c->is_group ? c->sub[0]->cfg.n_ensemble : c->cfg.n_ensemble;
     if (c->is_group) info->unitary_flow = c->sub[0]->unitary ? 1 : 0;
     info->lane_pair = (c->is_group ? c->sub[0]->pair : c->pair) ? 1 : 0;
+    info->states_stored = states_stored(c->is_group ? c->sub[0] : c) ? 1 : 0;
     return GRAPE_OK;
 }

@@ -78,10 +78,13 @@ struct TileParams {
     int32_t bt_in_lds;    // set by the launcher: the K transposed control operators are cached in LDS
     int32_t stage_ops;    // set by the launcher: prop kernel stages the generators in LDS
     int32_t unitary;      // every generator Hermitian: chain kernel carries M_t = P' M P, no stored states
+    int32_t herm_states;  // every Xi, Xt Hermitian (density operators): [X, L'] = Y - Y' with one product
+    int32_t split_at;     // set by the launcher: first slice of the second wave (chain_tile_split_kernel)
     double dt;
 };
 int tile_count(int n);    // NT for this n (0: not a tile-family size)
 hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
+bool tile_chain_is_split(const TileParams &p, bool keep_costates);   // the two-wave time-split chain: no full X_t store
 
 // G[q] = sum_k w_k member_out[k][q]  for q in [0, Q)  (Q = K*N + 1; the last entry is F).
 // partial: scratch of ksplit*Q doubles.  Deterministic (fixed summation tree).

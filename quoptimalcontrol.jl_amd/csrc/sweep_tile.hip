@@ -19,6 +19,7 @@
 //   gradient:     R = X L' (one A-layout conversion each of X and L), sandwich: minus L' X
 //                 = tmul_tn<conj Z>(L, X);  tr(L' B_c X) = sum R .* (B_c^T in D layout).
 #include <cstdlib>
+#include <cstring>
 
 #include "cmat.hpp"          // Taylor-8 coefficients, squarings_for
 #include "grape_kernels.hpp"
@@ -486,6 +487,221 @@ __global__ __launch_bounds__(128) void chain_tile2w_kernel(const TileParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two wavefronts per member, each owning one PART OF THE TIME AXIS (n <= 16, general flow, ensembles too small
+// to put two members on every SIMD -- C4).  v_mfma_f64_16x16x4 issues every ~150 cycles from one wave per
+// SIMD and every ~105 when two waves share it; chain_tile2w_kernel above buys the second wave by splitting
+// every product's real/imaginary part and pays a barrier + LDS swap per product.  Here the two waves run
+// INDEPENDENT product chains and meet once:
+//   wave 0 (slices [0, Nh)):  pass 1  forward sweep, X_t stored                      (2 products / slice, UG 1)
+//                             pass 2  L_Nh = T1' Xt T1, then the reference's backward sweep + gradient
+//   wave 1 (slices [Nh, N)):  pass 1  prefix products V_j = P_{Nh+j-1} ... P_Nh stored (1 product / slice)
+//                             pass 2  backward sweep from Xt, X_t = V_j X_Nh V_j' rebuilt on the fly
+//   exchange (LDS, one workgroup barrier): wave 0 -> X_Nh, wave 1 -> T1 = P_{N-1} ... P_Nh.
+// Nh balances the two waves' product counts.  When Xi, Xt are Hermitian (checked on the host; density
+// operators), X_t and L_t stay Hermitian under P X P' / P' L P, so [X, L'] = Y - Y' with Y = X L': the
+// second commutator product becomes one layout conversion (to_a_layout of Y IS the D layout of Y^T).
+template <int SAND>
+__global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams p)
+{
+    constexpr int NT = 1, TSZ = 256;
+    extern __shared__ double2 s_dynt[];
+    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double2 *s_img = s_dynt + (size_t)half * (kTileImage + 1);
+    double2 *s_xch = s_dynt + 2 * (kTileImage + 1);                // [0..255] X_Nh (wave 0), [256..511] T1 (wave 1)
+    double2 *s_bt = s_xch + 512;
+    const int k = blockIdx.x;
+    const int K = p.K, N = p.N, Nh = p.split_at;
+    const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
+    const double2 *__restrict__ opBT = ops + (size_t)(1 + K) * TSZ;
+    const bool bt_lds = p.bt_in_lds != 0;
+    const bool herm = SAND && p.herm_states != 0;
+    if (bt_lds) {
+        for (int i = threadIdx.x; i < K * TSZ; i += 128)
+            s_bt[i] = opBT[i];
+    }
+    const double2 *__restrict__ Pk = p.props + (size_t)k * N * TSZ;
+    double2 *__restrict__ Xk = p.states + (size_t)k * N * TSZ;
+    double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * N + 1);
+
+    // ------------------------------------------------------------ pass 1
+    if (half == 0) {
+        TMat<1> X, Pm, Pn, Y;
+        TOp<1> PA;
+        tload(X, ops + (size_t)(1 + 2 * K) * TSZ, lane);           // Xi
+        tload(Pm, Pk, lane);
+        for (int t = 0; t < Nh; ++t) {
+            tstore(Xk + (size_t)t * TSZ, X, lane);
+            if (t + 1 < Nh)
+                tload(Pn, Pk + (size_t)(t + 1) * TSZ, lane);
+            to_a_layout(PA, Pm, s_img, lane);
+            if (SAND) {
+                tmul_tb<NT, false, false>(Y, X, PA);               // (P X)^T
+                tmul_tb<NT, false, true>(X, Y, PA);                // (P X) P'
+            } else {
+                tmul_an<NT, false, false>(Y, PA, X);
+                X = Y;
+            }
+            Pm = Pn;
+        }
+        tstore(s_xch, X, lane);                                    // X_Nh
+    } else {
+        TMat<1> V, Pm, Pn, Y;
+        TOp<1> PA;
+        tzero(V);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * r + (lane >> 4) == (lane & 15))
+                V.re[0][0][r] = 1.0;
+        if (Nh < N)
+            tload(Pm, Pk + (size_t)Nh * TSZ, lane);
+        for (int t = Nh; t < N; ++t) {
+            tstore(Xk + (size_t)t * TSZ, V, lane);                 // V_{t-Nh}: X_t = V X_Nh V'
+            if (t + 1 < N)
+                tload(Pn, Pk + (size_t)(t + 1) * TSZ, lane);
+            to_a_layout(PA, Pm, s_img, lane);
+            tmul_an<NT, false, false>(Y, PA, V);                   // P V
+            V = Y;
+            Pm = Pn;
+        }
+        tstore(s_xch + 256, V, lane);                              // T1
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------ pass 2: backward sweep + gradient
+    const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
+    TMat<1> L, Pm, Pn, X, Xn, Y, R;
+    TOp<1> XA, LA;
+    // gradient entries + figure of merit of one slice from X_t, L_t (costate after pulling back through slice t)
+    auto emit = [&](int t) {
+        to_a_layout(XA, X, s_img, lane);
+        to_a_layout(LA, L, s_img, lane);
+        tprod<NT, false, true>(
+            R, [&](int I, int Kt, int kb, double &r, double &i) { r = XA.re[I][Kt][kb]; i = XA.im[I][Kt][kb]; },
+            [&](int Kt, int J, int kb, double &r, double &i) { r = LA.re[J][Kt][kb]; i = LA.im[J][Kt][kb]; });   // X L'
+        if (SAND) {
+            if (herm) {                                            // [X, L'] = Y - Y',  Y' = conj(Y^T)
+                TOp<1> RT;
+                to_a_layout(RT, R, s_img, lane);                   // D layout of Y^T
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    R.re[0][0][r] -= RT.re[0][0][r];
+                    R.im[0][0][r] += RT.im[0][0][r];
+                }
+            } else {
+                tmul_tn<NT, true, false>(Y, L, X);                 // L' X
+                R.re[0][0] -= Y.re[0][0];
+                R.im[0][0] -= Y.im[0][0];
+            }
+        }
+        double zr = 0.0, zi = 0.0;
+        for (int c0 = 0; c0 < K || c0 == 0; c0 += 4) {
+            double v[2 + 8];
+            v[0] = 0.0;
+            v[1] = 0.0;
+            if (!SAND || t == N - 1)
+                tdot_partial<NT, true>(v[0], v[1], X, L);          // tr(X' L)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int c = c0 + cc;
+                v[2 + 2 * cc] = 0.0;
+                v[3 + 2 * cc] = 0.0;
+                if (c < K) {
+                    TMat<NT> BT;
+                    if (bt_lds)
+                        tload(BT, s_bt + (size_t)c * TSZ, lane);
+                    else
+                        tload(BT, opBT + (size_t)c * TSZ, lane);
+                    tdot_partial<NT, false>(v[2 + 2 * cc], v[3 + 2 * cc], BT, R);
+                }
+            }
+            wave_sum_n(v);
+            zr = v[0];
+            zi = v[1];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int c = c0 + cc;
+                const double wr = v[2 + 2 * cc], wi = v[3 + 2 * cc];
+                const double im = SAND ? wi : fma(wr, zi, wi * zr);
+                if (c < K && lane == 0)
+                    out[c + (size_t)t * K] = gs * im;
+            }
+        }
+        if (t == N - 1 && lane == 0) {
+            if (SAND) {
+                const double inv = 1.0 / (double)p.n;
+                const double ar = zr * inv, ai = zi * inv;
+                out[(size_t)K * N] = 1.0 - (ar * ar + ai * ai);
+            } else {
+                out[(size_t)K * N] = zr * zr - zi * zi;
+            }
+        }
+    };
+    auto pull_back = [&]() {                                       // L <- P' L [P]
+        if (SAND) {
+            tmul_tn<NT, false, true>(Y, L, Pm);                    // (P' L)^T
+            tmul_tn<NT, false, false>(L, Y, Pm);                   // P' L P
+        } else {
+            tmul_tn<NT, true, false>(Y, Pm, L);                    // P' L
+            L = Y;
+        }
+    };
+    if (half == 1) {
+        if (Nh < N) {
+            TMat<1> Xh, V, Vn;
+            TOp<1> VA;
+            tload(Xh, s_xch, lane);                                // X_Nh
+            tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);       // Xt
+            tload(Pm, Pk + (size_t)(N - 1) * TSZ, lane);
+            tload(V, Xk + (size_t)(N - 1) * TSZ, lane);
+            for (int t = N - 1; t >= Nh; --t) {
+                if (t > Nh) {                                      // next slice's P, V in flight
+                    tload(Pn, Pk + (size_t)(t - 1) * TSZ, lane);
+                    tload(Vn, Xk + (size_t)(t - 1) * TSZ, lane);
+                }
+                pull_back();
+                if (t > Nh) {                                      // X_t = V X_Nh [V']
+                    to_a_layout(VA, V, s_img, lane);
+                    if (SAND) {
+                        tmul_tb<NT, false, false>(Y, Xh, VA);      // (V X_Nh)^T
+                        tmul_tb<NT, false, true>(X, Y, VA);        // (V X_Nh) V'
+                    } else {
+                        tmul_an<NT, false, false>(X, VA, Xh);
+                    }
+                } else {
+                    X = Xh;
+                }
+                emit(t);
+                Pm = Pn;
+                V = Vn;
+            }
+        }
+    } else {
+        {                                                          // L_Nh = T1' Xt [T1]
+            TMat<1> T1;
+            tload(T1, s_xch + 256, lane);
+            tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);       // Xt
+            Pm = T1;
+            if (Nh < N)
+                pull_back();
+        }
+        if (Nh > 0) {
+            tload(Pm, Pk + (size_t)(Nh - 1) * TSZ, lane);
+            tload(X, Xk + (size_t)(Nh - 1) * TSZ, lane);
+        }
+        for (int t = Nh - 1; t >= 0; --t) {
+            if (t > 0) {
+                tload(Pn, Pk + (size_t)(t - 1) * TSZ, lane);
+                tload(Xn, Xk + (size_t)(t - 1) * TSZ, lane);
+            }
+            pull_back();
+            emit(t);
+            Pm = Pn;
+            X = Xn;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Unitary flow (every generator Hermitian, so every P_t is unitary; same idea as sweep_small.hip):
 // the gradient matrix M_t = X_t L_t' (UnitaryGate) or [X_t, L_t'] (sandwich) obeys
 // M_t = P_t' M_{t+1} P_t, so no forward state is stored or re-read.  The forward pass only
@@ -641,6 +857,22 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
 // ---------------------------------------------------------------------------------------------
 int tile_count(int n) { return n <= 4 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : 0)); }
 
+static bool tile_chain_env(const char *what)                       // GRAPE_TILE_CHAIN=split|2w|1w: tuning / ablation
+{
+    static const char *chain_env = std::getenv("GRAPE_TILE_CHAIN");
+    if (!std::strcmp(what, "1w") && std::getenv("GRAPE_TILE_1WAVE"))
+        return true;
+    return chain_env && !std::strcmp(chain_env, what);
+}
+
+// does launch_sweep_tile run the time-split two-wave chain for this problem?  (then the `states` workspace
+// holds X_t only for the first part of the time axis and prefix products for the rest)
+bool tile_chain_is_split(const TileParams &p, bool keepl)
+{
+    return tile_count(p.n) == 1 && !p.pack2 && !keepl && !p.unitary && p.E < 2048 && p.N >= 4 &&
+           !tile_chain_env("1w") && !tile_chain_env("2w");
+}
+
 template <int NT>
 static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipStream_t stream)
 {
@@ -663,8 +895,24 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     const size_t lds = sizeof(double2) * (kTileImage + 1) + (q.bt_in_lds ? bt_bytes : 0);
     const dim3 grid(p.E), block(64);
     const bool pk = (NT == 1) && p.pack2;
-    if (NT == 1 && !pk && !keepl && !p.unitary && p.E < 2048 && !std::getenv("GRAPE_TILE_1WAVE")) {
-        // one member per wave would leave every SIMD with a single wave: split re/im over two waves
+    if (tile_chain_is_split(p, keepl)) {
+        // one member per wave would leave every SIMD with a single wave: two waves per member, each owning a
+        // part of the time axis, split so that their product counts balance (see chain_tile_split_kernel)
+        const int c0 = sandwich ? (p.herm_states ? 5 : 6) : 3, c1 = c0 + 1;
+        q.split_at = (int)(((long long)p.N * c1 + (c0 + c1) / 2) / (c0 + c1));
+        if (const char *sp = std::getenv("GRAPE_TILE_SPLIT_PERMILLE"))
+            q.split_at = (int)((long long)p.N * std::atoi(sp) / 1000);
+        if (q.split_at < 1) q.split_at = 1;
+        if (q.split_at > p.N - 1) q.split_at = p.N - 1;
+        const size_t bt_b = sizeof(double2) * (size_t)p.K * 256;
+        q.bt_in_lds = bt_b <= 24 * 1024 ? 1 : 0;                    // 4 workgroups per CU must still fit
+        const size_t lds2 = sizeof(double2) * (2 * (kTileImage + 1) + 512) + (q.bt_in_lds ? bt_b : 0);
+        if (sandwich) hipLaunchKernelGGL((chain_tile_split_kernel<1>), grid, dim3(128), lds2, stream, q);
+        else          hipLaunchKernelGGL((chain_tile_split_kernel<0>), grid, dim3(128), lds2, stream, q);
+        return hipGetLastError();
+    }
+    if (NT == 1 && !pk && !keepl && !p.unitary && p.E < 2048 && !tile_chain_env("1w")) {
+        // re/im split over two waves (kept for comparison: GRAPE_TILE_CHAIN=2w)
         const size_t bt_b = sizeof(double2) * (size_t)p.K * 256;
         q.bt_in_lds = bt_b <= 48 * 1024 ? 1 : 0;
         const size_t lds2 = sizeof(double2) * (2 * (kTileImage + 1) + 512) + (q.bt_in_lds ? bt_b : 0);

@@ -62,7 +62,8 @@ class GrapeInfo(C.Structure):
                 ("expm_squarings", C.c_int32), ("kernel_family", C.c_int32), ("unitary_flow", C.c_int32),
                 ("expm_theta", C.c_double), ("workspace_bytes", C.c_uint64), ("arch", C.c_char * 32),
                 ("n_devices", C.c_int32), ("comm_size", C.c_int32), ("comm_rank", C.c_int32),
-                ("members_first_device", C.c_int32), ("lane_pair", C.c_int32)]
+                ("members_first_device", C.c_int32), ("lane_pair", C.c_int32),
+                ("states_stored", C.c_int32)]
 
 
 class GrapeCommId(C.Structure):

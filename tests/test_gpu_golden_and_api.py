@@ -27,8 +27,8 @@ def test_hip_matches_golden(qoc, path, flow):
             got_traj = eng.trajectory(0, costates=True)
         else:
             inf = eng.info
-            if inf["kernel_family"] == 1 and not inf["unitary_flow"]:
-                got_traj = eng.trajectory(0)                     # tile kernels, non-Hermitian: states are stored
+            if inf["states_stored"]:
+                got_traj = eng.trajectory(0)                     # single-wave tile chain, non-Hermitian: states are stored
             else:
                 got_traj = (eng.trajectory(0, states=False)[0],)
                 with pytest.raises(qoc.GrapeError):
