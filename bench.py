@@ -171,7 +171,7 @@ def spawn_ranks(args):
     import torch                                   # device_count() does not initialise the GPU on this image
 
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not os.environ.get("GRAPE_BENCH_SHARE_GPU"):      # (sharing: plumbing tests only)
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) are visible; refusing to "
                          f"report a {args.gpus}-GPU number from fewer GPUs")
     port = 29500 + os.getpid() % 400
@@ -197,8 +197,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the device-resident loop and the extra configs")
     ap.add_argument("--extra-configs", default="C2,C4,C5")
-    ap.add_argument("--backend", default="cpu:gloo,cuda:nccl",
-                    help="torch.distributed control plane (the data-path collective is RCCL inside the library)")
+    ap.add_argument("--backend", default="",
+                    help="torch.distributed backend; default: gloo as the control plane when the data-path collective "
+                         "is RCCL inside the library (--collective lib), cpu:gloo,cuda:nccl for --collective torch")
     ap.add_argument("--collective", choices=["lib", "torch"], default="lib",
                     help="lib: ncclAllReduce inside libgrape_hip.so (grape_comm_attach); torch: torch.distributed.all_reduce")
     ap.add_argument("--force-dist", action="store_true",
@@ -236,7 +237,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(args.backend)
+        dist.init_process_group(args.backend or ("gloo" if args.collective == "lib" else "cpu:gloo,cuda:nccl"))
 
     base = qoc.workloads.config(args.config)
     E_cfg = args.ensemble or base.E

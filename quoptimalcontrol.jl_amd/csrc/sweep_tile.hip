@@ -318,180 +318,11 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Two wavefronts per member (n <= 16, ensembles too small to put two members on every SIMD):
-// v_mfma_f64_16x16x4 issues every ~150 cycles from one wave per SIMD but every ~105 when two waves
-// share the SIMD, so each member's products are split: wave 0 accumulates the REAL part
-// (Ar Br - Ai Bi), wave 1 the IMAGINARY part (Ar Bi + Ai Br), and the halves are swapped through
-// LDS after every product.  Both waves keep the full matrices; the K gradient traces are shared
-// out by control parity.  Same data flow and results as chain_tile_kernel.
-// `flip` alternates between two swap buffers, so ONE workgroup barrier per product suffices: a
-// buffer is rewritten two products later, after the barrier of the product in between.
-template <bool CONJ_A, bool CONJ_B, typename FA, typename FB>
-GRAPE_DEV void tprod_half(TMat<1> &out, int half, double2 *__restrict__ xch, int &flip, int lane, FA a, FB b)
-{
-    d4 c1 = (d4){0, 0, 0, 0}, c2 = (d4){0, 0, 0, 0};
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        double ar, ai, br, bi;
-        a(kb, ar, ai);
-        b(kb, br, bi);
-        if (CONJ_A) ai = -ai;
-        if (CONJ_B) bi = -bi;
-        if (half == 0) {                           // real part: ar*br - ai*bi
-            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, c2, 0, 0, 0);
-        } else {                                   // imaginary part: ar*bi + ai*br
-            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, c2, 0, 0, 0);
-        }
-    }
-    const d4 mine = c1 + c2;
-    // swap halves: slot [half][r][lane] as double (xch viewed as double array)
-    double *xd = reinterpret_cast<double *>(xch) + flip * 512;
-    flip ^= 1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        xd[(half * 4 + r) * 64 + lane] = mine[r];
-    __syncthreads();
-    d4 other;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        other[r] = xd[((1 - half) * 4 + r) * 64 + lane];
-    out.re[0][0] = half == 0 ? mine : other;
-    out.im[0][0] = half == 0 ? other : mine;
-}
-
-template <int SAND>
-__global__ __launch_bounds__(128) void chain_tile2w_kernel(const TileParams p)
-{
-    constexpr int NT = 1, TSZ = 256;
-    extern __shared__ double2 s_dynt[];
-    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double2 *s_img = s_dynt + (size_t)half * (kTileImage + 1);     // one layout-conversion image per wave
-    double2 *s_xch = s_dynt + 2 * (kTileImage + 1);                // 2 x (8 x 64) doubles: the half swap, two buffers
-    double2 *s_bt = s_xch + 512;
-    int flip = 0;
-    const int k = blockIdx.x;
-    const int K = p.K, N = p.N;
-    const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
-    const double2 *__restrict__ opBT = ops + (size_t)(1 + K) * TSZ;
-    const bool bt_lds = p.bt_in_lds != 0;
-    if (bt_lds) {
-        for (int i = threadIdx.x; i < K * TSZ; i += 128)
-            s_bt[i] = opBT[i];
-    }
-    __syncthreads();
-    const double2 *__restrict__ Pk = p.props + (size_t)k * N * TSZ;
-    double2 *__restrict__ Xk = p.states + (size_t)k * N * TSZ;
-    double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * N + 1);
-
-    auto dreg = [](const TMat<1> &z) { return [&z](int kb, double &r, double &i) { r = z.re[0][0][kb]; i = z.im[0][0][kb]; }; };
-    auto areg = [](const TOp<1> &z) { return [&z](int kb, double &r, double &i) { r = z.re[0][0][kb]; i = z.im[0][0][kb]; }; };
-
-    // ------------------------------------------------------------ forward sweep
-    {
-        TMat<1> X, Pm, Pn, Y;
-        TOp<1> PA;
-        tload(X, ops + (size_t)(1 + 2 * K) * TSZ, lane);           // Xi
-        tload(Pm, Pk, lane);
-        for (int t = 0; t < N; ++t) {
-            if (half == 0)
-                tstore(Xk + (size_t)t * TSZ, X, lane);
-            if (t + 2 < N)
-                tload(Pn, Pk + (size_t)(t + 1) * TSZ, lane);
-            if (t + 1 < N) {
-                to_a_layout(PA, Pm, s_img, lane);
-                if (SAND) {
-                    tprod_half<false, false>(Y, half, s_xch, flip, lane, dreg(X), areg(PA));      // X^T P^T = (P X)^T
-                    tprod_half<false, true>(X, half, s_xch, flip, lane, dreg(Y), areg(PA));       // (P X) P'
-                } else {
-                    tprod_half<false, false>(Y, half, s_xch, flip, lane, areg(PA), dreg(X));      // P X
-                    X = Y;
-                }
-            }
-            Pm = Pn;
-        }
-    }
-    __syncthreads();                                               // wave 0's X_t stores -> visible to wave 1 (same CU)
-
-    // ------------------------------------------------------------ backward sweep + gradient
-    TMat<1> L, Pm, X, Y, R, Pn, Xn;
-    TOp<1> XA, LA;
-    tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);               // Xt
-    const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
-    tload(Pm, Pk + (size_t)(N - 1) * TSZ, lane);
-    tload(X, Xk + (size_t)(N - 1) * TSZ, lane);
-    for (int t = N - 1; t >= 0; --t) {
-        if (t > 0) {
-            tload(Pn, Pk + (size_t)(t - 1) * TSZ, lane);
-            tload(Xn, Xk + (size_t)(t - 1) * TSZ, lane);
-        }
-        if (SAND) {
-            tprod_half<false, true>(Y, half, s_xch, flip, lane, dreg(L), dreg(Pm));               // L^T conj(P) = (P' L)^T
-            tprod_half<false, false>(L, half, s_xch, flip, lane, dreg(Y), dreg(Pm));              // P' L P
-        } else {
-            tprod_half<true, false>(Y, half, s_xch, flip, lane, dreg(Pm), dreg(L));               // P' L
-            L = Y;
-        }
-        to_a_layout(XA, X, s_img, lane);
-        to_a_layout(LA, L, s_img, lane);
-        tprod_half<false, true>(R, half, s_xch, flip, lane, areg(XA), areg(LA));                  // X L'
-        if (SAND) {
-            tprod_half<true, false>(Y, half, s_xch, flip, lane, dreg(L), dreg(X));                // L' X
-            R.re[0][0] -= Y.re[0][0];
-            R.im[0][0] -= Y.im[0][0];
-        }
-        // traces: this wave takes the controls c with c % 2 == half; both take tr(X' L)
-        double zr = 0.0, zi = 0.0;
-        for (int c0 = half; c0 < K || c0 == half; c0 += 8) {
-            double v[2 + 8];
-            tdot_partial<NT, true>(v[0], v[1], X, L);
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int c = c0 + 2 * cc;
-                v[2 + 2 * cc] = 0.0;
-                v[3 + 2 * cc] = 0.0;
-                if (c < K) {
-                    TMat<NT> BT;
-                    if (bt_lds)
-                        tload(BT, s_bt + (size_t)c * TSZ, lane);
-                    else
-                        tload(BT, opBT + (size_t)c * TSZ, lane);
-                    tdot_partial<NT, false>(v[2 + 2 * cc], v[3 + 2 * cc], BT, R);
-                }
-            }
-            wave_sum_n(v);
-            zr = v[0];
-            zi = v[1];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int c = c0 + 2 * cc;
-                const double wr = v[2 + 2 * cc], wi = v[3 + 2 * cc];
-                const double im = SAND ? wi : fma(wr, zi, wi * zr);
-                if (c < K && lane == 0)
-                    out[c + (size_t)t * K] = gs * im;
-            }
-        }
-        if (t == N - 1 && lane == 0 && half == 0) {
-            if (SAND) {
-                const double inv = 1.0 / (double)p.n;
-                const double ar = zr * inv, ai = zi * inv;
-                out[(size_t)K * N] = 1.0 - (ar * ar + ai * ai);
-            } else {
-                out[(size_t)K * N] = zr * zr - zi * zi;
-            }
-        }
-        Pm = Pn;
-        X = Xn;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Two wavefronts per member, each owning one PART OF THE TIME AXIS (n <= 16, general flow, ensembles too small
 // to put two members on every SIMD -- C4).  v_mfma_f64_16x16x4 issues every ~150 cycles from one wave per
-// SIMD and every ~105 when two waves share it; chain_tile2w_kernel above buys the second wave by splitting
-// every product's real/imaginary part and pays a barrier + LDS swap per product.  Here the two waves run
-// INDEPENDENT product chains and meet once:
+// SIMD and every ~105 when two waves share it.  (Round 1 bought the second wave by splitting every product's
+// real / imaginary part over two waves, at a barrier + LDS swap per product: 10.1 ms per C4 evaluation against
+// 6.9 ms for this kernel; removed.)  Here the two waves run INDEPENDENT product chains and meet once:
 //   wave 0 (slices [0, Nh)):  pass 1  forward sweep, X_t stored                      (2 products / slice, UG 1)
 //                             pass 2  L_Nh = T1' Xt T1, then the reference's backward sweep + gradient
 //   wave 1 (slices [Nh, N)):  pass 1  prefix products V_j = P_{Nh+j-1} ... P_Nh stored (1 product / slice)
@@ -857,7 +688,7 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
 // ---------------------------------------------------------------------------------------------
 int tile_count(int n) { return n <= 4 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : 0)); }
 
-static bool tile_chain_env(const char *what)                       // GRAPE_TILE_CHAIN=split|2w|1w: tuning / ablation
+static bool tile_chain_env(const char *what)                       // GRAPE_TILE_CHAIN=split|1w: tuning / ablation
 {
     static const char *chain_env = std::getenv("GRAPE_TILE_CHAIN");
     if (!std::strcmp(what, "1w") && std::getenv("GRAPE_TILE_1WAVE"))
@@ -870,7 +701,7 @@ static bool tile_chain_env(const char *what)                       // GRAPE_TILE
 bool tile_chain_is_split(const TileParams &p, bool keepl)
 {
     return tile_count(p.n) == 1 && !p.pack2 && !keepl && !p.unitary && p.E < 2048 && p.N >= 4 &&
-           !tile_chain_env("1w") && !tile_chain_env("2w");
+           !tile_chain_env("1w");
 }
 
 template <int NT>
@@ -909,15 +740,6 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         const size_t lds2 = sizeof(double2) * (2 * (kTileImage + 1) + 512) + (q.bt_in_lds ? bt_b : 0);
         if (sandwich) hipLaunchKernelGGL((chain_tile_split_kernel<1>), grid, dim3(128), lds2, stream, q);
         else          hipLaunchKernelGGL((chain_tile_split_kernel<0>), grid, dim3(128), lds2, stream, q);
-        return hipGetLastError();
-    }
-    if (NT == 1 && !pk && !keepl && !p.unitary && p.E < 2048 && !tile_chain_env("1w")) {
-        // re/im split over two waves (kept for comparison: GRAPE_TILE_CHAIN=2w)
-        const size_t bt_b = sizeof(double2) * (size_t)p.K * 256;
-        q.bt_in_lds = bt_b <= 48 * 1024 ? 1 : 0;
-        const size_t lds2 = sizeof(double2) * (2 * (kTileImage + 1) + 512) + (q.bt_in_lds ? bt_b : 0);
-        if (sandwich) hipLaunchKernelGGL((chain_tile2w_kernel<1>), grid, dim3(128), lds2, stream, q);
-        else          hipLaunchKernelGGL((chain_tile2w_kernel<0>), grid, dim3(128), lds2, stream, q);
         return hipGetLastError();
     }
 #define GRAPE_LAUNCH_CHAIN(KERNEL) hipLaunchKernelGGL(KERNEL, grid, block, lds, stream, q)

@@ -97,6 +97,12 @@ class ShardedGrape:
         if ok:
             self.collective = "lib"
             self.comm_size = self.local.info["comm_size"]
+        elif self.distributed and self.world > 1 and self.device.type == "cuda" and "nccl" not in dist.get_backend(self.group):
+            # fallback on a gloo control plane: give the data path its own RCCL group (torch's), not gloo
+            try:
+                self.group = dist.new_group(backend="nccl")
+            except Exception as exc:                  # noqa: BLE001 -- keep the (slow but correct) gloo path
+                self.attach_error = getattr(self, "attach_error", "") + f"; nccl group: {exc!r}"
 
     def eval_device(self, x_dev):
         """x_dev: float64 tensor holding x as (K,N) column-major, i.e. shape (N, K) contiguous.

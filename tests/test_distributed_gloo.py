@@ -31,14 +31,17 @@ class OracleLocal:
         fg[-1] = F
 
 
-def _worker(rank, world, port, E, out):
+def _worker(rank, world, port, E, out, backend="gloo", collective="torch"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     import quoptimalcontrol_jl_amd as qoc
     from quoptimalcontrol_jl_amd.distributed import ShardedGrape
     w = qoc.workloads.config("C3", E=E, N=30)
-    sg = ShardedGrape(w.E, w.K, w.N, lambda lo, hi: OracleLocal(w, lo, hi, w.K, w.N), torch.device("cpu"))
+    sg = ShardedGrape(w.E, w.K, w.N, lambda lo, hi: OracleLocal(w, lo, hi, w.K, w.N), torch.device("cpu"),
+                      collective=collective)
+    if collective == "lib":          # the stand-in evaluator cannot join a library communicator: every rank must
+        assert sg.collective == "torch" and "comm_attach" in sg.attach_error or "no members" in sg.attach_error
     F, G = sg.eval(w.x)
     if rank == 0:
         np.save(out, np.concatenate([G.reshape(-1), [F], [sg.lo, sg.hi]]))
@@ -55,3 +58,34 @@ def test_sharded_allreduce_matches_unsharded(tmp_path, oracle, qoc, E, world):
     F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
     assert_parity(got[-3], got[:-3].reshape(w.K, w.N), F_ref, G_ref, w.n, what=f"E={E} world={world}")
     assert (got[-2], got[-1]) == (0, -(-E // world))
+
+
+def test_library_collective_falls_back_consistently(tmp_path, oracle, qoc):
+    """collective='lib' on ranks that cannot attach (here: a CPU stand-in evaluator; on a GPU node: fewer members
+    than ranks, RCCL missing): all ranks agree on the torch.distributed fallback and the result is unchanged.
+    gloo is also bench.py's control plane (unique-id broadcast, barrier, max-time reduction)."""
+    out = str(tmp_path / "r0.npy")
+    port = 29600 + (os.getpid() + 91) % 300
+    mp.spawn(_worker, args=(2, port, 6, out, "gloo", "lib"), nprocs=2, join=True)
+    got = np.load(out)
+    w = qoc.workloads.config("C3", E=6, N=30)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    assert_parity(got[-3], got[:-3].reshape(w.K, w.N), F_ref, G_ref, w.n, what="lib->torch fallback")
+
+
+def _bcast_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from quoptimalcontrol_jl_amd.distributed import _bcast_bytes
+    token = bytes(range(128)) if rank == 0 else None
+    got = _bcast_bytes(dist, token, 128, None)
+    if rank == 1:
+        open(out, "wb").write(got)
+    dist.destroy_process_group()
+
+
+def test_unique_id_broadcast_reaches_the_other_rank(tmp_path):
+    out = str(tmp_path / "tok.bin")
+    mp.spawn(_bcast_worker, args=(2, 29600 + (os.getpid() + 173) % 300, out), nprocs=2, join=True)
+    assert open(out, "rb").read() == bytes(range(128))
