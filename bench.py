@@ -164,6 +164,34 @@ def run_extra_config(qoc, name, dev_index, steps, warmup):
             "roofline": roofline(w, info, kern_ms, kern_n, evals, 1, None)}
 
 
+def lbfgs_rates(qoc, dev_index):
+    """Optimiser iterations per second: the library's device-resident L-BFGS (grape_lbfgs) next to the host-driven
+    loop (SciPy L-BFGS-B calling grape_eval, the stand-in for Optim.jl) on two shapes: the reference's own
+    n_ens = 5 StateTransfer testset, and 30 iterations on the headline ensemble."""
+    import numpy as np
+    from quoptimalcontrol_jl_amd.api import _lbfgs
+    out = []
+    for label, w, iters in (("reference testset: StateTransfer 2x2, n_ens=5, N=25 (state_transfer_tests.jl:42)",
+                             qoc.workloads.reference_ensemble("StateTransfer", 5, 25, 5.0), 0),
+                            ("C3 headline ensemble, 30 iterations", qoc.workloads.config("C3"), 30)):
+        ug = w.sys_type == "UnitaryGate"
+        with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, device=dev_index,
+                             variant=1 if ug else 0, max_batch=4 if w.E <= 64 else 1) as eng:
+            eng.lbfgs(w.x, iterations=3)                                   # warm
+            _, info = eng.lbfgs(w.x, iterations=iters)
+            t0 = time.perf_counter()
+            res = _lbfgs(lambda x: eng.eval(x), w.x, {"iterations": iters} if iters else {})
+            host_s = time.perf_counter() - t0
+        out.append({"problem": label,
+                    "device_lbfgs": {"iterations": info["iterations"], "evaluations": info["evaluations"],
+                                     "probes_per_launch": info["probes"], "seconds": info["seconds"],
+                                     "iterations_per_s": info["iterations"] / info["seconds"], "minimum": info["minimum"],
+                                     "status": info["message"]},
+                    "host_driven_scipy": {"iterations": int(res.nit), "evaluations": int(res.nfev), "seconds": host_s,
+                                          "iterations_per_s": res.nit / host_s, "minimum": float(res.minimum)}})
+    return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks as fresh child
     processes (nothing in THIS process has touched the GPU yet), relay their output, exit with
@@ -350,6 +378,11 @@ def main():
         out = None
 
     sg.close()
+    if rank == 0 and world == 1 and not args.no_extra:
+        try:
+            out["extra"]["lbfgs"] = lbfgs_rates(qoc, dev_index)
+        except Exception as exc:                   # noqa: BLE001 -- an extra must not kill the headline
+            out["extra"]["lbfgs"] = {"error": repr(exc)}
     if rank == 0 and world == 1 and not args.no_extra and args.extra_configs:
         out["extra_configs"] = []
         for name in [s for s in args.extra_configs.split(",") if s and s != args.config]:

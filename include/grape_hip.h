@@ -208,6 +208,40 @@ int grape_eval_batch(grape_ctx *ctx, int32_t n_x, const double *x, double *F, do
 /* Device-pointer form: d_x (K,N,n_x), d_fg f64[(K*N + 1) * n_x] = n_x blocks of { G, F }. */
 int grape_eval_batch_device(grape_ctx *ctx, int32_t n_x, const double *d_x, double *d_fg, void *stream);
 
+/* Device-resident L-BFGS: stands in for
+ *     Optim.optimize(Optim.only_fg!(topt), x0, Optim.LBFGS(), optim_options)       src/solve.jl:138, :244
+ * with x, g, the (s, y) history and the line-search trial points kept on the GPU; per iteration the host
+ * reads eight scalars.  Optim's LBFGS() defaults are mirrored where they are plain numbers: memory m = 10,
+ * initial inverse-Hessian scaling s'y / y'y, initial step 1 (InitialStatic), g_tol = 1e-8 on |g|_inf,
+ * f_tol = x_tol = 0, 1000 iterations.  The line search is NOT HagerZhang: `probes` step lengths
+ * alpha, alpha/2, alpha/4, ... are evaluated by ONE batched launch (grape_config.max_batch >= probes; n <= 4)
+ * and the largest one with sufficient decrease (c1 = 1e-4) -- preferring one that also satisfies the strong
+ * Wolfe curvature condition (c2 = 0.9) -- is taken; contexts without batching probe one step per launch.
+ * The gradient is whatever the GRAPE evaluation returns, with the reference's conventions. */
+typedef struct grape_lbfgs_options {
+    int32_t memory;            /* m; 0 = 10                                              */
+    int32_t max_iterations;    /* 0 = 1000                                               */
+    double  g_tol;             /* < 0 = 1e-8; stop when |g|_inf <= g_tol                 */
+    double  f_tol;             /* stop when |f - f_prev| <= f_tol |f|  (Optim f_tol; 0 = off) */
+    int32_t max_linesearch;    /* trial steps per iteration before giving up; 0 = 40     */
+    int32_t probes;            /* step lengths per launch, 1..8; 0 = automatic           */
+} grape_lbfgs_options;
+
+typedef struct grape_lbfgs_result {
+    double  minimum;           /* Optim's res.minimum                                    */
+    double  g_norm;            /* |g|_inf at the minimiser                               */
+    double  seconds;           /* wall time of the whole optimisation                    */
+    int32_t iterations;
+    int32_t evaluations;       /* control arrays evaluated (probes count individually)   */
+    int32_t status;            /* 0 g_tol reached, 1 f_tol reached, 2 max_iterations, 3 line search failed */
+    int32_t probes;            /* step lengths per launch actually used                  */
+} grape_lbfgs_result;
+
+/* x0: host (K,N) f64 initial controls (Problem.guess); x_min: host (K,N) f64, receives res.minimizer.
+ * opts may be NULL (all defaults).  Single-device contexts only. */
+int grape_lbfgs(grape_ctx *ctx, const double *x0, const grape_lbfgs_options *opts, double *x_min,
+                grape_lbfgs_result *result);
+
 /* Debug/parity accessors (valid after an evaluation; needs GRAPE_FLAG_MEMBER_RESULTS; after a batched
  * evaluation they refer to control array 0):
  * per-member unweighted results, as the reference's `gradient[k,:,:]` and the F_k summands:

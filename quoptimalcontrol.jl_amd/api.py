@@ -80,6 +80,8 @@ class GRAPE:
     isinplace: bool = True
     optim_options: dict = field(default_factory=dict)
     device: int = -1               # HIP device ordinal (new: the reference has no devices)
+    optimizer: str = "host"        # "host": SciPy L-BFGS-B drives grape_eval (stand-in for Optim.jl on the host);
+                                   # "device": grape_lbfgs, the library's device-resident L-BFGS
 
 
 @dataclass
@@ -194,16 +196,31 @@ def _lbfgs(topt, x0, options):
     return res
 
 
+def _device_lbfgs(eng, x0, options):
+    """grape_lbfgs with Optim-style options (iterations, g_tol, f_tol); result mimics the fields solve() reads."""
+    from types import SimpleNamespace
+
+    x_min, info = eng.lbfgs(x0, iterations=int(options.get("iterations", 0)), g_tol=float(options.get("g_tol", -1.0)),
+                            f_tol=float(options.get("f_tol", 0.0)))
+    return SimpleNamespace(minimum=info["minimum"], minimizer=x_min, x=x_min.reshape(-1), fun=info["minimum"],
+                           nit=info["iterations"], nfev=info["evaluations"], message=info["message"],
+                           success=info["status"] in (0, 1), device_lbfgs=info)
+
+
 def solve(prob, alg: Optional[GRAPE] = None, engine=None):
     """solve(::Problem, ::GRAPE) / solve(::EnsembleProblem, ::GRAPE)."""
     if alg is None:
         raise TypeError("solve(prob) without an algorithm has no integrator in the reference either "
                         "(src/solve.jl:57,66); pass GRAPE(n_slices=...)")
     own = engine is None
-    eng = engine or make_engine(prob, alg)
+    device_opt = getattr(alg, "optimizer", "host") == "device"
+    eng = engine or make_engine(prob, alg, **({"max_batch": 4} if device_opt else {}))
     try:
         guess = np.asarray((prob.prob if isinstance(prob, EnsembleProblem) else prob).guess, float)
-        res = _lbfgs(lambda x: eng.eval(x), guess, alg.optim_options)
+        if device_opt:
+            res = _device_lbfgs(eng, guess, alg.optim_options)
+        else:
+            res = _lbfgs(lambda x: eng.eval(x), guess, alg.optim_options)
     finally:
         if own:
             eng.close()

@@ -1090,6 +1090,148 @@ static grape_ctx *owner_of(grape_ctx *c, int member, int *local)
     return nullptr;
 }
 
+// ------------------------------------------------------------------------------------------
+// Device-resident L-BFGS (lbfgs.hip): the optimiser loop of src/solve.jl:138 / :244
+extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_options *opts, double *x_min,
+                           grape_lbfgs_result *result)
+{
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (!x0 || !x_min || !result) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_lbfgs: null argument");
+    if (c->is_group || c->comm)
+        return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_lbfgs: single-device contexts only in this build");
+    if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, "grape_lbfgs: operators not set");
+    const size_t kn = KN(c), Q = kn + 1;
+    if (kn > (size_t)grape::kLbfgsMaxPer * 1024)
+        return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_lbfgs: n_controls * n_slices > 16384");
+    grape_lbfgs_options o{};
+    if (opts) o = *opts;
+    const int m = o.memory > 0 ? o.memory : 10;
+    const int max_it = o.max_iterations > 0 ? o.max_iterations : 1000;
+    const double g_tol = o.g_tol >= 0.0 ? o.g_tol : 1e-8;
+    const double f_tol = o.f_tol > 0.0 ? o.f_tol : 0.0;
+    const int max_ls = o.max_linesearch > 0 ? o.max_linesearch : 40;
+    if (m > 64) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_lbfgs: memory must be <= 64");
+    int B = o.probes;
+    if (B <= 0) {
+        // probing several step lengths multiplies the sweep's work: free while the ensemble leaves the chip
+        // mostly empty, not when it already fills it
+        const long waves = (long)c->cfg.n_ensemble * c->W;
+        B = waves * 4 <= 8L * c->compute_units ? 4 : (waves * 2 <= 8L * c->compute_units ? 2 : 1);
+    }
+    if (B > c->B) B = c->B;
+    if (B > grape::kLbfgsMaxProbes) B = grape::kLbfgsMaxProbes;
+    if (B < 1) B = 1;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->dev_pending) {
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_dev, 0));
+        c->dev_pending = false;
+    }
+    // workspace (freed on return): vectors + history + trial points/results + scalars
+    const size_t n_dbl = 3 * kn + 2 * (size_t)m * kn + m + (size_t)B * kn + (size_t)B * Q + grape::kLbfgsMaxProbes + 8;
+    double *buf = nullptr, *h_sc = nullptr, *d_h_sc = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&buf, sizeof(double) * n_dbl));
+    hipError_t he = hipHostMalloc((void **)&h_sc, sizeof(double) * 8, hipHostMallocMapped | hipHostMallocCoherent);
+    if (he == hipSuccess) he = hipHostGetDevicePointer((void **)&d_h_sc, h_sc, 0);
+    if (he != hipSuccess) {
+        (void)hipFree(buf);
+        if (h_sc) (void)hipHostFree(h_sc);
+        return fail(c, GRAPE_ERR_ALLOC, std::string("grape_lbfgs: ") + hipGetErrorString(he));
+    }
+    grape::LbfgsState st{};
+    double *p = buf;
+    st.x = p; p += kn;
+    st.g = p; p += kn;
+    st.d = p; p += kn;
+    st.S = p; p += (size_t)m * kn;
+    st.Y = p; p += (size_t)m * kn;
+    st.rho = p; p += m;
+    st.xt = p; p += (size_t)B * kn;
+    st.fgt = p; p += (size_t)B * Q;
+    st.alphas = p; p += grape::kLbfgsMaxProbes;
+    st.sc = p;
+    st.host_sc = d_h_sc;
+    st.c1 = 1e-4;
+    st.c2 = 0.9;
+    st.KN = (int32_t)kn;
+    st.m = m;
+    int rc = GRAPE_OK;
+    auto cleanup = [&](int code) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(buf);
+        (void)hipHostFree(h_sc);
+        return code;
+    };
+    auto signal = [&]() {
+        grape::DoneSignal d;
+        d.flag = c->d_h_flag;
+        d.seq = ++c->seq;
+        return d;
+    };
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    // f(x0), g(x0)
+    if (hipMemcpyAsync(st.x, x0, sizeof(double) * kn, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: upload of x0 failed"));
+    rc = enqueue_eval(c, st.x, st.fgt, c->stream, 1);
+    if (rc) return cleanup(rc);
+    if (grape::launch_lbfgs_init(st, c->stream, signal()) != hipSuccess)
+        return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed"));
+    rc = wait_flag(c);
+    if (rc) return cleanup(rc);
+    int evals = 1, it = 0, status = 2;
+    double F = h_sc[0], gnorm = h_sc[1];
+    if (gnorm <= g_tol) status = 0;
+    while (status == 2 && it < max_it) {
+        // Step lengths: start at 1 (Optim: InitialStatic(alpha = 1)); every launch probes B lengths in a
+        // factor-2 ladder.  Ladders tried in turn until one holds an acceptable step:
+        //   [1 .. 2^-(B-1)], then the next B LARGER lengths [2^B .. 2], then the next B smaller, ...
+        // (expansion matters for the reference's UnitaryGate conventions, where g is not the gradient of
+        // the reported figure of merit -- SURVEY.md App. C #2 -- and small steps along -g may not descend).
+        int tried = 0, shrink = 0, grow = 0;
+        bool accepted = false;
+        const double F_prev = F;
+        while (tried < max_ls) {
+            const bool up = (shrink > grow);                  // alternate: down, up, down, up, ...
+            const int top = up ? (grow + 1) * B : -shrink * B;    // exponent of the ladder's largest length
+            if (up) ++grow; else ++shrink;
+            if (top > 40 || top < -60) continue;
+            const double alpha0 = std::ldexp(1.0, top);
+            if (grape::launch_lbfgs_direction(st, B, alpha0, c->stream) != hipSuccess)
+                return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed"));
+            rc = enqueue_eval(c, st.xt, st.fgt, c->stream, B);
+            if (rc) return cleanup(rc);
+            if (grape::launch_lbfgs_select(st, B, c->stream, signal()) != hipSuccess)
+                return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed"));
+            rc = wait_flag(c);
+            if (rc) return cleanup(rc);
+            evals += B;
+            tried += B;
+            if (h_sc[5] == 0.0) { accepted = true; break; }
+        }
+        if (!accepted) { status = 3; break; }
+        ++it;
+        F = h_sc[0];
+        gnorm = h_sc[1];
+        if (gnorm <= g_tol) { status = 0; break; }
+        if (f_tol > 0.0 && std::fabs(F - F_prev) <= f_tol * std::fabs(F)) { status = 1; break; }
+    }
+    if (hipMemcpyAsync(c->h_fg, st.x, sizeof(double) * kn, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: download of the minimiser failed"));
+    std::memcpy(x_min, c->h_fg, sizeof(double) * kn);
+    timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    result->minimum = F;
+    result->g_norm = gnorm;
+    result->seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    result->iterations = it;
+    result->evaluations = evals;
+    result->status = status;
+    result->probes = B;
+    c->evaluated = true;
+    return cleanup(GRAPE_OK);
+}
+
 extern "C" int grape_get_member_results(grape_ctx *c, double *foms, double *grads)
 {
     if (!c) return GRAPE_ERR_INVALID_ARG;

@@ -96,6 +96,24 @@ int reduce_ksplit(int E);
 hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, int n_x, hipStream_t stream,
                               DoneSignal done = DoneSignal());
 
+// ---- device-resident L-BFGS (lbfgs.hip) -----------------------------------------------------------
+constexpr int kLbfgsMaxPer = 16;       // vector elements per thread of the 1024-thread workgroup: K*N <= 16384
+constexpr int kLbfgsMaxProbes = 8;     // trial step lengths per launch
+struct LbfgsState {
+    double *x, *g, *d;        // K*N each: iterate, its gradient, search direction
+    double *S, *Y, *rho;      // m x K*N history (circular), m curvature reciprocals
+    double *xt;               // B x K*N trial points x + alpha_j d   (the batched evaluation's input)
+    double *fgt;              // B x (K*N + 1) trial results { g_j, F_j } (the batched evaluation's output)
+    double *alphas;           // B trial step lengths
+    double *sc;               // 8 scalars: F, |g|_inf, g'd, gamma, accepted alpha, status (1: no acceptable probe), n_hist, head
+    double *host_sc;          // mapped host mirror of sc
+    double c1, c2;
+    int32_t KN, m;
+};
+hipError_t launch_lbfgs_init(const LbfgsState &st, hipStream_t stream, DoneSignal done);
+hipError_t launch_lbfgs_direction(const LbfgsState &st, int B, double alpha0, hipStream_t stream);
+hipError_t launch_lbfgs_select(const LbfgsState &st, int B, hipStream_t stream, DoneSignal done);
+
 // dst[i] = src[i], i < n: moves the all-reduced [G, F] into mapped pinned host memory (one small launch
 // instead of a D2H copy node: the host polls the stream)
 hipError_t launch_copy(const double *src, double *dst, int n, hipStream_t stream, DoneSignal done = DoneSignal());

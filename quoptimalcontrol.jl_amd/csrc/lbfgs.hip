@@ -1,0 +1,302 @@
+// lbfgs.hip -- device-resident L-BFGS around the GRAPE evaluation.
+//
+// Stands in for  Optim.optimize(Optim.only_fg!(topt), x0, Optim.LBFGS(), opts)
+// (/root/reference/src/solve.jl:138, :244) with every vector on the GPU: x, g, the m = 10 (s, y)
+// pairs, the search direction and the trial points never visit the host; per iteration the host
+// reads eight scalars (F, |g|_inf, the accepted step, ...) to decide convergence.
+//
+//   lbfgs_direction_kernel   two-loop recursion (Nocedal & Wright alg. 7.4, initial scaling
+//                            gamma = s'y / y'y, Optim's scaleinvH0) -> d, g'd, and the B trial
+//                            points x + alpha_j d of the line search, in ONE single-workgroup launch
+//   [GRAPE sweep + reduce on the B trial points: one batched evaluation]
+//   lbfgs_select_kernel      picks the largest trial step with sufficient decrease (Armijo, c1 = 1e-4)
+//                            that also meets the strong Wolfe curvature condition (c2 = 0.9) if any
+//                            does, updates x, g, pushes (s, y) when s'y > 0, publishes the scalars
+//
+// One workgroup of 1024 threads holds a K*N-vector in registers (up to kLbfgsMaxPer elements per
+// thread): every dot product is a wave shuffle tree + one LDS round, fixed summation order.
+#include "grape_kernels.hpp"
+
+namespace grape {
+
+constexpr int kLbfgsThreads = 1024;
+
+struct BlockSum {
+    double *s_part;          // 16 doubles
+    __device__ __forceinline__ double operator()(double v) const
+    {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            v += __shfl_xor(v, d, 64);
+        __syncthreads();                             // s_part may still be read from the previous sum
+        if ((threadIdx.x & 63) == 0)
+            s_part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kLbfgsThreads / 64; ++w)
+            t += s_part[w];
+        return t;
+    }
+};
+
+__global__ __launch_bounds__(kLbfgsThreads) void lbfgs_direction_kernel(LbfgsState st, int B, double alpha0)
+{
+    __shared__ double s_part[kLbfgsThreads / 64];
+    __shared__ double s_alpha[64];
+    const BlockSum sum{s_part};
+    const int KN = st.KN, m = st.m;
+    const int n_hist = (int)st.sc[6], head = (int)st.sc[7];
+    const double gamma = st.sc[3];
+    double q[kLbfgsMaxPer], gg[kLbfgsMaxPer];
+#pragma unroll
+    for (int i = 0; i < kLbfgsMaxPer; ++i) {
+        const int idx = threadIdx.x + i * kLbfgsThreads;
+        gg[i] = idx < KN ? st.g[idx] : 0.0;
+        q[i] = gg[i];
+    }
+    for (int h = 0; h < n_hist; ++h) {               // newest -> oldest
+        const int j = (head - h + m) % m;
+        const double *__restrict__ Sj = st.S + (size_t)j * KN, *__restrict__ Yj = st.Y + (size_t)j * KN;
+        double part = 0.0;
+#pragma unroll
+        for (int i = 0; i < kLbfgsMaxPer; ++i) {
+            const int idx = threadIdx.x + i * kLbfgsThreads;
+            if (idx < KN) part = fma(Sj[idx], q[i], part);
+        }
+        const double a = st.rho[j] * sum(part);
+        if (threadIdx.x == 0) s_alpha[h] = a;
+#pragma unroll
+        for (int i = 0; i < kLbfgsMaxPer; ++i) {
+            const int idx = threadIdx.x + i * kLbfgsThreads;
+            if (idx < KN) q[i] = fma(-a, Yj[idx], q[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kLbfgsMaxPer; ++i)
+        q[i] *= gamma;
+    __syncthreads();
+    for (int h = n_hist - 1; h >= 0; --h) {          // oldest -> newest
+        const int j = (head - h + m) % m;
+        const double *__restrict__ Sj = st.S + (size_t)j * KN, *__restrict__ Yj = st.Y + (size_t)j * KN;
+        double part = 0.0;
+#pragma unroll
+        for (int i = 0; i < kLbfgsMaxPer; ++i) {
+            const int idx = threadIdx.x + i * kLbfgsThreads;
+            if (idx < KN) part = fma(Yj[idx], q[i], part);
+        }
+        const double b = st.rho[j] * sum(part);
+        const double a = s_alpha[h];
+#pragma unroll
+        for (int i = 0; i < kLbfgsMaxPer; ++i) {
+            const int idx = threadIdx.x + i * kLbfgsThreads;
+            if (idx < KN) q[i] = fma(a - b, Sj[idx], q[i]);
+        }
+    }
+    double part = 0.0;
+#pragma unroll
+    for (int i = 0; i < kLbfgsMaxPer; ++i)
+        part = fma(-q[i], gg[i], part);
+    double dg = sum(part);
+    bool reset = !(dg < 0.0);                        // not a descent direction (or NaN): steepest descent, drop the history
+    if (reset) {
+        part = 0.0;
+#pragma unroll
+        for (int i = 0; i < kLbfgsMaxPer; ++i) {
+            q[i] = gg[i];
+            part = fma(-gg[i], gg[i], part);
+        }
+        dg = sum(part);
+    }
+#pragma unroll
+    for (int i = 0; i < kLbfgsMaxPer; ++i) {
+        const int idx = threadIdx.x + i * kLbfgsThreads;
+        if (idx < KN) {
+            const double di = -q[i];
+            st.d[idx] = di;
+            const double xi = st.x[idx];
+            for (int j = 0; j < B; ++j)
+                st.xt[(size_t)j * KN + idx] = fma(ldexp(alpha0, -j), di, xi);     // alpha0, alpha0/2, alpha0/4, ...
+        }
+    }
+    if (threadIdx.x < B)
+        st.alphas[threadIdx.x] = ldexp(alpha0, -(int)threadIdx.x);
+    if (threadIdx.x == 0) {
+        st.sc[2] = dg;
+        if (reset) st.sc[6] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(kLbfgsThreads) void lbfgs_select_kernel(LbfgsState st, int B, DoneSignal done)
+{
+    __shared__ double s_part[kLbfgsThreads / 64];
+    __shared__ int s_pick;
+    const BlockSum sum{s_part};
+    const int KN = st.KN, m = st.m, Q = KN + 1;
+    const double F0 = st.sc[0], dg0 = st.sc[2];
+    double dd[kLbfgsMaxPer];
+#pragma unroll
+    for (int i = 0; i < kLbfgsMaxPer; ++i) {
+        const int idx = threadIdx.x + i * kLbfgsThreads;
+        dd[i] = idx < KN ? st.d[idx] : 0.0;
+    }
+    // directional derivatives of the B trial points, then the choice (thread 0, broadcast through LDS)
+    double dgj[kLbfgsMaxProbes];
+    for (int j = 0; j < B; ++j) {
+        const double *__restrict__ gj = st.fgt + (size_t)j * Q;
+        double part = 0.0;
+#pragma unroll
+        for (int i = 0; i < kLbfgsMaxPer; ++i) {
+            const int idx = threadIdx.x + i * kLbfgsThreads;
+            if (idx < KN) part = fma(gj[idx], dd[i], part);
+        }
+        dgj[j] = sum(part);
+    }
+    if (threadIdx.x == 0) {
+        int armijo = -1, wolfe = -1;
+        for (int j = 0; j < B; ++j) {
+            const double Fj = st.fgt[(size_t)j * Q + KN];
+            const bool ok = (Fj == Fj) && fabs(Fj) < 1.0e300 && Fj <= F0 + st.c1 * st.alphas[j] * dg0;
+            if (ok && armijo < 0) armijo = j;
+            if (ok && wolfe < 0 && fabs(dgj[j]) <= st.c2 * fabs(dg0)) wolfe = j;
+        }
+        s_pick = wolfe >= 0 ? wolfe : armijo;
+    }
+    __syncthreads();
+    const int pick = s_pick;
+    double sc_out[8];
+    if (pick < 0) {                                  // no acceptable step among the probes: the host shrinks and retries
+        if (threadIdx.x == 0) st.sc[5] = 1.0;
+    } else {
+        const double alpha = st.alphas[pick];
+        const double *__restrict__ gj = st.fgt + (size_t)pick * Q;
+        double sy = 0.0, yy = 0.0, ss = 0.0, gmax = 0.0;
+        double gn[kLbfgsMaxPer], yv[kLbfgsMaxPer];
+#pragma unroll
+        for (int i = 0; i < kLbfgsMaxPer; ++i) {
+            const int idx = threadIdx.x + i * kLbfgsThreads;
+            gn[i] = idx < KN ? gj[idx] : 0.0;
+            yv[i] = idx < KN ? gn[i] - st.g[idx] : 0.0;
+            const double si = alpha * dd[i];
+            sy = fma(si, yv[i], sy);
+            yy = fma(yv[i], yv[i], yy);
+            ss = fma(si, si, ss);
+            gmax = fmax(gmax, fabs(gn[i]));
+        }
+        sy = sum(sy);
+        yy = sum(yy);
+        ss = sum(ss);
+        // |g|_inf: max through the same tree (all values >= 0: exact in any order)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            gmax = fmax(gmax, __shfl_xor(gmax, d, 64));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = gmax;
+        __syncthreads();
+        gmax = 0.0;
+#pragma unroll
+        for (int w = 0; w < kLbfgsThreads / 64; ++w)
+            gmax = fmax(gmax, s_part[w]);
+        const bool push = sy > 1e-10 * sqrt(ss * yy) && yy > 0.0;
+        int n_hist = (int)st.sc[6], head = (int)st.sc[7];
+        if (push) {
+            head = n_hist == 0 ? 0 : (head + 1) % m;
+            n_hist = n_hist < m ? n_hist + 1 : m;
+        }
+        double *__restrict__ Sj = st.S + (size_t)head * KN, *__restrict__ Yj = st.Y + (size_t)head * KN;
+        const double *__restrict__ xj = st.xt + (size_t)pick * KN;
+#pragma unroll
+        for (int i = 0; i < kLbfgsMaxPer; ++i) {
+            const int idx = threadIdx.x + i * kLbfgsThreads;
+            if (idx < KN) {
+                if (push) {
+                    Sj[idx] = alpha * dd[i];
+                    Yj[idx] = yv[i];
+                }
+                st.x[idx] = xj[idx];
+                st.g[idx] = gn[i];
+            }
+        }
+        if (threadIdx.x == 0) {
+            if (push) {
+                st.rho[head] = 1.0 / sy;
+                st.sc[3] = sy / yy;                  // gamma
+            }
+            st.sc[0] = gj[KN];                       // F
+            st.sc[1] = gmax;
+            st.sc[4] = alpha;
+            st.sc[5] = 0.0;
+            st.sc[6] = (double)n_hist;
+            st.sc[7] = (double)head;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            sc_out[i] = st.sc[i];
+            st.host_sc[i] = sc_out[i];
+        }
+        if (done.flag) {
+            __threadfence_system();
+            __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// first evaluation: fg0 = [g (KN), F] -> g, F, |g|_inf; empty history
+__global__ __launch_bounds__(kLbfgsThreads) void lbfgs_init_kernel(LbfgsState st, DoneSignal done)
+{
+    __shared__ double s_part[kLbfgsThreads / 64];
+    const int KN = st.KN;
+    double gmax = 0.0;
+    for (int idx = threadIdx.x; idx < KN; idx += kLbfgsThreads) {
+        const double v = st.fgt[idx];
+        st.g[idx] = v;
+        gmax = fmax(gmax, fabs(v));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        gmax = fmax(gmax, __shfl_xor(gmax, d, 64));
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = gmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        gmax = 0.0;
+        for (int w = 0; w < kLbfgsThreads / 64; ++w)
+            gmax = fmax(gmax, s_part[w]);
+        st.sc[0] = st.fgt[KN];
+        st.sc[1] = gmax;
+        st.sc[2] = 0.0;
+        st.sc[3] = 1.0;
+        st.sc[4] = 0.0;
+        st.sc[5] = 0.0;
+        st.sc[6] = 0.0;
+        st.sc[7] = 0.0;
+        for (int i = 0; i < 8; ++i)
+            st.host_sc[i] = st.sc[i];
+        if (done.flag) {
+            __threadfence_system();
+            __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+hipError_t launch_lbfgs_init(const LbfgsState &st, hipStream_t stream, DoneSignal done)
+{
+    hipLaunchKernelGGL(lbfgs_init_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, done);
+    return hipGetLastError();
+}
+
+hipError_t launch_lbfgs_direction(const LbfgsState &st, int B, double alpha0, hipStream_t stream)
+{
+    hipLaunchKernelGGL(lbfgs_direction_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, B, alpha0);
+    return hipGetLastError();
+}
+
+hipError_t launch_lbfgs_select(const LbfgsState &st, int B, hipStream_t stream, DoneSignal done)
+{
+    hipLaunchKernelGGL(lbfgs_select_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, B, done);
+    return hipGetLastError();
+}
+
+}  // namespace grape

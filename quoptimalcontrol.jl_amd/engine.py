@@ -36,7 +36,7 @@ STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID_ARG", -2: "GRAPE_ERR_UNSUPPORTED
 # every symbol include/grape_hip.h declares
 EXPORTS = ["grape_abi_version", "grape_create", "grape_destroy", "grape_set_operators",
            "grape_comm_unique_id", "grape_comm_attach",
-           "grape_eval", "grape_eval_device", "grape_eval_batch", "grape_eval_batch_device",
+           "grape_eval", "grape_eval_device", "grape_eval_batch", "grape_eval_batch_device", "grape_lbfgs",
            "grape_get_member_results", "grape_get_trajectory",
            "grape_get_kernel_time", "grape_get_phase_stamps", "grape_get_info", "grape_last_error"]
 
@@ -64,6 +64,16 @@ class GrapeInfo(C.Structure):
                 ("n_devices", C.c_int32), ("comm_size", C.c_int32), ("comm_rank", C.c_int32),
                 ("members_first_device", C.c_int32), ("lane_pair", C.c_int32),
                 ("states_stored", C.c_int32)]
+
+
+class GrapeLbfgsOptions(C.Structure):
+    _fields_ = [("memory", C.c_int32), ("max_iterations", C.c_int32), ("g_tol", C.c_double), ("f_tol", C.c_double),
+                ("max_linesearch", C.c_int32), ("probes", C.c_int32)]
+
+
+class GrapeLbfgsResult(C.Structure):
+    _fields_ = [("minimum", C.c_double), ("g_norm", C.c_double), ("seconds", C.c_double), ("iterations", C.c_int32),
+                ("evaluations", C.c_int32), ("status", C.c_int32), ("probes", C.c_int32)]
 
 
 class GrapeCommId(C.Structure):
@@ -107,6 +117,7 @@ def load_library():
     L.grape_eval_device.argtypes = [vp, vp, vp, vp]
     L.grape_eval_batch.argtypes = [vp, i32, vp, vp, vp]
     L.grape_eval_batch_device.argtypes = [vp, i32, vp, vp, vp]
+    L.grape_lbfgs.argtypes = [vp, vp, C.POINTER(GrapeLbfgsOptions), vp, C.POINTER(GrapeLbfgsResult)]
     L.grape_get_member_results.argtypes = [vp, vp, vp]
     L.grape_get_trajectory.argtypes = [vp, i32, vp, vp, vp]
     L.grape_get_kernel_time.argtypes = [vp, dp, C.POINTER(C.c_int64), i32]
@@ -253,6 +264,24 @@ class GrapeEngine:
         if rc:
             self._check(rc)
         return self._F.value
+
+    LBFGS_STATUS = {0: "g_tol reached", 1: "f_tol reached", 2: "max iterations", 3: "line search failed"}
+
+    def lbfgs(self, x0, memory=0, iterations=0, g_tol=-1.0, f_tol=0.0, max_linesearch=0, probes=0):
+        """grape_lbfgs: device-resident L-BFGS from x0 (K,N) -> (x_min (K,N), result dict).  Optim LBFGS()
+        defaults when the options are left at 0 / negative; `probes` step lengths are evaluated per launch
+        (needs max_batch >= probes at construction)."""
+        x0 = np.asarray(x0, dtype=np.float64)
+        if x0.shape != (self.K, self.N):
+            raise ValueError(f"x0 must be ({self.K},{self.N})")
+        xf = np.ascontiguousarray(x0.T)
+        out = np.empty_like(xf)
+        opts = GrapeLbfgsOptions(int(memory), int(iterations), float(g_tol), float(f_tol), int(max_linesearch), int(probes))
+        res = GrapeLbfgsResult()
+        self._check(self._lib.grape_lbfgs(self._h, _p(xf), C.byref(opts), _p(out), C.byref(res)))
+        info = {f: getattr(res, f) for f, _ in res._fields_}
+        info["message"] = self.LBFGS_STATUS.get(res.status, "?")
+        return np.ascontiguousarray(out.T), info
 
     def eval_batch(self, X):
         """grape_eval_batch: X (n_x, K, N) control arrays -> (F (n_x,), G (n_x, K, N)); entry b equals

@@ -76,6 +76,7 @@ int main(int argc, char **argv)
     bad |= grape_get_info(nullptr, &inf) != GRAPE_ERR_INVALID_ARG;
     bad |= grape_comm_attach(nullptr, &id, 0, 1) != GRAPE_ERR_INVALID_ARG;
     bad |= grape_comm_unique_id(nullptr) != GRAPE_ERR_INVALID_ARG;
+    bad |= grape_lbfgs(nullptr, x, nullptr, G, nullptr) != GRAPE_ERR_INVALID_ARG;
     bad |= grape_abi_version() != GRAPE_ABI_VERSION;
     if (bad) { std::fprintf(stderr, "a null-argument call returned the wrong status\n"); return 3; }
     std::printf("fuzz ok: %ld configs; status histogram:", iters);

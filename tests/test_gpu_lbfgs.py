@@ -1,0 +1,98 @@
+"""GPU: grape_lbfgs, the device-resident L-BFGS -- the reference's GRAPE convergence testsets
+(test/state_transfer_tests.jl, test/unitary_gate_tests.jl) driven through it, agreement with the host-driven
+loop, and its bookkeeping."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+tol = 1e-6
+
+
+def _problem(qoc, sys_type, N, T):
+    wl = qoc.workloads
+    ug = sys_type == "UnitaryGate"
+    return qoc.Problem(B=[wl.Sx, wl.Sy], A=wl.Sz, Xi=wl.U_init if ug else wl.rho_init,
+                       Xt=wl.U_fin if ug else wl.rho_fin, T=T, n_controls=2, guess=wl.controls(2, N),
+                       sys_type=qoc.UnitaryGate() if ug else qoc.StateTransfer())
+
+
+@pytest.mark.parametrize("sys_type,floor", [("StateTransfer", 0.75), ("UnitaryGate", 0.0)])
+@pytest.mark.parametrize("isinplace", [True, False])
+def test_reference_single_problem_testsets_device_optimizer(qoc, sys_type, floor, isinplace):
+    """test/state_transfer_tests.jl:4-37, test/unitary_gate_tests.jl:3-37: `@test minimum - C1(target, target) < tol`."""
+    prob = _problem(qoc, sys_type, 10, 1.0)
+    sol = qoc.solve(prob, qoc.GRAPE(n_slices=10, isinplace=isinplace, optimizer="device"))
+    assert isinstance(sol, qoc.SolutionResult)
+    assert sol.result.minimum - floor < tol
+    assert sol.opti_pulses.shape == (2, 10) and sol.fidelity == sol.result.minimum
+    assert sol.result.device_lbfgs["probes"] == 4                 # tiny problem: four step lengths per launch
+
+
+@pytest.mark.parametrize("sys_type,N,T,opts,isinplace,floor", [
+    ("StateTransfer", 25, 5.0, {}, True, 0.75), ("UnitaryGate", 100, 5.0, {"f_tol": 1e-3}, True, 0.75),
+    ("StateTransfer", 25, 5.0, {}, False, 0.75), ("UnitaryGate", 100, 10.0, {"f_tol": 1e-3}, False, 1.0)])
+def test_reference_ensemble_testsets_device_optimizer(qoc, sys_type, N, T, opts, isinplace, floor):
+    """the n_ens = 5 testsets (state_transfer_tests.jl:42-100, unitary_gate_tests.jl:41-112)."""
+    wl = qoc.workloads
+    ug = sys_type == "UnitaryGate"
+    prob = _problem(qoc, sys_type, N, T)
+    tgt = (wl.U_fin, wl.U_init) if ug else (wl.rho_fin, wl.rho_init)
+    ens = qoc.EnsembleProblem(prob=prob, n_ens=5, A_g=lambda k: (k - 2.5) / 2.5 * wl.Sz * 5,
+                              B_g=lambda k: [wl.Sx, wl.Sy], XiG=lambda k: prob.Xi,
+                              XtG=lambda k: tgt[0] if k % 2 else tgt[1], wts=np.ones(5) / 5)
+    sol = qoc.solve(ens, qoc.GRAPE(n_slices=N, isinplace=isinplace, optim_options=opts, optimizer="device"))
+    assert isinstance(sol, qoc.EnsembleSolutionResult)
+    assert sol.result.minimum - floor < tol * 10
+
+
+def test_device_and_host_optimizers_reach_the_same_minimum(qoc):
+    """StateTransfer ensemble: both drivers end at the 0.75 floor; the device loop reports its own bookkeeping."""
+    w = qoc.workloads.reference_ensemble("StateTransfer", 5, 25, 5.0)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, max_batch=4) as eng:
+        x_min, info = eng.lbfgs(w.x)
+        F_min, G_min = eng.eval(x_min)
+        from quoptimalcontrol_jl_amd.api import _lbfgs
+        res = _lbfgs(lambda x: eng.eval(x), w.x, {})
+    assert info["status"] in (0, 1, 3) and info["iterations"] >= 3 and info["evaluations"] >= info["iterations"]
+    assert abs(F_min - info["minimum"]) <= 1e-12                    # the returned point IS the reported minimum
+    assert np.abs(G_min).max() == pytest.approx(info["g_norm"], rel=1e-9, abs=1e-14)
+    assert abs(info["minimum"] - 0.75) < 1e-6 and abs(res.minimum - 0.75) < 1e-6
+
+
+def test_sequential_probes_without_batching(qoc):
+    """a context without batching (max_batch = 1, and the tile family): one step length per launch."""
+    w = qoc.workloads.reference_ensemble("StateTransfer", 3, 20, 4.0)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        x_min, info = eng.lbfgs(w.x, iterations=60)
+    assert info["probes"] == 1 and info["minimum"] < 0.76
+    rng = np.random.default_rng(5)
+    n, E, K, N = 8, 2, 2, 12
+
+    def herm():
+        M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        return (M + M.conj().T) / 2
+    A = np.array([herm() for _ in range(E)]) * 0.5
+    B = np.array([[herm() for _ in range(K)] for _ in range(E)]) * 0.5
+    v = rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))
+    v /= np.linalg.norm(v, axis=1)[:, None]
+    Xi = np.array([np.outer(v[0], v[0].conj())] * E)
+    Xt = np.array([np.outer(v[1], v[1].conj())] * E)
+    x0 = rng.uniform(-1, 1, (K, N))
+    with qoc.GrapeEngine("StateTransfer", A, B, Xi, Xt, np.ones(E) / E, 2.0, N) as eng:      # MFMA tile kernels
+        F0, _ = eng.eval(x0)
+        x_min, info = eng.lbfgs(x0, iterations=25)
+        F1, _ = eng.eval(x_min)
+    assert info["probes"] == 1 and F1 <= F0 and abs(F1 - info["minimum"]) <= 1e-12
+
+
+def test_lbfgs_argument_errors(qoc):
+    w = qoc.workloads.config("C1")
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, force_collective=True) as eng:
+        with pytest.raises(qoc.GrapeError) as ei:
+            eng.lbfgs(w.x)
+        assert ei.value.status == -2                                # single-device contexts only
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        with pytest.raises(ValueError):
+            eng.lbfgs(np.zeros((3, 3)))
+        with pytest.raises(qoc.GrapeError):
+            eng.lbfgs(w.x, memory=100)
