@@ -202,7 +202,7 @@ int grape_eval_device(grape_ctx *ctx, const double *d_x, double *d_fg, void *str
  * n_x <= max_batch independent control arrays evaluated against the same ensemble in ONE launch.
  *   x  host f64 (K,N,n_x)      F  host f64[n_x] (nullable)      G  host f64 (K,N,n_x) (nullable)
  * Entry b is exactly what grape_eval(ctx, x[:,:,b]) returns; with n_x = 1 the two calls are the same.
- * Needs grape_config.max_batch >= n_x; operator dimension n <= 4 in this build. */
+ * Needs grape_config.max_batch >= n_x (the workspace is sized for max_batch control arrays). */
 int grape_eval_batch(grape_ctx *ctx, int32_t n_x, const double *x, double *F, double *G);
 
 /* Device-pointer form: d_x (K,N,n_x), d_fg f64[(K*N + 1) * n_x] = n_x blocks of { G, F }. */
@@ -214,7 +214,7 @@ int grape_eval_batch_device(grape_ctx *ctx, int32_t n_x, const double *d_x, doub
  * reads eight scalars.  Optim's LBFGS() defaults are mirrored where they are plain numbers: memory m = 10,
  * initial inverse-Hessian scaling s'y / y'y, initial step 1 (InitialStatic), g_tol = 1e-8 on |g|_inf,
  * f_tol = x_tol = 0, 1000 iterations.  The line search is NOT HagerZhang: `probes` step lengths
- * alpha, alpha/2, alpha/4, ... are evaluated by ONE batched launch (grape_config.max_batch >= probes; n <= 4)
+ * alpha, alpha/2, alpha/4, ... are evaluated by ONE batched launch (grape_config.max_batch >= probes)
  * and the largest one with sufficient decrease (c1 = 1e-4) -- preferring one that also satisfies the strong
  * Wolfe curvature condition (c2 = 0.9) -- is taken; contexts without batching probe one step per launch.
  * The gradient is whatever the GRAPE evaluation returns, with the reference's conventions. */

@@ -245,8 +245,6 @@ static int validate_config(const grape_config *cfg)
     if (m != cfg->n && cfg->sys_type != GRAPE_UNITARY_GATE)
         return fail(nullptr, GRAPE_ERR_INVALID_ARG,
                     "grape_create: n x m states with m < n need UnitaryGate (the sandwich X P' is not defined)");
-    if (cfg->max_batch > 1 && wmax == 0)
-        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: max_batch > 1 needs operator dimension n <= 4 in this build");
     if ((cfg->flags & GRAPE_FLAG_PHASE_STAMPS) && wmax == 0)
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: GRAPE_FLAG_PHASE_STAMPS exists for n <= 4 only (the tile kernels write no stamps)");
     return GRAPE_OK;
@@ -718,9 +716,10 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     return GRAPE_OK;
 }
 
-static TileParams tile_params(const grape_ctx *c, const double *d_x)
+static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1)
 {
     TileParams p{};
+    p.n_x = n_x;
     p.ops = c->d_ops;
     p.x = d_x;
     p.props = c->d_props;
@@ -749,9 +748,9 @@ static bool states_stored(const grape_ctx *c)
     return !grape::tile_chain_is_split(tile_params(c, nullptr), false);
 }
 
-static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream)
+static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream, int n_x)
 {
-    const TileParams p = tile_params(c, d_x);
+    const TileParams p = tile_params(c, d_x, n_x);
     HIP_TRY(c, grape::launch_sweep_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE,
                                         c->d_costates != nullptr, p, stream));
     return GRAPE_OK;
@@ -821,15 +820,27 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
         else
             HIP_TRY(c, grape::launch_sweep_small(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, mode, p, stream));
     } else {
-        int rc = enqueue_tile(c, d_x, stream);
+        int rc = enqueue_tile(c, d_x, stream, n_x);
         if (rc) return rc;
     }
     if (timed) HIP_TRY(c, hipEventRecord(e1, stream));
     if (c->family == 0)
         HIP_TRY(c, grape::launch_reduce_rows(c->d_block_out, d_fg, c->NB, (int)(KN(c) + 1), n_x, stream, done));
-    else
-        HIP_TRY(c, grape::launch_reduce(c->d_member_out, c->d_wts, c->d_partial, d_fg, p.E,
-                                        (int)(KN(c) + 1), c->ksplit, stream, done));
+    else {
+        // one weighted reduction per control array (each reuses d_partial, in stream order); with a host
+        // destination only the last one publishes -- it copies out the whole staging buffer
+        const size_t Qs = KN(c) + 1;
+        for (int b = 0; b < n_x; ++b) {
+            grape::DoneSignal db;
+            if (b == n_x - 1 && done.flag) {
+                db = done;
+                db.stage_base = d_fg;
+                db.n_total = (int)(Qs * n_x);
+            }
+            HIP_TRY(c, grape::launch_reduce(c->d_member_out + (size_t)b * p.E * Qs, c->d_wts, c->d_partial,
+                                            d_fg + (size_t)b * Qs, p.E, (int)Qs, c->ksplit, stream, db));
+        }
+    }
     c->evaluated = true;
     return GRAPE_OK;
 }

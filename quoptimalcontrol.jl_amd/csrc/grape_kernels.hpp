@@ -16,6 +16,8 @@ struct DoneSignal {
     double *host_out = nullptr;                // reduce kernels: mapped host destination of [G, F]; the kernel's
                                                // `fg` argument is then a DEVICE staging buffer that the last
                                                // workgroup copies out in one coalesced burst before publishing
+    const double *stage_base = nullptr;        // reduce_stage2 of a batched evaluation: start of the whole staging
+    int n_total = 0;                           // buffer and its length (all n_x blocks), copied by the last launch
 };
 
 constexpr int kStampSlots = 8;   // [0..4] shader clock at phase boundaries, [5],[6] 100 MHz real time
@@ -80,6 +82,7 @@ struct TileParams {
     int32_t unitary;      // every generator Hermitian: chain kernel carries M_t = P' M P, no stored states
     int32_t herm_states;  // every Xi, Xt Hermitian (density operators): [X, L'] = Y - Y' with one product
     int32_t split_at;     // set by the launcher: first slice of the second wave (chain_tile_split_kernel)
+    int32_t n_x;          // control arrays evaluated by this launch (batched evaluation); x is (K, N, n_x)
     double dt;
 };
 int tile_count(int n);    // NT for this n (0: not a tile-family size)

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void reduce_stage2(const double *__restrict__ 
     if (done.flag) {
         if (ks == 0 && q < Q)
             stage_store(fg, q, v);
-        publish_via_last_block(done, fg, Q, gridDim.x);
+        publish_via_last_block(done, done.stage_base ? done.stage_base : fg, done.stage_base ? done.n_total : Q, gridDim.x);
     } else if (ks == 0 && q < Q) {
         fg[q] = v;
     }

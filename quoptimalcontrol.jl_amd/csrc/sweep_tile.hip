@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void prop_tile_kernel(const TileParams p)
     else
         tload(G, ops, lane);
     for (int c = 0; c < K; ++c) {
-        const double xv = p.x[c + (size_t)t * K];
+        const double xv = p.x[(size_t)blockIdx.z * K * p.N + c + (size_t)t * K];
         TMat<NT> B;
         if (STAGE)
             tload(B, s_ops + (size_t)(1 + c) * TSZ, lane);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void prop_tile_kernel(const TileParams p)
         tmul_an<NT, false, false>(T, opa, P);
         P = T;
     }
-    tstore(p.props + ((size_t)k * p.N + t) * TSZ, P, lane);
+    tstore(p.props + (((size_t)blockIdx.z * p.E + k) * p.N + t) * TSZ, P, lane);
   }
 }
 
@@ -200,14 +200,15 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
-    const double2 *__restrict__ Pk = p.props + (size_t)k * N * TSZ;
-    double2 *__restrict__ Xk = p.states + (size_t)k * N * TSZ;
+    const size_t kw = (size_t)blockIdx.y * p.E + k;                // workspace row: (control array, unit)
+    const double2 *__restrict__ Pk = p.props + kw * N * TSZ;
+    double2 *__restrict__ Xk = p.states + kw * N * TSZ;
     // pack2: this wave carries members 2k (tile rows/cols 0..7) and 2k+1 (8..15); after the
     // cross-lane sums lane 0 holds the first member's values and lane 8 the second's
     constexpr bool pack2 = PACK2;
     const int member = pack2 ? 2 * k + ((lane >> 3) & 1) : k;
     const bool writer = (pack2 ? (lane == 0 || lane == 8) : lane == 0) && member < p.E_members;
-    double *__restrict__ out = p.member_out + (size_t)member * ((size_t)K * N + 1);
+    double *__restrict__ out = p.member_out + ((size_t)blockIdx.y * p.E_members + member) * ((size_t)K * N + 1);
 
     // ------------------------------------------------------------ forward sweep
     {
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
             L = Y;
         }
         if (KEEPL)
-            tstore(p.costates + ((size_t)k * N + t) * TSZ, L, lane);
+            tstore(p.costates + (kw * N + t) * TSZ, L, lane);
         // R = X L' : A layout of X, B layout of L' = conj(A layout of L)
         to_a_layout(XA, X, s_img, lane);
         to_a_layout(LA, L, s_img, lane);
@@ -350,9 +351,10 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
         for (int i = threadIdx.x; i < K * TSZ; i += 128)
             s_bt[i] = opBT[i];
     }
-    const double2 *__restrict__ Pk = p.props + (size_t)k * N * TSZ;
-    double2 *__restrict__ Xk = p.states + (size_t)k * N * TSZ;
-    double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * N + 1);
+    const size_t kw = (size_t)blockIdx.y * p.E + k;                // workspace row: (control array, member)
+    const double2 *__restrict__ Pk = p.props + kw * N * TSZ;
+    double2 *__restrict__ Xk = p.states + kw * N * TSZ;
+    double *__restrict__ out = p.member_out + kw * ((size_t)K * N + 1);
 
     // ------------------------------------------------------------ pass 1
     if (half == 0) {
@@ -558,11 +560,11 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
-    const double2 *__restrict__ Pk = p.props + (size_t)k * N * TSZ;
+    const double2 *__restrict__ Pk = p.props + ((size_t)blockIdx.y * p.E + k) * N * TSZ;
     constexpr bool pack2 = PACK2;
     const int member = pack2 ? 2 * k + ((lane >> 3) & 1) : k;
     const bool writer = (pack2 ? (lane == 0 || lane == 8) : lane == 0) && member < p.E_members;
-    double *__restrict__ out = p.member_out + (size_t)member * ((size_t)K * N + 1);
+    double *__restrict__ out = p.member_out + ((size_t)blockIdx.y * p.E_members + member) * ((size_t)K * N + 1);
 
     TMat<NT> M, L, Y, Pm, Pn;
     double zr = 0.0, zi = 0.0;
@@ -714,7 +716,7 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         q.stage_ops = (NT == 1 && img_bytes + ops_bytes <= 64 * 1024) ? 1 : 0;
         const int per_block = q.stage_ops ? kPropSlices : 4;
         const size_t lds = img_bytes + (q.stage_ops ? ops_bytes : 0);
-        hipLaunchKernelGGL(prop_tile_kernel<NT>, dim3((p.N + per_block - 1) / per_block, p.E), dim3(256), lds,
+        hipLaunchKernelGGL(prop_tile_kernel<NT>, dim3((p.N + per_block - 1) / per_block, p.E, p.n_x), dim3(256), lds,
                            stream, q);
     }
     hipError_t e = hipGetLastError();
@@ -724,7 +726,7 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     const size_t bt_bytes = sizeof(double2) * (size_t)p.K * NT * NT * 256;
     q.bt_in_lds = bt_bytes <= 36 * 1024 ? 1 : 0;                   // 4 waves per CU must still fit
     const size_t lds = sizeof(double2) * (kTileImage + 1) + (q.bt_in_lds ? bt_bytes : 0);
-    const dim3 grid(p.E), block(64);
+    const dim3 grid(p.E, p.n_x), block(64);                        // y: control array of a batched evaluation
     const bool pk = (NT == 1) && p.pack2;
     if (tile_chain_is_split(p, keepl)) {
         // one member per wave would leave every SIMD with a single wave: two waves per member, each owning a

@@ -121,8 +121,6 @@ def test_argument_validation(qoc):
     assert lib.grape_create(C.byref(cfg), C.byref(h)) == -1                        # n_devices > 8
     cfg = qoc.engine.GrapeConfig(0, 0, 16, 2, 10, 1, 1.0, -1, 4, 0, 0, -1, 0)
     assert lib.grape_create(C.byref(cfg), C.byref(h)) == -2                        # phase stamps: n <= 4 only
-    cfg = qoc.engine.GrapeConfig(0, 0, 16, 2, 10, 1, 1.0, -1, 0, 0, 0, -1, 4)
-    assert lib.grape_create(C.byref(cfg), C.byref(h)) == -2                        # batching: n <= 4 only
     assert lib.grape_destroy(None) == 0
     assert lib.grape_eval(None, None, None, None) == -1
     assert lib.grape_comm_unique_id(None) == -1

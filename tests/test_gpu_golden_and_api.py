@@ -195,7 +195,8 @@ def test_full_size_properties(qoc, oracle):
     assert abs(Fw - foms @ w2.wts) <= 1e-12 and np.abs(Gw - np.tensordot(w2.wts, grads, 1)).max() <= 1e-14
 
 
-@pytest.mark.parametrize("name,wkw,n_x", [("C2", {"N": 200}, 7), ("C3", {"E": 5, "N": 60}, 4), ("C3", {"E": 40, "N": 130}, 3)])
+@pytest.mark.parametrize("name,wkw,n_x", [("C2", {"N": 200}, 7), ("C3", {"E": 5, "N": 60}, 4), ("C3", {"E": 40, "N": 130}, 3),
+                                          ("C4", {"E": 3, "N": 30}, 3), ("C5", {"E": 2, "N": 12}, 2)])
 @pytest.mark.parametrize("flow", ["auto", "general"])
 def test_batched_evaluation(qoc, oracle, name, wkw, n_x, flow):
     """grape_eval_batch (SURVEY.md 8f-2): n_x control arrays against one ensemble in a single launch;
