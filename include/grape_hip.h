@@ -118,7 +118,16 @@ typedef struct grape_config {
                                   evaluation ends in ONE RCCL all-reduce of the K*N+1 doubles [G, F]
                                   (src/solve.jl:171-186, :191) */
     int32_t device_ids[GRAPE_MAX_DEVICES];   /* HIP ordinals, used when n_devices >= 2 */
+    int32_t gradient;          /* grape_gradient: 0 = the reference's first-order grad_func! (src/GRAPE.jl:261-303),
+                                  1 = exact derivative of the objective (what ADGRAPE gets from Zygote,
+                                  src/GRAPE.jl:12-20; cf. expm_exact_gradient, src/grape_tools.jl:26-57); n <= 4 */
+    int32_t objective;         /* grape_objective: 0 = fom_func (src/cost_functions.jl:99-111),
+                                  1 = the ADGRAPE functional C1(Xt, U Xi [U']) for every system type
+                                  (src/solve.jl:268-291, :317-361); needs gradient = 1 */
 } grape_config;
+
+typedef enum grape_gradient { GRAPE_GRADIENT_REFERENCE = 0, GRAPE_GRADIENT_EXACT = 1 } grape_gradient;
+typedef enum grape_objective { GRAPE_OBJECTIVE_FOM = 0, GRAPE_OBJECTIVE_C1 = 1 } grape_objective;
 
 typedef struct grape_info {
     int32_t abi_version;

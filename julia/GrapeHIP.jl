@@ -44,6 +44,8 @@ struct GrapeConfig
     n_state_cols::Int32              # ABI v2: 0 = square states
     n_devices::Int32                 # ABI v2: 0/1 = one GPU; 2..8 = in-library sharding + RCCL all-reduce
     device_ids::NTuple{8,Int32}
+    gradient::Int32                  # 0 = reference first-order gradient, 1 = exact (n <= 4)
+    objective::Int32                 # 0 = fom_func, 1 = C1 functional of the ADGRAPE path
 end
 
 sys_code(::UnitaryGate) = Int32(0)
@@ -70,7 +72,7 @@ mutable struct GrapeContext
         nd = length(alg.devices)
         ids = ntuple(i -> i <= nd ? Int32(alg.devices[i]) : Int32(0), 8)
         cfg = GrapeConfig(sys_code(p1.sys_type), alg.isinplace ? 0 : 1, n, K, N, E, Float64(p1.T),
-                          nd == 1 ? alg.devices[1] : alg.device, 0, 0, 0, -1, 0, 0, nd > 1 ? nd : 0, ids)
+                          nd == 1 ? alg.devices[1] : alg.device, 0, 0, 0, -1, 0, 0, nd > 1 ? nd : 0, ids, 0, 0)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:grape_create, libgrape), Cint, (Ref{GrapeConfig}, Ref{Ptr{Cvoid}}), cfg, h)
         rc == 0 || error("grape_create: ", unsafe_string(ccall((:grape_last_error, libgrape), Cstring, (Ptr{Cvoid},), C_NULL)))

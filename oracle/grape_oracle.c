@@ -511,6 +511,117 @@ int oracle_member_eval_rect(int variant, int n, int m, int K, int N, double T, c
     return 0;
 }
 
+/* ---------------------------------------------------------------- exact gradient / ADGRAPE functional
+ *
+ * The reference's ADGRAPE path (src/solve.jl:255-361, src/GRAPE.jl:12-20) minimises
+ *     functional(x) = sum_k w_k C1(Xt_k, U Xi_k U')  (StateTransfer, :268-278 / :317-339)
+ *                     sum_k w_k C1(Xt_k, U Xi_k)     (UnitaryGate,   :280-291 / :342-361)
+ * with U = pw_evolve(...) = prod_t exp((-i dt)(A + sum_j B_j x[j,t]))  (src/timeevolution.jl:28-39) and takes
+ * its gradient from Zygote, i.e. the EXACT derivative.  Zygote is a third-party AD package absent here; what it
+ * returns is restated as the analytic derivative
+ *     dPhi/dx[c,t] = tr(L_{t+1}' dP_t[c] X_t)                         (UnitaryGate)
+ *                  = tr(L_{t+1}' (dP_t[c] X_t P_t' + P_t X_t dP_t[c]'))   (StateTransfer)
+ * where dP_t[c] is the Frechet derivative of exp at -i dt H_t in direction -i dt B_c, taken from the
+ * block-triangular identity  exp([[G, E], [0, G]]) = [[e^G, dexp_G(E)], [0, e^G]]  (Higham, Functions of
+ * Matrices, thm 4.12) with the SAME Pade expm as everywhere else in this file -- a different algorithm from the
+ * device's differentiated Taylor polynomial.  objective 0: the GRAPE figure of merit (fom_func) with its exact
+ * gradient; objective 1: the C1 functional above for every system type.  tests/ pin this against central
+ * finite differences of the objective and against 50-digit mpmath fixtures. */
+int oracle_member_exact(int objective, int sys_type, int variant, int n, int K, int N, double T, const cplx *A,
+                        const cplx *B, const cplx *Xi, const cplx *Xt, const double *x, double *fom, double *grad)
+{
+    const size_t nn = (size_t)n * n, n2 = (size_t)2 * n, nn4 = n2 * n2;
+    const int sandwich = (sys_type != ORACLE_UG);
+    cplx *w = (cplx *)malloc(sizeof(cplx) * (nn * N + 2 * nn * (N + 1) + 8 * nn + 2 * nn4));
+    if (!w) return -2;
+    cplx *props = w, *states = props + nn * N, *costates = states + nn * (N + 1);
+    cplx *G = costates + nn * (N + 1), *t1 = G + nn, *t2 = t1 + nn, *dP = t2 + nn, *W1 = dP + nn, *W2 = W1 + nn,
+         *Y = W2 + nn, *Y2 = Y + nn, *big = Y2 + nn, *bigout = big + nn4;
+    const double dt = T / N;
+    const cplx mi_dt = CMPLX(-0.0, -1.0) * dt;
+    int rc = 0;
+    memcpy(states, Xi, sizeof(cplx) * nn);
+    memcpy(costates + nn * N, Xt, sizeof(cplx) * nn);
+    for (int i = 0; i < N && rc == 0; ++i) {
+        if (variant == 0) {
+            for (size_t e = 0; e < nn; ++e) G[e] = 0.0;
+            for (int j = 0; j < K; ++j)
+                for (size_t e = 0; e < nn; ++e) G[e] = G[e] + B[e + nn * j] * x[j + (size_t)i * K];
+            for (size_t e = 0; e < nn; ++e) t1[e] = mi_dt * (G[e] + A[e]);
+        } else {
+            for (size_t e = 0; e < nn; ++e) G[e] = A[e];
+            for (int j = 0; j < K; ++j)
+                for (size_t e = 0; e < nn; ++e) G[e] = G[e] + B[e + nn * j] * x[j + (size_t)i * K];
+            for (size_t e = 0; e < nn; ++e) t1[e] = mi_dt * G[e];
+        }
+        rc = oracle_expm(n, t1, props + nn * i);
+    }
+    for (int t = 0; t < N && rc == 0; ++t) {
+        const cplx *P = props + nn * t;
+        if (!sandwich) mm(n, P, states + nn * t, states + nn * (t + 1));
+        else { mm_a_bh(n, states + nn * t, P, t1); mm(n, P, t1, states + nn * (t + 1)); }
+    }
+    for (int t = N - 1; t >= 0 && rc == 0; --t) {
+        const cplx *P = props + nn * t;
+        if (!sandwich) mm_ah_b(n, P, costates + nn * (t + 1), costates + nn * t);
+        else { mm(n, costates + nn * (t + 1), P, t1); mm_ah_b(n, P, t1, costates + nn * t); }
+    }
+    if (rc) { free(w); return rc; }
+    /* Phi = tr(Xt' X_N) */
+    cplx Phi = 0.0;
+    for (size_t e = 0; e < nn; ++e) Phi += conj(Xt[e]) * states[nn * N + e];
+    const int c1_obj = sandwich || objective == 1;
+    const double D2 = 1.0 / ((double)n * (double)n);
+    *fom = c1_obj ? 1.0 - D2 * (creal(Phi) * creal(Phi) + cimag(Phi) * cimag(Phi)) : creal(conj(Phi) * conj(Phi));
+    for (int t = 0; t < N && rc == 0; ++t) {
+        const cplx *P = props + nn * t, *X = states + nn * t, *Ln = costates + nn * (t + 1);
+        /* the generator of this slice again (same summation order as above) */
+        if (variant == 0) {
+            for (size_t e = 0; e < nn; ++e) G[e] = 0.0;
+            for (int j = 0; j < K; ++j)
+                for (size_t e = 0; e < nn; ++e) G[e] = G[e] + B[e + nn * j] * x[j + (size_t)t * K];
+            for (size_t e = 0; e < nn; ++e) G[e] = mi_dt * (G[e] + A[e]);
+        } else {
+            for (size_t e = 0; e < nn; ++e) G[e] = A[e];
+            for (int j = 0; j < K; ++j)
+                for (size_t e = 0; e < nn; ++e) G[e] = G[e] + B[e + nn * j] * x[j + (size_t)t * K];
+            for (size_t e = 0; e < nn; ++e) G[e] = mi_dt * G[e];
+        }
+        if (sandwich) {
+            mm_a_bh(n, X, P, Y);            /* X P'          */
+            mm_a_bh(n, Y, Ln, W1);          /* X P' L'       */
+            mm_ah_b(n, P, Ln, Y2);          /* P' L          */
+            mm_ah_b(n, X, Y2, W2);          /* X' P' L       */
+        } else {
+            mm_a_bh(n, X, Ln, W1);          /* X L'          */
+        }
+        for (int c = 0; c < K && rc == 0; ++c) {
+            for (size_t e = 0; e < nn4; ++e) big[e] = 0.0;
+            for (int j = 0; j < n; ++j)
+                for (int i = 0; i < n; ++i) {
+                    big[i + j * n2] = G[i + j * n];
+                    big[(i + n) + (j + n) * n2] = G[i + j * n];
+                    big[i + (j + n) * n2] = mi_dt * B[nn * c + i + j * n];
+                }
+            rc = oracle_expm(2 * n, big, bigout);
+            for (int j = 0; j < n; ++j)
+                for (int i = 0; i < n; ++i) dP[i + j * n] = bigout[i + (j + n) * n2];
+            cplx dPhi = 0.0;                 /* tr(dP W1) */
+            for (int j = 0; j < n; ++j)
+                for (int i = 0; i < n; ++i) dPhi += dP[i + j * n] * W1[j + i * n];
+            if (sandwich) {
+                cplx b = 0.0;
+                for (int j = 0; j < n; ++j)
+                    for (int i = 0; i < n; ++i) b += dP[i + j * n] * W2[j + i * n];
+                dPhi += conj(b);
+            }
+            grad[c + (size_t)t * K] = c1_obj ? -2.0 * D2 * creal(conj(Phi) * dPhi) : 2.0 * creal(Phi * dPhi);
+        }
+    }
+    free(w);
+    return rc;
+}
+
 /* C1(KT, KN) = 1 - |tr(KT' KN)/D|^2   -- src/cost_functions.jl:13-17 */
 double oracle_C1(int n, const cplx *KT, const cplx *KN)
 {

@@ -47,6 +47,8 @@ def lib():
         L.oracle_ensemble_eval.restype = C.c_int
         L.oracle_member_eval_rect.argtypes = [C.c_int] * 5 + [C.c_double] + [vp] * 4 + [vp, dp, vp, vp, vp, vp]
         L.oracle_member_eval_rect.restype = C.c_int
+        L.oracle_member_exact.argtypes = [C.c_int] * 6 + [C.c_double] + [vp] * 4 + [vp, dp, vp]
+        L.oracle_member_exact.restype = C.c_int
         L.oracle_C1.argtypes = [C.c_int, vp, vp]
         L.oracle_C1.restype = C.c_double
         _LIB = L
@@ -115,6 +117,37 @@ def member_eval(sys_type, A, B, Xi, Xt, x, T, variant=0, trajectory=False):
         sw = lambda a: np.ascontiguousarray(np.swapaxes(a, -1, -2))
         return fom.value, G, sw(props), sw(sts), sw(cos)
     return fom.value, G
+
+
+def member_exact(sys_type, A, B, Xi, Xt, x, T, variant=0, objective=0):
+    """Exact gradient of objective 0 (GRAPE fom_func) or 1 (the ADGRAPE C1 functional): (F, G[K,N])."""
+    st = SYS_TYPES[sys_type] if isinstance(sys_type, str) else int(sys_type)
+    A, B, Xi, Xt = pack_cm(A), pack_cm(B), pack_cm(Xi), pack_cm(Xt)
+    n, K = A.shape[0], B.shape[0]
+    x = np.asarray(x, dtype=np.float64)
+    N = x.shape[1]
+    xf = np.ascontiguousarray(x.T)
+    grad = np.empty((N, K))
+    fom = C.c_double()
+    rc = lib().oracle_member_exact(int(objective), st, int(variant), n, K, N, float(T), _p(A), _p(B), _p(Xi), _p(Xt),
+                                   _p(xf), C.byref(fom), _p(grad))
+    if rc:
+        raise RuntimeError(f"oracle_member_exact failed rc={rc}")
+    return fom.value, np.ascontiguousarray(grad.T)
+
+
+def ensemble_exact(sys_type, A, B, Xi, Xt, wts, x, T, variant=0, objective=0, per_member=False):
+    """sum_k w_k (F_k, g_k) of member_exact, k ascending (the ADGRAPE ensemble functionals, src/solve.jl:317-361)."""
+    res = [member_exact(sys_type, A[k], B[k], Xi[k], Xt[k], x, T, variant, objective) for k in range(len(A))]
+    foms = np.array([r[0] for r in res])
+    grads = np.array([r[1] for r in res])
+    wts = np.asarray(wts, dtype=np.float64)
+    F = 0.0
+    G = np.zeros_like(grads[0])
+    for k in range(len(A)):
+        F += foms[k] * wts[k]
+        G += grads[k] * wts[k]
+    return (F, G, foms, grads) if per_member else (F, G)
 
 
 def member_eval_rect(A, B, Xi, Xt, x, T, variant=0, trajectory=False, st=0):

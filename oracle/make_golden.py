@@ -99,6 +99,72 @@ def member(sys_type, variant, A, B, Xi, Xt, x, T):
     return F, g, P, X, L
 
 
+def member_exact(sys_type, variant, objective, A, B, Xi, Xt, x, T):
+    """Exact gradient at 50 digits (the ADGRAPE functional path): dP from the block-triangular exponential
+    exp([[G, E], [0, G]]) = [[e^G, dexp_G(E)], [0, e^G]]."""
+    K, N = x.shape
+    dt = mpf(T) / N
+    A, Xi, Xt = to_mp(A), to_mp(Xi), to_mp(Xt)
+    B = [to_mp(b) for b in B]
+    n = A.rows
+    sand = sys_type != "UnitaryGate"
+    Gs, P = [], []
+    for i in range(N):
+        H = zeros(n) if variant == 0 else A.copy()
+        for j in range(K):
+            H = H + B[j] * mpf(float(x[j, i]))
+        if variant == 0:
+            H = H + A
+        Gs.append(H * mpc(0, -1) * dt)
+        P.append(expm_mp(Gs[-1]))
+    X = [None] * (N + 1)
+    L = [None] * (N + 1)
+    X[0], L[N] = Xi, Xt
+    for t in range(N):
+        X[t + 1] = P[t] * X[t] * P[t].H if sand else P[t] * X[t]
+    for t in range(N - 1, -1, -1):
+        L[t] = P[t].H * L[t + 1] * P[t] if sand else P[t].H * L[t + 1]
+    Phi = tr(Xt.H * X[N])
+    c1 = sand or objective == 1
+    F = 1 - (Phi.real ** 2 + Phi.imag ** 2) / (n * n) if c1 else (Phi.conjugate() ** 2).real
+    g = [[None] * N for _ in range(K)]
+    for t in range(N):
+        for c in range(K):
+            big = zeros(2 * n)
+            E = B[c] * mpc(0, -1) * dt
+            for i in range(n):
+                for j in range(n):
+                    big[i, j] = Gs[t][i, j]
+                    big[i + n, j + n] = Gs[t][i, j]
+                    big[i, j + n] = E[i, j]
+            ex = expm_mp(big)
+            dP = matrix([[ex[i, j + n] for j in range(n)] for i in range(n)])
+            if sand:
+                dPhi = tr(L[t + 1].H * (dP * X[t] * P[t].H + P[t] * X[t] * dP.H))
+            else:
+                dPhi = tr(L[t + 1].H * dP * X[t])
+            g[c][t] = (-2 * (Phi.conjugate() * dPhi).real / (n * n)) if c1 else (2 * (Phi * dPhi).real)
+    return F, g
+
+
+def make_exact_case(name, w, variant):
+    out = {"name": name, "sys_type": w.sys_type, "variant": variant, "n": w.n, "m": w.n, "K": w.K, "N": w.N, "E": w.E,
+           "T": w.T, "digits": mp.dps, "layout": "matrices column-major [re, im]; x, G, g as [c][t]",
+           "inputs": {"A": [np_cm(a) for a in w.A], "B": [[np_cm(b) for b in bk] for bk in w.B],
+                      "Xi": [np_cm(a) for a in w.Xi], "Xt": [np_cm(a) for a in w.Xt],
+                      "wts": [float(v) for v in w.wts], "x": [[float(v) for v in row] for row in w.x]},
+           "exact": {}}
+    for objective in (0, 1):
+        res = [member_exact(w.sys_type, variant, objective, w.A[k], w.B[k], w.Xi[k], w.Xt[k], w.x, w.T) for k in range(w.E)]
+        Ftot = sum(res[k][0] * mpf(float(w.wts[k])) for k in range(w.E))
+        Gtot = [[sum(res[k][1][c][t] * mpf(float(w.wts[k])) for k in range(w.E)) for t in range(w.N)] for c in range(w.K)]
+        out["exact"][f"objective{objective}"] = {
+            "F": float(Ftot), "G": [[float(v) for v in row] for row in Gtot],
+            "member_F": [float(r[0]) for r in res],
+            "member_g": [[[float(v) for v in row] for row in r[1]] for r in res]}
+    return out
+
+
 def cm_list(M):
     """mp matrix -> [[re, im], ...] column-major float64"""
     return [[float(M[i, j].real), float(M[i, j].imag)] for j in range(M.cols) for i in range(M.rows)]
@@ -154,6 +220,17 @@ def main(only=None):
         ("st_8x8_pairs", "rand8"),                    # tile kernels, two members per 16x16 tile
         ("ct_16x16_nonherm", "rand16"),               # tile kernels, non-Hermitian generator
     ]
+    exact_cases = [("exact_ug_4x4", wl.config("C3", E=2, N=6), 1), ("exact_st_2x2", wl.reference_ensemble("StateTransfer", 3, 7, 5.0), 1),
+                   ("exact_ug_2x2", wl.reference_ensemble("UnitaryGate", 2, 6, 5.0), 0)]
+    for name, w, variant in exact_cases:
+        if only and name not in only:
+            continue
+        case = make_exact_case(name, w, variant)
+        path = os.path.join(out, "exact", f"{name}.json")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(case, fh)
+        print(path, os.path.getsize(path), "bytes  F0 =", case["exact"]["objective0"]["F"], " F1 =", case["exact"]["objective1"]["F"])
     for name, w in cases:
         if only and name not in only:
             continue

@@ -10,12 +10,12 @@ root-level shim:  `import quoptimalcontrol_jl_amd as qoc`.
 from . import workloads  # noqa: F401
 from .engine import GrapeEngine, GrapeError, library_path, load_library  # noqa: F401
 from .api import (  # noqa: F401
-    GRAPE, CoherenceTransfer, EnsembleProblem, EnsembleSolutionResult, Problem, SolutionResult,
+    ADGRAPE, GRAPE, CoherenceTransfer, EnsembleProblem, EnsembleSolutionResult, Problem, SolutionResult,
     StateTransfer, UnitaryGate, C1, init_ensemble, solve, fom_and_gradient, pulse_to_file, pulse_from_file,
 )
 
 __all__ = [
-    "workloads", "GrapeEngine", "GrapeError", "library_path", "load_library", "GRAPE",
+    "workloads", "GrapeEngine", "GrapeError", "library_path", "load_library", "GRAPE", "ADGRAPE",
     "CoherenceTransfer", "EnsembleProblem", "EnsembleSolutionResult", "Problem", "SolutionResult",
     "StateTransfer", "UnitaryGate", "C1", "init_ensemble", "solve", "fom_and_gradient", "pulse_to_file", "pulse_from_file",
 ]

@@ -85,6 +85,18 @@ class GRAPE:
 
 
 @dataclass
+class ADGRAPE:
+    """src/solve.jl:44-52: the functional path.  The reference differentiates
+    functional(x) = sum_k w_k C1(Xt_k, U Xi_k [U']) (src/solve.jl:268-361, U = pw_evolve) with Zygote; here the same
+    functional and its exact gradient come from the device (objective "c1", gradient "exact")."""
+    n_slices: int
+    expm_method: str = "fast"
+    optim_options: dict = field(default_factory=dict)
+    device: int = -1
+    optimizer: str = "host"
+
+
+@dataclass
 class SolutionResult:
     result: Any
     fidelity: float
@@ -140,6 +152,9 @@ def make_engine(prob, alg, **engine_kw):
     if len(first.B) != first.n_controls:
         raise ValueError("n_controls does not match the number of control operators")
     A, B, Xi, Xt = _pack(members)
+    if isinstance(alg, ADGRAPE):            # pw_evolve adds A first (src/timeevolution.jl:32-35): the static summation order
+        return GrapeEngine(first.sys_type.name, A, B, Xi, Xt, wts, first.T, alg.n_slices, variant=1, device=alg.device,
+                           gradient="exact", objective="c1", **engine_kw)
     return GrapeEngine(first.sys_type.name, A, B, Xi, Xt, wts, first.T, alg.n_slices,
                        variant=0 if alg.isinplace else 1, device=alg.device, **engine_kw)
 
@@ -214,7 +229,7 @@ def solve(prob, alg: Optional[GRAPE] = None, engine=None):
                         "(src/solve.jl:57,66); pass GRAPE(n_slices=...)")
     own = engine is None
     device_opt = getattr(alg, "optimizer", "host") == "device"
-    eng = engine or make_engine(prob, alg, **({"max_batch": 4} if device_opt else {}))
+    eng = engine or make_engine(prob, alg, **({"max_batch": 4} if device_opt and not isinstance(alg, ADGRAPE) else {}))
     try:
         guess = np.asarray((prob.prob if isinstance(prob, EnsembleProblem) else prob).guess, float)
         if device_opt:

@@ -1,0 +1,239 @@
+// exact_grad.hip -- exact control gradient for small operators (n <= 4): the functional path of the reference.
+//
+// The reference's GRAPE gradient (grad_func!, src/GRAPE.jl:261-287) is first order in dt.  Its ADGRAPE path
+// (src/solve.jl:268-361 with pw_evolve, src/timeevolution.jl:28-39) differentiates the functional
+//     F(x) = sum_k w_k C1(Xt_k, U_k Xi_k [U_k'])         U_k = prod_t exp(-i dt H_t)
+// exactly with Zygote, and src/grape_tools.jl:26-57 (eig_factors / expm_exact_gradient, unused) sketches the
+// exact derivative of the propagator.  This kernel gives that exact gradient without an AD tape:
+//     dPhi/dx[c,t] = tr( L_{t+1}' dP_t[c] X_t )                                  (UnitaryGate)
+//                  = tr( L_{t+1}' (dP_t[c] X_t P_t' + P_t X_t dP_t[c]') )        (State/CoherenceTransfer)
+// with X_t the state before slice t, L_{t+1} the costate after it (both left in HBM by the sweep's debug flow,
+// GRAPE_FLAG_KEEP_COSTATES), and dP_t[c] the Frechet derivative of exp at G_t = -i dt H_t in direction
+// B'_c = -i dt B_c, obtained by differentiating the sweep's own Taylor-8 + scaling/squaring evaluation
+// (cmat.hpp: expm_t8) operation by operation -- exact to the rounding of P_t itself.
+//     C1-type objectives (1 - |Phi/D|^2):   dF = -(2/D^2) Re( conj(Phi) dPhi )
+//     GRAPE UnitaryGate objective Re(z^2), z = conj(Phi):   dF = 2 Re( z conj(dPhi) )
+// One lane per (member, slice); a wave covers 64 slices of one member, so the member's operators are wave
+// uniform.  The register footprint (a dozen 4 x 4 complex matrices) spills to scratch: this is the optional
+// accuracy path, not the throughput path.
+#include "cmat.hpp"
+#include "grape_kernels.hpp"
+
+namespace grape {
+
+template <int N>
+GRAPE_DEV void lin2(CMat<N> &o, double a, const CMat<N> &x, double b, const CMat<N> &y)
+{
+#pragma unroll
+    for (int e = 0; e < N * N; ++e) {
+        o.re[e] = fma(a, x.re[e], b * y.re[e]);
+        o.im[e] = fma(a, x.im[e], b * y.im[e]);
+    }
+}
+
+template <int N>
+GRAPE_DEV void acc(CMat<N> &o, double a, const CMat<N> &x)
+{
+#pragma unroll
+    for (int e = 0; e < N * N; ++e) {
+        o.re[e] = fma(a, x.re[e], o.re[e]);
+        o.im[e] = fma(a, x.im[e], o.im[e]);
+    }
+}
+
+// o += a * b
+template <int N>
+GRAPE_DEV void mul_acc(CMat<N> &o, const CMat<N> &a, const CMat<N> &b)
+{
+    CMat<N> t;
+    mul(t, a, b);
+    acc(o, 1.0, t);
+}
+
+// tr(A * B) = sum_ij A[i,j] B[j,i]
+template <int N>
+GRAPE_DEV void trace_ab(double &zr, double &zi, const CMat<N> &a, const CMat<N> &b)
+{
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double ar = a.re[i + j * N], ai = a.im[i + j * N];
+            const double br = b.re[j + i * N], bi = b.im[j + i * N];
+            sr = fma(ar, br, sr); sr = fma(-ai, bi, sr);
+            si = fma(ar, bi, si); si = fma(ai, br, si);
+        }
+    zr = sr;
+    zi = si;
+}
+
+template <int N, int SAND>
+__global__ __launch_bounds__(64) void exact_grad_kernel(const double2 *__restrict__ ops_all, const double *__restrict__ x_all,
+                                                        const ExactParams p)
+{
+    constexpr int NN = N * N;
+    const int k = blockIdx.y;
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int K = p.K, Nsl = p.N;
+    const bool live = t < Nsl;
+    const int tt = live ? t : Nsl - 1;                   // surplus lanes repeat the last slice (never stored)
+    const double2 *__restrict__ ops = ops_all + (size_t)k * (K + 3) * NN;
+    const double2 *__restrict__ opB = ops + NN;
+    const double2 *__restrict__ opXt = ops + (size_t)(2 + K) * NN;
+    auto ws_load = [&](CMat<N> &m, const double2 *__restrict__ ws, int slice) {
+        const int L = slice / p.S, j = slice - L * p.S;
+        const double2 *__restrict__ base = ws + ((size_t)k * p.S + j) * NN * p.CH + L;
+#pragma unroll
+        for (int e = 0; e < NN; ++e) {
+            const double2 v = base[(size_t)e * p.CH];
+            m.re[e] = v.x;
+            m.im[e] = v.y;
+        }
+    };
+    CMat<N> P, X, Ln;
+    ws_load(P, p.props, tt);
+    ws_load(X, p.states, tt);
+    if (tt + 1 < Nsl) {
+        ws_load(Ln, p.costates, tt + 1);                 // costate after slice t
+    } else {
+#pragma unroll
+        for (int e = 0; e < NN; ++e) {
+            const double2 v = opXt[e];
+            Ln.re[e] = v.x;
+            Ln.im[e] = v.y;
+        }
+    }
+    // W: dPhi = tr(dP W1) [+ conj(tr(dP W2))] ;  Phi = tr(L_{t+1}' X_{t+1})
+    CMat<N> W1, W2, tmp;
+    double phr, phi;
+    if (SAND) {
+        CMat<N> Y;
+        mul_a_bh(Y, X, P);                               // X P'
+        mul_a_bh(W1, Y, Ln);                             // X P' L'
+        mul(tmp, P, Y);                                  // X_{t+1} = P X P'
+        trace_ah_b(phr, phi, Ln, tmp);
+        mul_ah_b(Y, P, Ln);                              // P' L
+        mul_ah_b(W2, X, Y);                              // X' P' L
+    } else {
+        mul_a_bh(W1, X, Ln);                             // X L'
+        mul(tmp, P, X);                                  // X_{t+1} = P X
+        trace_ah_b(phr, phi, Ln, tmp);
+    }
+    // generator of this slice and the shared part of the Taylor-8 evaluation
+    CMat<N> G;
+    if (p.variant == 0) {
+#pragma unroll
+        for (int e = 0; e < NN; ++e) { G.re[e] = 0.0; G.im[e] = 0.0; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < NN; ++e) { const double2 a = ops[e]; G.re[e] = a.x; G.im[e] = a.y; }
+    }
+    for (int c = 0; c < K; ++c) {
+        const double xv = x_all[c + (size_t)tt * K];
+#pragma unroll
+        for (int e = 0; e < NN; ++e) {
+            const double2 b = opB[c * NN + e];
+            G.re[e] = fma(b.x, xv, G.re[e]);
+            G.im[e] = fma(b.y, xv, G.im[e]);
+        }
+    }
+    if (p.variant == 0) {
+#pragma unroll
+        for (int e = 0; e < NN; ++e) { const double2 a = ops[e]; G.re[e] += a.x; G.im[e] += a.y; }
+    }
+    const int s = p.s_forced >= 0 ? p.s_forced : squarings_for(norm1_bound(G));
+    const double sc = s > 0 ? ldexp(1.0, -s) : 1.0;
+#pragma unroll
+    for (int e = 0; e < NN; ++e) { G.re[e] *= sc; G.im[e] *= sc; }
+    CMat<N> A2, T1, A4, U, T2;
+    mul(A2, G, G);
+    lin2(T1, kX1, G, kX2, A2);
+    mul(A4, A2, T1);
+    lin2(U, kX3, A2, 1.0, A4);
+    lin2(T2, kX5, G, kX6, A2);
+    acc(T2, kX7, A4);
+#pragma unroll
+    for (int i = 0; i < N; ++i) T2.re[i + i * N] += kX4;
+    // value at the scaled point (needed by the squaring chain rule): Ps = U T2 + G + y2 A2 + I
+    CMat<N> Ps;
+    mul(Ps, U, T2);
+    acc(Ps, 1.0, G);
+    acc(Ps, kY2, A2);
+#pragma unroll
+    for (int i = 0; i < N; ++i) Ps.re[i + i * N] += 1.0;
+
+    double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * Nsl + 1);
+    const double D2 = 1.0 / ((double)N * (double)N);
+    for (int c = 0; c < K; ++c) {
+        CMat<N> E;                                       // direction: B'_c, scaled like G
+#pragma unroll
+        for (int e = 0; e < NN; ++e) { const double2 b = opB[c * NN + e]; E.re[e] = sc * b.x; E.im[e] = sc * b.y; }
+        CMat<N> dA2, dT1, dA4, dU, dT2, dP;
+        mul(dA2, E, G);
+        mul_acc(dA2, G, E);
+        lin2(dT1, kX1, E, kX2, dA2);
+        mul(dA4, dA2, T1);
+        mul_acc(dA4, A2, dT1);
+        lin2(dU, kX3, dA2, 1.0, dA4);
+        lin2(dT2, kX5, E, kX6, dA2);
+        acc(dT2, kX7, dA4);
+        mul(dP, dU, T2);
+        mul_acc(dP, U, dT2);
+        acc(dP, 1.0, E);
+        acc(dP, kY2, dA2);
+        CMat<N> Pq = Ps;                                 // undo the scaling: P <- P^2, dP <- dP P + P dP
+        for (int i = 0; i < s; ++i) {
+            mul(tmp, dP, Pq);
+            mul_acc(tmp, Pq, dP);
+            dP = tmp;
+            mul(tmp, Pq, Pq);
+            Pq = tmp;
+        }
+        double ar, ai, dr, di;
+        trace_ab(ar, ai, dP, W1);                        // tr(L' dP X [P'])
+        dr = ar;
+        di = ai;
+        if (SAND) {
+            trace_ab(ar, ai, dP, W2);                    // + conj(tr(dP X' P' L))
+            dr += ar;
+            di -= ai;
+        }
+        double g;
+        if (SAND || p.objective == 1)
+            g = -2.0 * D2 * (phr * dr + phi * di);       // -(2/D^2) Re(conj(Phi) dPhi)
+        else
+            g = 2.0 * (phr * dr - phi * di);             // F = Re(z^2), z = conj(Phi): dF = 2 Re(z dz) = 2 Re(Phi dPhi)
+        if (live)
+            out[c + (size_t)t * K] = g;
+    }
+    if (live && t == Nsl - 1) {
+        double F;
+        if (SAND || p.objective == 1)
+            F = 1.0 - D2 * (phr * phr + phi * phi);      // C1, src/cost_functions.jl:13-17
+        else
+            F = phr * phr - phi * phi;                   // Re(z^2), z = conj(Phi): src/cost_functions.jl:99-101
+        out[(size_t)K * Nsl] = F;
+    }
+}
+
+template <int N>
+static hipError_t launch_exact_n(int sandwich, const ExactParams &p, hipStream_t stream)
+{
+    const dim3 grid((p.N + 63) / 64, p.E), block(64);
+    if (sandwich) hipLaunchKernelGGL((exact_grad_kernel<N, 1>), grid, block, 0, stream, p.ops, p.x, p);
+    else          hipLaunchKernelGGL((exact_grad_kernel<N, 0>), grid, block, 0, stream, p.ops, p.x, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_exact_grad(int n, int sandwich, const ExactParams &p, hipStream_t stream)
+{
+    switch (n) {
+    case 2: return launch_exact_n<2>(sandwich, p, stream);
+    case 3: return launch_exact_n<3>(sandwich, p, stream);
+    case 4: return launch_exact_n<4>(sandwich, p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace grape

@@ -245,6 +245,15 @@ static int validate_config(const grape_config *cfg)
     if (m != cfg->n && cfg->sys_type != GRAPE_UNITARY_GATE)
         return fail(nullptr, GRAPE_ERR_INVALID_ARG,
                     "grape_create: n x m states with m < n need UnitaryGate (the sandwich X P' is not defined)");
+    if (cfg->gradient < 0 || cfg->gradient > 1 || cfg->objective < 0 || cfg->objective > 1)
+        return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: bad gradient / objective");
+    if (cfg->objective == GRAPE_OBJECTIVE_C1 && cfg->gradient != GRAPE_GRADIENT_EXACT)
+        return fail(nullptr, GRAPE_ERR_INVALID_ARG,
+                    "grape_create: the C1 functional (ADGRAPE path) comes with the exact gradient: set gradient = 1");
+    if (cfg->gradient == GRAPE_GRADIENT_EXACT && wmax == 0)
+        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: the exact gradient exists for n <= 4 in this build");
+    if (cfg->gradient == GRAPE_GRADIENT_EXACT && cfg->max_batch > 1)
+        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: exact gradient and max_batch > 1 do not combine in this build");
     if ((cfg->flags & GRAPE_FLAG_PHASE_STAMPS) && wmax == 0)
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: GRAPE_FLAG_PHASE_STAMPS exists for n <= 4 only (the tile kernels write no stamps)");
     return GRAPE_OK;
@@ -341,7 +350,8 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     const size_t Q = KN(c) + 1;
     c->ws_elems = c->family == 0 ? (size_t)E * S * nn * c->CH : (size_t)c->EU * N * c->TSZ;
     const size_t ops_elems = c->family == 0 ? (size_t)E * (K + 3) * nn : (size_t)c->EU * (2 * K + 3) * c->TSZ;
-    const bool keepl = (cfg->flags & GRAPE_FLAG_KEEP_COSTATES) != 0;
+    const bool exact = cfg->gradient == GRAPE_GRADIENT_EXACT;  // needs every X_t and L_t in HBM: the debug flow
+    const bool keepl = (cfg->flags & GRAPE_FLAG_KEEP_COSTATES) != 0 || exact;
 
     auto alloc = [&](void **p, size_t bytes) -> hipError_t {
         c->bytes += bytes;
@@ -355,7 +365,7 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     if (e == hipSuccess) e = alloc((void **)&c->d_fg, sizeof(double) * Q * Bn);
     if (e == hipSuccess) e = alloc((void **)&c->d_props, sizeof(double2) * c->ws_elems * Bn);
     if (e == hipSuccess && keepl) e = alloc((void **)&c->d_costates, sizeof(double2) * c->ws_elems * Bn);
-    const bool want_rows = c->family == 1 || (cfg->flags & GRAPE_FLAG_MEMBER_RESULTS);
+    const bool want_rows = c->family == 1 || (cfg->flags & GRAPE_FLAG_MEMBER_RESULTS) || exact;
     if (e == hipSuccess && want_rows) e = alloc((void **)&c->d_member_out, sizeof(double) * E * Q * Bn);
     if (e == hipSuccess) e = alloc((void **)&c->d_partial, sizeof(double) * c->ksplit * Q);
     if (e == hipSuccess && c->family == 0) e = alloc((void **)&c->d_block_out, sizeof(double) * c->NB * Q * Bn);
@@ -666,7 +676,8 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     }
     // Data-flow choice: if every generator is Hermitian to rounding, every propagator is
     // unitary and the sweep can carry M_t = P_t' M_{t+1} P_t instead of storing X_t.
-    bool herm = !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES));
+    bool herm = !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) &&
+                c->cfg.gradient != GRAPE_GRADIENT_EXACT;
     const int n = c->cfg.n;
     for (size_t k = 0; k < E && herm; ++k) {
         for (size_t m = 0; m < K + 1 && herm; ++m) {
@@ -813,6 +824,8 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
         c->ev_issued += 1;
         HIP_TRY(c, hipEventRecord(e0, stream));
     }
+    const bool exact = c->cfg.gradient == GRAPE_GRADIENT_EXACT;
+    if (exact) p.member_out = nullptr;                       // the sweep's first-order rows are not wanted
     if (c->family == 0) {
         const int mode = c->unitary ? 2 : (c->d_costates ? 1 : 0);
         if (c->pair)
@@ -823,8 +836,29 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
         int rc = enqueue_tile(c, d_x, stream, n_x);
         if (rc) return rc;
     }
+    if (exact) {                                             // exact gradient + objective from the stored trajectory
+        grape::ExactParams q{};
+        q.ops = c->d_ops;
+        q.x = d_x;
+        q.props = c->d_props;
+        q.states = c->d_states;
+        q.costates = c->d_costates;
+        q.member_out = c->d_member_out;
+        q.K = c->cfg.n_controls;
+        q.N = c->cfg.n_slices;
+        q.E = c->cfg.n_ensemble;
+        q.S = c->S;
+        q.CH = c->CH;
+        q.s_forced = c->cfg.expm_squarings;
+        q.variant = c->cfg.variant;
+        q.objective = c->cfg.objective;
+        HIP_TRY(c, grape::launch_exact_grad(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, q, stream));
+    }
     if (timed) HIP_TRY(c, hipEventRecord(e1, stream));
-    if (c->family == 0)
+    if (exact)
+        HIP_TRY(c, grape::launch_reduce(c->d_member_out, c->d_wts, c->d_partial, d_fg, p.E, (int)(KN(c) + 1), c->ksplit,
+                                        stream, done));
+    else if (c->family == 0)
         HIP_TRY(c, grape::launch_reduce_rows(c->d_block_out, d_fg, c->NB, (int)(KN(c) + 1), n_x, stream, done));
     else {
         // one weighted reduction per control array (each reuses d_partial, in stream order); with a host

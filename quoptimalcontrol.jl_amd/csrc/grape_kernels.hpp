@@ -99,6 +99,19 @@ int reduce_ksplit(int E);
 hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, int n_x, hipStream_t stream,
                               DoneSignal done = DoneSignal());
 
+// ---- exact gradient / functional path (exact_grad.hip), n <= 4 ---------------------------------------
+struct ExactParams {
+    const double2 *ops;       // as SweepParams.ops (prescaled generators)
+    const double *x;          // (K, N)
+    const double2 *props, *states, *costates;   // the sweep's debug-flow stores (chunk-major workspace layout)
+    double *member_out;       // (K*N + 1) per member: exact gradient, then the objective
+    int32_t K, N, E;
+    int32_t S, CH;            // workspace decomposition: slice t = L*S + j of member k at ((k*S + j)*n*n + e)*CH + L
+    int32_t s_forced, variant;
+    int32_t objective;        // 0: the GRAPE figure of merit (fom_func), 1: C1 functional for every system type (ADGRAPE)
+};
+hipError_t launch_exact_grad(int n, int sandwich, const ExactParams &p, hipStream_t stream);
+
 // ---- device-resident L-BFGS (lbfgs.hip) -----------------------------------------------------------
 constexpr int kLbfgsMaxPer = 16;       // vector elements per thread of the 1024-thread workgroup: K*N <= 16384
 constexpr int kLbfgsMaxProbes = 8;     // trial step lengths per launch

@@ -53,7 +53,8 @@ class GrapeConfig(C.Structure):
                 ("duration", C.c_double), ("device", C.c_int32), ("flags", C.c_int32),
                 ("slices_per_lane", C.c_int32), ("waves_per_member", C.c_int32),
                 ("expm_squarings", C.c_int32), ("max_batch", C.c_int32),
-                ("n_state_cols", C.c_int32), ("n_devices", C.c_int32), ("device_ids", C.c_int32 * MAX_DEVICES)]
+                ("n_state_cols", C.c_int32), ("n_devices", C.c_int32), ("device_ids", C.c_int32 * MAX_DEVICES),
+                ("gradient", C.c_int32), ("objective", C.c_int32)]
 
 
 class GrapeInfo(C.Structure):
@@ -149,9 +150,11 @@ class GrapeEngine:
 
     def __init__(self, sys_type, A, B, Xi, Xt, wts, T, n_slices, variant=0, device=-1, flags=0,
                  slices_per_lane=0, waves_per_member=0, expm_squarings=-1, member_results=False, max_batch=1,
-                 devices=None, force_collective=False):
+                 devices=None, force_collective=False, gradient="reference", objective="fom"):
         """devices: list of HIP ordinals -> the library shards the ensemble over them itself
-        (grape_config.n_devices / device_ids) and all-reduces [G, F] with RCCL once per evaluation."""
+        (grape_config.n_devices / device_ids) and all-reduces [G, F] with RCCL once per evaluation.
+        gradient: "reference" (the first-order grad_func!) or "exact" (derivative of the objective, n <= 4);
+        objective: "fom" (fom_func) or "c1" (the ADGRAPE functional C1(Xt, U Xi [U']); needs gradient="exact")."""
         self._h = None
         self._lib = load_library()
         A = np.asarray(A, dtype=np.complex128)
@@ -183,7 +186,8 @@ class GrapeEngine:
             device = devices[0]
         cfg = GrapeConfig(code, int(variant), n, K, int(n_slices), E, float(T), int(device), int(flags),
                           int(slices_per_lane), int(waves_per_member), int(expm_squarings), int(max_batch),
-                          0 if m == n else m, len(devices) if len(devices) > 1 else 0, ids)
+                          0 if m == n else m, len(devices) if len(devices) > 1 else 0, ids,
+                          {"reference": 0, "exact": 1}[gradient], {"fom": 0, "c1": 1}[objective])
         self.max_batch = max(1, int(max_batch))
         h = C.c_void_p()
         rc = self._lib.grape_create(C.byref(cfg), C.byref(h))

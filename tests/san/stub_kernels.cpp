@@ -20,5 +20,6 @@ bool tile_chain_is_split(const TileParams &, bool) { return false; }
 hipError_t launch_lbfgs_init(const LbfgsState &, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
 hipError_t launch_lbfgs_direction(const LbfgsState &, int, double, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_lbfgs_select(const LbfgsState &, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
+hipError_t launch_exact_grad(int, int, const ExactParams &, hipStream_t) { return hipErrorNoDevice; }
 int reduce_ksplit(int E) { int ks = (E + 31) / 32; return ks > 32 ? 32 : (ks < 1 ? 1 : ks); }
 }  // namespace grape

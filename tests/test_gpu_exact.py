@@ -1,0 +1,98 @@
+"""GPU: the exact-gradient / ADGRAPE functional path (SURVEY.md 8f-3 exact gradient, 8f-4 functional path):
+grape_config.gradient = exact, objective = fom | c1, n <= 4; against the oracle's independent restatement
+(block-triangular Pade), the mpmath fixtures, and the reference's four ADGRAPE testsets through solve()."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+from test_oracle_exact import EXACT, load_exact
+
+pytestmark = pytest.mark.gpu
+tol = 1e-6
+
+
+@pytest.mark.parametrize("path", EXACT, ids=[os.path.basename(p)[:-5] for p in EXACT])
+@pytest.mark.parametrize("objective", ["fom", "c1"])
+@pytest.mark.parametrize("kernel", ["auto", "lane"])
+def test_hip_exact_matches_mpmath(qoc, path, objective, kernel, monkeypatch):
+    if kernel == "lane":
+        monkeypatch.setenv("GRAPE_SMALL_KERNEL", "lane")
+    c, A, B, Xi, Xt, wts, x = load_exact(path)
+    exp = c["exact"]["objective0" if objective == "fom" else "objective1"]
+    with qoc.GrapeEngine(c["sys_type"], A, B, Xi, Xt, wts, c["T"], c["N"], variant=c["variant"], gradient="exact",
+                         objective=objective) as eng:
+        F, G = eng.eval(x)
+        foms, grads = eng.member_results()
+    assert_parity(F, G, exp["F"], np.array(exp["G"]), c["n"], what="ensemble")
+    for k in range(c["E"]):
+        assert_parity(foms[k], grads[k], exp["member_F"][k], np.array(exp["member_g"][k]), c["n"], what=f"member {k}")
+
+
+@pytest.mark.parametrize("name,kw", [("C3", {"E": 70, "N": 130}), ("C2", {"N": 333}), ("C1", {})])
+@pytest.mark.parametrize("objective", ["fom", "c1"])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_hip_exact_matches_oracle(qoc, oracle, name, kw, objective, variant):
+    w = qoc.workloads.config(name, **kw)
+    F_ref, G_ref = oracle.ensemble_exact(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, variant=variant,
+                                         objective=0 if objective == "fom" else 1)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, variant=variant, gradient="exact",
+                         objective=objective) as eng:
+        F, G = eng.eval(w.x)
+    assert_parity(F, G, F_ref, G_ref, w.n, what=f"{name} {objective} v{variant}")
+
+
+def test_exact_with_squarings(qoc, oracle):
+    """large dt |H|: the derivative through the scaling-and-squaring chain."""
+    w = qoc.workloads.config("C3", E=3, N=8)
+    w.T = 24.0
+    F_ref, G_ref = oracle.ensemble_exact(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, variant=1, objective=1)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, variant=1, gradient="exact", objective="c1") as eng:
+        F, G = eng.eval(w.x)
+    assert_parity(F, G, F_ref, G_ref, w.n, what="exact, squaring path")
+
+
+def test_exact_argument_rules(qoc):
+    w = qoc.workloads.config("C1")
+    with pytest.raises(qoc.GrapeError) as ei:
+        qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, objective="c1")     # C1 functional needs exact
+    assert ei.value.status == -1
+    w4 = qoc.workloads.config("C4", E=1, N=4)
+    with pytest.raises(qoc.GrapeError) as ei:
+        qoc.GrapeEngine(w4.sys_type, w4.A, w4.B, w4.Xi, w4.Xt, w4.wts, w4.T, w4.N, gradient="exact")
+    assert ei.value.status == -2                                                                # n <= 4 in this build
+
+
+def _problem(qoc, sys_type, N, T):
+    wl = qoc.workloads
+    ug = sys_type == "UnitaryGate"
+    return qoc.Problem(B=[wl.Sx, wl.Sy], A=wl.Sz, Xi=wl.U_init if ug else wl.rho_init,
+                       Xt=wl.U_fin if ug else wl.rho_fin, T=T, n_controls=2, guess=wl.controls(2, N),
+                       sys_type=qoc.UnitaryGate() if ug else qoc.StateTransfer())
+
+
+@pytest.mark.parametrize("sys_type,N,floor", [("StateTransfer", 10, 0.75), ("UnitaryGate", 25, 0.0)])
+@pytest.mark.parametrize("optimizer", ["host", "device"])
+def test_reference_adgrape_single_testsets(qoc, sys_type, N, floor, optimizer):
+    """test/state_transfer_tests.jl:103-118 and test/unitary_gate_tests.jl:115-132 (ADGRAPE, single problem)."""
+    prob = _problem(qoc, sys_type, N, 1.0)
+    sol = qoc.solve(prob, qoc.ADGRAPE(n_slices=N, optimizer=optimizer))
+    assert isinstance(sol, qoc.SolutionResult)
+    assert sol.result.minimum - floor < tol
+
+
+@pytest.mark.parametrize("sys_type,N", [("StateTransfer", 25), ("UnitaryGate", 100)])
+def test_reference_adgrape_ensemble_testsets(qoc, sys_type, N):
+    """test/state_transfer_tests.jl:124-149 and test/unitary_gate_tests.jl:137-165 (ADGRAPE, n_ens = 5):
+    `@test sol.result.minimum - C1(rho_fin, rho_fin) < tol`."""
+    wl = qoc.workloads
+    ug = sys_type == "UnitaryGate"
+    prob = _problem(qoc, sys_type, N, 5.0)
+    tgt = (wl.U_fin, wl.U_init) if ug else (wl.rho_fin, wl.rho_init)
+    ens = qoc.EnsembleProblem(prob=prob, n_ens=5, A_g=lambda k: (k - 2.5) / 2.5 * wl.Sz * 5,
+                              B_g=lambda k: [wl.Sx, wl.Sy], XiG=lambda k: prob.Xi,
+                              XtG=lambda k: tgt[0] if k % 2 else tgt[1], wts=np.ones(5) / 5)
+    sol = qoc.solve(ens, qoc.ADGRAPE(n_slices=N))
+    assert isinstance(sol, qoc.EnsembleSolutionResult)
+    assert sol.result.minimum - 0.75 < tol * 10
