@@ -295,9 +295,11 @@ def main():
     Gf = np.empty_like(xf)
     direct = sg.local is not None and (sg.collective == "lib" or (world == 1 and not args.force_dist))
 
+    bound = sg.local.bind_eval(xf, Gf) if direct else None
+
     def step():
         if direct:
-            return sg.local.eval_cm(xf, Gf), Gf    # grape_eval: host -> GPUs -> host, all-reduce inside the library
+            return bound(), Gf                     # grape_eval: host -> GPUs -> host, all-reduce inside the library
         return sg.eval(x_host)
 
     for _ in range(args.warmup):

@@ -269,6 +269,26 @@ class GrapeEngine:
             self._check(rc)
         return self._F.value
 
+    def bind_eval(self, xf, G_out):
+        """Pre-bound grape_eval on fixed caller buffers (layout as eval_cm): returns a zero-argument callable that
+        runs one evaluation and returns F.  The ctypes argument objects are built once, so a call costs what the
+        foreign-function call itself costs -- the closest Python gets to the Julia `ccall` in julia/GrapeHIP.jl."""
+        if xf.dtype != np.float64 or not xf.flags.c_contiguous or xf.shape != (self.N, self.K):
+            raise ValueError(f"xf must be a C-contiguous float64 array of shape ({self.N},{self.K})")
+        if G_out.dtype != np.float64 or not G_out.flags.c_contiguous or G_out.shape != xf.shape:
+            raise ValueError("G_out must match xf")
+        fn, h, px, pg, F = self._lib.grape_eval, self._h, C.c_void_p(xf.ctypes.data), C.c_void_p(G_out.ctypes.data), self._F
+        pF = C.byref(F)
+        check = self._check
+
+        def call():
+            rc = fn(h, px, pF, pg)
+            if rc:
+                check(rc)
+            return F.value
+        call.buffers = (xf, G_out)              # keep them alive as long as the callable lives
+        return call
+
     LBFGS_STATUS = {0: "g_tol reached", 1: "f_tol reached", 2: "max iterations", 3: "line search failed"}
 
     def lbfgs(self, x0, memory=0, iterations=0, g_tol=-1.0, f_tol=0.0, max_linesearch=0, probes=0):
