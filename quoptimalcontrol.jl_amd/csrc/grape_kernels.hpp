@@ -47,6 +47,8 @@ struct SweepParams {
     uint32_t sk_magic;    // floor(2^32 / (S*K)) + 1: q / (S*K) == __umulhi(q, sk_magic)
     int32_t s_forced;     // expm squarings, -1 = per slice from the norm
     int32_t variant;      // 0 in-place, 1 static
+    int32_t plast_lds;    // pair kernel, set by its launcher: every chunk's LAST propagator also stays in LDS, where
+                          // the backward sweep (which starts with it) reads it instead of HBM
     double dt;
 };
 
@@ -62,7 +64,7 @@ size_t sweep_small_lds_bytes(int n, int MPB, int LT, int S, int K, bool xg_in_ld
 // lanes, LT/2 chunks per member; same SweepParams, workspace stride LT/2 instead of LT
 hipError_t launch_sweep_pair(int n, int sandwich, int mode, const SweepParams &p, hipStream_t stream);
 int sweep_pair_max_waves(int n);    // 0: no pair kernel for this n
-size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool xg_in_lds);
+size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool xg_in_lds, bool plast = false);
 
 // ---- tile (MFMA) family, n = 5..32, zero-padded to 16*NT ------------------------------------
 // All matrices are "D-layout dumps" (tile.hpp): (16 NT)^2 double2 each, TSZ = NT*NT*256.

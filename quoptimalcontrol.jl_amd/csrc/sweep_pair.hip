@@ -206,6 +206,8 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
                              : p.xg_scratch + (size_t)blockIdx.x * ((size_t)p.MPB * CH * (SK + 1) + p.MPB);
     double *s_xg = s_xg_all + (size_t)mb * CH * (SK + 1);
     double *s_F = s_xg_all + (size_t)p.MPB * CH * (SK + 1);
+    // (optional) the chunks' last propagators: element e of thread T at s_plast[e * blockDim.x + T]
+    double2 *s_plast = reinterpret_cast<double2 *>(s_F + ((p.MPB + 1) & ~1));
     // 1-norm bounds (max column sum of |re| + |im|) of this member's A' and B'_c: |G_t|_1 <= nrm[0] + sum |x_c| nrm[1+c]
     double *s_nrm = reinterpret_cast<double *>(s_ops_all + (size_t)p.MPB * 2 * NM * NE) + (size_t)mb * (K + 1);
     const unsigned magic = p.sk_magic;
@@ -337,6 +339,11 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
             pexpm_t8<N, UNI>(P, G, p.s_forced, nb);
             if (!(GRAPE_ABL & 2))
             pstore_ws(Pw + (size_t)j * NN * stride, stride, P, par);
+            if (UNI && XGLDS && p.plast_lds && j == S - 1) {          // the backward sweep's first operand stays on chip
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    s_plast[e * blockDim.x + threadIdx.x] = make_double2(P.re[e], P.im[e]);
+            }
             if (GRAPE_ABL & 4) { Qout = Qin; Qout.re[0] += P.re[1]; } else {
             fetch_partner(Ppar, P);
             pmul(Qout, P, Ppar, Qin); }
@@ -527,7 +534,16 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
                     s_F[mb] = pfigure_of_merit<N, SAND>(zr, zi);
             }
         };
-        pload_ws(PA, Pw + (size_t)(S - 1) * NN * stride, stride, par);
+        if (XGLDS && p.plast_lds) {                      // written by this very thread in phase A
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const double2 v = s_plast[e * blockDim.x + threadIdx.x];
+                PA.re[e] = v.x;
+                PA.im[e] = v.y;
+            }
+        } else {
+            pload_ws(PA, Pw + (size_t)(S - 1) * NN * stride, stride, par);
+        }
         int j = S - 1;
         for (; j >= 1; j -= 2) {
             if (!(GRAPE_ABL & 8)) pload_ws(PB, Pw + (size_t)(j - 1) * NN * stride, stride, par);
@@ -663,24 +679,35 @@ int sweep_pair_max_waves(int n)
     }
 }
 
-size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool xg_in_lds)
+size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool xg_in_lds, bool plast)
 {
     const int maxt = n == 2 ? PairTraits<2>::MAXT : PairTraits<4>::MAXT;
     size_t b = sizeof(double2) * (2 * (size_t)(maxt / 64) * n * n);
     b += sizeof(double2) * ((size_t)MPB * 2 * (2 * K + 3) * (n * (n / 2)) + ((size_t)MPB * (K + 1) + 1) / 2);
     if (xg_in_lds)
-        b += sizeof(double) * ((size_t)MPB * (LT / 2) * ((size_t)S * K + 1) + MPB);
+        b += sizeof(double) * ((size_t)MPB * (LT / 2) * ((size_t)S * K + 1) + ((MPB + 1) & ~1));
+    if (plast)
+        b += sizeof(double2) * (size_t)MPB * LT * (n * (n / 2));
     return b;
 }
 
 template <int N, int SAND, int MODE, bool XGLDS>
-static hipError_t plaunch_one(const SweepParams &p, hipStream_t stream)
+static hipError_t plaunch_one(const SweepParams &p0, hipStream_t stream)
 {
     constexpr int MAXT = PairTraits<N>::MAXT;
+    SweepParams p = p0;
     const dim3 grid(p.BPX * p.n_x), block(p.LT * p.MPB);
-    const size_t lds = sweep_pair_lds_bytes(N, p.MPB, p.LT, p.S, p.K, XGLDS);
+    size_t lds = sweep_pair_lds_bytes(N, p.MPB, p.LT, p.S, p.K, XGLDS);
     if (lds > 160 * 1024)
         return hipErrorInvalidConfiguration;
+    p.plast_lds = 0;
+    if (MODE == PMODE_UNITARY && XGLDS && p.S > 1) {         // room for the chunks' last propagators?
+        const size_t with = sweep_pair_lds_bytes(N, p.MPB, p.LT, p.S, p.K, true, true);
+        if (with <= 160 * 1024) {
+            p.plast_lds = 1;
+            lds = with;
+        }
+    }
     auto kern = sweep_pair_kernel<N, SAND, MODE, MAXT, XGLDS>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -14,7 +14,7 @@ hipError_t launch_copy(const double *, double *, int, hipStream_t, DoneSignal) {
 int sweep_small_max_waves(int n) { return n == 2 ? 16 : (n == 3 ? 8 : (n == 4 ? 4 : 0)); }
 int sweep_pair_max_waves(int n) { return n == 2 ? 16 : (n == 4 ? 8 : 0); }
 size_t sweep_small_lds_bytes(int n, int MPB, int LT, int S, int K, bool x) { return 16 * (size_t)n * n * 32 + (x ? 8 * ((size_t)MPB * LT * ((size_t)S * K + 1) + MPB) : 0); }
-size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool x) { return 16 * (size_t)n * n * 32 + 16 * (size_t)MPB * 2 * (2 * K + 3) * n * n / 2 + (x ? 8 * ((size_t)MPB * (LT / 2) * ((size_t)S * K + 1) + MPB) : 0); }
+size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool x, bool) { return 16 * (size_t)n * n * 32 + 16 * (size_t)MPB * 2 * (2 * K + 3) * n * n / 2 + (x ? 8 * ((size_t)MPB * (LT / 2) * ((size_t)S * K + 1) + MPB) : 0); }
 int tile_count(int n) { return n <= 4 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : 0)); }
 bool tile_chain_is_split(const TileParams &, bool) { return false; }
 hipError_t launch_lbfgs_init(const LbfgsState &, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
