@@ -173,7 +173,14 @@ def lbfgs_rates(qoc, dev_index):
     out = []
     for label, w, iters in (("reference testset: StateTransfer 2x2, n_ens=5, N=25 (state_transfer_tests.jl:42)",
                              qoc.workloads.reference_ensemble("StateTransfer", 5, 25, 5.0), 0),
-                            ("C3 headline ensemble, 30 iterations", qoc.workloads.config("C3"), 30)):
+                            ("C3-shaped StateTransfer ensemble (4x4, K=4, N=500, E=1024), 30 iterations", "st4", 30)):
+        if w == "st4":                              # the headline operators with density-matrix states: here the
+            w = qoc.workloads.config("C3")          # reference gradient is a consistent descent direction
+            rho0 = np.zeros((4, 4), complex); rho0[0, 0] = 1
+            psi = np.array([1, 1j, -1, 0.5]) / np.linalg.norm([1, 1j, -1, 0.5])
+            w.sys_type = "StateTransfer"
+            w.Xi = np.broadcast_to(rho0, (w.E, 4, 4)).copy()
+            w.Xt = np.broadcast_to(np.outer(psi, psi.conj()), (w.E, 4, 4)).copy()
         ug = w.sys_type == "UnitaryGate"
         with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, device=dev_index,
                              variant=1 if ug else 0, max_batch=4 if w.E <= 64 else 1) as eng:
@@ -394,11 +401,23 @@ def main():
                                                              1 if name == "C5" else (3 if heavy else 20)))
             except Exception as exc:               # noqa: BLE001 -- an extra line must not kill the headline
                 out["extra_configs"].append({"workload": name, "error": repr(exc)})
+    # the JSON line must be the LAST thing on stdout: flush what native libraries (RCCL prints a version banner
+    # through C stdio, block-buffered on a pipe) still hold, on every rank, before rank 0 prints
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                          # noqa: BLE001
+        pass
+    sys.stdout.flush()
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
-    if out is not None:                       # the JSON line is the last thing on stdout
-        sys.stdout.flush()
+    if out is not None:
         print(json.dumps(out), flush=True)
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                      # noqa: BLE001
+            pass
 
 
 if __name__ == "__main__":
