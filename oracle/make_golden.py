@@ -220,8 +220,11 @@ def main(only=None):
         ("st_8x8_pairs", "rand8"),                    # tile kernels, two members per 16x16 tile
         ("ct_16x16_nonherm", "rand16"),               # tile kernels, non-Hermitian generator
     ]
+    wv = wl.liouville_vec(2, 2, 3, 1.0, dissipative=True)      # 16 x 1 vec(rho), dissipative: stored zero-padded to 16 x 16
+    pad = lambda X: np.concatenate([X, np.zeros((X.shape[0], 16, 15), complex)], axis=2)
+    wv.Xi, wv.Xt = pad(wv.Xi), pad(wv.Xt)
     exact_cases = [("exact_ug_4x4", wl.config("C3", E=2, N=6), 1), ("exact_st_2x2", wl.reference_ensemble("StateTransfer", 3, 7, 5.0), 1),
-                   ("exact_ug_2x2", wl.reference_ensemble("UnitaryGate", 2, 6, 5.0), 0)]
+                   ("exact_ug_2x2", wl.reference_ensemble("UnitaryGate", 2, 6, 5.0), 0), ("exact_vec_16x1_diss", wv, 1)]
     for name, w, variant in exact_cases:
         if only and name not in only:
             continue

@@ -250,8 +250,6 @@ static int validate_config(const grape_config *cfg)
     if (cfg->objective == GRAPE_OBJECTIVE_C1 && cfg->gradient != GRAPE_GRADIENT_EXACT)
         return fail(nullptr, GRAPE_ERR_INVALID_ARG,
                     "grape_create: the C1 functional (ADGRAPE path) comes with the exact gradient: set gradient = 1");
-    if (cfg->gradient == GRAPE_GRADIENT_EXACT && wmax == 0)
-        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: the exact gradient exists for n <= 4 in this build");
     if (cfg->gradient == GRAPE_GRADIENT_EXACT && cfg->max_batch > 1)
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: exact gradient and max_batch > 1 do not combine in this build");
     if ((cfg->flags & GRAPE_FLAG_PHASE_STAMPS) && wmax == 0)
@@ -301,7 +299,8 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     c->B = cfg->max_batch > 1 ? cfg->max_batch : 1;
     c->NT = nt;
     c->TSZ = (size_t)nt * nt * 256;
-    c->pack2 = (c->family == 1 && cfg->n <= 8 && !std::getenv("GRAPE_TILE_NOPACK"));
+    c->pack2 = (c->family == 1 && cfg->n <= 8 && !std::getenv("GRAPE_TILE_NOPACK") &&
+                cfg->gradient != GRAPE_GRADIENT_EXACT);        // the exact-gradient kernel works on whole tiles
     c->EU = c->pack2 ? (E + 1) / 2 : E;
     c->pair = pair && c->family == 0;
     const int cpw = c->pair ? 32 : 64;                           // time chunks per wave
@@ -836,7 +835,10 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
         int rc = enqueue_tile(c, d_x, stream, n_x);
         if (rc) return rc;
     }
-    if (exact) {                                             // exact gradient + objective from the stored trajectory
+    if (exact && c->family == 1) {
+        HIP_TRY(c, grape::launch_exact_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, tile_params(c, d_x),
+                                            c->cfg.objective, stream));
+    } else if (exact) {                                      // exact gradient + objective from the stored trajectory
         grape::ExactParams q{};
         q.ops = c->d_ops;
         q.x = d_x;

@@ -113,6 +113,9 @@ struct ExactParams {
     int32_t objective;        // 0: the GRAPE figure of merit (fom_func), 1: C1 functional for every system type (ADGRAPE)
 };
 hipError_t launch_exact_grad(int n, int sandwich, const ExactParams &p, hipStream_t stream);
+// the same for the tile family (exact_tile.hip): reads the debug flow's props / states / costates dumps of TileParams
+struct TileParams;
+hipError_t launch_exact_tile(int n, int sandwich, const TileParams &p, int objective, hipStream_t stream);
 
 // ---- device-resident L-BFGS (lbfgs.hip) -----------------------------------------------------------
 constexpr int kLbfgsMaxPer = 16;       // vector elements per thread of the 1024-thread workgroup: K*N <= 16384

@@ -43,6 +43,50 @@ def test_hip_exact_matches_oracle(qoc, oracle, name, kw, objective, variant):
     assert_parity(F, G, F_ref, G_ref, w.n, what=f"{name} {objective} v{variant}")
 
 
+@pytest.mark.parametrize("n,herm,sys_type,E,N", [(8, True, "StateTransfer", 3, 9), (16, False, "CoherenceTransfer", 2, 7),
+                                                  (16, True, "UnitaryGate", 2, 6), (32, True, "UnitaryGate", 2, 4)])
+@pytest.mark.parametrize("objective", ["fom", "c1"])
+def test_hip_exact_tile_family_matches_oracle(qoc, oracle, n, herm, sys_type, E, N, objective):
+    """the MFMA tile kernels' exact gradient (exact_tile.hip), n = 8, 16, 32."""
+    rng = np.random.default_rng(7 * n + E)
+    K = 2
+
+    def gen():
+        M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        return (M + M.conj().T) / 2 if herm else M
+    A = np.array([gen() for _ in range(E)]) * 0.4
+    B = np.array([[gen() for _ in range(K)] for _ in range(E)]) * 0.3
+
+    def st():
+        if sys_type == "UnitaryGate":
+            return rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        v /= np.linalg.norm(v)
+        return np.outer(v, v.conj())
+    Xi, Xt = np.array([st() for _ in range(E)]), np.array([st() for _ in range(E)])
+    if sys_type == "UnitaryGate":
+        Xi, Xt = Xi / n, Xt / n
+    wts = rng.uniform(0.3, 1.0, E)
+    x = rng.uniform(-1, 1, (K, N))
+    F_ref, G_ref = oracle.ensemble_exact(sys_type, A, B, Xi, Xt, wts, x, 1.2, variant=1, objective=0 if objective == "fom" else 1)
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N, variant=1, gradient="exact", objective=objective) as eng:
+        F, G = eng.eval(x)
+    assert_parity(F, G, F_ref, G_ref, n, what=f"tile exact n={n} {objective}")
+
+
+def test_hip_exact_vectorised_liouvillian(qoc):
+    """16 x 1 vec(rho) under a dissipative Liouvillian (test/liou.jl's shape at two qubits), exact gradient of the
+    C1 functional: the device with native n x 1 states against the 50-digit fixture (computed zero-padded)."""
+    path = [p for p in EXACT if "vec_16x1" in p][0]
+    c, A, B, Xi, Xt, wts, x = load_exact(path)
+    exp = c["exact"]["objective1"]
+    with qoc.GrapeEngine(c["sys_type"], A, B, Xi[:, :, :1], Xt[:, :, :1], wts, c["T"], c["N"], variant=c["variant"],
+                         gradient="exact", objective="c1") as eng:
+        F, G = eng.eval(x)
+        assert eng.m == 1
+    assert_parity(F, G, exp["F"], np.array(exp["G"]), c["n"], what="vec(rho) 16x1 exact")
+
+
 def test_exact_with_squarings(qoc, oracle):
     """large dt |H|: the derivative through the scaling-and-squaring chain."""
     w = qoc.workloads.config("C3", E=3, N=8)
@@ -58,10 +102,9 @@ def test_exact_argument_rules(qoc):
     with pytest.raises(qoc.GrapeError) as ei:
         qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, objective="c1")     # C1 functional needs exact
     assert ei.value.status == -1
-    w4 = qoc.workloads.config("C4", E=1, N=4)
     with pytest.raises(qoc.GrapeError) as ei:
-        qoc.GrapeEngine(w4.sys_type, w4.A, w4.B, w4.Xi, w4.Xt, w4.wts, w4.T, w4.N, gradient="exact")
-    assert ei.value.status == -2                                                                # n <= 4 in this build
+        qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, gradient="exact", max_batch=2)
+    assert ei.value.status == -2                                                                # no batching with it
 
 
 def _problem(qoc, sys_type, N, T):
