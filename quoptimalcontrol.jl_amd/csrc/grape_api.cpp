@@ -313,6 +313,8 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
         W = (int)((slots + units - 1) / units);
         const int wneed = (N + cpw - 1) / cpw;
         if (W > wneed) W = wneed;
+        if (W > 8) W = 8;        // the wave totals of the scan combine sequentially: beyond 8 waves per member that
+                                 // costs more than the shorter chunks save (single qubit, N = 1000: 15.2 vs 18.1 us)
     }
     if (wmax > 0 && W > wmax) W = wmax;
     if (W < 1 || c->family == 1) W = 1;
