@@ -22,7 +22,7 @@ using QuOptimalControl: Problem, EnsembleProblem, StateTransfer, UnitaryGate, Co
 using Optim
 import QuOptimalControl: solve
 
-export GRAPE_HIP, GrapeContext
+export GRAPE_HIP, ADGRAPE_HIP, GrapeContext
 
 const libgrape = get(ENV, "LIBGRAPE_HIP", "libgrape_hip.so")
 
@@ -61,18 +61,36 @@ Base.@kwdef struct GRAPE_HIP{OPTS}
     optim_options::OPTS = Optim.Options()
 end
 
+"""
+Counterpart of `ADGRAPE` (src/solve.jl:44-52): the functional C1(Xt, U Xi [U']) of src/solve.jl:268-361 with its
+EXACT gradient from the device (grape_config.gradient = 1, objective = 1) instead of a Zygote tape.
+"""
+Base.@kwdef struct ADGRAPE_HIP{OPTS}
+    n_slices::Int
+    device::Int = -1
+    devices::Vector{Int} = Int[]
+    optim_options::OPTS = Optim.Options()
+end
+
+# per-algorithm settings of grape_config: (variant, gradient, objective)
+cfg_mode(alg::GRAPE_HIP) = (alg.isinplace ? Int32(0) : Int32(1), Int32(0), Int32(0))
+cfg_mode(::ADGRAPE_HIP) = (Int32(1), Int32(1), Int32(1))      # pw_evolve adds A first (src/timeevolution.jl:32-35)
+
 mutable struct GrapeContext
     handle::Ptr{Cvoid}
     K::Int
     N::Int
-    function GrapeContext(members::Vector{<:Problem}, wts::Vector{Float64}, alg::GRAPE_HIP)
+    function GrapeContext(members::Vector{<:Problem}, wts::Vector{Float64}, alg)
         p1 = members[1]
         n = size(p1.A, 1)
+        m = size(p1.Xi, 2)                 # n x m states (m < n: e.g. a vectorised density matrix, test/liou.jl)
         K, N, E = p1.n_controls, alg.n_slices, length(members)
         nd = length(alg.devices)
         ids = ntuple(i -> i <= nd ? Int32(alg.devices[i]) : Int32(0), 8)
-        cfg = GrapeConfig(sys_code(p1.sys_type), alg.isinplace ? 0 : 1, n, K, N, E, Float64(p1.T),
-                          nd == 1 ? alg.devices[1] : alg.device, 0, 0, 0, -1, 0, 0, nd > 1 ? nd : 0, ids, 0, 0)
+        variant, gradient, objective = cfg_mode(alg)
+        cfg = GrapeConfig(sys_code(p1.sys_type), variant, n, K, N, E, Float64(p1.T),
+                          nd == 1 ? alg.devices[1] : alg.device, 0, 0, 0, -1, 0, m == n ? 0 : m, nd > 1 ? nd : 0, ids,
+                          gradient, objective)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:grape_create, libgrape), Cint, (Ref{GrapeConfig}, Ref{Ptr{Cvoid}}), cfg, h)
         rc == 0 || error("grape_create: ", unsafe_string(ccall((:grape_last_error, libgrape), Cstring, (Ptr{Cvoid},), C_NULL)))
@@ -81,8 +99,8 @@ mutable struct GrapeContext
         # pack what init_ensemble produced (src/tools.jl:42-53) into contiguous column-major arrays
         A  = Array{ComplexF64}(undef, n, n, E)
         B  = Array{ComplexF64}(undef, n, n, K, E)
-        Xi = Array{ComplexF64}(undef, n, n, E)
-        Xt = Array{ComplexF64}(undef, n, n, E)
+        Xi = Array{ComplexF64}(undef, n, m, E)
+        Xt = Array{ComplexF64}(undef, n, m, E)
         for (k, p) in enumerate(members)
             A[:, :, k] .= p.A
             for j in 1:K
@@ -122,13 +140,13 @@ function make_topt(ctx::GrapeContext)
     end
 end
 
-function solve(prob::Problem, alg::GRAPE_HIP)
+function solve(prob::Problem, alg::Union{GRAPE_HIP,ADGRAPE_HIP})
     ctx = GrapeContext([prob], [1.0], alg)
     res = Optim.optimize(Optim.only_fg!(make_topt(ctx)), prob.guess, Optim.LBFGS(), alg.optim_options)   # src/solve.jl:138
     SolutionResult(res, res.minimum, res.minimizer, prob, alg)                                            # src/solve.jl:139
 end
 
-function solve(ens::EnsembleProblem, alg::GRAPE_HIP)
+function solve(ens::EnsembleProblem, alg::Union{GRAPE_HIP,ADGRAPE_HIP})
     members = init_ensemble(ens)                                                                          # src/solve.jl:150
     ctx = GrapeContext(members, Vector{Float64}(ens.wts), alg)
     res = Optim.optimize(Optim.only_fg!(make_topt(ctx)), members[1].guess, Optim.LBFGS(), alg.optim_options)  # :244
