@@ -105,6 +105,7 @@ struct grape_ctx {
     std::vector<grape_ctx *> sub;
     std::vector<int> sub_lo;      // first member of every shard
     double timeout_s = 600.0;
+    double eval_ema_s = 0.0;      // smoothed duration of the last evaluations (long ones sleep through most of it)
     mutable std::string err;
 };
 
@@ -963,17 +964,31 @@ static int wait_flag(grape_ctx *s)
     const unsigned long long want = s->seq;
     timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    long nap_ns = 20000;
-    for (unsigned it = 0;; ++it) {
-        if (*flag == want) {
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            return GRAPE_OK;
-        }
-        if ((it & 1023) != 1023) continue;
+    auto elapsed = [&]() {
         timespec t;
         clock_gettime(CLOCK_MONOTONIC, &t);
-        const double el = (double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec);
-        if (el < 500e-6) continue;                          // spin phase
+        return (double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec);
+    };
+    auto done = [&](double el) {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        s->eval_ema_s = s->eval_ema_s > 0.0 ? 0.75 * s->eval_ema_s + 0.25 * el : el;
+        return GRAPE_OK;
+    };
+    // evaluations known to take milliseconds (16 x 16 and larger): sleep through ~90 % of the expected
+    // duration in one go instead of burning a core, then spin for the rest
+    if (s->eval_ema_s > 1e-3) {
+        const double nap = 0.9 * s->eval_ema_s;
+        timespec ts{(time_t)nap, (long)((nap - (double)(time_t)nap) * 1e9)};
+        nanosleep(&ts, nullptr);
+    }
+    const double spin_until = s->eval_ema_s > 1e-3 ? 1.3 * s->eval_ema_s : 500e-6;
+    long nap_ns = 20000;
+    for (unsigned it = 0;; ++it) {
+        if (*flag == want)
+            return done(elapsed());
+        if ((it & 1023) != 1023) continue;
+        const double el = elapsed();
+        if (el < spin_until) continue;                      // spin phase
         const hipError_t q = hipStreamQuery(s->stream);     // a failed kernel never publishes: ask the runtime
         if (q != hipSuccess && q != hipErrorNotReady) HIP_TRY(s, q);
         if (q == hipSuccess && *flag != want)
