@@ -148,12 +148,15 @@ def run_extra_config(qoc, name, dev_index, steps, warmup):
     w = qoc.workloads.config(name)
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, device=dev_index,
                          flags=qoc.engine.FLAG_TIME_KERNELS) as eng:
+        import numpy as np
+        xf = np.ascontiguousarray(w.x.T)
+        call = eng.bind_eval(xf, np.empty_like(xf))           # the same copy-free host->host call as the headline step
         for _ in range(warmup):
-            eng.eval(w.x)
+            call()
         eng.kernel_time(reset=True)
         t0 = time.perf_counter()
         for _ in range(steps):
-            F, _ = eng.eval(w.x)
+            F = call()
         el = time.perf_counter() - t0
         kern_ms, kern_n = eng.kernel_time()
         info = eng.info
