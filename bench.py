@@ -126,8 +126,10 @@ def roofline(local, info, kern_ms, kern_n, evals_per_s, n_gpus, traffic):
                  "note": "achieved/frac price the sweep kernel with the ALGORITHMIC work of SURVEY.md 8d "
                          "(model S); `flow` prices the same launches with the bytes/flops of the data flow "
                          "actually run; end_to_end_frac = algorithmic work x this rank's evals/s / peak"})
-    if isinstance(traffic, dict):
-        roof["traffic_source"] = "rocprofv3 PMC passes of this command, committed under profiles/ (not re-measured in this run)"
+    if traffic is not None:
+        roof["traffic_source"] = ("HBM bytes per sweep launch = (2*FETCH_SIZE + WRITE_SIZE) KiB from the rocprofv3 --pmc passes of "
+                                  "this command committed as profiles/r02_C3_E1024_pmc.json (profiles/traffic.json); "
+                                  "NOT re-measured in this run")
     return roof
 
 
