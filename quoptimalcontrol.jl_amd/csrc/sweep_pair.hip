@@ -344,7 +344,9 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
                 for (int e = 0; e < NE; ++e)
                     s_plast[e * blockDim.x + threadIdx.x] = make_double2(P.re[e], P.im[e]);
             }
-            if (GRAPE_ABL & 4) { Qout = Qin; Qout.re[0] += P.re[1]; } else {
+            if (GRAPE_ABL & 4) { Qout = Qin; Qout.re[0] += P.re[1]; } else if (j == 0) {
+                Qout = P;                             // the chunk product starts from the identity: no product needed
+            } else {
             fetch_partner(Ppar, P);
             pmul(Qout, P, Ppar, Qin); }
             if (MODE == PMODE_GENERAL)                // in-chunk prefix product, read back in phase D
