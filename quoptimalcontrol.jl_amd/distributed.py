@@ -70,6 +70,7 @@ class ShardedGrape:
         self.fg = torch.zeros(K * N + 1, dtype=torch.float64, device=device)
         self.collective = "torch"
         self.comm_size = self.world
+        self.attach_timeout_s = 180.0
         if collective == "lib" and (self.world > 1 or force_collective):
             self._attach_library_communicator()
 
@@ -84,7 +85,24 @@ class ShardedGrape:
             token = self.local.comm_unique_id() if self.rank == 0 else None
             if self.distributed and self.world > 1:
                 token = _bcast_bytes(dist, token, 128, self.group)
-            self.local.comm_attach(token, self.rank, self.world)
+            # ncclCommInitRank blocks until every rank has joined; should the bootstrap wedge (no route between
+            # ranks, a rank that died), do not hang the job: give up after attach_timeout_s and fall back
+            import threading
+            box = {}
+
+            def _attach():
+                try:
+                    self.local.comm_attach(token, self.rank, self.world)
+                    box["ok"] = True
+                except Exception as exc:              # noqa: BLE001
+                    box["err"] = exc
+            th = threading.Thread(target=_attach, daemon=True)
+            th.start()
+            th.join(self.attach_timeout_s)
+            if th.is_alive():
+                raise TimeoutError(f"grape_comm_attach did not return within {self.attach_timeout_s} s")
+            if "err" in box:
+                raise box["err"]
         except Exception as exc:                      # noqa: BLE001 -- any failure means "fall back", consistently
             self.attach_error = repr(exc)
             ok = 0
