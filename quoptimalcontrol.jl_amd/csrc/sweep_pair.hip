@@ -397,22 +397,24 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
             if (cw == 31)
                 pstore_lds(&s_tot[0][wbase_tot + wave][par * NE], inc);
             __syncthreads();
-            PMat<N> pre, wt, wtp;
-            pset_identity(pre);
-            for (int w = 0; w < wave; ++w) {
-                pload_lds(wt, &s_tot[0][wbase_tot + w][par * NE]);
-                pload_lds(wtp, &s_tot[0][wbase_tot + w][(1 - par) * NE]);
-                pmul(tmp, wt, wtp, pre);
-                pre = tmp;
-            }
-            if (UNI) {
-                fetch_partner(ipar, inc);
-                pmul(tmp, inc, ipar, pre);
-                inc = tmp;
-            } else {
-                fetch_partner(ipar, oth);
-                pmul(tmp, oth, ipar, pre);
-                oth = tmp;
+            if (wave > 0) {                          // (wave is uniform: the first wave's prefix is the identity -- nothing to do)
+                PMat<N> pre, wt, wtp;
+                pload_lds(pre, &s_tot[0][wbase_tot][par * NE]);          // total of wave 0
+                for (int w = 1; w < wave; ++w) {
+                    pload_lds(wt, &s_tot[0][wbase_tot + w][par * NE]);
+                    pload_lds(wtp, &s_tot[0][wbase_tot + w][(1 - par) * NE]);
+                    pmul(tmp, wt, wtp, pre);
+                    pre = tmp;
+                }
+                if (UNI) {
+                    fetch_partner(ipar, inc);
+                    pmul(tmp, inc, ipar, pre);
+                    inc = tmp;
+                } else {
+                    fetch_partner(ipar, oth);
+                    pmul(tmp, oth, ipar, pre);
+                    oth = tmp;
+                }
             }
         }
         if (UNI) {
@@ -481,18 +483,20 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
             if (cw == 0)
                 pstore_lds(&s_tot[1][wbase_tot + wave][par * NE], inc);
             __syncthreads();
-            PMat<N> post, wt, wtp;
-            pset_identity(post);
-            for (int w = wave + 1; w < W; ++w) {
-                pload_lds(wt, &s_tot[1][wbase_tot + w][par * NE]);
-                pload_lds(wtp, &s_tot[1][wbase_tot + w][(1 - par) * NE]);
-                pmul(tmp, wt, wtp, post);
-                post = tmp;
+            if (wave + 1 < W) {                      // the last wave's suffix is the identity
+                PMat<N> post, wt, wtp;
+                pload_lds(post, &s_tot[1][wbase_tot + wave + 1][par * NE]);
+                for (int w = wave + 2; w < W; ++w) {
+                    pload_lds(wt, &s_tot[1][wbase_tot + w][par * NE]);
+                    pload_lds(wtp, &s_tot[1][wbase_tot + w][(1 - par) * NE]);
+                    pmul(tmp, wt, wtp, post);
+                    post = tmp;
+                }
+                PMat<N> pp;
+                fetch_partner(pp, post);
+                pmul(tmp, post, pp, oth);
+                oth = tmp;
             }
-            PMat<N> pp;
-            fetch_partner(pp, post);
-            pmul(tmp, post, pp, oth);
-            oth = tmp;
         }
         PMat<N> xt_m;
         pload_lds(xt_m, sXt);
