@@ -196,7 +196,7 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
     const int k = xi * p.E + kl;
     const int K = p.K, Nsl = p.N, S = p.S;
     const size_t stride = (size_t)CH;
-    const int NM = 2 * K + 3;
+    const int NM = 2 * K + 4;                     // images: A', B'_c, B'_c^T, Xi, Xt, and Xi Xt' (built in the prologue)
 
     double2 *s_ops_all = s_dyn + 2 * MAXW * NN;
     double2 *s_ops = s_ops_all + (size_t)mb * 2 * NM * NE;
@@ -234,6 +234,8 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
         for (int idx = L; idx < 2 * NM * NE; idx += LT) {
             const int q = idx / (NM * NE), rem = idx - q * NM * NE;
             const int mat = rem / NE, e = rem - mat * NE;
+            if (mat == 2 * K + 3)
+                continue;                            // Xi Xt': filled below
             const int r = e % N, jl = e / N;
             const int i = (((r / NC) ^ q) * NC) + (r % NC), j = q * NC + jl;
             int src;
@@ -242,6 +244,20 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
             else                     src = (mat - K) * NN + i + j * N;           // Xi, Xt
             s_ops[idx] = ops[src];
         }
+    }
+    if (L < 2 * NE) {                                // Xi Xt' (unitary UnitaryGate fix-up), one entry per lane, from the global operators
+        const double2 *__restrict__ ops = ops_all + (size_t)kl * (K + 3) * NN;
+        const double2 *__restrict__ gXi = ops + (size_t)(1 + K) * NN, *__restrict__ gXt = gXi + NN;
+        const int q = L / NE, e = L - q * NE;
+        const int r = e % N, jl = e / N;
+        const int i = (((r / NC) ^ q) * NC) + (r % NC), j = q * NC + jl;
+        double sr = 0.0, si = 0.0;
+        for (int kk = 0; kk < N; ++kk) {
+            const double2 a = gXi[i + kk * N], b = gXt[j + kk * N];      // Xi[i,k] conj(Xt[j,k])
+            sr = fma(a.x, b.x, sr); sr = fma(a.y, b.y, sr);
+            si = fma(a.y, b.x, si); si = fma(-a.x, b.y, si);
+        }
+        s_ops[((size_t)q * NM + (2 * K + 3)) * NE + e] = make_double2(sr, si);
     }
     __syncthreads();
     if (L <= K) {                                    // one lane per generator: max column sum of |re| + |im|
@@ -265,6 +281,7 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
     const double2 *sXt = sXi + NE;
     const double2 *sXi_o = s_ops + (size_t)(1 - par) * NM * NE + (size_t)(1 + 2 * K) * NE;   // the partner's images
     const double2 *sXt_o = sXi_o + NE;
+    const double2 *sXX = sXt + NE, *sXX_o = sXt_o + NE;
     double *xg = s_xg + ch * (SK + 1);
     const size_t wbase = (size_t)k * S * NN * stride + ch;
     double2 *__restrict__ Pw = p.props + wbase;
@@ -423,11 +440,13 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
             __syncthreads();
             PMat<N> T, Tp, C0, xi_m, xi_o, xt_m, xt_o;
             pload_lds(T, &s_tot[1][wbase_tot][par * NE]);
-            pload_lds(Tp, &s_tot[1][wbase_tot][(1 - par) * NE]);
-            pload_lds(xi_m, sXi);
-            pload_lds(xi_o, sXi_o);
-            pload_lds(xt_m, sXt);
-            pload_lds(xt_o, sXt_o);
+            if (SAND) {
+                pload_lds(Tp, &s_tot[1][wbase_tot][(1 - par) * NE]);
+                pload_lds(xi_m, sXi);
+                pload_lds(xi_o, sXi_o);
+                pload_lds(xt_m, sXt);
+                pload_lds(xt_o, sXt_o);
+            }
             if (SAND) {
                 PMat<N> Em, Ep;
                 pmul(tmp, xt_m, xt_o, T);            // Xt T
@@ -442,10 +461,9 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
                     C0.im[e] -= tmp.im[e];
                 }
             } else {
-                pmul_a_bh(tmp, xi_m, xi_o, xt_m, xt_o);   // Xi Xt'
-                PMat<N> tp;
-                fetch_partner(tp, tmp);
-                pmul(C0, tmp, tp, T);
+                pload_lds(xi_m, sXX);                // Xi Xt', both halves prepared in the prologue
+                pload_lds(xi_o, sXX_o);
+                pmul(C0, xi_m, xi_o, T);
             }
             fetch_partner(ipar, inc);
             pmul(tmp, inc, ipar, C0);
@@ -689,7 +707,7 @@ size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool xg_in_lds
 {
     const int maxt = n == 2 ? PairTraits<2>::MAXT : PairTraits<4>::MAXT;
     size_t b = sizeof(double2) * (2 * (size_t)(maxt / 64) * n * n);
-    b += sizeof(double2) * ((size_t)MPB * 2 * (2 * K + 3) * (n * (n / 2)) + ((size_t)MPB * (K + 1) + 1) / 2);
+    b += sizeof(double2) * ((size_t)MPB * 2 * (2 * K + 4) * (n * (n / 2)) + ((size_t)MPB * (K + 1) + 1) / 2);
     if (xg_in_lds)
         b += sizeof(double) * ((size_t)MPB * (LT / 2) * ((size_t)S * K + 1) + ((MPB + 1) & ~1));
     if (plast)
