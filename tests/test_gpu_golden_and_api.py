@@ -214,3 +214,39 @@ def test_batched_evaluation(qoc, oracle, name, wkw, n_x, flow):
         F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, X[b], w.T)
         assert_parity(F[b], G[b], F_ref, G_ref, w.n, what=f"batch entry {b}")
     assert F1 == F[1] and np.array_equal(G1, G[1])
+
+
+def test_create_destroy_cycles_do_not_leak(qoc):
+    """contexts own device memory, pinned/mapped host buffers, a fine-grained BAR buffer, events and a stream:
+    create / evaluate / destroy cycles must leave the device's free memory where it started (RCCL communicators
+    are measured separately: the collective library keeps some state of its own per communicator)."""
+    import torch
+    w = qoc.workloads.config("C3", E=64, N=100)
+    wt = qoc.workloads.config("C4", E=4, N=20)
+
+    def cycle(flags=0, **kw):
+        for ww in (w, wt):
+            with qoc.GrapeEngine(ww.sys_type, ww.A, ww.B, ww.Xi, ww.Xt, ww.wts, ww.T, ww.N, flags=flags, **kw) as eng:
+                eng.eval(ww.x)
+
+    def free():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+    full = qoc.engine.FLAG_TIME_KERNELS | qoc.engine.FLAG_MEMBER_RESULTS | qoc.engine.FLAG_KEEP_COSTATES
+    cycle(force_collective=True)                          # loads librccl, creates its process-wide state
+    # the runtime itself takes memory in 16/32 MiB steps the first times a kernel runs on each of its hardware queues
+    # (code objects, scratch); streams rotate over those queues, so growth must be judged in the steady state: a leak
+    # in the library shows in every block of cycles, the runtime's one-time steps do not
+    growth = []
+    for block in range(4):
+        free0 = free()
+        for i in range(15):
+            cycle()
+            cycle(flags=full)
+        growth.append(free0 - free())
+    assert min(growth[1:]) < 2 ** 20 and sum(growth[1:]) < 80 * 2 ** 20, ("plain contexts leak", growth)
+    free1 = free()
+    for i in range(4):
+        cycle(force_collective=True)
+    free2 = free()
+    assert free1 - free2 < 64 * 2 ** 20, ("collective contexts leak beyond RCCL's own per-communicator state", free1, free2)
