@@ -79,6 +79,7 @@ struct grape_ctx {
     // host-visible completion of an evaluation: the final kernel's last workgroup publishes `seq` in h_flag
     unsigned long long *h_flag = nullptr, *d_h_flag = nullptr;
     unsigned *d_done_counter = nullptr;
+    bool direct_publish = true;                // GRAPE_DIRECT_PUBLISH=0: always go through the reduce kernel
     unsigned long long seq = 0;
     int x_upload = 1;             // 0: hipMemcpyAsync, 1: copy kernel reading the mapped staging buffer,
                                   // 2: the host writes x straight into fine-grained device memory (large BAR)
@@ -388,6 +389,10 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->d_h_flag, c->h_flag, 0);
     if (e == hipSuccess) { *c->h_flag = 0; e = alloc((void **)&c->d_done_counter, 64); }
     if (e == hipSuccess) e = hipMemset(c->d_done_counter, 0, 64);
+    {
+        const char *dp = std::getenv("GRAPE_DIRECT_PUBLISH");
+        c->direct_publish = !(dp && dp[0] == '0');
+    }
     {
         // x upload path.  Default: if the device exposes its memory to the CPU (large BAR), the host
         // writes x straight into a fine-grained device buffer -- no upload kernel, no kernel boundary;
@@ -828,6 +833,13 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     }
     const bool exact = c->cfg.gradient == GRAPE_GRADIENT_EXACT;
     if (exact) p.member_out = nullptr;                       // the sweep's first-order rows are not wanted
+    // one workgroup holds the whole ensemble (single problems): its row is [G, F], no reduce launch
+    const bool direct = c->family == 0 && c->NB == 1 && n_x == 1 && !exact && c->direct_publish;
+    if (direct) {
+        p.direct_dst = done.flag && done.host_out ? done.host_out : d_fg;
+        p.direct_flag = done.flag;
+        p.direct_seq = done.seq;
+    }
     if (c->family == 0) {
         const int mode = c->unitary ? 2 : (c->d_costates ? 1 : 0);
         if (c->pair)
@@ -863,6 +875,8 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     if (exact)
         HIP_TRY(c, grape::launch_reduce(c->d_member_out, c->d_wts, c->d_partial, d_fg, p.E, (int)(KN(c) + 1), c->ksplit,
                                         stream, done));
+    else if (direct)
+        ;                                                    // the sweep kernel has written [G, F] (and the flag)
     else if (c->family == 0)
         HIP_TRY(c, grape::launch_reduce_rows(c->d_block_out, d_fg, c->NB, (int)(KN(c) + 1), n_x, stream, done));
     else {

@@ -50,6 +50,12 @@ struct SweepParams {
     int32_t plast_lds;    // pair kernel, set by its launcher: every chunk's LAST propagator also stays in LDS, where
                           // the backward sweep (which starts with it) reads it instead of HBM
     double dt;
+    // single workgroup (BPX == 1, n_x == 1: the single-problem closure, src/solve.jl:63-143): its weighted row IS
+    // [G, F], so the sweep kernel writes it to `direct_dst` itself (device buffer or mapped host memory) and, when
+    // direct_flag is set, publishes direct_seq there -- no reduce launch.  nullptr: off
+    double *direct_dst;
+    unsigned long long *direct_flag;
+    unsigned long long direct_seq;
 };
 
 // sandwich == 0: UnitaryGate chain; 1: State/CoherenceTransfer sandwich chain.

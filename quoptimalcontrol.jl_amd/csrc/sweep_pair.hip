@@ -679,7 +679,15 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
                 acc = fma(v, wb[m], acc);
             }
             bout[q] = acc;
+            if (p.direct_dst)
+                p.direct_dst[q] = acc;
         }
+    }
+    if (p.direct_flag) {               // one workgroup: the result is complete, tell the host (reduce.hip: signal_done)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(p.direct_flag, p.direct_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     pstamp(st, 4);
     if (st && lane == 0) {

@@ -68,3 +68,28 @@ def test_repeated_evaluations_and_new_controls(qoc, oracle):
             F, G = eng.eval(x)
             F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, x, w.T)
             assert_parity(F, G, F_ref, G_ref, w.n)
+
+
+@pytest.mark.parametrize("n,E", [(2, 1), (3, 1), (4, 1), (4, 3), (2, 9)])
+def test_single_workgroup_publishes_without_reduce_launch(qoc, oracle, monkeypatch, n, E):
+    """an ensemble that fits ONE workgroup (single problems, src/solve.jl:63-143) has its weighted row written to the
+    destination by the sweep kernel itself; same bits as through the reduce kernel, host and device entry points."""
+    import torch
+    w = _problem(qoc, n, 3, 200, E, "StateTransfer", seed=400 + n + E)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GRAPE_DIRECT_PUBLISH", mode)
+        with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+            F, G = eng.eval(w.x)
+            F2, G2 = eng.eval(w.x)
+            xd = torch.as_tensor(np.ascontiguousarray(w.x.T), device="cuda")
+            fg = torch.zeros(w.K * w.N + 1, dtype=torch.float64, device="cuda")
+            eng.eval_device(xd.data_ptr(), fg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            h = fg.cpu().numpy()
+        assert F2 == F and np.array_equal(G, G2)
+        assert h[-1] == F and np.array_equal(h[:-1].reshape(w.N, w.K).T, G)
+        assert_parity(F, G, F_ref, G_ref, n, what=f"direct={mode}")
+        res[mode] = (F, G)
+    assert res["1"][0] == res["0"][0] and np.array_equal(res["1"][1], res["0"][1])
