@@ -296,47 +296,46 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
 
     // ---------------------------------------------------------------- phase A
     PMat<N> Q, Q2;
-    pset_identity(Q);
     // returns an upper bound of |G|_1 from the members' operator norms: |A'| + sum_c |x_c| |B'_c|
     auto build = [&](int j, PMat<N> &G) -> double {
+        // operator images are fetched one control ahead with clamped (always valid) indices: no branches around
+        // the LDS reads; an odd K adds one pass with x = 0
         double nb = s_nrm[0];
-        if (p.variant == 0) {
-#pragma unroll
-            for (int e = 0; e < NE; ++e) { G.re[e] = 0.0; G.im[e] = 0.0; }
-        } else {
-            pload_lds(G, sA);
-        }
         double2 b0[NE], b1[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e)
             b0[e] = sB[e];
+        if (p.variant != 0)
+            pload_lds(G, sA);
         for (int c = 0; c < K; c += 2) {
+            const int c1 = min(c + 1, K - 1), c2 = min(c + 2, K - 1);
             const double x0 = xg[j * K + c];
-            const double x1 = (c + 1 < K) ? xg[j * K + c + 1] : 0.0;
+            const double x1 = (c + 1 < K) ? xg[j * K + c1] : 0.0;
             nb = fma(fabs(x0), s_nrm[1 + c], nb);
-            if (c + 1 < K)
-                nb = fma(fabs(x1), s_nrm[2 + c], nb);
-            if (c + 1 < K) {
+            nb = fma(fabs(x1), s_nrm[1 + c1], nb);
 #pragma unroll
-                for (int e = 0; e < NE; ++e)
-                    b1[e] = sB[(c + 1) * NE + e];
-            }
-#pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                G.re[e] = fma(b0[e].x, x0, G.re[e]);
-                G.im[e] = fma(b0[e].y, x0, G.im[e]);
-            }
-            if (c + 1 < K) {
-                if (c + 2 < K) {
-#pragma unroll
-                    for (int e = 0; e < NE; ++e)
-                        b0[e] = sB[(c + 2) * NE + e];
-                }
+            for (int e = 0; e < NE; ++e)
+                b1[e] = sB[c1 * NE + e];
+            if (c == 0 && p.variant == 0) {          // (0 + B_1 x_1): the sum starts here, timeevolution.jl:101-108
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
-                    G.re[e] = fma(b1[e].x, x1, G.re[e]);
-                    G.im[e] = fma(b1[e].y, x1, G.im[e]);
+                    G.re[e] = b0[e].x * x0;
+                    G.im[e] = b0[e].y * x0;
                 }
+            } else {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    G.re[e] = fma(b0[e].x, x0, G.re[e]);
+                    G.im[e] = fma(b0[e].y, x0, G.im[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                b0[e] = sB[c2 * NE + e];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                G.re[e] = fma(b1[e].x, x1, G.re[e]);
+                G.im[e] = fma(b1[e].y, x1, G.im[e]);
             }
         }
         if (p.variant == 0) {
@@ -349,42 +348,57 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
         }
         return nb;
     };
-    auto finish = [&](int j, PMat<N> &G, double nb, const PMat<N> &Qin, PMat<N> &Qout) {
-        if (t0 + j < Nsl) {
-            PMat<N> P, Ppar;
-            if (GRAPE_ABL & 32) P = G; else
-            pexpm_t8<N, UNI>(P, G, p.s_forced, nb);
-            if (!(GRAPE_ABL & 2))
-            pstore_ws(Pw + (size_t)j * NN * stride, stride, P, par);
-            if (UNI && XGLDS && p.plast_lds && j == S - 1) {          // the backward sweep's first operand stays on chip
+    // one slice: P_t = exp(G), stored; chunk product Qout = P_t Qin (FIRST: the product starts from the identity)
+    auto slice = [&](int j, PMat<N> &G, double nb, const PMat<N> &Qin, PMat<N> &Qout, bool first) {
+        PMat<N> P, Ppar;
+        __builtin_amdgcn_sched_barrier(0);            // stages stay apart: one long basic block otherwise costs ~50 spilled VGPRs
+        if (GRAPE_ABL & 32) P = G; else
+        pexpm_t8<N, UNI>(P, G, p.s_forced, nb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(GRAPE_ABL & 2))
+        pstore_ws(Pw + (size_t)j * NN * stride, stride, P, par);
+        if (UNI && XGLDS && p.plast_lds && j == S - 1) {          // the backward sweep's first operand stays on chip
 #pragma unroll
-                for (int e = 0; e < NE; ++e)
-                    s_plast[e * blockDim.x + threadIdx.x] = make_double2(P.re[e], P.im[e]);
-            }
-            if (GRAPE_ABL & 4) { Qout = Qin; Qout.re[0] += P.re[1]; } else if (j == 0) {
-                Qout = P;                             // the chunk product starts from the identity: no product needed
-            } else {
-            fetch_partner(Ppar, P);
-            pmul(Qout, P, Ppar, Qin); }
-            if (MODE == PMODE_GENERAL)                // in-chunk prefix product, read back in phase D
-                pstore_ws(Xw + (size_t)j * NN * stride, stride, Qout, par);
-        } else {
-            Qout = Qin;
+            for (int e = 0; e < NE; ++e)
+                s_plast[e * blockDim.x + threadIdx.x] = make_double2(P.re[e], P.im[e]);
         }
+        if (GRAPE_ABL & 4) { Qout = Qin; Qout.re[0] += P.re[1]; } else if (first) {
+            Qout = P;
+        } else {
+            fetch_partner(Ppar, P);
+            pmul(Qout, P, Ppar, Qin);
+        }
+        if (MODE == PMODE_GENERAL)                    // in-chunk prefix product, read back in phase D
+            pstore_ws(Xw + (size_t)j * NN * stride, stride, Qout, par);
+        __builtin_amdgcn_sched_barrier(0);
     };
-    {
+    // every lane of this wave owns S slices inside the pulse (all waves but the last of a ragged decomposition):
+    // no validity branches, the chunk product ping-pongs between two register sets (peeling the first slice
+    // as well costs ~50 spilled VGPRs with this compiler).  Otherwise: the same steps under per-lane validity.
+    if (__all(t0 + S <= Nsl)) {
         PMat<N> G;
+        pset_identity(Q);
         int j = 0;
         for (; j + 1 < S; j += 2) {
             double nb = build(j, G);
-            finish(j, G, nb, Q, Q2);
+            slice(j, G, nb, Q, Q2, j == 0);
             nb = build(j + 1, G);
-            finish(j + 1, G, nb, Q2, Q);
+            slice(j + 1, G, nb, Q2, Q, false);
         }
         if (j < S) {
             const double nb = build(j, G);
-            finish(j, G, nb, Q, Q2);
+            slice(j, G, nb, Q, Q2, j == 0);
             Q = Q2;
+        }
+    } else {
+        PMat<N> G;
+        pset_identity(Q);
+        for (int j = 0; j < S; ++j) {
+            if (t0 + j < Nsl) {
+                const double nb = build(j, G);
+                slice(j, G, nb, Q, Q2, j == 0);
+                Q = Q2;
+            }
         }
     }
 
@@ -541,6 +555,18 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
         PMat<N> M = Xs, Mp, tmp, PA, PB, Pp;
         auto step = [&](int j, const PMat<N> &P) {
             const int t = t0 + j;
+            if ((GRAPE_ABL & 64) && t < Nsl) {           // loads only: no products, no gradient
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    M.re[e] += P.re[e];
+                    M.im[e] += P.im[e];
+                }
+                double acc = 0.0;
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    acc += M.re[e] + M.im[e];
+                if (par == 0) xg[j * K] = acc;
+            } else
             if (t < Nsl) {
                 fetch_partner(Pp, P);
                 fetch_partner(Mp, M);

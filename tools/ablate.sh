@@ -1,7 +1,7 @@
 #!/bin/bash
 # Diagnostic: build variants of libgrape_hip.so with parts of sweep_pair.hip cut out (GRAPE_ABL bitmask:
 # 1 no operator LDS reads in the H build, 2 no P store, 4 no chunk product, 8 no P load in the backward
-# sweep, 16 no gradient traces, 32 no expm) into build/abl/.  Results are WRONG on purpose; only the
+# sweep, 16 no gradient traces, 32 no expm, 64 backward sweep = loads only) into build/abl/.  Results are WRONG on purpose; only the
 # kernel time of `python bench.py --no-extra --no-cpu-baseline` with GRAPE_HIP_LIB=<variant> is read.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
