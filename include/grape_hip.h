@@ -150,6 +150,9 @@ typedef struct grape_info {
     int32_t lane_pair;             /* 1: the lane-pair small-n kernel (two lanes per time chunk, two waves per SIMD) */
     int32_t states_stored;         /* 1: grape_get_trajectory can return the forward states (after set_operators);
                                       0: the flow in use rebuilds them on the fly -- ask for GRAPE_FLAG_KEEP_COSTATES */
+    int32_t rank_one_chain;        /* 1 after grape_set_operators found rank-one states in the 9 <= n <= 16 family
+                                      (Xi = v v', Xt = w w' under the sandwich, or n x 1 states): the sweeps run on
+                                      vectors; GRAPE_FLAG_FORCE_GENERAL keeps the dense chain */
 } grape_info;
 
 /* Opaque RCCL bootstrap token (ncclUniqueId), see grape_comm_unique_id / grape_comm_attach. */

@@ -79,6 +79,10 @@ struct grape_ctx {
     // host-visible completion of an evaluation: the final kernel's last workgroup publishes `seq` in h_flag
     unsigned long long *h_flag = nullptr, *d_h_flag = nullptr;
     unsigned *d_done_counter = nullptr;
+    bool thin = false;                         // rank-one states: matrix-vector chain (sweep_thin.hip)
+    bool herm_ctrl = false;                    // every B_c Hermitian
+    double2 *d_vecs = nullptr;                 // thin: per member [v0 | wT], 16 complex each
+    size_t states_bytes = 0;                   // size of d_states (vector records are smaller than state dumps)
     bool direct_publish = true;                // GRAPE_DIRECT_PUBLISH=0: always go through the reduce kernel
     unsigned long long seq = 0;
     int x_upload = 1;             // 0: hipMemcpyAsync, 1: copy kernel reading the mapped staging buffer,
@@ -207,6 +211,7 @@ static void free_all(grape_ctx *c)
     if (c->h_fg) (void)hipHostFree(c->h_fg);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     (void)hipFree(c->d_done_counter);
+    (void)hipFree(c->d_vecs);
     (void)hipFree(c->d_x_bar);
     delete c;
 }
@@ -718,9 +723,98 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             }
         c->herm_states = hs;
     }
-    if (!herm && !c->d_states) {
-        c->bytes += sizeof(double2) * c->ws_elems * c->B;
-        HIP_TRY(c, hipMalloc((void **)&c->d_states, sizeof(double2) * c->ws_elems * c->B));
+    // Rank-one states in the single-tile family (n = 9..16): X_t = v_t v_t' (sandwich, Xi = v0 v0', Xt = wT wT') or
+    // X_t = v_t (left multiplication of n x 1 states) -- the chain runs on vectors (sweep_thin.hip).
+    // GRAPE_FLAG_FORCE_GENERAL / KEEP_COSTATES / the exact gradient keep the dense chain.
+    std::vector<double> vecs;
+    bool thin = c->family == 1 && c->NT == 1 && !c->pack2 && c->cfg.gradient != GRAPE_GRADIENT_EXACT &&
+                !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) && !std::getenv("GRAPE_NO_THIN");
+    if (thin) {
+        const bool sand = c->cfg.sys_type != GRAPE_UNITARY_GATE;
+        vecs.assign(E * 64, 0.0);
+        if (!sand) {
+            thin = c->m == 1;
+            for (size_t k = 0; k < E && thin; ++k)
+                for (int i = 0; i < n; ++i)
+                    for (int which = 0; which < 2; ++which) {
+                        const double *M = (which ? Xt : Xi) + 2 * k * nn;      // zero padded to n x n: column 0
+                        vecs[k * 64 + which * 32 + 2 * i] = M[2 * i];
+                        vecs[k * 64 + which * 32 + 2 * i + 1] = M[2 * i + 1];
+                    }
+        } else {
+            thin = c->m == n;
+            for (size_t k = 0; k < E && thin; ++k)
+                for (int which = 0; which < 2 && thin; ++which) {
+                    // M = u u' ?  u = M[:, j] / sqrt(M[j, j]) for the largest diagonal entry j
+                    const double *M = (which ? Xt : Xi) + 2 * k * nn;
+                    int jb = 0;
+                    double scale = 0.0;
+                    for (int j = 0; j < n; ++j) {
+                        if (M[2 * (j + j * n)] > M[2 * (jb + jb * n)]) jb = j;
+                        for (int i = 0; i < n; ++i)
+                            scale = std::fmax(scale, std::fmax(std::fabs(M[2 * (i + j * n)]), std::fabs(M[2 * (i + j * n) + 1])));
+                    }
+                    const double d = M[2 * (jb + jb * n)];
+                    if (!(d > 0.0) || std::fabs(M[2 * (jb + jb * n) + 1]) > 4e-16 * scale) { thin = false; break; }
+                    double *u = vecs.data() + k * 64 + which * 32;
+                    const double inv = 1.0 / std::sqrt(d);
+                    for (int i = 0; i < n; ++i) {                              // column jb: u_i conj(u_jb), u_jb real
+                        u[2 * i] = M[2 * (i + jb * n)] * inv;
+                        u[2 * i + 1] = M[2 * (i + jb * n) + 1] * inv;
+                    }
+                    double dev = 0.0;
+                    for (int j = 0; j < n; ++j)
+                        for (int i = 0; i < n; ++i) {
+                            const double pr = u[2 * i] * u[2 * j] + u[2 * i + 1] * u[2 * j + 1];      // u_i conj(u_j)
+                            const double pi = u[2 * i + 1] * u[2 * j] - u[2 * i] * u[2 * j + 1];
+                            dev = std::fmax(dev, std::fmax(std::fabs(pr - M[2 * (i + j * n)]), std::fabs(pi - M[2 * (i + j * n) + 1])));
+                        }
+                    if (!(dev <= 8e-16 * scale)) thin = false;
+                }
+        }
+    }
+    c->thin = thin;
+    {                                                        // Hermitian control operators?
+        bool hb = true;
+        for (size_t k = 0; k < E && hb; ++k)
+            for (size_t m = 0; m < K && hb; ++m) {
+                const double *M = B + 2 * (k * K + m) * nn;
+                double scale = 0.0, dev = 0.0;
+                for (int j = 0; j < n; ++j)
+                    for (int i = 0; i < n; ++i) {
+                        const double re = M[2 * (i + j * n)], im = M[2 * (i + j * n) + 1];
+                        const double tr = M[2 * (j + i * n)], ti = M[2 * (j + i * n) + 1];
+                        scale = std::fmax(scale, std::fmax(std::fabs(re), std::fabs(im)));
+                        dev = std::fmax(dev, std::fmax(std::fabs(re - tr), std::fabs(im + ti)));
+                    }
+                if (!(dev <= 4e-16 * scale)) hb = false;
+            }
+        c->herm_ctrl = hb;
+    }
+    if (thin) {
+        c->unitary = false;                                  // the thin chain serves Hermitian generators as well
+        if (!c->d_vecs) {
+            c->bytes += sizeof(double) * E * 64;
+            HIP_TRY(c, hipMalloc((void **)&c->d_vecs, sizeof(double) * E * 64));
+        }
+        HIP_TRY(c, hipMemcpy(c->d_vecs, vecs.data(), sizeof(double) * E * 64, hipMemcpyHostToDevice));
+        const size_t rec = sizeof(double2) * E * ((size_t)c->cfg.n_slices + 1) * 16 * c->B;
+        if (c->states_bytes < rec) {                         // the forward pass's vector records: N + 1 per member
+            (void)hipFree(c->d_states);
+            c->d_states = nullptr;
+            c->bytes += rec - c->states_bytes;
+            c->states_bytes = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_states, rec));
+            c->states_bytes = rec;
+        }
+    } else if (!herm && c->states_bytes < sizeof(double2) * c->ws_elems * c->B) {
+        const size_t full = sizeof(double2) * c->ws_elems * c->B;
+        (void)hipFree(c->d_states);
+        c->d_states = nullptr;
+        c->bytes += full - c->states_bytes;
+        c->states_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_states, full));
+        c->states_bytes = full;
     }
     if (c->dev_pending) {                                    // an evaluation may still run on a caller's stream
         HIP_TRY(c, hipEventSynchronize(c->ev_dev));
@@ -755,6 +849,9 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.dt = c->cfg.duration / c->cfg.n_slices;
     p.unitary = c->unitary ? 1 : 0;
     p.herm_states = c->herm_states ? 1 : 0;
+    p.thin = c->thin ? 1 : 0;
+    p.herm_ctrl = c->herm_ctrl ? 1 : 0;
+    p.vecs = c->d_vecs;
     return p;
 }
 
@@ -762,7 +859,7 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
 static bool states_stored(const grape_ctx *c)
 {
     if (c->d_costates) return true;                          // debug flow stores everything
-    if (c->family == 0 || c->unitary) return false;          // fast small-n flows / unitary flows rebuild them
+    if (c->family == 0 || c->unitary || c->thin) return false;   // fast small-n flows / unitary / rank-one flows rebuild them
     return !grape::tile_chain_is_split(tile_params(c, nullptr), false);
 }
 
@@ -1338,7 +1435,7 @@ extern "C" int grape_get_member_results(grape_ctx *c, double *foms, double *grad
 }
 
 // gathers one member's slab from the lane-major workspace layout into (n,n,count) col-major
-static int fetch_slab(grape_ctx *c, const double2 *d_ws, int member, cplx *out)
+static int fetch_slab(grape_ctx *c, const double2 *d_ws, int member, cplx *out, bool odd_transposed = false)
 {
     if (c->family == 1) {
         const size_t N = c->cfg.n_slices, TSZ = c->TSZ;
@@ -1352,7 +1449,8 @@ static int fetch_slab(grape_ctx *c, const double2 *d_ws, int member, cplx *out)
                 for (int J = 0; J < NT; ++J)
                     for (int r = 0; r < 4; ++r)
                         for (int l = 0; l < 64; ++l) {
-                            const int row = 16 * I + 4 * r + (l >> 4) - off, col = 16 * J + (l & 15) - off;
+                            int row = 16 * I + 4 * r + (l >> 4) - off, col = 16 * J + (l & 15) - off;
+                            if (odd_transposed && (t & 1)) std::swap(row, col);      // rank-one chain: P_t^T dumps
                             if (row >= 0 && col >= 0 && row < n && col < n)
                                 out[t * n * n + row + (size_t)n * col] =
                                     h[t * TSZ + (size_t)((I * NT + J) * 4 + r) * 64 + l];
@@ -1396,7 +1494,7 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
     const int n = c->cfg.n;
     const size_t nn = (size_t)n * n, N = c->cfg.n_slices, K = c->cfg.n_controls;
     std::vector<cplx> P(N * nn);
-    int rc = fetch_slab(c, c->d_props, member, P.data());
+    int rc = fetch_slab(c, c->d_props, member, P.data(), c->thin);
     if (rc) return rc;
     if (props) std::memcpy(props, P.data(), sizeof(cplx) * N * nn);
     // n x m states: the workspace holds them zero-padded to n x n; hand out the first m columns
@@ -1530,5 +1628,6 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
     if (c->is_group) info->unitary_flow = c->sub[0]->unitary ? 1 : 0;
     info->lane_pair = (c->is_group ? c->sub[0]->pair : c->pair) ? 1 : 0;
     info->states_stored = states_stored(c->is_group ? c->sub[0] : c) ? 1 : 0;
+    info->rank_one_chain = (c->is_group ? c->sub[0]->thin : c->thin) ? 1 : 0;
     return GRAPE_OK;
 }

@@ -91,8 +91,14 @@ struct TileParams {
     int32_t herm_states;  // every Xi, Xt Hermitian (density operators): [X, L'] = Y - Y' with one product
     int32_t split_at;     // set by the launcher: first slice of the second wave (chain_tile_split_kernel)
     int32_t n_x;          // control arrays evaluated by this launch (batched evaluation); x is (K, N, n_x)
+    int32_t thin;         // rank-one states (sweep_thin.hip): matrix-vector chain; the prop kernel then stores P_t
+                          // TRANSPOSED for odd t; `states` holds the forward pass's vector records (N + 1 per member)
+    int32_t herm_ctrl;    // every control operator B_c Hermitian (thin chain: one bilinear form per control)
+    const double2 *vecs;  // thin: per member [v0 | wT], 16 complex each, zero padded
     double dt;
 };
+// the chain over rank-one states (n = 9..16, one member per wavefront); called by launch_sweep_tile when p.thin
+hipError_t launch_chain_thin(int sandwich, const TileParams &p, hipStream_t stream);
 int tile_count(int n);    // NT for this n (0: not a tile-family size)
 hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
 bool tile_chain_is_split(const TileParams &p, bool keep_costates);   // the two-wave time-split chain: no full X_t store

@@ -174,6 +174,16 @@ __global__ __launch_bounds__(256) void prop_tile_kernel(const TileParams p)
         tmul_an<NT, false, false>(T, opa, P);
         P = T;
     }
+    if (NT == 1 && p.thin && (t & 1)) {
+        // rank-one chain (sweep_thin.hip): odd slices are stored transposed -- the A-operand layout of P is the
+        // D layout of P^T -- so that its matrix-vector products never convert between vector formats
+        to_a_layout(opa, P, img, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            P.re[0][0][r] = opa.re[0][0][r];
+            P.im[0][0][r] = opa.im[0][0][r];
+        }
+    }
     tstore(p.props + (((size_t)blockIdx.z * p.E + k) * p.N + t) * TSZ, P, lane);
   }
 }
@@ -702,7 +712,7 @@ static bool tile_chain_env(const char *what)                       // GRAPE_TILE
 // holds X_t only for the first part of the time axis and prefix products for the rest)
 bool tile_chain_is_split(const TileParams &p, bool keepl)
 {
-    return tile_count(p.n) == 1 && !p.pack2 && !keepl && !p.unitary && p.E < 2048 && p.N >= 4 &&
+    return tile_count(p.n) == 1 && !p.pack2 && !keepl && !p.unitary && !p.thin && p.E < 2048 && p.N >= 4 &&
            !tile_chain_env("1w");
 }
 
@@ -722,6 +732,8 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
+    if (NT == 1 && p.thin)
+        return launch_chain_thin(sandwich, p, stream);
     TileParams q = p;
     const size_t bt_bytes = sizeof(double2) * (size_t)p.K * NT * NT * 256;
     q.bt_in_lds = bt_bytes <= 36 * 1024 ? 1 : 0;                   // 4 waves per CU must still fit

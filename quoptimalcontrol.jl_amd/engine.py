@@ -64,7 +64,7 @@ class GrapeInfo(C.Structure):
                 ("expm_theta", C.c_double), ("workspace_bytes", C.c_uint64), ("arch", C.c_char * 32),
                 ("n_devices", C.c_int32), ("comm_size", C.c_int32), ("comm_rank", C.c_int32),
                 ("members_first_device", C.c_int32), ("lane_pair", C.c_int32),
-                ("states_stored", C.c_int32)]
+                ("states_stored", C.c_int32), ("rank_one_chain", C.c_int32)]
 
 
 class GrapeLbfgsOptions(C.Structure):
@@ -197,6 +197,16 @@ class GrapeEngine:
         self._F = C.c_double()
         self._check(self._lib.grape_set_operators(h, _p(_cm(A)), _p(_cm(B)), _p(_cm(Xi)), _p(_cm(Xt)),
                                                   _p(wts)))
+
+    def set_operators(self, A, B, Xi, Xt, wts):
+        """grape_set_operators again on the same context (same shapes): new members' operators, new states."""
+        A, B = np.asarray(A, np.complex128), np.asarray(B, np.complex128)
+        Xi, Xt = np.asarray(Xi, np.complex128), np.asarray(Xt, np.complex128)
+        wts = np.ascontiguousarray(wts, dtype=np.float64)
+        if A.shape != (self.E, self.n, self.n) or B.shape != (self.E, self.K, self.n, self.n) or \
+                Xi.shape != (self.E, self.n, self.m) or Xt.shape != Xi.shape or wts.shape != (self.E,):
+            raise ValueError("operator shapes must match the context")
+        self._check(self._lib.grape_set_operators(self._h, _p(_cm(A)), _p(_cm(B)), _p(_cm(Xi)), _p(_cm(Xt)), _p(wts)))
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):

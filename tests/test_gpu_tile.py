@@ -13,7 +13,9 @@ def _engine(qoc, w, **kw):
     return qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, member_results=True, **kw)
 
 
-def _random_problem(qoc, n, K, N, E, sys_type, seed, hermitian=True):
+def _random_problem(qoc, n, K, N, E, sys_type, seed, hermitian=True, mixed=False):
+    """mixed: full-rank density operators (pure states are rank one and run the matrix-vector chain for 9 <= n <= 16,
+    tests/test_gpu_thin.py; the dense chains need states that are not)."""
     rng = np.random.default_rng(seed)
 
     def rnd():
@@ -25,10 +27,13 @@ def _random_problem(qoc, n, K, N, E, sys_type, seed, hermitian=True):
         Xi = np.array([np.eye(n, dtype=complex)] * E)
         Xt = np.array([np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))[0] for _ in range(E)])
     else:
-        def rho():
+        def pure():
             v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
             v /= np.linalg.norm(v)
             return np.outer(v, v.conj())
+
+        def rho():
+            return 0.6 * pure() + 0.3 * pure() + 0.1 * pure() if mixed else pure()
         Xi = np.array([rho() for _ in range(E)])
         Xt = np.array([rho() for _ in range(E)])
     w = qoc.workloads.Workload("rnd", sys_type, n, K, N, E, 1.0, A, B, Xi, Xt, np.full(E, 1.0 / E),
@@ -65,13 +70,13 @@ def test_tile_family_random(qoc, oracle, n, sys_type, herm, variant):
 @pytest.mark.parametrize("variant", [0, 1])
 def test_tile_family_unitary_flow(qoc, oracle, n, sys_type, variant):
     """Hermitian generators: the chain kernel carries M_t = P' M P and stores no forward states."""
-    w = _random_problem(qoc, n, 3, 14, 3, sys_type, seed=300 + n, hermitian=True)
+    w = _random_problem(qoc, n, 3, 14, 3, sys_type, seed=300 + n, hermitian=True, mixed=True)
     F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
                                                             variant=variant, per_member=True)
     with _engine(qoc, w, variant=variant) as eng:
         F, G = eng.eval(w.x)
         foms, grads = eng.member_results()
-        assert eng.info["kernel_family"] == 1 and eng.info["unitary_flow"] == 1
+        assert eng.info["kernel_family"] == 1 and eng.info["unitary_flow"] == 1 and eng.info["rank_one_chain"] == 0
         with pytest.raises(qoc.GrapeError):
             eng.trajectory(0)                               # no stored states in this flow
     for k in range(w.E):
@@ -79,22 +84,27 @@ def test_tile_family_unitary_flow(qoc, oracle, n, sys_type, variant):
     assert_parity(F, G, F_ref, G_ref, w.n, what=f"n={n}")
 
 
-def test_many_controls(qoc, oracle):
+@pytest.mark.parametrize("mixed", [True, False])
+def test_many_controls(qoc, oracle, mixed):
     """K = 17 controls at n = 12: neither the generator tiles nor the transposed operators fit
-    their LDS caches, so both kernels take their global-memory paths."""
-    w = _random_problem(qoc, 12, 17, 9, 2, "StateTransfer", seed=5)
+    their LDS caches, so the kernels take their global-memory paths (dense chain, and the rank-one chain)."""
+    w = _random_problem(qoc, 12, 17, 9, 2, "StateTransfer", seed=5, mixed=mixed)
     F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
     with _engine(qoc, w) as eng:
+        assert eng.info["rank_one_chain"] == (0 if mixed else 1)
         F, G = eng.eval(w.x)
     assert_parity(F, G, F_ref, G_ref, w.n, what="K=17")
 
 
-def test_c4_liouvillian_parity(qoc, oracle):
-    """BASELINE config 4 at parity size: 16x16 Liouvillian superoperators, CoherenceTransfer, K=4, N=1000."""
+@pytest.mark.parametrize("dense", [False, True])
+def test_c4_liouvillian_parity(qoc, oracle, dense):
+    """BASELINE config 4 at parity size: 16x16 Liouvillian superoperators, CoherenceTransfer, K=4, N=1000.  Its states
+    vec(rho) vec(rho)' are rank one: the default is the matrix-vector chain; dense = the MFMA chain on the same inputs."""
     w = qoc.workloads.config("C4", E=6)
     F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
                                                             per_member=True)
-    with _engine(qoc, w) as eng:
+    with _engine(qoc, w, flags=qoc.engine.FLAG_FORCE_GENERAL if dense else 0) as eng:
+        assert eng.info["rank_one_chain"] == (0 if dense else 1)
         F, G = eng.eval(w.x)
         foms, grads = eng.member_results()
     for k in range(w.E):
@@ -138,13 +148,15 @@ print("ok")
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("name,E,members", [("C4", 1024, (0, 1, 511, 1023)), ("C5", 1024, (0, 1023))])
-def test_full_size_spot_members(qoc, oracle, name, E, members):
+@pytest.mark.parametrize("name,E,members,dense", [("C4", 1024, (0, 1, 511, 1023), False), ("C4", 1024, (0, 1023), True),
+                                                  ("C5", 1024, (0, 1023), False)])
+def test_full_size_spot_members(qoc, oracle, name, E, members, dense):
     """Full BASELINE sizes (C4: E = 1024, N = 1000 -- the two-wave chain kernel the bench runs; C5: E = 1024 of
     4096, N = 2000, the unitary tile flow): spot members against the oracle, the weighted sum, reproducibility.
     The small-E parity tests above take different launch branches (E < 2048, pack2, LDS fit)."""
     w = qoc.workloads.config(name, E=E)
-    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N,
+                         flags=qoc.engine.FLAG_FORCE_GENERAL if dense else 0) as eng:
         F, G = eng.eval(w.x)
         foms, grads = eng.member_results()
         F2, G2 = eng.eval(w.x)
@@ -162,6 +174,7 @@ def test_c4_survey_target_ensemble_metric(qoc, oracle):
     by the generic-target case above)."""
     w = qoc.workloads.config("C4", E=12, N=1000, target="survey")
     F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, n_threads=8)
-    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
-        F, G = eng.eval(w.x)
-    assert_parity(F, G, F_ref, G_ref, w.n, what="C4 survey target, ensemble")
+    for flags in (0, qoc.engine.FLAG_FORCE_GENERAL):
+        with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, flags=flags) as eng:
+            F, G = eng.eval(w.x)
+        assert_parity(F, G, F_ref, G_ref, w.n, what=f"C4 survey target, ensemble (flags {flags})")
