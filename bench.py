@@ -101,11 +101,14 @@ def roofline(local, info, kern_ms, kern_n, evals_per_s, n_gpus, traffic):
     avg_ms = kern_ms / max(kern_n, 1)
     sec = avg_ms * 1e-3
     uni = bool(info.get("unitary_flow"))
+    thin = bool(info.get("rank_one_chain"))
     alg_bytes, alg_flops = local.algorithmic_bytes, local.algorithmic_flops
-    flow_bytes, flow_flops = local.flow_bytes(uni), local.flow_flops(uni)
+    flow_bytes, flow_flops = local.flow_bytes(uni, thin), local.flow_flops(uni, thin)
     gbs = alg_bytes / sec / 1e9 if sec > 0 else 0.0
     tfs = alg_flops / sec / 1e12 if sec > 0 else 0.0
-    flow = {"name": "unitary (P_t only)" if uni else "general (model S)", "bytes_per_launch": flow_bytes,
+    flow = {"name": "rank-one states: MFMA expm, then a matrix-vector chain (P_t written once, read twice)" if thin
+                    else ("unitary (P_t only)" if uni else "general (model S)"),
+            "bytes_per_launch": flow_bytes,
             "achieved_GBs": flow_bytes / sec / 1e9 if sec > 0 else 0.0,
             "frac_hbm": flow_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else 0.0,
             "flops_per_launch": flow_flops,
@@ -114,7 +117,8 @@ def roofline(local, info, kern_ms, kern_n, evals_per_s, n_gpus, traffic):
     if info.get("kernel_family") == 1:            # n > 4: FP64 matrix-core kernels, compute-bound
         roof = {"bound": "mfma", "achieved": tfs, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tfs / FP64_PEAK_TFLOPS, "traffic": traffic,
-                "kernel": "prop_tile_kernel + chain_tile*_kernel", "algorithmic_flops_per_launch": alg_flops,
+                "kernel": "prop_tile_kernel + " + ("chain_thin_kernel" if thin else "chain_tile*_kernel"),
+                "algorithmic_flops_per_launch": alg_flops,
                 "end_to_end_frac": alg_flops * evals_per_s / 1e12 / FP64_PEAK_TFLOPS}
     else:
         roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -146,10 +150,14 @@ def time_blocks(step, steps, blocks, barrier, reduce_max):
 
 
 def run_extra_config(qoc, name, dev_index, steps, warmup):
-    """One more BASELINE config on this GPU, host -> host, with its own roofline (N = 1 only)."""
-    w = qoc.workloads.config(name)
+    """One more BASELINE config on this GPU, host -> host, with its own roofline (N = 1 only).
+    "C4dense": C4 through the dense MFMA chain (GRAPE_FLAG_FORCE_GENERAL) instead of the rank-one vector chain its
+    vec(rho) vec(rho)' states allow."""
+    dense = name.endswith("dense")
+    cfg_name = name[:-5] if dense else name
+    w = qoc.workloads.config(cfg_name)
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, device=dev_index,
-                         flags=qoc.engine.FLAG_TIME_KERNELS) as eng:
+                         flags=qoc.engine.FLAG_TIME_KERNELS | (qoc.engine.FLAG_FORCE_GENERAL if dense else 0)) as eng:
         import numpy as np
         xf = np.ascontiguousarray(w.x.T)
         call = eng.bind_eval(xf, np.empty_like(xf))           # the same copy-free host->host call as the headline step
@@ -163,7 +171,8 @@ def run_extra_config(qoc, name, dev_index, steps, warmup):
         kern_ms, kern_n = eng.kernel_time()
         info = eng.info
     evals = steps / el
-    return {"workload": f"{name}: {w.sys_type} {w.n}x{w.n}, K={w.K}, N={w.N}, E={w.E}, host->host grape_eval",
+    return {"workload": f"{name}: {w.sys_type} {w.n}x{w.n}, K={w.K}, N={w.N}, E={w.E}, host->host grape_eval"
+                        + (" (dense chain forced)" if dense else ""),
             "value": evals, "unit": "gradient-evals/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
             "member_evals_per_s": evals * w.E, "F": F,
             "roofline": roofline(w, info, kern_ms, kern_n, evals, 1, None)}
@@ -236,7 +245,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the device-resident loop and the extra configs")
-    ap.add_argument("--extra-configs", default="C2,C4,C5")
+    ap.add_argument("--extra-configs", default="C2,C4,C4dense,C5")
     ap.add_argument("--backend", default="",
                     help="torch.distributed backend; default: gloo as the control plane when the data-path collective "
                          "is RCCL inside the library (--collective lib), cpu:gloo,cuda:nccl for --collective torch")
@@ -400,7 +409,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra and args.extra_configs:
         out["extra_configs"] = []
         for name in [s for s in args.extra_configs.split(",") if s and s != args.config]:
-            heavy = name in ("C4", "C5")
+            heavy = name in ("C4", "C4dense", "C5")
             try:
                 out["extra_configs"].append(run_extra_config(qoc, name, dev_index, 3 if name == "C5" else (20 if heavy else 200),
                                                              1 if name == "C5" else (3 if heavy else 20)))

@@ -34,7 +34,11 @@ namespace grape {
 
 namespace {
 
-constexpr int kRing = 4;          // slices of P in flight per wave (4 KB each)
+#ifndef GRAPE_THIN_ABL
+#define GRAPE_THIN_ABL 0      // diagnostic ablations: 1 no backward pass, 2 no bilinear forms, 4 no P loads in the backward pass, 8 forward pass = streaming only
+#endif
+constexpr int kRing = 4;          // backward pass: slices of P in flight per wave (4 KB each)
+constexpr int kRingF = 8;         // forward pass (one wave per member runs it alone)
 
 // sum over the 16 lanes of a DPP row (lanes sharing l >> 4), result in every lane: rotations by 8, 4, 2, 1
 template <int M>
@@ -58,20 +62,80 @@ GRAPE_DEV void row_sum_n(double (&v)[M])
 #undef GRAPE_ROR_STEP
 }
 
+// v = a + b after exchanging halves: v_permlane32_swap / v_permlane16_swap (gfx950) trade the upper half (odd
+// rows) of the first register for the lower half (even rows) of the second, so with (a, b) = (lower-index value,
+// upper-index value) the sum of the two results is, in every lane, own + partner of the value that lane KEEPS
+// (lanes 0..31 / even rows keep a, the others b): one step of a reduce-scatter without selects.  With a == b it
+// is a plain all-reduce step.
+GRAPE_DEV double swap32_add(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+GRAPE_DEV double swap16_add(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
 // sum over the 4 rows (lanes sharing l & 15), result in every lane
 template <int M>
 GRAPE_DEV void col_sum_n(double (&v)[M])
 {
 #pragma unroll
-    for (int d = 16; d <= 32; d <<= 1) {
-        double o[M];
+    for (int m = 0; m < M; ++m)
+        v[m] = swap16_add(v[m], v[m]);
 #pragma unroll
-        for (int m = 0; m < M; ++m)
-            o[m] = __shfl_xor(v[m], d, 64);
+    for (int m = 0; m < M; ++m)
+        v[m] = swap32_add(v[m], v[m]);
+}
+
+// one DPP-masked step of the reduce-scatter inside a row of 16 lanes: lanes whose bank (group of 4 lanes) is in
+// UPPER keep b, the others a; partners by the DPP control CTRL (row_ror:8 pairs l with l ^ 8, row_half_mirror
+// pairs l with 7 - l inside each group of 8: one lane on either side of bit 2)
+template <int CTRL, int UPPER>
+GRAPE_DEV double dpp_pair_add(double a, double b)
+{
+    constexpr int LOWER = 0xF & ~UPPER;
+    int klo = __double2loint(a), khi = __double2hiint(a);                 // kept value: a, or b in the upper banks
+    klo = __builtin_amdgcn_update_dpp(klo, __double2loint(b), 0xE4, 0xF, UPPER, false);      // quad_perm [0,1,2,3]
+    khi = __builtin_amdgcn_update_dpp(khi, __double2hiint(b), 0xE4, 0xF, UPPER, false);
+    int rlo = 0, rhi = 0;                                                 // the partner's value of the same index
+    rlo = __builtin_amdgcn_update_dpp(rlo, __double2loint(a), CTRL, 0xF, LOWER, false);
+    rhi = __builtin_amdgcn_update_dpp(rhi, __double2hiint(a), CTRL, 0xF, LOWER, false);
+    rlo = __builtin_amdgcn_update_dpp(rlo, __double2loint(b), CTRL, 0xF, UPPER, false);
+    rhi = __builtin_amdgcn_update_dpp(rhi, __double2hiint(b), CTRL, 0xF, UPPER, false);
+    return __hiloint2double(khi, klo) + __hiloint2double(rhi, rlo);
+}
+
+template <int CTRL>
+GRAPE_DEV double dpp_quad_add(double a)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), CTRL, 0xF, 0xF, true);
+    return a + __hiloint2double(hi, lo);
+}
+
+// 16 values per lane in, the wave-wide sum of value number (lane >> 2) out (in all four lanes of that quad):
+// a reduce-scatter -- 8 + 4 + 2 + 1 pair steps and two quad steps, 17 additions instead of 16 x 6.
+GRAPE_DEV double reduce_scatter16(const double (&v)[16])
+{
+    double a[8], b[4], c[2];
 #pragma unroll
-        for (int m = 0; m < M; ++m)
-            v[m] += o[m];
-    }
+    for (int i = 0; i < 8; ++i)
+        a[i] = swap32_add(v[i], v[i + 8]);                // lanes >= 32 keep values 8..15
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        b[i] = swap16_add(a[i], a[i + 4]);                // odd rows keep the upper four of their eight
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        c[i] = dpp_pair_add<0x128, 0xC>(b[i], b[i + 2]);  // row_ror:8; banks 2, 3 (lane bit 3) keep the upper two
+    double d = dpp_pair_add<0x141, 0xA>(c[0], c[1]);      // row_half_mirror; banks 1, 3 (lane bit 2) keep the upper one
+    d = dpp_quad_add<0x4E>(d);                            // quad_perm [2,3,0,1]
+    d = dpp_quad_add<0xB1>(d);                            // quad_perm [1,0,3,2]
+    return d;
 }
 
 struct Tile1 {                    // one 16 x 16 D-layout dump: 4 complex per lane
@@ -92,27 +156,35 @@ GRAPE_DEV void load_tile(Tile1 &m, const double2 *__restrict__ src, int lane)
 
 // SAND: sandwich formulas (State/CoherenceTransfer), else left multiplication (UnitaryGate, n x 1 states).
 // HERMB: every control operator is Hermitian, so b = conj(a) (sandwich only; left multiplication needs a alone).
-template <int SAND, bool HERMB>
+// INLDS: the member's 2K operator dumps are staged in LDS (else read from global memory / L2 every slice) -- a
+// template parameter, not a run-time branch: merged code would wait for ALL vector-memory operations (the
+// propagator prefetches too) before every form.
+// Both passes keep a ring of propagator tiles in flight.  The steady-state loops contain no branch around a
+// load and no per-slice bounds check (prefetch indices are clamped, the ragged group of slices is handled apart):
+// only then does the compiler's s_waitcnt placement wait for the OLDEST tile instead of draining the ring.
+template <int U>
+struct IC {
+    static constexpr int value = U;
+};
+
+template <int SAND, bool HERMB, bool INLDS>
 __global__ __launch_bounds__(64) void chain_thin_kernel(const TileParams p)
 {
     constexpr int TSZ = 256;
-    extern __shared__ double2 s_thin[];           // (bt_in_lds) this member's [B_c | B_c^T] dumps
+    extern __shared__ double2 s_thin[];           // (INLDS) this member's [B_c | B_c^T] dumps
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     const int k = blockIdx.x;
     const int K = p.K, N = p.N;
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
     const double2 *__restrict__ opB = ops + TSZ;                 // B_c at opB + c TSZ, B_c^T at opB + (K + c) TSZ
-    const bool in_lds = p.bt_in_lds != 0;
-    if (in_lds) {
+    if (INLDS) {
         for (int i = lane; i < 2 * K * TSZ; i += 64)
             s_thin[i] = opB[i];
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
-    // one operator dump: LDS and global memory keep their own address spaces (a generic pointer would turn these
-    // into flat loads, whose completion also waits for the propagator prefetches in flight)
     auto load_op = [&](Tile1 &m, int idx) {
-        if (in_lds)
+        if (INLDS)
             load_tile(m, s_thin + (size_t)idx * TSZ, lane);
         else
             load_tile(m, opB + (size_t)idx * TSZ, lane);
@@ -122,14 +194,14 @@ __global__ __launch_bounds__(64) void chain_thin_kernel(const TileParams p)
     double2 *__restrict__ V = p.states + kw * (size_t)(N + 1) * 16;       // records v_0 .. v_N, 16 complex each
     const double2 *__restrict__ v0 = p.vecs + (size_t)k * 32, *__restrict__ wT = v0 + 16;
     double *__restrict__ out = p.member_out + ((size_t)blockIdx.y * p.E_members + k) * ((size_t)K * N + 1);
+    const int sel = c & 3;                        // which of a lane's four gathered entries it writes to a record
 
     // ------------------------------------------------------------------ forward: v_{t+1} = P_t v_t
     {
-        Tile1 Pq[kRing];
+        Tile1 Pq[kRingF];
 #pragma unroll
-        for (int u = 0; u < kRing; ++u)
-            if (u < N)
-                load_tile(Pq[u], Pk + (size_t)u * TSZ, lane);
+        for (int u = 0; u < kRingF; ++u)
+            load_tile(Pq[u], Pk + (size_t)min(u, N - 1) * TSZ, lane);
         double vr, vi;                            // per-column format
         {
             const double2 t = v0[c];
@@ -137,53 +209,75 @@ __global__ __launch_bounds__(64) void chain_thin_kernel(const TileParams p)
             vi = t.y;
         }
         double y[8];                              // gathered format: re/im of x[4r + g]
-        for (int base = 0; base < N; base += kRing) {
 #pragma unroll
-            for (int u = 0; u < kRing; ++u) {
-                const int t = base + u;
-                if (t < N) {
-                    const Tile1 P = Pq[u];
-                    if (t + kRing < N)
-                        load_tile(Pq[u], Pk + (size_t)(t + kRing) * TSZ, lane);
-                    if ((u & 1) == 0) {           // even t: D layout of P, reg r = P[4r + g][c]
-                        if (g == 0)
-                            V[(size_t)t * 16 + c] = make_double2(vr, vi);
+        for (int e = 0; e < 8; ++e)
+            y[e] = 0.0;
+        // every lane stores entry (c & 3) of its four gathered ones (4 lanes per entry: no branch, same data); the pick
+        // is arithmetic (0/1 weights) -- a ternary chain on the lane index becomes an indexed array in scratch memory
+        const double m0 = sel == 0 ? 1.0 : 0.0, m1 = sel == 1 ? 1.0 : 0.0, m2 = sel == 2 ? 1.0 : 0.0, m3 = sel == 3 ? 1.0 : 0.0;
+        auto record_gathered = [&](int t) {
+            const double sr = fma(m3, y[6], fma(m2, y[4], fma(m1, y[2], m0 * y[0])));
+            const double si = fma(m3, y[7], fma(m2, y[5], fma(m1, y[3], m0 * y[1])));
+            V[(size_t)t * 16 + 4 * sel + g] = make_double2(sr, si);
+        };
+        auto step = [&](auto uc, int t) {
+            constexpr int u = decltype(uc)::value;
+            const Tile1 P = Pq[u];
+            load_tile(Pq[u], Pk + (size_t)min(t + kRingF, N - 1) * TSZ, lane);
+            if (GRAPE_THIN_ABL & 8) {             // streaming only
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            y[2 * r] = fma(P.re[r], vr, -P.im[r] * vi);
-                            y[2 * r + 1] = fma(P.re[r], vi, P.im[r] * vr);
-                        }
-                        row_sum_n(y);
-                    } else {                      // odd t: D layout of P^T, reg r = P[c][4r + g]
-                        if (c < 4) {
-                            const double sr = c == 0 ? y[0] : (c == 1 ? y[2] : (c == 2 ? y[4] : y[6]));
-                            const double si = c == 0 ? y[1] : (c == 1 ? y[3] : (c == 2 ? y[5] : y[7]));
-                            V[(size_t)t * 16 + 4 * c + g] = make_double2(sr, si);
-                        }
-                        double acc[2] = {0.0, 0.0};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            acc[0] = fma(P.re[r], y[2 * r], acc[0]);
-                            acc[0] = fma(-P.im[r], y[2 * r + 1], acc[0]);
-                            acc[1] = fma(P.re[r], y[2 * r + 1], acc[1]);
-                            acc[1] = fma(P.im[r], y[2 * r], acc[1]);
-                        }
-                        col_sum_n(acc);
-                        vr = acc[0];
-                        vi = acc[1];
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    vr += P.re[r];
+                    vi += P.im[r];
                 }
+            } else
+            if ((u & 1) == 0) {                   // even t: D layout of P, reg r = P[4r + g][c]
+                V[(size_t)t * 16 + c] = make_double2(vr, vi);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y[2 * r] = fma(P.re[r], vr, -P.im[r] * vi);
+                    y[2 * r + 1] = fma(P.re[r], vi, P.im[r] * vr);
+                }
+                row_sum_n(y);
+            } else {                              // odd t: D layout of P^T, reg r = P[c][4r + g]
+                record_gathered(t);
+                double acc[2] = {0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[0] = fma(P.re[r], y[2 * r], acc[0]);
+                    acc[0] = fma(-P.im[r], y[2 * r + 1], acc[0]);
+                    acc[1] = fma(P.re[r], y[2 * r + 1], acc[1]);
+                    acc[1] = fma(P.im[r], y[2 * r], acc[1]);
+                }
+                col_sum_n(acc);
+                vr = acc[0];
+                vi = acc[1];
             }
+        };
+        int base = 0;
+        for (; base + kRingF <= N; base += kRingF) {
+            step(IC<0>(), base);
+            step(IC<1>(), base + 1);
+            step(IC<2>(), base + 2);
+            step(IC<3>(), base + 3);
+            step(IC<4>(), base + 4);
+            step(IC<5>(), base + 5);
+            step(IC<6>(), base + 6);
+            step(IC<7>(), base + 7);
         }
+        static_assert(kRingF == 8, "unrolled by hand");
+        if (base + 0 < N) step(IC<0>(), base);
+        if (base + 1 < N) step(IC<1>(), base + 1);
+        if (base + 2 < N) step(IC<2>(), base + 2);
+        if (base + 3 < N) step(IC<3>(), base + 3);
+        if (base + 4 < N) step(IC<4>(), base + 4);
+        if (base + 5 < N) step(IC<5>(), base + 5);
+        if (base + 6 < N) step(IC<6>(), base + 6);
         // v_N: after an odd last slice it is in per-column format, after an even one gathered
-        if ((N & 1) == 0) {
-            if (g == 0)
-                V[(size_t)N * 16 + c] = make_double2(vr, vi);
-        } else if (c < 4) {
-            const double sr = c == 0 ? y[0] : (c == 1 ? y[2] : (c == 2 ? y[4] : y[6]));
-            const double si = c == 0 ? y[1] : (c == 1 ? y[3] : (c == 2 ? y[5] : y[7]));
-            V[(size_t)N * 16 + 4 * c + g] = make_double2(sr, si);
-        }
+        if ((N & 1) == 0)
+            V[(size_t)N * 16 + c] = make_double2(vr, vi);
+        else
+            record_gathered(N);
     }
     // the records were written by other lanes of this wave than the ones that read them back
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // stores drained, vector L1 invalidated
@@ -205,10 +299,12 @@ __global__ __launch_bounds__(64) void chain_thin_kernel(const TileParams p)
 
     // ------------------------------------------------------------------ backward: w_t = P_t' w_{t+1}, gradient
     {
+        static_assert(kRing == 4, "the gradient reduction batches the four slices of a ring pass");
         Tile1 Pq[kRing];
         double vq[kRing][8];                      // v_t records in the format slice t needs (even: gathered, odd: per-column)
         const int top = (N - 1) & ~(kRing - 1);
-        auto load_v = [&](int u, int t) {
+        auto load_v = [&](auto uc, int t) {
+            constexpr int u = decltype(uc)::value;
             if ((u & 1) == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -222,27 +318,25 @@ __global__ __launch_bounds__(64) void chain_thin_kernel(const TileParams p)
                 vq[u][1] = t2.y;
             }
         };
-#pragma unroll
-        for (int u = 0; u < kRing; ++u) {         // the last kRing slices: t = N-1 .. N-kRing, slot t & 3
-            const int t = N - 1 - u;
-            if (t >= 0) {
-                // slot of slice t is t & (kRing - 1): static only inside the unrolled sub-step loops below, so fill
-                // the ring through a switch on the (uniform) slot
-                const int slot = t & (kRing - 1);
-#pragma unroll
-                for (int q = 0; q < kRing; ++q)
-                    if (q == slot) {
-                        load_tile(Pq[q], Pk + (size_t)t * TSZ, lane);
-                        load_v(q, t);
-                    }
-            }
-        }
+        auto fill = [&](auto uc) {                // slot u first serves the largest t < N with t & 3 == u
+            constexpr int u = decltype(uc)::value;
+            const int t = max(top + u < N ? top + u : top + u - kRing, 0);
+            load_tile(Pq[u], Pk + (size_t)t * TSZ, lane);
+            load_v(uc, t);
+        };
+        fill(IC<0>());
+        fill(IC<1>());
+        fill(IC<2>());
+        fill(IC<3>());
         double wr = 0.0, wi = 0.0;                // per-column format
         double w4[8];                             // gathered format
         if ((N - 1) & 1) {                        // last slice odd: its input format is per-column
             const double2 t2 = wT[c];
             wr = t2.x;
             wi = t2.y;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                w4[e] = 0.0;
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -251,125 +345,150 @@ __global__ __launch_bounds__(64) void chain_thin_kernel(const TileParams p)
                 w4[2 * r + 1] = t2.y;
             }
         }
-        for (int base = top; base >= 0; base -= kRing) {
+        double q16[16];                           // [slice base + u][control slot i]: per-lane partial of g
+        auto step = [&](auto uc, int t) {
+            constexpr int u = decltype(uc)::value;
+            const Tile1 P = Pq[u];
+            double vt[8];
 #pragma unroll
-            for (int u = kRing - 1; u >= 0; --u) {
-                const int t = base + u;
-                if (t < N) {
-                    const Tile1 P = Pq[u];
-                    double vt[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        vt[e] = vq[u][e];
-                    if (t - kRing >= 0) {
-                        load_tile(Pq[u], Pk + (size_t)(t - kRing) * TSZ, lane);
-                        load_v(u, t - kRing);
-                    }
-                    double q4[4] = {0.0, 0.0, 0.0, 0.0};
-                    if ((u & 1) == 0) {
-                        // even t: reg r = P[4r + g][c];  w_t[c] = sum conj(P[4r+g][c]) w[4r+g]: gathered in, per-column out
-                        double acc[2] = {0.0, 0.0};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            acc[0] = fma(P.re[r], w4[2 * r], acc[0]);
-                            acc[0] = fma(P.im[r], w4[2 * r + 1], acc[0]);
-                            acc[1] = fma(P.re[r], w4[2 * r + 1], acc[1]);
-                            acc[1] = fma(-P.im[r], w4[2 * r], acc[1]);
-                        }
-                        col_sum_n(acc);
-                        wr = acc[0];
-                        wi = acc[1];
-                        // forms: w per-column, v gathered.  a = sum_{i,j} conj(w[i]) B[i][j] v[j] with the B^T dump
-                        // (reg r = B[c][4r + g]);  b = sum conj(v[i]) B[i][j] w[j] with the B dump (reg r = B[4r + g][c])
-                        for (int cc = 0; cc < K; ++cc) {
-                            Tile1 BT;
-                            load_op(BT, K + cc);
-                            double ur = 0.0, ui = 0.0;                 // sum_r B[c][4r+g] v[4r+g]
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                ur = fma(BT.re[r], vt[2 * r], ur);
-                                ur = fma(-BT.im[r], vt[2 * r + 1], ur);
-                                ui = fma(BT.re[r], vt[2 * r + 1], ui);
-                                ui = fma(BT.im[r], vt[2 * r], ui);
-                            }
-                            const double ar = wr * ur + wi * ui, ai = wr * ui - wi * ur;      // conj(w[c]) u
-                            double val = s_re * ai - s_im * ar;                                // Im(conj(s) a)
-                            if (SAND && !HERMB) {
-                                Tile1 Bm;
-                                load_op(Bm, cc);
-                                double xr = 0.0, xi = 0.0;             // sum_r conj(v[4r+g]) B[4r+g][c]
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    xr = fma(vt[2 * r], Bm.re[r], xr);
-                                    xr = fma(vt[2 * r + 1], Bm.im[r], xr);
-                                    xi = fma(vt[2 * r], Bm.im[r], xi);
-                                    xi = fma(-vt[2 * r + 1], Bm.re[r], xi);
-                                }
-                                const double br = xr * wr - xi * wi, bi = xr * wi + xi * wr;  // (..) w[c]
-                                val -= s_re * bi + s_im * br;                                  // - Im(s b)
-                            }
-                            if (cc < 4) q4[cc] = val; else { /* more than four controls: reduced one by one below */
-                                double one[1] = {val};
-                                row_sum_n(one);
-                                col_sum_n(one);
-                                if (lane == 0) out[cc + (size_t)t * K] = gs * one[0];
-                            }
-                        }
-                    } else {
-                        // odd t: reg r = P[c][4r + g];  w_t[4r+g] = sum_c conj(P[c][4r+g]) w[c]: per-column in, gathered out
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            w4[2 * r] = fma(P.re[r], wr, P.im[r] * wi);
-                            w4[2 * r + 1] = fma(P.re[r], wi, -P.im[r] * wr);
-                        }
-                        row_sum_n(w4);
-                        // forms: w gathered, v per-column.  a with the B dump (reg r = B[4r + g][c]);  b with the B^T dump
-                        const double vcr = vt[0], vci = vt[1];
-                        for (int cc = 0; cc < K; ++cc) {
-                            Tile1 Bm;
-                            load_op(Bm, cc);
-                            double ur = 0.0, ui = 0.0;                 // sum_r conj(w[4r+g]) B[4r+g][c]
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                ur = fma(w4[2 * r], Bm.re[r], ur);
-                                ur = fma(w4[2 * r + 1], Bm.im[r], ur);
-                                ui = fma(w4[2 * r], Bm.im[r], ui);
-                                ui = fma(-w4[2 * r + 1], Bm.re[r], ui);
-                            }
-                            const double ar = ur * vcr - ui * vci, ai = ur * vci + ui * vcr;  // (..) v[c]
-                            double val = s_re * ai - s_im * ar;
-                            if (SAND && !HERMB) {
-                                Tile1 BT;
-                                load_op(BT, K + cc);
-                                double xr = 0.0, xi = 0.0;             // sum_r B[c][4r+g] w[4r+g]
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    xr = fma(BT.re[r], w4[2 * r], xr);
-                                    xr = fma(-BT.im[r], w4[2 * r + 1], xr);
-                                    xi = fma(BT.re[r], w4[2 * r + 1], xi);
-                                    xi = fma(BT.im[r], w4[2 * r], xi);
-                                }
-                                const double br = vcr * xr + vci * xi, bi = vcr * xi - vci * xr;  // conj(v[c]) (..)
-                                val -= s_re * bi + s_im * br;
-                            }
-                            if (cc < 4) q4[cc] = val; else {
-                                double one[1] = {val};
-                                row_sum_n(one);
-                                col_sum_n(one);
-                                if (lane == 0) out[cc + (size_t)t * K] = gs * one[0];
-                            }
-                        }
-                    }
-                    row_sum_n(q4);
-                    col_sum_n(q4);
-                    if (lane == 0) {
-#pragma unroll
-                        for (int cc = 0; cc < 4; ++cc)
-                            if (cc < K)
-                                out[cc + (size_t)t * K] = gs * q4[cc];
-                    }
-                }
+            for (int e = 0; e < 8; ++e)
+                vt[e] = vq[u][e];
+            {
+                const int tn = max(t - kRing, 0);
+                if (!(GRAPE_THIN_ABL & 4))
+                load_tile(Pq[u], Pk + (size_t)tn * TSZ, lane);
+                load_v(uc, tn);
             }
+            double q4[4] = {0.0, 0.0, 0.0, 0.0};
+            auto all_forms = [&](auto form) {     // controls 0..3 go through the batched reduction
+                if (GRAPE_THIN_ABL & 2)
+                    return;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < K)
+                        q4[i] = form(i);
+                for (int cc = 4; cc < K; ++cc) {  // many controls: one by one
+                    double one[1] = {form(cc)};
+                    row_sum_n(one);
+                    col_sum_n(one);
+                    if (lane == 0)
+                        out[cc + (size_t)t * K] = gs * one[0];
+                }
+            };
+            if ((u & 1) == 0) {
+                // even t: reg r = P[4r + g][c];  w_t[c] = sum conj(P[4r+g][c]) w[4r+g]: gathered in, per-column out
+                double acc[2] = {0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[0] = fma(P.re[r], w4[2 * r], acc[0]);
+                    acc[0] = fma(P.im[r], w4[2 * r + 1], acc[0]);
+                    acc[1] = fma(P.re[r], w4[2 * r + 1], acc[1]);
+                    acc[1] = fma(-P.im[r], w4[2 * r], acc[1]);
+                }
+                col_sum_n(acc);
+                wr = acc[0];
+                wi = acc[1];
+                // forms: w per-column, v gathered.  a = sum_{i,j} conj(w[i]) B[i][j] v[j] with the B^T dump
+                // (reg r = B[c][4r + g]);  b = sum conj(v[i]) B[i][j] w[j] with the B dump (reg r = B[4r + g][c])
+                all_forms([&](int cc) -> double {
+                    Tile1 BT;
+                    load_op(BT, K + cc);
+                    double ur = 0.0, ui = 0.0;                 // sum_r B[c][4r+g] v[4r+g]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ur = fma(BT.re[r], vt[2 * r], ur);
+                        ur = fma(-BT.im[r], vt[2 * r + 1], ur);
+                        ui = fma(BT.re[r], vt[2 * r + 1], ui);
+                        ui = fma(BT.im[r], vt[2 * r], ui);
+                    }
+                    const double ar = wr * ur + wi * ui, ai = wr * ui - wi * ur;      // conj(w[c]) u
+                    double val = s_re * ai - s_im * ar;                                // Im(conj(s) a)
+                    if (SAND && !HERMB) {
+                        Tile1 Bm;
+                        load_op(Bm, cc);
+                        double xr = 0.0, xi = 0.0;             // sum_r conj(v[4r+g]) B[4r+g][c]
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            xr = fma(vt[2 * r], Bm.re[r], xr);
+                            xr = fma(vt[2 * r + 1], Bm.im[r], xr);
+                            xi = fma(vt[2 * r], Bm.im[r], xi);
+                            xi = fma(-vt[2 * r + 1], Bm.re[r], xi);
+                        }
+                        const double br = xr * wr - xi * wi, bi = xr * wi + xi * wr;  // (..) w[c]
+                        val -= s_re * bi + s_im * br;                                  // - Im(s b)
+                    }
+                    return val;
+                });
+            } else {
+                // odd t: reg r = P[c][4r + g];  w_t[4r+g] = sum_c conj(P[c][4r+g]) w[c]: per-column in, gathered out
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    w4[2 * r] = fma(P.re[r], wr, P.im[r] * wi);
+                    w4[2 * r + 1] = fma(P.re[r], wi, -P.im[r] * wr);
+                }
+                row_sum_n(w4);
+                // forms: w gathered, v per-column.  a with the B dump (reg r = B[4r + g][c]);  b with the B^T dump
+                const double vcr = vt[0], vci = vt[1];
+                all_forms([&](int cc) -> double {
+                    Tile1 Bm;
+                    load_op(Bm, cc);
+                    double ur = 0.0, ui = 0.0;                 // sum_r conj(w[4r+g]) B[4r+g][c]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ur = fma(w4[2 * r], Bm.re[r], ur);
+                        ur = fma(w4[2 * r + 1], Bm.im[r], ur);
+                        ui = fma(w4[2 * r], Bm.im[r], ui);
+                        ui = fma(-w4[2 * r + 1], Bm.re[r], ui);
+                    }
+                    const double ar = ur * vcr - ui * vci, ai = ur * vci + ui * vcr;  // (..) v[c]
+                    double val = s_re * ai - s_im * ar;
+                    if (SAND && !HERMB) {
+                        Tile1 BT;
+                        load_op(BT, K + cc);
+                        double xr = 0.0, xi = 0.0;             // sum_r B[c][4r+g] w[4r+g]
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            xr = fma(BT.re[r], w4[2 * r], xr);
+                            xr = fma(-BT.im[r], w4[2 * r + 1], xr);
+                            xi = fma(BT.re[r], w4[2 * r + 1], xi);
+                            xi = fma(BT.im[r], w4[2 * r], xi);
+                        }
+                        const double br = vcr * xr + vci * xi, bi = vcr * xi - vci * xr;  // conj(v[c]) (..)
+                        val -= s_re * bi + s_im * br;
+                    }
+                    return val;
+                });
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                q16[4 * u + i] = q4[i];
+        };
+        // one reduce-scatter for the four slices of a group: quad (lane >> 2) = 4 u + i ends up with the sum of
+        // control i of slice base + u
+        auto flush = [&](int base) {
+            const double tot = reduce_scatter16(q16);
+            const int uu = lane >> 4, ii = (lane >> 2) & 3;
+            if ((lane & 3) == 0 && base + uu < N && ii < K)
+                out[ii + (size_t)(base + uu) * K] = gs * tot;
+        };
+        int base = (GRAPE_THIN_ABL & 1) ? -1 : top;
+        if (base >= 0 && top + kRing > N) {       // the ragged last group
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                q16[e] = 0.0;
+            if (top + 3 < N) step(IC<3>(), top + 3);
+            if (top + 2 < N) step(IC<2>(), top + 2);
+            if (top + 1 < N) step(IC<1>(), top + 1);
+            step(IC<0>(), top);
+            flush(top);
+            base = top - kRing;
+        }
+        for (; base >= 0; base -= kRing) {
+            step(IC<3>(), base + 3);
+            step(IC<2>(), base + 2);
+            step(IC<1>(), base + 1);
+            step(IC<0>(), base);
+            flush(base);
         }
     }
     if (lane == 0) {
@@ -382,19 +501,28 @@ __global__ __launch_bounds__(64) void chain_thin_kernel(const TileParams p)
     }
 }
 
+template <int SAND, bool HERMB>
+static void launch_thin(const TileParams &q, size_t lds, hipStream_t stream)
+{
+    const dim3 grid(q.E, q.n_x);
+    if (q.bt_in_lds)
+        hipLaunchKernelGGL((chain_thin_kernel<SAND, HERMB, true>), grid, dim3(64), lds, stream, q);
+    else
+        hipLaunchKernelGGL((chain_thin_kernel<SAND, HERMB, false>), grid, dim3(64), 0, stream, q);
+}
+
 hipError_t launch_chain_thin(int sandwich, const TileParams &p, hipStream_t stream)
 {
     TileParams q = p;
     const size_t b_bytes = sizeof(double2) * 2 * (size_t)p.K * 256;
-    q.bt_in_lds = b_bytes <= 36 * 1024 ? 1 : 0;                   // four waves per CU still fit
+    q.bt_in_lds = b_bytes <= 36 * 1024 ? 1 : 0;                   // four workgroups per CU still fit
     const size_t lds = q.bt_in_lds ? b_bytes : 0;
-    const dim3 grid(p.E, p.n_x), block(64);
     if (!sandwich)
-        hipLaunchKernelGGL((chain_thin_kernel<0, true>), grid, block, lds, stream, q);
+        launch_thin<0, true>(q, lds, stream);
     else if (p.herm_ctrl)
-        hipLaunchKernelGGL((chain_thin_kernel<1, true>), grid, block, lds, stream, q);
+        launch_thin<1, true>(q, lds, stream);
     else
-        hipLaunchKernelGGL((chain_thin_kernel<1, false>), grid, block, lds, stream, q);
+        launch_thin<1, false>(q, lds, stream);
     return hipGetLastError();
 }
 
