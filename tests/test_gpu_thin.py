@@ -126,3 +126,29 @@ def test_batched_and_device_entry_points(qoc, oracle):
         F_ref, G_ref = oracle.ensemble_eval("CoherenceTransfer", A, B, Xi, Xt, wts, xs[b], 1.0)
         assert_parity(Fs[b], Gs[b], F_ref, G_ref, n, what=f"batch entry {b}")
     assert h[-1] == Fs[0] and np.array_equal(h[:-1].reshape(N, K).T, Gs[0])
+
+
+def _random_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        sys_type = str(rng.choice(["StateTransfer", "CoherenceTransfer", "UnitaryGate"]))
+        out.append((i, int(rng.integers(9, 17)), int(rng.integers(1, 10)), int(rng.choice([1, 2, 3, 5, 6, 9, 31, 32, 33, 64, 127, 200])),
+                    int(rng.choice([1, 2, 3, 7])), sys_type, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)),
+                    int(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("i,n,K,N,E,sys_type,herm_gen,herm_ctrl,variant", _random_cases(40, 2027))
+def test_rank_one_chain_random_shapes(qoc, oracle, i, n, K, N, E, sys_type, herm_gen, herm_ctrl, variant):
+    sand = sys_type != "UnitaryGate"
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sand, herm_gen, herm_ctrl, seed=900 + i)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 0.8, variant=variant,
+                                                             per_member=True)
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 0.8, N, variant=variant, member_results=True) as eng:
+        assert eng.info["rank_one_chain"] == 1
+        F, G = eng.eval(x)
+        foms, grads = eng.member_results()
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"case {i} member {k}")
+    assert_parity(F, G, F_ref, G_ref, n, what=f"case {i}")
