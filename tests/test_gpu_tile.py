@@ -121,33 +121,6 @@ def test_c5_five_qubit_parity(qoc, oracle):
     assert_parity(F, G, F_ref, G_ref, w.n, what="C5")
 
 
-def test_mfma_4x4x4_variant_in_subprocess(qoc):
-    """the v_mfma_f64_4x4x4_4b implementation of the tile family (sweep_tile4.hip, selected with
-    GRAPE_TILE_MFMA4=1; the switch is read once per process, hence the subprocess)."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
-import quoptimalcontrol_jl_amd as qoc
-from oracle import grape_oracle
-from conftest import assert_parity
-from test_gpu_tile import _random_problem
-for n, st, herm in ((16, "CoherenceTransfer", False), (9, "UnitaryGate", True), (32, "UnitaryGate", True), (20, "StateTransfer", True)):
-    w = _random_problem(qoc, n, 3, 10, 2, st, seed=7 + n, hermitian=herm)
-    F_ref, G_ref = grape_oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
-    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
-        F, G = eng.eval(w.x)
-    assert_parity(F, G, F_ref, G_ref, n, what=f"mfma4 n={n}")
-print("ok")
-'''
-    env = dict(os.environ, GRAPE_TILE_MFMA4="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
-
-
 @pytest.mark.parametrize("name,E,members,dense", [("C4", 1024, (0, 1, 511, 1023), False), ("C4", 1024, (0, 1023), True),
                                                   ("C5", 1024, (0, 1023), False)])
 def test_full_size_spot_members(qoc, oracle, name, E, members, dense):
