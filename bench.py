@@ -131,10 +131,20 @@ def roofline(local, info, kern_ms, kern_n, evals_per_s, n_gpus, traffic):
                          "(model S); `flow` prices the same launches with the bytes/flops of the data flow "
                          "actually run; end_to_end_frac = algorithmic work x this rank's evals/s / peak"})
     if traffic is not None:
-        roof["traffic_source"] = ("HBM bytes per sweep launch = (2*FETCH_SIZE + WRITE_SIZE) KiB from the rocprofv3 --pmc passes of "
-                                  "this command committed as profiles/r02_C3_E1024_pmc.json (profiles/traffic.json); "
+        roof["traffic_source"] = ("HBM bytes of the timed kernels per evaluation = (2*FETCH_SIZE + WRITE_SIZE) KiB from the rocprofv3 "
+                                  "--pmc passes of this command committed under profiles/ (profiles/traffic.json names the file); "
                                   "NOT re-measured in this run")
     return roof
+
+
+def committed_traffic(key):
+    """HBM bytes per evaluation from the committed PMC profile of this config (profiles/traffic.json), or None."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        v = json.load(open(tpath)).get(key)
+        return float(v) if v is not None else None
+    except Exception:                          # noqa: BLE001
+        return None
 
 
 def time_blocks(step, steps, blocks, barrier, reduce_max):
@@ -175,7 +185,7 @@ def run_extra_config(qoc, name, dev_index, steps, warmup):
                         + (" (dense chain forced)" if dense else ""),
             "value": evals, "unit": "gradient-evals/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
             "member_evals_per_s": evals * w.E, "F": F,
-            "roofline": roofline(w, info, kern_ms, kern_n, evals, 1, None)}
+            "roofline": roofline(w, info, kern_ms, kern_n, evals, 1, None if dense else committed_traffic(f"{cfg_name}_E{w.E}"))}
 
 
 def lbfgs_rates(qoc, dev_index):
@@ -352,13 +362,7 @@ def main():
         # report in the metric's unit (evaluations of the CONFIG's E-member ensemble).
         value = evals_per_s * (E_total / E_cfg)
         local = w.members(sg.lo, sg.hi)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"{args.config}_E{local.E}")
-            except Exception:
-                traffic = None
+        traffic = committed_traffic(f"{args.config}_E{local.E}")
         roof = roofline(local, info, kern_ms, kern_n, evals_per_s, world, traffic)
         n_joined = sg.comm_size if (world > 1 or args.force_dist) else 1
         out = {

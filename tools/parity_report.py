@@ -29,6 +29,7 @@ def compare(label, w, variant=0, **ekw):
     gm = [float(np.abs(grads[k] - grads_ref[k]).max() / np.abs(grads_ref[k]).max()) for k in range(w.E)]
     rows.append({"case": label, "n": w.n, "K": w.K, "N": w.N, "E": w.E, "sys_type": w.sys_type, "variant": variant,
                  "kernel_family": info["kernel_family"], "unitary_flow": info["unitary_flow"],
+                 "rank_one_chain": info["rank_one_chain"],
                  "abs_err_F": float(abs(F - F_ref)), "rel_err_G_inf": float(np.abs(G - G_ref).max() / np.abs(G_ref).max()),
                  "worst_member_rel_err_G": max(gm), "worst_member_abs_err_F": float(np.abs(foms - foms_ref).max()),
                  "bar": 1e-10})
@@ -41,6 +42,7 @@ compare("C3 4x4 UnitaryGate N=500, 64 of 1024 members", wl.config("C3", E=64))
 compare("C3 same, general flow forced", wl.config("C3", E=64), flags=qoc.engine.FLAG_FORCE_GENERAL)
 compare("C3 same, static variant", wl.config("C3", E=64), variant=1)
 compare("C4 16x16 Liouvillian CoherenceTransfer N=1000, 8 of 1024 members", wl.config("C4", E=8))
+compare("C4 same, dense MFMA chain forced", wl.config("C4", E=8), flags=qoc.engine.FLAG_FORCE_GENERAL)
 compare("C5 32x32 UnitaryGate N=2000, 2 of 4096 members", wl.config("C5", E=2))
 golden = []
 for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.json"))):

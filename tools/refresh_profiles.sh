@@ -1,0 +1,37 @@
+#!/bin/bash
+# Regenerates the evidence under profiles/ for the kernels of HEAD, on the GPU box (one gpurun call):
+#   tools/refresh_profiles.sh <tag>      -> gpurun_out/prof_<tag>/...   (copy what is to be judged into profiles/)
+# rocprofv3 runs the program itself after `--` (python3 bench.py ...), PMC passes are separate kernel-trace-only runs.
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+stats() {   # name, env, bench args...
+  local name=$1 envs=$2; shift 2
+  rm -rf /tmp/st_$name
+  env $envs true
+  ( export $envs; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$name -- python3 "$ROOT/bench.py" --blocks 1 --no-cpu-baseline --no-extra "$@" > "$OUT/stats_$name.log" 2>&1 )
+  f=$(find /tmp/st_$name -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp "$f" "$OUT/${name}_kernel_stats.csv"
+}
+stats C3_E1024 GRAPE_X=0 --steps 30 --warmup 5
+stats C4_E1024 GRAPE_X=0 --config C4 --steps 8 --warmup 2
+stats C4dense_E1024 GRAPE_NO_THIN=1 --config C4 --steps 8 --warmup 2
+stats C5_E4096 GRAPE_X=0 --config C5 --steps 2 --warmup 1
+bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C3" > "$OUT/pmc_C3.log" 2>&1
+bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C4" --config C4 > "$OUT/pmc_C4.log" 2>&1
+GRAPE_NO_THIN=1 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C4dense" --config C4 > "$OUT/pmc_C4dense.log" 2>&1
+cd "$ROOT"
+python3 tools/phase_profile.py --config C3 > "$OUT/C3_phase_stamps.json" 2> /dev/null
+python3 tools/parity_report.py > "$OUT/parity.json" 2> "$OUT/parity.log"
+python3 bench.py 2> /dev/null | tail -1 > "$OUT/bench_C3_1gpu.json"
+python3 bench.py --force-general --no-extra 2> /dev/null | tail -1 > "$OUT/bench_C3_general_flow_1gpu.json"
+python3 bench.py --force-dist --no-extra 2> /dev/null | tail -1 > "$OUT/bench_C3_1gpu_forced_1rank_collective.json"
+for E in 128 256 512; do
+  python3 bench.py --ensemble $E --no-extra --no-cpu-baseline 2> /dev/null | tail -1 > "$OUT/bench_C3_shard_E$E.json"
+done
+# keep the raw PMC CSVs out of the merge (64 MiB cap): summaries only
+find "$OUT" -name 'pass*' -maxdepth 2 -type d -exec rm -rf {} + 2> /dev/null
+ls -la "$OUT"
