@@ -34,7 +34,7 @@ namespace grape {
 constexpr int kPropSlices = 64;
 
 template <int NT>
-__global__ __launch_bounds__(256) void prop_tile_kernel(const TileParams p)
+__global__ __launch_bounds__(256, NT == 1 ? 4 : 1) void prop_tile_kernel(const TileParams p)
 {
     constexpr int TSZ = NT * NT * 256;                     // double2 per matrix dump
     const bool STAGE = (NT == 1) && p.stage_ops;           // set by the launcher when the tiles fit in LDS
