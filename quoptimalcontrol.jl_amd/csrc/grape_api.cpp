@@ -82,6 +82,9 @@ struct grape_ctx {
     bool thin = false;                         // rank-one states: matrix-vector chain (sweep_thin.hip)
     bool herm_ctrl = false;                    // every B_c Hermitian
     double2 *d_vecs = nullptr;                 // thin: per member [v0 | wT], 16 complex each
+    bool sparse_ctrl = false;                  // tile family: every B_c has <= kSparseMax non-zeros (sparse gradient traces)
+    double2 *d_sp_coef = nullptr;              // [E][K][kSparseMax]
+    int32_t *d_sp_addr = nullptr;
     size_t states_bytes = 0;                   // size of d_states (vector records are smaller than state dumps)
     bool direct_publish = true;                // GRAPE_DIRECT_PUBLISH=0: always go through the reduce kernel
     unsigned long long seq = 0;
@@ -191,6 +194,13 @@ static RcclApi *rccl()
             return fail(ctx, GRAPE_ERR_COMM, std::string(#call) + ": " + g_rccl.GetErrorString(r__)); \
     } while (0)
 
+// diagnostic switches: set and not "0"
+static bool env_on(const char *name)
+{
+    const char *v = std::getenv(name);
+    return v && v[0] && !(v[0] == '0' && !v[1]);
+}
+
 static size_t KN(const grape_ctx *c) { return (size_t)c->cfg.n_controls * c->cfg.n_slices; }
 
 static void free_all(grape_ctx *c)
@@ -212,6 +222,7 @@ static void free_all(grape_ctx *c)
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     (void)hipFree(c->d_done_counter);
     (void)hipFree(c->d_vecs);
+    (void)hipFree(c->d_sp_coef); (void)hipFree(c->d_sp_addr);
     (void)hipFree(c->d_x_bar);
     delete c;
 }
@@ -728,7 +739,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     // GRAPE_FLAG_FORCE_GENERAL / KEEP_COSTATES / the exact gradient keep the dense chain.
     std::vector<double> vecs;
     bool thin = c->family == 1 && c->NT == 1 && !c->pack2 && c->cfg.gradient != GRAPE_GRADIENT_EXACT &&
-                !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) && !std::getenv("GRAPE_NO_THIN");
+                !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) && !env_on("GRAPE_NO_THIN");
     if (thin) {
         const bool sand = c->cfg.sys_type != GRAPE_UNITARY_GATE;
         vecs.assign(E * 64, 0.0);
@@ -791,6 +802,42 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             }
         c->herm_ctrl = hb;
     }
+    {   // sparse control operators (Pauli-type controls): lists of (B_c[i][j], position of M[j][i]) per member and control
+        constexpr int SM = grape::kSparseMax;
+        bool sp = c->family == 1 && !c->pack2 && K >= 1 && K <= 16 && !env_on("GRAPE_NO_SPARSE");
+        std::vector<double> coef;
+        std::vector<int32_t> addr;
+        if (sp) {
+            coef.assign(E * K * SM * 2, 0.0);
+            addr.assign(E * K * SM, 0);
+            const int MS = 16 * c->NT + 1;
+            for (size_t k = 0; k < E && sp; ++k)
+                for (size_t m = 0; m < K && sp; ++m) {
+                    const double *M = B + 2 * (k * K + m) * nn;
+                    int cnt = 0;
+                    for (int j = 0; j < n && sp; ++j)
+                        for (int i = 0; i < n; ++i) {
+                            const double re = M[2 * (i + j * n)], im = M[2 * (i + j * n) + 1];
+                            if (re == 0.0 && im == 0.0) continue;
+                            if (cnt == SM) { sp = false; break; }
+                            const size_t e = (k * K + m) * SM + cnt++;
+                            coef[2 * e] = re;
+                            coef[2 * e + 1] = im;
+                            addr[e] = j * MS + i;                // B[i][j] multiplies M[j][i]: row j, column i
+                        }
+                }
+        }
+        c->sparse_ctrl = sp;
+        if (sp) {
+            if (!c->d_sp_coef) {
+                c->bytes += (sizeof(double2) + sizeof(int32_t)) * E * K * SM;
+                HIP_TRY(c, hipMalloc((void **)&c->d_sp_coef, sizeof(double2) * E * K * SM));
+                HIP_TRY(c, hipMalloc((void **)&c->d_sp_addr, sizeof(int32_t) * E * K * SM));
+            }
+            HIP_TRY(c, hipMemcpy(c->d_sp_coef, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->d_sp_addr, addr.data(), sizeof(int32_t) * addr.size(), hipMemcpyHostToDevice));
+        }
+    }
     if (thin) {
         c->unitary = false;                                  // the thin chain serves Hermitian generators as well
         if (!c->d_vecs) {
@@ -852,6 +899,9 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.thin = c->thin ? 1 : 0;
     p.herm_ctrl = c->herm_ctrl ? 1 : 0;
     p.vecs = c->d_vecs;
+    p.sparse = c->sparse_ctrl ? 1 : 0;
+    p.sp_coef = c->d_sp_coef;
+    p.sp_addr = c->d_sp_addr;
     return p;
 }
 
@@ -1629,5 +1679,6 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
     info->lane_pair = (c->is_group ? c->sub[0]->pair : c->pair) ? 1 : 0;
     info->states_stored = states_stored(c->is_group ? c->sub[0] : c) ? 1 : 0;
     info->rank_one_chain = (c->is_group ? c->sub[0]->thin : c->thin) ? 1 : 0;
+    info->sparse_controls = (c->is_group ? c->sub[0]->sparse_ctrl : c->sparse_ctrl) ? 1 : 0;
     return GRAPE_OK;
 }

@@ -95,8 +95,16 @@ struct TileParams {
                           // TRANSPOSED for odd t; `states` holds the forward pass's vector records (N + 1 per member)
     int32_t herm_ctrl;    // every control operator B_c Hermitian (thin chain: one bilinear form per control)
     const double2 *vecs;  // thin: per member [v0 | wT], 16 complex each, zero padded
+    // sparse control operators (every B_c of every member has at most kSparseMax non-zeros -- Pauli-type controls):
+    // per member and control kSparseMax entries, zero padded: sp_coef = B_c[i][j], sp_addr = position of M[j][i]
+    // in the wave's LDS image of M (row j, column i, row stride 16 NT + 1).  The gradient traces tr(B_c M_t) then
+    // read 64 entries instead of a dense transposed operator per control and slice.
+    int32_t sparse;
+    const double2 *sp_coef;   // [unit][K][kSparseMax]
+    const int32_t *sp_addr;   // [unit][K][kSparseMax]
     double dt;
 };
+constexpr int kSparseMax = 64;
 // the chain over rank-one states (n = 9..16, one member per wavefront); called by launch_sweep_tile when p.thin
 hipError_t launch_chain_thin(int sandwich, const TileParams &p, hipStream_t stream);
 int tile_count(int n);    // NT for this n (0: not a tile-family size)

@@ -40,104 +40,6 @@ namespace {
 constexpr int kRing = 4;          // backward pass: slices of P in flight per wave (4 KB each)
 constexpr int kRingF = 8;         // forward pass (one wave per member runs it alone)
 
-// sum over the 16 lanes of a DPP row (lanes sharing l >> 4), result in every lane: rotations by 8, 4, 2, 1
-template <int M>
-GRAPE_DEV void row_sum_n(double (&v)[M])
-{
-#define GRAPE_ROR_STEP(CTRL)                                                                                   \
-    {                                                                                                          \
-        double o[M];                                                                                           \
-        _Pragma("unroll") for (int m = 0; m < M; ++m)                                                          \
-        {                                                                                                      \
-            const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v[m]), CTRL, 0xF, 0xF, true);         \
-            const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v[m]), CTRL, 0xF, 0xF, true);         \
-            o[m] = __hiloint2double(hi, lo);                                                                   \
-        }                                                                                                      \
-        _Pragma("unroll") for (int m = 0; m < M; ++m) v[m] += o[m];                                            \
-    }
-    GRAPE_ROR_STEP(0x128)          // row_ror:8
-    GRAPE_ROR_STEP(0x124)          // row_ror:4
-    GRAPE_ROR_STEP(0x122)          // row_ror:2
-    GRAPE_ROR_STEP(0x121)          // row_ror:1
-#undef GRAPE_ROR_STEP
-}
-
-// v = a + b after exchanging halves: v_permlane32_swap / v_permlane16_swap (gfx950) trade the upper half (odd
-// rows) of the first register for the lower half (even rows) of the second, so with (a, b) = (lower-index value,
-// upper-index value) the sum of the two results is, in every lane, own + partner of the value that lane KEEPS
-// (lanes 0..31 / even rows keep a, the others b): one step of a reduce-scatter without selects.  With a == b it
-// is a plain all-reduce step.
-GRAPE_DEV double swap32_add(double a, double b)
-{
-    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
-    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-GRAPE_DEV double swap16_add(double a, double b)
-{
-    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
-    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-
-// sum over the 4 rows (lanes sharing l & 15), result in every lane
-template <int M>
-GRAPE_DEV void col_sum_n(double (&v)[M])
-{
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-        v[m] = swap16_add(v[m], v[m]);
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-        v[m] = swap32_add(v[m], v[m]);
-}
-
-// one DPP-masked step of the reduce-scatter inside a row of 16 lanes: lanes whose bank (group of 4 lanes) is in
-// UPPER keep b, the others a; partners by the DPP control CTRL (row_ror:8 pairs l with l ^ 8, row_half_mirror
-// pairs l with 7 - l inside each group of 8: one lane on either side of bit 2)
-template <int CTRL, int UPPER>
-GRAPE_DEV double dpp_pair_add(double a, double b)
-{
-    constexpr int LOWER = 0xF & ~UPPER;
-    int klo = __double2loint(a), khi = __double2hiint(a);                 // kept value: a, or b in the upper banks
-    klo = __builtin_amdgcn_update_dpp(klo, __double2loint(b), 0xE4, 0xF, UPPER, false);      // quad_perm [0,1,2,3]
-    khi = __builtin_amdgcn_update_dpp(khi, __double2hiint(b), 0xE4, 0xF, UPPER, false);
-    int rlo = 0, rhi = 0;                                                 // the partner's value of the same index
-    rlo = __builtin_amdgcn_update_dpp(rlo, __double2loint(a), CTRL, 0xF, LOWER, false);
-    rhi = __builtin_amdgcn_update_dpp(rhi, __double2hiint(a), CTRL, 0xF, LOWER, false);
-    rlo = __builtin_amdgcn_update_dpp(rlo, __double2loint(b), CTRL, 0xF, UPPER, false);
-    rhi = __builtin_amdgcn_update_dpp(rhi, __double2hiint(b), CTRL, 0xF, UPPER, false);
-    return __hiloint2double(khi, klo) + __hiloint2double(rhi, rlo);
-}
-
-template <int CTRL>
-GRAPE_DEV double dpp_quad_add(double a)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), CTRL, 0xF, 0xF, true);
-    return a + __hiloint2double(hi, lo);
-}
-
-// 16 values per lane in, the wave-wide sum of value number (lane >> 2) out (in all four lanes of that quad):
-// a reduce-scatter -- 8 + 4 + 2 + 1 pair steps and two quad steps, 17 additions instead of 16 x 6.
-GRAPE_DEV double reduce_scatter16(const double (&v)[16])
-{
-    double a[8], b[4], c[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        a[i] = swap32_add(v[i], v[i + 8]);                // lanes >= 32 keep values 8..15
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        b[i] = swap16_add(a[i], a[i + 4]);                // odd rows keep the upper four of their eight
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-        c[i] = dpp_pair_add<0x128, 0xC>(b[i], b[i + 2]);  // row_ror:8; banks 2, 3 (lane bit 3) keep the upper two
-    double d = dpp_pair_add<0x141, 0xA>(c[0], c[1]);      // row_half_mirror; banks 1, 3 (lane bit 2) keep the upper one
-    d = dpp_quad_add<0x4E>(d);                            // quad_perm [2,3,0,1]
-    d = dpp_quad_add<0xB1>(d);                            // quad_perm [1,0,3,2]
-    return d;
-}
-
 struct Tile1 {                    // one 16 x 16 D-layout dump: 4 complex per lane
     double re[4], im[4];
 };

@@ -37,14 +37,15 @@ template <int NT>
 __global__ __launch_bounds__(256, NT == 1 ? 4 : 1) void prop_tile_kernel(const TileParams p)
 {
     constexpr int TSZ = NT * NT * 256;                     // double2 per matrix dump
-    const bool STAGE = (NT == 1) && p.stage_ops;           // set by the launcher when the tiles fit in LDS
+    constexpr int NIMG = NT;                               // LDS conversion images per wave (one per tile of a row)
+    const bool STAGE = p.stage_ops != 0;                   // set by the launcher when the generator tiles fit in LDS
     extern __shared__ double2 s_prop[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = blockIdx.y;
     const int K = p.K;
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;   // [A | B_c | B_c^T | Xi | Xt]
-    double2 *img = s_prop + (size_t)wave * kTileImage;
-    double2 *s_ops = s_prop + 4 * kTileImage;              // STAGE: [A | B_1..B_K]
+    double2 *img = s_prop + (size_t)wave * NIMG * kTileImage;
+    double2 *s_ops = s_prop + 4 * NIMG * kTileImage;       // STAGE: [A | B_1..B_K]
     if (STAGE) {
         for (int i = threadIdx.x; i < (K + 1) * TSZ; i += 256)
             s_ops[i] = ops[i];
@@ -106,11 +107,11 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 1) void prop_tile_kernel(const T
                 G.im[I][J][r] = -dt * hr;
                 cs += fabs(G.re[I][J][r]) + fabs(G.im[I][J][r]);
             }
-        cs += __shfl_xor(cs, 16, 64);                      // rows live on lane>>4 and r
-        cs += __shfl_xor(cs, 32, 64);
+        cs = swap16_add(cs, cs);                           // rows live on lane>>4 and r
+        cs = swap32_add(cs, cs);
         colmax = fmax(colmax, cs);
     }
-    colmax = wave_max(colmax);
+    colmax = wave_max_fast(colmax);
     const int s = p.s_forced >= 0 ? p.s_forced : squarings_for(colmax);
     if (s > 0) {
         const double sc = ldexp(1.0, -s);
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 1) void prop_tile_kernel(const T
     // expm_t8 (cmat.hpp) with MFMA products; every matrix is a polynomial in G
     TOp<NT> opa;
     TMat<NT> A2, A4, U, T;
-    to_a_layout(opa, G, img, lane);
+    to_a_layout_rows(opa, G, img, lane);
     tmul_an<NT, false, false>(A2, opa, G);                 // A2 = G G
 #pragma unroll
     for (int I = 0; I < NT; ++I)
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 1) void prop_tile_kernel(const T
             T.re[I][J] = kX1 * G.re[I][J] + kX2 * A2.re[I][J];
             T.im[I][J] = kX1 * G.im[I][J] + kX2 * A2.im[I][J];
         }
-    to_a_layout(opa, A2, img, lane);
+    to_a_layout_rows(opa, A2, img, lane);
     tmul_an<NT, false, false>(A4, opa, T);                 // A4 = A2 (x1 G + x2 A2)
 #pragma unroll
     for (int I = 0; I < NT; ++I)
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 1) void prop_tile_kernel(const T
         for (int r = 0; r < 4; ++r)
             if (4 * r + (lane >> 4) == (lane & 15))
                 T.re[I][I][r] += kX4;
-    to_a_layout(opa, U, img, lane);
+    to_a_layout_rows(opa, U, img, lane);
     TMat<NT> P;
     tmul_an<NT, false, false>(P, opa, T);                  // A8
 #pragma unroll
@@ -170,14 +171,14 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 1) void prop_tile_kernel(const T
             if (4 * r + (lane >> 4) == (lane & 15))
                 P.re[I][I][r] += 1.0;
     for (int i = 0; i < s; ++i) {
-        to_a_layout(opa, P, img, lane);
+        to_a_layout_rows(opa, P, img, lane);
         tmul_an<NT, false, false>(T, opa, P);
         P = T;
     }
     if (NT == 1 && p.thin && (t & 1)) {
         // rank-one chain (sweep_thin.hip): odd slices are stored transposed -- the A-operand layout of P is the
         // D layout of P^T -- so that its matrix-vector products never convert between vector formats
-        to_a_layout(opa, P, img, lane);
+        to_a_layout_rows(opa, P, img, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             P.re[0][0][r] = opa.re[0][0][r];
@@ -551,20 +552,37 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
 // accumulates X_N = P_{N-1} ... P_0 Xi (UnitaryGate) or the total product T (sandwich:
 // X_N = T Xi T'), 1 product per slice; the backward pass carries M with 2 products per slice.
 // tr(X_t' L_t) is conj(tr M_t) (UnitaryGate) or t-invariant (sandwich, taken at t = N).
-template <int NT, int SAND, bool PACK2>
+// SPARSE (TileParams.sparse): every control operator has at most kSparseMax non-zeros.  The K dense transposed
+// operators (K x 16 KB at NT = 2, re-read by every wave for every slice: 3/4 of this kernel's memory traffic at C5,
+// which made it Infinity-Cache-bound) are replaced by K x 64 (coefficient, position) entries staged in LDS; M_t is
+// written to an LDS image once per slice and the entries pick what they need.  One reduce-scatter per slice.
+template <int NT, int SAND, bool PACK2, bool SPARSE = false>
 __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams p)
 {
     constexpr int TSZ = NT * NT * 256;
+    constexpr int MS = 16 * NT + 1;                  // row stride of the LDS image of M
     extern __shared__ double2 s_dynt[];
     double2 *s_img = s_dynt;
-    double2 *s_bt = s_dynt + kTileImage + 1;
+    double2 *s_bt = s_dynt + kTileImage + 1;         // dense: transposed operators;  sparse: coefficients, M image, positions
+    double2 *s_coef = s_bt;
+    double2 *s_M = s_coef + (size_t)p.K * kSparseMax;
+    int *s_addr = reinterpret_cast<int *>(s_M + 16 * NT * MS);
     const int lane = threadIdx.x;
     const int k = blockIdx.x;
     const int K = p.K, N = p.N;
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
     const double2 *__restrict__ opBT = ops + (size_t)(1 + K) * TSZ;
     const bool bt_lds = p.bt_in_lds != 0;
-    if (bt_lds) {
+    if (SPARSE) {
+        const double2 *__restrict__ gc = p.sp_coef + (size_t)k * K * kSparseMax;
+        const int32_t *__restrict__ ga = p.sp_addr + (size_t)k * K * kSparseMax;
+        for (int i = lane; i < K * kSparseMax; i += 64) {
+            s_coef[i] = gc[i];
+            s_addr[i] = ga[i];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    } else if (bt_lds) {
         for (int i = lane; i < K * TSZ; i += 64)
             s_bt[i] = opBT[i];
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -636,12 +654,57 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
 
     // ------------------------------------------------------------ backward: M_t = P_t' M_{t+1} P_t
     const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
+    if (SPARSE && !SAND) {                                         // z = conj(tr M), the same for every t
+        double zz[2] = {0.0, 0.0};
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * r + (lane >> 4) == (lane & 15)) {
+                    zz[0] += M.re[I][I][r];
+                    zz[1] += M.im[I][I][r];
+                }
+        wave_sum_n(zz);
+        zr = zz[0];
+        zi = -zz[1];
+    }
     tload(Pm, Pk + (size_t)(N - 1) * TSZ, lane);
     for (int t = N - 1; t >= 0; --t) {
         if (t > 0)
             tload(Pn, Pk + (size_t)(t - 1) * TSZ, lane);
         tmul_tn<NT, false, true>(Y, M, Pm);                        // (P' M)^T
         tmul_tn<NT, false, false>(M, Y, Pm);                       // P' M P
+        if (SPARSE) {
+            // tr(B_c M_t) = sum over the non-zeros B_c[i][j] of B_c[i][j] M_t[j][i]; with z = conj(tr M) taken once
+            // (the trace is invariant under M -> P' M P) every lane's share of g[c, t] is one real number
+#pragma unroll
+            for (int I = 0; I < NT; ++I)
+#pragma unroll
+                for (int J = 0; J < NT; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        s_M[(16 * I + 4 * r + (lane >> 4)) * MS + 16 * J + (lane & 15)] =
+                            make_double2(M.re[I][J][r], M.im[I][J][r]);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            double q16[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                q16[c] = 0.0;
+                if (c < K) {
+                    const double2 cf = s_coef[c * kSparseMax + lane];
+                    const double2 mv = s_M[s_addr[c * kSparseMax + lane]];
+                    const double pr = cf.x * mv.x - cf.y * mv.y, pi = cf.x * mv.y + cf.y * mv.x;
+                    q16[c] = SAND ? pi : fma(pr, zi, pi * zr);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                    // the image is overwritten by the next slice
+            __builtin_amdgcn_wave_barrier();
+            const double tot = reduce_scatter16(q16);
+            const int c = lane >> 2;
+            if ((lane & 3) == 0 && c < K)
+                out[c + (size_t)t * K] = gs * tot;
+        } else
         for (int c0 = 0; c0 < K; c0 += 4) {
             double v[2 + 8];
             v[0] = 0.0;
@@ -722,10 +785,19 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     {
         TileParams q = p;
         const size_t ops_bytes = sizeof(double2) * (size_t)(p.K + 1) * NT * NT * 256;
-        const size_t img_bytes = sizeof(double2) * 4 * (size_t)kTileImage;
-        q.stage_ops = (NT == 1 && img_bytes + ops_bytes <= 64 * 1024) ? 1 : 0;
+        const size_t img_bytes = sizeof(double2) * 4 * NT * (size_t)kTileImage;
+        // the member's K + 1 generator tiles in LDS, read once per kPropSlices slices: NT = 1 keeps room for four
+        // workgroups per CU; NT = 2 runs one workgroup per CU anyway (registers) and may take what is left of the
+        // 160 KB -- without it every wave waits for K + 1 dependent 16 KB fetches from L2 / Infinity Cache per slice
+        q.stage_ops = (img_bytes + ops_bytes <= (size_t)(NT == 1 ? 64 : 160) * 1024) ? 1 : 0;
         const int per_block = q.stage_ops ? kPropSlices : 4;
         const size_t lds = img_bytes + (q.stage_ops ? ops_bytes : 0);
+        if (lds > 64 * 1024) {
+            hipError_t ea = hipFuncSetAttribute((const void *)prop_tile_kernel<NT>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess)
+                return ea;
+        }
         hipLaunchKernelGGL(prop_tile_kernel<NT>, dim3((p.N + per_block - 1) / per_block, p.E, p.n_x), dim3(256), lds,
                            stream, q);
     }
@@ -757,7 +829,13 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         return hipGetLastError();
     }
 #define GRAPE_LAUNCH_CHAIN(KERNEL) hipLaunchKernelGGL(KERNEL, grid, block, lds, stream, q)
-    if (p.unitary && !keepl) {
+    if (p.unitary && !keepl && p.sparse && !pk) {
+        // image for layout conversions | coefficients | image of M | positions
+        const size_t lds_sp = sizeof(double2) * (kTileImage + 1 + (size_t)p.K * kSparseMax + 16 * NT * (16 * NT + 1)) +
+                              sizeof(int32_t) * (size_t)p.K * kSparseMax;
+        if (sandwich) hipLaunchKernelGGL((chain_tile_unitary_kernel<NT, 1, false, true>), grid, block, lds_sp, stream, q);
+        else          hipLaunchKernelGGL((chain_tile_unitary_kernel<NT, 0, false, true>), grid, block, lds_sp, stream, q);
+    } else if (p.unitary && !keepl) {
         if (sandwich) { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 1, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 1, false>)); }
         else          { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 0, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 0, false>)); }
     } else if (sandwich) {

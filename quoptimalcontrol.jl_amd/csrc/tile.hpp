@@ -55,27 +55,39 @@ GRAPE_DEV void tzero(TMat<NT> &m)
 template <int NT, bool CONJ_A, bool CONJ_B, typename FA, typename FB>
 GRAPE_DEV void tprod(TMat<NT> &out, FA a, FB b)
 {
+    // k-blocks outermost, all NT x NT output tiles innermost: 2 NT^2 independent accumulator chains are in flight,
+    // so consecutive MFMAs never wait for each other's result (one tile at a time leaves two chains per wave: a wave
+    // that has its SIMD to itself then issues one v_mfma_f64_16x16x4 per ~100 cycles instead of ~61)
+    tzero(out);
 #pragma unroll
-    for (int I = 0; I < NT; ++I)
+    for (int Kt = 0; Kt < NT; ++Kt)
 #pragma unroll
-        for (int J = 0; J < NT; ++J) {
-            d4 cr = (d4){0, 0, 0, 0}, ci = (d4){0, 0, 0, 0};
+        for (int kb = 0; kb < 4; ++kb) {
+            double ar[NT], ai[NT], br[NT], bi[NT];
 #pragma unroll
-            for (int Kt = 0; Kt < NT; ++Kt)
+            for (int I = 0; I < NT; ++I) {
+                a(I, Kt, kb, ar[I], ai[I]);
+                if (CONJ_A) ai[I] = -ai[I];
+            }
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    double ar, ai, br, bi;
-                    a(I, Kt, kb, ar, ai);
-                    b(Kt, J, kb, br, bi);
-                    if (CONJ_A) ai = -ai;
-                    if (CONJ_B) bi = -bi;
-                    cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cr, 0, 0, 0);
-                    cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cr, 0, 0, 0);
-                    ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, ci, 0, 0, 0);
-                    ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci, 0, 0, 0);
+            for (int J = 0; J < NT; ++J) {
+                b(Kt, J, kb, br[J], bi[J]);
+                if (CONJ_B) bi[J] = -bi[J];
+            }
+#pragma unroll
+            for (int I = 0; I < NT; ++I)
+#pragma unroll
+                for (int J = 0; J < NT; ++J) {
+                    out.re[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[I], br[J], out.re[I][J], 0, 0, 0);
+                    out.im[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[I], bi[J], out.im[I][J], 0, 0, 0);
                 }
-            out.re[I][J] = cr;
-            out.im[I][J] = ci;
+#pragma unroll
+            for (int I = 0; I < NT; ++I)
+#pragma unroll
+                for (int J = 0; J < NT; ++J) {
+                    out.re[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai[I], bi[J], out.re[I][J], 0, 0, 0);
+                    out.im[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[I], br[J], out.im[I][J], 0, 0, 0);
+                }
         }
 }
 
@@ -133,6 +145,36 @@ GRAPE_DEV void to_a_layout(TOp<NT> &a, const TMat<NT> &z, double2 *__restrict__ 
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
         }
+}
+
+// the same conversion, a ROW of tiles at a time (img: NT images): NT tiles are written, one wait, NT are read back --
+// 2 NT synchronisation points instead of 2 NT^2 (a wave that has its SIMD to itself pays every one of them)
+template <int NT>
+GRAPE_DEV void to_a_layout_rows(TOp<NT> &a, const TMat<NT> &z, double2 *__restrict__ img, int lane)
+{
+    const int rho = lane & 15, q = lane >> 4;
+    const int wr = 17 * (lane >> 4) + (lane & 15);
+    const int rd = 68 * (rho >> 2) + 17 * (rho & 3) + q;
+#pragma unroll
+    for (int I = 0; I < NT; ++I) {
+#pragma unroll
+        for (int Kt = 0; Kt < NT; ++Kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                img[Kt * kTileImage + 68 * r + wr] = make_double2(z.re[I][Kt][r], z.im[I][Kt][r]);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int Kt = 0; Kt < NT; ++Kt)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const double2 v = img[Kt * kTileImage + rd + 4 * kb];
+                a.re[I][Kt][kb] = v.x;
+                a.im[I][Kt][kb] = v.y;
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // memory dump <-> D registers: element (tile, r, lane) at ((I*NT + J)*4 + r)*64 + lane
@@ -241,6 +283,133 @@ GRAPE_DEV void tdot(double &zr, double &zi, const TMat<NT> &a, const TMat<NT> &b
             }
     zr = wave_sum(sr);
     zi = wave_sum(si);
+}
+
+// ---- cross-lane sums without LDS round trips (gfx950: DPP row rotations, v_permlane16_swap / v_permlane32_swap)
+
+// sum over the 16 lanes of a DPP row (lanes sharing l >> 4), result in every lane: rotations by 8, 4, 2, 1
+template <int M>
+GRAPE_DEV void row_sum_n(double (&v)[M])
+{
+#define GRAPE_ROR_STEP(CTRL)                                                                                   \
+    {                                                                                                          \
+        double o[M];                                                                                           \
+        _Pragma("unroll") for (int m = 0; m < M; ++m)                                                          \
+        {                                                                                                      \
+            const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v[m]), CTRL, 0xF, 0xF, true);         \
+            const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v[m]), CTRL, 0xF, 0xF, true);         \
+            o[m] = __hiloint2double(hi, lo);                                                                   \
+        }                                                                                                      \
+        _Pragma("unroll") for (int m = 0; m < M; ++m) v[m] += o[m];                                            \
+    }
+    GRAPE_ROR_STEP(0x128)          // row_ror:8
+    GRAPE_ROR_STEP(0x124)          // row_ror:4
+    GRAPE_ROR_STEP(0x122)          // row_ror:2
+    GRAPE_ROR_STEP(0x121)          // row_ror:1
+#undef GRAPE_ROR_STEP
+}
+
+// v = a + b after exchanging halves: v_permlane32_swap / v_permlane16_swap (gfx950) trade the upper half (odd
+// rows) of the first register for the lower half (even rows) of the second, so with (a, b) = (lower-index value,
+// upper-index value) the sum of the two results is, in every lane, own + partner of the value that lane KEEPS
+// (lanes 0..31 / even rows keep a, the others b): one step of a reduce-scatter without selects.  With a == b it
+// is a plain all-reduce step.
+GRAPE_DEV double swap32_add(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+GRAPE_DEV double swap16_add(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+// sum over the 4 rows (lanes sharing l & 15), result in every lane
+template <int M>
+GRAPE_DEV void col_sum_n(double (&v)[M])
+{
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+        v[m] = swap16_add(v[m], v[m]);
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+        v[m] = swap32_add(v[m], v[m]);
+}
+
+// one DPP-masked step of the reduce-scatter inside a row of 16 lanes: lanes whose bank (group of 4 lanes) is in
+// UPPER keep b, the others a; partners by the DPP control CTRL (row_ror:8 pairs l with l ^ 8, row_half_mirror
+// pairs l with 7 - l inside each group of 8: one lane on either side of bit 2)
+template <int CTRL, int UPPER>
+GRAPE_DEV double dpp_pair_add(double a, double b)
+{
+    constexpr int LOWER = 0xF & ~UPPER;
+    int klo = __double2loint(a), khi = __double2hiint(a);                 // kept value: a, or b in the upper banks
+    klo = __builtin_amdgcn_update_dpp(klo, __double2loint(b), 0xE4, 0xF, UPPER, false);      // quad_perm [0,1,2,3]
+    khi = __builtin_amdgcn_update_dpp(khi, __double2hiint(b), 0xE4, 0xF, UPPER, false);
+    int rlo = 0, rhi = 0;                                                 // the partner's value of the same index
+    rlo = __builtin_amdgcn_update_dpp(rlo, __double2loint(a), CTRL, 0xF, LOWER, false);
+    rhi = __builtin_amdgcn_update_dpp(rhi, __double2hiint(a), CTRL, 0xF, LOWER, false);
+    rlo = __builtin_amdgcn_update_dpp(rlo, __double2loint(b), CTRL, 0xF, UPPER, false);
+    rhi = __builtin_amdgcn_update_dpp(rhi, __double2hiint(b), CTRL, 0xF, UPPER, false);
+    return __hiloint2double(khi, klo) + __hiloint2double(rhi, rlo);
+}
+
+template <int CTRL>
+GRAPE_DEV double dpp_quad_add(double a)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), CTRL, 0xF, 0xF, true);
+    return a + __hiloint2double(hi, lo);
+}
+
+// 16 values per lane in, the wave-wide sum of value number (lane >> 2) out (in all four lanes of that quad):
+// a reduce-scatter -- 8 + 4 + 2 + 1 pair steps and two quad steps, 17 additions instead of 16 x 6.
+GRAPE_DEV double reduce_scatter16(const double (&v)[16])
+{
+    double a[8], b[4], c[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        a[i] = swap32_add(v[i], v[i + 8]);                // lanes >= 32 keep values 8..15
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        b[i] = swap16_add(a[i], a[i + 4]);                // odd rows keep the upper four of their eight
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        c[i] = dpp_pair_add<0x128, 0xC>(b[i], b[i + 2]);  // row_ror:8; banks 2, 3 (lane bit 3) keep the upper two
+    double d = dpp_pair_add<0x141, 0xA>(c[0], c[1]);      // row_half_mirror; banks 1, 3 (lane bit 2) keep the upper one
+    d = dpp_quad_add<0x4E>(d);                            // quad_perm [2,3,0,1]
+    d = dpp_quad_add<0xB1>(d);                            // quad_perm [1,0,3,2]
+    return d;
+}
+
+// wave-wide maximum of a non-negative double, result in every lane: row rotations + permlane swaps (no LDS round trips)
+GRAPE_DEV double wave_max_fast(double v)
+{
+#define GRAPE_ROR_MAX(CTRL)                                                                                    \
+    {                                                                                                          \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);                \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);                \
+        v = fmax(v, __hiloint2double(hi, lo));                                                                 \
+    }
+    GRAPE_ROR_MAX(0x128)
+    GRAPE_ROR_MAX(0x124)
+    GRAPE_ROR_MAX(0x122)
+    GRAPE_ROR_MAX(0x121)
+#undef GRAPE_ROR_MAX
+    {
+        const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = fmax(__hiloint2double(hi[0], lo[0]), __hiloint2double(hi[1], lo[1]));
+    }
+    {
+        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = fmax(__hiloint2double(hi[0], lo[0]), __hiloint2double(hi[1], lo[1]));
+    }
+    return v;
 }
 
 }  // namespace grape

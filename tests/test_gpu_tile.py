@@ -151,3 +151,53 @@ def test_c4_survey_target_ensemble_metric(qoc, oracle):
         with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, flags=flags) as eng:
             F, G = eng.eval(w.x)
         assert_parity(F, G, F_ref, G_ref, w.n, what=f"C4 survey target, ensemble (flags {flags})")
+
+
+def _sparse_problem(qoc, n, K, N, E, sys_type, seed, nnz_pairs=12):
+    """Hermitian generators whose CONTROL operators are sparse (a few symmetric off-diagonal pairs + diagonal entries),
+    like the Pauli-type controls of the BASELINE configs; mixed states so that the dense state chains run."""
+    w = _random_problem(qoc, n, K, N, E, sys_type, seed, hermitian=True, mixed=True)
+    rng = np.random.default_rng(seed + 1)
+    B = np.zeros_like(w.B)
+    for k in range(E):
+        for c in range(K):
+            for _ in range(nnz_pairs):
+                i, j = rng.integers(0, n, 2)
+                v = rng.standard_normal() + 1j * rng.standard_normal()
+                if i == j:
+                    B[k, c, i, i] = v.real
+                else:
+                    B[k, c, i, j] = v
+                    B[k, c, j, i] = np.conj(v)
+    w.B = B
+    return w
+
+
+@pytest.mark.parametrize("n,sys_type,K", [(9, "UnitaryGate", 3), (16, "UnitaryGate", 16), (16, "StateTransfer", 4),
+                                          (20, "UnitaryGate", 6), (32, "UnitaryGate", 6), (32, "StateTransfer", 2),
+                                          (27, "StateTransfer", 5)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_sparse_control_operators(qoc, oracle, monkeypatch, n, sys_type, K, variant):
+    """control operators with <= 64 non-zeros: the unitary chain reads (coefficient, position) lists from LDS instead of
+    dense transposed operators; same results as the oracle and as the dense path (GRAPE_NO_SPARSE=1)."""
+    w = _sparse_problem(qoc, n, K, 15, 3, sys_type, seed=40 + n + K)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
+                                                            variant=variant, per_member=True)
+    with _engine(qoc, w, variant=variant) as eng:
+        assert eng.info["sparse_controls"] == 1 and eng.info["unitary_flow"] == 1 and eng.info["rank_one_chain"] == 0
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+    for k in range(w.E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], w.n, what=f"n={n} member {k}")
+    assert_parity(F, G, F_ref, G_ref, w.n, what=f"n={n}")
+    monkeypatch.setenv("GRAPE_NO_SPARSE", "1")
+    with _engine(qoc, w, variant=variant) as eng:
+        assert eng.info["sparse_controls"] == 0
+        F_d, G_d = eng.eval(w.x)
+    assert_parity(F, G, F_d, G_d, w.n, what=f"n={n} sparse vs dense lists")
+
+
+def test_c5_controls_are_sparse(qoc):
+    w = qoc.workloads.config("C5", E=2)
+    with _engine(qoc, w) as eng:
+        assert eng.info["sparse_controls"] == 1
