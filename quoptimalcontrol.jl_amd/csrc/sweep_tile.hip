@@ -687,23 +687,26 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
                             make_double2(M.re[I][J][r], M.im[I][J][r]);
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
-            double q16[16];
+            for (int c0 = 0; c0 < K; c0 += 8) {                    // eight controls per reduce-scatter (upper half zero)
+                double q16[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                q16[c] = 0.0;
-                if (c < K) {
-                    const double2 cf = s_coef[c * kSparseMax + lane];
-                    const double2 mv = s_M[s_addr[c * kSparseMax + lane]];
-                    const double pr = cf.x * mv.x - cf.y * mv.y, pi = cf.x * mv.y + cf.y * mv.x;
-                    q16[c] = SAND ? pi : fma(pr, zi, pi * zr);
+                for (int cc = 0; cc < 8; ++cc) {
+                    q16[cc] = 0.0;
+                    q16[8 + cc] = 0.0;
+                    if (c0 + cc < K) {
+                        const double2 cf = s_coef[(c0 + cc) * kSparseMax + lane];
+                        const double2 mv = s_M[s_addr[(c0 + cc) * kSparseMax + lane]];
+                        const double pr = cf.x * mv.x - cf.y * mv.y, pi = cf.x * mv.y + cf.y * mv.x;
+                        q16[cc] = SAND ? pi : fma(pr, zi, pi * zr);
+                    }
                 }
+                const double tot = reduce_scatter16(q16);
+                const int c = c0 + (lane >> 2);
+                if ((lane & 3) == 0 && lane < 32 && c < K)
+                    out[c + (size_t)t * K] = gs * tot;
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);                    // the image is overwritten by the next slice
             __builtin_amdgcn_wave_barrier();
-            const double tot = reduce_scatter16(q16);
-            const int c = lane >> 2;
-            if ((lane & 3) == 0 && c < K)
-                out[c + (size_t)t * K] = gs * tot;
         } else
         for (int c0 = 0; c0 < K; c0 += 4) {
             double v[2 + 8];

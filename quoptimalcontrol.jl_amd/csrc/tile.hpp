@@ -55,9 +55,9 @@ GRAPE_DEV void tzero(TMat<NT> &m)
 template <int NT, bool CONJ_A, bool CONJ_B, typename FA, typename FB>
 GRAPE_DEV void tprod(TMat<NT> &out, FA a, FB b)
 {
-    // k-blocks outermost, all NT x NT output tiles innermost: 2 NT^2 independent accumulator chains are in flight,
-    // so consecutive MFMAs never wait for each other's result (one tile at a time leaves two chains per wave: a wave
-    // that has its SIMD to itself then issues one v_mfma_f64_16x16x4 per ~100 cycles instead of ~61)
+    // k-blocks outermost, all NT x NT output tiles innermost, accumulating in `out` itself.  (The order does not matter
+    // for the issue rate: tools/ubench/mfma_chains.hip shows ONE dependent v_mfma_f64_16x16x4 chain of one wave already
+    // running at one instruction per ~62 cycles -- back-to-back accumulation has no penalty on gfx950.)
     tzero(out);
 #pragma unroll
     for (int Kt = 0; Kt < NT; ++Kt)
