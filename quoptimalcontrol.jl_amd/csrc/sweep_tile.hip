@@ -190,7 +190,60 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 1) void prop_tile_kernel(const T
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NT, int SAND, bool KEEPL, bool PACK2>
+// Gradient traces from sparse control operators (TileParams.sparse): R (the matrix whose trace with B_c is wanted:
+// M_t, or [X_t, L_t'] / X_t L_t') goes to the wave's LDS image once, every lane picks the entry of its list position,
+// and one reduce-scatter per eight controls delivers  out_t[c] = gs * sum_nz (SAND ? Im : Im(. * z)) .
+template <int NT, int SAND>
+GRAPE_DEV void sparse_traces(const TMat<NT> &R, double2 *__restrict__ s_M, const double2 *__restrict__ s_coef,
+                             const int *__restrict__ s_addr, int K, double zr, double zi, double gs,
+                             double *__restrict__ out_t, int lane, bool writer_ok)
+{
+    constexpr int MS = 16 * NT + 1;
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                s_M[(16 * I + 4 * r + (lane >> 4)) * MS + 16 * J + (lane & 15)] = make_double2(R.re[I][J][r], R.im[I][J][r]);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int c0 = 0; c0 < K; c0 += 8) {                            // eight controls per reduce-scatter (upper half zero)
+        double q16[16];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            q16[cc] = 0.0;
+            q16[8 + cc] = 0.0;
+            if (c0 + cc < K) {
+                const double2 cf = s_coef[(c0 + cc) * kSparseMax + lane];
+                const double2 mv = s_M[s_addr[(c0 + cc) * kSparseMax + lane]];
+                const double pr = cf.x * mv.x - cf.y * mv.y, pi = cf.x * mv.y + cf.y * mv.x;
+                q16[cc] = SAND ? pi : fma(pr, zi, pi * zr);
+            }
+        }
+        const double tot = reduce_scatter16(q16);
+        const int c = c0 + (lane >> 2);
+        if (writer_ok && (lane & 3) == 0 && lane < 32 && c < K)
+            out_t[c] = gs * tot;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                            // the image is overwritten by the next slice
+    __builtin_amdgcn_wave_barrier();
+}
+
+// sparse-list staging: [coefficients K * kSparseMax double2 | image of M | positions K * kSparseMax int]
+template <int NT>
+GRAPE_DEV void stage_sparse_lists(const TileParams &p, int k, int lane, int nthreads, double2 *s_coef, int *s_addr)
+{
+    const double2 *__restrict__ gc = p.sp_coef + (size_t)k * p.K * kSparseMax;
+    const int32_t *__restrict__ ga = p.sp_addr + (size_t)k * p.K * kSparseMax;
+    for (int i = lane; i < p.K * kSparseMax; i += nthreads) {
+        s_coef[i] = gc[i];
+        s_addr[i] = ga[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NT, int SAND, bool KEEPL, bool PACK2, bool SPARSE = false>
 __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
 {
     constexpr int TSZ = NT * NT * 256;
@@ -198,14 +251,21 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
     // K transposed control operators, read K times per slice by the gradient traces
     extern __shared__ double2 s_dynt[];
     double2 *s_img = s_dynt;
-    double2 *s_bt = s_dynt + kTileImage + 1;
+    double2 *s_bt = s_dynt + kTileImage + 1;                       // SPARSE: coefficients | image | positions instead
+    double2 *s_coef = s_bt;
+    double2 *s_M = s_coef + (size_t)p.K * kSparseMax;
+    int *s_addr = reinterpret_cast<int *>(s_M + 16 * NT * (16 * NT + 1));
     const int lane = threadIdx.x;
     const int k = blockIdx.x;
     const int K = p.K, N = p.N;
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
     const double2 *__restrict__ opBT = ops + (size_t)(1 + K) * TSZ;
     const bool bt_lds = p.bt_in_lds != 0;
-    if (bt_lds) {
+    if (SPARSE) {
+        stage_sparse_lists<NT>(p, k, lane, 64, s_coef, s_addr);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    } else if (bt_lds) {
         for (int i = lane; i < K * TSZ; i += 64)
             s_bt[i] = opBT[i];
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -251,6 +311,7 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
     TOp<NT> XA, LA;
     tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);               // Xt
     const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
+    double z_keep_r = 0.0, z_keep_i = 0.0;
     tload(Pm, Pk + (size_t)(N - 1) * TSZ, lane);
     tload(X, Xk + (size_t)(N - 1) * TSZ, lane);
     for (int t = N - 1; t >= 0; --t) {
@@ -286,6 +347,20 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
         // all cross-lane sums of this slice are taken together (wave_sum_n): tr(X' L) and, per
         // control, sum R .* B^T
         double zr = 0.0, zi = 0.0;
+        if (SPARSE) {
+            // tr(X_t' L_t) does not depend on t, not even for non-unitary P: taken once, at the
+            // first slice processed; every lane's share of g[c, t] is then one real number
+            if (t == N - 1) {
+                double zz[2];
+                tdot_partial<NT, true>(zz[0], zz[1], X, L);
+                wave_sum_n(zz);
+                z_keep_r = zz[0];
+                z_keep_i = zz[1];
+            }
+            zr = z_keep_r;
+            zi = z_keep_i;
+            sparse_traces<NT, SAND>(R, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane, member < p.E_members);
+        } else
         for (int c0 = 0; c0 < K; c0 += 4) {
             double v[2 + 8];
             tdot_partial<NT, true>(v[0], v[1], X, L);              // tr(X' L)
@@ -574,12 +649,7 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
     const double2 *__restrict__ opBT = ops + (size_t)(1 + K) * TSZ;
     const bool bt_lds = p.bt_in_lds != 0;
     if (SPARSE) {
-        const double2 *__restrict__ gc = p.sp_coef + (size_t)k * K * kSparseMax;
-        const int32_t *__restrict__ ga = p.sp_addr + (size_t)k * K * kSparseMax;
-        for (int i = lane; i < K * kSparseMax; i += 64) {
-            s_coef[i] = gc[i];
-            s_addr[i] = ga[i];
-        }
+        stage_sparse_lists<NT>(p, k, lane, 64, s_coef, s_addr);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     } else if (bt_lds) {
@@ -677,36 +747,7 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
         if (SPARSE) {
             // tr(B_c M_t) = sum over the non-zeros B_c[i][j] of B_c[i][j] M_t[j][i]; with z = conj(tr M) taken once
             // (the trace is invariant under M -> P' M P) every lane's share of g[c, t] is one real number
-#pragma unroll
-            for (int I = 0; I < NT; ++I)
-#pragma unroll
-                for (int J = 0; J < NT; ++J)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        s_M[(16 * I + 4 * r + (lane >> 4)) * MS + 16 * J + (lane & 15)] =
-                            make_double2(M.re[I][J][r], M.im[I][J][r]);
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            for (int c0 = 0; c0 < K; c0 += 8) {                    // eight controls per reduce-scatter (upper half zero)
-                double q16[16];
-#pragma unroll
-                for (int cc = 0; cc < 8; ++cc) {
-                    q16[cc] = 0.0;
-                    q16[8 + cc] = 0.0;
-                    if (c0 + cc < K) {
-                        const double2 cf = s_coef[(c0 + cc) * kSparseMax + lane];
-                        const double2 mv = s_M[s_addr[(c0 + cc) * kSparseMax + lane]];
-                        const double pr = cf.x * mv.x - cf.y * mv.y, pi = cf.x * mv.y + cf.y * mv.x;
-                        q16[cc] = SAND ? pi : fma(pr, zi, pi * zr);
-                    }
-                }
-                const double tot = reduce_scatter16(q16);
-                const int c = c0 + (lane >> 2);
-                if ((lane & 3) == 0 && lane < 32 && c < K)
-                    out[c + (size_t)t * K] = gs * tot;
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);                    // the image is overwritten by the next slice
-            __builtin_amdgcn_wave_barrier();
+            sparse_traces<NT, SAND>(M, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane, true);
         } else
         for (int c0 = 0; c0 < K; c0 += 4) {
             double v[2 + 8];
@@ -841,6 +882,13 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     } else if (p.unitary && !keepl) {
         if (sandwich) { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 1, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 1, false>)); }
         else          { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 0, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 0, false>)); }
+    } else if (p.sparse && !pk) {
+        const size_t lds_sp = sizeof(double2) * (kTileImage + 1 + (size_t)p.K * kSparseMax + 16 * NT * (16 * NT + 1)) +
+                              sizeof(int32_t) * (size_t)p.K * kSparseMax;
+#define GRAPE_LAUNCH_SP(KERNEL) hipLaunchKernelGGL(KERNEL, grid, block, lds_sp, stream, q)
+        if (sandwich) { if (keepl) GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 1, true, false, true>)); else GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 1, false, false, true>)); }
+        else          { if (keepl) GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 0, true, false, true>)); else GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 0, false, false, true>)); }
+#undef GRAPE_LAUNCH_SP
     } else if (sandwich) {
         if (keepl) { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_kernel<NT, 1, true, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_kernel<NT, 1, true, false>)); }
         else       { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_kernel<NT, 1, false, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_kernel<NT, 1, false, false>)); }

@@ -197,6 +197,32 @@ def test_sparse_control_operators(qoc, oracle, monkeypatch, n, sys_type, K, vari
     assert_parity(F, G, F_d, G_d, w.n, what=f"n={n} sparse vs dense lists")
 
 
+@pytest.mark.parametrize("n,sys_type,K,keep", [(12, "StateTransfer", 3, True), (16, "UnitaryGate", 9, True),
+                                                 (24, "StateTransfer", 4, False), (32, "UnitaryGate", 6, False),
+                                                 (32, "CoherenceTransfer", 5, True)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_sparse_control_operators_general_flow(qoc, oracle, monkeypatch, n, sys_type, K, keep, variant):
+    """non-Hermitian drift (general flow, chain_tile_kernel) with sparse control operators; keep: the debug flow,
+    which also runs that kernel for n <= 16 (small ensembles otherwise take the two-wave split kernel)."""
+    w = _sparse_problem(qoc, n, K, 13, 3, sys_type, seed=70 + n + K)
+    rng = np.random.default_rng(n)
+    w.A = w.A + 0.2j * np.array([np.diag(rng.uniform(-1, 0, n)) for _ in range(w.E)])      # damping: not Hermitian
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
+                                                            variant=variant, per_member=True)
+    flags = qoc.engine.FLAG_KEEP_COSTATES if keep else 0
+    with _engine(qoc, w, variant=variant, flags=flags) as eng:
+        assert eng.info["sparse_controls"] == 1 and eng.info["unitary_flow"] == 0
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+    for k in range(w.E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], w.n, what=f"n={n} member {k}")
+    assert_parity(F, G, F_ref, G_ref, w.n, what=f"n={n}")
+    monkeypatch.setenv("GRAPE_NO_SPARSE", "1")
+    with _engine(qoc, w, variant=variant, flags=flags) as eng:
+        F_d, G_d = eng.eval(w.x)
+    assert_parity(F, G, F_d, G_d, w.n, what=f"n={n} sparse vs dense lists")
+
+
 def test_c5_controls_are_sparse(qoc):
     w = qoc.workloads.config("C5", E=2)
     with _engine(qoc, w) as eng:
