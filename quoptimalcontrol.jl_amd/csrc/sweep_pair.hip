@@ -30,6 +30,7 @@
 namespace grape {
 
 enum { PMODE_GENERAL = 0, PMODE_GENERAL_KEEPL = 1, PMODE_UNITARY = 2 };
+constexpr int kParityPad = 8;          // double2 slots (128 B = half an LDS row of 64 banks) between a member's two parity images
 
 // global element index i + j n of local element (r, jl) as seen by a lane of parity q
 template <int N>
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
     constexpr bool UNI = (MODE == PMODE_UNITARY);
     constexpr bool KEEPL = (MODE == PMODE_GENERAL_KEEPL);
     // dynamic LDS:  s_tot  2*MAXW*NN double2   wave totals of the two scans (both parity halves)
-    //               s_ops  MPB * 2 * NM * NE double2   parity images of the members' operators
+    //               s_ops  MPB * 2 * PS double2, PS = NM * NE + 8: parity images of the members' operators (the pad puts the
+    //                      two parities' images half an LDS row apart: a wave reads BOTH addresses in one instruction)
     //               s_xg   MPB*CH*(S*K+1) double      controls in / gradient out, chunk stride odd
     //               s_F    MPB double
     extern __shared__ double2 s_dyn[];
@@ -199,17 +201,18 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
     const int NM = 2 * K + 4;                     // images: A', B'_c, B'_c^T, Xi, Xt, and Xi Xt' (built in the prologue)
 
     double2 *s_ops_all = s_dyn + 2 * MAXW * NN;
-    double2 *s_ops = s_ops_all + (size_t)mb * 2 * NM * NE;
+    const int PS = NM * NE + kParityPad;          // stride between the two parity images of a member
+    double2 *s_ops = s_ops_all + (size_t)mb * 2 * PS;
     const int SK = S * K;
     const size_t nrm_d2 = ((size_t)p.MPB * (K + 1) + 1) / 2;        // double2 slots of the operator-norm table
-    double *s_xg_all = XGLDS ? reinterpret_cast<double *>(s_ops_all + (size_t)p.MPB * 2 * NM * NE + nrm_d2)
+    double *s_xg_all = XGLDS ? reinterpret_cast<double *>(s_ops_all + (size_t)p.MPB * 2 * PS + nrm_d2)
                              : p.xg_scratch + (size_t)blockIdx.x * ((size_t)p.MPB * CH * (SK + 1) + p.MPB);
     double *s_xg = s_xg_all + (size_t)mb * CH * (SK + 1);
     double *s_F = s_xg_all + (size_t)p.MPB * CH * (SK + 1);
     // (optional) the chunks' last propagators: element e of thread T at s_plast[e * blockDim.x + T]
     double2 *s_plast = reinterpret_cast<double2 *>(s_F + ((p.MPB + 1) & ~1));
     // 1-norm bounds (max column sum of |re| + |im|) of this member's A' and B'_c: |G_t|_1 <= nrm[0] + sum |x_c| nrm[1+c]
-    double *s_nrm = reinterpret_cast<double *>(s_ops_all + (size_t)p.MPB * 2 * NM * NE) + (size_t)mb * (K + 1);
+    double *s_nrm = reinterpret_cast<double *>(s_ops_all + (size_t)p.MPB * 2 * PS) + (size_t)mb * (K + 1);
     const unsigned magic = p.sk_magic;
     auto chunk_of = [&](int q) { return SK == 1 ? q : (int)__umulhi((unsigned)q, magic); };
     {
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
             if (mat <= K)            src = mat * NN + i + j * N;                 // A', B'_c
             else if (mat <= 2 * K)   src = (mat - K) * NN + j + i * N;           // B'_c transposed
             else                     src = (mat - K) * NN + i + j * N;           // Xi, Xt
-            s_ops[idx] = ops[src];
+            s_ops[(size_t)q * PS + rem] = ops[src];
         }
     }
     if (L < 2 * NE) {                                // Xi Xt' (unitary UnitaryGate fix-up), one entry per lane, from the global operators
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
             sr = fma(a.x, b.x, sr); sr = fma(a.y, b.y, sr);
             si = fma(a.y, b.x, si); si = fma(-a.x, b.y, si);
         }
-        s_ops[((size_t)q * NM + (2 * K + 3)) * NE + e] = make_double2(sr, si);
+        s_ops[(size_t)q * PS + (size_t)(2 * K + 3) * NE + e] = make_double2(sr, si);
     }
     __syncthreads();
     if (L <= K) {                                    // one lane per generator: max column sum of |re| + |im|
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
             for (int jl = 0; jl < NC; ++jl) {
                 double cs = 0.0;
                 for (int r = 0; r < N; ++r) {
-                    const double2 v = s_ops[((size_t)q * NM + L) * NE + r + jl * N];
+                    const double2 v = s_ops[(size_t)q * PS + (size_t)L * NE + r + jl * N];
                     cs += fabs(v.x) + fabs(v.y);
                 }
                 best = fmax(best, cs);
@@ -274,12 +277,12 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
         s_nrm[L] = best;
     }
     __syncthreads();
-    const double2 *sA = s_ops + (size_t)par * NM * NE;          // my parity's images
+    const double2 *sA = s_ops + (size_t)par * PS;               // my parity's images
     const double2 *sB = sA + NE;
     const double2 *sBT = sA + (size_t)(1 + K) * NE;
     const double2 *sXi = sA + (size_t)(1 + 2 * K) * NE;
     const double2 *sXt = sXi + NE;
-    const double2 *sXi_o = s_ops + (size_t)(1 - par) * NM * NE + (size_t)(1 + 2 * K) * NE;   // the partner's images
+    const double2 *sXi_o = s_ops + (size_t)(1 - par) * PS + (size_t)(1 + 2 * K) * NE;   // the partner's images
     const double2 *sXt_o = sXi_o + NE;
     const double2 *sXX = sXt + NE, *sXX_o = sXt_o + NE;
     double *xg = s_xg + ch * (SK + 1);
@@ -741,7 +744,7 @@ size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool xg_in_lds
 {
     const int maxt = n == 2 ? PairTraits<2>::MAXT : PairTraits<4>::MAXT;
     size_t b = sizeof(double2) * (2 * (size_t)(maxt / 64) * n * n);
-    b += sizeof(double2) * ((size_t)MPB * 2 * (2 * K + 4) * (n * (n / 2)) + ((size_t)MPB * (K + 1) + 1) / 2);
+    b += sizeof(double2) * ((size_t)MPB * 2 * ((2 * K + 4) * (n * (n / 2)) + kParityPad) + ((size_t)MPB * (K + 1) + 1) / 2);
     if (xg_in_lds)
         b += sizeof(double) * ((size_t)MPB * (LT / 2) * ((size_t)S * K + 1) + ((MPB + 1) & ~1));
     if (plast)
