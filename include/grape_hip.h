@@ -80,6 +80,11 @@ enum {
                                            applies.  KEEP_COSTATES implies it.          */
     GRAPE_FLAG_TIME_SAMPLED = 1 << 6,   /* with TIME_KERNELS: record the event pair on every 8th evaluation only
                                            (an event pair costs ~5 us of a ~90 us host->host call)  */
+    GRAPE_FLAG_GROUP_PEER_SUM = 1 << 7, /* multi-device contexts (n_devices >= 2): sum the shards' [G, F] on the first device
+                                           through peer copies and one reduction kernel (fixed shard order) instead of the
+                                           RCCL all-reduce; librccl is not loaded, and device_ids may repeat a device
+                                           (several shards on one GPU: the way the sharding logic is tested on a one-GPU
+                                           machine)                                                                    */
     GRAPE_FLAG_FORCE_COLLECTIVE = 1 << 5 /* create the RCCL communicator and run the all-reduce of
                                            [G, F] even when the context spans ONE device (a
                                            1-rank collective: exercises the multi-GPU code path

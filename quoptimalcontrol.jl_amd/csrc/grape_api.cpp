@@ -79,6 +79,9 @@ struct grape_ctx {
     // host-visible completion of an evaluation: the final kernel's last workgroup publishes `seq` in h_flag
     unsigned long long *h_flag = nullptr, *d_h_flag = nullptr;
     unsigned *d_done_counter = nullptr;
+    bool peer_sum = false;                     // group: [G, F] summed on the first device through peer copies (no RCCL)
+    double *d_gather = nullptr;                // group, peer_sum: one row of K*N+1 doubles per shard, on the first device
+    hipEvent_t ev_done = nullptr;              // shard of a peer_sum group: its evaluation has finished
     bool thin = false;                         // rank-one states: matrix-vector chain (sweep_thin.hip)
     bool herm_ctrl = false;                    // every B_c Hermitian
     double2 *d_vecs = nullptr;                 // thin: per member [v0 | wT], 16 complex each
@@ -208,11 +211,16 @@ static void free_all(grape_ctx *c)
     if (!c) return;
     for (grape_ctx *s : c->sub) free_all(s);
     c->sub.clear();
-    if (c->is_group) { delete c; return; }
+    if (c->is_group) {
+        if (c->d_gather) { (void)hipSetDevice(c->device); (void)hipFree(c->d_gather); }
+        delete c;
+        return;
+    }
     (void)hipSetDevice(c->device);
     if (c->comm && g_rccl.handle) (void)g_rccl.CommDestroy(c->comm);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_dev) (void)hipEventDestroy(c->ev_dev);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     (void)hipFree(c->d_ops); (void)hipFree(c->d_wts); (void)hipFree(c->d_x); (void)hipFree(c->d_fg);
     (void)hipFree(c->d_props); (void)hipFree(c->d_states); (void)hipFree(c->d_costates);
@@ -445,6 +453,7 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_dev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
     if (e == hipSuccess && (cfg->flags & GRAPE_FLAG_TIME_KERNELS)) {
         c->ev.reserve(2 * kEventRing);
         for (size_t i = 0; i < 2 * kEventRing && e == hipSuccess; ++i) {
@@ -491,8 +500,9 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
                             "grape_create: device_ids[" + std::to_string(i) + "]=" + std::to_string(d) +
                                 " but " + std::to_string(ndev) + " HIP device(s) are visible");
             for (int j = 0; j < i; ++j)
-                if (cfg->device_ids[j] == d)
-                    return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: device_ids holds a duplicate");
+                if (cfg->device_ids[j] == d && !(cfg->flags & GRAPE_FLAG_GROUP_PEER_SUM))
+                    return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: device_ids holds a duplicate "
+                                                                "(allowed only with GRAPE_FLAG_GROUP_PEER_SUM)");
             devs.push_back(d);
         }
     } else {
@@ -511,8 +521,9 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: max_batch > 1 is single-device in this build");
     if (cfg->flags & GRAPE_FLAG_PHASE_STAMPS)
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: GRAPE_FLAG_PHASE_STAMPS is single-device");
-    RcclApi *api = rccl();
-    if (!api) return fail(nullptr, GRAPE_ERR_COMM, "grape_create: " + g_rccl.err);
+    const bool peer_sum = (cfg->flags & GRAPE_FLAG_GROUP_PEER_SUM) != 0 && cfg->n_devices >= 2;
+    RcclApi *api = peer_sum ? nullptr : rccl();
+    if (!peer_sum && !api) return fail(nullptr, GRAPE_ERR_COMM, "grape_create: " + g_rccl.err);
 
     grape_ctx *g = new (std::nothrow) grape_ctx();
     if (!g) return fail(nullptr, GRAPE_ERR_ALLOC, "grape_create: out of host memory");
@@ -525,23 +536,38 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
         sc.n_ensemble = g->sub_lo[i + 1] - g->sub_lo[i];
         sc.device = devs[i];
         sc.n_devices = 0;
-        sc.flags &= ~GRAPE_FLAG_FORCE_COLLECTIVE;
+        sc.flags &= ~(GRAPE_FLAG_FORCE_COLLECTIVE | GRAPE_FLAG_GROUP_PEER_SUM);
         grape_ctx *s = nullptr;
         rc = create_shard(&sc, devs[i], &s);
         if (rc) { free_all(g); return rc; }
         g->sub.push_back(s);
     }
-    std::vector<ncclComm_t> comms(G);
-    std::vector<int> used(devs.begin(), devs.begin() + G);
-    const ncclResult_t nr = api->CommInitAll(comms.data(), G, used.data());
-    if (nr != ncclSuccess) {
-        free_all(g);
-        return fail(nullptr, GRAPE_ERR_COMM, std::string("grape_create: ncclCommInitAll: ") + api->GetErrorString(nr));
-    }
-    for (int i = 0; i < G; ++i) {
-        g->sub[i]->comm = comms[i];
-        g->sub[i]->comm_rank = i;
-        g->sub[i]->comm_size = G;
+    if (peer_sum) {
+        g->peer_sum = true;
+        g->device = g->sub[0]->device;
+        const size_t Q = (size_t)cfg->n_controls * cfg->n_slices + 1;
+        if (hipSetDevice(g->device) != hipSuccess ||
+            hipMalloc((void **)&g->d_gather, sizeof(double) * Q * G) != hipSuccess) {
+            free_all(g);
+            return fail(nullptr, GRAPE_ERR_ALLOC, "grape_create: device allocation failed (shard gather buffer)");
+        }
+        for (int i = 0; i < G; ++i) {
+            g->sub[i]->comm_rank = i;
+            g->sub[i]->comm_size = G;
+        }
+    } else {
+        std::vector<ncclComm_t> comms(G);
+        std::vector<int> used(devs.begin(), devs.begin() + G);
+        const ncclResult_t nr = api->CommInitAll(comms.data(), G, used.data());
+        if (nr != ncclSuccess) {
+            free_all(g);
+            return fail(nullptr, GRAPE_ERR_COMM, std::string("grape_create: ncclCommInitAll: ") + api->GetErrorString(nr));
+        }
+        for (int i = 0; i < G; ++i) {
+            g->sub[i]->comm = comms[i];
+            g->sub[i]->comm_rank = i;
+            g->sub[i]->comm_size = G;
+        }
     }
     const grape_ctx *s0 = g->sub[0];
     g->device = s0->device; g->compute_units = s0->compute_units; g->family = s0->family;
@@ -1165,6 +1191,9 @@ static int wait_flag(grape_ctx *s)
 
 static int group_fail(grape_ctx *g, grape_ctx *s, int rc) { return fail(g, rc, s->err); }
 
+static int enqueue_peer_sum(grape_ctx *g, double *target, hipStream_t lead_stream, bool shard0_on_lead,
+                            grape::DoneSignal done);
+
 extern "C" int grape_eval_device(grape_ctx *c, const double *d_x, double *d_fg, void *stream)
 {
     if (!c) return GRAPE_ERR_INVALID_ARG;
@@ -1198,6 +1227,15 @@ extern "C" int grape_eval_device(grape_ctx *c, const double *d_x, double *d_fg, 
         rc = enqueue_eval(s, s->d_x, s->d_fg, s->stream);
         if (rc) return group_fail(c, s, rc);
     }
+    if (c->peer_sum) {
+        rc = enqueue_peer_sum(c, d_fg, st, true, grape::DoneSignal());
+        if (rc) return rc;
+        HIP_TRY(c, hipSetDevice(s0->device));
+        HIP_TRY(c, hipEventRecord(s0->ev_dev, st));
+        s0->dev_pending = true;
+        c->evaluated = true;
+        return GRAPE_OK;
+    }
     NCCL_TRY(c, g_rccl.GroupStart());
     for (size_t i = 0; i < c->sub.size(); ++i) {
         grape_ctx *s = c->sub[i];
@@ -1213,6 +1251,29 @@ extern "C" int grape_eval_device(grape_ctx *c, const double *d_x, double *d_fg, 
     HIP_TRY(c, hipEventRecord(s0->ev_dev, st));
     s0->dev_pending = true;
     c->evaluated = true;
+    return GRAPE_OK;
+}
+
+// peer_sum group: every shard's [G, F] (K*N+1 doubles in its d_fg) is copied to the first device behind that shard's
+// own evaluation and ONE reduction kernel sums the rows in shard order into `target` (and, with `done`, publishes them
+// to the host like the single-GPU path).  `shard0_on_lead`: shard 0 was evaluated on `lead_stream` itself.
+static int enqueue_peer_sum(grape_ctx *g, double *target, hipStream_t lead_stream, bool shard0_on_lead,
+                            grape::DoneSignal done)
+{
+    grape_ctx *lead = g->sub[0];
+    const size_t Q = KN(g) + 1;
+    for (size_t i = 0; i < g->sub.size(); ++i) {
+        grape_ctx *s = g->sub[i];
+        if (!(i == 0 && shard0_on_lead)) {
+            HIP_TRY(g, hipSetDevice(s->device));
+            HIP_TRY(g, hipEventRecord(s->ev_done, s->stream));
+            HIP_TRY(g, hipSetDevice(lead->device));
+            HIP_TRY(g, hipStreamWaitEvent(lead_stream, s->ev_done, 0));
+        }
+        HIP_TRY(g, hipSetDevice(lead->device));
+        HIP_TRY(g, hipMemcpyPeerAsync(g->d_gather + i * Q, lead->device, s->d_fg, s->device, sizeof(double) * Q, lead_stream));
+    }
+    HIP_TRY(g, grape::launch_reduce_rows(g->d_gather, target, (int)g->sub.size(), (int)Q, 1, lead_stream, done));
     return GRAPE_OK;
 }
 
@@ -1233,7 +1294,19 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
         rc = shard_enqueue_host(c, x, n_x, c->d_h_fg, true);
         if (rc) return rc;
     } else {
-        if (c->is_group) {
+        if (c->is_group && c->peer_sum) {
+            for (grape_ctx *s : c->sub) {
+                rc = shard_enqueue_host(s, x, 1, s->d_fg, false);
+                if (rc) return group_fail(c, s, rc);
+            }
+            grape::DoneSignal done;                          // the reduction kernel publishes like the single-GPU path
+            done.counter = lead->d_done_counter;
+            done.flag = lead->d_h_flag;
+            done.seq = ++lead->seq;
+            done.host_out = lead->d_h_fg;
+            rc = enqueue_peer_sum(c, lead->d_fg, lead->stream, true, done);
+            if (rc) return rc;
+        } else if (c->is_group) {
             for (grape_ctx *s : c->sub) {
                 rc = shard_enqueue_host(s, x, 1, s->d_fg, false);
                 if (rc) return group_fail(c, s, rc);
@@ -1253,12 +1326,14 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
             rc = enqueue_allreduce(c, c->d_fg, c->d_fg, c->stream);
             if (rc) return rc;
         }
-        HIP_TRY(c, hipSetDevice(lead->device));
-        grape::DoneSignal done;
-        done.counter = lead->d_done_counter;
-        done.flag = lead->d_h_flag;
-        done.seq = ++lead->seq;
-        HIP_TRY(c, grape::launch_copy(lead->d_fg, lead->d_h_fg, (int)Q, lead->stream, done));
+        if (!(c->is_group && c->peer_sum)) {
+            HIP_TRY(c, hipSetDevice(lead->device));
+            grape::DoneSignal done;
+            done.counter = lead->d_done_counter;
+            done.flag = lead->d_h_flag;
+            done.seq = ++lead->seq;
+            HIP_TRY(c, grape::launch_copy(lead->d_fg, lead->d_h_fg, (int)Q, lead->stream, done));
+        }
     }
     rc = wait_flag(lead);                                    // [G, F] are in host memory
     if (rc) return c->is_group ? group_fail(c, lead, rc) : rc;

@@ -26,6 +26,7 @@ FLAG_FORCE_GENERAL = 8
 FLAG_MEMBER_RESULTS = 16
 FLAG_FORCE_COLLECTIVE = 32
 FLAG_TIME_SAMPLED = 64
+FLAG_GROUP_PEER_SUM = 128
 MAX_DEVICES = 8
 ABI_VERSION = 2
 

@@ -100,3 +100,49 @@ def test_timed_event_ring_wraps(qoc):
         eng.eval(w.x)
         ms2, n2 = eng.kernel_time()
         assert n2 == 1 and ms2 < ms
+
+
+@pytest.mark.parametrize("name,kw,devices", [("C3", {"E": 5, "N": 70}, [0, 0]), ("C3", {"E": 7, "N": 33}, [0, 0, 0]),
+                                             ("C1", {}, [0, 0]), ("C4", {"E": 5, "N": 24}, [0, 0]),
+                                             ("C3", {"E": 9, "N": 40}, [0, 0, 0, 0, 0, 0, 0, 0])])
+def test_multi_shard_group_on_one_gpu_with_peer_sum(qoc, oracle, name, kw, devices):
+    """SEVERAL shards behind one context on the one GPU there is (GRAPE_FLAG_GROUP_PEER_SUM lets device_ids repeat and
+    sums the shards' [G, F] on the first device instead of calling RCCL): contiguous ceil(E / G) blocks incl. empty
+    trailing ones, operator slicing, x fan-out, the sum, accessor routing -- everything of the in-library multi-GPU
+    path except the collective itself."""
+    import torch
+    w = qoc.workloads.config(name, **kw)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
+                                                             per_member=True)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, devices=devices,
+                         flags=qoc.engine.FLAG_GROUP_PEER_SUM, member_results=True) as eng:
+        info = eng.info
+        per = -(-w.E // len(devices))
+        assert info["n_devices"] == min(len(devices), -(-w.E // per)) and info["members_first_device"] == min(per, w.E)
+        F, G = eng.eval(w.x)
+        F2, G2 = eng.eval(w.x)
+        foms, grads = eng.member_results()
+        P_last = eng.trajectory(w.E - 1, states=False)[0]      # lives on the last non-empty shard
+        xd = torch.as_tensor(np.ascontiguousarray(w.x.T), device="cuda")
+        fg = torch.zeros(w.K * w.N + 1, dtype=torch.float64, device="cuda")
+        eng.eval_device(xd.data_ptr(), fg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        h = fg.cpu().numpy()
+        F3, G3 = eng.eval(0.5 * w.x)                            # host path right after the device path
+    assert_parity(F, G, F_ref, G_ref, w.n, what="multi-shard eval")
+    assert F == F2 and np.array_equal(G, G2)
+    assert h[-1] == F and np.array_equal(h[:-1].reshape(w.N, w.K).T, G)
+    for k in range(w.E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], w.n, what=f"member {k}")
+    if name == "C3":
+        P_ref = oracle.member_eval(w.sys_type, w.A[-1], w.B[-1], w.Xi[-1], w.Xt[-1], w.x, w.T, trajectory=True)[2]
+        assert np.abs(P_last - P_ref).max() <= 1e-12
+    F3_ref, G3_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, 0.5 * w.x, w.T)
+    assert_parity(F3, G3, F3_ref, G3_ref, w.n, what="second control array")
+
+
+def test_duplicate_devices_need_the_peer_sum_flag(qoc):
+    w = qoc.workloads.config("C3", E=4, N=10)
+    with pytest.raises(qoc.GrapeError) as ei:
+        qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, devices=[0, 0])
+    assert "duplicate" in str(ei.value)
