@@ -44,7 +44,7 @@ struct GrapeConfig
     n_state_cols::Int32              # ABI v2: 0 = square states
     n_devices::Int32                 # ABI v2: 0/1 = one GPU; 2..8 = in-library sharding + RCCL all-reduce
     device_ids::NTuple{8,Int32}
-    gradient::Int32                  # 0 = reference first-order gradient, 1 = exact (n <= 4)
+    gradient::Int32                  # 0 = reference first-order gradient, 1 = exact (n <= 32)
     objective::Int32                 # 0 = fom_func, 1 = C1 functional of the ADGRAPE path
 end
 
@@ -58,8 +58,13 @@ Base.@kwdef struct GRAPE_HIP{OPTS}
     isinplace::Bool = true           # selects the in-place / static formula variant (sign, sum order)
     device::Int = -1
     devices::Vector{Int} = Int[]     # 2..8 HIP ordinals: the ensemble is sharded over them inside the library
+    peer_sum::Bool = false           # GRAPE_FLAG_GROUP_PEER_SUM: sum the shards on devices[1] by peer copies, no RCCL
     optim_options::OPTS = Optim.Options()
 end
+
+const GRAPE_FLAG_GROUP_PEER_SUM = Int32(1 << 7)
+cfg_flags(alg::GRAPE_HIP) = alg.peer_sum ? GRAPE_FLAG_GROUP_PEER_SUM : Int32(0)
+cfg_flags(alg) = Int32(0)
 
 """
 Counterpart of `ADGRAPE` (src/solve.jl:44-52): the functional C1(Xt, U Xi [U']) of src/solve.jl:268-361 with its
@@ -89,7 +94,7 @@ mutable struct GrapeContext
         ids = ntuple(i -> i <= nd ? Int32(alg.devices[i]) : Int32(0), 8)
         variant, gradient, objective = cfg_mode(alg)
         cfg = GrapeConfig(sys_code(p1.sys_type), variant, n, K, N, E, Float64(p1.T),
-                          nd == 1 ? alg.devices[1] : alg.device, 0, 0, 0, -1, 0, m == n ? 0 : m, nd > 1 ? nd : 0, ids,
+                          nd == 1 ? alg.devices[1] : alg.device, cfg_flags(alg), 0, 0, -1, 0, m == n ? 0 : m, nd > 1 ? nd : 0, ids,
                           gradient, objective)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:grape_create, libgrape), Cint, (Ref{GrapeConfig}, Ref{Ptr{Cvoid}}), cfg, h)
