@@ -69,6 +69,7 @@ class ShardedGrape:
         self.local = make_local(self.lo, self.hi) if self.hi > self.lo else None
         self.fg = torch.zeros(K * N + 1, dtype=torch.float64, device=device)
         self.collective = "torch"
+        self.stage_through_host = False               # torch fallback on a gloo group with device tensors
         self.comm_size = self.world
         self.attach_timeout_s = 180.0
         if collective == "lib" and (self.world > 1 or force_collective):
@@ -116,11 +117,24 @@ class ShardedGrape:
             self.collective = "lib"
             self.comm_size = self.local.info["comm_size"]
         elif self.distributed and self.world > 1 and self.device.type == "cuda" and "nccl" not in dist.get_backend(self.group):
-            # fallback on a gloo control plane: give the data path its own RCCL group (torch's), not gloo
+            # fallback on a gloo control plane: give the data path its own RCCL group (torch's) and PROBE it -- RCCL
+            # refuses, at the first collective, ranks that share a GPU; all ranks then agree to stage through the host
+            control = self.group
+            works = 1
+            nccl_group = None
             try:
-                self.group = dist.new_group(backend="nccl")
+                nccl_group = dist.new_group(backend="nccl")
+                dist.all_reduce(torch.zeros(1, device=self.device), group=nccl_group)
+                torch.cuda.synchronize(self.device)
             except Exception as exc:                  # noqa: BLE001 -- keep the (slow but correct) gloo path
+                works = 0
                 self.attach_error = getattr(self, "attach_error", "") + f"; nccl group: {exc!r}"
+            flag = torch.tensor([works], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=control)
+            if int(flag.item()):
+                self.group = nccl_group
+            else:
+                self.stage_through_host = True
 
     def eval_device(self, x_dev):
         """x_dev: float64 tensor holding x as (K,N) column-major, i.e. shape (N, K) contiguous.
@@ -132,7 +146,14 @@ class ShardedGrape:
         else:
             self.fg.zero_()
         if self.collective == "torch" and (self.world > 1 or self.force_collective):
-            self.dist.all_reduce(self.fg, op=self.dist.ReduceOp.SUM, group=self.group)
+            if self.stage_through_host:
+                if self.device.type == "cuda":
+                    torch.cuda.current_stream(self.device).synchronize()
+                h = self.fg.cpu()
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+                self.fg.copy_(h)
+            else:
+                self.dist.all_reduce(self.fg, op=self.dist.ReduceOp.SUM, group=self.group)
         return self.fg
 
     def eval(self, x):

@@ -146,3 +146,25 @@ def test_duplicate_devices_need_the_peer_sum_flag(qoc):
     with pytest.raises(qoc.GrapeError) as ei:
         qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, devices=[0, 0])
     assert "duplicate" in str(ei.value)
+
+
+def test_two_ranks_sharing_the_gpu_fall_back_consistently(qoc):
+    """`python bench.py --gpus 2` on the one-GPU box (GRAPE_BENCH_SHARE_GPU=1: plumbing only): spawn -> rendezvous ->
+    grape_comm_attach refused by RCCL (both ranks on one GPU) -> torch's nccl group probed and refused -> every rank
+    agrees on the host-staged gloo sum; the JSON line must report both ranks and the right figure of merit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRAPE_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                          "--blocks", "1", "--no-extra", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["config"]["collective"] == "torch" and d["value"] > 0
+    w = qoc.workloads.config("C3")
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        F, _ = eng.eval(w.x)
+    assert abs(d["F"] - F) <= 1e-12
