@@ -33,11 +33,13 @@ namespace grape {
 // instead of once per slice -- the kernel was L2-bandwidth bound: 24 KB of operators per 4 KB of P)
 constexpr int kPropSlices = 64;
 
-template <int NT>
-__global__ __launch_bounds__(256, NT == 1 ? 4 : 1) void prop_tile_kernel(const TileParams p)
+// WPB waves per workgroup.  NT = 2: eight (two per SIMD, <= 256 registers each at the price of ~70 spilled VGPRs): the
+// second wave's MFMAs cover the first one's H build, layout conversions, norm and Taylor combinations.
+template <int NT, int WPB>
+__global__ __launch_bounds__(64 * WPB, NT == 1 ? 4 : 2) void prop_tile_kernel(const TileParams p)
 {
     constexpr int TSZ = NT * NT * 256;                     // double2 per matrix dump
-    constexpr int NIMG = NT;                               // LDS conversion images per wave (one per tile of a row)
+    constexpr int NIMG = WPB == 4 ? NT : 1;                // LDS conversion images per wave
     const bool STAGE = p.stage_ops != 0;                   // set by the launcher when the generator tiles fit in LDS
     extern __shared__ double2 s_prop[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -45,15 +47,15 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 1) void prop_tile_kernel(const T
     const int K = p.K;
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;   // [A | B_c | B_c^T | Xi | Xt]
     double2 *img = s_prop + (size_t)wave * NIMG * kTileImage;
-    double2 *s_ops = s_prop + 4 * NIMG * kTileImage;       // STAGE: [A | B_1..B_K]
+    double2 *s_ops = s_prop + WPB * NIMG * kTileImage;     // STAGE: [A | B_1..B_K]
     if (STAGE) {
-        for (int i = threadIdx.x; i < (K + 1) * TSZ; i += 256)
+        for (int i = threadIdx.x; i < (K + 1) * TSZ; i += 64 * WPB)
             s_ops[i] = ops[i];
         __syncthreads();
     }
-    const int t_lo = blockIdx.x * (STAGE ? kPropSlices : 4);
-    const int t_hi = min(p.N, t_lo + (STAGE ? kPropSlices : 4));
-  for (int t = t_lo + wave; t < t_hi; t += 4) {
+    const int t_lo = blockIdx.x * (STAGE ? kPropSlices : WPB);
+    const int t_hi = min(p.N, t_lo + (STAGE ? kPropSlices : WPB));
+  for (int t = t_lo + wave; t < t_hi; t += WPB) {
     TMat<NT> G;
     if (p.variant == 0)
         tzero(G);
@@ -124,10 +126,13 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 1) void prop_tile_kernel(const T
             }
     }
 
+    auto conv = [&](TOp<NT> &o, const TMat<NT> &z, double2 *im, int ln) {
+        if (NIMG == NT) to_a_layout_rows(o, z, im, ln); else to_a_layout(o, z, im, ln);
+    };
     // expm_t8 (cmat.hpp) with MFMA products; every matrix is a polynomial in G
     TOp<NT> opa;
     TMat<NT> A2, A4, U, T;
-    to_a_layout_rows(opa, G, img, lane);
+    conv(opa, G, img, lane);
     tmul_an<NT, false, false>(A2, opa, G);                 // A2 = G G
 #pragma unroll
     for (int I = 0; I < NT; ++I)
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 1) void prop_tile_kernel(const T
             T.re[I][J] = kX1 * G.re[I][J] + kX2 * A2.re[I][J];
             T.im[I][J] = kX1 * G.im[I][J] + kX2 * A2.im[I][J];
         }
-    to_a_layout_rows(opa, A2, img, lane);
+    conv(opa, A2, img, lane);
     tmul_an<NT, false, false>(A4, opa, T);                 // A4 = A2 (x1 G + x2 A2)
 #pragma unroll
     for (int I = 0; I < NT; ++I)
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 1) void prop_tile_kernel(const T
         for (int r = 0; r < 4; ++r)
             if (4 * r + (lane >> 4) == (lane & 15))
                 T.re[I][I][r] += kX4;
-    to_a_layout_rows(opa, U, img, lane);
+    conv(opa, U, img, lane);
     TMat<NT> P;
     tmul_an<NT, false, false>(P, opa, T);                  // A8
 #pragma unroll
@@ -171,14 +176,14 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 1) void prop_tile_kernel(const T
             if (4 * r + (lane >> 4) == (lane & 15))
                 P.re[I][I][r] += 1.0;
     for (int i = 0; i < s; ++i) {
-        to_a_layout_rows(opa, P, img, lane);
+        conv(opa, P, img, lane);
         tmul_an<NT, false, false>(T, opa, P);
         P = T;
     }
     if (NT == 1 && p.thin && (t & 1)) {
         // rank-one chain (sweep_thin.hip): odd slices are stored transposed -- the A-operand layout of P is the
         // D layout of P^T -- so that its matrix-vector products never convert between vector formats
-        to_a_layout_rows(opa, P, img, lane);
+        conv(opa, P, img, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             P.re[0][0][r] = opa.re[0][0][r];
@@ -829,20 +834,21 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     {
         TileParams q = p;
         const size_t ops_bytes = sizeof(double2) * (size_t)(p.K + 1) * NT * NT * 256;
-        const size_t img_bytes = sizeof(double2) * 4 * NT * (size_t)kTileImage;
+        constexpr int WPB = NT == 1 ? 4 : 8;
+        const size_t img_bytes = sizeof(double2) * WPB * (WPB == 4 ? NT : 1) * (size_t)kTileImage;
         // the member's K + 1 generator tiles in LDS, read once per kPropSlices slices: NT = 1 keeps room for four
         // workgroups per CU; NT = 2 runs one workgroup per CU anyway (registers) and may take what is left of the
         // 160 KB -- without it every wave waits for K + 1 dependent 16 KB fetches from L2 / Infinity Cache per slice
         q.stage_ops = (img_bytes + ops_bytes <= (size_t)(NT == 1 ? 64 : 160) * 1024) ? 1 : 0;
-        const int per_block = q.stage_ops ? kPropSlices : 4;
+        const int per_block = q.stage_ops ? kPropSlices : WPB;
         const size_t lds = img_bytes + (q.stage_ops ? ops_bytes : 0);
         if (lds > 64 * 1024) {
-            hipError_t ea = hipFuncSetAttribute((const void *)prop_tile_kernel<NT>,
+            hipError_t ea = hipFuncSetAttribute((const void *)prop_tile_kernel<NT, WPB>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (ea != hipSuccess)
                 return ea;
         }
-        hipLaunchKernelGGL(prop_tile_kernel<NT>, dim3((p.N + per_block - 1) / per_block, p.E, p.n_x), dim3(256), lds,
+        hipLaunchKernelGGL((prop_tile_kernel<NT, WPB>), dim3((p.N + per_block - 1) / per_block, p.E, p.n_x), dim3(64 * WPB), lds,
                            stream, q);
     }
     hipError_t e = hipGetLastError();
