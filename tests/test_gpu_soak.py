@@ -1,0 +1,17 @@
+"""GPU: a slice of tools/soak.py -- random problems of every kernel family and data flow against the oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [1, 8])
+def test_random_differential_soak(seed):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "400", str(seed)], capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "0 failures" in out.stdout

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Randomised differential soak: many random problems of every kernel family (n = 2..32, all system types, both
+variants, Hermitian / non-Hermitian generators, pure / mixed / rectangular states, dense / sparse controls, the data-flow
+flags) through the C ABI against the CPU oracle at the 1e-10 parity bar.  usage: tools/soak.py [cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import quoptimalcontrol_jl_amd as qoc  # noqa: E402
+from conftest import assert_parity  # noqa: E402
+from oracle import grape_oracle as orc  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+F = qoc.engine
+fails = 0
+t0 = time.time()
+for i in range(cases):
+    n = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32], p=[.1, .08, .14, .06, .06, .08, .08, .08, .12, .06, .06, .08]))
+    K = int(rng.integers(1, 9))
+    N = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 64, 100, 257])) if n <= 16 else int(rng.choice([1, 2, 5, 9, 20]))
+    E = int(rng.choice([1, 2, 3, 5, 9, 17])) if n <= 16 else int(rng.choice([1, 2, 3]))
+    sys_type = str(rng.choice(["UnitaryGate", "StateTransfer", "CoherenceTransfer"]))
+    variant = int(rng.integers(0, 2))
+    herm = bool(rng.integers(0, 2))
+    sparse = bool(rng.integers(0, 2))
+    states = str(rng.choice(["pure", "mixed", "rect"]))
+    flag = int(rng.choice([0, 0, F.FLAG_FORCE_GENERAL, F.FLAG_KEEP_COSTATES]))
+
+    def mat(h):
+        M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        return (M + M.conj().T) / 2 if h else M
+    # generator norms as in the BASELINE configs up to a few units of dt |H|_1 (each squaring of a non-normal propagator
+    # doubles its rounding error: the sweep's Taylor-8 scales further down than the oracle's Pade-13)
+    gscale = min(1.0, 4.0 / n)
+    A = np.array([mat(herm) for _ in range(E)]) * 0.6 * gscale
+    if sparse:
+        B = np.zeros((E, K, n, n), complex)
+        for k in range(E):
+            for c in range(K):
+                for _ in range(int(rng.integers(1, 14))):
+                    a, b = rng.integers(0, n, 2)
+                    v = (rng.standard_normal() + 1j * rng.standard_normal()) * (1.0 if gscale == 1.0 else 0.5)
+                    if a == b:
+                        B[k, c, a, a] = v.real
+                    else:
+                        B[k, c, a, b] = v
+                        B[k, c, b, a] = np.conj(v) if herm else 0.3 * v
+    else:
+        B = np.array([[mat(herm) for _ in range(K)] for _ in range(E)]) * 0.4 * gscale
+
+    def vec(m=1):
+        v = rng.standard_normal((n, m)) + 1j * rng.standard_normal((n, m))
+        return v / np.linalg.norm(v)
+    if sys_type == "UnitaryGate":
+        if states == "rect":
+            m = int(rng.integers(1, n))
+            Xi = np.array([vec(m) for _ in range(E)])
+            Xt = np.array([vec(m) for _ in range(E)])
+        else:
+            Xi = np.array([np.eye(n, dtype=complex)] * E)
+            Xt = np.array([np.linalg.qr(mat(False))[0] for _ in range(E)])
+    else:
+        def rho():
+            if states == "mixed":
+                return sum(p * (lambda v: v @ v.conj().T)(vec()) for p in (0.5, 0.3, 0.2))
+            v = vec()
+            return v @ v.conj().T
+        Xi = np.array([rho() for _ in range(E)])
+        Xt = np.array([rho() for _ in range(E)])
+    wts = rng.uniform(0.2, 1.0, E)
+    x = rng.uniform(-1, 1, (K, N))
+    T = float(rng.uniform(0.3, 2.0))
+    what = f"case {i}: n={n} K={K} N={N} E={E} {sys_type} v{variant} herm={herm} sparse={sparse} states={states} flag={flag}"
+    try:
+        F_ref, G_ref, foms_ref, grads_ref = orc.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, T, variant=variant, per_member=True)
+        with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, T, N, variant=variant, flags=flag, member_results=True) as eng:
+            Fv, G = eng.eval(x)
+            foms, grads = eng.member_results()
+            info = eng.info
+        for k in range(E):
+            assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=what + f" member {k}")
+        # ensemble: members' figures of merit can cancel in the weighted sum (UnitaryGate F_k = Re(z^2) has either sign),
+        # so the bar for F is taken relative to sum w_k |F_k|, the scale the members' own 1e-10 errors add up on
+        scale = float(np.abs(foms_ref) @ wts)
+        assert abs(Fv - F_ref) <= 1e-10 * max(scale, 1e-3 * n * n), (what, Fv, F_ref, scale)
+        assert_parity(F_ref, G, F_ref, G_ref, n, what=what)
+    except Exception as exc:                          # noqa: BLE001
+        fails += 1
+        print("FAIL", what, "->", repr(exc)[:300], flush=True)
+print(f"soak: {cases} cases, {fails} failures, {time.time() - t0:.1f} s (seed {seed})")
+sys.exit(1 if fails else 0)
