@@ -78,6 +78,21 @@ for i in range(cases):
     x = rng.uniform(-1, 1, (K, N))
     T = float(rng.uniform(0.3, 2.0))
     what = f"case {i}: n={n} K={K} N={N} E={E} {sys_type} v{variant} herm={herm} sparse={sparse} states={states} flag={flag}"
+    exact = rng.random() < 0.15 and N <= 33 and states != "rect"      # (the C oracle has no exact gradient for n x m states)
+    if exact:                                             # exact gradient of the figure of merit / of the C1 functional
+        objective = int(rng.integers(0, 2))
+        try:
+            F_ref, G_ref = orc.ensemble_exact(sys_type, A, B, Xi, Xt, wts, x, T, variant=variant, objective=objective)
+            with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, T, N, variant=variant, gradient="exact",
+                                 objective="c1" if objective else "fom") as eng:
+                Fv, G = eng.eval(x)
+            gs = max(np.abs(G_ref).max(), 1e-6)
+            assert abs(Fv - F_ref) <= 1e-9 * max(abs(F_ref), 1e-3 * n * n) and np.abs(G - G_ref).max() <= 1e-9 * gs, \
+                (what + f" exact objective={objective}", Fv, F_ref, np.abs(G - G_ref).max() / gs)
+        except Exception as exc:                          # noqa: BLE001
+            fails += 1
+            print("FAIL", what, f"exact objective={objective}", "->", repr(exc)[:300], flush=True)
+        continue
     try:
         F_ref, G_ref, foms_ref, grads_ref = orc.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, T, variant=variant, per_member=True)
         with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, T, N, variant=variant, flags=flag, member_results=True) as eng:
