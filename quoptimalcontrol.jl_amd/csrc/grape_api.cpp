@@ -35,6 +35,7 @@
 #include <string>
 #include <vector>
 
+#include "grape_host.hpp"
 #include "grape_kernels.hpp"
 
 using grape::SweepParams;
@@ -728,36 +729,15 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     bool herm = !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) &&
                 c->cfg.gradient != GRAPE_GRADIENT_EXACT;
     const int n = c->cfg.n;
-    for (size_t k = 0; k < E && herm; ++k) {
-        for (size_t m = 0; m < K + 1 && herm; ++m) {
-            const double *M = (m == 0) ? A + 2 * k * nn : B + 2 * (k * K + (m - 1)) * nn;
-            double scale = 0.0, dev = 0.0;
-            for (int j = 0; j < n; ++j)
-                for (int i = 0; i < n; ++i) {
-                    const double re = M[2 * (i + j * n)], im = M[2 * (i + j * n) + 1];
-                    const double tr = M[2 * (j + i * n)], ti = M[2 * (j + i * n) + 1];
-                    scale = std::fmax(scale, std::fmax(std::fabs(re), std::fabs(im)));
-                    dev = std::fmax(dev, std::fmax(std::fabs(re - tr), std::fabs(im + ti)));
-                }
-            if (!(dev <= 4e-16 * scale)) herm = false;      // also false on NaN
-        }
-    }
+    for (size_t k = 0; k < E && herm; ++k)
+        for (size_t m = 0; m < K + 1 && herm; ++m)
+            herm = grape_host::hermitian_to_rounding((m == 0) ? A + 2 * k * nn : B + 2 * (k * K + (m - 1)) * nn, n);
     c->unitary = herm;
     {                                                        // Hermitian initial / target operators (square states only)
         bool hs = c->m == c->cfg.n;
         for (size_t k = 0; k < E && hs; ++k)
-            for (int which = 0; which < 2 && hs; ++which) {
-                const double *M = (which ? Xt : Xi) + 2 * k * nn;
-                double scale = 0.0, dev = 0.0;
-                for (int j = 0; j < n; ++j)
-                    for (int i = 0; i < n; ++i) {
-                        const double re = M[2 * (i + j * n)], im = M[2 * (i + j * n) + 1];
-                        const double tr = M[2 * (j + i * n)], ti = M[2 * (j + i * n) + 1];
-                        scale = std::fmax(scale, std::fmax(std::fabs(re), std::fabs(im)));
-                        dev = std::fmax(dev, std::fmax(std::fabs(re - tr), std::fabs(im + ti)));
-                    }
-                if (!(dev <= 4e-16 * scale)) hs = false;
-            }
+            for (int which = 0; which < 2 && hs; ++which)
+                hs = grape_host::hermitian_to_rounding((which ? Xt : Xi) + 2 * k * nn, n);
         c->herm_states = hs;
     }
     // Rank-one states in the single-tile family (n = 9..16): X_t = v_t v_t' (sandwich, Xi = v0 v0', Xt = wT wT') or
@@ -782,31 +762,8 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             thin = c->m == n;
             for (size_t k = 0; k < E && thin; ++k)
                 for (int which = 0; which < 2 && thin; ++which) {
-                    // M = u u' ?  u = M[:, j] / sqrt(M[j, j]) for the largest diagonal entry j
                     const double *M = (which ? Xt : Xi) + 2 * k * nn;
-                    int jb = 0;
-                    double scale = 0.0;
-                    for (int j = 0; j < n; ++j) {
-                        if (M[2 * (j + j * n)] > M[2 * (jb + jb * n)]) jb = j;
-                        for (int i = 0; i < n; ++i)
-                            scale = std::fmax(scale, std::fmax(std::fabs(M[2 * (i + j * n)]), std::fabs(M[2 * (i + j * n) + 1])));
-                    }
-                    const double d = M[2 * (jb + jb * n)];
-                    if (!(d > 0.0) || std::fabs(M[2 * (jb + jb * n) + 1]) > 4e-16 * scale) { thin = false; break; }
-                    double *u = vecs.data() + k * 64 + which * 32;
-                    const double inv = 1.0 / std::sqrt(d);
-                    for (int i = 0; i < n; ++i) {                              // column jb: u_i conj(u_jb), u_jb real
-                        u[2 * i] = M[2 * (i + jb * n)] * inv;
-                        u[2 * i + 1] = M[2 * (i + jb * n) + 1] * inv;
-                    }
-                    double dev = 0.0;
-                    for (int j = 0; j < n; ++j)
-                        for (int i = 0; i < n; ++i) {
-                            const double pr = u[2 * i] * u[2 * j] + u[2 * i + 1] * u[2 * j + 1];      // u_i conj(u_j)
-                            const double pi = u[2 * i + 1] * u[2 * j] - u[2 * i] * u[2 * j + 1];
-                            dev = std::fmax(dev, std::fmax(std::fabs(pr - M[2 * (i + j * n)]), std::fabs(pi - M[2 * (i + j * n) + 1])));
-                        }
-                    if (!(dev <= 8e-16 * scale)) thin = false;
+                    if (!grape_host::factor_rank_one(M, n, vecs.data() + k * 64 + which * 32)) thin = false;
                 }
         }
     }
@@ -814,18 +771,8 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     {                                                        // Hermitian control operators?
         bool hb = true;
         for (size_t k = 0; k < E && hb; ++k)
-            for (size_t m = 0; m < K && hb; ++m) {
-                const double *M = B + 2 * (k * K + m) * nn;
-                double scale = 0.0, dev = 0.0;
-                for (int j = 0; j < n; ++j)
-                    for (int i = 0; i < n; ++i) {
-                        const double re = M[2 * (i + j * n)], im = M[2 * (i + j * n) + 1];
-                        const double tr = M[2 * (j + i * n)], ti = M[2 * (j + i * n) + 1];
-                        scale = std::fmax(scale, std::fmax(std::fabs(re), std::fabs(im)));
-                        dev = std::fmax(dev, std::fmax(std::fabs(re - tr), std::fabs(im + ti)));
-                    }
-                if (!(dev <= 4e-16 * scale)) hb = false;
-            }
+            for (size_t m = 0; m < K && hb; ++m)
+                hb = grape_host::hermitian_to_rounding(B + 2 * (k * K + m) * nn, n);
         c->herm_ctrl = hb;
     }
     {   // sparse control operators (Pauli-type controls): lists of (B_c[i][j], position of M[j][i]) per member and control
@@ -833,26 +780,8 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         bool sp = c->family == 1 && !c->pack2 && K >= 1 && K <= 16 && !env_on("GRAPE_NO_SPARSE");
         std::vector<double> coef;
         std::vector<int32_t> addr;
-        if (sp) {
-            coef.assign(E * K * SM * 2, 0.0);
-            addr.assign(E * K * SM, 0);
-            const int MS = 16 * c->NT + 1;
-            for (size_t k = 0; k < E && sp; ++k)
-                for (size_t m = 0; m < K && sp; ++m) {
-                    const double *M = B + 2 * (k * K + m) * nn;
-                    int cnt = 0;
-                    for (int j = 0; j < n && sp; ++j)
-                        for (int i = 0; i < n; ++i) {
-                            const double re = M[2 * (i + j * n)], im = M[2 * (i + j * n) + 1];
-                            if (re == 0.0 && im == 0.0) continue;
-                            if (cnt == SM) { sp = false; break; }
-                            const size_t e = (k * K + m) * SM + cnt++;
-                            coef[2 * e] = re;
-                            coef[2 * e + 1] = im;
-                            addr[e] = j * MS + i;                // B[i][j] multiplies M[j][i]: row j, column i
-                        }
-                }
-        }
+        if (sp)
+            sp = grape_host::build_sparse_lists(B, E, K, n, 16 * c->NT + 1, SM, coef, addr);
         c->sparse_ctrl = sp;
         if (sp) {
             if (!c->d_sp_coef) {

@@ -1,0 +1,88 @@
+// grape_host.hpp -- pure host-side analysis of the operators handed to grape_set_operators (no HIP calls), kept
+// separate so that the CPU sanitizer build can drive it directly (tests/san/host_detect.cpp):
+//   factor_rank_one      M = u u' ?  (pure-state density operators, vec(rho) vec(rho)')
+//   build_sparse_lists   (coefficient, position) lists of control operators with few non-zeros
+//   hermitian_to_rounding  M == M' to 4 ulp of its largest entry (all entries finite)
+// All matrices are n x n complex, column-major, interleaved {re, im}.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace grape_host {
+
+// M == u u' to 8 ulp of its largest entry?  u (2 n doubles) = M[:, j] / sqrt(M[j, j]) for the largest diagonal j.
+inline bool factor_rank_one(const double *M, int n, double *u)
+{
+    int jb = 0;
+    double scale = 0.0;
+    for (int j = 0; j < n; ++j) {
+        if (M[2 * (j + (size_t)j * n)] > M[2 * (jb + (size_t)jb * n)]) jb = j;
+        for (int i = 0; i < n; ++i) {
+            const double re = M[2 * (i + (size_t)j * n)], im = M[2 * (i + (size_t)j * n) + 1];
+            if (!std::isfinite(re) || !std::isfinite(im))
+                return false;                                  // (fmax drops NaN: non-finite entries are checked explicitly)
+            scale = std::fmax(scale, std::fmax(std::fabs(re), std::fabs(im)));
+        }
+    }
+    const double d = M[2 * (jb + (size_t)jb * n)];
+    if (!(d > 0.0) || !(std::fabs(M[2 * (jb + (size_t)jb * n) + 1]) <= 4e-16 * scale) || !std::isfinite(scale))
+        return false;
+    const double inv = 1.0 / std::sqrt(d);
+    for (int i = 0; i < n; ++i) {                              // column jb: u_i conj(u_jb), u_jb real
+        u[2 * i] = M[2 * (i + (size_t)jb * n)] * inv;
+        u[2 * i + 1] = M[2 * (i + (size_t)jb * n) + 1] * inv;
+    }
+    double dev = 0.0;
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+            const double pr = u[2 * i] * u[2 * j] + u[2 * i + 1] * u[2 * j + 1];      // u_i conj(u_j)
+            const double pi = u[2 * i + 1] * u[2 * j] - u[2 * i] * u[2 * j + 1];
+            dev = std::fmax(dev, std::fmax(std::fabs(pr - M[2 * (i + (size_t)j * n)]), std::fabs(pi - M[2 * (i + (size_t)j * n) + 1])));
+        }
+    return dev <= 8e-16 * scale;                               // false on NaN
+}
+
+// M == M' to 4 ulp of its largest entry and free of NaN / Inf?
+inline bool hermitian_to_rounding(const double *M, int n)
+{
+    double scale = 0.0, dev = 0.0;
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+            const double re = M[2 * (i + (size_t)j * n)], im = M[2 * (i + (size_t)j * n) + 1];
+            const double tr = M[2 * (j + (size_t)i * n)], ti = M[2 * (j + (size_t)i * n) + 1];
+            if (!std::isfinite(re) || !std::isfinite(im))
+                return false;
+            scale = std::fmax(scale, std::fmax(std::fabs(re), std::fabs(im)));
+            dev = std::fmax(dev, std::fmax(std::fabs(re - tr), std::fabs(im + ti)));
+        }
+    return dev <= 4e-16 * scale;
+}
+
+// Every B (E*K operators, n x n) with at most `max_nz` non-zeros?  Then coef[(k*K+c)*max_nz + e] = B[i][j] and
+// addr[...] = j * row_stride + i (the position of M[j][i] in a row-major image with `row_stride` columns), zero padded.
+inline bool build_sparse_lists(const double *B, size_t E, size_t K, int n, int row_stride, int max_nz,
+                               std::vector<double> &coef, std::vector<int32_t> &addr)
+{
+    coef.assign(E * K * (size_t)max_nz * 2, 0.0);
+    addr.assign(E * K * (size_t)max_nz, 0);
+    const size_t nn = (size_t)n * n;
+    for (size_t m = 0; m < E * K; ++m) {
+        const double *M = B + 2 * m * nn;
+        int cnt = 0;
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) {
+                const double re = M[2 * (i + (size_t)j * n)], im = M[2 * (i + (size_t)j * n) + 1];
+                if (re == 0.0 && im == 0.0) continue;
+                if (cnt == max_nz) return false;
+                const size_t e = m * (size_t)max_nz + cnt++;
+                coef[2 * e] = re;
+                coef[2 * e + 1] = im;
+                addr[e] = j * row_stride + i;                  // B[i][j] multiplies M[j][i]: row j, column i
+            }
+    }
+    return true;
+}
+
+}  // namespace grape_host

@@ -1,0 +1,91 @@
+// ASan/UBSan driver for the pure host-side operator analysis of grape_set_operators (csrc/grape_host.hpp): rank-one
+// factorisation and sparse control lists on random, exactly-structured, borderline and non-finite inputs, with the
+// output buffers sized EXACTLY so that any overrun is caught.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "grape_host.hpp"
+
+static uint64_t s = 0x243F6A8885A308D3ull;
+static uint64_t rnd() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+static double unif() { return (double)(rnd() >> 11) / 9007199254740992.0 * 2.0 - 1.0; }
+
+int main()
+{
+    long yes = 0, no = 0, sparse_yes = 0, sparse_no = 0;
+    for (int it = 0; it < 20000; ++it) {
+        const int n = 1 + (int)(rnd() % 32);
+        std::vector<double> M(2 * (size_t)n * n), u(2 * (size_t)n);
+        const int kind = (int)(rnd() % 6);
+        std::vector<double> v(2 * (size_t)n);
+        for (double &x : v) x = unif();
+        if (kind == 5) v[rnd() % v.size()] = 0.0;
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) {
+                double re = v[2 * i] * v[2 * j] + v[2 * i + 1] * v[2 * j + 1], im = v[2 * i + 1] * v[2 * j] - v[2 * i] * v[2 * j + 1];
+                if (kind == 1) { re = unif(); im = unif(); }                     // generic matrix
+                if (kind == 2 && i == j) re = -re;                               // negative diagonal
+                M[2 * (i + (size_t)j * n)] = re;
+                M[2 * (i + (size_t)j * n) + 1] = im;
+            }
+        if (kind == 3) M[rnd() % M.size()] = std::nan("");
+        if (kind == 4) M[rnd() % M.size()] += 1e-3;
+        const bool r1 = grape_host::factor_rank_one(M.data(), n, u.data());
+        if ((kind == 0 || kind == 5) && !r1 && n > 0) {
+            bool nonzero = false;
+            for (double x : v) nonzero = nonzero || x != 0.0;
+            if (nonzero) { std::printf("rank-one matrix not recognised (n=%d)\n", n); return 1; }
+        }
+        if ((kind == 1 && n > 1) && r1) { std::printf("generic matrix accepted (n=%d)\n", n); return 1; }
+        if (kind == 3 && r1) { std::printf("NaN accepted\n"); return 1; }
+        (r1 ? yes : no)++;
+        {   // Hermitian test: a Hermitian matrix passes, one NaN / Inf anywhere or a perturbed entry does not
+            std::vector<double> H(2 * (size_t)n * n);
+            for (int j = 0; j < n; ++j)
+                for (int i = 0; i <= j; ++i) {
+                    const double re = unif(), im = i == j ? 0.0 : unif();
+                    H[2 * (i + (size_t)j * n)] = re;  H[2 * (i + (size_t)j * n) + 1] = im;
+                    H[2 * (j + (size_t)i * n)] = re;  H[2 * (j + (size_t)i * n) + 1] = -im;
+                }
+            if (!grape_host::hermitian_to_rounding(H.data(), n)) { std::printf("Hermitian matrix rejected\n"); return 5; }
+            const size_t at = rnd() % H.size();
+            const double keep = H[at];
+            H[at] = (rnd() & 1) ? std::nan("") : INFINITY;
+            if (grape_host::hermitian_to_rounding(H.data(), n)) { std::printf("non-finite entry accepted as Hermitian\n"); return 6; }
+            H[at] = keep + 0.01;
+            if (n > 1 && (at / 2) % (size_t)(n + 1) != 0 && grape_host::hermitian_to_rounding(H.data(), n)) { std::printf("perturbed matrix accepted\n"); return 7; }
+        }
+
+        const size_t E = 1 + rnd() % 3, K = 1 + rnd() % 5;
+        const int max_nz = 1 + (int)(rnd() % 64), stride = n + (int)(rnd() % 3);
+        std::vector<double> B(2 * E * K * (size_t)n * n, 0.0);
+        const int fill = (int)(rnd() % (2 * max_nz + 1));
+        for (size_t m = 0; m < E * K; ++m)
+            for (int e = 0; e < fill; ++e)
+                B[2 * (m * n * n + rnd() % ((size_t)n * n)) + (rnd() & 1)] = unif();
+        std::vector<double> coef;
+        std::vector<int32_t> addr;
+        const bool sp = grape_host::build_sparse_lists(B.data(), E, K, n, stride, max_nz, coef, addr);
+        if (sp) {
+            if (coef.size() != 2 * E * K * (size_t)max_nz || addr.size() != E * K * (size_t)max_nz) return 2;
+            for (size_t m = 0; m < E * K; ++m) {                                   // the lists reproduce B exactly
+                std::vector<double> R(2 * (size_t)n * n, 0.0);
+                for (int e = 0; e < max_nz; ++e) {
+                    const int a = addr[m * max_nz + e];
+                    const int j = a / stride, i = a % stride;
+                    if (i < 0 || i >= n || j < 0 || j >= n) { std::printf("position out of range\n"); return 3; }
+                    R[2 * (i + (size_t)j * n)] += coef[2 * (m * max_nz + e)];
+                    R[2 * (i + (size_t)j * n) + 1] += coef[2 * (m * max_nz + e) + 1];
+                }
+                for (size_t q = 0; q < R.size(); ++q)
+                    if (R[q] != B[2 * m * n * n + q]) { std::printf("lists do not reproduce B\n"); return 4; }
+            }
+        }
+        (sp ? sparse_yes : sparse_no)++;
+    }
+    std::printf("host detect ok: rank-one %ld / not %ld, sparse %ld / dense %ld\n", yes, no, sparse_yes, sparse_no);
+    return 0;
+}

@@ -93,3 +93,20 @@ def test_single_workgroup_publishes_without_reduce_launch(qoc, oracle, monkeypat
         assert_parity(F, G, F_ref, G_ref, n, what=f"direct={mode}")
         res[mode] = (F, G)
     assert res["1"][0] == res["0"][0] and np.array_equal(res["1"][1], res["0"][1])
+
+
+@pytest.mark.parametrize("n,where", [(4, "A_lower"), (4, "B_upper"), (16, "A_lower"), (16, "Xt")])
+def test_non_finite_operator_entries_propagate(qoc, n, where):
+    """a NaN anywhere in the operators must reach F and G, as it would in the reference's arithmetic -- in particular it
+    must not be dropped by the Hermitian / rank-one shortcuts, which look at one triangle or one column only."""
+    w = _problem(qoc, n, 2, 20, 2, "StateTransfer", seed=3)
+    A, B, Xt = w.A.copy(), w.B.copy(), w.Xt.copy()
+    if where == "A_lower":
+        A[1, n - 1, 0] = np.nan
+    elif where == "B_upper":
+        B[0, 1, 0, n - 1] = np.nan
+    else:
+        Xt[1, n - 1, 1] = np.nan
+    with qoc.GrapeEngine(w.sys_type, A, B, w.Xi, Xt, w.wts, w.T, w.N) as eng:
+        F, G = eng.eval(w.x)
+    assert np.isnan(F) and np.isnan(G).any()

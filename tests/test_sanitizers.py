@@ -34,6 +34,16 @@ def test_oracle_under_asan_ubsan(tmp_path):
     assert p.returncode == 0 and "oracle sanitizer run ok" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-3000:])
 
 
+def test_operator_analysis_under_asan_ubsan(tmp_path):
+    """csrc/grape_host.hpp (rank-one factorisation, sparse control lists: what grape_set_operators decides the chain
+    kernels from) on 20k random / structured / non-finite inputs with exactly-sized buffers."""
+    exe = _build(str(tmp_path), "host_detect_san",
+                 ["g++", "-std=c++17", "-I" + os.path.join(ROOT, "quoptimalcontrol.jl_amd", "csrc")] + SAN +
+                 [os.path.join(ROOT, "tests", "san", "host_detect.cpp")])
+    p = subprocess.run([exe], capture_output=True, text=True, env=ENV, timeout=600)
+    assert p.returncode == 0 and "host detect ok" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-3000:])
+
+
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/include/hip/hip_runtime.h"), reason="needs the HIP host headers")
 def test_abi_host_layer_fuzz_under_asan_ubsan(tmp_path):
     """grape_api.cpp compiled as plain C++ (host HIP API only) + stub launchers, ASan/UBSan, 20k fuzzed configs.
