@@ -100,12 +100,17 @@ for i in range(cases):
             foms, grads = eng.member_results()
             info = eng.info
         for k in range(E):
+            # a member's whole gradient can be a near-zero (K = 1, N = 1: one entry passing through zero): the norm-wise
+            # bar then has no scale left, so an absolute floor of a few ulp of the O(1) traces applies
+            if np.abs(grads[k] - grads_ref[k]).max() <= 5e-14 * n and abs(foms[k] - foms_ref[k]) <= 1e-10 * max(abs(foms_ref[k]), 1e-3 * n * n):
+                continue
             assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=what + f" member {k}")
         # ensemble: members' figures of merit can cancel in the weighted sum (UnitaryGate F_k = Re(z^2) has either sign),
         # so the bar for F is taken relative to sum w_k |F_k|, the scale the members' own 1e-10 errors add up on
         scale = float(np.abs(foms_ref) @ wts)
         assert abs(Fv - F_ref) <= 1e-10 * max(scale, 1e-3 * n * n), (what, Fv, F_ref, scale)
-        assert_parity(F_ref, G, F_ref, G_ref, n, what=what)
+        if np.abs(G - G_ref).max() > 5e-14 * n:
+            assert_parity(F_ref, G, F_ref, G_ref, n, what=what)
     except Exception as exc:                          # noqa: BLE001
         fails += 1
         print("FAIL", what, "->", repr(exc)[:300], flush=True)
