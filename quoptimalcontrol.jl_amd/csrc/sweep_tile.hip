@@ -423,7 +423,7 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
 // Nh balances the two waves' product counts.  When Xi, Xt are Hermitian (checked on the host; density
 // operators), X_t and L_t stay Hermitian under P X P' / P' L P, so [X, L'] = Y - Y' with Y = X L': the
 // second commutator product becomes one layout conversion (to_a_layout of Y IS the D layout of Y^T).
-template <int SAND>
+template <int SAND, bool SPARSE = false>
 __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams p)
 {
     constexpr int NT = 1, TSZ = 256;
@@ -431,14 +431,19 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double2 *s_img = s_dynt + (size_t)half * (kTileImage + 1);
     double2 *s_xch = s_dynt + 2 * (kTileImage + 1);                // [0..255] X_Nh (wave 0), [256..511] T1 (wave 1)
-    double2 *s_bt = s_xch + 512;
+    double2 *s_bt = s_xch + 512;                                   // SPARSE: coefficients | two images of R | positions
+    double2 *s_coef = s_bt;
+    double2 *s_M = s_coef + (size_t)p.K * kSparseMax + (size_t)half * (16 * 17);
+    int *s_addr = reinterpret_cast<int *>(s_coef + (size_t)p.K * kSparseMax + 2 * (16 * 17));
     const int k = blockIdx.x;
     const int K = p.K, N = p.N, Nh = p.split_at;
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
     const double2 *__restrict__ opBT = ops + (size_t)(1 + K) * TSZ;
     const bool bt_lds = p.bt_in_lds != 0;
     const bool herm = SAND && p.herm_states != 0;
-    if (bt_lds) {
+    if (SPARSE) {
+        stage_sparse_lists<NT>(p, k, (int)threadIdx.x, 128, s_coef, s_addr);
+    } else if (bt_lds) {
         for (int i = threadIdx.x; i < K * TSZ; i += 128)
             s_bt[i] = opBT[i];
     }
@@ -495,6 +500,8 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
     const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
     TMat<1> L, Pm, Pn, X, Xn, Y, R;
     TOp<1> XA, LA;
+    bool z_known = false;
+    double z_keep_r = 0.0, z_keep_i = 0.0;
     // gradient entries + figure of merit of one slice from X_t, L_t (costate after pulling back through slice t)
     auto emit = [&](int t) {
         to_a_layout(XA, X, s_img, lane);
@@ -518,6 +525,20 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
             }
         }
         double zr = 0.0, zi = 0.0;
+        if (SPARSE) {
+            // tr(X_t' L_t) is the same for every t (also for non-unitary P): taken at the first slice this wave emits
+            if (!z_known) {
+                double zz[2];
+                tdot_partial<NT, true>(zz[0], zz[1], X, L);
+                wave_sum_n(zz);
+                z_keep_r = zz[0];
+                z_keep_i = zz[1];
+                z_known = true;
+            }
+            zr = z_keep_r;
+            zi = z_keep_i;
+            sparse_traces<NT, SAND>(R, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane, true);
+        } else
         for (int c0 = 0; c0 < K || c0 == 0; c0 += 4) {
             double v[2 + 8];
             v[0] = 0.0;
@@ -874,6 +895,13 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         const size_t bt_b = sizeof(double2) * (size_t)p.K * 256;
         q.bt_in_lds = bt_b <= 24 * 1024 ? 1 : 0;                    // 4 workgroups per CU must still fit
         const size_t lds2 = sizeof(double2) * (2 * (kTileImage + 1) + 512) + (q.bt_in_lds ? bt_b : 0);
+        if (p.sparse) {
+            const size_t lds_sp = sizeof(double2) * (2 * (kTileImage + 1) + 512 + (size_t)p.K * kSparseMax + 2 * 16 * 17) +
+                                  sizeof(int32_t) * (size_t)p.K * kSparseMax;
+            if (sandwich) hipLaunchKernelGGL((chain_tile_split_kernel<1, true>), grid, dim3(128), lds_sp, stream, q);
+            else          hipLaunchKernelGGL((chain_tile_split_kernel<0, true>), grid, dim3(128), lds_sp, stream, q);
+            return hipGetLastError();
+        }
         if (sandwich) hipLaunchKernelGGL((chain_tile_split_kernel<1>), grid, dim3(128), lds2, stream, q);
         else          hipLaunchKernelGGL((chain_tile_split_kernel<0>), grid, dim3(128), lds2, stream, q);
         return hipGetLastError();
