@@ -333,9 +333,10 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     const int cpw = c->pair ? 32 : 64;                           // time chunks per wave
     int W = cfg->waves_per_member;
     if (W <= 0) {
-        // lane kernel: one wave per SIMD; pair kernel: two (its registers allow it, and the FP64 pipe
-        // needs two waves to run near its peak)
-        const long slots = (c->pair ? 8L : 4L) * c->compute_units;
+        // n = 4 lane kernel: one wave per SIMD (256 registers); pair kernel and the n = 2, 3 lane kernels: two (their
+        // registers allow it, and the FP64 pipe needs two waves to run near its peak: n = 2, E = 1024, N = 500
+        // 28.0 -> 24.4 us, n = 3 48.4 -> 46.1 us)
+        const long slots = ((c->pair || cfg->n <= 3) ? 8L : 4L) * c->compute_units;
         const long units = (long)E * c->B;                       // a batch fills the chip like a larger ensemble
         W = (int)((slots + units - 1) / units);
         const int wneed = (N + cpw - 1) / cpw;
