@@ -196,7 +196,6 @@ __global__ __launch_bounds__(MAXT) void sweep_small_kernel(const double2 *__rest
     double2 *__restrict__ Xw = p.states + wbase;
     double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * Nsl + 1);
     const int t0 = L * S;
-    const double dt = p.dt;
     unsigned long long *__restrict__ st =
         p.stamps ? p.stamps + ((size_t)k * W + wave) * kStampSlots : nullptr;
     if (st && lane == 0)

@@ -33,10 +33,12 @@ namespace grape {
 // instead of once per slice -- the kernel was L2-bandwidth bound: 24 KB of operators per 4 KB of P)
 constexpr int kPropSlices = 64;
 
-// WPB waves per workgroup.  NT = 2: eight (two per SIMD, <= 256 registers each at the price of ~70 spilled VGPRs): the
-// second wave's MFMAs cover the first one's H build, layout conversions, norm and Taylor combinations.
+// WPB waves per workgroup.  NT = 2: four (one per SIMD with the whole register file) and three-product complex
+// multiplication; eight (two per SIMD, <= 256 registers each at the price of ~70 spilled VGPRs, the second wave's
+// MFMAs covering the first one's H build, layout conversions, norm and Taylor combinations) was the better choice
+// with four-product multiplication (137 vs 147 ms at C5) and is not with three (166 vs 133 ms).
 template <int NT, int WPB>
-__global__ __launch_bounds__(64 * WPB, NT == 1 ? 4 : 2) void prop_tile_kernel(const TileParams p)
+__global__ __launch_bounds__(64 * WPB, NT == 1 ? 4 : (WPB == 8 ? 2 : 1)) void prop_tile_kernel(const TileParams p)
 {
     constexpr int TSZ = NT * NT * 256;                     // double2 per matrix dump
     constexpr int NIMG = WPB == 4 ? NT : 1;                // LDS conversion images per wave
@@ -129,11 +131,17 @@ __global__ __launch_bounds__(64 * WPB, NT == 1 ? 4 : 2) void prop_tile_kernel(co
     auto conv = [&](TOp<NT> &o, const TMat<NT> &z, double2 *im, int ln) {
         if (NIMG == NT) to_a_layout_rows(o, z, im, ln); else to_a_layout(o, z, im, ln);
     };
-    // expm_t8 (cmat.hpp) with MFMA products; every matrix is a polynomial in G
+    // expm_t8 (cmat.hpp) with MFMA products; every matrix is a polynomial in G.  Three-product complex multiplication
+    // (tile.hpp) where the third accumulator set fits: at NT = 2 with two waves per SIMD (WPB = 8) it spills
+    // (C5: 137 -> 166 ms), with one wave per SIMD and the full register file it does not (147 -> 133 ms).
+#ifndef GRAPE_PROP2_3M
+#define GRAPE_PROP2_3M 1
+#endif
+    constexpr bool kM3 = NT == 1 || GRAPE_PROP2_3M;
     TOp<NT> opa;
     TMat<NT> A2, A4, U, T;
     conv(opa, G, img, lane);
-    tmul_an<NT, false, false>(A2, opa, G);                 // A2 = G G
+    tmul_an<NT, false, false, kM3>(A2, opa, G);                 // A2 = G G
 #pragma unroll
     for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(64 * WPB, NT == 1 ? 4 : 2) void prop_tile_kernel(co
             T.im[I][J] = kX1 * G.im[I][J] + kX2 * A2.im[I][J];
         }
     conv(opa, A2, img, lane);
-    tmul_an<NT, false, false>(A4, opa, T);                 // A4 = A2 (x1 G + x2 A2)
+    tmul_an<NT, false, false, kM3>(A4, opa, T);                 // A4 = A2 (x1 G + x2 A2)
 #pragma unroll
     for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(64 * WPB, NT == 1 ? 4 : 2) void prop_tile_kernel(co
                 T.re[I][I][r] += kX4;
     conv(opa, U, img, lane);
     TMat<NT> P;
-    tmul_an<NT, false, false>(P, opa, T);                  // A8
+    tmul_an<NT, false, false, kM3>(P, opa, T);                  // A8
 #pragma unroll
     for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(64 * WPB, NT == 1 ? 4 : 2) void prop_tile_kernel(co
                 P.re[I][I][r] += 1.0;
     for (int i = 0; i < s; ++i) {
         conv(opa, P, img, lane);
-        tmul_an<NT, false, false>(T, opa, P);
+        tmul_an<NT, false, false, kM3>(T, opa, P);
         P = T;
     }
     if (NT == 1 && p.thin && (t & 1)) {
@@ -855,7 +863,10 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     {
         TileParams q = p;
         const size_t ops_bytes = sizeof(double2) * (size_t)(p.K + 1) * NT * NT * 256;
-        constexpr int WPB = NT == 1 ? 4 : 8;
+#ifndef GRAPE_PROP2_WPB
+#define GRAPE_PROP2_WPB 4
+#endif
+        constexpr int WPB = NT == 1 ? 4 : GRAPE_PROP2_WPB;
         const size_t img_bytes = sizeof(double2) * WPB * (WPB == 4 ? NT : 1) * (size_t)kTileImage;
         // the member's K + 1 generator tiles in LDS, read once per kPropSlices slices: NT = 1 keeps room for four
         // workgroups per CU; NT = 2 runs one workgroup per CU anyway (registers) and may take what is left of the
