@@ -855,6 +855,7 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.thin = c->thin ? 1 : 0;
     p.herm_ctrl = c->herm_ctrl ? 1 : 0;
     p.vecs = c->d_vecs;
+    p.cus = c->compute_units;
     p.sparse = c->sparse_ctrl ? 1 : 0;
     p.sp_coef = c->d_sp_coef;
     p.sp_addr = c->d_sp_addr;

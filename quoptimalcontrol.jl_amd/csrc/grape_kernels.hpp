@@ -95,6 +95,11 @@ struct TileParams {
                           // TRANSPOSED for odd t; `states` holds the forward pass's vector records (N + 1 per member)
     int32_t herm_ctrl;    // every control operator B_c Hermitian (thin chain: one bilinear form per control)
     const double2 *vecs;  // thin: per member [v0 | wT], 16 complex each, zero padded
+    int32_t cus;          // compute units of the device
+    int32_t fuse_fwd;     // set by the launcher (thin): one workgroup of prop_tile_kernel walks ALL slices of a member and
+                          // runs the forward vector chain v_{t+1} = P_t v_t on the propagators it still holds in
+                          // registers, writing the records; chain_thin_kernel then only runs its backward pass
+                          // (P_t is read from HBM once instead of twice)
     // sparse control operators (every B_c of every member has at most kSparseMax non-zeros -- Pauli-type controls):
     // per member and control kSparseMax entries, zero padded: sp_coef = B_c[i][j], sp_addr = position of M[j][i]
     // in the wave's LDS image of M (row j, column i, row stride 16 NT + 1).  The gradient traces tr(B_c M_t) then

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(64) void chain_thin_kernel(const TileParams p)
     const int sel = c & 3;                        // which of a lane's four gathered entries it writes to a record
 
     // ------------------------------------------------------------------ forward: v_{t+1} = P_t v_t
-    {
+    // (already done by prop_tile_kernel when it walked the member's slices in order: TileParams.fuse_fwd)
+    if (!p.fuse_fwd) {
         Tile1 Pq[kRingF];
 #pragma unroll
         for (int u = 0; u < kRingF; ++u)

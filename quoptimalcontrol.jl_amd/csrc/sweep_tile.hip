@@ -50,13 +50,25 @@ __global__ __launch_bounds__(64 * WPB, NT == 1 ? 4 : (WPB == 8 ? 2 : 1)) void pr
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;   // [A | B_c | B_c^T | Xi | Xt]
     double2 *img = s_prop + (size_t)wave * NIMG * kTileImage;
     double2 *s_ops = s_prop + WPB * NIMG * kTileImage;     // STAGE: [A | B_1..B_K]
+    // FUSE (rank-one chain, NT = 1): this workgroup walks every slice of the member, wave w the slices t = w mod WPB,
+    // and the forward vector v_t is handed from wave to wave through LDS: [v even | v odd | flag]
+    const bool FUSE = NT == 1 && p.fuse_fwd != 0;
+    double2 *s_vec = s_ops + (STAGE ? (size_t)(K + 1) * TSZ : 0);
+    volatile int *s_flag = reinterpret_cast<volatile int *>(s_vec + 32);
     if (STAGE) {
         for (int i = threadIdx.x; i < (K + 1) * TSZ; i += 64 * WPB)
             s_ops[i] = ops[i];
-        __syncthreads();
     }
-    const int t_lo = blockIdx.x * (STAGE ? kPropSlices : WPB);
-    const int t_hi = min(p.N, t_lo + (STAGE ? kPropSlices : WPB));
+    if (FUSE) {
+        if (threadIdx.x < 16)
+            s_vec[threadIdx.x] = p.vecs[(size_t)k * 32 + threadIdx.x];
+        if (threadIdx.x == 0)
+            *s_flag = 0;
+    }
+    if (STAGE || FUSE)
+        __syncthreads();
+    const int t_lo = FUSE ? 0 : blockIdx.x * (STAGE ? kPropSlices : WPB);
+    const int t_hi = FUSE ? p.N : min(p.N, t_lo + (STAGE ? kPropSlices : WPB));
   for (int t = t_lo + wave; t < t_hi; t += WPB) {
     TMat<NT> G;
     if (p.variant == 0)
@@ -196,6 +208,62 @@ __global__ __launch_bounds__(64 * WPB, NT == 1 ? 4 : (WPB == 8 ? 2 : 1)) void pr
         for (int r = 0; r < 4; ++r) {
             P.re[0][0][r] = opa.re[0][0][r];
             P.im[0][0][r] = opa.im[0][0][r];
+        }
+    }
+    if constexpr (NT == 1) {
+        if (FUSE && p.fuse_fwd == 1) {
+            // v_{t+1} = P_t v_t as chain_thin_kernel's forward pass does it (same register contents: the D layout of
+            // P_t for even t, of P_t^T for odd t; same summation trees), the vector taken from / handed to the
+            // neighbouring waves through LDS.  All WPB waves are resident, so the wait cannot starve.  The hand-over
+            // is the serial part of this kernel (N steps per member): nothing but LDS traffic may sit between the
+            // flag read and the flag write -- no memory fence (it would wait for the global stores), the stores of
+            // P_t and of the record come afterwards.  A wave's LDS operations complete in order.
+            const int g = lane >> 4, c = lane & 15;
+            const double2 *vb = s_vec + (t & 1) * 16;
+            double2 *vn = s_vec + ((t + 1) & 1) * 16;
+            double2 *__restrict__ V = p.states + ((size_t)blockIdx.z * p.E + k) * (size_t)(p.N + 1) * 16;
+            while (*s_flag != t)
+                __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            const double2 rec = vb[c];                     // per-column: x[c]
+            double2 out_rec = make_double2(0.0, 0.0);
+            if ((t & 1) == 0) {                            // per-column in, gathered out
+                double y[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y[2 * r] = fma(P.re[0][0][r], rec.x, -P.im[0][0][r] * rec.y);
+                    y[2 * r + 1] = fma(P.re[0][0][r], rec.y, P.im[0][0][r] * rec.x);
+                }
+                row_sum_n(y);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c == r)
+                        vn[4 * r + g] = make_double2(y[2 * r], y[2 * r + 1]);
+            } else {                                       // gathered in, per-column out
+                double acc[2] = {0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double2 v = vb[4 * r + g];
+                    acc[0] = fma(P.re[0][0][r], v.x, acc[0]);
+                    acc[0] = fma(-P.im[0][0][r], v.y, acc[0]);
+                    acc[1] = fma(P.re[0][0][r], v.y, acc[1]);
+                    acc[1] = fma(P.im[0][0][r], v.x, acc[1]);
+                }
+                col_sum_n(acc);
+                if (g == 0)
+                    vn[c] = make_double2(acc[0], acc[1]);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            asm volatile("" ::: "memory");
+            if (t == p.N - 1)
+                out_rec = vn[c];
+            if (lane == 0)
+                *s_flag = t + 1;
+            if (g == 0) {
+                V[(size_t)t * 16 + c] = rec;
+                if (t == p.N - 1)
+                    V[(size_t)p.N * 16 + c] = out_rec;
+            }
         }
     }
     tstore(p.props + (((size_t)blockIdx.z * p.E + k) * p.N + t) * TSZ, P, lane);
@@ -873,21 +941,30 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         // 160 KB -- without it every wave waits for K + 1 dependent 16 KB fetches from L2 / Infinity Cache per slice
         q.stage_ops = (img_bytes + ops_bytes <= (size_t)(NT == 1 ? 64 : 160) * 1024) ? 1 : 0;
         const int per_block = q.stage_ops ? kPropSlices : WPB;
-        const size_t lds = img_bytes + (q.stage_ops ? ops_bytes : 0);
+        // rank-one chain: fuse the forward vector pass into this kernel when one workgroup per member fills the
+        // device (four workgroups of four waves per CU): the last round of workgroups must be at least 90 % full
+        q.fuse_fwd = 0;
+        if (NT == 1 && p.thin && q.stage_ops && !std::getenv("GRAPE_NO_FUSE")) {
+            const long wgs = (long)p.E * p.n_x, slots = 4L * (p.cus > 0 ? p.cus : 256);
+            const long rounds = (wgs + slots - 1) / slots;
+            if (std::getenv("GRAPE_FORCE_FUSE") || 10 * wgs >= 9 * rounds * slots)
+                q.fuse_fwd = std::getenv("GRAPE_FUSE_ABL") ? 2 : 1;
+        }
+        const size_t lds = img_bytes + (q.stage_ops ? ops_bytes : 0) + (q.fuse_fwd ? sizeof(double2) * 33 : 0);
         if (lds > 64 * 1024) {
             hipError_t ea = hipFuncSetAttribute((const void *)prop_tile_kernel<NT, WPB>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (ea != hipSuccess)
                 return ea;
         }
-        hipLaunchKernelGGL((prop_tile_kernel<NT, WPB>), dim3((p.N + per_block - 1) / per_block, p.E, p.n_x), dim3(64 * WPB), lds,
-                           stream, q);
+        hipLaunchKernelGGL((prop_tile_kernel<NT, WPB>), dim3(q.fuse_fwd ? 1 : (p.N + per_block - 1) / per_block, p.E, p.n_x),
+                           dim3(64 * WPB), lds, stream, q);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+        if (NT == 1 && p.thin)
+            return launch_chain_thin(sandwich, q, stream);
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess)
-        return e;
-    if (NT == 1 && p.thin)
-        return launch_chain_thin(sandwich, p, stream);
     TileParams q = p;
     const size_t bt_bytes = sizeof(double2) * (size_t)p.K * NT * NT * 256;
     q.bt_in_lds = bt_bytes <= 36 * 1024 ? 1 : 0;                   // 4 waves per CU must still fit

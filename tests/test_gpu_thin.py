@@ -50,7 +50,12 @@ CASES = [  # n, K, N, E, sys_type, Hermitian generators (drift), Hermitian contr
 
 @pytest.mark.parametrize("n,K,N,E,sys_type,herm_gen,herm_ctrl", CASES)
 @pytest.mark.parametrize("variant", [0, 1])
-def test_rank_one_chain_matches_dense_oracle(qoc, oracle, n, K, N, E, sys_type, herm_gen, herm_ctrl, variant):
+@pytest.mark.parametrize("fused", [False, True])
+def test_rank_one_chain_matches_dense_oracle(qoc, oracle, monkeypatch, n, K, N, E, sys_type, herm_gen, herm_ctrl, variant,
+                                             fused):
+    # fused: the expm kernel walks a member's slices in order and runs the forward vector pass itself (chosen by the
+    # library when one workgroup per member fills the device; forced here for the small shapes)
+    monkeypatch.setenv("GRAPE_FORCE_FUSE" if fused else "GRAPE_NO_FUSE", "1")
     sand = sys_type != "UnitaryGate"
     A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sand, herm_gen, herm_ctrl, seed=7 * n + N + K)
     F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.2, variant=variant,
@@ -152,3 +157,24 @@ def test_rank_one_chain_random_shapes(qoc, oracle, i, n, K, N, E, sys_type, herm
     for k in range(E):
         assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"case {i} member {k}")
     assert_parity(F, G, F_ref, G_ref, n, what=f"case {i}")
+
+
+@pytest.mark.parametrize("sys_type", ["CoherenceTransfer", "UnitaryGate"])
+def test_fused_forward_pass_is_bitwise_the_separate_one(qoc, monkeypatch, sys_type):
+    """E = 1024 fills the device with one workgroup per member, so the library fuses the forward vector pass into the
+    expm kernel by itself; the same summation trees run in both flows, so the results agree to the last bit."""
+    n, K, N, E = 16, 4, 37, 1024
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sys_type != "UnitaryGate", False, True, seed=5)
+    res = {}
+    for mode in ("auto", "separate"):
+        if mode == "separate":
+            monkeypatch.setenv("GRAPE_NO_FUSE", "1")
+        with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N, member_results=True, max_batch=3) as eng:
+            assert eng.info["rank_one_chain"] == 1
+            F, G = eng.eval(x)
+            xs = np.stack([x, 0.5 * x, -x])
+            Fb, Gb = eng.eval_batch(xs)
+            res[mode] = (F, G.copy(), eng.member_results()[1].copy(), np.array(Fb), np.array(Gb))
+    for a, b in zip(res["auto"], res["separate"]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    assert np.isfinite(res["auto"][1]).all() and abs(res["auto"][3][0] - res["auto"][0]) <= 1e-12
