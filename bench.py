@@ -103,10 +103,13 @@ def roofline(local, info, kern_ms, kern_n, evals_per_s, n_gpus, traffic):
     uni = bool(info.get("unitary_flow"))
     thin = bool(info.get("rank_one_chain"))
     alg_bytes, alg_flops = local.algorithmic_bytes, local.algorithmic_flops
-    flow_bytes, flow_flops = local.flow_bytes(uni, thin), local.flow_flops(uni, thin)
+    fused = bool(info.get("fused_forward"))
+    flow_bytes, flow_flops = local.flow_bytes(uni, thin, fused), local.flow_flops(uni, thin)
     gbs = alg_bytes / sec / 1e9 if sec > 0 else 0.0
     tfs = alg_flops / sec / 1e12 if sec > 0 else 0.0
-    flow = {"name": "rank-one states: MFMA expm, then a matrix-vector chain (P_t written once, read twice)" if thin
+    flow = {"name": ("rank-one states: MFMA expm + forward vector pass in one kernel, then the backward vector pass "
+                     "(P_t written once, read once)" if fused else
+                     "rank-one states: MFMA expm, then a matrix-vector chain (P_t written once, read twice)") if thin
                     else ("unitary (P_t only)" if uni else "general (model S)"),
             "bytes_per_launch": flow_bytes,
             "achieved_GBs": flow_bytes / sec / 1e9 if sec > 0 else 0.0,

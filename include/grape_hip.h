@@ -161,6 +161,9 @@ typedef struct grape_info {
     int32_t sparse_controls;       /* 1: every control operator has at most 64 non-zeros (Pauli-type controls) and the
                                       kernels that support it read (coefficient, position) lists instead of dense
                                       operators for the gradient traces */
+    int32_t fused_forward;         /* rank-one chain, single evaluations: 1 when the forward vector pass runs inside the
+                                      expm kernel (one workgroup per member fills the device), so every propagator is
+                                      read from HBM once instead of twice */
 } grape_info;
 
 /* Opaque RCCL bootstrap token (ncclUniqueId), see grape_comm_unique_id / grape_comm_attach. */

@@ -1686,5 +1686,9 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
     info->states_stored = states_stored(c->is_group ? c->sub[0] : c) ? 1 : 0;
     info->rank_one_chain = (c->is_group ? c->sub[0]->thin : c->thin) ? 1 : 0;
     info->sparse_controls = (c->is_group ? c->sub[0]->sparse_ctrl : c->sparse_ctrl) ? 1 : 0;
+    {
+        const grape_ctx *s0 = c->is_group ? c->sub[0] : c;
+        info->fused_forward = (s0->thin && tile_fuse_forward(tile_params(s0, nullptr, 1)) == 1) ? 1 : 0;
+    }
     return GRAPE_OK;
 }

@@ -113,6 +113,7 @@ constexpr int kSparseMax = 64;
 // the chain over rank-one states (n = 9..16, one member per wavefront); called by launch_sweep_tile when p.thin
 hipError_t launch_chain_thin(int sandwich, const TileParams &p, hipStream_t stream);
 int tile_count(int n);    // NT for this n (0: not a tile-family size)
+int tile_fuse_forward(const TileParams &p);   // thin: forward vector pass runs inside prop_tile_kernel for this launch?
 hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
 bool tile_chain_is_split(const TileParams &p, bool keep_costates);   // the two-wave time-split chain: no full X_t store
 

@@ -925,6 +925,22 @@ bool tile_chain_is_split(const TileParams &p, bool keepl)
            !tile_chain_env("1w");
 }
 
+// rank-one chain: is the forward vector pass fused into the expm kernel for this launch?  (0 no, 1 yes, 2 ablation:
+// the fused kernel's grid without the hand-over.)  Only when one workgroup per member fills the device -- four
+// workgroups of four waves per CU -- i.e. the last round of workgroups is at least 90 % full.
+int tile_fuse_forward(const TileParams &p)
+{
+    if (tile_count(p.n) != 1 || !p.thin || std::getenv("GRAPE_NO_FUSE"))
+        return 0;
+    if (sizeof(double2) * (4 * (size_t)kTileImage + (size_t)(p.K + 1) * 256) > 64 * 1024)   // generators not staged
+        return 0;
+    const long wgs = (long)p.E * p.n_x, slots = 4L * (p.cus > 0 ? p.cus : 256);
+    const long rounds = (wgs + slots - 1) / slots;
+    if (std::getenv("GRAPE_FORCE_FUSE") || 10 * wgs >= 9 * rounds * slots)
+        return std::getenv("GRAPE_FUSE_ABL") ? 2 : 1;
+    return 0;
+}
+
 template <int NT>
 static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipStream_t stream)
 {
@@ -943,13 +959,7 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         const int per_block = q.stage_ops ? kPropSlices : WPB;
         // rank-one chain: fuse the forward vector pass into this kernel when one workgroup per member fills the
         // device (four workgroups of four waves per CU): the last round of workgroups must be at least 90 % full
-        q.fuse_fwd = 0;
-        if (NT == 1 && p.thin && q.stage_ops && !std::getenv("GRAPE_NO_FUSE")) {
-            const long wgs = (long)p.E * p.n_x, slots = 4L * (p.cus > 0 ? p.cus : 256);
-            const long rounds = (wgs + slots - 1) / slots;
-            if (std::getenv("GRAPE_FORCE_FUSE") || 10 * wgs >= 9 * rounds * slots)
-                q.fuse_fwd = std::getenv("GRAPE_FUSE_ABL") ? 2 : 1;
-        }
+        q.fuse_fwd = (NT == 1 && q.stage_ops) ? tile_fuse_forward(p) : 0;
         const size_t lds = img_bytes + (q.stage_ops ? ops_bytes : 0) + (q.fuse_fwd ? sizeof(double2) * 33 : 0);
         if (lds > 64 * 1024) {
             hipError_t ea = hipFuncSetAttribute((const void *)prop_tile_kernel<NT, WPB>,

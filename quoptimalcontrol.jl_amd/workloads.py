@@ -118,15 +118,16 @@ class Workload:
         p = (2 + 4 / 3) if n <= 4 else (3 + 4 / 3)
         return E * N * (8 * n ** 3 * (p + q) + 12 * K * n * n)
 
-    def flow_bytes(self, unitary_flow, rank_one=False):
+    def flow_bytes(self, unitary_flow, rank_one=False, fused_forward=False):
         """HBM bytes of the data flow the kernels actually run, per ensemble
         evaluation: the general flow is model S (P_t and one state-like matrix per slice make one
         round trip); the unitary flow (all generators Hermitian) moves only P_t; the rank-one chain
         (9 <= n <= 16, vectors instead of state matrices) writes the zero-padded 16 x 16 P_t once, reads it
-        twice and round-trips one 16-vector per slice."""
+        twice (once when the forward vector pass is fused into the expm kernel) and round-trips one 16-vector per
+        slice."""
         n, K, N, E = self.n, self.K, self.N, self.E
         if rank_one:
-            return E * (N * (3 * 16 * 16 * 16 + 2 * 16 * 16) + 16 * K * N + 16 * (2 * K + 3) * 256)
+            return E * (N * ((2 if fused_forward else 3) * 16 * 16 * 16 + 2 * 16 * 16) + 16 * K * N + 16 * (2 * K + 3) * 256)
         per_slice = 32 if unitary_flow else 64
         return E * (per_slice * n * n * N + 16 * K * N + 16 * (K + 3) * n * n)
 

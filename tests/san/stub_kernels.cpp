@@ -17,6 +17,7 @@ size_t sweep_small_lds_bytes(int n, int MPB, int LT, int S, int K, bool x) { ret
 size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool x, bool) { return 16 * (size_t)n * n * 32 + 16 * (size_t)MPB * 2 * (2 * K + 3) * n * n / 2 + (x ? 8 * ((size_t)MPB * (LT / 2) * ((size_t)S * K + 1) + MPB) : 0); }
 int tile_count(int n) { return n <= 4 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : 0)); }
 bool tile_chain_is_split(const TileParams &, bool) { return false; }
+int tile_fuse_forward(const TileParams &) { return 0; }
 hipError_t launch_lbfgs_init(const LbfgsState &, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
 hipError_t launch_lbfgs_direction(const LbfgsState &, int, double, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_lbfgs_select(const LbfgsState &, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }

@@ -170,7 +170,7 @@ def test_fused_forward_pass_is_bitwise_the_separate_one(qoc, monkeypatch, sys_ty
         if mode == "separate":
             monkeypatch.setenv("GRAPE_NO_FUSE", "1")
         with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N, member_results=True, max_batch=3) as eng:
-            assert eng.info["rank_one_chain"] == 1
+            assert eng.info["rank_one_chain"] == 1 and eng.info["fused_forward"] == (1 if mode == "auto" else 0)
             F, G = eng.eval(x)
             xs = np.stack([x, 0.5 * x, -x])
             Fb, Gb = eng.eval_batch(xs)
