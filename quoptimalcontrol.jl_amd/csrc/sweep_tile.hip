@@ -768,36 +768,37 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
 
     TMat<NT> M, L, Y, Pm, Pn;
     double zr = 0.0, zi = 0.0;
-    // ------------------------------------------------------------ forward: X_N (or T)
+    // ------------------------------------------------------------ forward: X_N = T Xi [T'],  T = P_{N-1} ... P_0
+    // The total product is taken from the LAST slice down, V <- P_t^T V: a D-layout matrix is its own transpose as
+    // an A operand, so the N products need no layout conversion (they did: 4 LDS round trips per slice at NT = 2,
+    // half of this pass's time with one wave per SIMD), and V ends as T^T, which is T as an A operand again.
     {
-        TMat<NT> X;
-        TOp<NT> PA;
-        if (SAND) {                                                // T starts as the identity
-            tzero(X);
+        TMat<NT> X, V;
+        tzero(V);
 #pragma unroll
-            for (int I = 0; I < NT; ++I)
+        for (int I = 0; I < NT; ++I)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * r + (lane >> 4) == (lane & 15))
-                        X.re[I][I][r] = 1.0;
-        } else {
-            tload(X, ops + (size_t)(1 + 2 * K) * TSZ, lane);       // Xi
-        }
-        tload(Pm, Pk, lane);
-        for (int t = 0; t < N; ++t) {
-            if (t + 1 < N)
-                tload(Pn, Pk + (size_t)(t + 1) * TSZ, lane);       // next slice's P in flight
-            to_a_layout(PA, Pm, s_img, lane);
-            tmul_an<NT, false, false>(Y, PA, X);                   // P X
-            X = Y;
+            for (int r = 0; r < 4; ++r)
+                if (4 * r + (lane >> 4) == (lane & 15))
+                    V.re[I][I][r] = 1.0;
+        tload(Pm, Pk + (size_t)(N - 1) * TSZ, lane);
+        for (int t = N - 1; t >= 0; --t) {
+            if (t > 0)
+                tload(Pn, Pk + (size_t)(t - 1) * TSZ, lane);       // next slice's P in flight
+            tmul_tn<NT, false, false>(Y, Pm, V);                   // P_t^T V
+            V = Y;
             Pm = Pn;
         }
-        if (SAND) {                                                // X_N = T Xi T'
+        {
             TMat<NT> Xi;
             tload(Xi, ops + (size_t)(1 + 2 * K) * TSZ, lane);
-            to_a_layout(PA, X, s_img, lane);
-            tmul_tb<NT, false, false>(Y, Xi, PA);                  // (T Xi)^T
-            tmul_tb<NT, false, true>(X, Y, PA);                    // (T Xi) T'
+            tmul_tn<NT, false, false>(X, V, Xi);                   // (T^T)^T Xi = T Xi
+        }
+        if (SAND) {                                                // X_N = (T Xi) T' = (T Xi) conj(T^T)
+            TOp<NT> YA;
+            to_a_layout(YA, X, s_img, lane);
+            tmul_an<NT, false, true>(Y, YA, V);
+            X = Y;
         }
         tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);           // L_N = Xt
         // M_N = X_N L_N'  [ - L_N' X_N ]

@@ -116,6 +116,8 @@ GRAPE_DEV void tprod(TMat<NT> &out, FA a, FB b)
 #pragma unroll
                 for (int J = 0; J < NT; ++J)
                     out.im[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[I], bs[J], out.im[I][J], 0, 0, 0);
+            if (NT == 2)
+                __builtin_amdgcn_sched_barrier(0);        // keep the operand sums of one k-block local (registers)
         }
     } else {
 #pragma unroll
