@@ -23,6 +23,7 @@ stats C5_E4096 GRAPE_X=0 --config C5 --steps 2 --warmup 1
 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C3" > "$OUT/pmc_C3.log" 2>&1
 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C4" --config C4 > "$OUT/pmc_C4.log" 2>&1
 GRAPE_NO_THIN=1 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C4dense" --config C4 > "$OUT/pmc_C4dense.log" 2>&1
+bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C5" --config C5 --steps 2 --warmup 1 > "$OUT/pmc_C5.log" 2>&1
 cd "$ROOT"
 python3 tools/phase_profile.py --config C3 > "$OUT/C3_phase_stamps.json" 2> /dev/null
 python3 tools/parity_report.py > "$OUT/parity.json" 2> "$OUT/parity.log"
