@@ -781,13 +781,16 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
             for (int r = 0; r < 4; ++r)
                 if (4 * r + (lane >> 4) == (lane & 15))
                     V.re[I][I][r] = 1.0;
+        // two slices in flight: this pass is one product per 16 NT^2 KB streamed, close to HBM-bound
+        TMat<NT> Pnn;
         tload(Pm, Pk + (size_t)(N - 1) * TSZ, lane);
+        tload(Pn, Pk + (size_t)max(N - 2, 0) * TSZ, lane);
         for (int t = N - 1; t >= 0; --t) {
-            if (t > 0)
-                tload(Pn, Pk + (size_t)(t - 1) * TSZ, lane);       // next slice's P in flight
+            tload(Pnn, Pk + (size_t)max(t - 2, 0) * TSZ, lane);
             tmul_tn<NT, false, false>(Y, Pm, V);                   // P_t^T V
             V = Y;
             Pm = Pn;
+            Pn = Pnn;
         }
         {
             TMat<NT> Xi;
@@ -841,10 +844,11 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
         zr = zz[0];
         zi = -zz[1];
     }
+    TMat<NT> Pnn;
     tload(Pm, Pk + (size_t)(N - 1) * TSZ, lane);
+    tload(Pn, Pk + (size_t)max(N - 2, 0) * TSZ, lane);
     for (int t = N - 1; t >= 0; --t) {
-        if (t > 0)
-            tload(Pn, Pk + (size_t)(t - 1) * TSZ, lane);
+        tload(Pnn, Pk + (size_t)max(t - 2, 0) * TSZ, lane);        // two slices in flight
         tmul_tn<NT, false, true>(Y, M, Pm);                        // (P' M)^T
         tmul_tn<NT, false, false>(M, Y, Pm);                       // P' M P
         if (SPARSE) {
@@ -904,6 +908,7 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
             }
         }
         Pm = Pn;
+        Pn = Pnn;
     }
 }
 
