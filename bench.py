@@ -359,6 +359,33 @@ def main():
             "what": "grape_eval_device back to back, x and [G,F] resident in HBM, one sync after all steps: "
                     "kernel throughput, not a rate a sequential optimiser can reach"}}
 
+    # ---- N > 1: the companion weak-scaling figure (every GPU a full-size ensemble shard, same step, same all-reduce):
+    # the headline stays the north star's strong-scaling number; this one shows what the exchange costs when the
+    # per-GPU work does not shrink
+    if world > 1 and args.scaling == "strong" and not args.no_extra:
+        try:
+            w_weak = qoc.workloads.config(args.config, E=E_cfg * world)
+            sg_w = sharded_engine(w_weak, device, force_collective=args.force_dist, collective=args.collective,
+                                  flags=qoc.engine.FLAG_FORCE_GENERAL if args.force_general else 0)
+            xw = np.ascontiguousarray(w_weak.x.T)
+            Gw = np.empty_like(xw)
+            direct_w = sg_w.local is not None and sg_w.collective == "lib"
+            bound_w = sg_w.local.bind_eval(xw, Gw) if direct_w else None
+            step_w = (lambda: bound_w()) if direct_w else (lambda: sg_w.eval(np.ascontiguousarray(w_weak.x)))
+            for _ in range(min(args.warmup, 10)):
+                step_w()
+            weak_s = statistics.median(time_blocks(step_w, args.steps, args.blocks, barrier, reduce_max))
+            sg_w.close()
+            extra = dict(extra or {})
+            extra["weak_scaling"] = {
+                "value": args.steps / weak_s * world, "unit": "gradient-evals/s", "ms_per_step": 1e3 * weak_s / args.steps,
+                "ensemble_total": E_cfg * world, "scaling": "weak",
+                "what": f"every GPU evaluates a full E={E_cfg} shard of a {E_cfg * world}-member ensemble per step, one "
+                        f"all-reduce; value = steps/s x {world} in units of the config's {E_cfg}-member evaluation"}
+        except Exception as exc:                   # noqa: BLE001 -- an extra must not kill the headline
+            extra = dict(extra or {})
+            extra["weak_scaling"] = {"error": repr(exc)}
+
     if rank == 0:
         evals_per_s = args.steps / elapsed
         # units: with weak scaling the job evaluates world x the config's ensemble per step;

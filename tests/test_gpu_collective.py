@@ -159,11 +159,14 @@ def test_two_ranks_sharing_the_gpu_fall_back_consistently(qoc):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GRAPE_BENCH_SHARE_GPU="1")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-                          "--blocks", "1", "--no-extra", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                          "--blocks", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
-    assert d["n_gpus"] == 2 and d["config"]["collective"] == "torch" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["config"]["collective"] == "torch" and d["value"] > 0 and d["scaling"] == "strong"
+    # N > 1 runs carry the weak-scaling companion (every rank a full 1024-member shard) next to the strong headline
+    weak = d["extra"]["weak_scaling"]
+    assert weak["ensemble_total"] == 2048 and weak["value"] > 0 and weak["scaling"] == "weak", weak
     w = qoc.workloads.config("C3")
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
         F, _ = eng.eval(w.x)
