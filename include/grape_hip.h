@@ -162,7 +162,7 @@ typedef struct grape_info {
                                       kernels that support it read (coefficient, position) lists instead of dense
                                       operators for the gradient traces */
     int32_t fused_forward;         /* rank-one chain, single evaluations: 1 when the forward vector pass runs inside the
-                                      expm kernel (one workgroup per member fills the device), so every propagator is
+                                      expm kernel (ensembles of at least 2 x compute_units members), so every propagator is
                                       read from HBM once instead of twice */
 } grape_info;
 

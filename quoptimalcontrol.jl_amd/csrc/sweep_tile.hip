@@ -932,8 +932,10 @@ bool tile_chain_is_split(const TileParams &p, bool keepl)
 }
 
 // rank-one chain: is the forward vector pass fused into the expm kernel for this launch?  (0 no, 1 yes, 2 ablation:
-// the fused kernel's grid without the hand-over.)  Only when one workgroup per member fills the device -- four
-// workgroups of four waves per CU -- i.e. the last round of workgroups is at least 90 % full.
+// the fused kernel's grid without the hand-over.)  One workgroup then walks a member's N slices, so a member takes at
+// least N x (one propagator / 4 waves) -- 1.6 ms at C4's N = 1000 however small the ensemble; it pays from half a
+// device of workgroups on (four workgroups of four waves per CU).  Measured at C4, separate / fused, ms per
+// evaluation: E = 256 1.40 / 1.63, 448 2.00 / 2.11, 512 2.35 / 2.12, 1024 3.62 / 3.15, 1536 5.99 / 5.64, 4096 14.3 / 11.9.
 int tile_fuse_forward(const TileParams &p)
 {
     if (tile_count(p.n) != 1 || !p.thin || std::getenv("GRAPE_NO_FUSE"))
@@ -941,8 +943,7 @@ int tile_fuse_forward(const TileParams &p)
     if (sizeof(double2) * (4 * (size_t)kTileImage + (size_t)(p.K + 1) * 256) > 64 * 1024)   // generators not staged
         return 0;
     const long wgs = (long)p.E * p.n_x, slots = 4L * (p.cus > 0 ? p.cus : 256);
-    const long rounds = (wgs + slots - 1) / slots;
-    if (std::getenv("GRAPE_FORCE_FUSE") || 10 * wgs >= 9 * rounds * slots)
+    if (std::getenv("GRAPE_FORCE_FUSE") || 2 * wgs >= slots)
         return std::getenv("GRAPE_FUSE_ABL") ? 2 : 1;
     return 0;
 }

@@ -160,10 +160,11 @@ def test_rank_one_chain_random_shapes(qoc, oracle, i, n, K, N, E, sys_type, herm
 
 
 @pytest.mark.parametrize("sys_type", ["CoherenceTransfer", "UnitaryGate"])
-def test_fused_forward_pass_is_bitwise_the_separate_one(qoc, monkeypatch, sys_type):
-    """E = 1024 fills the device with one workgroup per member, so the library fuses the forward vector pass into the
-    expm kernel by itself; the same summation trees run in both flows, so the results agree to the last bit."""
-    n, K, N, E = 16, 4, 37, 1024
+@pytest.mark.parametrize("E", [1024, 520])
+def test_fused_forward_pass_is_bitwise_the_separate_one(qoc, monkeypatch, sys_type, E):
+    """From half a device of members on (2 x 256 CUs) the library fuses the forward vector pass into the expm kernel by
+    itself; the same summation trees run in both flows, so the results agree to the last bit."""
+    n, K, N = 16, 4, 37
     A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sys_type != "UnitaryGate", False, True, seed=5)
     res = {}
     for mode in ("auto", "separate"):
