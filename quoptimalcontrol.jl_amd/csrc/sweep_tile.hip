@@ -33,15 +33,17 @@ namespace grape {
 // instead of once per slice -- the kernel was L2-bandwidth bound: 24 KB of operators per 4 KB of P)
 constexpr int kPropSlices = 64;
 
-// WPB waves per workgroup.  NT = 2: four (one per SIMD with the whole register file) and three-product complex
-// multiplication; eight (two per SIMD, <= 256 registers each at the price of ~70 spilled VGPRs, the second wave's
-// MFMAs covering the first one's H build, layout conversions, norm and Taylor combinations) was the better choice
-// with four-product multiplication (137 vs 147 ms at C5) and is not with three (166 vs 133 ms).
-template <int NT, int WPB>
-__global__ __launch_bounds__(64 * WPB, NT == 1 ? 4 : (WPB == 8 ? 2 : 1)) void prop_tile_kernel(const TileParams p)
+// Four waves per workgroup, one slice each.  NT = 2 runs them one per SIMD with the whole register file: eight waves
+// (two per SIMD, <= 256 registers each at the price of ~70 spilled VGPRs, the second wave's MFMAs covering the first
+// one's H build, layout conversions, norm and Taylor combinations) was the better choice with four-product complex
+// multiplication (137 vs 147 ms at C5) and is not with three (166 vs 133 ms: the third accumulator set spills).
+constexpr int kPropWaves = 4;
+template <int NT>
+__global__ __launch_bounds__(64 * kPropWaves, NT == 1 ? 4 : 1) void prop_tile_kernel(const TileParams p)
 {
     constexpr int TSZ = NT * NT * 256;                     // double2 per matrix dump
-    constexpr int NIMG = WPB == 4 ? NT : 1;                // LDS conversion images per wave
+    constexpr int WPB = kPropWaves;
+    constexpr int NIMG = NT;                               // LDS conversion images per wave: a row of tiles per pass
     const bool STAGE = p.stage_ops != 0;                   // set by the launcher when the generator tiles fit in LDS
     extern __shared__ double2 s_prop[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -141,19 +143,14 @@ __global__ __launch_bounds__(64 * WPB, NT == 1 ? 4 : (WPB == 8 ? 2 : 1)) void pr
     }
 
     auto conv = [&](TOp<NT> &o, const TMat<NT> &z, double2 *im, int ln) {
-        if (NIMG == NT) to_a_layout_rows(o, z, im, ln); else to_a_layout(o, z, im, ln);
+        to_a_layout_rows(o, z, im, ln);
     };
-    // expm_t8 (cmat.hpp) with MFMA products; every matrix is a polynomial in G.  Three-product complex multiplication
-    // (tile.hpp) where the third accumulator set fits: at NT = 2 with two waves per SIMD (WPB = 8) it spills
-    // (C5: 137 -> 166 ms), with one wave per SIMD and the full register file it does not (147 -> 133 ms).
-#ifndef GRAPE_PROP2_3M
-#define GRAPE_PROP2_3M 1
-#endif
-    constexpr bool kM3 = NT == 1 || GRAPE_PROP2_3M;
+    // expm_t8 (cmat.hpp) with MFMA products (three-product complex multiplication, tile.hpp); every matrix is a
+    // polynomial in G
     TOp<NT> opa;
     TMat<NT> A2, A4, U, T;
     conv(opa, G, img, lane);
-    tmul_an<NT, false, false, kM3>(A2, opa, G);                 // A2 = G G
+    tmul_an<NT, false, false>(A2, opa, G);                 // A2 = G G
 #pragma unroll
     for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -162,7 +159,7 @@ __global__ __launch_bounds__(64 * WPB, NT == 1 ? 4 : (WPB == 8 ? 2 : 1)) void pr
             T.im[I][J] = kX1 * G.im[I][J] + kX2 * A2.im[I][J];
         }
     conv(opa, A2, img, lane);
-    tmul_an<NT, false, false, kM3>(A4, opa, T);                 // A4 = A2 (x1 G + x2 A2)
+    tmul_an<NT, false, false>(A4, opa, T);                 // A4 = A2 (x1 G + x2 A2)
 #pragma unroll
     for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -181,7 +178,7 @@ __global__ __launch_bounds__(64 * WPB, NT == 1 ? 4 : (WPB == 8 ? 2 : 1)) void pr
                 T.re[I][I][r] += kX4;
     conv(opa, U, img, lane);
     TMat<NT> P;
-    tmul_an<NT, false, false, kM3>(P, opa, T);                  // A8
+    tmul_an<NT, false, false>(P, opa, T);                  // A8
 #pragma unroll
     for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -197,7 +194,7 @@ __global__ __launch_bounds__(64 * WPB, NT == 1 ? 4 : (WPB == 8 ? 2 : 1)) void pr
                 P.re[I][I][r] += 1.0;
     for (int i = 0; i < s; ++i) {
         conv(opa, P, img, lane);
-        tmul_an<NT, false, false, kM3>(T, opa, P);
+        tmul_an<NT, false, false>(T, opa, P);
         P = T;
     }
     if (NT == 1 && p.thin && (t & 1)) {
@@ -954,11 +951,8 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     {
         TileParams q = p;
         const size_t ops_bytes = sizeof(double2) * (size_t)(p.K + 1) * NT * NT * 256;
-#ifndef GRAPE_PROP2_WPB
-#define GRAPE_PROP2_WPB 4
-#endif
-        constexpr int WPB = NT == 1 ? 4 : GRAPE_PROP2_WPB;
-        const size_t img_bytes = sizeof(double2) * WPB * (WPB == 4 ? NT : 1) * (size_t)kTileImage;
+        constexpr int WPB = kPropWaves;
+        const size_t img_bytes = sizeof(double2) * WPB * NT * (size_t)kTileImage;
         // the member's K + 1 generator tiles in LDS, read once per kPropSlices slices: NT = 1 keeps room for four
         // workgroups per CU; NT = 2 runs one workgroup per CU anyway (registers) and may take what is left of the
         // 160 KB -- without it every wave waits for K + 1 dependent 16 KB fetches from L2 / Infinity Cache per slice
@@ -969,12 +963,12 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         q.fuse_fwd = (NT == 1 && q.stage_ops) ? tile_fuse_forward(p) : 0;
         const size_t lds = img_bytes + (q.stage_ops ? ops_bytes : 0) + (q.fuse_fwd ? sizeof(double2) * 33 : 0);
         if (lds > 64 * 1024) {
-            hipError_t ea = hipFuncSetAttribute((const void *)prop_tile_kernel<NT, WPB>,
+            hipError_t ea = hipFuncSetAttribute((const void *)prop_tile_kernel<NT>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (ea != hipSuccess)
                 return ea;
         }
-        hipLaunchKernelGGL((prop_tile_kernel<NT, WPB>), dim3(q.fuse_fwd ? 1 : (p.N + per_block - 1) / per_block, p.E, p.n_x),
+        hipLaunchKernelGGL((prop_tile_kernel<NT>), dim3(q.fuse_fwd ? 1 : (p.N + per_block - 1) / per_block, p.E, p.n_x),
                            dim3(64 * WPB), lds, stream, q);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess)

@@ -50,16 +50,15 @@ GRAPE_DEV void tzero(TMat<NT> &m)
         }
 }
 
-// out (+)= op(A) * op(B), operands given per (tile, tile, k-block).  NEGI_A / NEGI_B conjugate.
+// out = op(A) * op(B), operands given per (tile, tile, k-block).  CONJ_A / CONJ_B conjugate.
 // a(I, Kt, kb) -> {re, im} of the A operand, b(Kt, J, kb) likewise.
-template <int NT, bool CONJ_A, bool CONJ_B, bool M3 = true, typename FA, typename FB>
+template <int NT, bool CONJ_A, bool CONJ_B, typename FA, typename FB>
 GRAPE_DEV void tprod(TMat<NT> &out, FA a, FB b)
 {
     // k-blocks outermost, all NT x NT output tiles innermost, accumulating in `out` itself.  (The order does not matter
     // for the issue rate: tools/ubench/mfma_chains.hip shows ONE dependent v_mfma_f64_16x16x4 chain of one wave already
     // running at one instruction per ~62 cycles -- back-to-back accumulation has no penalty on gfx950.)
     tzero(out);
-    if constexpr (M3) {
     // Three real products per complex product: T1 = Ar Br, T2 = Ai Bi accumulate in out.re / out.im, then
     // re = T1 - T2 and im = -(T1 + T2) + (Ar + Ai)(Br + Bi) with the third chain accumulating onto -(T1 + T2).
     // 12 NT^3 matrix-core instructions instead of 16 NT^3 for 16 NT^2 extra FP64 vector additions; the rounding error
@@ -119,38 +118,6 @@ GRAPE_DEV void tprod(TMat<NT> &out, FA a, FB b)
             if (NT == 2)
                 __builtin_amdgcn_sched_barrier(0);        // keep the operand sums of one k-block local (registers)
         }
-    } else {
-#pragma unroll
-    for (int Kt = 0; Kt < NT; ++Kt)
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            double ar[NT], ai[NT], br[NT], bi[NT];
-#pragma unroll
-            for (int I = 0; I < NT; ++I) {
-                a(I, Kt, kb, ar[I], ai[I]);
-                if (CONJ_A) ai[I] = -ai[I];
-            }
-#pragma unroll
-            for (int J = 0; J < NT; ++J) {
-                b(Kt, J, kb, br[J], bi[J]);
-                if (CONJ_B) bi[J] = -bi[J];
-            }
-#pragma unroll
-            for (int I = 0; I < NT; ++I)
-#pragma unroll
-                for (int J = 0; J < NT; ++J) {
-                    out.re[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[I], br[J], out.re[I][J], 0, 0, 0);
-                    out.im[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[I], bi[J], out.im[I][J], 0, 0, 0);
-                }
-#pragma unroll
-            for (int I = 0; I < NT; ++I)
-#pragma unroll
-                for (int J = 0; J < NT; ++J) {
-                    out.re[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai[I], bi[J], out.re[I][J], 0, 0, 0);
-                    out.im[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[I], br[J], out.im[I][J], 0, 0, 0);
-                }
-        }
-    }
 }
 
 // out = op(Z)^T * op(W)   (both in D layout, no data movement)
@@ -163,10 +130,10 @@ GRAPE_DEV void tmul_tn(TMat<NT> &out, const TMat<NT> &z, const TMat<NT> &w)
 }
 
 // out = op(A) * op(W),  A given in A-operand layout (TOp), W in D layout
-template <int NT, bool CONJ_A, bool CONJ_W, bool M3 = true>
+template <int NT, bool CONJ_A, bool CONJ_W>
 GRAPE_DEV void tmul_an(TMat<NT> &out, const TOp<NT> &a, const TMat<NT> &w)
 {
-    tprod<NT, CONJ_A, CONJ_W, M3>(
+    tprod<NT, CONJ_A, CONJ_W>(
         out, [&](int I, int Kt, int kb, double &r, double &i) { r = a.re[I][Kt][kb]; i = a.im[I][Kt][kb]; },
         [&](int Kt, int J, int kb, double &r, double &i) { r = w.re[Kt][J][kb]; i = w.im[Kt][J][kb]; });
 }
