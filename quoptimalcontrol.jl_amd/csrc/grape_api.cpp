@@ -24,6 +24,7 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -90,6 +91,10 @@ struct grape_ctx {
     double2 *d_sp_coef = nullptr;              // [E][K][kSparseMax]
     int32_t *d_sp_addr = nullptr;
     size_t states_bytes = 0;                   // size of d_states (vector records are smaller than state dumps)
+    int tp_C = 0, tp_S = 0;                    // tile family, unitary flow, small ensembles: time chunks per unit (0 = sequential chain)
+    double2 *d_tp_q = nullptr, *d_tp_r = nullptr, *d_tp_m = nullptr;   // chunk products, products after each chunk, M_N
+    double *d_tp_z = nullptr;
+    size_t tp_bytes = 0;
     bool direct_publish = true;                // GRAPE_DIRECT_PUBLISH=0: always go through the reduce kernel
     unsigned long long seq = 0;
     int x_upload = 1;             // 0: hipMemcpyAsync, 1: copy kernel reading the mapped staging buffer,
@@ -232,6 +237,7 @@ static void free_all(grape_ctx *c)
     (void)hipFree(c->d_done_counter);
     (void)hipFree(c->d_vecs);
     (void)hipFree(c->d_sp_coef); (void)hipFree(c->d_sp_addr);
+    (void)hipFree(c->d_tp_q); (void)hipFree(c->d_tp_r); (void)hipFree(c->d_tp_m); (void)hipFree(c->d_tp_z);
     (void)hipFree(c->d_x_bar);
     delete c;
 }
@@ -794,6 +800,39 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             HIP_TRY(c, hipMemcpy(c->d_sp_addr, addr.data(), sizeof(int32_t) * addr.size(), hipMemcpyHostToDevice));
         }
     }
+    {   // time-parallel unitary chain: fewer units than wavefront slots (one wave per unit and chunk, 4 per CU).
+        // Dependent products per evaluation: 3 S + C (S slices per chunk, C chunks) instead of 3 N.
+        c->tp_C = c->tp_S = 0;
+        const long units = (long)c->EU, N = c->cfg.n_slices, slots = 4L * c->compute_units;
+        if (c->family == 1 && herm && !thin && c->cfg.gradient != GRAPE_GRADIENT_EXACT && !c->d_costates && N >= 8 &&
+            2 * units <= slots && !env_on("GRAPE_NO_TP")) {
+            long s_lat = std::lround(std::sqrt((double)N / 3.0));
+            if (s_lat < 2) s_lat = 2;
+            long C = std::min(slots / units, (N + s_lat - 1) / s_lat);
+            if (const char *e = std::getenv("GRAPE_TP_CHUNKS")) C = std::atol(e);
+            if (C > N / 2) C = N / 2;
+            if (C >= 2) {
+                c->tp_S = (int)((N + C - 1) / C);
+                c->tp_C = (int)((N + c->tp_S - 1) / c->tp_S);
+            }
+        }
+        if (c->tp_C) {
+            const size_t tsz = (size_t)c->NT * c->NT * 256, rows = (size_t)c->EU * c->B;
+            const size_t need = sizeof(double2) * rows * tsz * (2 * (size_t)c->tp_C + 1) + sizeof(double) * rows * 128;
+            if (c->tp_bytes < need) {
+                (void)hipFree(c->d_tp_q); (void)hipFree(c->d_tp_r); (void)hipFree(c->d_tp_m); (void)hipFree(c->d_tp_z);
+                c->d_tp_q = c->d_tp_r = c->d_tp_m = nullptr;
+                c->d_tp_z = nullptr;
+                c->bytes += need - c->tp_bytes;
+                c->tp_bytes = 0;
+                HIP_TRY(c, hipMalloc((void **)&c->d_tp_q, sizeof(double2) * rows * tsz * c->tp_C));
+                HIP_TRY(c, hipMalloc((void **)&c->d_tp_r, sizeof(double2) * rows * tsz * c->tp_C));
+                HIP_TRY(c, hipMalloc((void **)&c->d_tp_m, sizeof(double2) * rows * tsz));
+                HIP_TRY(c, hipMalloc((void **)&c->d_tp_z, sizeof(double) * rows * 128));
+                c->tp_bytes = need;
+            }
+        }
+    }
     if (thin) {
         c->unitary = false;                                  // the thin chain serves Hermitian generators as well
         if (!c->d_vecs) {
@@ -856,6 +895,12 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.herm_ctrl = c->herm_ctrl ? 1 : 0;
     p.vecs = c->d_vecs;
     p.cus = c->compute_units;
+    p.tp_chunks = c->tp_C;
+    p.tp_S = c->tp_S;
+    p.tp_q = c->d_tp_q;
+    p.tp_r = c->d_tp_r;
+    p.tp_m = c->d_tp_m;
+    p.tp_z = c->d_tp_z;
     p.sparse = c->sparse_ctrl ? 1 : 0;
     p.sp_coef = c->d_sp_coef;
     p.sp_addr = c->d_sp_addr;
@@ -1689,6 +1734,7 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
     {
         const grape_ctx *s0 = c->is_group ? c->sub[0] : c;
         info->fused_forward = (s0->thin && tile_fuse_forward(tile_params(s0, nullptr, 1)) == 1) ? 1 : 0;
+        info->time_chunks = s0->tp_C;
     }
     return GRAPE_OK;
 }

@@ -96,6 +96,13 @@ struct TileParams {
     int32_t herm_ctrl;    // every control operator B_c Hermitian (thin chain: one bilinear form per control)
     const double2 *vecs;  // thin: per member [v0 | wT], 16 complex each, zero padded
     int32_t cus;          // compute units of the device
+    // time-parallel unitary chain (small ensembles, sweep_tile.hip): the N slices of a unit are cut into tp_chunks chunks
+    // of tp_S slices, one wavefront per chunk; 0 = the sequential chain (one wavefront walks all N slices)
+    int32_t tp_chunks, tp_S;
+    double2 *tp_q;        // [control array][unit][chunk] chunk products Q_c = P_hi-1 ... P_lo (D-layout dumps)
+    double2 *tp_r;        // same shape: R_c = Q_C-1 ... Q_c+1, the product of everything after chunk c
+    double2 *tp_m;        // [control array][unit]: M_N
+    double *tp_z;         // [control array][unit][lane][2]: tr(X_N' L_N) of the lane's member (sandwich)
     int32_t fuse_fwd;     // set by the launcher (thin): one workgroup of prop_tile_kernel walks ALL slices of a member and
                           // runs the forward vector chain v_{t+1} = P_t v_t on the propagators it still holds in
                           // registers, writing the records; chain_thin_kernel then only runs its backward pass

@@ -765,6 +765,21 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
 
     TMat<NT> M, L, Y, Pm, Pn;
     double zr = 0.0, zi = 0.0;
+    // time-parallel mode (TileParams.tp_chunks): this wavefront owns the slices [t_lo, t_hi) of its unit; M_N and the
+    // product R of everything after the chunk come from chunk_scan_kernel, M at the chunk's end is R' M_N R
+    const int C = p.tp_chunks;
+    const int t_lo = C ? (int)blockIdx.z * p.tp_S : 0, t_hi = C ? min(N, t_lo + p.tp_S) : N;
+    if (C) {
+        const size_t kw = (size_t)blockIdx.y * p.E + k;
+        tload(M, p.tp_m + kw * TSZ, lane);
+        if (SAND) {
+            zr = p.tp_z[(kw * 64 + lane) * 2];
+            zi = p.tp_z[(kw * 64 + lane) * 2 + 1];
+        }
+        tload(Pm, p.tp_r + (kw * C + blockIdx.z) * TSZ, lane);
+        tmul_tn<NT, false, true>(Y, M, Pm);                        // (R' M)^T
+        tmul_tn<NT, false, false>(M, Y, Pm);                       // R' M R
+    } else
     // ------------------------------------------------------------ forward: X_N = T Xi [T'],  T = P_{N-1} ... P_0
     // The total product is taken from the LAST slice down, V <- P_t^T V: a D-layout matrix is its own transpose as
     // an A operand, so the N products need no layout conversion (they did: 4 LDS round trips per slice at NT = 2,
@@ -842,9 +857,9 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
         zi = -zz[1];
     }
     TMat<NT> Pnn;
-    tload(Pm, Pk + (size_t)(N - 1) * TSZ, lane);
-    tload(Pn, Pk + (size_t)max(N - 2, 0) * TSZ, lane);
-    for (int t = N - 1; t >= 0; --t) {
+    tload(Pm, Pk + (size_t)(t_hi - 1) * TSZ, lane);
+    tload(Pn, Pk + (size_t)max(t_hi - 2, 0) * TSZ, lane);
+    for (int t = t_hi - 1; t >= t_lo; --t) {
         tload(Pnn, Pk + (size_t)max(t - 2, 0) * TSZ, lane);        // two slices in flight
         tmul_tn<NT, false, true>(Y, M, Pm);                        // (P' M)^T
         tmul_tn<NT, false, false>(M, Y, Pm);                       // P' M P
@@ -907,6 +922,130 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
         Pm = Pn;
         Pn = Pnn;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Time-parallel unitary chain for SMALL ensembles (fewer units than SIMDs: the sequential chain above leaves the
+// device idle and takes N x 3 dependent products -- 27 ms for one 32 x 32 problem of 2000 slices).  The same idea as
+// the chunk scan of sweep_small.hip / sweep_pair.hip, on tiles:
+//   chunk_product_kernel   one wavefront per (unit, chunk): Q_c = P_hi-1 ... P_lo        (S products, in parallel)
+//   chunk_scan_kernel      one wavefront per unit: R_c = Q_C-1 ... Q_c+1 for every c, T = R_-1, then X_N, M_N, z
+//                          exactly as the sequential kernel forms them                    (C products, serial)
+//   chain_tile_unitary_kernel with grid.z = C: M at the end of chunk c = R_c' M_N R_c, then the backward sweep
+//                          and the gradient traces over the chunk's own slices           (2 S products, in parallel)
+// One more product per slice than the sequential chain, 3 S + C dependent products instead of 3 N.
+// Transposes are free as A operands (a D-layout dump of Z is Z^T as the left factor), so every product here is
+// Z^T W on D-layout registers; the chunk kernels convert once at the end to hand out Q_c and R_c untransposed.
+template <int NT>
+GRAPE_DEV void transpose_via_a_layout(TMat<NT> &zt, const TMat<NT> &z, double2 *__restrict__ img, int lane)
+{
+    TOp<NT> a;
+    to_a_layout(a, z, img, lane);                                  // a[I][Kt][kb] = Z[16I + c][16Kt + 4kb + g] = Z^T in D layout at [Kt][I][kb]
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int Kt = 0; Kt < NT; ++Kt)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                zt.re[Kt][I][kb] = a.re[I][Kt][kb];
+                zt.im[Kt][I][kb] = a.im[I][Kt][kb];
+            }
+}
+
+template <int NT>
+GRAPE_DEV void tidentity(TMat<NT> &m, int lane)
+{
+    tzero(m);
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * r + (lane >> 4) == (lane & 15))
+                m.re[I][I][r] = 1.0;
+}
+
+template <int NT>
+__global__ __launch_bounds__(64) void chunk_product_kernel(const TileParams p)
+{
+    constexpr int TSZ = NT * NT * 256;
+    extern __shared__ double2 s_dynt[];
+    const int lane = threadIdx.x, k = blockIdx.x, c = blockIdx.z;
+    const int N = p.N, C = p.tp_chunks;
+    const size_t kw = (size_t)blockIdx.y * p.E + k;
+    const double2 *__restrict__ Pk = p.props + kw * N * TSZ;
+    const int t_lo = c * p.tp_S, t_hi = min(N, t_lo + p.tp_S);
+    TMat<NT> V, Y, Pm, Pn;
+    tidentity(V, lane);
+    tload(Pm, Pk + (size_t)(t_hi - 1) * TSZ, lane);
+    for (int t = t_hi - 1; t >= t_lo; --t) {                       // V <- P_t^T V: ends as (P_hi-1 ... P_lo)^T
+        tload(Pn, Pk + (size_t)max(t - 1, 0) * TSZ, lane);
+        tmul_tn<NT, false, false>(Y, Pm, V);
+        V = Y;
+        Pm = Pn;
+    }
+    transpose_via_a_layout(Y, V, s_dynt, lane);
+    tstore(p.tp_q + (kw * C + c) * TSZ, Y, lane);
+}
+
+template <int NT, int SAND, bool PACK2>
+__global__ __launch_bounds__(64) void chunk_scan_kernel(const TileParams p)
+{
+    constexpr int TSZ = NT * NT * 256;
+    extern __shared__ double2 s_dynt[];
+    double2 *s_img = s_dynt;
+    const int lane = threadIdx.x, k = blockIdx.x;
+    const int K = p.K, C = p.tp_chunks;
+    const size_t kw = (size_t)blockIdx.y * p.E + k;
+    const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
+    const double2 *__restrict__ Qk = p.tp_q + kw * C * TSZ;
+    double2 *__restrict__ Rk = p.tp_r + kw * C * TSZ;
+    TMat<NT> V, Y, Q, Qn;
+    tidentity(V, lane);                                            // V = R_c^T, from the last chunk down
+    tload(Q, Qk + (size_t)(C - 1) * TSZ, lane);
+    for (int c = C - 1; c >= 0; --c) {
+        tload(Qn, Qk + (size_t)max(c - 1, 0) * TSZ, lane);
+        transpose_via_a_layout(Y, V, s_img, lane);
+        tstore(Rk + (size_t)c * TSZ, Y, lane);                     // R_c
+        tmul_tn<NT, false, false>(Y, Q, V);                        // R_{c-1}^T = Q_c^T R_c^T
+        V = Y;
+        Q = Qn;
+    }
+    // V = T^T: X_N, M_N and z as chain_tile_unitary_kernel forms them
+    TMat<NT> X, L, M;
+    {
+        TMat<NT> Xi;
+        tload(Xi, ops + (size_t)(1 + 2 * K) * TSZ, lane);
+        tmul_tn<NT, false, false>(X, V, Xi);                       // T Xi
+    }
+    if (SAND) {
+        TOp<NT> YA;
+        to_a_layout(YA, X, s_img, lane);
+        tmul_an<NT, false, true>(Y, YA, V);                        // (T Xi) T'
+        X = Y;
+    }
+    tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);               // L_N = Xt
+    TOp<NT> XA, LA;
+    to_a_layout(XA, X, s_img, lane);
+    to_a_layout(LA, L, s_img, lane);
+    tprod<NT, false, true>(
+        M, [&](int I, int Kt, int kb, double &r, double &i) { r = XA.re[I][Kt][kb]; i = XA.im[I][Kt][kb]; },
+        [&](int Kt, int J, int kb, double &r, double &i) { r = LA.re[J][Kt][kb]; i = LA.im[J][Kt][kb]; });
+    if (SAND) {
+        tmul_tn<NT, true, false>(Y, L, X);                         // L' X
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                M.re[I][J] -= Y.re[I][J];
+                M.im[I][J] -= Y.im[I][J];
+            }
+        double zz[2];
+        tdot_partial<NT, true>(zz[0], zz[1], X, L);                // tr(X' L), the same for every t
+        wave_sum_n(zz, PACK2);
+        p.tp_z[(kw * 64 + lane) * 2] = zz[0];
+        p.tp_z[(kw * 64 + lane) * 2 + 1] = zz[1];
+    }
+    tstore(p.tp_m + kw * TSZ, M, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1005,16 +1144,32 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         else          hipLaunchKernelGGL((chain_tile_split_kernel<0>), grid, dim3(128), lds2, stream, q);
         return hipGetLastError();
     }
+    // unitary flow, small ensembles: the time axis in chunks (chunk_product_kernel / chunk_scan_kernel above), grid.z = chunk
+    const bool tp = p.tp_chunks > 1 && p.unitary && !keepl;
+    q.tp_chunks = tp ? p.tp_chunks : 0;
+    const dim3 ugrid(p.E, p.n_x, tp ? p.tp_chunks : 1);
+    if (tp) {
+        const size_t lds_img = sizeof(double2) * (kTileImage + 1);
+        hipLaunchKernelGGL((chunk_product_kernel<NT>), ugrid, block, lds_img, stream, q);
+        if (sandwich) { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, NT == 1>), grid, block, lds_img, stream, q);
+                        else    hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, false>), grid, block, lds_img, stream, q); }
+        else          { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 0, NT == 1>), grid, block, lds_img, stream, q);
+                        else    hipLaunchKernelGGL((chunk_scan_kernel<NT, 0, false>), grid, block, lds_img, stream, q); }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+    }
 #define GRAPE_LAUNCH_CHAIN(KERNEL) hipLaunchKernelGGL(KERNEL, grid, block, lds, stream, q)
+#define GRAPE_LAUNCH_UNI(KERNEL) hipLaunchKernelGGL(KERNEL, ugrid, block, lds, stream, q)
     if (p.unitary && !keepl && p.sparse && !pk) {
         // image for layout conversions | coefficients | image of M | positions
         const size_t lds_sp = sizeof(double2) * (kTileImage + 1 + (size_t)p.K * kSparseMax + 16 * NT * (16 * NT + 1)) +
                               sizeof(int32_t) * (size_t)p.K * kSparseMax;
-        if (sandwich) hipLaunchKernelGGL((chain_tile_unitary_kernel<NT, 1, false, true>), grid, block, lds_sp, stream, q);
-        else          hipLaunchKernelGGL((chain_tile_unitary_kernel<NT, 0, false, true>), grid, block, lds_sp, stream, q);
+        if (sandwich) hipLaunchKernelGGL((chain_tile_unitary_kernel<NT, 1, false, true>), ugrid, block, lds_sp, stream, q);
+        else          hipLaunchKernelGGL((chain_tile_unitary_kernel<NT, 0, false, true>), ugrid, block, lds_sp, stream, q);
     } else if (p.unitary && !keepl) {
-        if (sandwich) { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 1, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 1, false>)); }
-        else          { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 0, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_unitary_kernel<NT, 0, false>)); }
+        if (sandwich) { if (pk) GRAPE_LAUNCH_UNI((chain_tile_unitary_kernel<NT, 1, NT == 1>)); else GRAPE_LAUNCH_UNI((chain_tile_unitary_kernel<NT, 1, false>)); }
+        else          { if (pk) GRAPE_LAUNCH_UNI((chain_tile_unitary_kernel<NT, 0, NT == 1>)); else GRAPE_LAUNCH_UNI((chain_tile_unitary_kernel<NT, 0, false>)); }
     } else if (p.sparse && !pk) {
         const size_t lds_sp = sizeof(double2) * (kTileImage + 1 + (size_t)p.K * kSparseMax + 16 * NT * (16 * NT + 1)) +
                               sizeof(int32_t) * (size_t)p.K * kSparseMax;
@@ -1030,6 +1185,7 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         else       { if (pk) GRAPE_LAUNCH_CHAIN((chain_tile_kernel<NT, 0, false, NT == 1>)); else GRAPE_LAUNCH_CHAIN((chain_tile_kernel<NT, 0, false, false>)); }
     }
 #undef GRAPE_LAUNCH_CHAIN
+#undef GRAPE_LAUNCH_UNI
     return hipGetLastError();
 }
 

@@ -66,7 +66,8 @@ class GrapeInfo(C.Structure):
                 ("n_devices", C.c_int32), ("comm_size", C.c_int32), ("comm_rank", C.c_int32),
                 ("members_first_device", C.c_int32), ("lane_pair", C.c_int32),
                 ("states_stored", C.c_int32), ("rank_one_chain", C.c_int32),
-                ("sparse_controls", C.c_int32), ("fused_forward", C.c_int32)]
+                ("sparse_controls", C.c_int32), ("fused_forward", C.c_int32),
+                ("time_chunks", C.c_int32)]
 
 
 class GrapeLbfgsOptions(C.Structure):
