@@ -87,6 +87,7 @@ struct TileParams {
     int32_t s_forced, variant;
     int32_t bt_in_lds;    // set by the launcher: the K transposed control operators are cached in LDS
     int32_t stage_ops;    // set by the launcher: prop kernel stages the generators in LDS
+    int32_t prop_slices;  // set by the launcher: slices one workgroup of the prop kernel walks
     int32_t unitary;      // every generator Hermitian: chain kernel carries M_t = P' M P, no stored states
     int32_t herm_states;  // every Xi, Xt Hermitian (density operators): [X, L'] = Y - Y' with one product
     int32_t split_at;     // set by the launcher: first slice of the second wave (chain_tile_split_kernel)

@@ -22,6 +22,7 @@
 #include <cstring>
 
 #include "cmat.hpp"          // Taylor-8 coefficients, squarings_for
+#include <algorithm>
 #include "grape_kernels.hpp"
 #include "tile.hpp"
 
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(64 * kPropWaves, NT == 1 ? 4 : 1) void prop_tile_ke
     }
     if (STAGE || FUSE)
         __syncthreads();
-    const int t_lo = FUSE ? 0 : blockIdx.x * (STAGE ? kPropSlices : WPB);
-    const int t_hi = FUSE ? p.N : min(p.N, t_lo + (STAGE ? kPropSlices : WPB));
+    const int t_lo = FUSE ? 0 : blockIdx.x * p.prop_slices;
+    const int t_hi = FUSE ? p.N : min(p.N, t_lo + p.prop_slices);
   for (int t = t_lo + wave; t < t_hi; t += WPB) {
     TMat<NT> G;
     if (p.variant == 0)
@@ -1096,7 +1097,17 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         // workgroups per CU; NT = 2 runs one workgroup per CU anyway (registers) and may take what is left of the
         // 160 KB -- without it every wave waits for K + 1 dependent 16 KB fetches from L2 / Infinity Cache per slice
         q.stage_ops = (img_bytes + ops_bytes <= (size_t)(NT == 1 ? 64 : 160) * 1024) ? 1 : 0;
-        const int per_block = q.stage_ops ? kPropSlices : WPB;
+        // slices per workgroup: kPropSlices when that still fills the device, fewer for small ensembles (a single 32 x 32
+        // problem of 2000 slices ran 32 workgroups: 235 us) -- as many as make ONE round of resident workgroups
+        // (NT = 2 holds a CU per workgroup, NT = 1 a quarter), in multiples of the four waves
+        int per_block = WPB;
+        if (q.stage_ops) {
+            const long resident = (long)(p.cus > 0 ? p.cus : 256) * (NT == 1 ? 4 : 1);
+            const long total = (long)p.N * p.E * p.n_x;
+            const long want = ((total + resident - 1) / resident + WPB - 1) / WPB * WPB;
+            per_block = (int)std::min<long>(kPropSlices, std::max<long>(WPB, want));
+        }
+        q.prop_slices = per_block;
         // rank-one chain: fuse the forward vector pass into this kernel when one workgroup per member fills the
         // device (four workgroups of four waves per CU): the last round of workgroups must be at least 90 % full
         q.fuse_fwd = (NT == 1 && q.stage_ops) ? tile_fuse_forward(p) : 0;

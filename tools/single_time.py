@@ -29,7 +29,7 @@ for n, K, N in [(8, 4, 500), (16, 4, 1000), (32, 6, 2000)]:
         Xt = np.array([Q for _ in range(E)])
         x = rng.uniform(-1, 1, (K, N))
         with qoc.GrapeEngine("UnitaryGate", A, B, Xi, Xt, np.ones(E) / E, 2.0, N, flags=qoc.engine.FLAG_TIME_KERNELS) as eng:
-            for _ in range(3):
+            for _ in range(12):                                       # (large workspaces are still being paged in)
                 eng.eval(x)
             eng.kernel_time(reset=True)
             t0 = time.perf_counter()
