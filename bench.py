@@ -104,13 +104,15 @@ def roofline(local, info, kern_ms, kern_n, evals_per_s, n_gpus, traffic):
     thin = bool(info.get("rank_one_chain"))
     alg_bytes, alg_flops = local.algorithmic_bytes, local.algorithmic_flops
     fused = bool(info.get("fused_forward"))
-    flow_bytes, flow_flops = local.flow_bytes(uni, thin, fused), local.flow_flops(uni, thin)
+    chunks = int(info.get("time_chunks") or 0)
+    flow_bytes, flow_flops = local.flow_bytes(uni, thin, fused), local.flow_flops(uni, thin, chunked=chunks > 1)
     gbs = alg_bytes / sec / 1e9 if sec > 0 else 0.0
     tfs = alg_flops / sec / 1e12 if sec > 0 else 0.0
     flow = {"name": ("rank-one states: MFMA expm + forward vector pass in one kernel, then the backward vector pass "
                      "(P_t written once, read once)" if fused else
                      "rank-one states: MFMA expm, then a matrix-vector chain (P_t written once, read twice)") if thin
-                    else ("unitary (P_t only)" if uni else "general (model S)"),
+                    else ((f"unitary (P_t only), time axis in {chunks} parallel chunks" if chunks > 1 else "unitary (P_t only)")
+                          if uni else "general (model S)"),
             "bytes_per_launch": flow_bytes,
             "achieved_GBs": flow_bytes / sec / 1e9 if sec > 0 else 0.0,
             "frac_hbm": flow_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else 0.0,
@@ -165,10 +167,14 @@ def time_blocks(step, steps, blocks, barrier, reduce_max):
 def run_extra_config(qoc, name, dev_index, steps, warmup):
     """One more BASELINE config on this GPU, host -> host, with its own roofline (N = 1 only).
     "C4dense": C4 through the dense MFMA chain (GRAPE_FLAG_FORCE_GENERAL) instead of the rank-one vector chain its
-    vec(rho) vec(rho)' states allow."""
+    vec(rho) vec(rho)' states allow.  "C5x1": ONE 32 x 32 problem of C5's shape -- the single-`Problem` closure
+    (src/solve.jl:63-143), latency-bound: the time axis is evaluated in parallel chunks."""
     dense = name.endswith("dense")
     cfg_name = name[:-5] if dense else name
-    w = qoc.workloads.config(cfg_name)
+    members = 0
+    if "x" in cfg_name:                                    # "C5x1": the config's shape with that many members
+        cfg_name, members = cfg_name.split("x")[0], int(cfg_name.split("x")[1])
+    w = qoc.workloads.config(cfg_name, E=members) if members else qoc.workloads.config(cfg_name)
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, device=dev_index,
                          flags=qoc.engine.FLAG_TIME_KERNELS | (qoc.engine.FLAG_FORCE_GENERAL if dense else 0)) as eng:
         import numpy as np
@@ -258,7 +264,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the device-resident loop and the extra configs")
-    ap.add_argument("--extra-configs", default="C2,C4,C4dense,C5")
+    ap.add_argument("--extra-configs", default="C2,C4,C4dense,C5,C5x1")
     ap.add_argument("--backend", default="",
                     help="torch.distributed backend; default: gloo as the control plane when the data-path collective "
                          "is RCCL inside the library (--collective lib), cpu:gloo,cuda:nccl for --collective torch")
@@ -443,7 +449,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra and args.extra_configs:
         out["extra_configs"] = []
         for name in [s for s in args.extra_configs.split(",") if s and s != args.config]:
-            heavy = name in ("C4", "C4dense", "C5")
+            heavy = name in ("C4", "C4dense", "C5", "C5x1")
             try:
                 out["extra_configs"].append(run_extra_config(qoc, name, dev_index, 3 if name == "C5" else (20 if heavy else 200),
                                                              1 if name == "C5" else (3 if heavy else 20)))

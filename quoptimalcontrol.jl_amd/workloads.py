@@ -131,7 +131,7 @@ class Workload:
         per_slice = 32 if unitary_flow else 64
         return E * (per_slice * n * n * N + 16 * K * N + 16 * (K + 3) * n * n)
 
-    def flow_flops(self, unitary_flow, rank_one=False):
+    def flow_flops(self, unitary_flow, rank_one=False, chunked=False):
         """FP64 flops of the flow in use: expm (Taylor-8: 3 products) + chain products per slice
         (unitary flow: 3 = chunk/forward product + P'MP; general: 3 UnitaryGate / 6 sandwich) + H build
         and the K traces.  Rank-one chain: expm + two matrix-vector products + K bilinear forms."""
@@ -139,6 +139,8 @@ class Workload:
         if rank_one:
             return E * N * (8 * n ** 3 * 3 + 2 * 8 * n * n + K * 10 * n * n + 4 * K * n * n)
         q = 3 if (unitary_flow or self.sys_type == "UnitaryGate") else 6
+        if chunked and unitary_flow:                       # chunk products replace the forward product, + the chunk transform
+            q = 4
         return E * N * (8 * n ** 3 * (3 + q) + 12 * K * n * n)
 
 

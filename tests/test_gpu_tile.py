@@ -68,8 +68,13 @@ def test_tile_family_random(qoc, oracle, n, sys_type, herm, variant):
                                         (16, "StateTransfer"), (23, "StateTransfer"), (32, "UnitaryGate"),
                                         (32, "StateTransfer")])
 @pytest.mark.parametrize("variant", [0, 1])
-def test_tile_family_unitary_flow(qoc, oracle, n, sys_type, variant):
-    """Hermitian generators: the chain kernel carries M_t = P' M P and stores no forward states."""
+@pytest.mark.parametrize("chain", ["chunked", "sequential"])
+def test_tile_family_unitary_flow(qoc, oracle, monkeypatch, n, sys_type, variant, chain):
+    """Hermitian generators: the chain kernel carries M_t = P' M P and stores no forward states.  Small ensembles cut
+    the time axis into chunks evaluated in parallel (grape_info.time_chunks); GRAPE_NO_TP=1 keeps the one-wavefront
+    chain large ensembles run."""
+    if chain == "sequential":
+        monkeypatch.setenv("GRAPE_NO_TP", "1")
     w = _random_problem(qoc, n, 3, 14, 3, sys_type, seed=300 + n, hermitian=True, mixed=True)
     F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
                                                             variant=variant, per_member=True)
@@ -77,6 +82,7 @@ def test_tile_family_unitary_flow(qoc, oracle, n, sys_type, variant):
         F, G = eng.eval(w.x)
         foms, grads = eng.member_results()
         assert eng.info["kernel_family"] == 1 and eng.info["unitary_flow"] == 1 and eng.info["rank_one_chain"] == 0
+        assert (eng.info["time_chunks"] >= 2) == (chain == "chunked")
         with pytest.raises(qoc.GrapeError):
             eng.trajectory(0)                               # no stored states in this flow
     for k in range(w.E):
@@ -112,13 +118,49 @@ def test_c4_liouvillian_parity(qoc, oracle, dense):
     assert_parity(F, G, F_ref, G_ref, w.n, what="C4")
 
 
-def test_c5_five_qubit_parity(qoc, oracle):
-    """BASELINE config 5 at parity size: 32x32 UnitaryGate, K=6, N=2000 (2 members)."""
+@pytest.mark.parametrize("chain", ["chunked", "sequential"])
+def test_c5_five_qubit_parity(qoc, oracle, monkeypatch, chain):
+    """BASELINE config 5 at parity size: 32x32 UnitaryGate, K=6, N=2000 (2 members): the chunked time axis small
+    ensembles get, and the one-wavefront chain of the full-size ensemble."""
+    if chain == "sequential":
+        monkeypatch.setenv("GRAPE_NO_TP", "1")
     w = qoc.workloads.config("C5", E=2)
     F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
     with _engine(qoc, w) as eng:
+        assert (eng.info["time_chunks"] >= 2) == (chain == "chunked")
         F, G = eng.eval(w.x)
     assert_parity(F, G, F_ref, G_ref, w.n, what="C5")
+
+
+@pytest.mark.parametrize("n,sys_type,E,N,chunks", [(7, "UnitaryGate", 5, 37, 5), (8, "StateTransfer", 1, 64, 9),
+                                                   (16, "UnitaryGate", 1, 101, 13), (16, "StateTransfer", 4, 50, 2),
+                                                   (24, "UnitaryGate", 2, 33, 16), (32, "StateTransfer", 1, 41, 4)])
+def test_time_chunks_ragged_and_entry_points(qoc, oracle, monkeypatch, n, sys_type, E, N, chunks):
+    """The chunked time axis with chunk counts that do not divide N (ragged last chunk), pair-packed members (n <= 8),
+    single problems, and through the batched and device entry points."""
+    import torch
+    monkeypatch.setenv("GRAPE_TP_CHUNKS", str(chunks))
+    w = _random_problem(qoc, n, 3, N, E, sys_type, seed=77 + n + N, hermitian=True, mixed=True)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, member_results=True, max_batch=3) as eng:
+        S = -(-N // chunks)
+        assert eng.info["time_chunks"] == -(-N // S) and eng.info["unitary_flow"] == 1
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+        xs = np.stack([w.x, -0.5 * w.x, 0.25 * w.x + 0.1])
+        Fb, Gb = eng.eval_batch(xs)
+        x_dev = torch.as_tensor(np.ascontiguousarray(w.x.T), device="cuda")
+        fg = torch.zeros(w.K * w.N + 1, dtype=torch.float64, device="cuda")
+        eng.eval_device(x_dev.data_ptr(), fg.data_ptr())
+        torch.cuda.synchronize()
+        fg = fg.cpu().numpy()
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, per_member=True)
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k}")
+    assert_parity(F, G, F_ref, G_ref, n, what="ensemble")
+    assert_parity(fg[-1], fg[:-1].reshape(w.N, w.K).T, F_ref, G_ref, n, what="device entry point")
+    for b in range(3):
+        Fr, Gr = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, xs[b], w.T)
+        assert_parity(Fb[b], Gb[b], Fr, Gr, n, what=f"batch entry {b}")
 
 
 @pytest.mark.parametrize("name,E,members,dense", [("C4", 1024, (0, 1, 511, 1023), False), ("C4", 1024, (0, 1023), True),
@@ -177,9 +219,12 @@ def _sparse_problem(qoc, n, K, N, E, sys_type, seed, nnz_pairs=12):
                                           (20, "UnitaryGate", 6), (32, "UnitaryGate", 6), (32, "StateTransfer", 2),
                                           (27, "StateTransfer", 5)])
 @pytest.mark.parametrize("variant", [0, 1])
-def test_sparse_control_operators(qoc, oracle, monkeypatch, n, sys_type, K, variant):
+@pytest.mark.parametrize("chain", ["chunked", "sequential"])
+def test_sparse_control_operators(qoc, oracle, monkeypatch, n, sys_type, K, variant, chain):
     """control operators with <= 64 non-zeros: the unitary chain reads (coefficient, position) lists from LDS instead of
     dense transposed operators; same results as the oracle and as the dense path (GRAPE_NO_SPARSE=1)."""
+    if chain == "sequential":
+        monkeypatch.setenv("GRAPE_NO_TP", "1")
     w = _sparse_problem(qoc, n, K, 15, 3, sys_type, seed=40 + n + K)
     F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
                                                             variant=variant, per_member=True)
