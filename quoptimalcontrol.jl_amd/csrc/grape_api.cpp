@@ -94,6 +94,7 @@ struct grape_ctx {
     int tp_C = 0, tp_S = 0;                    // tile family, unitary flow, small ensembles: time chunks per unit (0 = sequential chain)
     double2 *d_tp_q = nullptr, *d_tp_r = nullptr, *d_tp_m = nullptr;   // chunk products, products after each chunk, M_N
     double *d_tp_z = nullptr;
+    double2 *d_tp_vec = nullptr;               // rank-one chain: v at every chunk's start, w at its end
     size_t tp_bytes = 0;
     bool direct_publish = true;                // GRAPE_DIRECT_PUBLISH=0: always go through the reduce kernel
     unsigned long long seq = 0;
@@ -237,7 +238,7 @@ static void free_all(grape_ctx *c)
     (void)hipFree(c->d_done_counter);
     (void)hipFree(c->d_vecs);
     (void)hipFree(c->d_sp_coef); (void)hipFree(c->d_sp_addr);
-    (void)hipFree(c->d_tp_q); (void)hipFree(c->d_tp_r); (void)hipFree(c->d_tp_m); (void)hipFree(c->d_tp_z);
+    (void)hipFree(c->d_tp_q); (void)hipFree(c->d_tp_r); (void)hipFree(c->d_tp_m); (void)hipFree(c->d_tp_z); (void)hipFree(c->d_tp_vec);
     (void)hipFree(c->d_x_bar);
     delete c;
 }
@@ -800,12 +801,15 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             HIP_TRY(c, hipMemcpy(c->d_sp_addr, addr.data(), sizeof(int32_t) * addr.size(), hipMemcpyHostToDevice));
         }
     }
-    {   // time-parallel unitary chain: fewer units than wavefront slots (one wave per unit and chunk, 4 per CU).
-        // Dependent products per evaluation: 3 S + C (S slices per chunk, C chunks) instead of 3 N.
+    {   // time-parallel chains: fewer units than wavefront slots (one wave per unit and chunk, 4 per CU).
+        // Unitary flow: 3 S + C dependent products per evaluation (S slices per chunk, C chunks) instead of 3 N.
+        // Rank-one chain: S dense chunk-product steps + 2 S vector steps + 2 C scan steps instead of 2 N vector steps;
+        // its chunks start at multiples of 8 slices (the vector formats and prefetch rings follow the slice index).
         c->tp_C = c->tp_S = 0;
         const long units = (long)c->EU, N = c->cfg.n_slices, slots = 4L * c->compute_units;
-        if (c->family == 1 && herm && !thin && c->cfg.gradient != GRAPE_GRADIENT_EXACT && !c->d_costates && N >= 8 &&
-            2 * units <= slots && !env_on("GRAPE_NO_TP")) {
+        const bool small = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT && !c->d_costates &&
+                           2 * units <= slots && !env_on("GRAPE_NO_TP");
+        if (small && herm && !thin && N >= 8) {
             long s_lat = std::lround(std::sqrt((double)N / 3.0));
             if (s_lat < 2) s_lat = 2;
             long C = std::min(slots / units, (N + s_lat - 1) / s_lat);
@@ -815,19 +819,34 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                 c->tp_S = (int)((N + C - 1) / C);
                 c->tp_C = (int)((N + c->tp_S - 1) / c->tp_S);
             }
+        } else if (small && thin && N >= 32 && 2 * units < slots) {      // (from half a device on, the fused forward pass)
+            // measured optimum at C4's shape (N = 1000): 16..32 slices per chunk for 1..16 members (tools/single_open.py)
+            long s_lat = 8 * std::max(1L, std::lround(std::sqrt(0.6 * (double)N) / 8.0));
+            long C = std::min(slots / units, (N + s_lat - 1) / s_lat);
+            if (const char *e = std::getenv("GRAPE_TP_CHUNKS")) C = std::atol(e);
+            if (C >= 2) {
+                const long S = ((N + C - 1) / C + 7) / 8 * 8;
+                if ((N + S - 1) / S >= 2) {
+                    c->tp_S = (int)S;
+                    c->tp_C = (int)((N + S - 1) / S);
+                }
+            }
         }
         if (c->tp_C) {
             const size_t tsz = (size_t)c->NT * c->NT * 256, rows = (size_t)c->EU * c->B;
-            const size_t need = sizeof(double2) * rows * tsz * (2 * (size_t)c->tp_C + 1) + sizeof(double) * rows * 128;
+            const size_t need = sizeof(double2) * rows * (tsz * (2 * (size_t)c->tp_C + 1) + 32 * (size_t)c->tp_C) +
+                                sizeof(double) * rows * 128;
             if (c->tp_bytes < need) {
                 (void)hipFree(c->d_tp_q); (void)hipFree(c->d_tp_r); (void)hipFree(c->d_tp_m); (void)hipFree(c->d_tp_z);
-                c->d_tp_q = c->d_tp_r = c->d_tp_m = nullptr;
+                (void)hipFree(c->d_tp_vec);
+                c->d_tp_q = c->d_tp_r = c->d_tp_m = c->d_tp_vec = nullptr;
                 c->d_tp_z = nullptr;
                 c->bytes += need - c->tp_bytes;
                 c->tp_bytes = 0;
                 HIP_TRY(c, hipMalloc((void **)&c->d_tp_q, sizeof(double2) * rows * tsz * c->tp_C));
                 HIP_TRY(c, hipMalloc((void **)&c->d_tp_r, sizeof(double2) * rows * tsz * c->tp_C));
                 HIP_TRY(c, hipMalloc((void **)&c->d_tp_m, sizeof(double2) * rows * tsz));
+                HIP_TRY(c, hipMalloc((void **)&c->d_tp_vec, sizeof(double2) * rows * 32 * c->tp_C));
                 HIP_TRY(c, hipMalloc((void **)&c->d_tp_z, sizeof(double) * rows * 128));
                 c->tp_bytes = need;
             }
@@ -901,6 +920,7 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.tp_r = c->d_tp_r;
     p.tp_m = c->d_tp_m;
     p.tp_z = c->d_tp_z;
+    p.tp_vec = c->d_tp_vec;
     p.sparse = c->sparse_ctrl ? 1 : 0;
     p.sp_coef = c->d_sp_coef;
     p.sp_addr = c->d_sp_addr;

@@ -76,7 +76,12 @@ __global__ __launch_bounds__(64) void chain_thin_kernel(const TileParams p)
     extern __shared__ double2 s_thin[];           // (INLDS) this member's [B_c | B_c^T] dumps
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     const int k = blockIdx.x;
-    const int K = p.K, N = p.N;
+    // time-parallel mode (TileParams.tp_chunks, small ensembles): this wavefront owns the slices [lo, lo + N) of its
+    // member; v at the chunk's start, w at its end and s come from chunk_scan_thin_kernel.  Chunks start at multiples
+    // of 8, so slice parities and ring slots are those of the whole pulse.
+    const int C = p.tp_chunks;
+    const int lo = C ? (int)blockIdx.z * p.tp_S : 0;
+    const int K = p.K, N = C ? min(p.N, lo + p.tp_S) - lo : p.N;
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
     const double2 *__restrict__ opB = ops + TSZ;                 // B_c at opB + c TSZ, B_c^T at opB + (K + c) TSZ
     if (INLDS) {
@@ -92,10 +97,12 @@ __global__ __launch_bounds__(64) void chain_thin_kernel(const TileParams p)
             load_tile(m, opB + (size_t)idx * TSZ, lane);
     };
     const size_t kw = (size_t)blockIdx.y * p.E + k;
-    const double2 *__restrict__ Pk = p.props + kw * N * TSZ;
-    double2 *__restrict__ V = p.states + kw * (size_t)(N + 1) * 16;       // records v_0 .. v_N, 16 complex each
-    const double2 *__restrict__ v0 = p.vecs + (size_t)k * 32, *__restrict__ wT = v0 + 16;
-    double *__restrict__ out = p.member_out + ((size_t)blockIdx.y * p.E_members + k) * ((size_t)K * N + 1);
+    const double2 *__restrict__ Pk = p.props + (kw * p.N + lo) * TSZ;
+    double2 *__restrict__ V = p.states + (kw * (size_t)(p.N + 1) + lo) * 16;   // records v_0 .. v_N, 16 complex each
+    const double2 *__restrict__ v0 = C ? p.tp_vec + (kw * C + blockIdx.z) * 32 : p.vecs + (size_t)k * 32;
+    const double2 *__restrict__ wT = v0 + 16;
+    double *__restrict__ out_member = p.member_out + ((size_t)blockIdx.y * p.E_members + k) * ((size_t)K * p.N + 1);
+    double *__restrict__ out = out_member + (size_t)lo * K;
     const int sel = c & 3;                        // which of a lane's four gathered entries it writes to a record
 
     // ------------------------------------------------------------------ forward: v_{t+1} = P_t v_t
@@ -177,7 +184,9 @@ __global__ __launch_bounds__(64) void chain_thin_kernel(const TileParams p)
         if (base + 5 < N) step(IC<5>(), base + 5);
         if (base + 6 < N) step(IC<6>(), base + 6);
         // v_N: after an odd last slice it is in per-column format, after an even one gathered
-        if ((N & 1) == 0)
+        // (a chunk leaves that record to the next chunk, whose first record it is)
+        if (C) {
+        } else if ((N & 1) == 0)
             V[(size_t)N * 16 + c] = make_double2(vr, vi);
         else
             record_gathered(N);
@@ -187,7 +196,10 @@ __global__ __launch_bounds__(64) void chain_thin_kernel(const TileParams p)
 
     // ------------------------------------------------------------------ s = wT' v_N
     double s_re, s_im;
-    {
+    if (C) {
+        s_re = p.tp_z[kw * 128];
+        s_im = p.tp_z[kw * 128 + 1];
+    } else {
         double z[2] = {0.0, 0.0};
         if (g == 0) {
             const double2 w = wT[c], v = V[(size_t)N * 16 + c];
@@ -394,20 +406,136 @@ __global__ __launch_bounds__(64) void chain_thin_kernel(const TileParams p)
             flush(base);
         }
     }
-    if (lane == 0) {
+    if (lane == 0 && (!C || (int)blockIdx.z == C - 1)) {
         if (SAND) {
             const double z = (s_re * s_re + s_im * s_im) / (double)p.n;   // tr(L' X) / D = |s|^2 / n
-            out[(size_t)K * N] = 1.0 - z * z;
+            out_member[(size_t)K * p.N] = 1.0 - z * z;
         } else {
-            out[(size_t)K * N] = s_re * s_re - s_im * s_im;               // Re(z^2), z = conj(s)
+            out_member[(size_t)K * p.N] = s_re * s_re - s_im * s_im;      // Re(z^2), z = conj(s)
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Time-parallel vector chain for small ensembles (see "Time-parallel unitary chain" in sweep_tile.hip): dense chunk
+// products Q_c on the matrix cores (one wavefront per member and chunk), then one wavefront per member carries v
+// through the chunk starts (v <- Q_c v) and w back through the chunk ends (w <- Q_c' w), and the chunks run the
+// kernel above on their own slices.  The propagators are stored transposed for odd t: an odd slice is a free left
+// factor (Z^T W with Z the dump), an even one goes through the layout conversion.
+__global__ __launch_bounds__(64) void chunk_product_thin_kernel(const TileParams p)
+{
+    constexpr int TSZ = 256;
+    extern __shared__ double2 s_thin[];
+    const int lane = threadIdx.x, k = blockIdx.x, ch = blockIdx.z;
+    const int C = p.tp_chunks;
+    const size_t kw = (size_t)blockIdx.y * p.E + k;
+    const int lo = ch * p.tp_S, hi = min(p.N, lo + p.tp_S);
+    const double2 *__restrict__ Pk = p.props + kw * p.N * TSZ;
+    TMat<1> W, Y, Pm, Pn;
+    tzero(W);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (4 * r + (lane >> 4) == (lane & 15))
+            W.re[0][0][r] = 1.0;
+    tload(Pm, Pk + (size_t)lo * TSZ, lane);
+    for (int t = lo; t < hi; ++t) {                                 // W <- P_t W
+        tload(Pn, Pk + (size_t)min(t + 1, p.N - 1) * TSZ, lane);
+        if (t & 1) {
+            tmul_tn<1, false, false>(Y, Pm, W);                     // the dump is P_t^T
+        } else {
+            TOp<1> PA;
+            to_a_layout(PA, Pm, s_thin, lane);
+            tmul_an<1, false, false>(Y, PA, W);
+        }
+        W = Y;
+        Pm = Pn;
+    }
+    tstore(p.tp_q + (kw * C + ch) * TSZ, W, lane);
+}
+
+__global__ __launch_bounds__(64) void chunk_scan_thin_kernel(const TileParams p)
+{
+    constexpr int TSZ = 256;
+    __shared__ double2 s_v[16];
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15, k = blockIdx.x;
+    const int C = p.tp_chunks;
+    const size_t kw = (size_t)blockIdx.y * p.E + k;
+    const double2 *__restrict__ Qk = p.tp_q + kw * C * TSZ;
+    double2 *__restrict__ vec = p.tp_vec + kw * C * 32;
+    const double2 *__restrict__ v0 = p.vecs + (size_t)k * 32, *__restrict__ wT = v0 + 16;
+    Tile1 Q, Qn;
+    // forward: v at every chunk start (per-column: lane holds v[c]);  reg r of the dump = Q[4r + g][c]
+    double2 v = v0[c];
+    load_tile(Q, Qk, lane);
+    for (int ch = 0; ch < C; ++ch) {
+        load_tile(Qn, Qk + (size_t)min(ch + 1, C - 1) * TSZ, lane);
+        if (g == 0)
+            vec[(size_t)ch * 32 + c] = v;
+        double y[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            y[2 * r] = fma(Q.re[r], v.x, -Q.im[r] * v.y);
+            y[2 * r + 1] = fma(Q.re[r], v.y, Q.im[r] * v.x);
+        }
+        row_sum_n(y);                                               // every lane of row g: (Q v)[4r + g]
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (c == r)
+                s_v[4 * r + g] = make_double2(y[2 * r], y[2 * r + 1]);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        v = s_v[c];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        Q = Qn;
+    }
+    // s = wT' v_N
+    {
+        double z[2] = {0.0, 0.0};
+        if (g == 0) {
+            const double2 w = wT[c];
+            z[0] = w.x * v.x + w.y * v.y;
+            z[1] = w.x * v.y - w.y * v.x;
+        }
+        row_sum_n(z);
+        const double s_re = __shfl(z[0], 0, 64), s_im = __shfl(z[1], 0, 64);
+        if (lane == 0) {
+            p.tp_z[kw * 128] = s_re;
+            p.tp_z[kw * 128 + 1] = s_im;
+        }
+    }
+    // backward: w at every chunk end;  (Q' w)[c] = sum_i conj(Q[i][c]) w[i]
+    double2 w = wT[c];
+    load_tile(Q, Qk + (size_t)(C - 1) * TSZ, lane);
+    for (int ch = C - 1; ch >= 0; --ch) {
+        load_tile(Qn, Qk + (size_t)max(ch - 1, 0) * TSZ, lane);
+        if (g == 0) {
+            vec[(size_t)ch * 32 + 16 + c] = w;
+            s_v[c] = w;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        double acc[2] = {0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 wi = s_v[4 * r + g];
+            acc[0] = fma(Q.re[r], wi.x, acc[0]);
+            acc[0] = fma(Q.im[r], wi.y, acc[0]);
+            acc[1] = fma(Q.re[r], wi.y, acc[1]);
+            acc[1] = fma(-Q.im[r], wi.x, acc[1]);
+        }
+        col_sum_n(acc);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        w = make_double2(acc[0], acc[1]);
+        Q = Qn;
     }
 }
 
 template <int SAND, bool HERMB>
 static void launch_thin(const TileParams &q, size_t lds, hipStream_t stream)
 {
-    const dim3 grid(q.E, q.n_x);
+    const dim3 grid(q.E, q.n_x, q.tp_chunks ? q.tp_chunks : 1);
     if (q.bt_in_lds)
         hipLaunchKernelGGL((chain_thin_kernel<SAND, HERMB, true>), grid, dim3(64), lds, stream, q);
     else
@@ -417,6 +545,13 @@ static void launch_thin(const TileParams &q, size_t lds, hipStream_t stream)
 hipError_t launch_chain_thin(int sandwich, const TileParams &p, hipStream_t stream)
 {
     TileParams q = p;
+    if (q.tp_chunks > 1 && !q.fuse_fwd) {
+        const dim3 cgrid(p.E, p.n_x, p.tp_chunks);
+        hipLaunchKernelGGL(chunk_product_thin_kernel, cgrid, dim3(64), sizeof(double2) * (kTileImage + 1), stream, q);
+        hipLaunchKernelGGL(chunk_scan_thin_kernel, dim3(p.E, p.n_x), dim3(64), 0, stream, q);
+    } else {
+        q.tp_chunks = 0;
+    }
     const size_t b_bytes = sizeof(double2) * 2 * (size_t)p.K * 256;
     q.bt_in_lds = b_bytes <= 36 * 1024 ? 1 : 0;                   // four workgroups per CU still fit
     const size_t lds = q.bt_in_lds ? b_bytes : 0;
