@@ -179,3 +179,43 @@ def test_fused_forward_pass_is_bitwise_the_separate_one(qoc, monkeypatch, sys_ty
     for a, b in zip(res["auto"], res["separate"]):
         assert np.array_equal(np.asarray(a), np.asarray(b))
     assert np.isfinite(res["auto"][1]).all() and abs(res["auto"][3][0] - res["auto"][0]) <= 1e-12
+
+
+@pytest.mark.parametrize("n,K,N,E,sys_type,chunks", [(16, 4, 257, 1, "CoherenceTransfer", 0), (16, 3, 100, 3, "StateTransfer", 3),
+                                                     (12, 2, 64, 2, "UnitaryGate", 8), (16, 4, 1000, 1, "UnitaryGate", 0),
+                                                     (9, 5, 41, 4, "CoherenceTransfer", 2), (16, 6, 200, 2, "StateTransfer", 25)])
+@pytest.mark.parametrize("chain", ["chunked", "sequential"])
+def test_rank_one_chain_time_chunks(qoc, oracle, monkeypatch, n, K, N, E, sys_type, chunks, chain):
+    """Small ensembles of rank-one problems cut the time axis into chunks of a multiple of 8 slices (dense chunk
+    products, vector scan over the chunk boundaries, chunk-parallel vector sweeps: grape_info.time_chunks); ragged
+    last chunks, the library's own chunk count (0) and forced ones, batched and device entry points -- and the
+    one-wavefront chain (GRAPE_NO_TP=1) on the same inputs."""
+    import torch
+    if chain == "sequential":
+        monkeypatch.setenv("GRAPE_NO_TP", "1")
+    elif chunks:
+        monkeypatch.setenv("GRAPE_TP_CHUNKS", str(chunks))
+    sand = sys_type != "UnitaryGate"
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sand, False, True, seed=11 * n + N)
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N, member_results=True, max_batch=2) as eng:
+        info = eng.info
+        assert info["rank_one_chain"] == 1 and (info["time_chunks"] >= 2) == (chain == "chunked")
+        if chain == "chunked" and chunks:
+            S = -(-(-(-N // chunks)) // 8) * 8
+            assert info["time_chunks"] == -(-N // S)
+        F, G = eng.eval(x)
+        foms, grads = eng.member_results()
+        xs = np.stack([x, 0.3 - x])
+        Fb, Gb = eng.eval_batch(xs)
+        x_dev = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda")
+        fg = torch.zeros(K * N + 1, dtype=torch.float64, device="cuda")
+        eng.eval_device(x_dev.data_ptr(), fg.data_ptr())
+        torch.cuda.synchronize()
+        fg = fg.cpu().numpy()
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.2, per_member=True)
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k}")
+    assert_parity(F, G, F_ref, G_ref, n, what="ensemble")
+    assert_parity(fg[-1], fg[:-1].reshape(N, K).T, F_ref, G_ref, n, what="device entry point")
+    Fr, Gr = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, xs[1], 1.2)
+    assert_parity(Fb[1], Gb[1], Fr, Gr, n, what="batch entry 1")
