@@ -95,7 +95,7 @@ struct grape_ctx {
     double2 *d_tp_q = nullptr, *d_tp_r = nullptr, *d_tp_m = nullptr;   // chunk products, products after each chunk, M_N
     double *d_tp_z = nullptr;
     double2 *d_tp_vec = nullptr;               // rank-one chain: v at every chunk's start, w at its end
-    size_t tp_bytes = 0;
+    size_t tp_cap[5] = {0, 0, 0, 0, 0};        // bytes behind d_tp_q, d_tp_r, d_tp_m, d_tp_vec, d_tp_z
     bool direct_publish = true;                // GRAPE_DIRECT_PUBLISH=0: always go through the reduce kernel
     unsigned long long seq = 0;
     int x_upload = 1;             // 0: hipMemcpyAsync, 1: copy kernel reading the mapped staging buffer,
@@ -809,7 +809,8 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         const long units = (long)c->EU, N = c->cfg.n_slices, slots = 4L * c->compute_units;
         const bool small = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT && !c->d_costates &&
                            2 * units <= slots && !env_on("GRAPE_NO_TP");
-        if (small && herm && !thin && N >= 8) {
+        const bool general = !herm && !thin;                 // non-unitary propagators, full-rank states: prefix AND suffix products
+        if (small && !thin && N >= 8) {
             long s_lat = std::lround(std::sqrt((double)N / 3.0));
             if (s_lat < 2) s_lat = 2;
             long C = std::min(slots / units, (N + s_lat - 1) / s_lat);
@@ -834,22 +835,24 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         }
         if (c->tp_C) {
             const size_t tsz = (size_t)c->NT * c->NT * 256, rows = (size_t)c->EU * c->B;
-            const size_t need = sizeof(double2) * rows * (tsz * (2 * (size_t)c->tp_C + 1) + 32 * (size_t)c->tp_C) +
-                                sizeof(double) * rows * 128;
-            if (c->tp_bytes < need) {
-                (void)hipFree(c->d_tp_q); (void)hipFree(c->d_tp_r); (void)hipFree(c->d_tp_m); (void)hipFree(c->d_tp_z);
-                (void)hipFree(c->d_tp_vec);
-                c->d_tp_q = c->d_tp_r = c->d_tp_m = c->d_tp_vec = nullptr;
-                c->d_tp_z = nullptr;
-                c->bytes += need - c->tp_bytes;
-                c->tp_bytes = 0;
-                HIP_TRY(c, hipMalloc((void **)&c->d_tp_q, sizeof(double2) * rows * tsz * c->tp_C));
-                HIP_TRY(c, hipMalloc((void **)&c->d_tp_r, sizeof(double2) * rows * tsz * c->tp_C));
-                HIP_TRY(c, hipMalloc((void **)&c->d_tp_m, sizeof(double2) * rows * tsz));
-                HIP_TRY(c, hipMalloc((void **)&c->d_tp_vec, sizeof(double2) * rows * 32 * c->tp_C));
-                HIP_TRY(c, hipMalloc((void **)&c->d_tp_z, sizeof(double) * rows * 128));
-                c->tp_bytes = need;
-            }
+            const size_t dumps = (general ? 2 : 1) * (size_t)c->tp_C;     // general flow: [Q_c | Q_c^T] and [R_c | U_c^T]
+            auto ensure = [&](void **ptr, size_t *cap, size_t bytes) -> hipError_t {
+                if (*cap >= bytes)
+                    return hipSuccess;
+                (void)hipFree(*ptr);
+                *ptr = nullptr;
+                c->bytes += bytes - *cap;
+                *cap = 0;
+                const hipError_t e = hipMalloc(ptr, bytes);
+                if (e == hipSuccess)
+                    *cap = bytes;
+                return e;
+            };
+            HIP_TRY(c, ensure((void **)&c->d_tp_q, &c->tp_cap[0], sizeof(double2) * rows * tsz * dumps));
+            HIP_TRY(c, ensure((void **)&c->d_tp_r, &c->tp_cap[1], sizeof(double2) * rows * tsz * dumps));
+            HIP_TRY(c, ensure((void **)&c->d_tp_m, &c->tp_cap[2], sizeof(double2) * rows * tsz));
+            HIP_TRY(c, ensure((void **)&c->d_tp_vec, &c->tp_cap[3], sizeof(double2) * rows * 32 * c->tp_C));
+            HIP_TRY(c, ensure((void **)&c->d_tp_z, &c->tp_cap[4], sizeof(double) * rows * 128));
         }
     }
     if (thin) {
@@ -921,6 +924,11 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.tp_m = c->d_tp_m;
     p.tp_z = c->d_tp_z;
     p.tp_vec = c->d_tp_vec;
+    if (c->tp_C && !c->unitary && !c->thin) {                // general flow: second halves of the dump buffers
+        const size_t half = (size_t)c->EU * c->B * c->tp_C * c->NT * c->NT * 256;
+        p.tp_qt = c->d_tp_q + half;
+        p.tp_u = c->d_tp_r + half;
+    }
     p.sparse = c->sparse_ctrl ? 1 : 0;
     p.sp_coef = c->d_sp_coef;
     p.sp_addr = c->d_sp_addr;

@@ -103,6 +103,8 @@ struct TileParams {
     double2 *tp_q;        // [control array][unit][chunk] chunk products Q_c = P_hi-1 ... P_lo (D-layout dumps)
     double2 *tp_r;        // same shape: R_c = Q_C-1 ... Q_c+1, the product of everything after chunk c
     double2 *tp_m;        // [control array][unit]: M_N
+    double2 *tp_qt;       // general flow only (else null): Q_c^T dumps, and
+    double2 *tp_u;        //   U_c^T, U_c = Q_c-1 ... Q_0 the product of everything before chunk c
     double *tp_z;         // [control array][unit][lane][2]: tr(X_N' L_N) of the lane's member (sandwich); rank-one chain: s
     double2 *tp_vec;      // rank-one chain: [control array][unit][chunk][v at the chunk's start | w at its end], 16 complex each
     int32_t fuse_fwd;     // set by the launcher (thin): one workgroup of prop_tile_kernel walks ALL slices of a member and

@@ -360,18 +360,34 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
     const bool writer = (pack2 ? (lane == 0 || lane == 8) : lane == 0) && member < p.E_members;
     double *__restrict__ out = p.member_out + ((size_t)blockIdx.y * p.E_members + member) * ((size_t)K * N + 1);
 
+    // time-parallel mode (TileParams.tp_chunks, small ensembles): this wavefront owns the slices [t_lo, t_hi); the
+    // state at t_lo is U Xi [U'] with U the product of the chunks before, the costate at t_hi R' Xt [R] with R the
+    // product of the chunks after (chunk_scan_general_kernel)
+    const int C = KEEPL ? 0 : p.tp_chunks;
+    const int t_lo = C ? (int)blockIdx.z * p.tp_S : 0, t_hi = C ? min(N, t_lo + p.tp_S) : N;
     // ------------------------------------------------------------ forward sweep
     {
         TMat<NT> X, Pm, Y;
         TOp<NT> PA;
         TMat<NT> Pn;
         tload(X, ops + (size_t)(1 + 2 * K) * TSZ, lane);           // Xi
-        tload(Pm, Pk, lane);
-        for (int t = 0; t < N; ++t) {
+        if (C) {
+            TMat<NT> Ut;
+            tload(Ut, p.tp_u + (kw * C + blockIdx.z) * TSZ, lane);
+            tmul_tn<NT, false, false>(Y, Ut, X);                   // U Xi
+            X = Y;
+            if (SAND) {
+                to_a_layout(PA, X, s_img, lane);
+                tmul_an<NT, false, true>(Y, PA, Ut);               // (U Xi) U'
+                X = Y;
+            }
+        }
+        tload(Pm, Pk + (size_t)t_lo * TSZ, lane);
+        for (int t = t_lo; t < t_hi; ++t) {
             tstore(Xk + (size_t)t * TSZ, X, lane);
-            if (t + 2 < N)
+            if (t + 2 < t_hi)
                 tload(Pn, Pk + (size_t)(t + 1) * TSZ, lane);       // next slice's P in flight
-            if (t + 1 < N) {                                       // X_N is never read
+            if (t + 1 < t_hi) {                                    // the state after the last slice is never read
                 to_a_layout(PA, Pm, s_img, lane);
                 if (SAND) {
                     tmul_tb<NT, false, false>(Y, X, PA);           // (P X)^T
@@ -389,12 +405,22 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
     TMat<NT> L, Pm, X, Y, R, Pn, Xn;
     TOp<NT> XA, LA;
     tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);               // Xt
+    if (C) {
+        tload(Pm, p.tp_r + (kw * C + blockIdx.z) * TSZ, lane);     // R
+        if (SAND) {
+            tmul_tn<NT, false, true>(Y, L, Pm);                    // (R' Xt)^T
+            tmul_tn<NT, false, false>(L, Y, Pm);                   // R' Xt R
+        } else {
+            tmul_tn<NT, true, false>(Y, Pm, L);                    // R' Xt
+            L = Y;
+        }
+    }
     const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
     double z_keep_r = 0.0, z_keep_i = 0.0;
-    tload(Pm, Pk + (size_t)(N - 1) * TSZ, lane);
-    tload(X, Xk + (size_t)(N - 1) * TSZ, lane);
-    for (int t = N - 1; t >= 0; --t) {
-        if (t > 0) {                                               // next slice's P, X in flight
+    tload(Pm, Pk + (size_t)(t_hi - 1) * TSZ, lane);
+    tload(X, Xk + (size_t)(t_hi - 1) * TSZ, lane);
+    for (int t = t_hi - 1; t >= t_lo; --t) {
+        if (t > t_lo) {                                            // next slice's P, X in flight
             tload(Pn, Pk + (size_t)(t - 1) * TSZ, lane);
             tload(Xn, Xk + (size_t)(t - 1) * TSZ, lane);
         }
@@ -429,7 +455,7 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
         if (SPARSE) {
             // tr(X_t' L_t) does not depend on t, not even for non-unitary P: taken once, at the
             // first slice processed; every lane's share of g[c, t] is then one real number
-            if (t == N - 1) {
+            if (t == t_hi - 1) {
                 double zz[2];
                 tdot_partial<NT, true>(zz[0], zz[1], X, L);
                 wave_sum_n(zz);
@@ -984,8 +1010,50 @@ __global__ __launch_bounds__(64) void chunk_product_kernel(const TileParams p)
         V = Y;
         Pm = Pn;
     }
+    if (p.tp_qt)
+        tstore(p.tp_qt + (kw * C + c) * TSZ, V, lane);             // Q_c^T: the general flow's prefix scan needs Q_c as a left factor
     transpose_via_a_layout(Y, V, s_dynt, lane);
     tstore(p.tp_q + (kw * C + c) * TSZ, Y, lane);
+}
+
+// general (non-unitary) flow: U_c = Q_c-1 ... Q_0 (handed out transposed: a free left factor) and R_c = Q_C-1 ... Q_c+1
+template <int NT>
+__global__ __launch_bounds__(64) void chunk_scan_general_kernel(const TileParams p)
+{
+    constexpr int TSZ = NT * NT * 256;
+    extern __shared__ double2 s_dynt[];
+    const int lane = threadIdx.x, k = blockIdx.x;
+    const int C = p.tp_chunks;
+    const size_t kw = (size_t)blockIdx.y * p.E + k;
+    TMat<NT> V, Y, Q, Qn;
+    {
+        const double2 *__restrict__ Qt = p.tp_qt + kw * C * TSZ;
+        double2 *__restrict__ Uk = p.tp_u + kw * C * TSZ;
+        tidentity(V, lane);                                        // V = U_c
+        tload(Q, Qt, lane);
+        for (int c = 0; c < C; ++c) {
+            tload(Qn, Qt + (size_t)min(c + 1, C - 1) * TSZ, lane);
+            transpose_via_a_layout(Y, V, s_dynt, lane);
+            tstore(Uk + (size_t)c * TSZ, Y, lane);                 // U_c^T
+            tmul_tn<NT, false, false>(Y, Q, V);                    // U_{c+1} = Q_c U_c
+            V = Y;
+            Q = Qn;
+        }
+    }
+    {
+        const double2 *__restrict__ Qk = p.tp_q + kw * C * TSZ;
+        double2 *__restrict__ Rk = p.tp_r + kw * C * TSZ;
+        tidentity(V, lane);                                        // V = R_c^T
+        tload(Q, Qk + (size_t)(C - 1) * TSZ, lane);
+        for (int c = C - 1; c >= 0; --c) {
+            tload(Qn, Qk + (size_t)max(c - 1, 0) * TSZ, lane);
+            transpose_via_a_layout(Y, V, s_dynt, lane);
+            tstore(Rk + (size_t)c * TSZ, Y, lane);                 // R_c
+            tmul_tn<NT, false, false>(Y, Q, V);                    // R_{c-1}^T = Q_c^T R_c^T
+            V = Y;
+            Q = Qn;
+        }
+    }
 }
 
 template <int NT, int SAND, bool PACK2>
@@ -1065,7 +1133,7 @@ static bool tile_chain_env(const char *what)                       // GRAPE_TILE
 bool tile_chain_is_split(const TileParams &p, bool keepl)
 {
     return tile_count(p.n) == 1 && !p.pack2 && !keepl && !p.unitary && !p.thin && p.E < 2048 && p.N >= 4 &&
-           !tile_chain_env("1w");
+           p.tp_chunks < 2 && !tile_chain_env("1w");
 }
 
 // rank-one chain: is the forward vector pass fused into the expm kernel for this launch?  (0 no, 1 yes, 2 ablation:
@@ -1156,21 +1224,24 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         return hipGetLastError();
     }
     // unitary flow, small ensembles: the time axis in chunks (chunk_product_kernel / chunk_scan_kernel above), grid.z = chunk
-    const bool tp = p.tp_chunks > 1 && p.unitary && !keepl;
+    const bool tp = p.tp_chunks > 1 && !keepl;
     q.tp_chunks = tp ? p.tp_chunks : 0;
     const dim3 ugrid(p.E, p.n_x, tp ? p.tp_chunks : 1);
     if (tp) {
         const size_t lds_img = sizeof(double2) * (kTileImage + 1);
+        if (p.unitary)
+            q.tp_qt = nullptr;                                     // only the general flow's prefix scan needs Q_c^T
         hipLaunchKernelGGL((chunk_product_kernel<NT>), ugrid, block, lds_img, stream, q);
-        if (sandwich) { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, NT == 1>), grid, block, lds_img, stream, q);
-                        else    hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, false>), grid, block, lds_img, stream, q); }
-        else          { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 0, NT == 1>), grid, block, lds_img, stream, q);
-                        else    hipLaunchKernelGGL((chunk_scan_kernel<NT, 0, false>), grid, block, lds_img, stream, q); }
+        if (!p.unitary)  hipLaunchKernelGGL((chunk_scan_general_kernel<NT>), grid, block, lds_img, stream, q);
+        else if (sandwich) { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, NT == 1>), grid, block, lds_img, stream, q);
+                             else    hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, false>), grid, block, lds_img, stream, q); }
+        else               { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 0, NT == 1>), grid, block, lds_img, stream, q);
+                             else    hipLaunchKernelGGL((chunk_scan_kernel<NT, 0, false>), grid, block, lds_img, stream, q); }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return e;
     }
-#define GRAPE_LAUNCH_CHAIN(KERNEL) hipLaunchKernelGGL(KERNEL, grid, block, lds, stream, q)
+#define GRAPE_LAUNCH_CHAIN(KERNEL) hipLaunchKernelGGL(KERNEL, ugrid, block, lds, stream, q)
 #define GRAPE_LAUNCH_UNI(KERNEL) hipLaunchKernelGGL(KERNEL, ugrid, block, lds, stream, q)
     if (p.unitary && !keepl && p.sparse && !pk) {
         // image for layout conversions | coefficients | image of M | positions
@@ -1184,7 +1255,7 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     } else if (p.sparse && !pk) {
         const size_t lds_sp = sizeof(double2) * (kTileImage + 1 + (size_t)p.K * kSparseMax + 16 * NT * (16 * NT + 1)) +
                               sizeof(int32_t) * (size_t)p.K * kSparseMax;
-#define GRAPE_LAUNCH_SP(KERNEL) hipLaunchKernelGGL(KERNEL, grid, block, lds_sp, stream, q)
+#define GRAPE_LAUNCH_SP(KERNEL) hipLaunchKernelGGL(KERNEL, ugrid, block, lds_sp, stream, q)
         if (sandwich) { if (keepl) GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 1, true, false, true>)); else GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 1, false, false, true>)); }
         else          { if (keepl) GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 0, true, false, true>)); else GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 0, false, false, true>)); }
 #undef GRAPE_LAUNCH_SP
