@@ -164,7 +164,7 @@ typedef struct grape_info {
     int32_t fused_forward;         /* rank-one chain, single evaluations: 1 when the forward vector pass runs inside the
                                       expm kernel (ensembles of at least 2 x compute_units members), so every propagator is
                                       read from HBM once instead of twice */
-    int32_t time_chunks;           /* n = 5..32, Hermitian generators or rank-one states, fewer members than wavefront slots: the time axis
+    int32_t time_chunks;           /* n = 5..32, fewer members than wavefront slots: the time axis
                                       of every member is cut into this many chunks evaluated in parallel (0 = one
                                       wavefront walks all slices) */
 } grape_info;

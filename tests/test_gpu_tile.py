@@ -272,3 +272,32 @@ def test_c5_controls_are_sparse(qoc):
     w = qoc.workloads.config("C5", E=2)
     with _engine(qoc, w) as eng:
         assert eng.info["sparse_controls"] == 1
+
+
+@pytest.mark.parametrize("n,sys_type,E,N,chunks", [(6, "StateTransfer", 4, 40, 0), (8, "UnitaryGate", 1, 64, 7),
+                                                   (12, "CoherenceTransfer", 3, 37, 5), (16, "UnitaryGate", 1, 200, 0),
+                                                   (16, "StateTransfer", 2, 100, 9), (20, "StateTransfer", 1, 33, 4),
+                                                   (32, "UnitaryGate", 2, 48, 0)])
+@pytest.mark.parametrize("chain", ["chunked", "sequential"])
+def test_general_flow_time_chunks(qoc, oracle, monkeypatch, n, sys_type, E, N, chunks, chain):
+    """Non-Hermitian generators with full-rank states (the general flow: forward states stored, costates pulled back):
+    small ensembles cut the time axis into chunks between the prefix and suffix products of the chunk products;
+    pair-packed members, ragged chunks, 32 x 32 tiles, and the sequential chains (GRAPE_NO_TP=1) on the same inputs."""
+    if chain == "sequential":
+        monkeypatch.setenv("GRAPE_NO_TP", "1")
+    elif chunks:
+        monkeypatch.setenv("GRAPE_TP_CHUNKS", str(chunks))
+    w = _random_problem(qoc, n, 3, N, E, sys_type, seed=500 + n + N, hermitian=False, mixed=True)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, per_member=True)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, member_results=True, max_batch=2) as eng:
+        info = eng.info
+        assert info["unitary_flow"] == 0 and info["rank_one_chain"] == 0 and (info["time_chunks"] >= 2) == (chain == "chunked")
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+        xs = np.stack([w.x, 0.2 - 0.5 * w.x])
+        Fb, Gb = eng.eval_batch(xs)
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k}")
+    assert_parity(F, G, F_ref, G_ref, n, what="ensemble")
+    Fr, Gr = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, xs[1], w.T)
+    assert_parity(Fb[1], Gb[1], Fr, Gr, n, what="batch entry 1")
