@@ -807,8 +807,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // its chunks start at multiples of 8 slices (the vector formats and prefetch rings follow the slice index).
         c->tp_C = c->tp_S = 0;
         const long units = (long)c->EU, N = c->cfg.n_slices, slots = 4L * c->compute_units;
-        const bool small = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT && !c->d_costates &&
-                           2 * units <= slots && !env_on("GRAPE_NO_TP");
+        const bool small = c->family == 1 && 2 * units <= slots && !env_on("GRAPE_NO_TP");
         const bool general = !herm && !thin;                 // non-unitary propagators, full-rank states: prefix AND suffix products
         if (small && !thin && N >= 8) {
             long s_lat = std::lround(std::sqrt((double)N / 3.0));

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
     // time-parallel mode (TileParams.tp_chunks, small ensembles): this wavefront owns the slices [t_lo, t_hi); the
     // state at t_lo is U Xi [U'] with U the product of the chunks before, the costate at t_hi R' Xt [R] with R the
     // product of the chunks after (chunk_scan_general_kernel)
-    const int C = KEEPL ? 0 : p.tp_chunks;
+    const int C = p.tp_chunks;
     const int t_lo = C ? (int)blockIdx.z * p.tp_S : 0, t_hi = C ? min(N, t_lo + p.tp_S) : N;
     // ------------------------------------------------------------ forward sweep
     {
@@ -1224,7 +1224,7 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         return hipGetLastError();
     }
     // unitary flow, small ensembles: the time axis in chunks (chunk_product_kernel / chunk_scan_kernel above), grid.z = chunk
-    const bool tp = p.tp_chunks > 1 && !keepl;
+    const bool tp = p.tp_chunks > 1 && !(keepl && p.unitary);      // (stored costates always come with the general flow)
     q.tp_chunks = tp ? p.tp_chunks : 0;
     const dim3 ugrid(p.E, p.n_x, tp ? p.tp_chunks : 1);
     if (tp) {
