@@ -264,7 +264,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the device-resident loop and the extra configs")
-    ap.add_argument("--extra-configs", default="C2,C4,C4dense,C5,C5x1")
+    ap.add_argument("--extra-configs", default="C2,C4,C4dense,C5,C5x1,C4x1")
     ap.add_argument("--backend", default="",
                     help="torch.distributed backend; default: gloo as the control plane when the data-path collective "
                          "is RCCL inside the library (--collective lib), cpu:gloo,cuda:nccl for --collective torch")
@@ -449,7 +449,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra and args.extra_configs:
         out["extra_configs"] = []
         for name in [s for s in args.extra_configs.split(",") if s and s != args.config]:
-            heavy = name in ("C4", "C4dense", "C5", "C5x1")
+            heavy = name in ("C4", "C4dense", "C5")
             try:
                 out["extra_configs"].append(run_extra_config(qoc, name, dev_index, 3 if name == "C5" else (20 if heavy else 200),
                                                              1 if name == "C5" else (3 if heavy else 20)))
