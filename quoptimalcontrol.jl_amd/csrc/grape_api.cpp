@@ -819,7 +819,8 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                 c->tp_S = (int)((N + C - 1) / C);
                 c->tp_C = (int)((N + c->tp_S - 1) / c->tp_S);
             }
-        } else if (small && thin && N >= 32 && 2 * units < slots) {      // (from half a device on, the fused forward pass)
+        } else if (small && thin && N >= 32 && 4 * units < slots) {      // C4's shape: 128 members 1.18 -> 0.87 ms, 256 members 1.39 -> 1.53
+                                                                          // (and from half a device on, the fused forward pass)
             // measured optimum at C4's shape (N = 1000): 16..32 slices per chunk for 1..16 members (tools/single_open.py)
             long s_lat = 8 * std::max(1L, std::lround(std::sqrt(0.6 * (double)N) / 8.0));
             long C = std::min(slots / units, (N + s_lat - 1) / s_lat);
