@@ -16,7 +16,7 @@ stats() {   # name, env, bench args...
   f=$(find /tmp/st_$name -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${name}_kernel_stats.csv"
 }
-stats C3_E1024 GRAPE_X=0 --steps 30 --warmup 5
+stats C3_E1024 GRAPE_X=0 --steps 400 --warmup 50    # (a 36-launch run averages the cold first launches in: 78 us)
 stats C4_E1024 GRAPE_X=0 --config C4 --steps 8 --warmup 2
 stats C4dense_E1024 GRAPE_NO_THIN=1 --config C4 --steps 8 --warmup 2
 stats C5_E4096 GRAPE_X=0 --config C5 --steps 2 --warmup 1
