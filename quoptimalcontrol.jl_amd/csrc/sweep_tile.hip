@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(64) void chunk_scan_general_kernel(const TileParams
     const int C = p.tp_chunks;
     const size_t kw = (size_t)blockIdx.y * p.E + k;
     TMat<NT> V, Y, Q, Qn;
-    {
+    if (blockIdx.z == 0) {                                         // the two scans are independent: one wavefront each
         const double2 *__restrict__ Qt = p.tp_qt + kw * C * TSZ;
         double2 *__restrict__ Uk = p.tp_u + kw * C * TSZ;
         tidentity(V, lane);                                        // V = U_c
@@ -1039,8 +1039,7 @@ __global__ __launch_bounds__(64) void chunk_scan_general_kernel(const TileParams
             V = Y;
             Q = Qn;
         }
-    }
-    {
+    } else {
         const double2 *__restrict__ Qk = p.tp_q + kw * C * TSZ;
         double2 *__restrict__ Rk = p.tp_r + kw * C * TSZ;
         tidentity(V, lane);                                        // V = R_c^T
@@ -1232,7 +1231,7 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         if (p.unitary)
             q.tp_qt = nullptr;                                     // only the general flow's prefix scan needs Q_c^T
         hipLaunchKernelGGL((chunk_product_kernel<NT>), ugrid, block, lds_img, stream, q);
-        if (!p.unitary)  hipLaunchKernelGGL((chunk_scan_general_kernel<NT>), grid, block, lds_img, stream, q);
+        if (!p.unitary)  hipLaunchKernelGGL((chunk_scan_general_kernel<NT>), dim3(p.E, p.n_x, 2), block, lds_img, stream, q);
         else if (sandwich) { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, NT == 1>), grid, block, lds_img, stream, q);
                              else    hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, false>), grid, block, lds_img, stream, q); }
         else               { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 0, NT == 1>), grid, block, lds_img, stream, q);
