@@ -95,7 +95,9 @@ struct grape_ctx {
     double2 *d_tp_q = nullptr, *d_tp_r = nullptr, *d_tp_m = nullptr;   // chunk products, products after each chunk, M_N
     double *d_tp_z = nullptr;
     double2 *d_tp_vec = nullptr;               // rank-one chain: v at every chunk's start, w at its end
-    size_t tp_cap[5] = {0, 0, 0, 0, 0};        // bytes behind d_tp_q, d_tp_r, d_tp_m, d_tp_vec, d_tp_z
+    size_t tp_cap[6] = {0, 0, 0, 0, 0, 0};     // bytes behind d_tp_q, d_tp_r, d_tp_m, d_tp_vec, d_tp_z, d_tp_a
+    int tp_G = 0, tp_g = 0;                    // two-level scan: groups, chunks per group
+    double2 *d_tp_a = nullptr;
     bool direct_publish = true;                // GRAPE_DIRECT_PUBLISH=0: always go through the reduce kernel
     unsigned long long seq = 0;
     int x_upload = 1;             // 0: hipMemcpyAsync, 1: copy kernel reading the mapped staging buffer,
@@ -238,7 +240,7 @@ static void free_all(grape_ctx *c)
     (void)hipFree(c->d_done_counter);
     (void)hipFree(c->d_vecs);
     (void)hipFree(c->d_sp_coef); (void)hipFree(c->d_sp_addr);
-    (void)hipFree(c->d_tp_q); (void)hipFree(c->d_tp_r); (void)hipFree(c->d_tp_m); (void)hipFree(c->d_tp_z); (void)hipFree(c->d_tp_vec);
+    (void)hipFree(c->d_tp_q); (void)hipFree(c->d_tp_r); (void)hipFree(c->d_tp_m); (void)hipFree(c->d_tp_z); (void)hipFree(c->d_tp_vec); (void)hipFree(c->d_tp_a);
     (void)hipFree(c->d_x_bar);
     delete c;
 }
@@ -805,13 +807,18 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // Unitary flow: 3 S + C dependent products per evaluation (S slices per chunk, C chunks) instead of 3 N.
         // Rank-one chain: S dense chunk-product steps + 2 S vector steps + 2 C scan steps instead of 2 N vector steps;
         // its chunks start at multiples of 8 slices (the vector formats and prefetch rings follow the slice index).
-        c->tp_C = c->tp_S = 0;
+        c->tp_C = c->tp_S = c->tp_G = c->tp_g = 0;
         const long units = (long)c->EU, N = c->cfg.n_slices, slots = 4L * c->compute_units;
         const bool small = c->family == 1 && 2 * units <= slots && !env_on("GRAPE_NO_TP");
         const bool general = !herm && !thin;                 // non-unitary propagators, full-rank states: prefix AND suffix products
         if (small && !thin && N >= 8) {
-            long s_lat = std::lround(std::sqrt((double)N / 3.0));
+            // slices per chunk at the latency optimum: one-level scan 3 S + N / S dependent products (general flow),
+            // two-level scan (unitary flow) 3 S + 2 sqrt(N / S); measured optima (tools/tp_sweep.py): 32 x 32, N = 2000:
+            // 12 slices, 16 x 16, N = 1000: 4..5
+            long s_lat = general ? std::lround(std::sqrt((double)N / 3.0))
+                                 : std::lround(std::cbrt((double)N / 9.0) * (c->NT == 2 ? 2.0 : 1.0));
             if (s_lat < 2) s_lat = 2;
+            if (!general && s_lat < 4 && N >= 64 && !env_on("GRAPE_TP_ONE_LEVEL")) s_lat = 4;
             long C = std::min(slots / units, (N + s_lat - 1) / s_lat);
             if (const char *e = std::getenv("GRAPE_TP_CHUNKS")) C = std::atol(e);
             if (C > N / 2) C = N / 2;
@@ -853,6 +860,13 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             HIP_TRY(c, ensure((void **)&c->d_tp_m, &c->tp_cap[2], sizeof(double2) * rows * tsz));
             HIP_TRY(c, ensure((void **)&c->d_tp_vec, &c->tp_cap[3], sizeof(double2) * rows * 32 * c->tp_C));
             HIP_TRY(c, ensure((void **)&c->d_tp_z, &c->tp_cap[4], sizeof(double) * rows * 128));
+            // unitary flow, many chunks: two-level scan over groups of ~sqrt(C) chunks
+            c->tp_G = c->tp_g = 0;
+            if (herm && !thin && c->tp_C >= 16 && !env_on("GRAPE_TP_ONE_LEVEL")) {
+                c->tp_g = (int)std::lround(std::ceil(std::sqrt((double)c->tp_C)));
+                c->tp_G = (c->tp_C + c->tp_g - 1) / c->tp_g;
+                HIP_TRY(c, ensure((void **)&c->d_tp_a, &c->tp_cap[5], sizeof(double2) * rows * tsz * 2 * c->tp_G));
+            }
         }
     }
     if (thin) {
@@ -924,6 +938,9 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.tp_m = c->d_tp_m;
     p.tp_z = c->d_tp_z;
     p.tp_vec = c->d_tp_vec;
+    p.tp_groups = c->tp_C ? c->tp_G : 0;
+    p.tp_gsize = c->tp_g;
+    p.tp_a = c->d_tp_a;
     if (c->tp_C && !c->unitary && !c->thin) {                // general flow: second halves of the dump buffers
         const size_t half = (size_t)c->EU * c->B * c->tp_C * c->NT * c->NT * 256;
         p.tp_qt = c->d_tp_q + half;

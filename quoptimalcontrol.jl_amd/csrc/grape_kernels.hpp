@@ -103,6 +103,10 @@ struct TileParams {
     double2 *tp_q;        // [control array][unit][chunk] chunk products Q_c = P_hi-1 ... P_lo (D-layout dumps)
     double2 *tp_r;        // same shape: R_c = Q_C-1 ... Q_c+1, the product of everything after chunk c
     double2 *tp_m;        // [control array][unit]: M_N
+    // unitary flow, many chunks: two-level scan.  Groups of tp_gsize consecutive chunks; tp_r then holds the product of
+    // the chunks after c INSIDE its group, tp_a the product of the groups after group j (tp_groups of them; 0 = one level)
+    int32_t tp_groups, tp_gsize;
+    double2 *tp_a;        // [control array][unit][group]: A_j, followed by the group products themselves (scan input)
     double2 *tp_qt;       // general flow only (else null): Q_c^T dumps, and
     double2 *tp_u;        //   U_c^T, U_c = Q_c-1 ... Q_0 the product of everything before chunk c
     double *tp_z;         // [control array][unit][lane][2]: tr(X_N' L_N) of the lane's member (sandwich); rank-one chain: s

@@ -803,6 +803,11 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
             zr = p.tp_z[(kw * 64 + lane) * 2];
             zi = p.tp_z[(kw * 64 + lane) * 2 + 1];
         }
+        if (p.tp_groups) {                                         // two-level scan: R = A_group R_local
+            tload(Pm, p.tp_a + (kw * p.tp_groups + blockIdx.z / p.tp_gsize) * TSZ, lane);
+            tmul_tn<NT, false, true>(Y, M, Pm);
+            tmul_tn<NT, false, false>(M, Y, Pm);                   // A' M_N A
+        }
         tload(Pm, p.tp_r + (kw * C + blockIdx.z) * TSZ, lane);
         tmul_tn<NT, false, true>(Y, M, Pm);                        // (R' M)^T
         tmul_tn<NT, false, false>(M, Y, Pm);                       // R' M R
@@ -1055,6 +1060,35 @@ __global__ __launch_bounds__(64) void chunk_scan_general_kernel(const TileParams
     }
 }
 
+// two-level scan (many chunks): one wavefront per GROUP of tp_gsize consecutive chunks forms, for every chunk, the
+// product of the chunks after it inside the group, and the group's own product; chunk_scan_kernel then runs over the
+// groups instead of the chunks (2 sqrt(C) dependent products instead of C)
+template <int NT>
+__global__ __launch_bounds__(64) void chunk_scan_group_kernel(const TileParams p)
+{
+    constexpr int TSZ = NT * NT * 256;
+    extern __shared__ double2 s_dynt[];
+    const int lane = threadIdx.x, k = blockIdx.x, j = blockIdx.z;
+    const int C = p.tp_chunks, G = p.tp_groups;
+    const size_t kw = (size_t)blockIdx.y * p.E + k;
+    const double2 *__restrict__ Qk = p.tp_q + kw * C * TSZ;
+    double2 *__restrict__ Rk = p.tp_r + kw * C * TSZ;
+    const int c_lo = j * p.tp_gsize, c_hi = min(C, c_lo + p.tp_gsize);
+    TMat<NT> V, Y, Q, Qn;
+    tidentity(V, lane);
+    tload(Q, Qk + (size_t)(c_hi - 1) * TSZ, lane);
+    for (int c = c_hi - 1; c >= c_lo; --c) {
+        tload(Qn, Qk + (size_t)max(c - 1, 0) * TSZ, lane);
+        transpose_via_a_layout(Y, V, s_dynt, lane);
+        tstore(Rk + (size_t)c * TSZ, Y, lane);                     // product of the chunks after c inside the group
+        tmul_tn<NT, false, false>(Y, Q, V);
+        V = Y;
+        Q = Qn;
+    }
+    transpose_via_a_layout(Y, V, s_dynt, lane);
+    tstore(p.tp_a + ((kw + (size_t)gridDim.y * p.E) * G + j) * TSZ, Y, lane);   // the group's product, behind the A_j block
+}
+
 template <int NT, int SAND, bool PACK2>
 __global__ __launch_bounds__(64) void chunk_scan_kernel(const TileParams p)
 {
@@ -1230,12 +1264,23 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         const size_t lds_img = sizeof(double2) * (kTileImage + 1);
         if (p.unitary)
             q.tp_qt = nullptr;                                     // only the general flow's prefix scan needs Q_c^T
+        else
+            q.tp_groups = 0;                                       // (the two-level scan serves the unitary flow)
         hipLaunchKernelGGL((chunk_product_kernel<NT>), ugrid, block, lds_img, stream, q);
         if (!p.unitary)  hipLaunchKernelGGL((chunk_scan_general_kernel<NT>), dim3(p.E, p.n_x, 2), block, lds_img, stream, q);
-        else if (sandwich) { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, NT == 1>), grid, block, lds_img, stream, q);
-                             else    hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, false>), grid, block, lds_img, stream, q); }
-        else               { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 0, NT == 1>), grid, block, lds_img, stream, q);
-                             else    hipLaunchKernelGGL((chunk_scan_kernel<NT, 0, false>), grid, block, lds_img, stream, q); }
+        else {
+            TileParams s2 = q;                                     // what the serial scan runs over: chunks, or groups of chunks
+            if (q.tp_groups) {
+                hipLaunchKernelGGL((chunk_scan_group_kernel<NT>), dim3(p.E, p.n_x, q.tp_groups), block, lds_img, stream, q);
+                s2.tp_chunks = q.tp_groups;
+                s2.tp_q = q.tp_a + (size_t)p.n_x * p.E * q.tp_groups * NT * NT * 256;
+                s2.tp_r = q.tp_a;
+            }
+            if (sandwich) { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, NT == 1>), grid, block, lds_img, stream, s2);
+                            else    hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, false>), grid, block, lds_img, stream, s2); }
+            else          { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 0, NT == 1>), grid, block, lds_img, stream, s2);
+                            else    hipLaunchKernelGGL((chunk_scan_kernel<NT, 0, false>), grid, block, lds_img, stream, s2); }
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return e;
