@@ -40,6 +40,10 @@ import subprocess
 import sys
 import time
 
+# the CPU baseline's OpenMP workers must not spin after their parallel region: the latency-bound lines that follow
+# (L-BFGS iterations per second, single problems) poll a host flag and were seen 3x slower next to spinning threads
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
