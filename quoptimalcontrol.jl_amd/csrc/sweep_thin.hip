@@ -464,6 +464,7 @@ __global__ __launch_bounds__(64) void chunk_scan_thin_kernel(const TileParams p)
     double2 *__restrict__ vec = p.tp_vec + kw * C * 32;
     const double2 *__restrict__ v0 = p.vecs + (size_t)k * 32, *__restrict__ wT = v0 + 16;
     Tile1 Q, Qn;
+    if (blockIdx.z == 0) {                                          // the two scans are independent: one wavefront each
     // forward: v at every chunk start (per-column: lane holds v[c]);  reg r of the dump = Q[4r + g][c]
     double2 v = v0[c];
     load_tile(Q, Qk, lane);
@@ -503,6 +504,8 @@ __global__ __launch_bounds__(64) void chunk_scan_thin_kernel(const TileParams p)
             p.tp_z[kw * 128] = s_re;
             p.tp_z[kw * 128 + 1] = s_im;
         }
+    }
+    return;
     }
     // backward: w at every chunk end;  (Q' w)[c] = sum_i conj(Q[i][c]) w[i]
     double2 w = wT[c];
@@ -548,7 +551,7 @@ hipError_t launch_chain_thin(int sandwich, const TileParams &p, hipStream_t stre
     if (q.tp_chunks > 1 && !q.fuse_fwd) {
         const dim3 cgrid(p.E, p.n_x, p.tp_chunks);
         hipLaunchKernelGGL(chunk_product_thin_kernel, cgrid, dim3(64), sizeof(double2) * (kTileImage + 1), stream, q);
-        hipLaunchKernelGGL(chunk_scan_thin_kernel, dim3(p.E, p.n_x), dim3(64), 0, stream, q);
+        hipLaunchKernelGGL(chunk_scan_thin_kernel, dim3(p.E, p.n_x, 2), dim3(64), 0, stream, q);
     } else {
         q.tp_chunks = 0;
     }
