@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(64) void chunk_scan_general_kernel(const TileParams
     const int lane = threadIdx.x, k = blockIdx.x;
     const int C = p.tp_chunks;
     const size_t kw = (size_t)blockIdx.y * p.E + k;
-    TMat<NT> V, Y, Q, Qn;
+    TMat<NT> V, Y, T, Q, Qn;
     if (blockIdx.z == 0) {                                         // the two scans are independent: one wavefront each
         const double2 *__restrict__ Qt = p.tp_qt + kw * C * TSZ;
         double2 *__restrict__ Uk = p.tp_u + kw * C * TSZ;
@@ -1038,9 +1038,9 @@ __global__ __launch_bounds__(64) void chunk_scan_general_kernel(const TileParams
         tload(Q, Qt, lane);
         for (int c = 0; c < C; ++c) {
             tload(Qn, Qt + (size_t)min(c + 1, C - 1) * TSZ, lane);
-            transpose_via_a_layout(Y, V, s_dynt, lane);
-            tstore(Uk + (size_t)c * TSZ, Y, lane);                 // U_c^T
             tmul_tn<NT, false, false>(Y, Q, V);                    // U_{c+1} = Q_c U_c
+            transpose_via_a_layout(T, V, s_dynt, lane);
+            tstore(Uk + (size_t)c * TSZ, T, lane);                 // U_c^T
             V = Y;
             Q = Qn;
         }
@@ -1051,9 +1051,9 @@ __global__ __launch_bounds__(64) void chunk_scan_general_kernel(const TileParams
         tload(Q, Qk + (size_t)(C - 1) * TSZ, lane);
         for (int c = C - 1; c >= 0; --c) {
             tload(Qn, Qk + (size_t)max(c - 1, 0) * TSZ, lane);
-            transpose_via_a_layout(Y, V, s_dynt, lane);
-            tstore(Rk + (size_t)c * TSZ, Y, lane);                 // R_c
             tmul_tn<NT, false, false>(Y, Q, V);                    // R_{c-1}^T = Q_c^T R_c^T
+            transpose_via_a_layout(T, V, s_dynt, lane);
+            tstore(Rk + (size_t)c * TSZ, T, lane);                 // R_c
             V = Y;
             Q = Qn;
         }
@@ -1074,14 +1074,14 @@ __global__ __launch_bounds__(64) void chunk_scan_group_kernel(const TileParams p
     const double2 *__restrict__ Qk = p.tp_q + kw * C * TSZ;
     double2 *__restrict__ Rk = p.tp_r + kw * C * TSZ;
     const int c_lo = j * p.tp_gsize, c_hi = min(C, c_lo + p.tp_gsize);
-    TMat<NT> V, Y, Q, Qn;
+    TMat<NT> V, Y, T, Q, Qn;
     tidentity(V, lane);
     tload(Q, Qk + (size_t)(c_hi - 1) * TSZ, lane);
     for (int c = c_hi - 1; c >= c_lo; --c) {
         tload(Qn, Qk + (size_t)max(c - 1, 0) * TSZ, lane);
-        transpose_via_a_layout(Y, V, s_dynt, lane);
-        tstore(Rk + (size_t)c * TSZ, Y, lane);                     // product of the chunks after c inside the group
-        tmul_tn<NT, false, false>(Y, Q, V);
+        tmul_tn<NT, false, false>(Y, Q, V);                        // issued first: the conversion below runs while the matrix cores work
+        transpose_via_a_layout(T, V, s_dynt, lane);
+        tstore(Rk + (size_t)c * TSZ, T, lane);                     // product of the chunks after c inside the group
         V = Y;
         Q = Qn;
     }
@@ -1101,14 +1101,14 @@ __global__ __launch_bounds__(64) void chunk_scan_kernel(const TileParams p)
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
     const double2 *__restrict__ Qk = p.tp_q + kw * C * TSZ;
     double2 *__restrict__ Rk = p.tp_r + kw * C * TSZ;
-    TMat<NT> V, Y, Q, Qn;
+    TMat<NT> V, Y, T, Q, Qn;
     tidentity(V, lane);                                            // V = R_c^T, from the last chunk down
     tload(Q, Qk + (size_t)(C - 1) * TSZ, lane);
     for (int c = C - 1; c >= 0; --c) {
         tload(Qn, Qk + (size_t)max(c - 1, 0) * TSZ, lane);
-        transpose_via_a_layout(Y, V, s_img, lane);
-        tstore(Rk + (size_t)c * TSZ, Y, lane);                     // R_c
-        tmul_tn<NT, false, false>(Y, Q, V);                        // R_{c-1}^T = Q_c^T R_c^T
+        tmul_tn<NT, false, false>(Y, Q, V);                        // R_{c-1}^T = Q_c^T R_c^T (issued first: the conversion overlaps it)
+        transpose_via_a_layout(T, V, s_img, lane);
+        tstore(Rk + (size_t)c * TSZ, T, lane);                     // R_c
         V = Y;
         Q = Qn;
     }
