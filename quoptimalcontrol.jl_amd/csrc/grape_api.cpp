@@ -815,10 +815,12 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             // slices per chunk at the latency optimum: one-level scan 3 S + N / S dependent products (general flow),
             // two-level scan (unitary flow) 3 S + 2 sqrt(N / S); measured optima (tools/tp_sweep.py): 32 x 32, N = 2000:
             // 12 slices, 16 x 16, N = 1000: 4..5
-            long s_lat = general ? std::lround(std::sqrt((double)N / 3.0))
+            // general flow (a slice costs ~6 products there): (0.17 sqrt N)^(2/3), 4 at N = 1000
+            long s_lat = general ? std::lround(std::pow(0.17 * std::sqrt((double)N), 2.0 / 3.0))
                                  : std::lround(std::cbrt((double)N / 9.0) * (c->NT == 2 ? 2.0 : 1.0));
+            if (env_on("GRAPE_TP_ONE_LEVEL")) s_lat = std::lround(std::sqrt((double)N / 3.0));
             if (s_lat < 2) s_lat = 2;
-            if (!general && s_lat < 4 && N >= 64 && !env_on("GRAPE_TP_ONE_LEVEL")) s_lat = 4;
+            if (s_lat < 4 && N >= 64 && !env_on("GRAPE_TP_ONE_LEVEL")) s_lat = 4;
             long C = std::min(slots / units, (N + s_lat - 1) / s_lat);
             if (const char *e = std::getenv("GRAPE_TP_CHUNKS")) C = std::atol(e);
             if (C > N / 2) C = N / 2;
@@ -862,10 +864,10 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             HIP_TRY(c, ensure((void **)&c->d_tp_z, &c->tp_cap[4], sizeof(double) * rows * 128));
             // unitary flow, many chunks: two-level scan over groups of ~sqrt(C) chunks
             c->tp_G = c->tp_g = 0;
-            if (herm && !thin && c->tp_C >= 16 && !env_on("GRAPE_TP_ONE_LEVEL")) {
+            if (!thin && c->tp_C >= 16 && !env_on("GRAPE_TP_ONE_LEVEL")) {
                 c->tp_g = (int)std::lround(std::ceil(std::sqrt((double)c->tp_C)));
                 c->tp_G = (c->tp_C + c->tp_g - 1) / c->tp_g;
-                HIP_TRY(c, ensure((void **)&c->d_tp_a, &c->tp_cap[5], sizeof(double2) * rows * tsz * 2 * c->tp_G));
+                HIP_TRY(c, ensure((void **)&c->d_tp_a, &c->tp_cap[5], sizeof(double2) * rows * tsz * (general ? 4 : 2) * c->tp_G));
             }
         }
     }

@@ -373,14 +373,19 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
         tload(X, ops + (size_t)(1 + 2 * K) * TSZ, lane);           // Xi
         if (C) {
             TMat<NT> Ut;
-            tload(Ut, p.tp_u + (kw * C + blockIdx.z) * TSZ, lane);
-            tmul_tn<NT, false, false>(Y, Ut, X);                   // U Xi
-            X = Y;
-            if (SAND) {
-                to_a_layout(PA, X, s_img, lane);
-                tmul_an<NT, false, true>(Y, PA, Ut);               // (U Xi) U'
+            auto apply = [&](const double2 *__restrict__ src) {    // X <- U X [U'],  src = the D-layout dump of U^T
+                tload(Ut, src, lane);
+                tmul_tn<NT, false, false>(Y, Ut, X);
                 X = Y;
-            }
+                if (SAND) {
+                    to_a_layout(PA, X, s_img, lane);
+                    tmul_an<NT, false, true>(Y, PA, Ut);
+                    X = Y;
+                }
+            };
+            if (p.tp_groups)                                       // two-level scan: U = U_local B_group
+                apply(p.tp_a + ((2 * (size_t)gridDim.y * p.E + kw) * p.tp_groups + blockIdx.z / p.tp_gsize) * TSZ);
+            apply(p.tp_u + (kw * C + blockIdx.z) * TSZ);
         }
         tload(Pm, Pk + (size_t)t_lo * TSZ, lane);
         for (int t = t_lo; t < t_hi; ++t) {
@@ -406,14 +411,19 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
     TOp<NT> XA, LA;
     tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);               // Xt
     if (C) {
-        tload(Pm, p.tp_r + (kw * C + blockIdx.z) * TSZ, lane);     // R
-        if (SAND) {
-            tmul_tn<NT, false, true>(Y, L, Pm);                    // (R' Xt)^T
-            tmul_tn<NT, false, false>(L, Y, Pm);                   // R' Xt R
-        } else {
-            tmul_tn<NT, true, false>(Y, Pm, L);                    // R' Xt
-            L = Y;
-        }
+        auto pull = [&](const double2 *__restrict__ src) {         // L <- R' L [R]
+            tload(Pm, src, lane);
+            if (SAND) {
+                tmul_tn<NT, false, true>(Y, L, Pm);
+                tmul_tn<NT, false, false>(L, Y, Pm);
+            } else {
+                tmul_tn<NT, true, false>(Y, Pm, L);
+                L = Y;
+            }
+        };
+        if (p.tp_groups)                                           // two-level scan: R = A_group R_local
+            pull(p.tp_a + (kw * p.tp_groups + blockIdx.z / p.tp_gsize) * TSZ);
+        pull(p.tp_r + (kw * C + blockIdx.z) * TSZ);
     }
     const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
     double z_keep_r = 0.0, z_keep_i = 0.0;
@@ -1021,8 +1031,12 @@ __global__ __launch_bounds__(64) void chunk_product_kernel(const TileParams p)
     tstore(p.tp_q + (kw * C + c) * TSZ, Y, lane);
 }
 
-// general (non-unitary) flow: U_c = Q_c-1 ... Q_0 (handed out transposed: a free left factor) and R_c = Q_C-1 ... Q_c+1
-template <int NT>
+// general (non-unitary) flow: U_c = Q_c-1 ... Q_0 (handed out transposed: a free left factor) and R_c = Q_C-1 ... Q_c+1,
+// one wavefront per direction.  GROUPS: the two-level form -- blockIdx.z >> 1 is a group of tp_gsize consecutive chunks,
+// the products stay inside the group, and the suffix wavefront also hands out the group's own product (plain and
+// transposed: the scan over the groups is this kernel again, without GROUPS, on those).
+// tp_a, in blocks of (control arrays x units x groups) tiles: [A_j | group products | B_j^T | group products transposed]
+template <int NT, bool GROUPS>
 __global__ __launch_bounds__(64) void chunk_scan_general_kernel(const TileParams p)
 {
     constexpr int TSZ = NT * NT * 256;
@@ -1030,13 +1044,15 @@ __global__ __launch_bounds__(64) void chunk_scan_general_kernel(const TileParams
     const int lane = threadIdx.x, k = blockIdx.x;
     const int C = p.tp_chunks;
     const size_t kw = (size_t)blockIdx.y * p.E + k;
+    const int j = (int)blockIdx.z >> 1;
+    const int c_lo = GROUPS ? j * p.tp_gsize : 0, c_hi = GROUPS ? min(C, c_lo + p.tp_gsize) : C;
     TMat<NT> V, Y, T, Q, Qn;
-    if (blockIdx.z == 0) {                                         // the two scans are independent: one wavefront each
+    if ((blockIdx.z & 1) == 0) {                                   // the two scans are independent: one wavefront each
         const double2 *__restrict__ Qt = p.tp_qt + kw * C * TSZ;
         double2 *__restrict__ Uk = p.tp_u + kw * C * TSZ;
         tidentity(V, lane);                                        // V = U_c
-        tload(Q, Qt, lane);
-        for (int c = 0; c < C; ++c) {
+        tload(Q, Qt + (size_t)c_lo * TSZ, lane);
+        for (int c = c_lo; c < c_hi; ++c) {
             tload(Qn, Qt + (size_t)min(c + 1, C - 1) * TSZ, lane);
             tmul_tn<NT, false, false>(Y, Q, V);                    // U_{c+1} = Q_c U_c
             transpose_via_a_layout(T, V, s_dynt, lane);
@@ -1048,14 +1064,20 @@ __global__ __launch_bounds__(64) void chunk_scan_general_kernel(const TileParams
         const double2 *__restrict__ Qk = p.tp_q + kw * C * TSZ;
         double2 *__restrict__ Rk = p.tp_r + kw * C * TSZ;
         tidentity(V, lane);                                        // V = R_c^T
-        tload(Q, Qk + (size_t)(C - 1) * TSZ, lane);
-        for (int c = C - 1; c >= 0; --c) {
+        tload(Q, Qk + (size_t)(c_hi - 1) * TSZ, lane);
+        for (int c = c_hi - 1; c >= c_lo; --c) {
             tload(Qn, Qk + (size_t)max(c - 1, 0) * TSZ, lane);
             tmul_tn<NT, false, false>(Y, Q, V);                    // R_{c-1}^T = Q_c^T R_c^T
             transpose_via_a_layout(T, V, s_dynt, lane);
             tstore(Rk + (size_t)c * TSZ, T, lane);                 // R_c
             V = Y;
             Q = Qn;
+        }
+        if (GROUPS) {                                              // V = (the group's product)^T
+            const size_t blk = (size_t)gridDim.y * p.E * p.tp_groups, at = kw * p.tp_groups + j;
+            tstore(p.tp_a + (3 * blk + at) * TSZ, V, lane);
+            transpose_via_a_layout(T, V, s_dynt, lane);
+            tstore(p.tp_a + (blk + at) * TSZ, T, lane);
         }
     }
 }
@@ -1264,10 +1286,23 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         const size_t lds_img = sizeof(double2) * (kTileImage + 1);
         if (p.unitary)
             q.tp_qt = nullptr;                                     // only the general flow's prefix scan needs Q_c^T
-        else
-            q.tp_groups = 0;                                       // (the two-level scan serves the unitary flow)
+
         hipLaunchKernelGGL((chunk_product_kernel<NT>), ugrid, block, lds_img, stream, q);
-        if (!p.unitary)  hipLaunchKernelGGL((chunk_scan_general_kernel<NT>), dim3(p.E, p.n_x, 2), block, lds_img, stream, q);
+        if (!p.unitary) {
+            if (q.tp_groups) {                                     // two levels: inside the groups, then over the groups
+                hipLaunchKernelGGL((chunk_scan_general_kernel<NT, true>), dim3(p.E, p.n_x, 2 * q.tp_groups), block, lds_img, stream, q);
+                TileParams s2 = q;
+                const size_t blk = (size_t)p.n_x * p.E * q.tp_groups * NT * NT * 256;
+                s2.tp_chunks = q.tp_groups;
+                s2.tp_r = q.tp_a;
+                s2.tp_q = q.tp_a + blk;
+                s2.tp_u = q.tp_a + 2 * blk;
+                s2.tp_qt = q.tp_a + 3 * blk;
+                hipLaunchKernelGGL((chunk_scan_general_kernel<NT, false>), dim3(p.E, p.n_x, 2), block, lds_img, stream, s2);
+            } else {
+                hipLaunchKernelGGL((chunk_scan_general_kernel<NT, false>), dim3(p.E, p.n_x, 2), block, lds_img, stream, q);
+            }
+        }
         else {
             TileParams s2 = q;                                     // what the serial scan runs over: chunks, or groups of chunks
             if (q.tp_groups) {
