@@ -29,7 +29,8 @@ def compare(label, w, variant=0, **ekw):
     gm = [float(np.abs(grads[k] - grads_ref[k]).max() / np.abs(grads_ref[k]).max()) for k in range(w.E)]
     rows.append({"case": label, "n": w.n, "K": w.K, "N": w.N, "E": w.E, "sys_type": w.sys_type, "variant": variant,
                  "kernel_family": info["kernel_family"], "unitary_flow": info["unitary_flow"],
-                 "rank_one_chain": info["rank_one_chain"],
+                 "rank_one_chain": info["rank_one_chain"], "time_chunks": info["time_chunks"],
+                 "fused_forward": info["fused_forward"],
                  "abs_err_F": float(abs(F - F_ref)), "rel_err_G_inf": float(np.abs(G - G_ref).max() / np.abs(G_ref).max()),
                  "worst_member_rel_err_G": max(gm), "worst_member_abs_err_F": float(np.abs(foms - foms_ref).max()),
                  "bar": 1e-10})
