@@ -7,8 +7,12 @@
 //   chain_tile_kernel  evolve_func! forward and backward + grad_func! + fom_func
 //                      (src/GRAPE.jl:216-287, src/cost_functions.jl:99-111): one wave per member
 //                      walks the time axis serially; with E >= #SIMDs the ensemble alone fills the
-//                      chip, so no time-parallel scan is needed at these sizes.  The reference's
-//                      data flow is kept (forward states stored, costates pulled back in registers).
+//                      chip.  The reference's data flow is kept (forward states stored, costates
+//                      pulled back in registers).
+//   chain_tile_split_kernel / chain_tile_unitary_kernel   the same sweep with two waves per member / for Hermitian
+//                      generators (M_t = P' M P, no stored states).
+//   chunk_product_kernel, chunk_scan_*_kernel   SMALL ensembles (single problems): the time axis in chunks, one wave
+//                      per (member, chunk); the chain kernels then run with grid.z = chunk ("Time-parallel ..." below).
 //
 // Products are arranged so that every operand is either a lane-contiguous dump load or the D
 // registers of the running matrix (tile.hpp):
@@ -18,11 +22,11 @@
 //            ST:  Y^T = L^T conj(P) = tmul_tn<., conj W>(L, P);  L' = Y P = tmul_tn(Y^T, P)
 //   gradient:     R = X L' (one A-layout conversion each of X and L), sandwich: minus L' X
 //                 = tmul_tn<conj Z>(L, X);  tr(L' B_c X) = sum R .* (B_c^T in D layout).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
 #include "cmat.hpp"          // Taylor-8 coefficients, squarings_for
-#include <algorithm>
 #include "grape_kernels.hpp"
 #include "tile.hpp"
 
