@@ -20,6 +20,8 @@ stats C3_E1024 GRAPE_X=0 --steps 400 --warmup 50    # (a 36-launch run averages 
 stats C4_E1024 GRAPE_X=0 --config C4 --steps 8 --warmup 2
 stats C4dense_E1024 GRAPE_NO_THIN=1 --config C4 --steps 8 --warmup 2
 stats C5_E4096 GRAPE_X=0 --config C5 --steps 2 --warmup 1
+stats C5x1 GRAPE_X=0 --config C5 --ensemble 1 --steps 200 --warmup 20     # single problems: the chunked time axis
+stats C4x1 GRAPE_X=0 --config C4 --ensemble 1 --steps 200 --warmup 20
 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C3" > "$OUT/pmc_C3.log" 2>&1
 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C4" --config C4 > "$OUT/pmc_C4.log" 2>&1
 GRAPE_NO_THIN=1 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C4dense" --config C4 > "$OUT/pmc_C4dense.log" 2>&1
