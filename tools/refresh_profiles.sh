@@ -17,8 +17,8 @@ stats() {   # name, env, bench args...
   [ -n "$f" ] && cp "$f" "$OUT/${name}_kernel_stats.csv"
 }
 stats C3_E1024 GRAPE_X=0 --steps 400 --warmup 50    # (a 36-launch run averages the cold first launches in: 78 us)
-stats C4_E1024 GRAPE_X=0 --config C4 --steps 8 --warmup 2
-stats C4dense_E1024 GRAPE_NO_THIN=1 --config C4 --steps 8 --warmup 2
+stats C4_E1024 GRAPE_X=0 --config C4 --steps 40 --warmup 5
+stats C4dense_E1024 GRAPE_NO_THIN=1 --config C4 --steps 40 --warmup 5
 stats C5_E4096 GRAPE_X=0 --config C5 --steps 2 --warmup 1
 stats C5x1 GRAPE_X=0 --config C5 --ensemble 1 --steps 200 --warmup 20     # single problems: the chunked time axis
 stats C4x1 GRAPE_X=0 --config C4 --ensemble 1 --steps 200 --warmup 20
