@@ -777,6 +777,10 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                 }
         }
     }
+    // ONE rank-one problem is latency-bound either way, and the dense chunked flows (two-level scan, 4-slice chunks) are
+    // ahead of the vector chain's chunked mode there: 0.083 vs 0.100 ms per evaluation for C4's operators, N = 1000
+    if (thin && E == 1 && c->cfg.n_slices >= 64 && !env_on("GRAPE_NO_TP") && !env_on("GRAPE_THIN_SINGLE"))
+        thin = false;
     c->thin = thin;
     {                                                        // Hermitian control operators?
         bool hb = true;

@@ -191,6 +191,7 @@ def test_rank_one_chain_time_chunks(qoc, oracle, monkeypatch, n, K, N, E, sys_ty
     last chunks, the library's own chunk count (0) and forced ones, batched and device entry points -- and the
     one-wavefront chain (GRAPE_NO_TP=1) on the same inputs."""
     import torch
+    monkeypatch.setenv("GRAPE_THIN_SINGLE", "1")      # (a single rank-one problem would take the dense chunked flows)
     if chain == "sequential":
         monkeypatch.setenv("GRAPE_NO_TP", "1")
     elif chunks:
@@ -219,3 +220,17 @@ def test_rank_one_chain_time_chunks(qoc, oracle, monkeypatch, n, K, N, E, sys_ty
     assert_parity(fg[-1], fg[:-1].reshape(N, K).T, F_ref, G_ref, n, what="device entry point")
     Fr, Gr = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, xs[1], 1.2)
     assert_parity(Fb[1], Gb[1], Fr, Gr, n, what="batch entry 1")
+
+
+@pytest.mark.parametrize("sys_type,herm_gen", [("CoherenceTransfer", False), ("StateTransfer", True), ("UnitaryGate", False)])
+def test_single_rank_one_problem_takes_the_dense_chunked_flows(qoc, oracle, sys_type, herm_gen):
+    """ONE rank-one problem of at least 64 slices is latency-bound and the dense flows with the chunked time axis are
+    the faster ones there; the library routes it to them (general flow, or unitary flow for Hermitian generators)."""
+    n, K, N = 16, 3, 96
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, 1, sys_type != "UnitaryGate", herm_gen, True, seed=3)
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N) as eng:
+        info = eng.info
+        assert info["rank_one_chain"] == 0 and info["time_chunks"] >= 2 and info["unitary_flow"] == (1 if herm_gen else 0)
+        F, G = eng.eval(x)
+    F_ref, G_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.2)
+    assert_parity(F, G, F_ref, G_ref, n, what="single rank-one problem")
