@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GRAPE_ABI_VERSION 2
+#define GRAPE_ABI_VERSION 3
 
 typedef enum grape_status {
     GRAPE_OK = 0,
@@ -167,6 +167,11 @@ typedef struct grape_info {
     int32_t time_chunks;           /* n = 5..32, fewer members than wavefront slots: the time axis
                                       of every member is cut into this many chunks evaluated in parallel (0 = one
                                       wavefront walks all slices) */
+    /* ---- ABI v3 ---- */
+    int32_t hoisted_controls;      /* 1 after grape_set_operators found the control operators B_c identical for every
+                                      member (B_gens = k -> [Sx, Sy], test/setup_tests.jl:32) in the n = 5..32 family:
+                                      the control sum sum_c x[c,t] B_c of src/timeevolution.jl:105-107 is formed once per
+                                      slice and evaluation instead of once per (member, slice) */
 } grape_info;
 
 /* Opaque RCCL bootstrap token (ncclUniqueId), see grape_comm_unique_id / grape_comm_attach. */

@@ -90,6 +90,11 @@ struct grape_ctx {
     bool sparse_ctrl = false;                  // tile family: every B_c has <= kSparseMax non-zeros (sparse gradient traces)
     double2 *d_sp_coef = nullptr;              // [E][K][kSparseMax]
     int32_t *d_sp_addr = nullptr;
+    bool hoist = false;                        // tile family: member-invariant control operators, control sum formed once per slice
+    double2 *d_ha = nullptr;                   // [EU] dumps of A'_k = (-i dt) A_k
+    double *d_ha_norm = nullptr;               // [EU] |A'_k|_1 bound / theta8
+    double2 *d_gc = nullptr;                   // [B][N] dumps of Gc_t
+    double *d_gcn = nullptr;                   // [B][N] |Gc_t|_1 bound / theta8
     size_t states_bytes = 0;                   // size of d_states (vector records are smaller than state dumps)
     int tp_C = 0, tp_S = 0;                    // tile family, unitary flow, small ensembles: time chunks per unit (0 = sequential chain)
     double2 *d_tp_q = nullptr, *d_tp_r = nullptr, *d_tp_m = nullptr;   // chunk products, products after each chunk, M_N
@@ -242,6 +247,7 @@ static void free_all(grape_ctx *c)
     (void)hipFree(c->d_sp_coef); (void)hipFree(c->d_sp_addr);
     (void)hipFree(c->d_tp_q); (void)hipFree(c->d_tp_r); (void)hipFree(c->d_tp_m); (void)hipFree(c->d_tp_z); (void)hipFree(c->d_tp_vec); (void)hipFree(c->d_tp_a);
     (void)hipFree(c->d_x_bar);
+    (void)hipFree(c->d_ha); (void)hipFree(c->d_ha_norm); (void)hipFree(c->d_gc); (void)hipFree(c->d_gcn);
     delete c;
 }
 
@@ -807,6 +813,65 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             HIP_TRY(c, hipMemcpy(c->d_sp_addr, addr.data(), sizeof(int32_t) * addr.size(), hipMemcpyHostToDevice));
         }
     }
+    {   // member-invariant control operators (every BASELINE config, every reference test: B_gens = k -> [Sx, Sy],
+        // test/setup_tests.jl:32): the control sum (-i dt) sum_c x[c,t] B_c is formed once per slice and evaluation
+        // (prop_hoist.hip) and a (member, slice) adds its own A'_k = (-i dt) A_k.  Single-tile and two-tile matrices,
+        // one member per tile; ensembles of at least 8 units (below that the pre-pass launch costs more than it saves).
+        // GRAPE_HOIST=0 keeps the per-member build, GRAPE_HOIST=1 forces the hoisted one for any ensemble size.
+        bool hz = c->family == 1 && !c->pack2 && c->cfg.gradient != GRAPE_GRADIENT_EXACT;
+        const char *he = std::getenv("GRAPE_HOIST");
+        if (he && he[0] == '0') hz = false;
+        if (hz && !(he && he[0] == '1') && c->EU < 8) hz = false;
+        if (hz && c->NT != 1) hz = false;
+        for (size_t k = 1; k < E && hz; ++k)
+            hz = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
+        c->hoist = hz;
+        if (hz) {
+            const double dt = c->cfg.duration / c->cfg.n_slices;
+            const size_t TSZ = c->TSZ;
+            std::vector<double> ha, hn;
+            try {
+                ha.assign(2 * (size_t)c->EU * TSZ, 0.0);
+                hn.assign((size_t)c->EU, 0.0);
+            } catch (...) {
+                return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: out of host memory");
+            }
+            const int nd = c->cfg.n, NT = c->NT;
+            for (size_t k = 0; k < E; ++k) {
+                const double *M = A + 2 * k * nn;
+                double *dst = ha.data() + 2 * k * TSZ;
+                double best = 0.0;
+                for (int col = 0; col < nd; ++col) {
+                    double cs = 0.0;
+                    for (int row = 0; row < nd; ++row) {
+                        const double re = dt * M[2 * (row + (size_t)nd * col) + 1], im = -dt * M[2 * (row + (size_t)nd * col)];
+                        const int I = row >> 4, J = col >> 4, r = (row & 15) >> 2, l = 16 * (row & 3) + (col & 15);
+                        const size_t o = 2 * ((size_t)((I * NT + J) * 4 + r) * 64 + l);
+                        dst[o] = re;
+                        dst[o + 1] = im;
+                        cs += std::fabs(re) + std::fabs(im);
+                    }
+                    if (!(cs <= best)) best = cs;                 // NaN-propagating maximum
+                }
+                hn[k] = best / 0.05;                               // / theta8 (cmat.hpp: kTheta8)
+            }
+            const size_t gc_elems = (size_t)c->B * c->cfg.n_slices * TSZ;
+            if (!c->d_ha) {
+                c->bytes += sizeof(double2) * ((size_t)c->EU * TSZ + gc_elems) + sizeof(double) * ((size_t)c->EU + (size_t)c->B * c->cfg.n_slices);
+                HIP_TRY(c, hipMalloc((void **)&c->d_ha, sizeof(double2) * (size_t)c->EU * TSZ));
+            }
+            if (!c->d_ha_norm) HIP_TRY(c, hipMalloc((void **)&c->d_ha_norm, sizeof(double) * (size_t)c->EU));
+            if (!c->d_gc) HIP_TRY(c, hipMalloc((void **)&c->d_gc, sizeof(double2) * gc_elems));
+            if (!c->d_gcn) HIP_TRY(c, hipMalloc((void **)&c->d_gcn, sizeof(double) * (size_t)c->B * c->cfg.n_slices));
+            if (c->dev_pending) {                                // an evaluation may still read the old dumps
+                HIP_TRY(c, hipEventSynchronize(c->ev_dev));
+                c->dev_pending = false;
+            }
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipMemcpy(c->d_ha, ha.data(), sizeof(double) * ha.size(), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->d_ha_norm, hn.data(), sizeof(double) * hn.size(), hipMemcpyHostToDevice));
+        }
+    }
     {   // time-parallel chains: fewer units than wavefront slots (one wave per unit and chunk, 4 per CU).
         // Unitary flow: 3 S + C dependent products per evaluation (S slices per chunk, C chunks) instead of 3 N.
         // Rank-one chain: S dense chunk-product steps + 2 S vector steps + 2 C scan steps instead of 2 N vector steps;
@@ -955,6 +1020,11 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.sparse = c->sparse_ctrl ? 1 : 0;
     p.sp_coef = c->d_sp_coef;
     p.sp_addr = c->d_sp_addr;
+    p.hoist = c->hoist ? 1 : 0;
+    p.ha = c->d_ha;
+    p.ha_norm = c->d_ha_norm;
+    p.gc = c->d_gc;
+    p.gcn = c->d_gcn;
     return p;
 }
 
@@ -1786,6 +1856,7 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
         const grape_ctx *s0 = c->is_group ? c->sub[0] : c;
         info->fused_forward = (s0->thin && tile_fuse_forward(tile_params(s0, nullptr, 1)) == 1) ? 1 : 0;
         info->time_chunks = s0->tp_C;
+        info->hoisted_controls = s0->hoist ? 1 : 0;
     }
     return GRAPE_OK;
 }

@@ -122,6 +122,12 @@ struct TileParams {
     int32_t sparse;
     const double2 *sp_coef;   // [unit][K][kSparseMax]
     const int32_t *sp_addr;   // [unit][K][kSparseMax]
+    // member-invariant control operators (prop_hoist.hip): the control sum is formed once per slice and evaluation
+    int32_t hoist;            // set by the host layer: every member has the same B_c (and the ensemble is worth a pre-pass)
+    const double2 *ha;        // [unit] D-layout dumps of A'_k = (-i dt) A_k
+    const double *ha_norm;    // [unit] |A'_k|_1 bound (max column sum of |re| + |im|) / theta8
+    double2 *gc;              // [control array][slice] D-layout dumps of Gc_t = (-i dt) sum_c x[c,t] B_c
+    double *gcn;              // [control array][slice] |Gc_t|_1 bound / theta8
     double dt;
 };
 constexpr int kSparseMax = 64;
@@ -130,6 +136,8 @@ hipError_t launch_chain_thin(int sandwich, const TileParams &p, hipStream_t stre
 int tile_count(int n);    // NT for this n (0: not a tile-family size)
 int tile_fuse_forward(const TileParams &p);   // thin: forward vector pass runs inside prop_tile_kernel for this launch?
 hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
+// prop_hoist.hip: control-sum pre-pass + the expm kernel on A'_k + Gc_t; q = the launcher's parameters (prop_slices, fuse_fwd set)
+hipError_t launch_prop_hoist(int NT, const TileParams &q, hipStream_t stream);
 bool tile_chain_is_split(const TileParams &p, bool keep_costates);   // the two-wave time-split chain: no full X_t store
 
 // G[q] = sum_k w_k member_out[k][q]  for q in [0, Q)  (Q = K*N + 1; the last entry is F).

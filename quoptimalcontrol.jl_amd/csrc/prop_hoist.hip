@@ -1,0 +1,352 @@
+// prop_hoist.hip -- pw_prop_save! (src/timeevolution.jl:98-110) of the tile family when the control operators are the
+// SAME for every ensemble member (B_gens = k -> [Sx, Sy], test/setup_tests.jl:32; every BASELINE config):
+//
+//   ctrl_sum_kernel     once per evaluation and slice:  Gc_t = (-i dt) sum_c x[c,t] B_c  as a D-layout dump, and its
+//                       norm bound |Gc_t|_1 (max column sum of |re| + |im|);
+//   prop_hoist_kernel   per (member, slice):  G = A'_k + Gc_t  with A'_k = (-i dt) A_k prepared at grape_set_operators
+//                       (one tile add instead of K tile FMAs + K operator-tile reads), squarings from the bound
+//                       |A'_k|_1 + |Gc_t|_1 >= |G|_1 (two scalars: no cross-lane norm reduction), Taylor-8 on the
+//                       FP64 matrix cores, P_t dumped in D layout (rank-one chain: transposed for odd t).
+//
+// The reference sums the controls first and adds A last (variant 0; the static variant adds A first): hoisting the
+// control sum keeps that association and only moves the scalar (-i dt) inside the sum -- a rounding-level change.
+//
+// Why this file exists (profiles/r02_C4_E1024_pmc.json, tools/ubench/pipe_mix.hip): on gfx950 a SIMD does not overlap
+// v_mfma_f64_16x16x4 with vector instructions of the waves that issue the MFMAs -- a propagator costs
+// 64 cycles x MFMAs + ~4.3 cycles x VALU instructions, whatever the occupancy.  The round-2 kernel issued ~490 vector
+// instructions per 38.6 MFMAs (16 x 16) and 2255 per 319 (32 x 32, two thirds of them register moves between the
+// VGPR and AGPR halves of a 420-register allocation).  Here every remaining vector instruction is arithmetic the
+// algorithm needs: no packing moves in front of LDS stores (ds_write2_b64 takes re and im from separate registers),
+// no cross-lane norm, no control FMAs, negations folded into operands, the identity added through a 0/1 register.
+#include <algorithm>
+#include <cstdlib>
+
+#include "cmat.hpp"          // Taylor-8 coefficients, squarings_for
+#include "grape_kernels.hpp"
+#include "tile.hpp"
+
+namespace grape {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gc_t and its norm bound: one wave per (slice, control array); tiles one after the other
+template <int NT>
+__global__ __launch_bounds__(64) void ctrl_sum_kernel(const TileParams p)
+{
+    constexpr int TSZ = NT * NT * 256;
+    const int lane = threadIdx.x, t = blockIdx.x, z = blockIdx.y;
+    const int K = p.K;
+    const double2 *__restrict__ B0 = p.ops + TSZ;                  // unit 0: [A | B_1..B_K | ...]
+    const double *__restrict__ x = p.x + (size_t)z * K * p.N + (size_t)t * K;
+    double2 *__restrict__ out = p.gc + ((size_t)z * p.N + t) * TSZ;
+    const double dt = p.dt;
+    double colmax = 0.0;
+#pragma unroll
+    for (int J = 0; J < NT; ++J) {
+        double cs = 0.0;
+#pragma unroll
+        for (int I = 0; I < NT; ++I) {
+            double hr[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+            for (int c = 0; c < K; ++c) {
+                const double xv = x[c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double2 b = B0[(size_t)c * TSZ + ((I * NT + J) * 4 + r) * 64 + lane];
+                    hr[r] = fma(b.x, xv, hr[r]);
+                    hi[r] = fma(b.y, xv, hi[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double gr = dt * hi[r], gi = -dt * hr[r];    // (-i dt) H
+                out[((I * NT + J) * 4 + r) * 64 + lane] = make_double2(gr, gi);
+                cs += fabs(gr) + fabs(gi);
+            }
+        }
+        cs = swap16_add(cs, cs);                                   // rows live on lane >> 4 and r
+        cs = swap32_add(cs, cs);
+        colmax = fmax(colmax, cs);
+    }
+    colmax = wave_max_fast(colmax);
+    if (lane == 0)
+        p.gcn[(size_t)z * p.N + t] = colmax * (1.0 / kTheta8);     // the expm kernel adds |A'_k|_1 / theta8
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS layout conversion without packing moves.  The image of tile.hpp (slot = 68 r + 17 (lane >> 4) + (lane & 15) for
+// the D registers; the A operand of k-block kb at slot 68 (rho >> 2) + 17 (rho & 3) + q + 4 kb) is written with
+// ds_write2_b64: re and im come from their own register pairs and land in adjacent 8-byte words -- the same
+// interleaved double2 image as a ds_write_b128 of a packed quad, minus the eight v_mov_b32 that packing costs.
+// Offsets are in 8-byte units and at most 255: rows 2, 3 go through a second base address (+ 2 x 68 slots).
+// RAW: `im` (or `re`) may be the untouched result of an MFMA.  The compiler's hazard recogniser does not look inside
+// inline assembly, so the wait states an LDS store needs behind a v_mfma_f64_16x16x4 that wrote its data register
+// (18, CDNA3/4 ISA "XDL write VGPR -> LDS read") are spelled out here.  RAW = false is for data a vector instruction
+// produced (the recogniser has put the wait in front of THAT instruction).
+template <bool RAW>
+GRAPE_DEV void img_write_tile(unsigned base, const d4 &re, const d4 &im)
+{
+    if (RAW)
+        asm volatile("s_nop 15\n\ts_nop 2" ::: "memory");
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:0 offset1:1" : : "v"(base), "v"(re[0]), "v"(im[0]) : "memory");
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:136 offset1:137" : : "v"(base), "v"(re[1]), "v"(im[1]) : "memory");
+    const unsigned base2 = base + 2 * 68 * 16;
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:0 offset1:1" : : "v"(base2), "v"(re[2]), "v"(im[2]) : "memory");
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:136 offset1:137" : : "v"(base2), "v"(re[3]), "v"(im[3]) : "memory");
+}
+
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+// the A operand of one tile: four (re, im) pairs, one per k-block, each an aligned register quad
+struct AOp {
+    d2v v[4];
+};
+
+// the four reads and the wait for them in one statement: the outputs exist only behind the s_waitcnt, so no consumer can
+// be scheduled in front of it.  LDS operations of one wave execute in issue order: the reads see the image that the
+// same wave's img_write_tile stored just before, without a wait in between.
+GRAPE_DEV void img_read_tile(AOp &a, unsigned rd)
+{
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+                 "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a.v[0]), "=&v"(a.v[1]), "=&v"(a.v[2]), "=&v"(a.v[3])
+                 : "v"(rd)
+                 : "memory");
+}
+
+// squarings from a norm bound already divided by theta8: 0 when v <= 1 (and for NaN: the polynomial propagates it),
+// else 1 + the binary exponent of v (one more than needed when v is an exact power of two) -- scalar integer
+// arithmetic on the bits of v, no FP64 vector instruction
+GRAPE_DEV int squarings_from_ratio(double v)
+{
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    const int e = (hi >> 20) & 0x7ff;
+    if (hi < 0 || e < 1023 || e == 0x7ff)
+        return 0;
+    if (e == 1023 && (hi & 0xfffff) == 0 && __builtin_amdgcn_readfirstlane(__double2loint(v)) == 0)
+        return 0;                                                  // v == 1 exactly
+    return min(e - 1022, 60);
+}
+
+#define GRAPE_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// one 16 x 16 complex tile product  (re, im) = A * W  with A an AOp and W in D layout, three real products
+// (tile.hpp tprod), written so that the only vector instructions are the 8 operand sums and the 8 combinations
+GRAPE_DEV void tile_prod(d4 &ore, d4 &oim, const AOp &a, const d4 &wre, const d4 &wim)
+{
+    d4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        t1 = GRAPE_MFMA(a.v[kb][0], wre[kb], t1);
+        t2 = GRAPE_MFMA(a.v[kb][1], wim[kb], t2);
+    }
+    double as[4], bs[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        as[kb] = a.v[kb][0] + a.v[kb][1];
+        bs[kb] = wre[kb] + wim[kb];
+    }
+    d4 t3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        ore[r] = t1[r] - t2[r];
+        t3[r] = -t1[r] - t2[r];                                    // one v_add_f64 with both operands negated
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+        t3 = GRAPE_MFMA(as[kb], bs[kb], t3);
+    oim = t3;
+}
+
+// Taylor-8 constants rearranged so that two of the three combinations are a single FMA per element:
+//   A4' = A2 (A2 + c1 G)            = A4 / x2
+//   A8' = (A4' + c3 A2) (x4 I + x5 G + x6 A2 + c7 A4')   = A8 / x2
+//   P   = x2 A8' + (I + G + y2 A2)
+constexpr double kC1 = kX1 / kX2, kC3 = kX3 / kX2, kC7 = kX7 * kX2;
+
+constexpr int kHoistWaves = 4;
+
+// NT = 1.  FUSE: rank-one chain with one workgroup per member (sweep_tile.hip, tile_fuse_forward): wave w walks the
+// slices t = w mod 4 and the forward vector v_{t+1} = P_t v_t goes from wave to wave through LDS.  Here EVERY slice's
+// propagator is converted to its transposed registers (one LDS round trip, no vector instruction) before the wave
+// waits for its turn, so the serial hand-over is the short form for all t: gathered reads of v from LDS, 16 FMAs, a
+// sum over the four lane rows (two permlane swaps), per-column write.
+template <bool FUSE>
+__global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const TileParams p)
+{
+    constexpr int TSZ = 256, WPB = kHoistWaves;
+    extern __shared__ double2 s_hoist[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = blockIdx.y, z = blockIdx.z;
+    double2 *img = s_hoist + (size_t)wave * kTileImage;
+    double2 *s_vec = s_hoist + (size_t)WPB * kTileImage;           // FUSE: [v even | v odd | flag]
+    volatile int *s_flag = reinterpret_cast<volatile int *>(s_vec + 32);
+    const unsigned img_base = (unsigned)(size_t)img;               // LDS byte address (the low 32 bits of a __shared__ pointer)
+    const unsigned wr = img_base + 16u * (17 * (lane >> 4) + (lane & 15));
+    const unsigned rd = img_base + 16u * (68 * ((lane & 15) >> 2) + 17 * (lane & 3) + (lane >> 4));
+    if (FUSE) {
+        if (threadIdx.x < 16)
+            s_vec[threadIdx.x] = p.vecs[(size_t)k * 32 + threadIdx.x];
+        if (threadIdx.x == 0)
+            *s_flag = 0;
+        __syncthreads();
+    }
+    // A'_k stays in registers for every slice this wave walks
+    d4 Are, Aim, diag;
+    {
+        const double2 *__restrict__ ha = p.ha + (size_t)k * TSZ;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 v = ha[r * 64 + lane];
+            Are[r] = v.x;
+            Aim[r] = v.y;
+            diag[r] = (4 * r + (lane >> 4) == (lane & 15)) ? 1.0 : 0.0;
+        }
+    }
+    const double nA = p.ha_norm[k];
+    const double *__restrict__ gcn = p.gcn + (size_t)z * p.N;
+    const double2 *__restrict__ gc = p.gc + (size_t)z * p.N * TSZ;
+    double2 *__restrict__ props = p.props + ((size_t)z * p.E + k) * (size_t)p.N * TSZ;
+    const int t_lo = FUSE ? 0 : blockIdx.x * p.prop_slices;
+    const int t_hi = FUSE ? p.N : min(p.N, t_lo + p.prop_slices);
+    int t = t_lo + wave;
+    double2 gnext[4];
+    if (t < t_hi) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            gnext[r] = gc[(size_t)t * TSZ + r * 64 + lane];
+    }
+    for (; t < t_hi; t += WPB) {
+        d4 Gre, Gim;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Gre[r] = Are[r] + gnext[r].x;
+            Gim[r] = Aim[r] + gnext[r].y;
+        }
+        const int s = p.s_forced >= 0 ? p.s_forced : squarings_from_ratio(nA + gcn[t]);   // both already / theta8
+        {
+            const int tn = min(t + WPB, t_hi - 1);                 // next slice's control sum in flight (clamped: no branch)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                gnext[r] = gc[(size_t)tn * TSZ + r * 64 + lane];
+        }
+        if (s > 0) {
+            const double sc = ldexp(1.0, -s);
+            Gre *= sc;
+            Gim *= sc;
+        }
+        AOp opa;
+        d4 A2re, A2im, A4re, A4im, Tre, Tim, Ure, Uim;
+        img_write_tile<false>(wr, Gre, Gim);
+        img_read_tile(opa, rd);
+        tile_prod(A2re, A2im, opa, Gre, Gim);                      // A2 = G G
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Tre[r] = fma(kC1, Gre[r], A2re[r]);
+            Tim[r] = fma(kC1, Gim[r], A2im[r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // A2im is a raw MFMA result: its first readers are the FMAs above
+        img_write_tile<false>(wr, A2re, A2im);
+        img_read_tile(opa, rd);
+        tile_prod(A4re, A4im, opa, Tre, Tim);                      // A4' = A2 (A2 + c1 G)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Ure[r] = fma(kC3, A2re[r], A4re[r]);
+            Uim[r] = fma(kC3, A2im[r], A4im[r]);
+            Tre[r] = fma(kC7, A4re[r], fma(kX6, A2re[r], fma(kX5, Gre[r], kX4 * diag[r])));
+            Tim[r] = fma(kC7, A4im[r], fma(kX6, A2im[r], kX5 * Gim[r]));
+        }
+        img_write_tile<false>(wr, Ure, Uim);
+        img_read_tile(opa, rd);
+        d4 Pre, Pim;
+        tile_prod(Pre, Pim, opa, Tre, Tim);                        // A8'
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Pre[r] = fma(kX2, Pre[r], fma(kY2, A2re[r], Gre[r] + diag[r]));
+            Pim[r] = fma(kX2, Pim[r], fma(kY2, A2im[r], Gim[r]));
+        }
+        for (int i = 0; i < s; ++i) {
+            img_write_tile<true>(wr, Pre, Pim);
+                img_read_tile(opa, rd);
+                d4 Qre, Qim;
+            tile_prod(Qre, Qim, opa, Pre, Pim);
+            Pre = Qre;
+            Pim = Qim;
+        }
+        double2 *__restrict__ dst = props + (size_t)t * TSZ;
+        const bool transposed = p.thin && (t & 1);
+        if (FUSE || transposed) {
+            img_write_tile<true>(wr, Pre, Pim);
+                img_read_tile(opa, rd);                                // opa.v[r] = {re, im} of P^T's D register r
+            }
+        if (FUSE && p.fuse_fwd == 1) {
+            const int g = lane >> 4, c = lane & 15;
+            const double2 *vb = s_vec + (t & 1) * 16;
+            double2 *vn = s_vec + ((t + 1) & 1) * 16;
+            double2 *__restrict__ V = p.states + ((size_t)z * p.E + k) * (size_t)(p.N + 1) * 16;
+            while (*s_flag != t)
+                __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            double acc[2] = {0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                          // y[c] = sum_j P[c][j] v[j], j = 4 r + g
+                const double2 v = vb[4 * r + g];
+                acc[0] = fma(opa.v[r][0], v.x, acc[0]);
+                acc[0] = fma(-opa.v[r][1], v.y, acc[0]);
+                acc[1] = fma(opa.v[r][0], v.y, acc[1]);
+                acc[1] = fma(opa.v[r][1], v.x, acc[1]);
+            }
+            const double2 rec = vb[c];                             // v_t per column: the record of slice t
+            col_sum_n(acc);
+            if (g == 0)
+                vn[c] = make_double2(acc[0], acc[1]);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            asm volatile("" ::: "memory");
+            if (lane == 0)
+                *s_flag = t + 1;
+            if (g == 0) {
+                V[(size_t)t * 16 + c] = rec;
+                if (t == p.N - 1)
+                    V[(size_t)p.N * 16 + c] = make_double2(acc[0], acc[1]);
+            }
+        }
+        if (transposed) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                dst[r * 64 + lane] = make_double2(opa.v[r][0], opa.v[r][1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                dst[r * 64 + lane] = make_double2(Pre[r], Pim[r]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+hipError_t launch_ctrl_sum(int NT, const TileParams &p, hipStream_t stream)
+{
+    const dim3 grid(p.N, p.n_x), block(64);
+    if (NT == 1)
+        hipLaunchKernelGGL((ctrl_sum_kernel<1>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((ctrl_sum_kernel<2>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+// q: the launcher's copy of the parameters with prop_slices / fuse_fwd decided (sweep_tile.hip: launch_nt)
+hipError_t launch_prop_hoist(int NT, const TileParams &q, hipStream_t stream)
+{
+    hipError_t e = launch_ctrl_sum(NT, q, stream);
+    if (e != hipSuccess)
+        return e;
+    if (NT == 1) {
+        const size_t lds = sizeof(double2) * (kHoistWaves * (size_t)kTileImage + 33);
+        const dim3 grid(q.fuse_fwd ? 1 : (q.N + q.prop_slices - 1) / q.prop_slices, q.E, q.n_x), block(64 * kHoistWaves);
+        if (q.fuse_fwd)
+            hipLaunchKernelGGL((prop_hoist1_kernel<true>), grid, block, lds, stream, q);
+        else
+            hipLaunchKernelGGL((prop_hoist1_kernel<false>), grid, block, lds, stream, q);
+        return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace grape

@@ -1228,7 +1228,8 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         // problem of 2000 slices ran 32 workgroups: 235 us) -- as many as make ONE round of resident workgroups
         // (NT = 2 holds a CU per workgroup, NT = 1 a quarter), in multiples of the four waves
         int per_block = WPB;
-        if (q.stage_ops) {
+        const bool hoisted = p.hoist && NT == 1;                   // prop_hoist.hip: A'_k in registers, nothing staged
+        if (q.stage_ops || hoisted) {
             const long resident = (long)(p.cus > 0 ? p.cus : 256) * (NT == 1 ? 4 : 1);
             const long total = (long)p.N * p.E * p.n_x;
             const long want = ((total + resident - 1) / resident + WPB - 1) / WPB * WPB;
@@ -1237,7 +1238,7 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         q.prop_slices = per_block;
         // rank-one chain: fuse the forward vector pass into this kernel when one workgroup per member fills the
         // device (four workgroups of four waves per CU): the last round of workgroups must be at least 90 % full
-        q.fuse_fwd = (NT == 1 && q.stage_ops) ? tile_fuse_forward(p) : 0;
+        q.fuse_fwd = (NT == 1 && (q.stage_ops || hoisted)) ? tile_fuse_forward(p) : 0;
         const size_t lds = img_bytes + (q.stage_ops ? ops_bytes : 0) + (q.fuse_fwd ? sizeof(double2) * 33 : 0);
         if (lds > 64 * 1024) {
             hipError_t ea = hipFuncSetAttribute((const void *)prop_tile_kernel<NT>,
@@ -1245,9 +1246,14 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
             if (ea != hipSuccess)
                 return ea;
         }
-        hipLaunchKernelGGL((prop_tile_kernel<NT>), dim3(q.fuse_fwd ? 1 : (p.N + per_block - 1) / per_block, p.E, p.n_x),
-                           dim3(64 * WPB), lds, stream, q);
-        hipError_t e = hipGetLastError();
+        hipError_t e;
+        if (hoisted) {                                             // member-invariant controls: prop_hoist.hip
+            e = launch_prop_hoist(NT, q, stream);
+        } else {
+            hipLaunchKernelGGL((prop_tile_kernel<NT>), dim3(q.fuse_fwd ? 1 : (p.N + per_block - 1) / per_block, p.E, p.n_x),
+                               dim3(64 * WPB), lds, stream, q);
+            e = hipGetLastError();
+        }
         if (e != hipSuccess)
             return e;
         if (NT == 1 && p.thin)

@@ -1,0 +1,143 @@
+"""GPU: member-invariant control operators in the n = 5..32 family (csrc/prop_hoist.hip) -- the control sum of
+src/timeevolution.jl:105-107 formed once per slice (ctrl_sum_kernel) and A'_k added per member, squarings from the norm
+bound |A'_k| + |Gc_t| -- against the oracle at the 1e-10 bar, against the library's own per-member build
+(GRAPE_HOIST=0), for every chain that consumes the propagators (rank-one vector chain with and without the fused
+forward pass, dense general chains, unitary chains, time chunks), both formula variants, the squaring path, batches,
+and bitwise reproducibility (the kernel hands data between LDS stores written in assembly and matrix-core results)."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(n, K, N, E, sand, herm_gen, seed, rank_one=True, scale=0.6, cols=None):
+    rng = np.random.default_rng(seed)
+
+    def gen(h):
+        M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        return (M + M.conj().T) / 2 if h else M
+    A = np.array([gen(herm_gen) for _ in range(E)]) * scale
+    B1 = np.array([gen(True) for _ in range(K)]) * 0.4
+    B = np.broadcast_to(B1, (E, K, n, n)).copy()                   # the SAME control operators for every member
+
+    def vec():
+        v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        return v / np.linalg.norm(v)
+
+    def rho():
+        if rank_one:
+            v = vec()
+            return np.outer(v, v.conj())
+        return sum(p * np.outer(v, v.conj()) for p, v in zip((0.6, 0.3, 0.1), (vec(), vec(), vec())))
+    if sand:
+        Xi = np.array([rho() for _ in range(E)])
+        Xt = np.array([rho() for _ in range(E)])
+    elif cols == 1:
+        Xi = np.array([vec().reshape(n, 1) for _ in range(E)])
+        Xt = np.array([vec().reshape(n, 1) for _ in range(E)])
+    else:
+        def unitary():
+            q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+            return q
+        Xi = np.array([np.eye(n, dtype=complex) for _ in range(E)])
+        Xt = np.array([unitary() for _ in range(E)])
+    return A, B, Xi, Xt, rng.uniform(0.2, 1.0, E), rng.uniform(-1, 1, (K, N))
+
+
+CASES = [  # n, K, N, E, sys_type, Hermitian drift, rank-one states, state columns (UnitaryGate)
+    (16, 4, 37, 9, "CoherenceTransfer", False, True, None),        # rank-one vector chain, non-Hermitian generator (C4's shape)
+    (16, 3, 8, 12, "StateTransfer", True, True, None),
+    (12, 2, 21, 8, "CoherenceTransfer", False, True, None),        # zero-padded tile
+    (16, 4, 64, 10, "UnitaryGate", False, True, 1),                # n x 1 states, left multiplication
+    (16, 4, 33, 8, "CoherenceTransfer", False, False, None),       # mixed states: dense general chain (two-wave split)
+    (16, 2, 19, 9, "UnitaryGate", True, False, None),              # unitary flow
+    (9, 5, 12, 8, "StateTransfer", True, False, None),
+    (16, 1, 1, 8, "CoherenceTransfer", False, True, None),         # a single slice
+]
+
+
+@pytest.mark.parametrize("n,K,N,E,sys_type,herm_gen,rank_one,cols", CASES)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_hoisted_control_sum_matches_oracle_and_per_member_build(qoc, oracle, monkeypatch, n, K, N, E, sys_type, herm_gen,
+                                                                 rank_one, cols, variant):
+    sand = sys_type != "UnitaryGate"
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sand, herm_gen, seed=31 * n + N + K, rank_one=rank_one, cols=cols)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.1, variant=variant,
+                                                             per_member=True)
+    res = {}
+    for hoist in ("1", "0"):
+        monkeypatch.setenv("GRAPE_HOIST", hoist)
+        for fuse in (("GRAPE_FORCE_FUSE", "GRAPE_NO_FUSE") if (rank_one and (sand or cols == 1)) else ("",)):
+            monkeypatch.delenv("GRAPE_FORCE_FUSE", raising=False)
+            monkeypatch.delenv("GRAPE_NO_FUSE", raising=False)
+            if fuse:
+                monkeypatch.setenv(fuse, "1")
+            with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.1, N, variant=variant, member_results=True) as eng:
+                assert eng.info["hoisted_controls"] == int(hoist) and eng.info["kernel_family"] == 1
+                F, G = eng.eval(x)
+                foms, grads = eng.member_results()
+                F2, G2 = eng.eval(x)
+            assert F == F2 and np.array_equal(G, G2), "run-to-run reproducibility"
+            for k in range(E):
+                assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"hoist {hoist} {fuse} member {k}")
+            assert_parity(F, G, F_ref, G_ref, n, what=f"hoist {hoist} {fuse} ensemble")
+            res[(hoist, fuse)] = (F, G)
+    keys = list(res)
+    for key in keys[1:]:
+        assert abs(res[key][0] - res[keys[0]][0]) <= 1e-12 * max(1.0, abs(res[keys[0]][0]))
+        assert np.abs(res[key][1] - res[keys[0]][1]).max() <= 1e-12 * np.abs(res[keys[0]][1]).max() + 1e-15
+
+
+@pytest.mark.parametrize("scale,N", [(6.0, 9), (40.0, 5)])
+def test_hoisted_squaring_path_and_propagators(qoc, oracle, monkeypatch, scale, N):
+    """dt |H| of 2..20: two to six squarings chosen from the norm BOUND; propagators against the oracle's Pade."""
+    monkeypatch.setenv("GRAPE_HOIST", "1")
+    n, K, E = 16, 3, 8
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, True, seed=5, scale=scale)
+    F_ref, G_ref = oracle.ensemble_eval("StateTransfer", A, B, Xi, Xt, wts, x, 1.0)
+    with qoc.GrapeEngine("StateTransfer", A, B, Xi, Xt, wts, 1.0, N) as eng:
+        assert eng.info["hoisted_controls"] == 1
+        F, G = eng.eval(x)
+        P = eng.trajectory(E - 1, states=False)[0]
+    assert_parity(F, G, F_ref, G_ref, n, what="squaring path")
+    P_ref = oracle.member_eval("StateTransfer", A[-1], B[-1], Xi[-1], Xt[-1], x, 1.0, trajectory=True)[2]
+    assert np.abs(P - P_ref).max() <= 1e-11 * max(1.0, np.abs(P_ref).max())
+
+
+def test_hoisted_batch_and_device_entry_points(qoc, oracle, monkeypatch):
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("GRAPE_HOIST", "1")
+    n, K, N, E = 16, 4, 29, 8
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, False, seed=77)
+    xs = np.stack([x, 0.5 * x, -x])
+    with qoc.GrapeEngine("CoherenceTransfer", A, B, Xi, Xt, wts, 0.9, N, max_batch=3) as eng:
+        assert eng.info["hoisted_controls"] == 1
+        Fb, Gb = eng.eval_batch(xs)
+        F1, G1 = eng.eval(x)
+        d_x = torch.tensor(np.asfortranarray(x).T.copy().reshape(-1), device="cuda")
+        d_fg = torch.empty(K * N + 1, dtype=torch.float64, device="cuda")
+        eng.eval_device(d_x.data_ptr(), d_fg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        fg = d_fg.cpu().numpy()
+    for b in range(3):
+        Fr, Gr = oracle.ensemble_eval("CoherenceTransfer", A, B, Xi, Xt, wts, xs[b], 0.9)
+        assert_parity(Fb[b], Gb[b], Fr, Gr, n, what=f"batch entry {b}")
+    assert F1 == Fb[0] and np.array_equal(G1, Gb[0])
+    assert fg[-1] == F1 and np.array_equal(fg[:-1].reshape(N, K).T, G1)
+
+
+def test_operators_reupload_switches_between_hoisted_and_per_member(qoc, oracle):
+    """grape_set_operators decides per upload: invariant B -> hoisted, member-dependent B -> per-member build."""
+    n, K, N, E = 16, 2, 17, 8
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, False, seed=3)
+    B2 = B.copy()
+    B2[3, 1] *= 1.25
+    with qoc.GrapeEngine("CoherenceTransfer", A, B, Xi, Xt, wts, 0.7, N) as eng:
+        for Bk, want in ((B, 1), (B2, 0), (B, 1)):
+            eng.set_operators(A, Bk, Xi, Xt, wts)
+            assert eng.info["hoisted_controls"] == want
+            F, G = eng.eval(x)
+            Fr, Gr = oracle.ensemble_eval("CoherenceTransfer", A, Bk, Xi, Xt, wts, x, 0.7)
+            assert_parity(F, G, Fr, Gr, n, what=f"upload (hoisted {want})")

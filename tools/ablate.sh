@@ -9,6 +9,6 @@ C=$ROOT/quoptimalcontrol.jl_amd/csrc
 mkdir -p $ROOT/build/abl
 for m in "$@"; do
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=on -DGRAPE_ABL=$m -c $C/sweep_pair.hip -o $ROOT/build/abl/sweep_pair_$m.o &&
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build/abl/libgrape_abl_$m.so $C/grape_api.o $C/sweep_small.o $ROOT/build/abl/sweep_pair_$m.o $C/sweep_tile.o $C/reduce.o $C/lbfgs.o $C/exact_grad.o $C/exact_tile.o -ldl ) &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build/abl/libgrape_abl_$m.so $C/grape_api.o $C/sweep_small.o $ROOT/build/abl/sweep_pair_$m.o $C/sweep_tile.o $C/sweep_thin.o $C/prop_hoist.o $C/reduce.o $C/lbfgs.o $C/exact_grad.o $C/exact_tile.o -ldl ) &
 done
 wait
