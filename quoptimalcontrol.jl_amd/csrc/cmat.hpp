@@ -6,6 +6,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "grape_kernels.hpp"   // kTheta8
+
 namespace grape {
 
 template <int N>
@@ -141,7 +143,7 @@ GRAPE_DEV void shfl_down(CMat<N> &dst, const CMat<N> &src, int delta)
 // 2^-53 |G|.  The reference calls Julia's LinearAlgebra.exp! (Higham-2005 Pade, restated in
 // oracle/grape_oracle.c); both are backward stable and agree to ~1e-16 per propagator.
 // ---------------------------------------------------------------------------------------
-constexpr double kTheta8 = 0.05;
+// kTheta8 (grape_kernels.hpp): the norm up to which the degree-8 polynomial is used unscaled
 
 constexpr double kSqrt177 = 13.304134695650071;
 constexpr double kX3 = 2.0 / 3.0;

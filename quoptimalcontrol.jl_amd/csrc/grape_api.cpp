@@ -853,7 +853,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                     }
                     if (!(cs <= best)) best = cs;                 // NaN-propagating maximum
                 }
-                hn[k] = best / 0.05;                               // / theta8 (cmat.hpp: kTheta8)
+                hn[k] = best / grape::kTheta8;
             }
             const size_t gc_elems = (size_t)c->B * c->cfg.n_slices * TSZ;
             if (!c->d_ha) {
@@ -1840,7 +1840,7 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
     info->expm_squarings = c->cfg.expm_squarings;
     info->kernel_family = c->family;
     info->unitary_flow = c->unitary ? 1 : 0;
-    info->expm_theta = 0.05;
+    info->expm_theta = grape::kTheta8;
     info->workspace_bytes = c->bytes;
     std::snprintf(info->arch, sizeof(info->arch), "%s", c->arch);
     info->n_devices = c->is_group ? (int32_t)c->sub.size() : 1;

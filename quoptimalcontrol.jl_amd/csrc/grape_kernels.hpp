@@ -7,6 +7,15 @@
 
 namespace grape {
 
+// Scaling threshold of the expm: a generator of norm bound theta <= kTheta8 goes through the degree-8 Taylor polynomial
+// unscaled, larger ones are halved s times first and the result squared s times.  The truncation error of the
+// polynomial is theta^9 / 9! = 3.7e-16 at 0.08 (absolute, |P| ~ 1) -- the size of one rounding error of its three
+// products, and 7e-13 if it added up coherently over 2000 slices, against the 1e-10 parity bar.  (Rounds 1-2 used
+// 0.05, the bound for a backward error of 2^-53 RELATIVE TO |G|; every slice of C4 and C5 sits below 0.08, 26 % / 40 %
+// of them above 0.05: one squaring -- a fourth matrix product -- each, and in C4 all of them in the far-detuned
+// members, whose workgroups then set the kernel's run time.)
+constexpr double kTheta8 = 0.08;
+
 // optional host-visible completion signal of an evaluation's FINAL kernel (reduce.hip: signal_done);
 // flag == nullptr: none (device-pointer entry points, intermediate kernels)
 struct DoneSignal {

@@ -77,14 +77,13 @@ __global__ __launch_bounds__(64) void ctrl_sum_kernel(const TileParams p)
 // ds_write2_b64: re and im come from their own register pairs and land in adjacent 8-byte words -- the same
 // interleaved double2 image as a ds_write_b128 of a packed quad, minus the eight v_mov_b32 that packing costs.
 // Offsets are in 8-byte units and at most 255: rows 2, 3 go through a second base address (+ 2 x 68 slots).
-// RAW: `im` (or `re`) may be the untouched result of an MFMA.  The compiler's hazard recogniser does not look inside
+// raw: `im` (or `re`) may be the untouched result of an MFMA.  The compiler's hazard recogniser does not look inside
 // inline assembly, so the wait states an LDS store needs behind a v_mfma_f64_16x16x4 that wrote its data register
-// (18, CDNA3/4 ISA "XDL write VGPR -> LDS read") are spelled out here.  RAW = false is for data a vector instruction
+// (18, CDNA3/4 ISA "XDL write VGPR -> LDS read") are spelled out here.  raw = false is for data a vector instruction
 // produced (the recogniser has put the wait in front of THAT instruction).
-template <bool RAW>
-GRAPE_DEV void img_write_tile(unsigned base, const d4 &re, const d4 &im)
+GRAPE_DEV void img_write_tile(unsigned base, const d4 &re, const d4 &im, bool raw)
 {
-    if (RAW)
+    if (raw)
         asm volatile("s_nop 15\n\ts_nop 2" ::: "memory");
     asm volatile("ds_write2_b64 %0, %1, %2 offset0:0 offset1:1" : : "v"(base), "v"(re[0]), "v"(im[0]) : "memory");
     asm volatile("ds_write2_b64 %0, %1, %2 offset0:136 offset1:137" : : "v"(base), "v"(re[1]), "v"(im[1]) : "memory");
@@ -110,6 +109,69 @@ GRAPE_DEV void img_read_tile(AOp &a, unsigned rd)
                  : "=&v"(a.v[0]), "=&v"(a.v[1]), "=&v"(a.v[2]), "=&v"(a.v[3])
                  : "v"(rd)
                  : "memory");
+}
+
+// the image read back as it was written (D registers r = 0..3 of the tile, re and im packed in one register quad): what a
+// 16-byte global store wants -- the LDS round trip packs the pairs without a vector instruction
+GRAPE_DEV void img_read_rows(AOp &a, unsigned wr)
+{
+    const unsigned wr2 = wr + 2 * 68 * 16;
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1088\n\tds_read_b128 %2, %5\n\t"
+                 "ds_read_b128 %3, %5 offset:1088\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a.v[0]), "=&v"(a.v[1]), "=&v"(a.v[2]), "=&v"(a.v[3])
+                 : "v"(wr), "v"(wr2)
+                 : "memory");
+}
+
+// x += c in the lanes of `mask` only (the diagonal of a D-layout tile): exec is narrowed around ONE v_add_f64 -- no 0/1
+// registers, no select
+GRAPE_DEV double add_masked(double x, double c, unsigned long long mask)
+{
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %3\n\tv_add_f64 %0, %0, %2\n\ts_mov_b64 exec, %1"
+                 : "+v"(x), "=&s"(save)
+                 : "s"(c), "s"(mask));
+    return x;
+}
+
+// LDS word read / write by byte address (the hand-over flag of the fused forward pass: a volatile C++ access would
+// go through the flat aperture)
+GRAPE_DEV int lds_load_word(unsigned addr)
+{
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+GRAPE_DEV void lds_store_word(unsigned addr, int v)
+{
+    asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v) : "memory");
+}
+
+// a pointer every lane agrees on, moved to scalar registers and typed as GLOBAL memory: accesses then take the SGPR base +
+// 32-bit lane offset form of global_load / global_store instead of a 64-bit address per lane kept (or spilled) across
+// the slice loop.  (Elements are plain vector types: HIP's double2 class does not live in a named address space.)
+typedef __attribute__((address_space(1))) d2v *gptr;
+typedef const __attribute__((address_space(1))) d2v *gcptr;
+GRAPE_DEV gptr uniform_global(const void *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (gptr)(((unsigned long long)hi << 32) | lo);
+}
+
+// The waves a SIMD hosts run the same program from the same start, and its arbiter favours the oldest: at C4 the first
+// workgroups of the fused-forward grid finished after 53 % of the kernel's run time and the last ones had the SIMDs to
+// themselves (one wave alone cannot cover its own LDS and matrix-core latencies).  A priority that rotates with TIME over
+// the wave slots -- every wave of a SIMD holds each of the four levels for the same share of the time, never two the
+// same level -- lets them progress together: all workgroups end within 10 % of each other, the kernel 5-6 % earlier.
+GRAPE_DEV void rotate_priority()
+{
+    const int slot = __builtin_amdgcn_s_getreg(6148);              // HW_REG_HW_ID[3:0]: wave slot on its SIMD
+    const int pr = ((int)(__builtin_amdgcn_s_memtime() >> 16) + slot) & 3;
+    if (pr == 0) __builtin_amdgcn_s_setprio(0);
+    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
 }
 
 // squarings from a norm bound already divided by theta8: 0 when v <= 1 (and for NaN: the polynomial propagates it),
@@ -178,56 +240,54 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
     const int k = blockIdx.y, z = blockIdx.z;
     double2 *img = s_hoist + (size_t)wave * kTileImage;
     double2 *s_vec = s_hoist + (size_t)WPB * kTileImage;           // FUSE: [v even | v odd | flag]
-    volatile int *s_flag = reinterpret_cast<volatile int *>(s_vec + 32);
-    const unsigned img_base = (unsigned)(size_t)img;               // LDS byte address (the low 32 bits of a __shared__ pointer)
+    const unsigned flag_addr = (unsigned)(size_t)(s_vec + 32);     // LDS byte addresses: the low 32 bits of a __shared__ pointer
+    const unsigned img_base = (unsigned)(size_t)img;
     const unsigned wr = img_base + 16u * (17 * (lane >> 4) + (lane & 15));
     const unsigned rd = img_base + 16u * (68 * ((lane & 15) >> 2) + 17 * (lane & 3) + (lane >> 4));
     if (FUSE) {
         if (threadIdx.x < 16)
             s_vec[threadIdx.x] = p.vecs[(size_t)k * 32 + threadIdx.x];
         if (threadIdx.x == 0)
-            *s_flag = 0;
+            *reinterpret_cast<int *>(s_vec + 32) = 0;
         __syncthreads();
     }
-    // A'_k stays in registers for every slice this wave walks
-    d4 Are, Aim, diag;
+    // A'_k stays in registers for every slice this wave walks; the diagonal of the tile as four lane masks
+    d4 Are, Aim;
+    unsigned long long dmask[4];
     {
-        const double2 *__restrict__ ha = p.ha + (size_t)k * TSZ;
+        const gcptr ha = uniform_global(p.ha + (size_t)k * TSZ);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const double2 v = ha[r * 64 + lane];
-            Are[r] = v.x;
-            Aim[r] = v.y;
-            diag[r] = (4 * r + (lane >> 4) == (lane & 15)) ? 1.0 : 0.0;
+            const d2v v = ha[r * 64 + lane];
+            Are[r] = v[0];
+            Aim[r] = v[1];
+            dmask[r] = __builtin_amdgcn_ballot_w64(4 * r + (lane >> 4) == (lane & 15));
         }
     }
     const double nA = p.ha_norm[k];
     const double *__restrict__ gcn = p.gcn + (size_t)z * p.N;
-    const double2 *__restrict__ gc = p.gc + (size_t)z * p.N * TSZ;
-    double2 *__restrict__ props = p.props + ((size_t)z * p.E + k) * (size_t)p.N * TSZ;
+    const gcptr gc = uniform_global(p.gc + (size_t)z * p.N * TSZ);
+    const gptr props = uniform_global(p.props + ((size_t)z * p.E + k) * (size_t)p.N * TSZ);
+    const gptr V = uniform_global(FUSE ? p.states + ((size_t)z * p.E + k) * (size_t)(p.N + 1) * 16 : p.states);
     const int t_lo = FUSE ? 0 : blockIdx.x * p.prop_slices;
     const int t_hi = FUSE ? p.N : min(p.N, t_lo + p.prop_slices);
     int t = t_lo + wave;
-    double2 gnext[4];
+    d2v gnext[4];
     if (t < t_hi) {
+        const gcptr g0 = gc + (size_t)t * TSZ;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            gnext[r] = gc[(size_t)t * TSZ + r * 64 + lane];
+            gnext[r] = g0[r * 64 + lane];
     }
     for (; t < t_hi; t += WPB) {
+        rotate_priority();
         d4 Gre, Gim;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            Gre[r] = Are[r] + gnext[r].x;
-            Gim[r] = Aim[r] + gnext[r].y;
+            Gre[r] = Are[r] + gnext[r][0];
+            Gim[r] = Aim[r] + gnext[r][1];
         }
         const int s = p.s_forced >= 0 ? p.s_forced : squarings_from_ratio(nA + gcn[t]);   // both already / theta8
-        {
-            const int tn = min(t + WPB, t_hi - 1);                 // next slice's control sum in flight (clamped: no branch)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                gnext[r] = gc[(size_t)tn * TSZ + r * 64 + lane];
-        }
         if (s > 0) {
             const double sc = ldexp(1.0, -s);
             Gre *= sc;
@@ -235,7 +295,7 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
         }
         AOp opa;
         d4 A2re, A2im, A4re, A4im, Tre, Tim, Ure, Uim;
-        img_write_tile<false>(wr, Gre, Gim);
+        img_write_tile(wr, Gre, Gim, false);
         img_read_tile(opa, rd);
         tile_prod(A2re, A2im, opa, Gre, Gim);                      // A2 = G G
 #pragma unroll
@@ -244,47 +304,69 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
             Tim[r] = fma(kC1, Gim[r], A2im[r]);
         }
         __builtin_amdgcn_sched_barrier(0);                         // A2im is a raw MFMA result: its first readers are the FMAs above
-        img_write_tile<false>(wr, A2re, A2im);
+        img_write_tile(wr, A2re, A2im, false);
         img_read_tile(opa, rd);
         tile_prod(A4re, A4im, opa, Tre, Tim);                      // A4' = A2 (A2 + c1 G)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             Ure[r] = fma(kC3, A2re[r], A4re[r]);
             Uim[r] = fma(kC3, A2im[r], A4im[r]);
-            Tre[r] = fma(kC7, A4re[r], fma(kX6, A2re[r], fma(kX5, Gre[r], kX4 * diag[r])));
+            Tre[r] = fma(kC7, A4re[r], fma(kX6, A2re[r], kX5 * Gre[r]));
             Tim[r] = fma(kC7, A4im[r], fma(kX6, A2im[r], kX5 * Gim[r]));
+            Tre[r] = add_masked(Tre[r], kX4, dmask[r]);
         }
-        img_write_tile<false>(wr, Ure, Uim);
+        img_write_tile(wr, Ure, Uim, false);
         img_read_tile(opa, rd);
         d4 Pre, Pim;
         tile_prod(Pre, Pim, opa, Tre, Tim);                        // A8'
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            Pre[r] = fma(kX2, Pre[r], fma(kY2, A2re[r], Gre[r] + diag[r]));
+            Pre[r] = fma(kX2, Pre[r], fma(kY2, A2re[r], Gre[r]));
             Pim[r] = fma(kX2, Pim[r], fma(kY2, A2im[r], Gim[r]));
+            Pre[r] = add_masked(Pre[r], 1.0, dmask[r]);
         }
         for (int i = 0; i < s; ++i) {
-            img_write_tile<true>(wr, Pre, Pim);
-                img_read_tile(opa, rd);
-                d4 Qre, Qim;
+            img_write_tile(wr, Pre, Pim, i > 0);
+            img_read_tile(opa, rd);
+            d4 Qre, Qim;
             tile_prod(Qre, Qim, opa, Pre, Pim);
             Pre = Qre;
             Pim = Qim;
         }
-        double2 *__restrict__ dst = props + (size_t)t * TSZ;
+        // P_t goes to memory through the image: read back as written for P_t itself, transposed for P_t^T (rank-one
+        // chain: odd slices are stored transposed, and the fused forward pass multiplies by the transposed registers)
         const bool transposed = p.thin && (t & 1);
-        if (FUSE || transposed) {
-            img_write_tile<true>(wr, Pre, Pim);
-                img_read_tile(opa, rd);                                // opa.v[r] = {re, im} of P^T's D register r
-            }
+        const gptr dst = props + (size_t)t * TSZ;
+        img_write_tile(wr, Pre, Pim, s > 0);
+        {   // the next slice's control sum: in flight during the conversions, the hand-over and the stores below
+            const int tn = min(t + WPB, t_hi - 1);                 // (clamped: no branch around the loads)
+            const gcptr g1 = gc + (size_t)tn * TSZ;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                gnext[r] = g1[r * 64 + lane];
+        }
+        if (!transposed) {
+            AOp pk;
+            img_read_rows(pk, wr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                dst[r * 64 + lane] = pk.v[r];
+        }
+        if (FUSE || transposed)
+            img_read_tile(opa, rd);                                // opa.v[r] = {re, im} of P^T's D register r
+        if (transposed) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                dst[r * 64 + lane] = opa.v[r];
+        }
         if (FUSE && p.fuse_fwd == 1) {
+            // the serial part of the kernel (N hand-overs per member): between the flag read and the flag write there is
+            // only LDS traffic -- no memory fence, the global stores above are not waited for
             const int g = lane >> 4, c = lane & 15;
             const double2 *vb = s_vec + (t & 1) * 16;
             double2 *vn = s_vec + ((t + 1) & 1) * 16;
-            double2 *__restrict__ V = p.states + ((size_t)z * p.E + k) * (size_t)(p.N + 1) * 16;
-            while (*s_flag != t)
+            while (lds_load_word(flag_addr) != t)
                 __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
             double acc[2] = {0.0, 0.0};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {                          // y[c] = sum_j P[c][j] v[j], j = 4 r + g
@@ -298,24 +380,14 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
             col_sum_n(acc);
             if (g == 0)
                 vn[c] = make_double2(acc[0], acc[1]);
-            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                    // this wave's reads of v_t and its write of v_{t+1} are done
             asm volatile("" ::: "memory");
-            if (lane == 0)
-                *s_flag = t + 1;
+            lds_store_word(flag_addr, t + 1);
             if (g == 0) {
-                V[(size_t)t * 16 + c] = rec;
+                V[(size_t)t * 16 + c] = (d2v){rec.x, rec.y};
                 if (t == p.N - 1)
-                    V[(size_t)p.N * 16 + c] = make_double2(acc[0], acc[1]);
+                    V[(size_t)p.N * 16 + c] = (d2v){acc[0], acc[1]};
             }
-        }
-        if (transposed) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                dst[r * 64 + lane] = make_double2(opa.v[r][0], opa.v[r][1]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                dst[r * 64 + lane] = make_double2(Pre[r], Pim[r]);
         }
     }
 }
