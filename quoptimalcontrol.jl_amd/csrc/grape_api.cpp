@@ -822,7 +822,6 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         const char *he = std::getenv("GRAPE_HOIST");
         if (he && he[0] == '0') hz = false;
         if (hz && !(he && he[0] == '1') && c->EU < 8) hz = false;
-        if (hz && c->NT != 1) hz = false;
         for (size_t k = 1; k < E && hz; ++k)
             hz = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
         c->hoist = hz;

@@ -194,27 +194,34 @@ GRAPE_DEV int squarings_from_ratio(double v)
 // (tile.hpp tprod), written so that the only vector instructions are the 8 operand sums and the 8 combinations
 GRAPE_DEV void tile_prod(d4 &ore, d4 &oim, const AOp &a, const d4 &wre, const d4 &wim)
 {
-    d4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        t1 = GRAPE_MFMA(a.v[kb][0], wre[kb], t1);
-        t2 = GRAPE_MFMA(a.v[kb][1], wim[kb], t2);
-    }
+    // vector instructions placed BETWEEN matrix-core instructions cost ~7 cycles each instead of ~4.4 in a burst
+    // (tools/ubench/pipe_mix.hip, experiment C): the operand sums go in front of the first chain, the combinations
+    // between the chains, and the scheduler is kept from spreading them (sched_barrier)
     double as[4], bs[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         as[kb] = a.v[kb][0] + a.v[kb][1];
         bs[kb] = wre[kb] + wim[kb];
     }
+    __builtin_amdgcn_sched_barrier(0);
+    d4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        t1 = GRAPE_MFMA(a.v[kb][0], wre[kb], t1);
+        t2 = GRAPE_MFMA(a.v[kb][1], wim[kb], t2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     d4 t3;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         ore[r] = t1[r] - t2[r];
         t3[r] = -t1[r] - t2[r];                                    // one v_add_f64 with both operands negated
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
         t3 = GRAPE_MFMA(as[kb], bs[kb], t3);
+    __builtin_amdgcn_sched_barrier(0);
     oim = t3;
 }
 
@@ -393,6 +400,292 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// NT = 2 (n = 17..32): FOUR waves share one propagator, wave (I, J) owns tile (I, J) of every matrix of the polynomial.
+//
+// Round 2's kernel gave a wave the whole 2 x 2-tile matrix: ~450 live registers, 164 of them on the AGPR side of the
+// file where vector instructions cannot reach them -- 1 350 of its 2 255 vector instructions per slice only moved
+// data between the two halves (profiles/r02_C5_E4096_pmc.json).  Here a wave keeps 16 registers per matrix, and
+// the operands of a product travel through LDS, where the layout conversion had to go anyway:
+//   * every factor is written ONCE, by the owners of its tiles, as the padded image of tile.hpp plus a third plane
+//     holding re + im (the operand sums of the three-product complex multiplication are formed once per element
+//     instead of once per consumer);
+//   * read with the transposing pattern an image tile is an A operand, read back as written it is a B operand;
+//   * wave (I, J) multiplies  sum_Kt X(I, Kt) Y(Kt, J):  Kt = I first, with its OWN tile of Y from registers, then
+//     Kt = 1 - I with Y(1 - I, J) from the image -- 24 matrix-core instructions per product and wave.
+// Two workgroup barriers per product: one behind the image writes, one behind the operand reads (all operands are in
+// registers before the first MFMA), so the compute phases of the four waves -- and of the second workgroup on the
+// CU -- are free to drift apart.  One slice at a time per workgroup; A'_k's tile stays in registers.
+constexpr int kImg2Plane = kTileImage * 16;                        // bytes of the interleaved (re, im) plane of one tile
+constexpr int kImg2Tile = kImg2Plane + kTileImage * 8 + 8;         // + the sum plane; 16-byte aligned
+constexpr int kImg2Matrix = 4 * kImg2Tile;
+
+struct Tile3 {                                                     // one tile of a factor in D layout + its operand sums
+    d4 re, im, sm;
+};
+struct AOp3 {                                                      // A operand of one tile: (re, im) per k-block + the sums
+    d2v v[4];
+    d2v s01, s23;
+};
+struct BOp3 {                                                      // B operand of one tile read back from an image
+    d2v v[4];
+    d2v s01, s23;
+};
+
+// tile (re, im, sum) -> image.  `plane`: LDS byte address of the tile's (re, im) plane + this lane's write offset
+GRAPE_DEV void img2_write(unsigned plane, unsigned sums, const Tile3 &t)
+{
+    // rows 0, 1 pairwise (re and im land in adjacent words); rows 2, 3 lie beyond the 8-bit offsets of ds_write2 and go
+    // word by word with 16-bit byte offsets: no second base address, no address arithmetic in the slice loop
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:0 offset1:1" : : "v"(plane), "v"(t.re[0]), "v"(t.im[0]) : "memory");
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:136 offset1:137" : : "v"(plane), "v"(t.re[1]), "v"(t.im[1]) : "memory");
+    asm volatile("ds_write_b64 %0, %1 offset:2176" : : "v"(plane), "v"(t.re[2]) : "memory");
+    asm volatile("ds_write_b64 %0, %1 offset:2184" : : "v"(plane), "v"(t.im[2]) : "memory");
+    asm volatile("ds_write_b64 %0, %1 offset:3264" : : "v"(plane), "v"(t.re[3]) : "memory");
+    asm volatile("ds_write_b64 %0, %1 offset:3272" : : "v"(plane), "v"(t.im[3]) : "memory");
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:0 offset1:68" : : "v"(sums), "v"(t.sm[0]), "v"(t.sm[1]) : "memory");
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:136 offset1:204" : : "v"(sums), "v"(t.sm[2]), "v"(t.sm[3]) : "memory");
+}
+
+// no wait inside: the caller drains all reads of a product together (img2_wait)
+GRAPE_DEV void img2_read_a(AOp3 &a, unsigned plane_rd, unsigned sums_rd)
+{
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a.v[0]) : "v"(plane_rd) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(a.v[1]) : "v"(plane_rd) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:128" : "=v"(a.v[2]) : "v"(plane_rd) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:192" : "=v"(a.v[3]) : "v"(plane_rd) : "memory");
+    asm volatile("ds_read2_b64 %0, %1 offset0:0 offset1:4" : "=v"(a.s01) : "v"(sums_rd) : "memory");
+    asm volatile("ds_read2_b64 %0, %1 offset0:8 offset1:12" : "=v"(a.s23) : "v"(sums_rd) : "memory");
+}
+GRAPE_DEV void img2_read_b(BOp3 &b, unsigned plane_wr, unsigned sums_wr)
+{
+    asm volatile("ds_read_b128 %0, %1" : "=v"(b.v[0]) : "v"(plane_wr) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:1088" : "=v"(b.v[1]) : "v"(plane_wr) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:2176" : "=v"(b.v[2]) : "v"(plane_wr) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:3264" : "=v"(b.v[3]) : "v"(plane_wr) : "memory");
+    asm volatile("ds_read2_b64 %0, %1 offset0:0 offset1:68" : "=v"(b.s01) : "v"(sums_wr) : "memory");
+    asm volatile("ds_read2_b64 %0, %1 offset0:136 offset1:204" : "=v"(b.s23) : "v"(sums_wr) : "memory");
+}
+// every register the reads above fill is an in/out operand of the wait: no consumer can be scheduled in front of it
+GRAPE_DEV void img2_wait(AOp3 &a0, AOp3 &a1, BOp3 &b)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a0.v[0]), "+v"(a0.v[1]), "+v"(a0.v[2]), "+v"(a0.v[3]), "+v"(a0.s01), "+v"(a0.s23), "+v"(a1.v[0]),
+                   "+v"(a1.v[1]), "+v"(a1.v[2]), "+v"(a1.v[3]), "+v"(a1.s01), "+v"(a1.s23), "+v"(b.v[0]), "+v"(b.v[1]),
+                   "+v"(b.v[2]), "+v"(b.v[3]), "+v"(b.s01), "+v"(b.s23)
+                 :
+                 : "memory");
+}
+GRAPE_DEV void lds_drain_and_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// (ore, oim) = X(I, I) own(I, J) + X(I, 1 - I) Y(1 - I, J): a0 = X(I, I), a1 = X(I, 1 - I) as A operands, `own` this wave's
+// tile of Y (registers), b = Y(1 - I, J) read back from the image
+GRAPE_DEV void tile2_prod(d4 &ore, d4 &oim, const AOp3 &a0, const AOp3 &a1, const Tile3 &own, const BOp3 &b)
+{
+    __builtin_amdgcn_sched_barrier(0);                             // vector work stays in bursts outside the MFMA chains
+    d4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        t1 = GRAPE_MFMA(a0.v[kb][0], own.re[kb], t1);
+        t2 = GRAPE_MFMA(a0.v[kb][1], own.im[kb], t2);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        t1 = GRAPE_MFMA(a1.v[kb][0], b.v[kb][0], t1);
+        t2 = GRAPE_MFMA(a1.v[kb][1], b.v[kb][1], t2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    d4 t3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        ore[r] = t1[r] - t2[r];
+        t3[r] = -t1[r] - t2[r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    t3 = GRAPE_MFMA(a0.s01[0], own.sm[0], t3);
+    t3 = GRAPE_MFMA(a0.s01[1], own.sm[1], t3);
+    t3 = GRAPE_MFMA(a0.s23[0], own.sm[2], t3);
+    t3 = GRAPE_MFMA(a0.s23[1], own.sm[3], t3);
+    t3 = GRAPE_MFMA(a1.s01[0], b.s01[0], t3);
+    t3 = GRAPE_MFMA(a1.s01[1], b.s01[1], t3);
+    t3 = GRAPE_MFMA(a1.s23[0], b.s23[0], t3);
+    t3 = GRAPE_MFMA(a1.s23[1], b.s23[1], t3);
+    __builtin_amdgcn_sched_barrier(0);
+    oim = t3;
+}
+
+constexpr int kHoist2Slices = 16;                                  // slices a workgroup walks (A'_k's tiles loaded once)
+
+__global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
+{
+    constexpr int TSZ = 1024;
+    extern __shared__ double2 s_hoist[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int I = wave >> 1, J = wave & 1, tile = wave;            // own tile (I, J) = dump tile I * 2 + J
+    const int k = blockIdx.y, z = blockIdx.z;
+    const unsigned lds0 = (unsigned)(size_t)s_hoist;
+    const unsigned wr_off = 16u * (17 * (lane >> 4) + (lane & 15));
+    const unsigned rd_off = 16u * (68 * ((lane & 15) >> 2) + 17 * (lane & 3) + (lane >> 4));
+    // image X (A-operand role; both roles for G G and the squarings) and image Y (B-operand role)
+    const unsigned imgX = lds0, imgY = lds0 + kImg2Matrix;
+    auto plane_of = [&](unsigned img, int t) { return img + (unsigned)t * kImg2Tile; };
+    const unsigned own_x_wr = plane_of(imgX, tile) + wr_off, own_x_sm = plane_of(imgX, tile) + kImg2Plane + wr_off / 2;
+    const unsigned own_y_wr = plane_of(imgY, tile) + wr_off, own_y_sm = plane_of(imgY, tile) + kImg2Plane + wr_off / 2;
+    const unsigned a0_rd = plane_of(imgX, I * 2 + I) + rd_off, a0_sm = plane_of(imgX, I * 2 + I) + kImg2Plane + rd_off / 2;
+    const unsigned a1_rd = plane_of(imgX, I * 2 + (1 - I)) + rd_off, a1_sm = plane_of(imgX, I * 2 + (1 - I)) + kImg2Plane + rd_off / 2;
+    const int tb = (1 - I) * 2 + J;                                // Y(1 - I, J)
+    const unsigned bx_wr = plane_of(imgX, tb) + wr_off, bx_sm = plane_of(imgX, tb) + kImg2Plane + wr_off / 2;
+    const unsigned by_wr = plane_of(imgY, tb) + wr_off, by_sm = plane_of(imgY, tb) + kImg2Plane + wr_off / 2;
+
+    unsigned long long dmask[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        dmask[r] = (I == J) ? __builtin_amdgcn_ballot_w64(4 * r + (lane >> 4) == (lane & 15)) : 0ull;
+    // A'_k's tile is re-read from L2 with every slice's control sum (16 registers kept free: three waves per SIMD)
+    const gcptr ha = uniform_global(p.ha + (size_t)k * TSZ + tile * 256);
+    const double nA = p.ha_norm[k];
+    const double *__restrict__ gcn = p.gcn + (size_t)z * p.N;
+    const gcptr gc = uniform_global(p.gc + (size_t)z * p.N * TSZ + tile * 256);
+    const gptr props = uniform_global(p.props + ((size_t)z * p.E + k) * (size_t)p.N * TSZ + tile * 256);
+    const int t_lo = blockIdx.x * p.prop_slices, t_hi = min(p.N, t_lo + p.prop_slices);
+    d2v gnext[4], anext[4];
+    if (t_lo < t_hi) {
+        const gcptr g0 = gc + (size_t)t_lo * TSZ;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gnext[r] = g0[r * 64 + lane];
+            anext[r] = ha[r * 64 + lane];
+        }
+    }
+    for (int t = t_lo; t < t_hi; ++t) {
+        rotate_priority();
+        Tile3 G;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            G.re[r] = anext[r][0] + gnext[r][0];
+            G.im[r] = anext[r][1] + gnext[r][1];
+        }
+        const int s = p.s_forced >= 0 ? p.s_forced : squarings_from_ratio(nA + gcn[t]);
+        if (s > 0) {
+            const double sc = ldexp(1.0, -s);
+            G.re *= sc;
+            G.im *= sc;
+        }
+        G.sm = G.re + G.im;
+        AOp3 a0, a1;
+        BOp3 b;
+        d4 A2re, A2im, A4re, A4im;
+        // ---- A2 = G G: one image in both roles
+        img2_write(own_x_wr, own_x_sm, G);
+        lds_drain_and_barrier();
+        img2_read_a(a0, a0_rd, a0_sm);
+        img2_read_a(a1, a1_rd, a1_sm);
+        img2_read_b(b, bx_wr, bx_sm);
+        img2_wait(a0, a1, b);
+        __builtin_amdgcn_s_barrier();
+        tile2_prod(A2re, A2im, a0, a1, G, b);
+        // ---- A4' = A2 (A2 + c1 G)
+        Tile3 X, Y;
+        X.re = A2re;
+        X.im = A2im;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Y.re[r] = fma(kC1, G.re[r], A2re[r]);
+            Y.im[r] = fma(kC1, G.im[r], A2im[r]);
+        }
+        X.sm = X.re + X.im;
+        Y.sm = Y.re + Y.im;
+        __builtin_amdgcn_sched_barrier(0);                         // the raw MFMA result A2im has been read by the vector ALU above
+        img2_write(own_x_wr, own_x_sm, X);
+        img2_write(own_y_wr, own_y_sm, Y);
+        lds_drain_and_barrier();
+        img2_read_a(a0, a0_rd, a0_sm);
+        img2_read_a(a1, a1_rd, a1_sm);
+        img2_read_b(b, by_wr, by_sm);
+        img2_wait(a0, a1, b);
+        __builtin_amdgcn_s_barrier();
+        tile2_prod(A4re, A4im, a0, a1, Y, b);
+        // ---- A8' = (A4' + c3 A2) (x4 I + x5 G + x6 A2 + c7 A4')
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            X.re[r] = fma(kC3, A2re[r], A4re[r]);
+            X.im[r] = fma(kC3, A2im[r], A4im[r]);
+            Y.re[r] = fma(kC7, A4re[r], fma(kX6, A2re[r], kX5 * G.re[r]));
+            Y.im[r] = fma(kC7, A4im[r], fma(kX6, A2im[r], kX5 * G.im[r]));
+            Y.re[r] = add_masked(Y.re[r], kX4, dmask[r]);
+        }
+        X.sm = X.re + X.im;
+        Y.sm = Y.re + Y.im;
+        __builtin_amdgcn_sched_barrier(0);
+        img2_write(own_x_wr, own_x_sm, X);
+        img2_write(own_y_wr, own_y_sm, Y);
+        lds_drain_and_barrier();
+        img2_read_a(a0, a0_rd, a0_sm);
+        img2_read_a(a1, a1_rd, a1_sm);
+        img2_read_b(b, by_wr, by_sm);
+        img2_wait(a0, a1, b);
+        __builtin_amdgcn_s_barrier();
+        Tile3 P;
+        tile2_prod(P.re, P.im, a0, a1, Y, b);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            P.re[r] = fma(kX2, P.re[r], fma(kY2, A2re[r], G.re[r]));
+            P.im[r] = fma(kX2, P.im[r], fma(kY2, A2im[r], G.im[r]));
+            P.re[r] = add_masked(P.re[r], 1.0, dmask[r]);
+        }
+        for (int i = 0; i < s; ++i) {                              // P <- P P
+            P.sm = P.re + P.im;
+            __builtin_amdgcn_sched_barrier(0);
+            img2_write(own_x_wr, own_x_sm, P);
+            lds_drain_and_barrier();
+            img2_read_a(a0, a0_rd, a0_sm);
+            img2_read_a(a1, a1_rd, a1_sm);
+            img2_read_b(b, bx_wr, bx_sm);
+            img2_wait(a0, a1, b);
+            __builtin_amdgcn_s_barrier();
+            Tile3 Q;
+            tile2_prod(Q.re, Q.im, a0, a1, P, b);
+            P.re = Q.re;
+            P.im = Q.im;
+        }
+        // ---- next slice's control sum in flight; P_t's tile packed through the wave's own region of image Y (nobody reads
+        //      image Y before the next slice's second product) and stored
+        {
+            const int tn = min(t + 1, t_hi - 1);
+            const gcptr g1 = gc + (size_t)tn * TSZ;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                gnext[r] = g1[r * 64 + lane];
+                anext[r] = ha[r * 64 + lane];
+            }
+        }
+        if (s > 0)
+            asm volatile("s_nop 15\n\ts_nop 2" ::: "memory");      // P.im is a raw MFMA result after a squaring
+        {
+            asm volatile("ds_write2_b64 %0, %1, %2 offset0:0 offset1:1" : : "v"(own_y_wr), "v"(P.re[0]), "v"(P.im[0]) : "memory");
+            asm volatile("ds_write2_b64 %0, %1, %2 offset0:136 offset1:137" : : "v"(own_y_wr), "v"(P.re[1]), "v"(P.im[1]) : "memory");
+            asm volatile("ds_write_b64 %0, %1 offset:2176" : : "v"(own_y_wr), "v"(P.re[2]) : "memory");
+            asm volatile("ds_write_b64 %0, %1 offset:2184" : : "v"(own_y_wr), "v"(P.im[2]) : "memory");
+            asm volatile("ds_write_b64 %0, %1 offset:3264" : : "v"(own_y_wr), "v"(P.re[3]) : "memory");
+            asm volatile("ds_write_b64 %0, %1 offset:3272" : : "v"(own_y_wr), "v"(P.im[3]) : "memory");
+            AOp pk;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1088\n\tds_read_b128 %2, %4 offset:2176\n\t"
+                         "ds_read_b128 %3, %4 offset:3264\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(pk.v[0]), "=&v"(pk.v[1]), "=&v"(pk.v[2]), "=&v"(pk.v[3])
+                         : "v"(own_y_wr)
+                         : "memory");
+            const gptr dst = props + (size_t)t * TSZ;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                dst[r * 64 + lane] = pk.v[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 hipError_t launch_ctrl_sum(int NT, const TileParams &p, hipStream_t stream)
 {
     const dim3 grid(p.N, p.n_x), block(64);
@@ -416,6 +709,13 @@ hipError_t launch_prop_hoist(int NT, const TileParams &q, hipStream_t stream)
             hipLaunchKernelGGL((prop_hoist1_kernel<true>), grid, block, lds, stream, q);
         else
             hipLaunchKernelGGL((prop_hoist1_kernel<false>), grid, block, lds, stream, q);
+        return hipGetLastError();
+    }
+    if (NT == 2) {
+        const size_t lds = 2 * (size_t)kImg2Matrix;
+        const int per = q.prop_slices;
+        const dim3 grid((q.N + per - 1) / per, q.E, q.n_x), block(256);
+        hipLaunchKernelGGL(prop_hoist2_kernel, grid, block, lds, stream, q);
         return hipGetLastError();
     }
     return hipErrorInvalidValue;

@@ -1228,9 +1228,9 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         // problem of 2000 slices ran 32 workgroups: 235 us) -- as many as make ONE round of resident workgroups
         // (NT = 2 holds a CU per workgroup, NT = 1 a quarter), in multiples of the four waves
         int per_block = WPB;
-        const bool hoisted = p.hoist && NT == 1;                   // prop_hoist.hip: A'_k in registers, nothing staged
+        const bool hoisted = p.hoist != 0;                         // prop_hoist.hip: A'_k in registers, nothing staged
         if (q.stage_ops || hoisted) {
-            const long resident = (long)(p.cus > 0 ? p.cus : 256) * (NT == 1 ? 4 : 1);
+            const long resident = (long)(p.cus > 0 ? p.cus : 256) * (NT == 1 ? 4 : (hoisted ? 3 : 1));
             const long total = (long)p.N * p.E * p.n_x;
             const long want = ((total + resident - 1) / resident + WPB - 1) / WPB * WPB;
             per_block = (int)std::min<long>(kPropSlices, std::max<long>(WPB, want));

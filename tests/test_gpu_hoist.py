@@ -55,6 +55,11 @@ CASES = [  # n, K, N, E, sys_type, Hermitian drift, rank-one states, state colum
     (16, 2, 19, 9, "UnitaryGate", True, False, None),              # unitary flow
     (9, 5, 12, 8, "StateTransfer", True, False, None),
     (16, 1, 1, 8, "CoherenceTransfer", False, True, None),         # a single slice
+    (32, 6, 20, 8, "UnitaryGate", True, False, None),              # two-tile family: four waves per propagator (C5's shape)
+    (32, 3, 7, 9, "StateTransfer", False, False, None),            # general flow, non-Hermitian generator
+    (24, 2, 11, 8, "CoherenceTransfer", True, False, None),        # zero-padded second tile
+    (17, 4, 5, 8, "UnitaryGate", False, False, None),
+    (32, 2, 1, 8, "UnitaryGate", True, False, None),
 ]
 
 
@@ -91,10 +96,11 @@ def test_hoisted_control_sum_matches_oracle_and_per_member_build(qoc, oracle, mo
 
 
 @pytest.mark.parametrize("scale,N", [(6.0, 9), (40.0, 5)])
-def test_hoisted_squaring_path_and_propagators(qoc, oracle, monkeypatch, scale, N):
+@pytest.mark.parametrize("n", [16, 32])
+def test_hoisted_squaring_path_and_propagators(qoc, oracle, monkeypatch, scale, N, n):
     """dt |H| of 2..20: two to six squarings chosen from the norm BOUND; propagators against the oracle's Pade."""
     monkeypatch.setenv("GRAPE_HOIST", "1")
-    n, K, E = 16, 3, 8
+    K, E = 3, 8
     A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, True, seed=5, scale=scale)
     F_ref, G_ref = oracle.ensemble_eval("StateTransfer", A, B, Xi, Xt, wts, x, 1.0)
     with qoc.GrapeEngine("StateTransfer", A, B, Xi, Xt, wts, 1.0, N) as eng:
