@@ -100,45 +100,103 @@ def cpu_baseline(workload, seconds, sample_members):
     }, (foms, grads)
 
 
-def roofline(local, info, kern_ms, kern_n, evals_per_s, n_gpus, traffic):
-    """The dominant kernel of one shard (`local` = the members this rank owns) against its roof."""
-    avg_ms = kern_ms / max(kern_n, 1)
-    sec = avg_ms * 1e-3
+def _stats_us(ms):
+    import numpy as np
+    a = np.asarray(ms, dtype=float) * 1e3
+    if a.size == 0:
+        return {"kernel_avg_us": 0.0, "kernel_min_us": 0.0, "kernel_median_us": 0.0, "kernel_launches": 0}
+    return {"kernel_avg_us": float(a.mean()), "kernel_min_us": float(a.min()), "kernel_median_us": float(np.median(a)),
+            "kernel_launches": int(a.size)}
+
+
+def tile_kernel_models(local, info):
+    """Work of the two halves of a tile-family (n = 5..32) evaluation AS RUN: matrix-core flops
+    = v_mfma_f64_16x16x4 instructions x 2048 (a complex tile product is 12 of them: three real products), HBM bytes =
+    the padded D-layout dumps each kernel writes / reads.  Squarings (data dependent, none at the BASELINE configs with
+    theta8 = 0.08) are not counted."""
+    n, K, N, E = local.n, local.K, local.N, local.E
+    NT = 1 if n <= 16 else 2
+    units = (E + 1) // 2 if n <= 8 else E                  # n <= 8: two members share a tile
+    tsz = (16 * NT) ** 2 * 16                              # bytes of one matrix dump
+    prod = 12 * NT ** 3 * 2048                             # flops of one complex tile-matrix product
+    thin, fused, uni = bool(info.get("rank_one_chain")), bool(info.get("fused_forward")), bool(info.get("unitary_flow"))
+    sand = local.sys_type != "UnitaryGate"
+    expm = {"name": "expm: " + ("ctrl_sum_kernel + prop_hoist kernel" if info.get("hoisted_controls") else "prop_tile_kernel"),
+            "flops": units * N * 3 * prod, "bytes": units * N * tsz + (units * (N + 1) * 256 if fused else 0)}
+    if thin:
+        chain = {"name": "chain_thin_kernel (matrix-vector chain" + (", backward pass only)" if fused else ", both passes)"),
+                 "flops": units * N * ((1 if fused else 2) * 8 * 256 + K * 14 * 256),
+                 "bytes": units * N * tsz * (1 if fused else 2) + units * (N + 1) * 256 * (1 if fused else 2)}
+    elif uni:
+        chain = {"name": "chain_tile_unitary_kernel (M_t = P' M P, forward product P^T V)", "flops": units * N * 3 * prod,
+                 "bytes": units * N * tsz * 2}
+    else:
+        q = 6 if sand else 3
+        chain = {"name": "chain_tile kernels (general flow: forward states stored)", "flops": units * N * q * prod,
+                 "bytes": units * N * tsz * 4}
+    return expm, chain
+
+
+def roofline(local, info, samples, evals_per_s, n_gpus, traffic, profile=None):
+    """The dominant kernel of one shard (`local` = the members this rank owns) against its roof.
+    samples = (total_ms[], first_ms[]) of the evaluations inside the timed region (HIP events on the launch stream)."""
+    import numpy as np
+    tot_ms, first_ms = (np.asarray(a, dtype=float) for a in samples)
+    st = _stats_us(tot_ms)
+    sec = st["kernel_avg_us"] * 1e-6
     uni = bool(info.get("unitary_flow"))
     thin = bool(info.get("rank_one_chain"))
     alg_bytes, alg_flops = local.algorithmic_bytes, local.algorithmic_flops
     fused = bool(info.get("fused_forward"))
     chunks = int(info.get("time_chunks") or 0)
-    flow_bytes, flow_flops = local.flow_bytes(uni, thin, fused), local.flow_flops(uni, thin, chunked=chunks > 1)
-    gbs = alg_bytes / sec / 1e9 if sec > 0 else 0.0
-    tfs = alg_flops / sec / 1e12 if sec > 0 else 0.0
-    flow = {"name": ("rank-one states: MFMA expm + forward vector pass in one kernel, then the backward vector pass "
-                     "(P_t written once, read once)" if fused else
-                     "rank-one states: MFMA expm, then a matrix-vector chain (P_t written once, read twice)") if thin
-                    else ((f"unitary (P_t only), time axis in {chunks} parallel chunks" if chunks > 1 else "unitary (P_t only)")
-                          if uni else "general (model S)"),
-            "bytes_per_launch": flow_bytes,
-            "achieved_GBs": flow_bytes / sec / 1e9 if sec > 0 else 0.0,
-            "frac_hbm": flow_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else 0.0,
-            "flops_per_launch": flow_flops,
-            "achieved_TFLOPs": flow_flops / sec / 1e12 if sec > 0 else 0.0,
-            "frac_fp64": flow_flops / sec / 1e12 / FP64_PEAK_TFLOPS if sec > 0 else 0.0}
-    if info.get("kernel_family") == 1:            # n > 4: FP64 matrix-core kernels, compute-bound
-        roof = {"bound": "mfma", "achieved": tfs, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tfs / FP64_PEAK_TFLOPS, "traffic": traffic,
-                "kernel": "prop_tile_kernel + " + ("chain_thin_kernel" if thin else "chain_tile*_kernel"),
-                "algorithmic_flops_per_launch": alg_flops,
-                "end_to_end_frac": alg_flops * evals_per_s / 1e12 / FP64_PEAK_TFLOPS}
+    if info.get("kernel_family") == 1:            # n > 4: FP64 matrix-core kernels
+        # priced PER KERNEL on the flow actually run (the rank-one / unitary / chunked flows do less work than model S,
+        # so model-S flops over their run time can exceed the peak: kept below as model_s_equivalent only)
+        expm, chain = tile_kernel_models(local, info)
+        t_first = float(first_ms.mean()) * 1e-3 if first_ms.size else 0.0
+        parts = []
+        for part, t in ((expm, t_first), (chain, max(sec - t_first, 0.0))):
+            tf = part["flops"] / t / 1e12 if t > 0 else 0.0
+            gb = part["bytes"] / t / 1e9 if t > 0 else 0.0
+            fm, fh = tf / FP64_PEAK_TFLOPS, gb / HBM_PEAK_GBS
+            parts.append({"kernel": part["name"], "avg_us": 1e6 * t, "mfma_flops_per_launch": part["flops"],
+                          "hbm_bytes_per_launch": part["bytes"], "achieved_TFLOPs": tf, "achieved_GBs": gb,
+                          "frac_mfma": fm, "frac_hbm": fh, "bound": "mfma" if fm >= fh else "hbm"})
+        dom = max(parts, key=lambda d: d["avg_us"])
+        mf = dom["bound"] == "mfma"
+        roof = {"bound": dom["bound"], "achieved": dom["achieved_TFLOPs"] if mf else dom["achieved_GBs"],
+                "peak": FP64_PEAK_TFLOPS if mf else HBM_PEAK_GBS, "unit": "TFLOP/s" if mf else "GB/s",
+                "frac": dom["frac_mfma"] if mf else dom["frac_hbm"], "traffic": traffic,
+                "kernel": dom["kernel"], "kernels": parts,
+                "model_s_equivalent": {"flops_per_launch": alg_flops, "TFLOPs": alg_flops / sec / 1e12 if sec > 0 else 0.0,
+                                       "frac_fp64": alg_flops / sec / 1e12 / FP64_PEAK_TFLOPS if sec > 0 else 0.0,
+                                       "end_to_end_frac": alg_flops * evals_per_s / 1e12 / FP64_PEAK_TFLOPS,
+                                       "note": "SURVEY.md 8d model-S flops (dense four-product flow) over the measured run time: "
+                                               "exceeds 1 where the flow run does less work than model S"},
+                "note": "frac = work of the flow ACTUALLY RUN by the dominant (longer) kernel / its HIP-event time / peak: "
+                        "matrix-core flops = MFMA instructions x 2048, HBM bytes = dumps written + read; `kernels` prices both halves"}
+        if profile:
+            roof["mfma_utilisation_from_profile"] = profile
     else:
+        gbs = alg_bytes / sec / 1e9 if sec > 0 else 0.0
+        flow_bytes, flow_flops = local.flow_bytes(uni, thin, fused), local.flow_flops(uni, thin, chunked=chunks > 1)
+        flow = {"name": (f"unitary (P_t only), time axis in {chunks} parallel chunks" if chunks > 1 else "unitary (P_t only)")
+                        if uni else "general (model S)",
+                "bytes_per_launch": flow_bytes,
+                "achieved_GBs": flow_bytes / sec / 1e9 if sec > 0 else 0.0,
+                "frac_hbm": flow_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else 0.0,
+                "flops_per_launch": flow_flops,
+                "achieved_TFLOPs": flow_flops / sec / 1e12 if sec > 0 else 0.0,
+                "frac_fp64": flow_flops / sec / 1e12 / FP64_PEAK_TFLOPS if sec > 0 else 0.0}
         roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "sweep_pair_kernel" if info.get("lane_pair") else "sweep_small_kernel",
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "end_to_end_frac": alg_bytes * evals_per_s / 1e9 / HBM_PEAK_GBS}
-    roof.update({"kernel_avg_us": 1e3 * avg_ms, "kernel_launches": kern_n, "flow": flow,
-                 "note": "achieved/frac price the sweep kernel with the ALGORITHMIC work of SURVEY.md 8d "
-                         "(model S); `flow` prices the same launches with the bytes/flops of the data flow "
-                         "actually run; end_to_end_frac = algorithmic work x this rank's evals/s / peak"})
+                "end_to_end_frac": alg_bytes * evals_per_s / 1e9 / HBM_PEAK_GBS, "flow": flow,
+                "note": "achieved/frac price the sweep kernel with the ALGORITHMIC bytes of SURVEY.md 8d "
+                        "(model S); `flow` prices the same launches with the bytes/flops of the data flow "
+                        "actually run; end_to_end_frac = algorithmic work x this rank's evals/s / peak"}
+    roof.update(st)
     if traffic is not None:
         roof["traffic_source"] = ("HBM bytes of the timed kernels per evaluation = (2*FETCH_SIZE + WRITE_SIZE) KiB from the rocprofv3 "
                                   "--pmc passes of this command committed under profiles/ (profiles/traffic.json names the file); "
@@ -154,6 +212,29 @@ def committed_traffic(key):
         return float(v) if v is not None else None
     except Exception:                          # noqa: BLE001
         return None
+
+
+def committed_mfma(key):
+    """{kernel: matrix-core pipe utilisation} from the committed PMC profile of this config ("from profile"), or None."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(tpath))
+        v = t.get("mfma_utilisation", {}).get(key)
+        return dict(v, source=t.get("_sources", {}).get(key, "profiles/")) if v else None
+    except Exception:                          # noqa: BLE001
+        return None
+
+
+def clock_ramp(step, seconds=0.35):
+    """Untimed evaluations for at least `seconds` before the first timed block, whatever --warmup says: a 20-step run
+    of 0.1 ms calls used to be measured on a GPU still raising its clock (round 2: 83.7 us kernels in the driver's
+    run against 72 us in every longer one)."""
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        step()
+        n += 1
+    return n
 
 
 def time_blocks(step, steps, blocks, barrier, reduce_max):
@@ -186,19 +267,21 @@ def run_extra_config(qoc, name, dev_index, steps, warmup):
         call = eng.bind_eval(xf, np.empty_like(xf))           # the same copy-free host->host call as the headline step
         for _ in range(warmup):
             call()
+        clock_ramp(call)
         eng.kernel_time(reset=True)
         t0 = time.perf_counter()
         for _ in range(steps):
             F = call()
         el = time.perf_counter() - t0
-        kern_ms, kern_n = eng.kernel_time()
+        samples = eng.kernel_samples()
         info = eng.info
     evals = steps / el
     return {"workload": f"{name}: {w.sys_type} {w.n}x{w.n}, K={w.K}, N={w.N}, E={w.E}, host->host grape_eval"
                         + (" (dense chain forced)" if dense else ""),
             "value": evals, "unit": "gradient-evals/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
             "member_evals_per_s": evals * w.E, "F": F,
-            "roofline": roofline(w, info, kern_ms, kern_n, evals, 1, None if dense else committed_traffic(f"{cfg_name}_E{w.E}"))}
+            "roofline": roofline(w, info, samples, evals, 1, None if dense else committed_traffic(f"{cfg_name}_E{w.E}"),
+                                 committed_mfma(f"{name}_E{w.E}"))}
 
 
 def lbfgs_rates(qoc, dev_index):
@@ -348,11 +431,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    ramp_steps = clock_ramp(step)                  # >= 0.35 s of untimed calls: the timed blocks see a warm clock
     barrier()
     if sg.local is not None:
         sg.local.kernel_time(reset=True)
     block_s = time_blocks(step, args.steps, args.blocks, barrier, reduce_max)
-    kern_ms, kern_n = sg.local.kernel_time() if sg.local is not None else (0.0, 0)
+    samples = sg.local.kernel_samples() if sg.local is not None else ([], [])
     F_last, _ = step()
     info = sg.local.info if sg.local is not None else {}
     elapsed = statistics.median(block_s)
@@ -403,7 +487,7 @@ def main():
         value = evals_per_s * (E_total / E_cfg)
         local = w.members(sg.lo, sg.hi)
         traffic = committed_traffic(f"{args.config}_E{local.E}")
-        roof = roofline(local, info, kern_ms, kern_n, evals_per_s, world, traffic)
+        roof = roofline(local, info, samples, evals_per_s, world, traffic, committed_mfma(f"{args.config}_E{local.E}"))
         n_joined = sg.comm_size if (world > 1 or args.force_dist) else 1
         out = {
             "metric": "GRAPE gradient-evals/sec", "value": value, "unit": "gradient-evals/s",
@@ -420,7 +504,8 @@ def main():
                        "collective": sg.collective if (world > 1 or args.force_dist) else None,
                        "slices_per_lane": info.get("slices_per_lane"),
                        "waves_per_member": info.get("waves_per_member")},
-            "blocks": {"count": args.blocks, "steps_each": args.steps, "seconds": block_s, "statistic": "median"},
+            "blocks": {"count": args.blocks, "steps_each": args.steps, "seconds": block_s, "statistic": "median",
+                       "untimed_ramp_steps": ramp_steps},
             "member_evals_per_s": evals_per_s * E_total,
             "roofline": roof,
             "F": float(F_last),

@@ -294,6 +294,13 @@ int grape_get_trajectory(grape_ctx *ctx, int32_t member, double *props, double *
  * (GRAPE_FLAG_TIME_KERNELS).  Synchronises the recorded events.  reset != 0 clears them. */
 int grape_get_kernel_time(grape_ctx *ctx, double *total_ms, int64_t *launches, int32_t reset);
 
+/* The individual durations behind grape_get_kernel_time since its last reset (at most 65536 are kept): the most recent
+ * min(capacity, *count) of them, oldest first.  total_ms[i] = all sweep kernels of one evaluation; first_ms[i] (nullable)
+ * = the part in front of the chain kernels (n = 5..32: control-sum pre-pass + expm kernel, pw_prop_save!,
+ * src/timeevolution.jl:98-110; 0 for n <= 4, where one kernel does everything).  Multi-device contexts report the
+ * first device.  *count (nullable) receives the number of durations available. */
+int grape_get_kernel_samples(grape_ctx *ctx, double *total_ms, double *first_ms, int64_t capacity, int64_t *count);
+
 /* Diagnostic (GRAPE_FLAG_PHASE_STAMPS): the stamps of the last evaluation, 8 uint64 per wave,
  * waves ordered (member, wave-in-member): [0..4] shader clock at start / after propagators /
  * after scan / after forward sweep / end, [5],[6] 100 MHz real-time counter at start / end,

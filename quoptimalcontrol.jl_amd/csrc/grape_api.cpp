@@ -114,7 +114,9 @@ struct grape_ctx {
     bool herm_states = false;     // all Xi, Xt Hermitian (tile family: one-product commutator)
     // GRAPE_FLAG_TIME_KERNELS: a fixed ring of start/stop event pairs around the sweep launches,
     // created at grape_create; when the ring wraps, the oldest pair is folded into ev_total_ms
-    std::vector<hipEvent_t> ev;
+    std::vector<hipEvent_t> ev;               // three per ring slot: start, middle (tile family: behind the expm kernel), stop
+    std::vector<char> ev_has_mid;             // per slot: the middle event was recorded
+    std::vector<float> smp_total, smp_first;  // folded per-launch durations since the last reset (grape_get_kernel_samples)
     uint64_t ev_issued = 0, ev_folded = 0;    // pairs
     uint64_t launches = 0;                    // evaluations enqueued (GRAPE_FLAG_TIME_SAMPLED)
     double ev_total_ms = 0.0;
@@ -472,8 +474,9 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_dev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
     if (e == hipSuccess && (cfg->flags & GRAPE_FLAG_TIME_KERNELS)) {
-        c->ev.reserve(2 * kEventRing);
-        for (size_t i = 0; i < 2 * kEventRing && e == hipSuccess; ++i) {
+        c->ev.reserve(3 * kEventRing);
+        c->ev_has_mid.assign(kEventRing, 0);
+        for (size_t i = 0; i < 3 * kEventRing && e == hipSuccess; ++i) {
             hipEvent_t evn = nullptr;
             e = hipEventCreate(&evn);
             if (e == hipSuccess) c->ev.push_back(evn);
@@ -1035,9 +1038,10 @@ static bool states_stored(const grape_ctx *c)
     return !grape::tile_chain_is_split(tile_params(c, nullptr), false);
 }
 
-static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream, int n_x)
+static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream, int n_x, hipEvent_t ev_mid = nullptr)
 {
-    const TileParams p = tile_params(c, d_x, n_x);
+    TileParams p = tile_params(c, d_x, n_x);
+    p.ev_mid = ev_mid;
     HIP_TRY(c, grape::launch_sweep_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE,
                                         c->d_costates != nullptr, p, stream));
     return GRAPE_OK;
@@ -1048,9 +1052,15 @@ static int fold_events(grape_ctx *c, uint64_t count)
 {
     for (uint64_t i = 0; i < count && c->ev_folded < c->ev_issued; ++i) {
         const size_t slot = (size_t)(c->ev_folded % kEventRing);
-        HIP_TRY(c, hipEventSynchronize(c->ev[2 * slot + 1]));
-        float ms = 0.f;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2 * slot], c->ev[2 * slot + 1]));
+        HIP_TRY(c, hipEventSynchronize(c->ev[3 * slot + 2]));
+        float ms = 0.f, first = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[3 * slot], c->ev[3 * slot + 2]));
+        if (c->ev_has_mid[slot])
+            HIP_TRY(c, hipEventElapsedTime(&first, c->ev[3 * slot], c->ev[3 * slot + 1]));
+        if (c->smp_total.size() < 65536) {
+            c->smp_total.push_back(ms);
+            c->smp_first.push_back(first);
+        }
         c->ev_total_ms += ms;
         c->ev_count += 1;
         c->ev_folded += 1;
@@ -1088,15 +1098,17 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     bool timed = (c->cfg.flags & GRAPE_FLAG_TIME_KERNELS) != 0;
     if (timed && (c->cfg.flags & GRAPE_FLAG_TIME_SAMPLED) && (c->launches++ & 7) != 0)
         timed = false;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, emid = nullptr;
     if (timed) {
         if (c->ev_issued - c->ev_folded == kEventRing) {   // ring full: fold the oldest pair (long finished)
             int rc = fold_events(c, 1);
             if (rc) return rc;
         }
         const size_t slot = (size_t)(c->ev_issued % kEventRing);
-        e0 = c->ev[2 * slot];
-        e1 = c->ev[2 * slot + 1];
+        e0 = c->ev[3 * slot];
+        e1 = c->ev[3 * slot + 2];
+        if (c->family == 1) emid = c->ev[3 * slot + 1];
+        c->ev_has_mid[slot] = emid ? 1 : 0;
         c->ev_issued += 1;
         HIP_TRY(c, hipEventRecord(e0, stream));
     }
@@ -1116,7 +1128,7 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
         else
             HIP_TRY(c, grape::launch_sweep_small(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, mode, p, stream));
     } else {
-        int rc = enqueue_tile(c, d_x, stream, n_x);
+        int rc = enqueue_tile(c, d_x, stream, n_x, emid);
         if (rc) return rc;
     }
     if (exact && c->family == 1) {
@@ -1807,7 +1819,27 @@ extern "C" int grape_get_kernel_time(grape_ctx *c, double *total_ms, int64_t *la
     if (rc) return rc;
     if (total_ms) *total_ms = c->ev_total_ms;
     if (launches) *launches = c->ev_count;
-    if (reset) { c->ev_total_ms = 0.0; c->ev_count = 0; }
+    if (reset) { c->ev_total_ms = 0.0; c->ev_count = 0; c->smp_total.clear(); c->smp_first.clear(); }
+    return GRAPE_OK;
+}
+
+extern "C" int grape_get_kernel_samples(grape_ctx *c, double *total_ms, double *first_ms, int64_t capacity, int64_t *count)
+{
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (c->is_group) {                                       // the shards run concurrently: the first device stands for them
+        const int rc = grape_get_kernel_samples(c->sub[0], total_ms, first_ms, capacity, count);
+        return rc ? group_fail(c, c->sub[0], rc) : GRAPE_OK;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = fold_events(c, c->ev_issued - c->ev_folded);
+    if (rc) return rc;
+    const int64_t have = (int64_t)c->smp_total.size();
+    if (count) *count = have;
+    const int64_t n = capacity < have ? (capacity < 0 ? 0 : capacity) : have;
+    for (int64_t i = 0; i < n; ++i) {                        // the most recent n, oldest first
+        if (total_ms) total_ms[i] = c->smp_total[(size_t)(have - n + i)];
+        if (first_ms) first_ms[i] = c->smp_first[(size_t)(have - n + i)];
+    }
     return GRAPE_OK;
 }
 

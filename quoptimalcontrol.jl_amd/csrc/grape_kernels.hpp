@@ -137,6 +137,7 @@ struct TileParams {
     const double *ha_norm;    // [unit] |A'_k|_1 bound (max column sum of |re| + |im|) / theta8
     double2 *gc;              // [control array][slice] D-layout dumps of Gc_t = (-i dt) sum_c x[c,t] B_c
     double *gcn;              // [control array][slice] |Gc_t|_1 bound / theta8
+    hipEvent_t ev_mid;        // timing (GRAPE_FLAG_TIME_KERNELS): recorded behind the expm kernel, in front of the chain kernels; or null
     double dt;
 };
 constexpr int kSparseMax = 64;

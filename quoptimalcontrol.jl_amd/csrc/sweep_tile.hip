@@ -1256,6 +1256,11 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         }
         if (e != hipSuccess)
             return e;
+        if (p.ev_mid) {
+            e = hipEventRecord(p.ev_mid, stream);
+            if (e != hipSuccess)
+                return e;
+        }
         if (NT == 1 && p.thin)
             return launch_chain_thin(sandwich, q, stream);
     }

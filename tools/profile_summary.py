@@ -34,10 +34,19 @@ for k, cs in raw.items():
 path = os.path.join(root, "profiles", f"{tag}_pmc.json")
 json.dump(out, open(path, "w"), indent=1)
 print("wrote", path)
-if len(sys.argv) > 4 and "sweep" in out["kernels"] and "hbm_traffic_bytes" in out["kernels"]["sweep"]:
+if len(sys.argv) > 4:
+    # profiles/traffic.json: what bench.py quotes "from profile" -- HBM bytes of the timed kernels per evaluation and the
+    # matrix-core pipe utilisation of every MFMA kernel of this configuration
+    key = sys.argv[4]
+    timed = [k for k in out["kernels"] if not k.startswith("reduce") and "hbm_traffic_bytes" in out["kernels"][k]]
     tpath = os.path.join(root, "profiles", "traffic.json")
     t = json.load(open(tpath)) if os.path.exists(tpath) else {}
-    t[sys.argv[4]] = out["kernels"]["sweep"]["hbm_traffic_bytes"]
-    t["_source"] = f"profiles/{tag}_pmc.json"
+    if timed:
+        t[key] = sum(out["kernels"][k]["hbm_traffic_bytes"] for k in timed)
+    mf = {k: round(d["mfma_utilisation"], 4) for k, d in out["kernels"].items() if d.get("mfma_utilisation")}
+    if mf:
+        t.setdefault("mfma_utilisation", {})[key] = mf
+    t.setdefault("_sources", {})[key] = f"profiles/{tag}_pmc.json ({' + '.join(timed)})"
+    t.pop("_source", None)
     json.dump(t, open(tpath, "w"), indent=1)
     print("updated", tpath)
