@@ -17,6 +17,8 @@
  *   - x and G are (K, N) column-major Float64: x[j,i] at j + i*K  (what Optim hands in/out).
  *   - host-pointer arguments are only read/written during the call; the library keeps no
  *     caller pointer after return (Julia: GC.@preserve for the duration of the ccall).
+ *   - every entry point selects the device(s) of its context and restores the calling thread's current HIP device before
+ *     it returns (a host framework in the same thread keeps allocating and launching where it was).
  *   - one evaluation in flight per context (like the reference's closure, which shares one
  *     evolve_store, src/solve.jl:162); distinct contexts are independent.
  */
@@ -241,21 +243,34 @@ int grape_eval_batch_device(grape_ctx *ctx, int32_t n_x, const double *d_x, doub
 
 /* Device-resident L-BFGS: stands in for
  *     Optim.optimize(Optim.only_fg!(topt), x0, Optim.LBFGS(), optim_options)       src/solve.jl:138, :244
- * with x, g, the (s, y) history and the line-search trial points kept on the GPU; per iteration the host
- * reads eight scalars.  Optim's LBFGS() defaults are mirrored where they are plain numbers: memory m = 10,
- * initial inverse-Hessian scaling s'y / y'y, initial step 1 (InitialStatic), g_tol = 1e-8 on |g|_inf,
- * f_tol = x_tol = 0, 1000 iterations.  The line search is NOT HagerZhang: `probes` step lengths
- * alpha, alpha/2, alpha/4, ... are evaluated by ONE batched launch (grape_config.max_batch >= probes)
- * and the largest one with sufficient decrease (c1 = 1e-4) -- preferring one that also satisfies the strong
- * Wolfe curvature condition (c2 = 0.9) -- is taken; contexts without batching probe one step per launch.
- * The gradient is whatever the GRAPE evaluation returns, with the reference's conventions (SURVEY.md App. C). */
+ * with x, g, the (s, y) history and the line-search trial points kept on the GPU; per evaluation the host
+ * reads two scalars (phi, phi').  Optim's LBFGS() defaults are mirrored: memory m = 10, initial inverse-Hessian
+ * scaling s'y / y'y, initial step 1 (InitialStatic), g_tol = 1e-8 on |g|_inf, f_tol = x_tol = 0, 1000 iterations, and
+ * the line search is Hager-Zhang with LineSearches.jl's constants (delta 0.1, sigma 0.9, rho 5, epsilon 1e-6,
+ * gamma 0.66, psi3 0.1, at most 50 evaluations): bracketing, secant^2 and bisection on phi(alpha), phi'(alpha), one
+ * GRAPE evaluation per trial step.  line_search:
+ *   0  Hager-Zhang; the initial step is taken at once when it satisfies the (approximate) Wolfe conditions
+ *   1  Hager-Zhang exactly as Optim runs it behind InitialStatic (`mayterminate` false: the initial step is never
+ *      accepted without a second evaluation)
+ *   2  the factor-2 ladder of ABI v2: `probes` step lengths alpha, alpha/2, ... per BATCHED launch
+ *      (grape_config.max_batch >= probes), the largest with sufficient decrease (c1 = 1e-4), preferring the strong Wolfe
+ *      curvature condition (c2 = 0.9); single-device contexts only
+ * Multi-device contexts (n_devices >= 2) and contexts with an attached communicator run modes 0 and 1: the vectors
+ * live on the first device (every rank's device), each evaluation is the sharded one with its all-reduce.  With
+ * grape_comm_attach all ranks must call grape_lbfgs together (they take identical decisions on identical [G, F]).
+ * A Hager-Zhang search that cannot bracket -- the reference's UnitaryGate gradient is not the derivative of its figure
+ * of merit -- hands that iteration to the ladder (single-device) or ends with status 3.
+ * The gradient is whatever the GRAPE evaluation returns, with the reference's conventions. */
 typedef struct grape_lbfgs_options {
     int32_t memory;            /* m; 0 = 10                                              */
     int32_t max_iterations;    /* 0 = 1000                                               */
     double  g_tol;             /* < 0 = 1e-8; stop when |g|_inf <= g_tol                 */
     double  f_tol;             /* stop when |f - f_prev| <= f_tol |f|  (Optim f_tol; 0 = off) */
-    int32_t max_linesearch;    /* trial steps per iteration before giving up; 0 = 40     */
-    int32_t probes;            /* step lengths per launch, 1..8; 0 = automatic           */
+    int32_t max_linesearch;    /* evaluations per line search before giving up; 0 = 50   */
+    int32_t probes;            /* ladder search: step lengths per launch, 1..8; 0 = automatic */
+    /* ---- ABI v3 ---- */
+    int32_t line_search;       /* 0, 1 Hager-Zhang (see above), 2 ladder                 */
+    int32_t reserved;
 } grape_lbfgs_options;
 
 typedef struct grape_lbfgs_result {
@@ -266,10 +281,13 @@ typedef struct grape_lbfgs_result {
     int32_t evaluations;       /* control arrays evaluated (probes count individually)   */
     int32_t status;            /* 0 g_tol reached, 1 f_tol reached, 2 max_iterations, 3 line search failed */
     int32_t probes;            /* step lengths per launch actually used                  */
+    /* ---- ABI v3 ---- */
+    int32_t line_search;       /* the mode that ran                                      */
+    int32_t ladder_fallbacks;  /* iterations whose Hager-Zhang search could not bracket  */
 } grape_lbfgs_result;
 
 /* x0: host (K,N) f64 initial controls (Problem.guess); x_min: host (K,N) f64, receives res.minimizer.
- * opts may be NULL (all defaults).  Single-device contexts only. */
+ * opts may be NULL (all defaults). */
 int grape_lbfgs(grape_ctx *ctx, const double *x0, const grape_lbfgs_options *opts, double *x_min,
                 grape_lbfgs_result *result);
 

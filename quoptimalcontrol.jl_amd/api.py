@@ -81,7 +81,11 @@ class GRAPE:
     optim_options: dict = field(default_factory=dict)
     device: int = -1               # HIP device ordinal (new: the reference has no devices)
     optimizer: str = "host"        # "host": SciPy L-BFGS-B drives grape_eval (stand-in for Optim.jl on the host);
-                                   # "device": grape_lbfgs, the library's device-resident L-BFGS
+                                   # "device": grape_lbfgs, the library's device-resident L-BFGS (Hager-Zhang line search;
+                                   # optim_options["line_search"]: "hagerzhang" | "optim" | "ladder")
+    devices: Optional[list] = None  # HIP ordinals: the library shards the ensemble over them (grape_config.n_devices /
+                                    # device_ids, as julia/GrapeHIP.jl's `devices`) and all-reduces [G, F] once per evaluation
+    peer_sum: bool = False         # with `devices`: GRAPE_FLAG_GROUP_PEER_SUM (sum on the first device, ids may repeat)
 
 
 @dataclass
@@ -94,6 +98,8 @@ class ADGRAPE:
     optim_options: dict = field(default_factory=dict)
     device: int = -1
     optimizer: str = "host"
+    devices: Optional[list] = None
+    peer_sum: bool = False
 
 
 @dataclass
@@ -152,6 +158,11 @@ def make_engine(prob, alg, **engine_kw):
     if len(first.B) != first.n_controls:
         raise ValueError("n_controls does not match the number of control operators")
     A, B, Xi, Xt = _pack(members)
+    if getattr(alg, "devices", None):
+        from .engine import FLAG_GROUP_PEER_SUM
+        engine_kw = dict(engine_kw, devices=list(alg.devices))
+        if getattr(alg, "peer_sum", False):
+            engine_kw["flags"] = engine_kw.get("flags", 0) | FLAG_GROUP_PEER_SUM
     if isinstance(alg, ADGRAPE):            # pw_evolve adds A first (src/timeevolution.jl:32-35): the static summation order
         return GrapeEngine(first.sys_type.name, A, B, Xi, Xt, wts, first.T, alg.n_slices, variant=1, device=alg.device,
                            gradient="exact", objective="c1", **engine_kw)
@@ -216,7 +227,8 @@ def _device_lbfgs(eng, x0, options):
     from types import SimpleNamespace
 
     x_min, info = eng.lbfgs(x0, iterations=int(options.get("iterations", 0)), g_tol=float(options.get("g_tol", -1.0)),
-                            f_tol=float(options.get("f_tol", 0.0)))
+                            f_tol=float(options.get("f_tol", 0.0)), line_search=options.get("line_search", "hagerzhang"),
+                            probes=int(options.get("probes", 0)))
     return SimpleNamespace(minimum=info["minimum"], minimizer=x_min, x=x_min.reshape(-1), fun=info["minimum"],
                            nit=info["iterations"], nfev=info["evaluations"], message=info["message"],
                            success=info["status"] in (0, 1), device_lbfgs=info)
@@ -229,7 +241,9 @@ def solve(prob, alg: Optional[GRAPE] = None, engine=None):
                         "(src/solve.jl:57,66); pass GRAPE(n_slices=...)")
     own = engine is None
     device_opt = getattr(alg, "optimizer", "host") == "device"
-    eng = engine or make_engine(prob, alg, **({"max_batch": 4} if device_opt and not isinstance(alg, ADGRAPE) else {}))
+    batched = device_opt and not isinstance(alg, ADGRAPE) and not getattr(alg, "devices", None) and \
+        alg.optim_options.get("line_search") == "ladder"          # the ladder search probes several step lengths per launch
+    eng = engine or make_engine(prob, alg, **({"max_batch": 4} if batched else {}))
     try:
         guess = np.asarray((prob.prob if isinstance(prob, EnsembleProblem) else prob).guess, float)
         if device_opt:

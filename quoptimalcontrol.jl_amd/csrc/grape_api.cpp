@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <new>
 #include <utility>
@@ -212,6 +213,16 @@ static RcclApi *rccl()
         if (r__ != ncclSuccess)                                                                \
             return fail(ctx, GRAPE_ERR_COMM, std::string(#call) + ": " + g_rccl.GetErrorString(r__)); \
     } while (0)
+
+// Every entry point selects its shard's device; the CALLER's current device is restored on every return path (a host
+// framework in the same thread -- torch tensors, the caller's own streams -- keeps allocating and launching where it was).
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 
 // diagnostic switches: set and not "0"
 static bool env_on(const char *name)
@@ -502,6 +513,7 @@ static void shard_plan(int E, int G, std::vector<int> &lo)
 
 extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
 {
+    DeviceGuard guard;
     if (out) *out = nullptr;
     if (!cfg || !out) return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: null argument");
     int rc = validate_config(cfg);
@@ -600,6 +612,7 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
 
 extern "C" int grape_destroy(grape_ctx *ctx)
 {
+    DeviceGuard guard;
     if (!ctx) return GRAPE_OK;
     if (ctx->is_group) {
         for (grape_ctx *s : ctx->sub) {
@@ -628,6 +641,7 @@ extern "C" int grape_comm_unique_id(grape_comm_id *out)
 
 extern "C" int grape_comm_attach(grape_ctx *c, const grape_comm_id *id, int32_t rank, int32_t n_ranks)
 {
+    DeviceGuard guard;
     if (!c) return GRAPE_ERR_INVALID_ARG;
     if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks)
         return fail(c, GRAPE_ERR_INVALID_ARG, "grape_comm_attach: bad rank / n_ranks / id");
@@ -667,7 +681,15 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         c->evaluated = false;
         return GRAPE_OK;
     }
+    DeviceGuard guard;
     HIP_TRY(c, hipSetDevice(c->device));
+    // ordered behind the last evaluation BEFORE any device buffer is touched (the sparse lists, vectors and hoisted
+    // generators below are rewritten in place): an evaluation may still run on a caller's stream
+    if (c->dev_pending) {
+        HIP_TRY(c, hipEventSynchronize(c->ev_dev));
+        c->dev_pending = false;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     const size_t nn = (size_t)c->cfg.n * c->cfg.n, K = c->cfg.n_controls, E = c->cfg.n_ensemble;
     // n x m states with m < n (UnitaryGate-style left multiplication of m column vectors, e.g. m = 1:
     // a vectorised density matrix under Liouvillian superoperators, test/liou.jl:38-48): run zero-padded
@@ -808,9 +830,12 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         c->sparse_ctrl = sp;
         if (sp) {
             if (!c->d_sp_coef) {
-                c->bytes += (sizeof(double2) + sizeof(int32_t)) * E * K * SM;
                 HIP_TRY(c, hipMalloc((void **)&c->d_sp_coef, sizeof(double2) * E * K * SM));
+                c->bytes += sizeof(double2) * E * K * SM;
+            }
+            if (!c->d_sp_addr) {                             // (independent checks: the second allocation may fail alone)
                 HIP_TRY(c, hipMalloc((void **)&c->d_sp_addr, sizeof(int32_t) * E * K * SM));
+                c->bytes += sizeof(int32_t) * E * K * SM;
             }
             HIP_TRY(c, hipMemcpy(c->d_sp_coef, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice));
             HIP_TRY(c, hipMemcpy(c->d_sp_addr, addr.data(), sizeof(int32_t) * addr.size(), hipMemcpyHostToDevice));
@@ -865,11 +890,6 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             if (!c->d_ha_norm) HIP_TRY(c, hipMalloc((void **)&c->d_ha_norm, sizeof(double) * (size_t)c->EU));
             if (!c->d_gc) HIP_TRY(c, hipMalloc((void **)&c->d_gc, sizeof(double2) * gc_elems));
             if (!c->d_gcn) HIP_TRY(c, hipMalloc((void **)&c->d_gcn, sizeof(double) * (size_t)c->B * c->cfg.n_slices));
-            if (c->dev_pending) {                                // an evaluation may still read the old dumps
-                HIP_TRY(c, hipEventSynchronize(c->ev_dev));
-                c->dev_pending = false;
-            }
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
             HIP_TRY(c, hipMemcpy(c->d_ha, ha.data(), sizeof(double) * ha.size(), hipMemcpyHostToDevice));
             HIP_TRY(c, hipMemcpy(c->d_ha_norm, hn.data(), sizeof(double) * hn.size(), hipMemcpyHostToDevice));
         }
@@ -967,11 +987,6 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         HIP_TRY(c, hipMalloc((void **)&c->d_states, full));
         c->states_bytes = full;
     }
-    if (c->dev_pending) {                                    // an evaluation may still run on a caller's stream
-        HIP_TRY(c, hipEventSynchronize(c->ev_dev));
-        c->dev_pending = false;
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->d_ops, packed.data(), sizeof(double) * packed.size(), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_wts, wts, sizeof(double) * E, hipMemcpyHostToDevice));
     c->ops_set = true;
@@ -1264,9 +1279,16 @@ static int wait_flag(grape_ctx *s)
         clock_gettime(CLOCK_MONOTONIC, &t);
         return (double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec);
     };
-    auto done = [&](double el) {
+    bool napped = false;
+    auto done = [&](double el, bool first_look) {
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        s->eval_ema_s = s->eval_ema_s > 0.0 ? 0.75 * s->eval_ema_s + 0.25 * el : el;
+        // The estimate only ever learns from waits that SAW the flag unset after the nap (el is then the evaluation's
+        // duration to within one poll).  When the flag was already set on wake-up the nap overshot: halve the estimate
+        // instead of feeding the nap back into it (one 50 ms hiccup used to cost ~200 slow calls).
+        if (napped && first_look)
+            s->eval_ema_s *= 0.5;
+        else
+            s->eval_ema_s = s->eval_ema_s > 0.0 ? 0.75 * s->eval_ema_s + 0.25 * el : el;
         return GRAPE_OK;
     };
     // evaluations known to take milliseconds (16 x 16 and larger): sleep through ~90 % of the expected
@@ -1275,12 +1297,13 @@ static int wait_flag(grape_ctx *s)
         const double nap = 0.9 * s->eval_ema_s;
         timespec ts{(time_t)nap, (long)((nap - (double)(time_t)nap) * 1e9)};
         nanosleep(&ts, nullptr);
+        napped = true;
     }
     const double spin_until = s->eval_ema_s > 1e-3 ? 1.3 * s->eval_ema_s : 500e-6;
     long nap_ns = 20000;
     for (unsigned it = 0;; ++it) {
         if (*flag == want)
-            return done(elapsed());
+            return done(elapsed(), it == 0);
         if ((it & 1023) != 1023) continue;
         const double el = elapsed();
         if (el < spin_until) continue;                      // spin phase
@@ -1304,6 +1327,7 @@ static int enqueue_peer_sum(grape_ctx *g, double *target, hipStream_t lead_strea
 
 extern "C" int grape_eval_device(grape_ctx *c, const double *d_x, double *d_fg, void *stream)
 {
+    DeviceGuard guard;
     if (!c) return GRAPE_ERR_INVALID_ARG;
     if (!d_x || !d_fg) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval_device: null argument");
     if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, "grape_eval_device: operators not set");
@@ -1388,6 +1412,7 @@ static int enqueue_peer_sum(grape_ctx *g, double *target, hipStream_t lead_strea
 // host -> device(s) -> host: the (F, G, x) closure body.  n_x > 1: grape_eval_batch.
 static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *G, const char *who)
 {
+    DeviceGuard guard;
     if (!c) return GRAPE_ERR_INVALID_ARG;
     if (!x) return fail(c, GRAPE_ERR_INVALID_ARG, std::string(who) + ": x is null");
     if (n_x < 1 || n_x > c->B)
@@ -1473,6 +1498,7 @@ extern "C" int grape_eval_batch(grape_ctx *c, int32_t n_x, const double *x, doub
 
 extern "C" int grape_eval_batch_device(grape_ctx *c, int32_t n_x, const double *d_x, double *d_fg, void *stream)
 {
+    DeviceGuard guard;
     if (!c) return GRAPE_ERR_INVALID_ARG;
     if (!d_x || !d_fg) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval_batch_device: null argument");
     if (n_x < 1 || n_x > c->B)
@@ -1499,14 +1525,235 @@ static grape_ctx *owner_of(grape_ctx *c, int member, int *local)
 }
 
 // ------------------------------------------------------------------------------------------
-// Device-resident L-BFGS (lbfgs.hip): the optimiser loop of src/solve.jl:138 / :244
+// Device-resident L-BFGS (lbfgs.hip): the optimiser loop of src/solve.jl:138 / :244.
+//
+// x, g, the (s, y) history, the direction and the trial points live on the (first) device; the host sees scalars only.
+// Line search (grape_lbfgs_options.line_search):
+//   0, 1  Hager-Zhang (LineSearches.jl's HagerZhang(), Optim's default for LBFGS(): delta 0.1, sigma 0.9, rho 5,
+//         epsilon 1e-6, gamma 0.66, psi3 0.1; initial step 1 = InitialStatic) run HERE on phi(alpha), phi'(alpha) -- one
+//         evaluation per trial step, whatever the context (groups of devices, attached communicators, no batching);
+//         0 accepts the initial step when it already satisfies the (approximate) Wolfe conditions, 1 never does
+//         (Optim's literal behaviour with InitialStatic: `mayterminate` stays false)
+//   2     the factor-2 ladder of rounds 1-2: `probes` step lengths per batched launch (single-device contexts)
+// A Hager-Zhang search that cannot bracket (the reference's UnitaryGate gradient is not the derivative of its figure
+// of merit) hands that iteration to the ladder.
+namespace {
+
+struct LbfgsRun {
+    grape_ctx *c = nullptr, *lead = nullptr;      // lead: the context that owns the vectors, the stream and the host flag
+    grape::LbfgsState st{};
+    double *h_sc = nullptr;
+    int evals = 0;
+    bool hung = false;                            // a wait timed out: the device is presumed hung, nothing is synchronised any more
+
+    grape::DoneSignal signal()
+    {
+        grape::DoneSignal d;
+        d.flag = lead->d_h_flag;
+        d.seq = ++lead->seq;
+        return d;
+    }
+    int wait()
+    {
+        const int rc = wait_flag(lead);
+        if (rc == GRAPE_ERR_TIMEOUT) hung = true;
+        return rc ? (c->is_group ? group_fail(c, lead, rc) : rc) : GRAPE_OK;
+    }
+    // [G, F] of the n_x control arrays in st.xt -> st.fgt, on the lead stream, nothing synchronised
+    int evaluate(int n_x)
+    {
+        evals += n_x;
+        if (c->is_group)                          // fan-out of x, every shard, the grouped all-reduce / peer sum
+            return grape_eval_device(c, st.xt, st.fgt, lead->stream);
+        int rc = enqueue_eval(c, st.xt, st.fgt, c->stream, n_x);
+        if (rc == GRAPE_OK && c->comm) rc = enqueue_allreduce(c, st.fgt, st.fgt, c->stream);
+        return rc;
+    }
+    // phi(alpha), phi'(alpha) along the current direction; `have_trial`: slot 0 already holds x + alpha d
+    int phi(double alpha, bool have_trial, double &f, double &df)
+    {
+        HIP_TRY(c, hipSetDevice(lead->device));
+        if (!have_trial && grape::launch_lbfgs_trial(st, alpha, lead->stream) != hipSuccess)
+            return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
+        int rc = evaluate(1);
+        if (rc) return rc;
+        HIP_TRY(c, hipSetDevice(lead->device));
+        if (grape::launch_lbfgs_select(st, 1, lead->stream, signal(), 1) != hipSuccess)
+            return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
+        rc = wait();
+        if (rc) return rc;
+        f = h_sc[8];
+        df = h_sc[9];
+        return GRAPE_OK;
+    }
+};
+
+// LineSearches.jl HagerZhang on scalars.  Returns 0 with the accepted step (which is the LAST evaluated point unless
+// *reeval is set), 1 when the search failed (no bracket / iteration limit), or a negative grape_status.
+struct HagerZhang {
+    LbfgsRun &run;
+    double phi0, dphi0, phi_lim;
+    std::vector<double> al, va, sl;               // evaluated steps, values, slopes; index 0 = (0, phi0, dphi0)
+    double last_alpha = -1.0;
+    int budget;
+    static constexpr double delta = 0.1, sigma = 0.9, rho = 5.0, epsilon = 1e-6, gamma = 0.66, psi3 = 0.1;
+
+    int eval(double c_, bool have_trial = false)
+    {
+        double f, df;
+        if (budget-- <= 0) return 1;
+        const int rc = run.phi(c_, have_trial, f, df);
+        if (rc) return rc;
+        al.push_back(c_); va.push_back(f); sl.push_back(df);
+        last_alpha = c_;
+        return 0;
+    }
+    bool wolfe(size_t i) const
+    {
+        const double c_ = al[i], f = va[i], df = sl[i];
+        const bool w1 = delta * dphi0 >= (f - phi0) / c_ && df >= sigma * dphi0;
+        const bool w2 = (2.0 * delta - 1.0) * dphi0 >= df && df >= sigma * dphi0 && f <= phi_lim;
+        return w1 || w2;
+    }
+    static double secant(double a, double b, double da, double db) { return (a * db - b * da) / (db - da); }
+    // HZ U3: bisection on [a, b] with phi'(a) < 0, phi(a) <= phi_lim, phi'(b) < 0, phi(b) > phi_lim
+    int bisect(size_t &ia, size_t &ib)
+    {
+        while (al[ib] - al[ia] > std::numeric_limits<double>::epsilon() * al[ib]) {
+            const int rc = eval(0.5 * (al[ia] + al[ib]));
+            if (rc) return rc;
+            const size_t id = al.size() - 1;
+            if (sl[id] >= 0.0) { ib = id; return 0; }
+            if (va[id] <= phi_lim) ia = id; else ib = id;
+        }
+        return 0;
+    }
+    // HZ U0-U3
+    int update(size_t ia, size_t ib, size_t ic, size_t &oa, size_t &ob)
+    {
+        oa = ia; ob = ib;
+        if (al[ic] < al[ia] || al[ic] > al[ib]) return 0;
+        if (sl[ic] >= 0.0) { ob = ic; return 0; }
+        if (va[ic] <= phi_lim) { oa = ic; return 0; }
+        ob = ic;
+        return bisect(oa, ob);
+    }
+    int secant2(size_t ia, size_t ib, bool &iswolfe, size_t &oa, size_t &ob)
+    {
+        iswolfe = false;
+        double c_ = secant(al[ia], al[ib], sl[ia], sl[ib]);
+        if (!(c_ == c_) || std::isinf(c_)) { oa = ia; ob = ib; return 1; }
+        int rc = eval(c_);
+        if (rc) return rc;
+        size_t ic = al.size() - 1;
+        if (wolfe(ic)) { iswolfe = true; oa = ob = ic; return 0; }
+        size_t iA, iB;
+        rc = update(ia, ib, ic, iA, iB);
+        if (rc) return rc;
+        const double a = al[iA], b = al[iB];
+        bool second = false;
+        if (iB == ic) { c_ = secant(al[ib], al[iB], sl[ib], sl[iB]); second = true; }
+        else if (iA == ic) { c_ = secant(al[ia], al[iA], sl[ia], sl[iA]); second = true; }
+        if (second && a <= c_ && c_ <= b) {
+            rc = eval(c_);
+            if (rc) return rc;
+            ic = al.size() - 1;
+            if (wolfe(ic)) { iswolfe = true; oa = ob = ic; return 0; }
+            size_t nA, nB;
+            rc = update(iA, iB, ic, nA, nB);
+            if (rc) return rc;
+            iA = nA; iB = nB;
+        }
+        oa = iA; ob = iB;
+        return 0;
+    }
+    // alpha0 has been written to trial slot 0 by the direction kernel
+    int search(double alpha0, bool mayterminate, double &alpha_out, double &phi_out, bool &reeval)
+    {
+        reeval = false;
+        phi_lim = phi0 + epsilon * std::fabs(phi0);
+        double c_ = alpha0;
+        al.assign(1, 0.0); va.assign(1, phi0); sl.assign(1, 0.0);
+        int rc = eval(c_, true);                                   // the probe also publishes phi'(0) = g.d of the direction kernel
+        if (rc) return rc;
+        dphi0 = run.h_sc[10];
+        sl[0] = dphi0;
+        if (!(dphi0 < 0.0)) return 1;
+        for (int it = 0; !(std::isfinite(va.back()) && std::isfinite(sl.back())); ++it) {   // shrink out of a non-finite region
+            if (it >= 52) return 1;
+            al.pop_back(); va.pop_back(); sl.pop_back();
+            c_ *= psi3;
+            rc = eval(c_);
+            if (rc) return rc;
+        }
+        auto accept = [&](size_t i) {
+            alpha_out = al[i]; phi_out = va[i];
+            reeval = al[i] != last_alpha;
+            return 0;
+        };
+        if (mayterminate && wolfe(al.size() - 1)) return accept(al.size() - 1);
+        // bracketing, HZ B0-B3
+        size_t ia = 0, ib = 1;
+        bool bracketed = false;
+        while (!bracketed) {
+            const size_t ic = al.size() - 1;
+            if (sl[ic] >= 0.0) {                                   // B1: reached the upward slope
+                ib = ic;
+                for (size_t i = ib; i-- > 0;)
+                    if (va[i] <= phi_lim) { ia = i; break; }
+                bracketed = true;
+            } else if (va[ic] > phi_lim) {                         // B2: over the crest, slope still downward: bisect
+                ia = 0; ib = ic;
+                rc = bisect(ia, ib);
+                if (rc) return rc;
+                bracketed = true;
+            } else {                                               // B3: still going downhill: expand
+                const double cold = c_;
+                c_ *= rho;
+                if (!(c_ < 1e30)) return 1;
+                rc = eval(c_);
+                if (rc) return rc;
+                for (int it = 0; !(std::isfinite(va.back()) && std::isfinite(sl.back())); ++it) {   // back towards the last finite point
+                    if (it >= 52) return 1;
+                    al.pop_back(); va.pop_back(); sl.pop_back();
+                    c_ = 0.5 * (cold + c_);
+                    rc = eval(c_);
+                    if (rc) return rc;
+                }
+            }
+        }
+        if (ia != ib && wolfe(ib) && ib != 0) return accept(ib);   // (a bracketing point may already do)
+        for (;;) {
+            const double a = al[ia], b = al[ib];
+            if (b - a <= std::numeric_limits<double>::epsilon() * b)
+                return ia == 0 ? 1 : accept(ia);
+            bool iswolfe;
+            size_t iA, iB;
+            rc = secant2(ia, ib, iswolfe, iA, iB);
+            if (rc) return rc;
+            if (iswolfe) return accept(iA);
+            if (al[iB] - al[iA] < gamma * (b - a)) {
+                if (std::nextafter(va[ia], INFINITY) >= va[ib] && std::nextafter(va[iA], INFINITY) >= va[iB])
+                    return iA == 0 ? 1 : accept(iA);               // flat to the last bit
+                ia = iA; ib = iB;
+            } else {                                               // secant converges too slowly: bisect
+                rc = eval(0.5 * (al[iA] + al[iB]));
+                if (rc) return rc;
+                rc = update(iA, iB, al.size() - 1, ia, ib);
+                if (rc) return rc;
+            }
+        }
+    }
+};
+
+}  // namespace
+
 extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_options *opts, double *x_min,
                            grape_lbfgs_result *result)
 {
+    DeviceGuard guard;
     if (!c) return GRAPE_ERR_INVALID_ARG;
     if (!x0 || !x_min || !result) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_lbfgs: null argument");
-    if (c->is_group || c->comm)
-        return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_lbfgs: single-device contexts only in this build");
     if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, "grape_lbfgs: operators not set");
     const size_t kn = KN(c), Q = kn + 1;
     if (kn > (size_t)grape::kLbfgsMaxPer * 1024)
@@ -1517,35 +1764,48 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
     const int max_it = o.max_iterations > 0 ? o.max_iterations : 1000;
     const double g_tol = o.g_tol >= 0.0 ? o.g_tol : 1e-8;
     const double f_tol = o.f_tol > 0.0 ? o.f_tol : 0.0;
-    const int max_ls = o.max_linesearch > 0 ? o.max_linesearch : 40;
+    const int max_ls = o.max_linesearch > 0 ? o.max_linesearch : 50;
     if (m > 64) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_lbfgs: memory must be <= 64");
-    int B = o.probes;
-    if (B <= 0) {
-        // probing several step lengths multiplies the sweep's work: free while the ensemble leaves the chip
-        // mostly empty, not when it already fills it
-        const long waves = (long)c->cfg.n_ensemble * c->W;
-        B = waves * 4 <= 8L * c->compute_units ? 4 : (waves * 2 <= 8L * c->compute_units ? 2 : 1);
+    if (o.line_search < 0 || o.line_search > 2) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_lbfgs: line_search must be 0, 1 or 2");
+    const bool multi = c->is_group || c->comm != nullptr;
+    if (multi && o.line_search == 2)
+        return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_lbfgs: the batched ladder search (line_search = 2) is single-device; "
+                                              "multi-device contexts use the Hager-Zhang search");
+    grape_ctx *lead = c->is_group ? c->sub[0] : c;
+    int B = 1;
+    if (o.line_search == 2 || (!multi && o.probes > 1)) {
+        B = o.probes;
+        if (B <= 0) {
+            // probing several step lengths multiplies the sweep's work: free while the ensemble leaves the chip
+            // mostly empty, not when it already fills it
+            const long waves = (long)c->cfg.n_ensemble * c->W;
+            B = waves * 4 <= 8L * c->compute_units ? 4 : (waves * 2 <= 8L * c->compute_units ? 2 : 1);
+        }
+        if (B > c->B) B = c->B;
+        if (B > grape::kLbfgsMaxProbes) B = grape::kLbfgsMaxProbes;
+        if (B < 1) B = 1;
     }
-    if (B > c->B) B = c->B;
-    if (B > grape::kLbfgsMaxProbes) B = grape::kLbfgsMaxProbes;
-    if (B < 1) B = 1;
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (c->dev_pending) {
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_dev, 0));
-        c->dev_pending = false;
+    HIP_TRY(c, hipSetDevice(lead->device));
+    if (lead->dev_pending) {
+        HIP_TRY(c, hipStreamWaitEvent(lead->stream, lead->ev_dev, 0));
+        lead->dev_pending = false;
     }
     // workspace (freed on return): vectors + history + trial points/results + scalars
     const size_t n_dbl = 3 * kn + 2 * (size_t)m * kn + m + (size_t)B * kn + (size_t)B * Q + grape::kLbfgsMaxProbes + 8;
     double *buf = nullptr, *h_sc = nullptr, *d_h_sc = nullptr;
     HIP_TRY(c, hipMalloc((void **)&buf, sizeof(double) * n_dbl));
-    hipError_t he = hipHostMalloc((void **)&h_sc, sizeof(double) * 8, hipHostMallocMapped | hipHostMallocCoherent);
+    hipError_t he = hipHostMalloc((void **)&h_sc, sizeof(double) * 16, hipHostMallocMapped | hipHostMallocCoherent);
     if (he == hipSuccess) he = hipHostGetDevicePointer((void **)&d_h_sc, h_sc, 0);
     if (he != hipSuccess) {
         (void)hipFree(buf);
         if (h_sc) (void)hipHostFree(h_sc);
         return fail(c, GRAPE_ERR_ALLOC, std::string("grape_lbfgs: ") + hipGetErrorString(he));
     }
-    grape::LbfgsState st{};
+    LbfgsRun run;
+    run.c = c;
+    run.lead = lead;
+    run.h_sc = h_sc;
+    grape::LbfgsState &st = run.st;
     double *p = buf;
     st.x = p; p += kn;
     st.g = p; p += kn;
@@ -1564,57 +1824,96 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
     st.m = m;
     int rc = GRAPE_OK;
     auto cleanup = [&](int code) {
-        (void)hipStreamSynchronize(c->stream);
+        // after a timeout the device is presumed hung: synchronising would block for ever and freeing memory a running
+        // kernel may still write is no better -- the buffers are leaked and the error returned
+        if (run.hung) return code;
+        (void)hipSetDevice(lead->device);
+        (void)hipStreamSynchronize(lead->stream);
         (void)hipFree(buf);
         (void)hipHostFree(h_sc);
         return code;
     };
-    auto signal = [&]() {
-        grape::DoneSignal d;
-        d.flag = c->d_h_flag;
-        d.seq = ++c->seq;
-        return d;
-    };
     timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    // f(x0), g(x0)
-    if (hipMemcpyAsync(st.x, x0, sizeof(double) * kn, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    // f(x0), g(x0): x0 goes to the trial slot, the evaluation's [g, F] to the iterate
+    if (hipMemcpyAsync(st.x, x0, sizeof(double) * kn, hipMemcpyHostToDevice, lead->stream) != hipSuccess ||
+        hipMemcpyAsync(st.xt, st.x, sizeof(double) * kn, hipMemcpyDeviceToDevice, lead->stream) != hipSuccess)
         return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: upload of x0 failed"));
-    rc = enqueue_eval(c, st.x, st.fgt, c->stream, 1);
+    rc = run.evaluate(1);
     if (rc) return cleanup(rc);
-    if (grape::launch_lbfgs_init(st, c->stream, signal()) != hipSuccess)
+    HIP_TRY(c, hipSetDevice(lead->device));
+    if (grape::launch_lbfgs_init(st, lead->stream, run.signal()) != hipSuccess)
         return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed"));
-    rc = wait_flag(c);
+    rc = run.wait();
     if (rc) return cleanup(rc);
-    int evals = 1, it = 0, status = 2;
+    int it = 0, status = 2, hz_fallbacks = 0;
     double F = h_sc[0], gnorm = h_sc[1];
     if (gnorm <= g_tol) status = 0;
-    while (status == 2 && it < max_it) {
+    // the factor-2 ladder search of one iteration (trial points of the first ladder already written when `first_written`)
+    auto ladder = [&](bool &accepted) -> int {
         // Step lengths: start at 1 (Optim: InitialStatic(alpha = 1)); every launch probes B lengths in a
         // factor-2 ladder.  Ladders tried in turn until one holds an acceptable step:
         //   [1 .. 2^-(B-1)], then the next B LARGER lengths [2^B .. 2], then the next B smaller, ...
         // (expansion matters for the reference's UnitaryGate conventions, where g is not the gradient of
         // the reported figure of merit -- SURVEY.md App. C #2 -- and small steps along -g may not descend).
         int tried = 0, shrink = 0, grow = 0;
-        bool accepted = false;
-        const double F_prev = F;
+        accepted = false;
         while (tried < max_ls) {
             const bool up = (shrink > grow);                  // alternate: down, up, down, up, ...
             const int top = up ? (grow + 1) * B : -shrink * B;    // exponent of the ladder's largest length
             if (up) ++grow; else ++shrink;
-            if (top > 40 || top < -60) continue;
+            if (top > 40 && -shrink * B < -60) break;         // both directions exhausted: no acceptable step exists
+            if (top > 40 || top < -60) { tried += B; continue; }
             const double alpha0 = std::ldexp(1.0, top);
-            if (grape::launch_lbfgs_direction(st, B, alpha0, c->stream) != hipSuccess)
-                return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed"));
-            rc = enqueue_eval(c, st.xt, st.fgt, c->stream, B);
-            if (rc) return cleanup(rc);
-            if (grape::launch_lbfgs_select(st, B, c->stream, signal()) != hipSuccess)
-                return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed"));
-            rc = wait_flag(c);
-            if (rc) return cleanup(rc);
-            evals += B;
+            HIP_TRY(c, hipSetDevice(lead->device));
+            if (grape::launch_lbfgs_direction(st, B, alpha0, lead->stream) != hipSuccess)
+                return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
+            int r = run.evaluate(B);
+            if (r) return r;
+            HIP_TRY(c, hipSetDevice(lead->device));
+            if (grape::launch_lbfgs_select(st, B, lead->stream, run.signal(), 0) != hipSuccess)
+                return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
+            r = run.wait();
+            if (r) return r;
             tried += B;
             if (h_sc[5] == 0.0) { accepted = true; break; }
+        }
+        return GRAPE_OK;
+    };
+    while (status == 2 && it < max_it) {
+        const double F_prev = F;
+        bool accepted = false;
+        if (o.line_search == 2) {
+            rc = ladder(accepted);
+            if (rc) return cleanup(rc);
+        } else {
+            // direction + the trial point x + d (InitialStatic: alpha = 1)
+            HIP_TRY(c, hipSetDevice(lead->device));
+            if (grape::launch_lbfgs_direction(st, 1, 1.0, lead->stream) != hipSuccess)
+                return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed"));
+            HagerZhang hz{run, F, 0.0, 0.0, {}, {}, {}, -1.0, max_ls};
+            double alpha = 1.0, fa = F;
+            bool reeval = false;
+            const int hr = hz.search(1.0, o.line_search == 0, alpha, fa, reeval);
+            if (hr < 0) return cleanup(hr);
+            if (hr == 0) {
+                if (reeval) {                                      // the accepted step is not the one evaluated last
+                    double f2, df2;
+                    rc = run.phi(alpha, false, f2, df2);
+                    if (rc) return cleanup(rc);
+                }
+                HIP_TRY(c, hipSetDevice(lead->device));
+                if (grape::launch_lbfgs_select(st, 1, lead->stream, run.signal(), 2) != hipSuccess)
+                    return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed"));
+                rc = run.wait();
+                if (rc) return cleanup(rc);
+                accepted = true;
+            } else {                                               // no bracket: the ladder search takes this iteration
+                ++hz_fallbacks;
+                if (multi) { status = 3; break; }
+                rc = ladder(accepted);
+                if (rc) return cleanup(rc);
+            }
         }
         if (!accepted) { status = 3; break; }
         ++it;
@@ -1623,25 +1922,29 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
         if (gnorm <= g_tol) { status = 0; break; }
         if (f_tol > 0.0 && std::fabs(F - F_prev) <= f_tol * std::fabs(F)) { status = 1; break; }
     }
-    if (hipMemcpyAsync(c->h_fg, st.x, sizeof(double) * kn, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess)
+    HIP_TRY(c, hipSetDevice(lead->device));
+    if (hipMemcpyAsync(lead->h_fg, st.x, sizeof(double) * kn, hipMemcpyDeviceToHost, lead->stream) != hipSuccess ||
+        hipStreamSynchronize(lead->stream) != hipSuccess)
         return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: download of the minimiser failed"));
-    std::memcpy(x_min, c->h_fg, sizeof(double) * kn);
+    std::memcpy(x_min, lead->h_fg, sizeof(double) * kn);
     timespec t1;
     clock_gettime(CLOCK_MONOTONIC, &t1);
     result->minimum = F;
     result->g_norm = gnorm;
     result->seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     result->iterations = it;
-    result->evaluations = evals;
+    result->evaluations = run.evals;
     result->status = status;
     result->probes = B;
+    result->line_search = o.line_search;
+    result->ladder_fallbacks = hz_fallbacks;
     c->evaluated = true;
     return cleanup(GRAPE_OK);
 }
 
 extern "C" int grape_get_member_results(grape_ctx *c, double *foms, double *grads)
 {
+    DeviceGuard guard;
     if (!c) return GRAPE_ERR_INVALID_ARG;
     if (!c->evaluated) return fail(c, GRAPE_ERR_NOT_READY, "grape_get_member_results: no evaluation yet");
     if (c->is_group) {
@@ -1705,6 +2008,7 @@ static int fetch_slab(grape_ctx *c, const double2 *d_ws, int member, cplx *out, 
 extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props, double *states,
                                     double *costates)
 {
+    DeviceGuard guard;
     if (!c) return GRAPE_ERR_INVALID_ARG;
     if (!c->evaluated) return fail(c, GRAPE_ERR_NOT_READY, "grape_get_trajectory: no evaluation yet");
     if (member < 0 || member >= c->cfg.n_ensemble)
@@ -1798,6 +2102,7 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
 
 extern "C" int grape_get_kernel_time(grape_ctx *c, double *total_ms, int64_t *launches, int32_t reset)
 {
+    DeviceGuard guard;
     if (!c) return GRAPE_ERR_INVALID_ARG;
     if (c->is_group) {                                       // the shards run concurrently: report the slowest device
         double worst = 0.0;
@@ -1825,6 +2130,7 @@ extern "C" int grape_get_kernel_time(grape_ctx *c, double *total_ms, int64_t *la
 
 extern "C" int grape_get_kernel_samples(grape_ctx *c, double *total_ms, double *first_ms, int64_t capacity, int64_t *count)
 {
+    DeviceGuard guard;
     if (!c) return GRAPE_ERR_INVALID_ARG;
     if (c->is_group) {                                       // the shards run concurrently: the first device stands for them
         const int rc = grape_get_kernel_samples(c->sub[0], total_ms, first_ms, capacity, count);
@@ -1845,6 +2151,7 @@ extern "C" int grape_get_kernel_samples(grape_ctx *c, double *total_ms, double *
 
 extern "C" int grape_get_phase_stamps(grape_ctx *c, uint64_t *out, int64_t capacity, int64_t *count)
 {
+    DeviceGuard guard;
     if (!c) return GRAPE_ERR_INVALID_ARG;
     if (c->is_group || !c->d_stamps || !c->evaluated)
         return fail(c, GRAPE_ERR_NOT_READY, "grape_get_phase_stamps: needs GRAPE_FLAG_PHASE_STAMPS and an evaluation");

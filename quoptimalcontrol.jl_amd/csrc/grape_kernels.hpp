@@ -186,13 +186,14 @@ struct LbfgsState {
     double *fgt;              // B x (K*N + 1) trial results { g_j, F_j } (the batched evaluation's output)
     double *alphas;           // B trial step lengths
     double *sc;               // 8 scalars: F, |g|_inf, g'd, gamma, accepted alpha, status (1: no acceptable probe), n_hist, head
-    double *host_sc;          // mapped host mirror of sc
+    double *host_sc;          // mapped host mirror of sc (8 doubles) + [8] phi, [9] phi' of the last probe
     double c1, c2;
     int32_t KN, m;
 };
 hipError_t launch_lbfgs_init(const LbfgsState &st, hipStream_t stream, DoneSignal done);
 hipError_t launch_lbfgs_direction(const LbfgsState &st, int B, double alpha0, hipStream_t stream);
-hipError_t launch_lbfgs_select(const LbfgsState &st, int B, hipStream_t stream, DoneSignal done);
+hipError_t launch_lbfgs_select(const LbfgsState &st, int B, hipStream_t stream, DoneSignal done, int mode = 0);
+hipError_t launch_lbfgs_trial(const LbfgsState &st, double alpha, hipStream_t stream);
 
 // dst[i] = src[i], i < n: moves the all-reduced [G, F] into mapped pinned host memory (one small launch
 // instead of a D2H copy node: the host polls the stream)

@@ -127,7 +127,10 @@ __global__ __launch_bounds__(kLbfgsThreads) void lbfgs_direction_kernel(LbfgsSta
     }
 }
 
-__global__ __launch_bounds__(kLbfgsThreads) void lbfgs_select_kernel(LbfgsState st, int B, DoneSignal done)
+// mode 0: choose among the B probes (factor-2 ladder search); mode 1: PROBE -- publish phi = F and phi' = g.d of trial
+// slot 0 in host_sc[8], host_sc[9] and change nothing (the host runs the HagerZhang logic on those two scalars);
+// mode 2: COMMIT trial slot 0 unconditionally (the line search accepted it)
+__global__ __launch_bounds__(kLbfgsThreads) void lbfgs_select_kernel(LbfgsState st, int B, int mode, DoneSignal done)
 {
     __shared__ double s_part[kLbfgsThreads / 64];
     __shared__ int s_pick;
@@ -152,7 +155,21 @@ __global__ __launch_bounds__(kLbfgsThreads) void lbfgs_select_kernel(LbfgsState 
         }
         dgj[j] = sum(part);
     }
-    if (threadIdx.x == 0) {
+    if (mode == 1) {
+        if (threadIdx.x == 0) {
+            st.host_sc[8] = st.fgt[KN];
+            st.host_sc[9] = dgj[0];
+            st.host_sc[10] = dg0;                                  // phi'(0) = g.d, left by the direction kernel
+            if (done.flag) {
+                __threadfence_system();
+                __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
+    if (threadIdx.x == 0 && mode == 2)
+        s_pick = 0;
+    if (threadIdx.x == 0 && mode == 0) {
         int armijo = -1, wolfe = -1;
         for (int j = 0; j < B; ++j) {
             const double Fj = st.fgt[(size_t)j * Q + KN];
@@ -293,9 +310,24 @@ hipError_t launch_lbfgs_direction(const LbfgsState &st, int B, double alpha0, hi
     return hipGetLastError();
 }
 
-hipError_t launch_lbfgs_select(const LbfgsState &st, int B, hipStream_t stream, DoneSignal done)
+hipError_t launch_lbfgs_select(const LbfgsState &st, int B, hipStream_t stream, DoneSignal done, int mode)
 {
-    hipLaunchKernelGGL(lbfgs_select_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, B, done);
+    hipLaunchKernelGGL(lbfgs_select_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, B, mode, done);
+    return hipGetLastError();
+}
+
+// trial slot 0 <- x + alpha d
+__global__ __launch_bounds__(kLbfgsThreads) void lbfgs_trial_kernel(LbfgsState st, double alpha)
+{
+    for (int idx = threadIdx.x; idx < st.KN; idx += kLbfgsThreads)
+        st.xt[idx] = fma(alpha, st.d[idx], st.x[idx]);
+    if (threadIdx.x == 0)
+        st.alphas[0] = alpha;
+}
+
+hipError_t launch_lbfgs_trial(const LbfgsState &st, double alpha, hipStream_t stream)
+{
+    hipLaunchKernelGGL(lbfgs_trial_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, alpha);
     return hipGetLastError();
 }
 

@@ -517,7 +517,6 @@ GRAPE_DEV void tile2_prod(d4 &ore, d4 &oim, const AOp3 &a0, const AOp3 &a1, cons
     oim = t3;
 }
 
-constexpr int kHoist2Slices = 16;                                  // slices a workgroup walks (A'_k's tiles loaded once)
 
 __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
 {

@@ -73,12 +73,13 @@ class GrapeInfo(C.Structure):
 
 class GrapeLbfgsOptions(C.Structure):
     _fields_ = [("memory", C.c_int32), ("max_iterations", C.c_int32), ("g_tol", C.c_double), ("f_tol", C.c_double),
-                ("max_linesearch", C.c_int32), ("probes", C.c_int32)]
+                ("max_linesearch", C.c_int32), ("probes", C.c_int32), ("line_search", C.c_int32), ("reserved", C.c_int32)]
 
 
 class GrapeLbfgsResult(C.Structure):
     _fields_ = [("minimum", C.c_double), ("g_norm", C.c_double), ("seconds", C.c_double), ("iterations", C.c_int32),
-                ("evaluations", C.c_int32), ("status", C.c_int32), ("probes", C.c_int32)]
+                ("evaluations", C.c_int32), ("status", C.c_int32), ("probes", C.c_int32),
+                ("line_search", C.c_int32), ("ladder_fallbacks", C.c_int32)]
 
 
 class GrapeCommId(C.Structure):
@@ -306,16 +307,20 @@ class GrapeEngine:
 
     LBFGS_STATUS = {0: "g_tol reached", 1: "f_tol reached", 2: "max iterations", 3: "line search failed"}
 
-    def lbfgs(self, x0, memory=0, iterations=0, g_tol=-1.0, f_tol=0.0, max_linesearch=0, probes=0):
+    LINE_SEARCH = {"hagerzhang": 0, "hz": 0, "optim": 1, "hagerzhang_strict": 1, "ladder": 2}
+
+    def lbfgs(self, x0, memory=0, iterations=0, g_tol=-1.0, f_tol=0.0, max_linesearch=0, probes=0, line_search="hagerzhang"):
         """grape_lbfgs: device-resident L-BFGS from x0 (K,N) -> (x_min (K,N), result dict).  Optim LBFGS()
-        defaults when the options are left at 0 / negative; `probes` step lengths are evaluated per launch
-        (needs max_batch >= probes at construction)."""
+        defaults when the options are left at 0 / negative.  line_search: "hagerzhang" (Optim's line search, the
+        initial step accepted when it satisfies the Wolfe conditions), "optim" (Hager-Zhang exactly as Optim runs it
+        behind InitialStatic) or "ladder" (`probes` step lengths per batched launch; needs max_batch >= probes)."""
         x0 = np.asarray(x0, dtype=np.float64)
         if x0.shape != (self.K, self.N):
             raise ValueError(f"x0 must be ({self.K},{self.N})")
         xf = np.ascontiguousarray(x0.T)
         out = np.empty_like(xf)
-        opts = GrapeLbfgsOptions(int(memory), int(iterations), float(g_tol), float(f_tol), int(max_linesearch), int(probes))
+        opts = GrapeLbfgsOptions(int(memory), int(iterations), float(g_tol), float(f_tol), int(max_linesearch), int(probes),
+                                 self.LINE_SEARCH[line_search] if isinstance(line_search, str) else int(line_search), 0)
         res = GrapeLbfgsResult()
         self._check(self._lib.grape_lbfgs(self._h, _p(xf), C.byref(opts), _p(out), C.byref(res)))
         info = {f: getattr(res, f) for f, _ in res._fields_}

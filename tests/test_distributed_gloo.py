@@ -41,7 +41,8 @@ def _worker(rank, world, port, E, out, backend="gloo", collective="torch"):
     sg = ShardedGrape(w.E, w.K, w.N, lambda lo, hi: OracleLocal(w, lo, hi, w.K, w.N), torch.device("cpu"),
                       collective=collective)
     if collective == "lib":          # the stand-in evaluator cannot join a library communicator: every rank must
-        assert sg.collective == "torch" and "comm_attach" in sg.attach_error or "no members" in sg.attach_error
+        assert sg.collective == "torch" and ("comm_attach" in sg.attach_error or "no members" in sg.attach_error or
+                                             "another rank" in sg.attach_error)
     F, G = sg.eval(w.x)
     if rank == 0:
         np.save(out, np.concatenate([G.reshape(-1), [F], [sg.lo, sg.hi]]))
@@ -71,6 +72,47 @@ def test_library_collective_falls_back_consistently(tmp_path, oracle, qoc):
     w = qoc.workloads.config("C3", E=6, N=30)
     F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
     assert_parity(got[-3], got[:-3].reshape(w.K, w.N), F_ref, G_ref, w.n, what="lib->torch fallback")
+
+
+class AttachableLocal(OracleLocal):
+    """a stand-in that COULD join a library communicator (has comm_attach): a rank without members must stop the
+    others from calling it -- they would wait in ncclCommInitRank for a rank that never comes"""
+    calls = 0
+
+    def comm_unique_id(self):
+        return bytes(128)
+
+    def comm_attach(self, token, rank, world):
+        AttachableLocal.calls += 1
+        raise AssertionError("comm_attach called although a rank has no members")
+
+
+def _empty_rank_worker(rank, world, port, E, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import quoptimalcontrol_jl_amd as qoc
+    from quoptimalcontrol_jl_amd.distributed import ShardedGrape
+    w = qoc.workloads.config("C3", E=E, N=30)
+    sg = ShardedGrape(w.E, w.K, w.N, lambda lo, hi: AttachableLocal(w, lo, hi, w.K, w.N), torch.device("cpu"), collective="lib")
+    assert sg.collective == "torch" and AttachableLocal.calls == 0
+    assert ("no members" in sg.attach_error) == (sg.local is None)
+    F, G = sg.eval(w.x)
+    if rank == 0:
+        np.save(out, np.concatenate([G.reshape(-1), [F]]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("E,world", [(1, 2), (5, 4)])
+def test_rank_without_members_sends_everybody_to_the_fallback_before_any_attach(tmp_path, oracle, qoc, E, world):
+    """shard_bounds leaves trailing ranks empty (E = 1 on 2 ranks, E = 5 on 4); feasibility is agreed by an
+    all-reduce(MIN) BEFORE the unique-id broadcast, so the collectives stay matched and nobody blocks in the attach."""
+    out = str(tmp_path / "r0.npy")
+    mp.spawn(_empty_rank_worker, args=(world, 29600 + (os.getpid() + 211 + E) % 300, E, out), nprocs=world, join=True)
+    got = np.load(out)
+    w = qoc.workloads.config("C3", E=E, N=30)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    assert_parity(got[-1], got[:-1].reshape(w.K, w.N), F_ref, G_ref, w.n, what=f"E={E} world={world}")
 
 
 def _bcast_worker(rank, world, port, out):

@@ -25,7 +25,10 @@ def test_reference_single_problem_testsets_device_optimizer(qoc, sys_type, floor
     assert isinstance(sol, qoc.SolutionResult)
     assert sol.result.minimum - floor < tol
     assert sol.opti_pulses.shape == (2, 10) and sol.fidelity == sol.result.minimum
-    assert sol.result.device_lbfgs["probes"] == 4                 # tiny problem: four step lengths per launch
+    assert sol.result.device_lbfgs["probes"] == 1 and sol.result.device_lbfgs["line_search"] == 0   # Hager-Zhang, one trial per launch
+    lad = qoc.solve(prob, qoc.GRAPE(n_slices=10, isinplace=isinplace, optimizer="device", optim_options={"line_search": "ladder"}))
+    assert lad.result.minimum - floor < tol
+    assert lad.result.device_lbfgs["probes"] == 4 and lad.result.device_lbfgs["line_search"] == 2    # tiny problem: four step lengths per launch
 
 
 @pytest.mark.parametrize("sys_type,N,T,opts,isinplace,floor", [
@@ -85,12 +88,63 @@ def test_sequential_probes_without_batching(qoc):
     assert info["probes"] == 1 and F1 <= F0 and abs(F1 - info["minimum"]) <= 1e-12
 
 
+@pytest.mark.parametrize("mode", ["hagerzhang", "optim"])
+def test_hager_zhang_is_a_wolfe_line_search(qoc, mode):
+    """C3-shaped StateTransfer ensemble (the bench's optimiser problem, smaller): per iteration the device loop with
+    Optim's line search makes at least the progress of SciPy's L-BFGS-B (Wolfe line search, dcsrch) for the same
+    number of evaluations; the strict mode (Optim behind InitialStatic) never accepts a step on one evaluation."""
+    w = qoc.workloads.config("C3", E=64, N=100)
+    rho0 = np.zeros((4, 4), complex); rho0[0, 0] = 1
+    psi = np.array([1, 1j, -1, 0.5]) / np.linalg.norm([1, 1j, -1, 0.5])
+    Xi = np.broadcast_to(rho0, (w.E, 4, 4)).copy()
+    Xt = np.broadcast_to(np.outer(psi, psi.conj()), (w.E, 4, 4)).copy()
+    with qoc.GrapeEngine("StateTransfer", w.A, w.B, Xi, Xt, w.wts, w.T, w.N) as eng:
+        F0, _ = eng.eval(w.x)
+        x_min, info = eng.lbfgs(w.x, iterations=20, line_search=mode)
+        F1, _ = eng.eval(x_min)
+        from quoptimalcontrol_jl_amd.api import _lbfgs
+        res = _lbfgs(lambda x: eng.eval(x), w.x, {"iterations": 20})
+    assert info["line_search"] == (0 if mode == "hagerzhang" else 1) and info["ladder_fallbacks"] == 0
+    assert abs(F1 - info["minimum"]) <= 1e-12 and F1 < F0
+    assert info["evaluations"] >= (1 + info["iterations"] * (2 if mode == "optim" else 1))
+    # same iteration budget: the device loop's minimum is in the same league as SciPy's (both far below the start)
+    assert info["minimum"] - F0 <= 0.7 * (res.minimum - F0)
+
+
+def test_lbfgs_on_a_device_group_and_with_a_communicator(qoc):
+    """Multi-device contexts run the Hager-Zhang search (vectors on the first device, every evaluation the sharded one):
+    three shards on GPU 0 through the peer sum, and a 1-rank RCCL communicator, against the single-device run."""
+    w = qoc.workloads.reference_ensemble("StateTransfer", 5, 25, 5.0)
+    args = (w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N)
+    with qoc.GrapeEngine(*args) as eng:
+        x1, i1 = eng.lbfgs(w.x, iterations=15)
+    with qoc.GrapeEngine(*args, devices=[0, 0, 0], flags=qoc.engine.FLAG_GROUP_PEER_SUM) as eng:
+        assert eng.info["n_devices"] == 3
+        x3, i3 = eng.lbfgs(w.x, iterations=15)
+        with pytest.raises(qoc.GrapeError) as ei:
+            eng.lbfgs(w.x, line_search="ladder")
+        assert ei.value.status == -2                                # the batched ladder is single-device
+    with qoc.GrapeEngine(*args, force_collective=True) as eng:
+        xc, ic = eng.lbfgs(w.x, iterations=15)
+    for info, x in ((i3, x3), (ic, xc)):
+        assert info["iterations"] == i1["iterations"] and info["evaluations"] == i1["evaluations"]
+        assert abs(info["minimum"] - i1["minimum"]) <= 1e-10 and np.abs(x - x1).max() <= 1e-7
+
+
+def test_solve_shards_over_devices(qoc):
+    """GRAPE(devices=[...]) reaches grape_config.n_devices / device_ids (the Julia glue's `devices`): three shards on
+    GPU 0 with the peer sum, host-driven and device-resident optimisers."""
+    wl = qoc.workloads
+    prob = _problem(qoc, "StateTransfer", 25, 5.0)
+    ens = qoc.EnsembleProblem(prob=prob, n_ens=5, A_g=lambda k: (k - 2.5) / 2.5 * wl.Sz * 5, B_g=lambda k: [wl.Sx, wl.Sy],
+                              XiG=lambda k: prob.Xi, XtG=lambda k: wl.rho_fin if k % 2 else wl.rho_init, wts=np.ones(5) / 5)
+    for optimizer in ("host", "device"):
+        sol = qoc.solve(ens, qoc.GRAPE(n_slices=25, devices=[0, 0, 0], peer_sum=True, optimizer=optimizer))
+        assert sol.result.minimum - 0.75 < 1e-5
+
+
 def test_lbfgs_argument_errors(qoc):
     w = qoc.workloads.config("C1")
-    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, force_collective=True) as eng:
-        with pytest.raises(qoc.GrapeError) as ei:
-            eng.lbfgs(w.x)
-        assert ei.value.status == -2                                # single-device contexts only
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
         with pytest.raises(ValueError):
             eng.lbfgs(np.zeros((3, 3)))
