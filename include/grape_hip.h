@@ -319,6 +319,12 @@ int grape_get_kernel_time(grape_ctx *ctx, double *total_ms, int64_t *launches, i
  * first device.  *count (nullable) receives the number of durations available. */
 int grape_get_kernel_samples(grape_ctx *ctx, double *total_ms, double *first_ms, int64_t capacity, int64_t *count);
 
+/* Host-side cost of the sharded grape_eval of a multi-device context (n_devices >= 2), means over the evaluations since the
+ * last reset: out[0] = evaluations, then microseconds: out[1] writing x into every shard's buffer, out[2] first to last
+ * shard launch (the issue skew: one issuing thread per shard), out[3] issuing the sum (peer copies + reduction, or
+ * the grouped ncclAllReduce + publication), out[4] waiting for [G, F], out[5] the whole call.  out: double[6]. */
+int grape_get_group_timing(grape_ctx *ctx, double *out, int32_t reset);
+
 /* Diagnostic (GRAPE_FLAG_PHASE_STAMPS): the stamps of the last evaluation, 8 uint64 per wave,
  * waves ordered (member, wave-in-member): [0..4] shader clock at start / after propagators /
  * after scan / after forward sweep / end, [5],[6] 100 MHz real-time counter at start / end,

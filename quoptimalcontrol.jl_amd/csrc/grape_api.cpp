@@ -31,7 +31,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <utility>
 #include <string>
@@ -83,6 +86,7 @@ struct grape_ctx {
     unsigned long long *h_flag = nullptr, *d_h_flag = nullptr;
     unsigned *d_done_counter = nullptr;
     bool peer_sum = false;                     // group: [G, F] summed on the first device through peer copies (no RCCL)
+    bool peer_direct = false;                  // group: the first device can read every shard's memory (peer access): the sum reads the rows in place
     double *d_gather = nullptr;                // group, peer_sum: one row of K*N+1 doubles per shard, on the first device
     hipEvent_t ev_done = nullptr;              // shard of a peer_sum group: its evaluation has finished
     bool thin = false;                         // rank-one states: matrix-vector chain (sweep_thin.hip)
@@ -132,6 +136,9 @@ struct grape_ctx {
     bool is_group = false;
     std::vector<grape_ctx *> sub;
     std::vector<int> sub_lo;      // first member of every shard
+    struct GroupWorker *worker = nullptr;     // shard of a group (not the first): the thread that issues its launches
+    double group_tm[5] = {0, 0, 0, 0, 0};     // group: accumulated seconds [x fan-out, shard launches first->last, sum issue, wait, total]
+    uint64_t group_tm_n = 0;
     double timeout_s = 600.0;
     double eval_ema_s = 0.0;      // smoothed duration of the last evaluations (long ones sleep through most of it)
     mutable std::string err;
@@ -224,6 +231,42 @@ struct DeviceGuard {
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
+// One issuing thread per shard of an in-process group (all but the first, which the calling thread serves): a group
+// evaluation used to be issued shard after shard by ONE host thread -- two launches and an event per shard, ~10 us each,
+// so that the eighth shard of a C3 evaluation started ~70 us after the first, twice its own 32 us kernel.  The workers
+// spin on a sequence word while evaluations keep coming (an optimiser calls every ~100 us) and go to sleep on a
+// condition variable after 2 ms without work.
+struct GroupWorker {
+    std::thread th;
+    std::atomic<uint64_t> req{0}, done{0};
+    std::atomic<bool> asleep{false}, stop{false};
+    std::mutex mu;
+    std::condition_variable cv;
+    grape_ctx *shard = nullptr;
+    int (*job)(grape_ctx *) = nullptr;             // what to issue for this shard (set before req is bumped)
+    int rc = 0;
+    void post(int (*fn)(grape_ctx *))
+    {
+        job = fn;
+        req.fetch_add(1, std::memory_order_release);
+        if (asleep.load(std::memory_order_acquire)) {
+            std::lock_guard<std::mutex> lk(mu);
+            cv.notify_one();
+        }
+    }
+    int wait()                                     // the poster's side: spin until the job has been issued
+    {
+        const uint64_t want = req.load(std::memory_order_relaxed);
+        while (done.load(std::memory_order_acquire) != want) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        return rc;
+    }
+    void run();
+};
+
 // diagnostic switches: set and not "0"
 static bool env_on(const char *name)
 {
@@ -236,6 +279,17 @@ static size_t KN(const grape_ctx *c) { return (size_t)c->cfg.n_controls * c->cfg
 static void free_all(grape_ctx *c)
 {
     if (!c) return;
+    if (c->worker) {
+        GroupWorker *w = c->worker;
+        w->stop.store(true);
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->cv.notify_one();
+        }
+        if (w->th.joinable()) w->th.join();
+        delete w;
+        c->worker = nullptr;
+    }
     for (grape_ctx *s : c->sub) free_all(s);
     c->sub.clear();
     if (c->is_group) {
@@ -599,6 +653,36 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
             g->sub[i]->comm = comms[i];
             g->sub[i]->comm_rank = i;
             g->sub[i]->comm_size = G;
+        }
+    }
+    // peer access between every pair of distinct devices of the group: x fan-out and the [G, F] rows travel device to
+    // device over xGMI instead of being staged through host memory ("already enabled" is fine)
+    g->peer_direct = G <= grape::kMaxShards;
+    for (int i = 0; i < G; ++i)
+        for (int j = 0; j < G; ++j) {
+            const int di = g->sub[i]->device, dj = g->sub[j]->device;
+            if (di == dj) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, di, dj) != hipSuccess || !can) {
+                if (i == 0) g->peer_direct = false;
+                continue;
+            }
+            if (hipSetDevice(di) == hipSuccess) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(dj, 0);
+                if (pe != hipSuccess) (void)hipGetLastError();     // hipErrorPeerAccessAlreadyEnabled and friends
+            }
+        }
+    // one issuing thread per shard beyond the first (GroupWorker): the shards of an evaluation are launched at once
+    for (int i = 1; i < G; ++i) {
+        GroupWorker *w = new (std::nothrow) GroupWorker();
+        if (!w) { free_all(g); return fail(nullptr, GRAPE_ERR_ALLOC, "grape_create: out of host memory"); }
+        w->shard = g->sub[i];
+        g->sub[i]->worker = w;
+        try {
+            w->th = std::thread([w] { w->run(); });
+        } catch (...) {
+            free_all(g);
+            return fail(nullptr, GRAPE_ERR_ALLOC, "grape_create: cannot start the issuing thread of a shard");
         }
     }
     const grape_ctx *s0 = g->sub[0];
@@ -1230,8 +1314,24 @@ static int wait_stream(grape_ctx *c, hipStream_t stream)
     }
 }
 
-// x (host) -> this shard's d_x, evaluation into `target`, all on the shard's private stream
-static int shard_enqueue_host(grape_ctx *s, const double *x, int n_x, double *target, bool signal)
+// x (host) -> where this shard's kernels will read it: straight into device memory through the BAR, or the mapped staging
+// buffer that shard_issue's copy launch drains.  Host work only (no HIP call).
+static void shard_stage_x(grape_ctx *s, const double *x, int n_x)
+{
+    const size_t kn = KN(s);
+    if (s->x_upload == 2) {     // posted writes through the BAR; the doorbell of the launch that follows them orders them
+        std::memcpy(s->d_x_bar, x, sizeof(double) * kn * n_x);
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#if defined(__x86_64__)
+        __builtin_ia32_sfence();
+#endif
+    } else {
+        std::memcpy(s->h_stage, x, sizeof(double) * kn * n_x);
+    }
+}
+
+// the launches of one shard's evaluation of the staged x into `target`, on the shard's private stream
+static int shard_issue(grape_ctx *s, int n_x, double *target, bool signal)
 {
     HIP_TRY(s, hipSetDevice(s->device));
     if (s->dev_pending) {                                   // order behind the last grape_eval_device
@@ -1240,20 +1340,12 @@ static int shard_enqueue_host(grape_ctx *s, const double *x, int n_x, double *ta
     }
     const size_t kn = KN(s);
     const double *d_x = s->d_x;
-    if (s->x_upload == 2) {     // posted writes through the BAR; the doorbell of the launch below follows them
-        std::memcpy(s->d_x_bar, x, sizeof(double) * kn * n_x);
-        __atomic_thread_fence(__ATOMIC_SEQ_CST);
-#if defined(__x86_64__)
-        __builtin_ia32_sfence();
-#endif
+    if (s->x_upload == 2)
         d_x = s->d_x_bar;
-    } else {
-        std::memcpy(s->h_stage, x, sizeof(double) * kn * n_x);
-        if (s->x_upload == 1)   // a small kernel pulls x out of the coherent mapped staging buffer
-            HIP_TRY(s, grape::launch_copy(s->d_h_stage, s->d_x, (int)(kn * n_x), s->stream));
-        else
-            HIP_TRY(s, hipMemcpyAsync(s->d_x, s->h_stage, sizeof(double) * kn * n_x, hipMemcpyHostToDevice, s->stream));
-    }
+    else if (s->x_upload == 1)  // a small kernel pulls x out of the coherent mapped staging buffer
+        HIP_TRY(s, grape::launch_copy(s->d_h_stage, s->d_x, (int)(kn * n_x), s->stream));
+    else
+        HIP_TRY(s, hipMemcpyAsync(s->d_x, s->h_stage, sizeof(double) * kn * n_x, hipMemcpyHostToDevice, s->stream));
     grape::DoneSignal done;
     if (signal) {                  // single GPU: the reduce kernel stages [G, F] in d_fg and its last workgroup
         done.counter = s->d_done_counter;          // writes them to the mapped host buffer + the completion flag
@@ -1263,6 +1355,53 @@ static int shard_enqueue_host(grape_ctx *s, const double *x, int n_x, double *ta
         target = s->d_fg;
     }
     return enqueue_eval(s, d_x, target, s->stream, n_x, done);
+}
+
+static int shard_enqueue_host(grape_ctx *s, const double *x, int n_x, double *target, bool signal)
+{
+    shard_stage_x(s, x, n_x);
+    return shard_issue(s, n_x, target, signal);
+}
+
+// a group shard's share of grape_eval: its launches, then the event the sum on the first device waits for
+static int shard_issue_group(grape_ctx *s)
+{
+    int rc = shard_issue(s, 1, s->d_fg, false);
+    if (rc == GRAPE_OK && s->ev_done && hipEventRecord(s->ev_done, s->stream) != hipSuccess)
+        rc = fail(s, GRAPE_ERR_HIP, "hipEventRecord failed");
+    return rc;
+}
+
+void GroupWorker::run()
+{
+    (void)hipSetDevice(shard->device);
+    uint64_t seen = 0;
+    timespec idle_since;
+    clock_gettime(CLOCK_MONOTONIC, &idle_since);
+    for (;;) {
+        unsigned spins = 0;
+        while (req.load(std::memory_order_acquire) == seen) {
+            if (stop.load(std::memory_order_relaxed)) return;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+            if ((++spins & 4095) == 0) {                     // 2 ms without work: sleep until the next post
+                timespec now;
+                clock_gettime(CLOCK_MONOTONIC, &now);
+                const double idle = (double)(now.tv_sec - idle_since.tv_sec) + 1e-9 * (double)(now.tv_nsec - idle_since.tv_nsec);
+                if (idle > 2e-3) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    asleep.store(true, std::memory_order_release);
+                    cv.wait(lk, [&] { return req.load(std::memory_order_acquire) != seen || stop.load(); });
+                    asleep.store(false, std::memory_order_release);
+                }
+            }
+        }
+        seen = req.load(std::memory_order_acquire);
+        rc = job ? job(shard) : 0;
+        done.store(seen, std::memory_order_release);
+        clock_gettime(CLOCK_MONOTONIC, &idle_since);
+    }
 }
 
 // Blocks until the final kernel has published sequence number s->seq in the host flag (see
@@ -1323,7 +1462,7 @@ static int wait_flag(grape_ctx *s)
 static int group_fail(grape_ctx *g, grape_ctx *s, int rc) { return fail(g, rc, s->err); }
 
 static int enqueue_peer_sum(grape_ctx *g, double *target, hipStream_t lead_stream, bool shard0_on_lead,
-                            grape::DoneSignal done);
+                            grape::DoneSignal done, bool record = true);
 
 extern "C" int grape_eval_device(grape_ctx *c, const double *d_x, double *d_fg, void *stream)
 {
@@ -1390,21 +1529,33 @@ extern "C" int grape_eval_device(grape_ctx *c, const double *d_x, double *d_fg, 
 // own evaluation and ONE reduction kernel sums the rows in shard order into `target` (and, with `done`, publishes them
 // to the host like the single-GPU path).  `shard0_on_lead`: shard 0 was evaluated on `lead_stream` itself.
 static int enqueue_peer_sum(grape_ctx *g, double *target, hipStream_t lead_stream, bool shard0_on_lead,
-                            grape::DoneSignal done)
+                            grape::DoneSignal done, bool record)
 {
     grape_ctx *lead = g->sub[0];
     const size_t Q = KN(g) + 1;
+    grape::ShardRows rows{};
+    rows.n = (int)g->sub.size();
+    const bool direct = g->peer_direct;                      // every shard's row readable from the first device
     for (size_t i = 0; i < g->sub.size(); ++i) {
         grape_ctx *s = g->sub[i];
+        rows.p[i] = s->d_fg;
         if (!(i == 0 && shard0_on_lead)) {
-            HIP_TRY(g, hipSetDevice(s->device));
-            HIP_TRY(g, hipEventRecord(s->ev_done, s->stream));
+            if (record) {                                    // (grape_eval's issuing threads have recorded it themselves)
+                HIP_TRY(g, hipSetDevice(s->device));
+                HIP_TRY(g, hipEventRecord(s->ev_done, s->stream));
+            }
             HIP_TRY(g, hipSetDevice(lead->device));
             HIP_TRY(g, hipStreamWaitEvent(lead_stream, s->ev_done, 0));
         }
-        HIP_TRY(g, hipSetDevice(lead->device));
-        HIP_TRY(g, hipMemcpyPeerAsync(g->d_gather + i * Q, lead->device, s->d_fg, s->device, sizeof(double) * Q, lead_stream));
     }
+    HIP_TRY(g, hipSetDevice(lead->device));
+    if (direct && g->sub.size() <= (size_t)grape::kMaxShards) {
+        // one kernel on the first device reads the G rows where the shards left them (peer access) and publishes
+        HIP_TRY(g, grape::launch_reduce_shards(rows, target, (int)Q, lead_stream, done));
+        return GRAPE_OK;
+    }
+    for (size_t i = 0; i < g->sub.size(); ++i)               // no peer access between some pair: staged copies
+        HIP_TRY(g, hipMemcpyPeerAsync(g->d_gather + i * Q, lead->device, g->sub[i]->d_fg, g->sub[i]->device, sizeof(double) * Q, lead_stream));
     HIP_TRY(g, grape::launch_reduce_rows(g->d_gather, target, (int)g->sub.size(), (int)Q, 1, lead_stream, done));
     return GRAPE_OK;
 }
@@ -1427,32 +1578,52 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
         rc = shard_enqueue_host(c, x, n_x, c->d_h_fg, true);
         if (rc) return rc;
     } else {
-        if (c->is_group && c->peer_sum) {
-            for (grape_ctx *s : c->sub) {
-                rc = shard_enqueue_host(s, x, 1, s->d_fg, false);
-                if (rc) return group_fail(c, s, rc);
+        if (c->is_group) {
+            // x into every shard's buffer first, then all shards issue AT ONCE: shard 0 from this thread, the others from
+            // their own issuing threads (GroupWorker) -- the last shard starts one launch latency behind the first one,
+            // not G of them
+            timespec ts0, ts1, ts2, ts3;
+            clock_gettime(CLOCK_MONOTONIC, &ts0);
+            for (grape_ctx *s : c->sub) shard_stage_x(s, x, 1);
+            clock_gettime(CLOCK_MONOTONIC, &ts1);
+            for (size_t i = 1; i < c->sub.size(); ++i) c->sub[i]->worker->post(shard_issue_group);
+            rc = shard_issue(lead, 1, lead->d_fg, false);
+            int rc_w = GRAPE_OK;
+            grape_ctx *bad = nullptr;
+            for (size_t i = 1; i < c->sub.size(); ++i) {
+                const int r = c->sub[i]->worker->wait();
+                if (r && !rc_w) { rc_w = r; bad = c->sub[i]; }
             }
-            grape::DoneSignal done;                          // the reduction kernel publishes like the single-GPU path
-            done.counter = lead->d_done_counter;
-            done.flag = lead->d_h_flag;
-            done.seq = ++lead->seq;
-            done.host_out = lead->d_h_fg;
-            rc = enqueue_peer_sum(c, lead->d_fg, lead->stream, true, done);
-            if (rc) return rc;
-        } else if (c->is_group) {
-            for (grape_ctx *s : c->sub) {
-                rc = shard_enqueue_host(s, x, 1, s->d_fg, false);
-                if (rc) return group_fail(c, s, rc);
-            }
-            NCCL_TRY(c, g_rccl.GroupStart());
-            for (grape_ctx *s : c->sub) {
-                const ncclResult_t r = g_rccl.AllReduce(s->d_fg, s->d_fg, Q, ncclDouble, ncclSum, s->comm, s->stream);
-                if (r != ncclSuccess) {
-                    (void)g_rccl.GroupEnd();
-                    return fail(c, GRAPE_ERR_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+            if (rc) return group_fail(c, lead, rc);
+            if (rc_w) return group_fail(c, bad, rc_w);
+            clock_gettime(CLOCK_MONOTONIC, &ts2);
+            if (c->peer_sum) {
+                grape::DoneSignal done;                      // the reduction kernel publishes like the single-GPU path
+                done.counter = lead->d_done_counter;
+                done.flag = lead->d_h_flag;
+                done.seq = ++lead->seq;
+                done.host_out = lead->d_h_fg;
+                rc = enqueue_peer_sum(c, lead->d_fg, lead->stream, true, done, false);
+                if (rc) return rc;
+            } else {
+                NCCL_TRY(c, g_rccl.GroupStart());
+                for (grape_ctx *s : c->sub) {
+                    const ncclResult_t r = g_rccl.AllReduce(s->d_fg, s->d_fg, Q, ncclDouble, ncclSum, s->comm, s->stream);
+                    if (r != ncclSuccess) {
+                        (void)g_rccl.GroupEnd();
+                        return fail(c, GRAPE_ERR_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+                    }
                 }
+                NCCL_TRY(c, g_rccl.GroupEnd());
             }
-            NCCL_TRY(c, g_rccl.GroupEnd());
+            clock_gettime(CLOCK_MONOTONIC, &ts3);
+            auto dt = [](const timespec &a, const timespec &b) { return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec); };
+            c->group_tm[0] += dt(ts0, ts1);
+            c->group_tm[1] += dt(ts1, ts2);
+            c->group_tm[2] += dt(ts2, ts3);
+            c->group_tm_n += 1;
+            c->group_tm[4] -= (double)ts0.tv_sec + 1e-9 * (double)ts0.tv_nsec;      // (+ the end time below)
+            c->group_tm[3] -= (double)ts3.tv_sec + 1e-9 * (double)ts3.tv_nsec;
         } else {
             rc = shard_enqueue_host(c, x, 1, c->d_fg, false);
             if (rc) return rc;
@@ -1469,6 +1640,13 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
         }
     }
     rc = wait_flag(lead);                                    // [G, F] are in host memory
+    if (c->is_group) {
+        timespec te;
+        clock_gettime(CLOCK_MONOTONIC, &te);
+        const double tend = (double)te.tv_sec + 1e-9 * (double)te.tv_nsec;
+        c->group_tm[3] += tend;
+        c->group_tm[4] += tend;
+    }
     if (rc) return c->is_group ? group_fail(c, lead, rc) : rc;
     if (c->is_group) {
         // the other shards' streams finish with the same all-reduce; drain them so that the next call
@@ -2145,6 +2323,19 @@ extern "C" int grape_get_kernel_samples(grape_ctx *c, double *total_ms, double *
     for (int64_t i = 0; i < n; ++i) {                        // the most recent n, oldest first
         if (total_ms) total_ms[i] = c->smp_total[(size_t)(have - n + i)];
         if (first_ms) first_ms[i] = c->smp_first[(size_t)(have - n + i)];
+    }
+    return GRAPE_OK;
+}
+
+extern "C" int grape_get_group_timing(grape_ctx *c, double *out, int32_t reset)
+{
+    if (!c || !out) return GRAPE_ERR_INVALID_ARG;
+    const double n = c->group_tm_n ? (double)c->group_tm_n : 1.0;
+    out[0] = (double)c->group_tm_n;
+    for (int i = 0; i < 5; ++i) out[1 + i] = 1e6 * c->group_tm[i] / n;
+    if (reset) {
+        c->group_tm_n = 0;
+        for (double &v : c->group_tm) v = 0.0;
     }
     return GRAPE_OK;
 }

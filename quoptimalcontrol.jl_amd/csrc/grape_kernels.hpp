@@ -160,6 +160,15 @@ int reduce_ksplit(int E);
 hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, int n_x, hipStream_t stream,
                               DoneSignal done = DoneSignal());
 
+// fg[q] = sum_g rows.p[g][q] over the G <= 8 shards of a multi-device context, in shard order; the rows are read in place
+// (peer access), no staging copies
+constexpr int kMaxShards = 8;
+struct ShardRows {
+    const double *p[kMaxShards];
+    int n;
+};
+hipError_t launch_reduce_shards(const ShardRows &rows, double *fg, int Q, hipStream_t stream, DoneSignal done = DoneSignal());
+
 // ---- exact gradient / functional path (exact_grad.hip), n <= 4 ---------------------------------------
 struct ExactParams {
     const double2 *ops;       // as SweepParams.ops (prescaled generators)

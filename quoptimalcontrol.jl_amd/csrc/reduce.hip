@@ -222,6 +222,43 @@ __global__ __launch_bounds__(256) void reduce_few_kernel(const double *__restric
     }
 }
 
+// the shards of a multi-device context: fg[q] = sum over the shards' rows, in shard order, each row read where it was
+// produced (the devices of a group have peer access to each other) -- no staging copies, one launch
+__global__ __launch_bounds__(256) void reduce_shards_kernel(ShardRows rows, double *__restrict__ fg, int Q, DoneSignal done)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    double acc = 0.0;
+    if (q < Q) {
+        double v[kMaxShards];
+#pragma unroll
+        for (int g = 0; g < kMaxShards; ++g)
+            v[g] = g < rows.n ? rows.p[g][q] : 0.0;           // all loads in flight together
+#pragma unroll
+        for (int g = 0; g < kMaxShards; ++g)
+            acc += v[g];
+    }
+    if (done.flag && done.host_out) {
+        if (q < Q)
+            stage_store(fg, q, acc);
+        publish_via_last_block(done, fg, Q, gridDim.x);
+    } else {
+        if (q < Q)
+            fg[q] = acc;
+        if (done.flag) {
+            __threadfence_system();
+            __syncthreads();
+            if (threadIdx.x == 0)
+                signal_done(done, gridDim.x);
+        }
+    }
+}
+
+hipError_t launch_reduce_shards(const ShardRows &rows, double *fg, int Q, hipStream_t stream, DoneSignal done)
+{
+    hipLaunchKernelGGL(reduce_shards_kernel, dim3((Q + 255) / 256), dim3(256), 0, stream, rows, fg, Q, done);
+    return hipGetLastError();
+}
+
 hipError_t launch_reduce(const double *member_out, const double *wts, double *partial, double *fg,
                          int E, int Q, int ksplit, hipStream_t stream, DoneSignal done)
 {

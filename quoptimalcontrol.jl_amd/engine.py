@@ -39,7 +39,8 @@ EXPORTS = ["grape_abi_version", "grape_create", "grape_destroy", "grape_set_oper
            "grape_comm_unique_id", "grape_comm_attach",
            "grape_eval", "grape_eval_device", "grape_eval_batch", "grape_eval_batch_device", "grape_lbfgs",
            "grape_get_member_results", "grape_get_trajectory",
-           "grape_get_kernel_time", "grape_get_kernel_samples", "grape_get_phase_stamps", "grape_get_info",
+           "grape_get_kernel_time", "grape_get_kernel_samples", "grape_get_group_timing", "grape_get_phase_stamps",
+           "grape_get_info",
            "grape_last_error"]
 
 
@@ -128,6 +129,7 @@ def load_library():
     L.grape_get_trajectory.argtypes = [vp, i32, vp, vp, vp]
     L.grape_get_kernel_time.argtypes = [vp, dp, C.POINTER(C.c_int64), i32]
     L.grape_get_kernel_samples.argtypes = [vp, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.grape_get_group_timing.argtypes = [vp, vp, i32]
     L.grape_get_phase_stamps.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.grape_get_info.argtypes = [vp, C.POINTER(GrapeInfo)]
     L.grape_last_error.argtypes = [vp]
@@ -372,6 +374,12 @@ class GrapeEngine:
         out = np.empty(cnt.value, dtype=np.uint64)
         self._check(self._lib.grape_get_phase_stamps(self._h, _p(out), cnt.value, C.byref(cnt)))
         return out.reshape(-1, 8)
+
+    def group_timing(self, reset=False):
+        """multi-device contexts: mean host-side microseconds per grape_eval since the last reset."""
+        out = np.zeros(6)
+        self._check(self._lib.grape_get_group_timing(self._h, _p(out), int(reset)))
+        return dict(zip(("evaluations", "stage_x_us", "issue_skew_us", "sum_issue_us", "wait_us", "total_us"), out.tolist()))
 
     def kernel_samples(self, capacity=65536):
         """(total_ms, first_ms): per-evaluation kernel durations since the last kernel_time(reset=True) (FLAG_TIME_KERNELS);

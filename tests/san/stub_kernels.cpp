@@ -11,6 +11,7 @@ hipError_t launch_sweep_tile(int, int, bool, const TileParams &, hipStream_t) { 
 hipError_t launch_reduce(const double *, const double *, double *, double *, int, int, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
 hipError_t launch_reduce_rows(const double *, double *, int, int, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
 hipError_t launch_copy(const double *, double *, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
+hipError_t launch_reduce_shards(const ShardRows &, double *, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
 int sweep_small_max_waves(int n) { return n == 2 ? 16 : (n == 3 ? 8 : (n == 4 ? 4 : 0)); }
 int sweep_pair_max_waves(int n) { return n == 2 ? 16 : (n == 4 ? 8 : 0); }
 size_t sweep_small_lds_bytes(int n, int MPB, int LT, int S, int K, bool x) { return 16 * (size_t)n * n * 32 + (x ? 8 * ((size_t)MPB * LT * ((size_t)S * K + 1) + MPB) : 0); }
