@@ -933,7 +933,9 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         bool hz = c->family == 1 && !c->pack2 && c->cfg.gradient != GRAPE_GRADIENT_EXACT;
         const char *he = std::getenv("GRAPE_HOIST");
         if (he && he[0] == '0') hz = false;
-        if (hz && !(he && he[0] == '1') && c->EU < 8) hz = false;
+        // (16 x 16: below 8 units the pre-pass launch costs more than it saves; 32 x 32: the hoisted kernel is also the
+        //  four-waves-per-propagator one, 4-6x shorter per slice than prop_tile_kernel<2> -- single problems take it too)
+        if (hz && !(he && he[0] == '1') && c->EU < 8 && c->NT == 1) hz = false;
         for (size_t k = 1; k < E && hz; ++k)
             hz = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
         c->hoist = hz;

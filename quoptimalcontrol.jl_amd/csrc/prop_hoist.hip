@@ -28,46 +28,61 @@
 namespace grape {
 
 // ---------------------------------------------------------------------------------------------------------------
-// Gc_t and its norm bound: one wave per (slice, control array); tiles one after the other
+// Gc_t and its norm bound: one workgroup per (slice, control array), one wave per tile (a single problem's evaluation
+// waits for this pre-pass: the K dependent tile loads of the four tiles run side by side)
 template <int NT>
-__global__ __launch_bounds__(64) void ctrl_sum_kernel(const TileParams p)
+__global__ __launch_bounds__(64 * NT * NT) void ctrl_sum_kernel(const TileParams p)
 {
     constexpr int TSZ = NT * NT * 256;
-    const int lane = threadIdx.x, t = blockIdx.x, z = blockIdx.y;
+    __shared__ double s_col[NT * NT][16];
+    const int lane = threadIdx.x & 63, tile = threadIdx.x >> 6, t = blockIdx.x, z = blockIdx.y;
     const int K = p.K;
-    const double2 *__restrict__ B0 = p.ops + TSZ;                  // unit 0: [A | B_1..B_K | ...]
+    const double2 *__restrict__ B0 = p.ops + TSZ + tile * 256;     // unit 0: [A | B_1..B_K | ...]
     const double *__restrict__ x = p.x + (size_t)z * K * p.N + (size_t)t * K;
-    double2 *__restrict__ out = p.gc + ((size_t)z * p.N + t) * TSZ;
+    double2 *__restrict__ out = p.gc + ((size_t)z * p.N + t) * TSZ + tile * 256;
     const double dt = p.dt;
-    double colmax = 0.0;
+    double hr[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+    for (int c = 0; c < K; ++c) {
+        const double xv = x[c];
 #pragma unroll
-    for (int J = 0; J < NT; ++J) {
-        double cs = 0.0;
-#pragma unroll
-        for (int I = 0; I < NT; ++I) {
-            double hr[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
-            for (int c = 0; c < K; ++c) {
-                const double xv = x[c];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double2 b = B0[(size_t)c * TSZ + ((I * NT + J) * 4 + r) * 64 + lane];
-                    hr[r] = fma(b.x, xv, hr[r]);
-                    hi[r] = fma(b.y, xv, hi[r]);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double gr = dt * hi[r], gi = -dt * hr[r];    // (-i dt) H
-                out[((I * NT + J) * 4 + r) * 64 + lane] = make_double2(gr, gi);
-                cs += fabs(gr) + fabs(gi);
-            }
+        for (int r = 0; r < 4; ++r) {
+            const double2 b = B0[(size_t)c * TSZ + r * 64 + lane];
+            hr[r] = fma(b.x, xv, hr[r]);
+            hi[r] = fma(b.y, xv, hi[r]);
         }
-        cs = swap16_add(cs, cs);                                   // rows live on lane >> 4 and r
-        cs = swap32_add(cs, cs);
-        colmax = fmax(colmax, cs);
     }
-    colmax = wave_max_fast(colmax);
-    if (lane == 0)
+    double cs = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double gr = dt * hi[r], gi = -dt * hr[r];            // (-i dt) H
+        out[r * 64 + lane] = make_double2(gr, gi);
+        cs += fabs(gr) + fabs(gi);
+    }
+    cs = swap16_add(cs, cs);                                       // rows live on lane >> 4 and r: column sums of this tile
+    cs = swap32_add(cs, cs);
+    if (NT > 1) {                                                  // (every wave reaches every barrier)
+        if (lane < 16)
+            s_col[tile][lane] = cs;
+        __syncthreads();
+        cs = 0.0;                                                  // waves 0..NT-1: column block J summed over the tile rows
+        if (tile < NT) {
+#pragma unroll
+            for (int I = 0; I < NT; ++I)
+                cs += s_col[I * NT + tile][lane & 15];
+        }
+    }
+    double colmax = wave_max_fast(cs);
+    if (NT > 1) {
+        __syncthreads();
+        if (lane == 0)
+            s_col[tile][0] = colmax;
+        __syncthreads();
+        colmax = 0.0;
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+            colmax = fmax(colmax, s_col[J][0]);
+    }
+    if (lane == 0 && tile == 0)
         p.gcn[(size_t)z * p.N + t] = colmax * (1.0 / kTheta8);     // the expm kernel adds |A'_k|_1 / theta8
 }
 
@@ -687,7 +702,7 @@ __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
 // ---------------------------------------------------------------------------------------------------------------
 hipError_t launch_ctrl_sum(int NT, const TileParams &p, hipStream_t stream)
 {
-    const dim3 grid(p.N, p.n_x), block(64);
+    const dim3 grid(p.N, p.n_x), block(64 * NT * NT);
     if (NT == 1)
         hipLaunchKernelGGL((ctrl_sum_kernel<1>), grid, block, 0, stream, p);
     else
