@@ -164,10 +164,11 @@ def test_time_chunks_ragged_and_entry_points(qoc, oracle, monkeypatch, n, sys_ty
 
 
 @pytest.mark.parametrize("name,E,members,dense", [("C4", 1024, (0, 1, 511, 1023), False), ("C4", 1024, (0, 1023), True),
-                                                  ("C5", 1024, (0, 1023), False)])
+                                                  ("C5", 1024, (0, 1023), False), ("C5", 4096, (0, 2047, 4095), False)])
 def test_full_size_spot_members(qoc, oracle, name, E, members, dense):
     """Full BASELINE sizes (C4: E = 1024, N = 1000 -- the two-wave chain kernel the bench runs; C5: E = 1024 of
-    4096, N = 2000, the unitary tile flow): spot members against the oracle, the weighted sum, reproducibility.
+    4096, N = 2000, the unitary tile flow, and the whole E = 4096 ensemble on ONE GPU as the bench times it -- 134 GB
+    of propagators): spot members against the oracle, the weighted sum, reproducibility.
     The small-E parity tests above take different launch branches (E < 2048, pack2, LDS fit)."""
     w = qoc.workloads.config(name, E=E)
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N,
