@@ -3,7 +3,7 @@
 #   tools/refresh_profiles.sh <tag>      -> gpurun_out/prof_<tag>/...   (copy what is to be judged into profiles/)
 # rocprofv3 runs the program itself after `--` (python3 bench.py ...), PMC passes are separate kernel-trace-only runs.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -28,8 +28,14 @@ GRAPE_NO_THIN=1 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C4dense" --config C4 > 
 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C5" --config C5 --steps 2 --warmup 1 > "$OUT/pmc_C5.log" 2>&1
 cd "$ROOT"
 python3 tools/phase_profile.py --config C3 > "$OUT/C3_phase_stamps.json" 2> /dev/null
+python3 tools/group_overhead.py > "$OUT/group_overhead_C3.json" 2> /dev/null
+python3 tools/group_overhead.py --ensemble 128 > "$OUT/group_overhead_C3_E128.json" 2> /dev/null
+./tools/ubench/pipe_mix > "$OUT/pipe_mix.txt" 2>&1
+for seed in 31 32 33 34 35 36 37 38; do python3 tools/soak.py 1500 $seed 2>&1 | tail -1; done > "$OUT/soak.txt"
+python3 tools/soak_api.py 600 5 2>&1 | tail -1 >> "$OUT/soak.txt"
 python3 tools/parity_report.py > "$OUT/parity.json" 2> "$OUT/parity.log"
 python3 bench.py 2> /dev/null | tail -1 > "$OUT/bench_C3_1gpu.json"
+python3 bench.py --steps 20 --warmup 5 2> /dev/null | tail -1 > "$OUT/bench_C3_1gpu_driver_args.json"
 python3 bench.py --force-general --no-extra 2> /dev/null | tail -1 > "$OUT/bench_C3_general_flow_1gpu.json"
 python3 bench.py --force-dist --no-extra 2> /dev/null | tail -1 > "$OUT/bench_C3_1gpu_forced_1rank_collective.json"
 for E in 128 256 512; do
