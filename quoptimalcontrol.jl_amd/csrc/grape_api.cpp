@@ -1776,6 +1776,8 @@ struct HagerZhang {
     std::vector<double> al, va, sl;               // evaluated steps, values, slopes; index 0 = (0, phi0, dphi0)
     double last_alpha = -1.0;
     int budget;
+    bool seeded = false;                          // the first trial (alpha0) has been evaluated already: seed_f, seed_df, dphi0 are set
+    double seed_f = 0.0, seed_df = 0.0;
     static constexpr double delta = 0.1, sigma = 0.9, rho = 5.0, epsilon = 1e-6, gamma = 0.66, psi3 = 0.1;
 
     int eval(double c_, bool have_trial = false)
@@ -1854,9 +1856,16 @@ struct HagerZhang {
         phi_lim = phi0 + epsilon * std::fabs(phi0);
         double c_ = alpha0;
         al.assign(1, 0.0); va.assign(1, phi0); sl.assign(1, 0.0);
-        int rc = eval(c_, true);                                   // the probe also publishes phi'(0) = g.d of the direction kernel
-        if (rc) return rc;
-        dphi0 = run.h_sc[10];
+        int rc = 0;
+        if (seeded) {
+            --budget;
+            al.push_back(c_); va.push_back(seed_f); sl.push_back(seed_df);
+            last_alpha = c_;
+        } else {
+            rc = eval(c_, true);                                   // the probe also publishes phi'(0) = g.d of the direction kernel
+            if (rc) return rc;
+            dphi0 = run.h_sc[10];
+        }
         sl[0] = dphi0;
         if (!(dphi0 < 0.0)) return 1;
         for (int it = 0; !(std::isfinite(va.back()) && std::isfinite(sl.back())); ++it) {   // shrink out of a non-finite region
@@ -2060,47 +2069,97 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
         }
         return GRAPE_OK;
     };
-    while (status == 2 && it < max_it) {
-        const double F_prev = F;
-        bool accepted = false;
-        if (o.line_search == 2) {
+    auto launch_step = [&](int commit, bool with_signal) -> int {
+        HIP_TRY(c, hipSetDevice(lead->device));
+        if (grape::launch_lbfgs_step(st, commit, lead->stream, with_signal ? run.signal() : grape::DoneSignal()) != hipSuccess)
+            return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
+        return GRAPE_OK;
+    };
+    auto launch_probe = [&]() -> int {                       // trial slot 0: evaluate, publish phi, phi' (and phi'(0))
+        int r = run.evaluate(1);
+        if (r) return r;
+        HIP_TRY(c, hipSetDevice(lead->device));
+        if (grape::launch_lbfgs_select(st, 1, lead->stream, run.signal(), 1) != hipSuccess)
+            return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
+        return GRAPE_OK;
+    };
+    if (o.line_search == 2) {
+        while (status == 2 && it < max_it) {
+            const double F_prev = F;
+            bool accepted = false;
             rc = ladder(accepted);
             if (rc) return cleanup(rc);
-        } else {
-            // direction + the trial point x + d (InitialStatic: alpha = 1)
-            HIP_TRY(c, hipSetDevice(lead->device));
-            if (grape::launch_lbfgs_direction(st, 1, 1.0, lead->stream) != hipSuccess)
-                return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed"));
-            HagerZhang hz{run, F, 0.0, 0.0, {}, {}, {}, -1.0, max_ls};
+            if (!accepted) { status = 3; break; }
+            ++it;
+            F = h_sc[0];
+            gnorm = h_sc[1];
+            if (gnorm <= g_tol) { status = 0; break; }
+            if (f_tol > 0.0 && std::fabs(F - F_prev) <= f_tol * std::fabs(F)) { status = 1; break; }
+        }
+    } else if (status == 2) {
+        // Hager-Zhang, pipelined: an accepted step is committed and the next direction formed by ONE single-wave kernel
+        // (lbfgs_step_kernel) that the host does not wait for -- the evaluation of the next trial point x + d is queued
+        // right behind it, and the committed iterate's F and |g| arrive with that evaluation's probe.  (When the
+        // iterate turns out to have converged, that one evaluation was speculative.)
+        rc = launch_step(0, false);
+        if (rc == GRAPE_OK) rc = launch_probe();
+        if (rc) return cleanup(rc);
+        bool committed = false;                              // h_sc[0..1] hold an iterate the convergence tests have not seen
+        double F_before = F;
+        for (;;) {
+            rc = run.wait();
+            if (rc) return cleanup(rc);
+            if (committed) {
+                F = h_sc[0];
+                gnorm = h_sc[1];
+                committed = false;
+                if (gnorm <= g_tol) { status = 0; break; }
+                if (f_tol > 0.0 && std::fabs(F - F_before) <= f_tol * std::fabs(F)) { status = 1; break; }
+                if (it >= max_it) break;
+            }
+            HagerZhang hz{run, F, h_sc[10], 0.0, {}, {}, {}, -1.0, max_ls};
+            hz.seeded = true;
+            hz.seed_f = h_sc[8];
+            hz.seed_df = h_sc[9];
             double alpha = 1.0, fa = F;
             bool reeval = false;
             const int hr = hz.search(1.0, o.line_search == 0, alpha, fa, reeval);
             if (hr < 0) return cleanup(hr);
+            F_before = F;
             if (hr == 0) {
                 if (reeval) {                                      // the accepted step is not the one evaluated last
                     double f2, df2;
                     rc = run.phi(alpha, false, f2, df2);
                     if (rc) return cleanup(rc);
                 }
-                HIP_TRY(c, hipSetDevice(lead->device));
-                if (grape::launch_lbfgs_select(st, 1, lead->stream, run.signal(), 2) != hipSuccess)
-                    return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed"));
-                rc = run.wait();
+                ++it;
+                committed = true;
+                if (it >= max_it) {                                // the last iterate: commit, wait, no further trial
+                    rc = launch_step(1, true);
+                    if (rc) return cleanup(rc);
+                    continue;                                      // (the wait at the top reads its F and |g|)
+                }
+                rc = launch_step(1, false);
+                if (rc == GRAPE_OK) rc = launch_probe();
                 if (rc) return cleanup(rc);
-                accepted = true;
             } else {                                               // no bracket: the ladder search takes this iteration
                 ++hz_fallbacks;
+                bool accepted = false;
                 if (multi) { status = 3; break; }
                 rc = ladder(accepted);
                 if (rc) return cleanup(rc);
+                if (!accepted) { status = 3; break; }
+                ++it;
+                F = h_sc[0];
+                gnorm = h_sc[1];
+                if (gnorm <= g_tol) { status = 0; break; }
+                if (f_tol > 0.0 && std::fabs(F - F_before) <= f_tol * std::fabs(F)) { status = 1; break; }
+                if (it >= max_it) break;
+                rc = launch_step(0, false);
+                if (rc == GRAPE_OK) rc = launch_probe();
+                if (rc) return cleanup(rc);
             }
         }
-        if (!accepted) { status = 3; break; }
-        ++it;
-        F = h_sc[0];
-        gnorm = h_sc[1];
-        if (gnorm <= g_tol) { status = 0; break; }
-        if (f_tol > 0.0 && std::fabs(F - F_prev) <= f_tol * std::fabs(F)) { status = 1; break; }
     }
     HIP_TRY(c, hipSetDevice(lead->device));
     if (hipMemcpyAsync(lead->h_fg, st.x, sizeof(double) * kn, hipMemcpyDeviceToHost, lead->stream) != hipSuccess ||

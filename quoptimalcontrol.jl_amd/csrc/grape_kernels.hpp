@@ -203,6 +203,8 @@ hipError_t launch_lbfgs_init(const LbfgsState &st, hipStream_t stream, DoneSigna
 hipError_t launch_lbfgs_direction(const LbfgsState &st, int B, double alpha0, hipStream_t stream);
 hipError_t launch_lbfgs_select(const LbfgsState &st, int B, hipStream_t stream, DoneSignal done, int mode = 0);
 hipError_t launch_lbfgs_trial(const LbfgsState &st, double alpha, hipStream_t stream);
+// one wave: commit trial slot 0 (commit != 0), then the next direction, phi'(0) and the trial point x + d
+hipError_t launch_lbfgs_step(const LbfgsState &st, int commit, hipStream_t stream, DoneSignal done = DoneSignal());
 
 // dst[i] = src[i], i < n: moves the all-reduced [G, F] into mapped pinned host memory (one small launch
 // instead of a D2H copy node: the host polls the stream)
