@@ -95,7 +95,7 @@ struct grape_ctx {
     bool sparse_ctrl = false;                  // tile family: every B_c has <= kSparseMax non-zeros (sparse gradient traces)
     double2 *d_sp_coef = nullptr;              // [E][K][kSparseMax]
     int32_t *d_sp_addr = nullptr;
-    bool hoist = false;                        // tile family: member-invariant control operators, control sum formed once per slice
+    int hoist = 0;                             // tile family, prop_hoist.hip kernels: 1 member-invariant controls (control sum formed once per slice), 2 per-member controls
     double2 *d_ha = nullptr;                   // [EU] dumps of A'_k = (-i dt) A_k
     double *d_ha_norm = nullptr;               // [EU] |A'_k|_1 bound / theta8
     double2 *d_gc = nullptr;                   // [B][N] dumps of Gc_t
@@ -925,55 +925,64 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             HIP_TRY(c, hipMemcpy(c->d_sp_addr, addr.data(), sizeof(int32_t) * addr.size(), hipMemcpyHostToDevice));
         }
     }
-    {   // member-invariant control operators (every BASELINE config, every reference test: B_gens = k -> [Sx, Sy],
-        // test/setup_tests.jl:32): the control sum (-i dt) sum_c x[c,t] B_c is formed once per slice and evaluation
-        // (prop_hoist.hip) and a (member, slice) adds its own A'_k = (-i dt) A_k.  Single-tile and two-tile matrices,
-        // one member per tile; ensembles of at least 8 units (below that the pre-pass launch costs more than it saves).
-        // GRAPE_HOIST=0 keeps the per-member build, GRAPE_HOIST=1 forces the hoisted one for any ensemble size.
+    {   // The expm kernels of prop_hoist.hip (n = 5..32, one member per tile).  hoist = 1: member-invariant control operators
+        // (every BASELINE config, every reference test: B_gens = k -> [Sx, Sy], test/setup_tests.jl:32) -- the control sum
+        // (-i dt) sum_c x[c,t] B_c is formed once per slice and evaluation by a pre-pass and a (member, slice) adds its own
+        // A'_k = (-i dt) A_k.  hoist = 2: the members have their own control operators (amplitude-scaled controls of a
+        // robustness ensemble, ...): the same kernels form the sum themselves.  16 x 16 with shared controls: from 8 units
+        // on (below, the pre-pass launch costs more than it saves and the round-2 kernel stays).  GRAPE_HOIST=0 keeps
+        // prop_tile_kernel, GRAPE_HOIST=1 forces the new kernels for any ensemble size.
         bool hz = c->family == 1 && !c->pack2 && c->cfg.gradient != GRAPE_GRADIENT_EXACT;
         const char *he = std::getenv("GRAPE_HOIST");
         if (he && he[0] == '0') hz = false;
-        // (16 x 16: below 8 units the pre-pass launch costs more than it saves; 32 x 32: the hoisted kernel is also the
-        //  four-waves-per-propagator one, 4-6x shorter per slice than prop_tile_kernel<2> -- single problems take it too)
-        if (hz && !(he && he[0] == '1') && c->EU < 8 && c->NT == 1) hz = false;
-        for (size_t k = 1; k < E && hz; ++k)
-            hz = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
-        c->hoist = hz;
+        bool invariant = hz;
+        for (size_t k = 1; k < E && invariant; ++k)
+            invariant = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
+        // (32 x 32: the new kernel is also the four-waves-per-propagator one -- single problems take it too)
+        if (hz && invariant && !(he && he[0] == '1') && c->EU < 8 && c->NT == 1) hz = false;
+        c->hoist = hz ? (invariant ? 1 : 2) : 0;
         if (hz) {
             const double dt = c->cfg.duration / c->cfg.n_slices;
-            const size_t TSZ = c->TSZ;
+            const size_t TSZ = c->TSZ, ns = invariant ? 1 : 1 + K;      // norm bounds per unit: |A'| [, |B'_1| .. |B'_K|]
             std::vector<double> ha, hn;
             try {
                 ha.assign(2 * (size_t)c->EU * TSZ, 0.0);
-                hn.assign((size_t)c->EU, 0.0);
+                hn.assign((size_t)c->EU * ns, 0.0);
             } catch (...) {
                 return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: out of host memory");
             }
             const int nd = c->cfg.n, NT = c->NT;
-            for (size_t k = 0; k < E; ++k) {
-                const double *M = A + 2 * k * nn;
-                double *dst = ha.data() + 2 * k * TSZ;
+            auto norm1 = [&](const double *M) {                  // max column sum of |re| + |im|, NaN-propagating
                 double best = 0.0;
                 for (int col = 0; col < nd; ++col) {
                     double cs = 0.0;
+                    for (int row = 0; row < nd; ++row)
+                        cs += std::fabs(M[2 * (row + (size_t)nd * col)]) + std::fabs(M[2 * (row + (size_t)nd * col) + 1]);
+                    if (!(cs <= best)) best = cs;
+                }
+                return best;
+            };
+            for (size_t k = 0; k < E; ++k) {
+                const double *M = A + 2 * k * nn;
+                double *dst = ha.data() + 2 * k * TSZ;
+                for (int col = 0; col < nd; ++col)
                     for (int row = 0; row < nd; ++row) {
                         const double re = dt * M[2 * (row + (size_t)nd * col) + 1], im = -dt * M[2 * (row + (size_t)nd * col)];
                         const int I = row >> 4, J = col >> 4, r = (row & 15) >> 2, l = 16 * (row & 3) + (col & 15);
                         const size_t o = 2 * ((size_t)((I * NT + J) * 4 + r) * 64 + l);
                         dst[o] = re;
                         dst[o + 1] = im;
-                        cs += std::fabs(re) + std::fabs(im);
                     }
-                    if (!(cs <= best)) best = cs;                 // NaN-propagating maximum
-                }
-                hn[k] = best / grape::kTheta8;
+                hn[k * ns] = std::fabs(dt) * norm1(M) / grape::kTheta8;
+                for (size_t cc = 0; cc + 1 < ns; ++cc)
+                    hn[k * ns + 1 + cc] = std::fabs(dt) * norm1(B + 2 * (k * K + cc) * nn) / grape::kTheta8;
             }
             const size_t gc_elems = (size_t)c->B * c->cfg.n_slices * TSZ;
             if (!c->d_ha) {
-                c->bytes += sizeof(double2) * ((size_t)c->EU * TSZ + gc_elems) + sizeof(double) * ((size_t)c->EU + (size_t)c->B * c->cfg.n_slices);
+                c->bytes += sizeof(double2) * ((size_t)c->EU * TSZ + gc_elems) + sizeof(double) * ((size_t)c->EU * (1 + K) + (size_t)c->B * c->cfg.n_slices);
                 HIP_TRY(c, hipMalloc((void **)&c->d_ha, sizeof(double2) * (size_t)c->EU * TSZ));
             }
-            if (!c->d_ha_norm) HIP_TRY(c, hipMalloc((void **)&c->d_ha_norm, sizeof(double) * (size_t)c->EU));
+            if (!c->d_ha_norm) HIP_TRY(c, hipMalloc((void **)&c->d_ha_norm, sizeof(double) * (size_t)c->EU * (1 + K)));
             if (!c->d_gc) HIP_TRY(c, hipMalloc((void **)&c->d_gc, sizeof(double2) * gc_elems));
             if (!c->d_gcn) HIP_TRY(c, hipMalloc((void **)&c->d_gcn, sizeof(double) * (size_t)c->B * c->cfg.n_slices));
             HIP_TRY(c, hipMemcpy(c->d_ha, ha.data(), sizeof(double) * ha.size(), hipMemcpyHostToDevice));
@@ -1123,7 +1132,7 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.sparse = c->sparse_ctrl ? 1 : 0;
     p.sp_coef = c->d_sp_coef;
     p.sp_addr = c->d_sp_addr;
-    p.hoist = c->hoist ? 1 : 0;
+    p.hoist = c->hoist;
     p.ha = c->d_ha;
     p.ha_norm = c->d_ha_norm;
     p.gc = c->d_gc;
@@ -2446,7 +2455,7 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
         const grape_ctx *s0 = c->is_group ? c->sub[0] : c;
         info->fused_forward = (s0->thin && tile_fuse_forward(tile_params(s0, nullptr, 1)) == 1) ? 1 : 0;
         info->time_chunks = s0->tp_C;
-        info->hoisted_controls = s0->hoist ? 1 : 0;
+        info->hoisted_controls = s0->hoist == 1 ? 1 : 0;
     }
     return GRAPE_OK;
 }

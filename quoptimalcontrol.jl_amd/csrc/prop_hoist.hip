@@ -253,7 +253,11 @@ constexpr int kHoistWaves = 4;
 // propagator is converted to its transposed registers (one LDS round trip, no vector instruction) before the wave
 // waits for its turn, so the serial hand-over is the short form for all t: gathered reads of v from LDS, 16 FMAs, a
 // sum over the four lane rows (two permlane swaps), per-column write.
-template <bool FUSE>
+// HOIST: Gc_t comes from the pre-pass (member-invariant control operators).  !HOIST: the member has its own control
+// operators (amplitude-scaled controls of a robustness ensemble, ...): the control sum is formed here from the member's
+// operator dumps, G = A'_k + sum_c (dt x[c,t]) (Im B_c, -Re B_c), the squaring bound from |A'_k| + sum_c |x_c| |B'_c| --
+// everything behind the H build is the same kernel.
+template <bool FUSE, bool HOIST>
 __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const TileParams p)
 {
     constexpr int TSZ = 256, WPB = kHoistWaves;
@@ -286,16 +290,20 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
             dmask[r] = __builtin_amdgcn_ballot_w64(4 * r + (lane >> 4) == (lane & 15));
         }
     }
-    const double nA = p.ha_norm[k];
+    const int K = p.K;
+    const int nstride = HOIST ? 1 : 1 + K;                         // ha_norm: [unit] or [unit][|A'|, |B'_1| .. |B'_K|], all / theta8
+    const double nA = p.ha_norm[(size_t)k * nstride];
     const double *__restrict__ gcn = p.gcn + (size_t)z * p.N;
     const gcptr gc = uniform_global(p.gc + (size_t)z * p.N * TSZ);
+    const gcptr Bk = uniform_global(p.ops + ((size_t)k * (2 * K + 3) + 1) * TSZ);      // !HOIST: this member's B_1 .. B_K dumps
+    const double *__restrict__ xz = p.x + (size_t)z * K * p.N;
     const gptr props = uniform_global(p.props + ((size_t)z * p.E + k) * (size_t)p.N * TSZ);
     const gptr V = uniform_global(FUSE ? p.states + ((size_t)z * p.E + k) * (size_t)(p.N + 1) * 16 : p.states);
     const int t_lo = FUSE ? 0 : blockIdx.x * p.prop_slices;
     const int t_hi = FUSE ? p.N : min(p.N, t_lo + p.prop_slices);
     int t = t_lo + wave;
     d2v gnext[4];
-    if (t < t_hi) {
+    if (HOIST && t < t_hi) {
         const gcptr g0 = gc + (size_t)t * TSZ;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -304,12 +312,30 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
     for (; t < t_hi; t += WPB) {
         rotate_priority();
         d4 Gre, Gim;
+        double bound;
+        if (HOIST) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            Gre[r] = Are[r] + gnext[r][0];
-            Gim[r] = Aim[r] + gnext[r][1];
+            for (int r = 0; r < 4; ++r) {
+                Gre[r] = Are[r] + gnext[r][0];
+                Gim[r] = Aim[r] + gnext[r][1];
+            }
+            bound = nA + gcn[t];
+        } else {
+            Gre = Are;
+            Gim = Aim;
+            bound = nA;
+            for (int c = 0; c < K; ++c) {
+                const double xv = xz[c + (size_t)t * K], sx = p.dt * xv;
+                bound = fma(fabs(xv), p.ha_norm[(size_t)k * nstride + 1 + c], bound);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const d2v b = Bk[(size_t)c * TSZ + r * 64 + lane];
+                    Gre[r] = fma(sx, b[1], Gre[r]);                // (-i dt x)(br + i bi) = dt x (bi - i br)
+                    Gim[r] = fma(-sx, b[0], Gim[r]);
+                }
+            }
         }
-        const int s = p.s_forced >= 0 ? p.s_forced : squarings_from_ratio(nA + gcn[t]);   // both already / theta8
+        const int s = p.s_forced >= 0 ? p.s_forced : squarings_from_ratio(bound);          // bounds are stored / theta8
         if (s > 0) {
             const double sc = ldexp(1.0, -s);
             Gre *= sc;
@@ -360,7 +386,7 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
         const bool transposed = p.thin && (t & 1);
         const gptr dst = props + (size_t)t * TSZ;
         img_write_tile(wr, Pre, Pim, s > 0);
-        {   // the next slice's control sum: in flight during the conversions, the hand-over and the stores below
+        if (HOIST) {   // the next slice's control sum: in flight during the conversions, the hand-over and the stores below
             const int tn = min(t + WPB, t_hi - 1);                 // (clamped: no branch around the loads)
             const gcptr g1 = gc + (size_t)tn * TSZ;
 #pragma unroll
@@ -533,6 +559,7 @@ GRAPE_DEV void tile2_prod(d4 &ore, d4 &oim, const AOp3 &a0, const AOp3 &a1, cons
 }
 
 
+template <bool HOIST>
 __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
 {
     constexpr int TSZ = 1024;
@@ -560,9 +587,13 @@ __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
         dmask[r] = (I == J) ? __builtin_amdgcn_ballot_w64(4 * r + (lane >> 4) == (lane & 15)) : 0ull;
     // A'_k's tile is re-read from L2 with every slice's control sum (16 registers kept free: three waves per SIMD)
     const gcptr ha = uniform_global(p.ha + (size_t)k * TSZ + tile * 256);
-    const double nA = p.ha_norm[k];
+    const int K = p.K;
+    const int nstride = HOIST ? 1 : 1 + K;
+    const double nA = p.ha_norm[(size_t)k * nstride];
     const double *__restrict__ gcn = p.gcn + (size_t)z * p.N;
     const gcptr gc = uniform_global(p.gc + (size_t)z * p.N * TSZ + tile * 256);
+    const gcptr Bk = uniform_global(p.ops + ((size_t)k * (2 * K + 3) + 1) * TSZ + tile * 256);   // !HOIST: own tile of B_1 .. B_K
+    const double *__restrict__ xz = p.x + (size_t)z * K * p.N;
     const gptr props = uniform_global(p.props + ((size_t)z * p.E + k) * (size_t)p.N * TSZ + tile * 256);
     const int t_lo = blockIdx.x * p.prop_slices, t_hi = min(p.N, t_lo + p.prop_slices);
     d2v gnext[4], anext[4];
@@ -570,19 +601,40 @@ __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
         const gcptr g0 = gc + (size_t)t_lo * TSZ;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            gnext[r] = g0[r * 64 + lane];
+            if (HOIST) gnext[r] = g0[r * 64 + lane];
             anext[r] = ha[r * 64 + lane];
         }
     }
     for (int t = t_lo; t < t_hi; ++t) {
         rotate_priority();
         Tile3 G;
+        double bound;
+        if (HOIST) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            G.re[r] = anext[r][0] + gnext[r][0];
-            G.im[r] = anext[r][1] + gnext[r][1];
+            for (int r = 0; r < 4; ++r) {
+                G.re[r] = anext[r][0] + gnext[r][0];
+                G.im[r] = anext[r][1] + gnext[r][1];
+            }
+            bound = nA + gcn[t];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                G.re[r] = anext[r][0];
+                G.im[r] = anext[r][1];
+            }
+            bound = nA;
+            for (int c = 0; c < K; ++c) {
+                const double xv = xz[c + (size_t)t * K], sx = p.dt * xv;
+                bound = fma(fabs(xv), p.ha_norm[(size_t)k * nstride + 1 + c], bound);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const d2v b = Bk[(size_t)c * TSZ + r * 64 + lane];
+                    G.re[r] = fma(sx, b[1], G.re[r]);
+                    G.im[r] = fma(-sx, b[0], G.im[r]);
+                }
+            }
         }
-        const int s = p.s_forced >= 0 ? p.s_forced : squarings_from_ratio(nA + gcn[t]);
+        const int s = p.s_forced >= 0 ? p.s_forced : squarings_from_ratio(bound);
         if (s > 0) {
             const double sc = ldexp(1.0, -s);
             G.re *= sc;
@@ -672,7 +724,7 @@ __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
             const gcptr g1 = gc + (size_t)tn * TSZ;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                gnext[r] = g1[r * 64 + lane];
+                if (HOIST) gnext[r] = g1[r * 64 + lane];
                 anext[r] = ha[r * 64 + lane];
             }
         }
@@ -711,25 +763,33 @@ hipError_t launch_ctrl_sum(int NT, const TileParams &p, hipStream_t stream)
 }
 
 // q: the launcher's copy of the parameters with prop_slices / fuse_fwd decided (sweep_tile.hip: launch_nt)
+// q.hoist: 1 = member-invariant controls (pre-pass + hoisted kernels), 2 = per-member controls (same kernels, H build inside)
 hipError_t launch_prop_hoist(int NT, const TileParams &q, hipStream_t stream)
 {
-    hipError_t e = launch_ctrl_sum(NT, q, stream);
-    if (e != hipSuccess)
-        return e;
+    const bool hoisted = q.hoist == 1;
+    if (hoisted) {
+        hipError_t e = launch_ctrl_sum(NT, q, stream);
+        if (e != hipSuccess)
+            return e;
+    }
     if (NT == 1) {
         const size_t lds = sizeof(double2) * (kHoistWaves * (size_t)kTileImage + 33);
         const dim3 grid(q.fuse_fwd ? 1 : (q.N + q.prop_slices - 1) / q.prop_slices, q.E, q.n_x), block(64 * kHoistWaves);
-        if (q.fuse_fwd)
-            hipLaunchKernelGGL((prop_hoist1_kernel<true>), grid, block, lds, stream, q);
-        else
-            hipLaunchKernelGGL((prop_hoist1_kernel<false>), grid, block, lds, stream, q);
+        if (q.fuse_fwd) {
+            if (hoisted) hipLaunchKernelGGL((prop_hoist1_kernel<true, true>), grid, block, lds, stream, q);
+            else         hipLaunchKernelGGL((prop_hoist1_kernel<true, false>), grid, block, lds, stream, q);
+        } else {
+            if (hoisted) hipLaunchKernelGGL((prop_hoist1_kernel<false, true>), grid, block, lds, stream, q);
+            else         hipLaunchKernelGGL((prop_hoist1_kernel<false, false>), grid, block, lds, stream, q);
+        }
         return hipGetLastError();
     }
     if (NT == 2) {
         const size_t lds = 2 * (size_t)kImg2Matrix;
         const int per = q.prop_slices;
         const dim3 grid((q.N + per - 1) / per, q.E, q.n_x), block(256);
-        hipLaunchKernelGGL(prop_hoist2_kernel, grid, block, lds, stream, q);
+        if (hoisted) hipLaunchKernelGGL(prop_hoist2_kernel<true>, grid, block, lds, stream, q);
+        else         hipLaunchKernelGGL(prop_hoist2_kernel<false>, grid, block, lds, stream, q);
         return hipGetLastError();
     }
     return hipErrorInvalidValue;

@@ -141,9 +141,39 @@ def test_operators_reupload_switches_between_hoisted_and_per_member(qoc, oracle)
     B2 = B.copy()
     B2[3, 1] *= 1.25
     with qoc.GrapeEngine("CoherenceTransfer", A, B, Xi, Xt, wts, 0.7, N) as eng:
-        for Bk, want in ((B, 1), (B2, 0), (B, 1)):
+        for Bk, want in ((B, 1), (B2, 0), (B, 1)):                 # (B2: the same kernels with the per-member control sum)
             eng.set_operators(A, Bk, Xi, Xt, wts)
             assert eng.info["hoisted_controls"] == want
             F, G = eng.eval(x)
             Fr, Gr = oracle.ensemble_eval("CoherenceTransfer", A, Bk, Xi, Xt, wts, x, 0.7)
             assert_parity(F, G, Fr, Gr, n, what=f"upload (hoisted {want})")
+
+
+@pytest.mark.parametrize("n,K,N,E,sys_type,herm_gen,rank_one", [(16, 4, 37, 9, "CoherenceTransfer", False, True),
+                                                               (16, 3, 20, 2, "UnitaryGate", True, False),
+                                                               (32, 6, 12, 3, "UnitaryGate", True, False),
+                                                               (24, 2, 9, 2, "StateTransfer", False, False)])
+def test_per_member_controls_run_the_new_kernels_too(qoc, oracle, monkeypatch, n, K, N, E, sys_type, herm_gen, rank_one):
+    """Members with their OWN control operators (amplitude-scaled controls of a robustness ensemble): the round-3 expm
+    kernels form the control sum themselves (no pre-pass); against the oracle and against the round-2 kernel."""
+    sand = sys_type != "UnitaryGate"
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sand, herm_gen, seed=n + 7 * N, rank_one=rank_one)
+    B = B * (1.0 + 0.07 * np.arange(E))[:, None, None, None]        # B_k = (1 + eps_k) B
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 0.9, per_member=True)
+    res = {}
+    for hoist in (None, "0"):
+        if hoist is None:
+            monkeypatch.delenv("GRAPE_HOIST", raising=False)
+        else:
+            monkeypatch.setenv("GRAPE_HOIST", hoist)
+        with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 0.9, N, member_results=True) as eng:
+            assert eng.info["hoisted_controls"] == 0
+            F, G = eng.eval(x)
+            foms, grads = eng.member_results()
+            F2, G2 = eng.eval(x)
+        assert F == F2 and np.array_equal(G, G2)
+        for k in range(E):
+            assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k} (GRAPE_HOIST={hoist})")
+        assert_parity(F, G, F_ref, G_ref, n, what=f"ensemble (GRAPE_HOIST={hoist})")
+        res[hoist] = (F, G)
+    assert np.abs(res[None][1] - res["0"][1]).max() <= 1e-12 * np.abs(res["0"][1]).max() + 1e-15

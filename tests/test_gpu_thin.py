@@ -163,22 +163,36 @@ def test_rank_one_chain_random_shapes(qoc, oracle, i, n, K, N, E, sys_type, herm
 @pytest.mark.parametrize("E", [1024, 520])
 def test_fused_forward_pass_is_bitwise_the_separate_one(qoc, monkeypatch, sys_type, E):
     """From half a device of members on (2 x 256 CUs) the library fuses the forward vector pass into the expm kernel by
-    itself; the same summation trees run in both flows, so the results agree to the last bit."""
+    itself.  With the round-2 expm kernel (GRAPE_HOIST=0) the same summation trees run in both flows and the results
+    agree to the last bit; the round-3 kernel multiplies EVERY slice by its transposed registers (the short hand-over),
+    a different tree on the even slices: agreement to rounding, each flow bitwise reproducible."""
     n, K, N = 16, 4, 37
     A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sys_type != "UnitaryGate", False, True, seed=5)
-    res = {}
-    for mode in ("auto", "separate"):
-        if mode == "separate":
-            monkeypatch.setenv("GRAPE_NO_FUSE", "1")
-        with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N, member_results=True, max_batch=3) as eng:
-            assert eng.info["rank_one_chain"] == 1 and eng.info["fused_forward"] == (1 if mode == "auto" else 0)
-            F, G = eng.eval(x)
-            xs = np.stack([x, 0.5 * x, -x])
-            Fb, Gb = eng.eval_batch(xs)
-            res[mode] = (F, G.copy(), eng.member_results()[1].copy(), np.array(Fb), np.array(Gb))
-    for a, b in zip(res["auto"], res["separate"]):
-        assert np.array_equal(np.asarray(a), np.asarray(b))
-    assert np.isfinite(res["auto"][1]).all() and abs(res["auto"][3][0] - res["auto"][0]) <= 1e-12
+    for hoist in ("0", None):
+        if hoist is None:
+            monkeypatch.delenv("GRAPE_HOIST", raising=False)
+        else:
+            monkeypatch.setenv("GRAPE_HOIST", hoist)
+        monkeypatch.delenv("GRAPE_NO_FUSE", raising=False)
+        res = {}
+        for mode in ("auto", "separate"):
+            if mode == "separate":
+                monkeypatch.setenv("GRAPE_NO_FUSE", "1")
+            with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N, member_results=True, max_batch=3) as eng:
+                assert eng.info["rank_one_chain"] == 1 and eng.info["fused_forward"] == (1 if mode == "auto" else 0)
+                F, G = eng.eval(x)
+                F2, G2 = eng.eval(x)
+                assert F == F2 and np.array_equal(G, G2)
+                xs = np.stack([x, 0.5 * x, -x])
+                Fb, Gb = eng.eval_batch(xs)
+                res[mode] = (F, G.copy(), eng.member_results()[1].copy(), np.array(Fb), np.array(Gb))
+        for a, b in zip(res["auto"], res["separate"]):
+            a, b = np.asarray(a), np.asarray(b)
+            if hoist == "0":
+                assert np.array_equal(a, b)
+            else:
+                assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
+        assert np.isfinite(res["auto"][1]).all() and abs(res["auto"][3][0] - res["auto"][0]) <= 1e-12 * max(1.0, abs(res["auto"][0]))
 
 
 @pytest.mark.parametrize("n,K,N,E,sys_type,chunks", [(16, 4, 257, 1, "CoherenceTransfer", 0), (16, 3, 100, 3, "StateTransfer", 3),
