@@ -932,10 +932,10 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // robustness ensemble, ...): the same kernels form the sum themselves.  16 x 16 with shared controls: from 8 units
         // on (below, the pre-pass launch costs more than it saves and the round-2 kernel stays).  GRAPE_HOIST=0 keeps
         // prop_tile_kernel, GRAPE_HOIST=1 forces the new kernels for any ensemble size.
-        bool hz = c->family == 1 && !c->pack2 && c->cfg.gradient != GRAPE_GRADIENT_EXACT;
+        bool hz = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT;
         const char *he = std::getenv("GRAPE_HOIST");
         if (he && he[0] == '0') hz = false;
-        bool invariant = hz;
+        bool invariant = hz && !c->pack2;                        // (block-diagonal member pairs, n <= 8: always the in-kernel sum)
         for (size_t k = 1; k < E && invariant; ++k)
             invariant = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
         // (32 x 32: the new kernel is also the four-waves-per-propagator one -- single problems take it too)
@@ -964,18 +964,22 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             };
             for (size_t k = 0; k < E; ++k) {
                 const double *M = A + 2 * k * nn;
-                double *dst = ha.data() + 2 * k * TSZ;
+                const size_t unit = c->pack2 ? k / 2 : k;            // pack2: two members per tile, block diagonal
+                const int off = c->pack2 ? 8 * (int)(k & 1) : 0;
+                double *dst = ha.data() + 2 * unit * TSZ;
                 for (int col = 0; col < nd; ++col)
                     for (int row = 0; row < nd; ++row) {
                         const double re = dt * M[2 * (row + (size_t)nd * col) + 1], im = -dt * M[2 * (row + (size_t)nd * col)];
-                        const int I = row >> 4, J = col >> 4, r = (row & 15) >> 2, l = 16 * (row & 3) + (col & 15);
+                        const int rr = row + off, cc2 = col + off;
+                        const int I = rr >> 4, J = cc2 >> 4, r = (rr & 15) >> 2, l = 16 * (rr & 3) + (cc2 & 15);
                         const size_t o = 2 * ((size_t)((I * NT + J) * 4 + r) * 64 + l);
                         dst[o] = re;
                         dst[o + 1] = im;
                     }
-                hn[k * ns] = std::fabs(dt) * norm1(M) / grape::kTheta8;
+                auto upd = [](double &slot, double v) { if (!(v <= slot)) slot = v; };      // the norm of a block-diagonal pair: the larger block's
+                upd(hn[unit * ns], std::fabs(dt) * norm1(M) / grape::kTheta8);
                 for (size_t cc = 0; cc + 1 < ns; ++cc)
-                    hn[k * ns + 1 + cc] = std::fabs(dt) * norm1(B + 2 * (k * K + cc) * nn) / grape::kTheta8;
+                    upd(hn[unit * ns + 1 + cc], std::fabs(dt) * norm1(B + 2 * (k * K + cc) * nn) / grape::kTheta8);
             }
             const size_t gc_elems = (size_t)c->B * c->cfg.n_slices * TSZ;
             if (!c->d_ha) {
