@@ -11,11 +11,11 @@ from . import workloads  # noqa: F401
 from .engine import GrapeEngine, GrapeError, library_path, load_library  # noqa: F401
 from .api import (  # noqa: F401
     ADGRAPE, GRAPE, CoherenceTransfer, EnsembleProblem, EnsembleSolutionResult, Problem, SolutionResult,
-    StateTransfer, UnitaryGate, C1, init_ensemble, solve, fom_and_gradient, pulse_to_file, pulse_from_file,
+    StateTransfer, UnitaryGate, C1, init_ensemble, solve, fom_and_gradient, pulse_to_file, pulse_from_file, save, load,
 )
 
 __all__ = [
     "workloads", "GrapeEngine", "GrapeError", "library_path", "load_library", "GRAPE", "ADGRAPE",
     "CoherenceTransfer", "EnsembleProblem", "EnsembleSolutionResult", "Problem", "SolutionResult",
-    "StateTransfer", "UnitaryGate", "C1", "init_ensemble", "solve", "fom_and_gradient", "pulse_to_file", "pulse_from_file",
+    "StateTransfer", "UnitaryGate", "C1", "init_ensemble", "solve", "fom_and_gradient", "pulse_to_file", "pulse_from_file", "save", "load",
 ]

@@ -181,6 +181,54 @@ def fom_and_gradient(prob, alg, x, engine=None):
             eng.close()
 
 
+def save(solres, file_path):
+    """src/tools.jl:59-72: every field of a SolutionResult / EnsembleSolutionResult but the optimiser's own result object
+    (the reference drops it too: `fieldnames(...)[2:end]`) into one file -- NumPy's .npz here instead of BSON.  The
+    problem's operators and states are stored as arrays; generator closures of an EnsembleProblem are stored as the
+    members they generate."""
+    prob = solres.problem
+    ens = isinstance(prob, EnsembleProblem)
+    base = prob.prob if ens else prob
+    alg = solres.alg
+    data = {
+        "kind": np.array("ensemble" if ens else "single"),
+        "fidelity": np.array(float(solres.fidelity)),
+        "opti_pulses": np.asarray(solres.opti_pulses, dtype=np.float64),
+        "sys_type": np.array(base.sys_type.name), "T": np.array(float(base.T)), "n_controls": np.array(int(base.n_controls)),
+        "A": np.asarray(base.A, complex), "B": np.asarray(base.B, complex), "Xi": np.asarray(base.Xi, complex),
+        "Xt": np.asarray(base.Xt, complex), "guess": np.asarray(base.guess, dtype=np.float64),
+        "alg_kind": np.array(type(alg).__name__), "n_slices": np.array(int(alg.n_slices)),
+        "isinplace": np.array(bool(getattr(alg, "isinplace", True))),
+    }
+    if ens:
+        members = init_ensemble(prob)
+        data.update(n_ens=np.array(int(prob.n_ens)), wts=np.asarray(prob.wts, dtype=np.float64),
+                    A_members=np.array([np.asarray(m.A, complex) for m in members]),
+                    B_members=np.array([np.asarray(m.B, complex) for m in members]),
+                    Xi_members=np.array([np.asarray(m.Xi, complex) for m in members]),
+                    Xt_members=np.array([np.asarray(m.Xt, complex) for m in members]))
+    with open(file_path, "wb") as io:
+        np.savez(io, **data)
+
+
+def load(file_path):
+    """src/tools.jl:75-85 (whose own version passes four arguments to a five-field struct): the SolutionResult back,
+    with `result = None` as the reference intends."""
+    d = np.load(file_path, allow_pickle=False)
+    st = {"StateTransfer": StateTransfer, "UnitaryGate": UnitaryGate, "CoherenceTransfer": CoherenceTransfer}[str(d["sys_type"])]()
+    base = Problem(B=list(d["B"]), A=d["A"], Xi=d["Xi"], Xt=d["Xt"], T=float(d["T"]), n_controls=int(d["n_controls"]),
+                   guess=d["guess"], sys_type=st)
+    alg_cls = ADGRAPE if str(d["alg_kind"]) == "ADGRAPE" else GRAPE
+    alg = alg_cls(n_slices=int(d["n_slices"])) if alg_cls is ADGRAPE else GRAPE(n_slices=int(d["n_slices"]),
+                                                                                  isinplace=bool(d["isinplace"]))
+    if str(d["kind"]) == "ensemble":
+        Am, Bm, Xim, Xtm = d["A_members"], d["B_members"], d["Xi_members"], d["Xt_members"]
+        ens = EnsembleProblem(prob=base, n_ens=int(d["n_ens"]), A_g=lambda k: Am[k - 1], B_g=lambda k: list(Bm[k - 1]),
+                              XiG=lambda k: Xim[k - 1], XtG=lambda k: Xtm[k - 1], wts=d["wts"])
+        return EnsembleSolutionResult(None, float(d["fidelity"]), d["opti_pulses"], ens, alg)
+    return SolutionResult(None, float(d["fidelity"]), d["opti_pulses"], base, alg)
+
+
 def pulse_to_file(pulse, file_path, duration=None):
     """src/tools.jl:90-104: write a (K, N) pulse as delimited text with time going down the file
     (`writedlm(io, pulse')`, tab separated); with `duration`, a leading time column

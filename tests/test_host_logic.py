@@ -95,3 +95,28 @@ def test_pulse_file_round_trip(qoc, tmp_path):
     qoc.pulse_to_file(x[:1], f, duration=2.0)
     back, t = qoc.pulse_from_file(f, has_time_column=True)
     assert np.array_equal(back, x[:1]) and t[0] == 0.0 and t[-1] == 2.0
+
+
+def test_solution_save_and_load_round_trip(qoc, tmp_path):
+    """src/tools.jl:59-85: save(solres, path) / load(path) for both result types (npz instead of BSON; the optimiser's own
+    result object is not stored, as in the reference)."""
+    wl = qoc.workloads
+    prob = qoc.Problem(B=[wl.Sx, wl.Sy], A=wl.Sz, Xi=wl.rho_init, Xt=wl.rho_fin, T=1.0, n_controls=2, guess=wl.controls(2, 10),
+                       sys_type=qoc.StateTransfer())
+    sol = qoc.SolutionResult(object(), 0.7512, np.arange(20.0).reshape(2, 10), prob, qoc.GRAPE(n_slices=10, isinplace=False))
+    f = str(tmp_path / "sol.npz")
+    qoc.save(sol, f)
+    back = qoc.load(f)
+    assert isinstance(back, qoc.SolutionResult) and back.result is None and back.fidelity == 0.7512
+    assert np.array_equal(back.opti_pulses, sol.opti_pulses) and back.alg.n_slices == 10 and back.alg.isinplace is False
+    assert np.array_equal(back.problem.A, wl.Sz) and np.array_equal(np.array(back.problem.B), np.array([wl.Sx, wl.Sy]))
+    assert type(back.problem.sys_type).__name__ == "StateTransfer" and back.problem.T == 1.0
+    ens = qoc.EnsembleProblem(prob=prob, n_ens=3, A_g=lambda k: k * wl.Sz, B_g=lambda k: [wl.Sx, wl.Sy],
+                              XiG=lambda k: prob.Xi, XtG=lambda k: prob.Xt, wts=np.ones(3) / 3)
+    esol = qoc.EnsembleSolutionResult(None, 0.8, np.ones((2, 10)), ens, qoc.GRAPE(n_slices=10))
+    qoc.save(esol, f)
+    eback = qoc.load(f)
+    assert isinstance(eback, qoc.EnsembleSolutionResult) and eback.problem.n_ens == 3
+    members = qoc.init_ensemble(eback.problem)
+    assert [np.array_equal(m.A, k * wl.Sz) for k, m in enumerate(members, 1)] == [True] * 3
+    assert np.allclose(eback.problem.wts, 1 / 3)
