@@ -33,6 +33,7 @@ Prints ONE JSON line on rank 0 (contract: see the task statement), including
   extra_configs C2, C4 (E=1024), C5 (E=4096) host->host value + roofline on one GPU (N = 1 only).
 """
 import argparse
+import math
 import json
 import os
 import statistics
@@ -109,6 +110,30 @@ def _stats_us(ms):
             "kernel_launches": int(a.size)}
 
 
+_ACT_TOL = 3.7e-16
+_ACT_THETA = [(_ACT_TOL * math.factorial(m + 1)) ** (1.0 / (m + 1)) for m in range(1, 25)]
+
+
+def action_steps(local):
+    """Horner steps (matrix-vector products per chain) action_thin_kernel takes over all members and slices: the degree
+    table of csrc/action_thin.hip on  max(|A'_k|_1, |A'_k|_inf) + max over the step's two slices of the same bound of
+    Gc_t  (one wave runs the forward slice i and the backward slice N-1-i together)."""
+    import numpy as np
+    dt = local.T / local.N
+
+    def bound(M):
+        a = np.abs(M.real) + np.abs(M.imag)
+        return np.maximum(a.sum(-2).max(-1), a.sum(-1).max(-1))
+    an = dt * bound(local.A)                                             # (E,)
+    Gc = dt * np.einsum("ct,cij->tij", local.x, local.B[0])              # (N, n, n): the controls are member-invariant
+    gn = bound(Gc)
+    gn = np.maximum(gn, gn[::-1])
+    th = an[:, None] + gn[None, :]
+    pieces = np.where(th > 1.40513, np.ceil(th / 1.40513), 1.0)
+    deg = 1 + np.searchsorted(np.asarray(_ACT_THETA), th / pieces, side="left")
+    return float((np.minimum(deg, 24) * pieces).sum())
+
+
 def tile_kernel_models(local, info):
     """Work of the two halves of a tile-family (n = 5..32) evaluation AS RUN: matrix-core flops
     = v_mfma_f64_16x16x4 instructions x 2048 (a complex tile product is 12 of them: three real products), HBM bytes =
@@ -121,6 +146,18 @@ def tile_kernel_models(local, info):
     prod = 12 * NT ** 3 * 2048                             # flops of one complex tile-matrix product
     thin, fused, uni = bool(info.get("rank_one_chain")), bool(info.get("fused_forward")), bool(info.get("unitary_flow"))
     sand = local.sys_type != "UnitaryGate"
+    if info.get("expm_action"):
+        # rank-one states, shared controls: exp(G_t) applied to the two chains' vectors (csrc/action_thin.hip).  Vector FP64
+        # flops = Horner steps x 256 complex multiply-adds x 8, the steps from the kernel's own rule (degree table on the
+        # norm bound, replicated in action_steps); HBM bytes = the vector records written, then read by the forms kernel
+        steps = action_steps(local)
+        act = {"name": "action_rows_kernel + action_thin_kernel (exp(G) v by Taylor series, both chains; vector FP64)",
+               "flops": steps * 2 * 256 * 8, "bytes": 2 * units * (N + 1) * 256, "pipe": "valu_fp64",
+               "taylor_steps_per_slice": steps / (units * N)}
+        forms = {"name": "action_forms_kernel (bilinear forms w' B_c v, one lane per slice; vector FP64)",
+                 "flops": units * N * K * (256 + 16) * 8, "bytes": 2 * units * (N + 1) * 256 + units * K * N * 8,
+                 "pipe": "valu_fp64"}
+        return act, forms
     expm = {"name": "expm: " + ("ctrl_sum_kernel + prop_hoist kernel" if info.get("hoisted_controls") else "prop_tile_kernel"),
             "flops": units * N * 3 * prod, "bytes": units * N * tsz + (units * (N + 1) * 256 if fused else 0)}
     if thin:
@@ -159,14 +196,18 @@ def roofline(local, info, samples, evals_per_s, n_gpus, traffic, profile=None):
             tf = part["flops"] / t / 1e12 if t > 0 else 0.0
             gb = part["bytes"] / t / 1e9 if t > 0 else 0.0
             fm, fh = tf / FP64_PEAK_TFLOPS, gb / HBM_PEAK_GBS
-            parts.append({"kernel": part["name"], "avg_us": 1e6 * t, "mfma_flops_per_launch": part["flops"],
-                          "hbm_bytes_per_launch": part["bytes"], "achieved_TFLOPs": tf, "achieved_GBs": gb,
-                          "frac_mfma": fm, "frac_hbm": fh, "bound": "mfma" if fm >= fh else "hbm"})
+            pipe = part.get("pipe", "mfma")                   # "valu_fp64": vector FP64 (same 78.6 TFLOP/s peak as the matrix pipe)
+            d = {"kernel": part["name"], "avg_us": 1e6 * t, pipe + "_flops_per_launch": part["flops"],
+                 "hbm_bytes_per_launch": part["bytes"], "achieved_TFLOPs": tf, "achieved_GBs": gb,
+                 "frac_" + pipe: fm, "frac_hbm": fh, "bound": pipe if fm >= fh else "hbm"}
+            if "taylor_steps_per_slice" in part:
+                d["taylor_steps_per_slice"] = part["taylor_steps_per_slice"]
+            parts.append(d)
         dom = max(parts, key=lambda d: d["avg_us"])
-        mf = dom["bound"] == "mfma"
+        mf = dom["bound"] != "hbm"
         roof = {"bound": dom["bound"], "achieved": dom["achieved_TFLOPs"] if mf else dom["achieved_GBs"],
                 "peak": FP64_PEAK_TFLOPS if mf else HBM_PEAK_GBS, "unit": "TFLOP/s" if mf else "GB/s",
-                "frac": dom["frac_mfma"] if mf else dom["frac_hbm"], "traffic": traffic,
+                "frac": dom.get("frac_mfma", dom.get("frac_valu_fp64")) if mf else dom["frac_hbm"], "traffic": traffic,
                 "kernel": dom["kernel"], "kernels": parts,
                 "model_s_equivalent": {"flops_per_launch": alg_flops, "TFLOPs": alg_flops / sec / 1e12 if sec > 0 else 0.0,
                                        "frac_fp64": alg_flops / sec / 1e12 / FP64_PEAK_TFLOPS if sec > 0 else 0.0,
@@ -175,7 +216,7 @@ def roofline(local, info, samples, evals_per_s, n_gpus, traffic, profile=None):
                                                "exceeds 1 where the flow run does less work than model S"},
                 "note": "frac = work of the flow ACTUALLY RUN by the dominant (longer) kernel / its HIP-event time / peak: "
                         "matrix-core flops = MFMA instructions x 2048, HBM bytes = dumps written + read; `kernels` prices both halves"}
-        if profile:
+        if profile and not info.get("expm_action"):
             roof["mfma_utilisation_from_profile"] = profile
     else:
         gbs = alg_bytes / sec / 1e9 if sec > 0 else 0.0

@@ -99,7 +99,10 @@ struct grape_ctx {
     double2 *d_ha = nullptr;                   // [EU] dumps of A'_k = (-i dt) A_k
     double *d_ha_norm = nullptr;               // [EU] |A'_k|_1 bound / theta8
     double2 *d_gc = nullptr;                   // [B][N] dumps of Gc_t
-    double *d_gcn = nullptr;                   // [B][N] |Gc_t|_1 bound / theta8
+    double *d_gcn = nullptr;
+    bool action = false;                       // rank-one states + member-invariant controls: exp(G) v on vectors (action_thin.hip)
+    double2 *d_act_a = nullptr, *d_act_b = nullptr, *d_act_bf = nullptr, *d_act_g = nullptr;
+    double *d_act_an = nullptr, *d_act_gn = nullptr;                   // [B][N] |Gc_t|_1 bound / theta8
     size_t states_bytes = 0;                   // size of d_states (vector records are smaller than state dumps)
     int tp_C = 0, tp_S = 0;                    // tile family, unitary flow, small ensembles: time chunks per unit (0 = sequential chain)
     double2 *d_tp_q = nullptr, *d_tp_r = nullptr, *d_tp_m = nullptr;   // chunk products, products after each chunk, M_N
@@ -315,6 +318,8 @@ static void free_all(grape_ctx *c)
     (void)hipFree(c->d_tp_q); (void)hipFree(c->d_tp_r); (void)hipFree(c->d_tp_m); (void)hipFree(c->d_tp_z); (void)hipFree(c->d_tp_vec); (void)hipFree(c->d_tp_a);
     (void)hipFree(c->d_x_bar);
     (void)hipFree(c->d_ha); (void)hipFree(c->d_ha_norm); (void)hipFree(c->d_gc); (void)hipFree(c->d_gcn);
+    (void)hipFree(c->d_act_a); (void)hipFree(c->d_act_b); (void)hipFree(c->d_act_bf); (void)hipFree(c->d_act_g);
+    (void)hipFree(c->d_act_an); (void)hipFree(c->d_act_gn);
     delete c;
 }
 
@@ -746,6 +751,15 @@ extern "C" int grape_comm_attach(grape_ctx *c, const grape_comm_id *id, int32_t 
     return GRAPE_OK;
 }
 
+// smallest ensemble the vector flow of action_thin.hip is chosen for: one wavefront per member has to fill the SIMDs
+// (4 per compute unit) -- a member's two chains are strictly sequential in time, so a smaller ensemble leaves SIMDs idle
+// for the whole evaluation, where the expm kernel spreads (member, slice) pairs over all of them.  GRAPE_ACTION_MIN overrides.
+static long act_min_units(const grape_ctx *c)
+{
+    if (const char *e = std::getenv("GRAPE_ACTION_MIN")) return std::atol(e);
+    return 4L * c->compute_units;
+}
+
 extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *B, const double *Xi,
                                    const double *Xt, const double *wts)
 {
@@ -1061,6 +1075,75 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             }
         }
     }
+    {   // Rank-one states with member-invariant control operators: the evaluation runs on vectors alone (action_thin.hip) --
+        // exp(G_t) applied to the two chains' vectors by its Taylor series, no propagator formed or stored.  Ensembles that
+        // fill the device (the chunked flows of small ensembles keep the expm kernel: they need the chunk PRODUCTS);
+        // GRAPE_ACTION=0 keeps the expm + chain kernels, GRAPE_ACTION=1 forces the vector flow for any ensemble size.
+        const char *ae = std::getenv("GRAPE_ACTION");
+        bool act = thin && !(ae && ae[0] == '0') && c->cfg.n_slices <= 16384;   // (the kernel's per-slice plan lives in LDS)
+        for (size_t k = 1; k < E && act; ++k)
+            act = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
+        if (act && !(ae && ae[0] == '1') && (c->tp_C || (long)c->EU < act_min_units(c))) act = false;
+        c->action = act;
+        if (act) {
+            c->tp_C = c->tp_S = c->tp_G = c->tp_g = 0;
+            const double dt = c->cfg.duration / c->cfg.n_slices;
+            const int nd = c->cfg.n;
+            std::vector<double> aa, an, bb, bf;
+            try {
+                aa.assign(2 * E * 512, 0.0);
+                an.assign(E, 0.0);
+                bb.assign(2 * K * 512, 0.0);
+                bf.assign(2 * K * 256, 0.0);
+            } catch (...) {
+                return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: out of host memory");
+            }
+            // dst: [M' | M''] row-major, zero padded to 16 x 16, M' = (-i dt) M (column-major n x n input); returns max(|M'|_1, |M'|_inf)
+            auto images = [&](double *dst, const double *M) {
+                double colsum[16] = {0}, rowsum[16] = {0};
+                for (int col = 0; col < nd; ++col)
+                    for (int row = 0; row < nd; ++row) {
+                        const double re = dt * M[2 * (row + (size_t)nd * col) + 1], im = -dt * M[2 * (row + (size_t)nd * col)];
+                        dst[2 * (row * 16 + col)] = re;
+                        dst[2 * (row * 16 + col) + 1] = im;
+                        dst[2 * (256 + col * 16 + row)] = re;            // (M'')[col][row] = conj(M'[row][col])
+                        dst[2 * (256 + col * 16 + row) + 1] = -im;
+                        colsum[col] += std::fabs(re) + std::fabs(im);
+                        rowsum[row] += std::fabs(re) + std::fabs(im);
+                    }
+                double best = 0.0;
+                for (int q = 0; q < 16; ++q) {
+                    if (!(colsum[q] <= best)) best = colsum[q];
+                    if (!(rowsum[q] <= best)) best = rowsum[q];
+                }
+                return best;
+            };
+            for (size_t k = 0; k < E; ++k)
+                an[k] = images(aa.data() + 2 * k * 512, A + 2 * k * nn);
+            for (size_t cc = 0; cc < K; ++cc) {
+                (void)images(bb.data() + 2 * cc * 512, B + 2 * cc * nn);
+                for (int col = 0; col < nd; ++col)
+                    for (int row = 0; row < nd; ++row) {
+                        bf[2 * (cc * 256 + row * 16 + col)] = B[2 * (cc * nn + row + (size_t)nd * col)];
+                        bf[2 * (cc * 256 + row * 16 + col) + 1] = B[2 * (cc * nn + row + (size_t)nd * col) + 1];
+                    }
+            }
+            const size_t g_elems = (size_t)c->B * c->cfg.n_slices * 512;
+            if (!c->d_act_a) {
+                c->bytes += sizeof(double2) * (E * 512 + K * 768 + g_elems) + sizeof(double) * (E + (size_t)c->B * c->cfg.n_slices);
+                HIP_TRY(c, hipMalloc((void **)&c->d_act_a, sizeof(double2) * E * 512));
+            }
+            if (!c->d_act_an) HIP_TRY(c, hipMalloc((void **)&c->d_act_an, sizeof(double) * E));
+            if (!c->d_act_b) HIP_TRY(c, hipMalloc((void **)&c->d_act_b, sizeof(double2) * K * 512));
+            if (!c->d_act_bf) HIP_TRY(c, hipMalloc((void **)&c->d_act_bf, sizeof(double2) * K * 256));
+            if (!c->d_act_g) HIP_TRY(c, hipMalloc((void **)&c->d_act_g, sizeof(double2) * g_elems));
+            if (!c->d_act_gn) HIP_TRY(c, hipMalloc((void **)&c->d_act_gn, sizeof(double) * (size_t)c->B * c->cfg.n_slices));
+            HIP_TRY(c, hipMemcpy(c->d_act_a, aa.data(), sizeof(double) * aa.size(), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->d_act_an, an.data(), sizeof(double) * an.size(), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->d_act_b, bb.data(), sizeof(double) * bb.size(), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->d_act_bf, bf.data(), sizeof(double) * bf.size(), hipMemcpyHostToDevice));
+        }
+    }
     if (thin) {
         c->unitary = false;                                  // the thin chain serves Hermitian generators as well
         if (!c->d_vecs) {
@@ -1141,6 +1224,13 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.ha_norm = c->d_ha_norm;
     p.gc = c->d_gc;
     p.gcn = c->d_gcn;
+    p.action = c->action ? 1 : 0;
+    p.act_a = c->d_act_a;
+    p.act_an = c->d_act_an;
+    p.act_b = c->d_act_b;
+    p.act_bf = c->d_act_bf;
+    p.act_g = c->d_act_g;
+    p.act_gn = c->d_act_gn;
     return p;
 }
 
@@ -2274,6 +2364,10 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
     if (costates && !c->d_costates)
         return fail(c, GRAPE_ERR_NOT_READY,
                     "grape_get_trajectory: costates need GRAPE_FLAG_KEEP_COSTATES at grape_create");
+    if (props && c->action)
+        return fail(c, GRAPE_ERR_NOT_READY,
+                    "grape_get_trajectory: this flow applies exp(G_t) to vectors and forms no propagators; create the "
+                    "context with GRAPE_FLAG_KEEP_COSTATES");
     if (states && !states_stored(c))
         return fail(c, GRAPE_ERR_NOT_READY,
                     "grape_get_trajectory: forward states are stored only by the debug flow; create the "
@@ -2457,9 +2551,10 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
     info->sparse_controls = (c->is_group ? c->sub[0]->sparse_ctrl : c->sparse_ctrl) ? 1 : 0;
     {
         const grape_ctx *s0 = c->is_group ? c->sub[0] : c;
-        info->fused_forward = (s0->thin && tile_fuse_forward(tile_params(s0, nullptr, 1)) == 1) ? 1 : 0;
+        info->fused_forward = (s0->thin && !s0->action && tile_fuse_forward(tile_params(s0, nullptr, 1)) == 1) ? 1 : 0;
         info->time_chunks = s0->tp_C;
         info->hoisted_controls = s0->hoist == 1 ? 1 : 0;
+        info->expm_action = s0->action ? 1 : 0;
     }
     return GRAPE_OK;
 }

@@ -137,12 +137,22 @@ struct TileParams {
     const double *ha_norm;    // [unit] |A'_k|_1 bound (max column sum of |re| + |im|) / theta8
     double2 *gc;              // [control array][slice] D-layout dumps of Gc_t = (-i dt) sum_c x[c,t] B_c
     double *gcn;              // [control array][slice] |Gc_t|_1 bound / theta8
+    // rank-one states + member-invariant controls (action_thin.hip): exp(G_t) applied to the chains' vectors, no propagators
+    int32_t action;           // set by the host layer
+    const double2 *act_a;     // [unit][2][256] row-major [A'_k | A'_k'] (conjugate transpose), zero padded to 16 x 16
+    const double *act_an;     // [unit] max(|A'_k|_1, |A'_k|_inf)
+    const double2 *act_b;     // [K][2][256] row-major [B'_c | B'_c'], B'_c = (-i dt) B_c
+    const double2 *act_bf;    // [K][256] row-major B_c (the gradient's bilinear forms)
+    double2 *act_g;           // [control array][slice][2][256]: [Gc_t | Gc_t'], written by the pre-pass
+    double *act_gn;           // [control array][slice] max(|Gc_t|_1, |Gc_t|_inf)
     hipEvent_t ev_mid;        // timing (GRAPE_FLAG_TIME_KERNELS): recorded behind the expm kernel, in front of the chain kernels; or null
     double dt;
 };
 constexpr int kSparseMax = 64;
 // the chain over rank-one states (n = 9..16, one member per wavefront); called by launch_sweep_tile when p.thin
 hipError_t launch_chain_thin(int sandwich, const TileParams &p, hipStream_t stream);
+// rank-one states, member-invariant controls: the evaluation on vectors (action_thin.hip); called by launch_sweep_tile when p.action
+hipError_t launch_action_thin(int sandwich, const TileParams &p, hipStream_t stream);
 int tile_count(int n);    // NT for this n (0: not a tile-family size)
 int tile_fuse_forward(const TileParams &p);   // thin: forward vector pass runs inside prop_tile_kernel for this launch?
 hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);

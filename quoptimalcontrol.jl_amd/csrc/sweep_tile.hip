@@ -1367,6 +1367,8 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
 
 hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream)
 {
+    if (p.action)
+        return launch_action_thin(sandwich, p, stream);
     switch (tile_count(n)) {
     case 1: return launch_nt<1>(sandwich, keep_costates, p, stream);
     case 2: return launch_nt<2>(sandwich, keep_costates, p, stream);

@@ -69,7 +69,8 @@ class GrapeInfo(C.Structure):
                 ("members_first_device", C.c_int32), ("lane_pair", C.c_int32),
                 ("states_stored", C.c_int32), ("rank_one_chain", C.c_int32),
                 ("sparse_controls", C.c_int32), ("fused_forward", C.c_int32),
-                ("time_chunks", C.c_int32), ("hoisted_controls", C.c_int32)]
+                ("time_chunks", C.c_int32), ("hoisted_controls", C.c_int32),
+                ("expm_action", C.c_int32)]
 
 
 class GrapeLbfgsOptions(C.Structure):

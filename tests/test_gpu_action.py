@@ -1,0 +1,167 @@
+"""GPU: rank-one states with member-invariant control operators -- the evaluation on vectors alone
+(csrc/action_thin.hip: exp(G_t) applied to the two chains' vectors by its Taylor series, no propagators) -- against
+the oracle's DENSE evaluation of the same inputs (the reference's formulas, src/GRAPE.jl:216-303, with
+exp(-i dt H) from the Pade expm) at the 1e-10 bar, and against the library's expm + vector-chain flow (GRAPE_ACTION=0)."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(n, K, N, E, sand, herm_gen, herm_ctrl, seed, scale=1.0, shared=True):
+    rng = np.random.default_rng(seed)
+
+    def gen(h):
+        M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        return (M + M.conj().T) / 2 if h else M
+    A = np.array([gen(herm_gen) for _ in range(E)]) * 0.6 * scale
+    B0 = np.array([gen(herm_ctrl) for _ in range(K)]) * 0.4 * scale
+    B = np.array([B0 if shared else np.array([gen(herm_ctrl) for _ in range(K)]) * 0.4 * scale for _ in range(E)])
+
+    def vec():
+        v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        return v / np.linalg.norm(v)
+    if sand:
+        def rho():
+            v = vec()
+            return np.outer(v, v.conj())
+        Xi = np.array([rho() for _ in range(E)])
+        Xt = np.array([rho() for _ in range(E)])
+    else:
+        Xi = np.array([vec().reshape(n, 1) for _ in range(E)])
+        Xt = np.array([vec().reshape(n, 1) for _ in range(E)])
+    return A, B, Xi, Xt, rng.uniform(0.2, 1.0, E), rng.uniform(-1, 1, (K, N))
+
+
+CASES = [  # n, K, N, E, sys_type, Hermitian generators (drift), Hermitian controls
+    (16, 4, 1, 2, "CoherenceTransfer", False, True), (16, 4, 2, 2, "CoherenceTransfer", False, True),
+    (16, 3, 3, 3, "StateTransfer", True, True), (16, 2, 4, 2, "CoherenceTransfer", False, False),
+    (16, 4, 5, 2, "StateTransfer", False, False), (12, 1, 7, 3, "CoherenceTransfer", False, True),
+    (9, 6, 8, 2, "StateTransfer", False, False), (16, 5, 33, 2, "CoherenceTransfer", False, True),
+    (13, 3, 100, 5, "StateTransfer", True, True), (16, 4, 257, 3, "CoherenceTransfer", False, True),
+    (16, 4, 1, 2, "UnitaryGate", False, True), (16, 3, 2, 3, "UnitaryGate", True, True),
+    (10, 2, 5, 2, "UnitaryGate", False, False), (16, 6, 64, 4, "UnitaryGate", False, False),
+    (16, 4, 101, 2, "UnitaryGate", False, True), (15, 2, 130, 70, "CoherenceTransfer", False, True),
+]
+
+
+@pytest.mark.parametrize("n,K,N,E,sys_type,herm_gen,herm_ctrl", CASES)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_vector_flow_matches_dense_oracle(qoc, oracle, monkeypatch, n, K, N, E, sys_type, herm_gen, herm_ctrl, variant):
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    sand = sys_type != "UnitaryGate"
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sand, herm_gen, herm_ctrl, seed=7 * n + N + K)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.2, variant=variant,
+                                                             per_member=True)
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N, variant=variant, member_results=True) as eng:
+        info = eng.info
+        assert info["rank_one_chain"] == 1 and info["expm_action"] == 1 and info["time_chunks"] == 0
+        assert info["fused_forward"] == 0 and info["states_stored"] == 0
+        F, G = eng.eval(x)
+        foms, grads = eng.member_results()
+        F2, G2 = eng.eval(x)
+        assert F == F2 and np.array_equal(G, G2)          # run-to-run bitwise
+        with pytest.raises(qoc.engine.GrapeError, match="forms no propagators"):
+            eng.trajectory(0, states=False)
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k}")
+    assert_parity(F, G, F_ref, G_ref, n, what="ensemble")
+    # the library's expm kernel + vector chain on the same inputs
+    monkeypatch.setenv("GRAPE_ACTION", "0")
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N, variant=variant) as eng:
+        assert eng.info["rank_one_chain"] == 1 and eng.info["expm_action"] == 0
+        F_c, G_c = eng.eval(x)
+    assert_parity(F, G, F_c, G_c, n, what="vector flow vs expm + chain")
+
+
+@pytest.mark.parametrize("scale,N,n,sys_type", [(0.01, 40, 16, "CoherenceTransfer"), (0.2, 40, 16, "CoherenceTransfer"),
+                                                (3.0, 24, 16, "CoherenceTransfer"), (3.0, 24, 11, "UnitaryGate"),
+                                                (12.0, 16, 16, "StateTransfer"), (40.0, 8, 16, "UnitaryGate")])
+def test_degrees_and_pieces(qoc, oracle, monkeypatch, scale, N, n, sys_type):
+    """dt |H| from 0.005 to ~100: Taylor degrees 4..20 from the table, then the generator split into pieces."""
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    K, E = 3, 3
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sys_type != "UnitaryGate", True, True, seed=int(10 * scale) + N,
+                                    scale=scale)
+    F_ref, G_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.0)
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.0, N) as eng:
+        assert eng.info["expm_action"] == 1
+        F, G = eng.eval(x)
+    assert_parity(F, G, F_ref, G_ref, n, what=f"scale {scale}")
+
+
+@pytest.mark.parametrize("squarings", [0, 3])
+def test_forced_squarings_become_pieces(qoc, oracle, monkeypatch, squarings):
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    n, K, N, E = 16, 2, 20, 2
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, False, True, seed=4, scale=0.5)
+    F_ref, G_ref = oracle.ensemble_eval("CoherenceTransfer", A, B, Xi, Xt, wts, x, 1.0)
+    with qoc.GrapeEngine("CoherenceTransfer", A, B, Xi, Xt, wts, 1.0, N, expm_squarings=squarings) as eng:
+        assert eng.info["expm_action"] == 1
+        F, G = eng.eval(x)
+    assert_parity(F, G, F_ref, G_ref, n, what=f"s = {squarings}")
+
+
+def test_chosen_for_ensembles_that_fill_the_device(qoc, oracle, monkeypatch):
+    # default threshold: one wavefront per member fills the SIMDs (4 x compute units members); lowered here to keep the
+    # problem small
+    monkeypatch.delenv("GRAPE_ACTION", raising=False)
+    monkeypatch.setenv("GRAPE_ACTION_MIN", "256")
+    n, K, N = 16, 2, 24
+    for E, want in ((4, 0), (255, 0), (300, 1)):
+        A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, False, True, seed=E)
+        with qoc.GrapeEngine("CoherenceTransfer", A, B, Xi, Xt, wts, 1.0, N, member_results=True) as eng:
+            assert eng.info["rank_one_chain"] == 1 and eng.info["expm_action"] == want
+            F, G = eng.eval(x)
+            foms, grads = eng.member_results()
+        for k in (0, E // 2, E - 1):
+            f_ref, g_ref = oracle.member_eval("CoherenceTransfer", A[k], B[k], Xi[k], Xt[k], x, 1.0)[:2]
+            assert_parity(foms[k], grads[k], f_ref, g_ref, n, what=f"E = {E}, member {k}")
+        assert abs(F - float(np.dot(wts, foms))) <= 1e-12 * max(1.0, abs(F))
+
+
+def test_per_member_controls_keep_the_expm_flow_and_uploads_switch(qoc, oracle, monkeypatch):
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    n, K, N, E = 16, 3, 30, 3
+    A, B, Xi, Xt, wts, _ = _problem(n, K, N, E, True, False, True, seed=1)
+    with qoc.GrapeEngine("CoherenceTransfer", A, B, Xi, Xt, wts, 1.0, N) as eng:
+        for shared in (True, False, True):
+            A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, False, True, seed=11, shared=shared)
+            eng.set_operators(A, B, Xi, Xt, wts)
+            assert eng.info["rank_one_chain"] == 1 and eng.info["expm_action"] == (1 if shared else 0)
+            F, G = eng.eval(x)
+            F_ref, G_ref = oracle.ensemble_eval("CoherenceTransfer", A, B, Xi, Xt, wts, x, 1.0)
+            assert_parity(F, G, F_ref, G_ref, n, what=f"shared={shared}")
+
+
+def test_batched_and_device_entry_points(qoc, oracle, monkeypatch):
+    import torch
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    n, K, N, E = 16, 4, 50, 3
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, False, True, seed=3)
+    rng = np.random.default_rng(0)
+    xs = np.stack([x, rng.uniform(-1, 1, (K, N)), 0.5 * x])
+    with qoc.GrapeEngine("CoherenceTransfer", A, B, Xi, Xt, wts, 1.0, N, max_batch=3) as eng:
+        assert eng.info["expm_action"] == 1
+        Fs, Gs = eng.eval_batch(xs)
+        xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda")
+        fg = torch.zeros(K * N + 1, dtype=torch.float64, device="cuda")
+        eng.eval_device(xd.data_ptr(), fg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        h = fg.cpu().numpy()
+    for b in range(3):
+        F_ref, G_ref = oracle.ensemble_eval("CoherenceTransfer", A, B, Xi, Xt, wts, xs[b], 1.0)
+        assert_parity(Fs[b], Gs[b], F_ref, G_ref, n, what=f"batch {b}")
+    assert_parity(h[-1], h[:-1].reshape(N, K).T, Fs[0], Gs[0], n, what="device entry point")
+
+
+def test_nan_controls_propagate(qoc, monkeypatch):
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    n, K, N, E = 16, 2, 12, 2
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, False, True, seed=9)
+    x[1, 5] = np.nan
+    with qoc.GrapeEngine("CoherenceTransfer", A, B, Xi, Xt, wts, 1.0, N) as eng:
+        F, G = eng.eval(x)
+    assert np.isnan(F) and np.isnan(G).any()
