@@ -142,10 +142,17 @@ __global__ __launch_bounds__(256) void action_rows_kernel(const TileParams p)
     }
 }
 
-__global__ __launch_bounds__(64) void action_thin_kernel(const TileParams p)
+// Workgroups of kActWaves members (one wave each, no communication): the launcher sizes the dynamic LDS so that exactly as
+// many workgroups fit a compute unit as an even spread needs.  With one-wave workgroups the dispatcher doubled up waves
+// on some SIMDs while others idled (1024 members: 1.99 ms, 768 and fewer: 1.33 ms).
+constexpr int kActWaves = 4;
+__global__ __launch_bounds__(64 * kActWaves) void action_thin_kernel(const TileParams p)
 {
-    const int lane = threadIdx.x, r = lane & 15, d = lane >> 5, h = (lane >> 4) & 1;
-    const int k = blockIdx.x, y = blockIdx.y, N = p.N;
+    const int lane = threadIdx.x & 63, r = lane & 15, d = lane >> 5, h = (lane >> 4) & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = blockIdx.x * kActWaves + wave, y = blockIdx.y, N = p.N;
+    if (k >= p.E)
+        return;
     const size_t kw = (size_t)y * p.E + k;
     const int off = d * 256 + r * 16 + 8 * h;
     const double2 *__restrict__ Ak = p.act_a + (size_t)k * 512 + off;
@@ -179,7 +186,8 @@ __global__ __launch_bounds__(64) void action_thin_kernel(const TileParams p)
     // the plan of every step i (forward slice i, backward slice N-1-i): Taylor degree and number of pieces from the larger of
     // the two slices' bounds.  Worked out here by all lanes at once -- inside the chain the table search is five dependent
     // scalar-memory round trips per slice (measured: 45 % of the kernel in s_waitcnt)
-    extern __shared__ unsigned s_plan[];
+    extern __shared__ unsigned s_plan_all[];
+    unsigned *s_plan = s_plan_all + (size_t)wave * N;             // this wave's own plan: no workgroup barrier anywhere
     {
         const int forced = p.s_forced;
         for (int i0 = 0; i0 < N; i0 += 64) {
@@ -194,7 +202,9 @@ __global__ __launch_bounds__(64) void action_thin_kernel(const TileParams p)
                 th /= (double)pieces;
             s_plan[i] = (unsigned)min(act_degree(th), 24) | ((unsigned)pieces << 8);
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     // loop state: the vector as the products read it, x[(r + 8h) mod 16] (in the h = 0 rows that IS element r), and the
     // component this row updates (h = 0: real part, h = 1: imaginary part of element r)
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(64) void action_thin_kernel(const TileParams p)
 }
 
 // grid (ceil(N / 64), E, n_x): lane = slice.  act_bf = the K control operators B_c, row-major, zero padded to 16 x 16
-template <int SAND, bool HERMB, bool SKIP>
+template <int SAND, bool HERMB>
 __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
 {
     const int lane = threadIdx.x, k = blockIdx.y, y = blockIdx.z, K = p.K, N = p.N;
@@ -278,24 +288,20 @@ __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
     const double gs = SAND ? -p.dt * (HERMB ? 2.0 : 1.0) : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
     double *__restrict__ out_member = p.member_out + ((size_t)y * p.E_members + k) * ((size_t)K * N + 1);
     for (int c = 0; c < K; ++c) {
-        // (constant address space: the operators are read through the scalar cache, one s_load per 1..4 entries)
-        // (constant address space: the operators are read through the scalar cache; an entry that is zero -- most of a
-        // Liouville-space control superoperator -- is skipped by a scalar branch on its bits)
+        // (constant address space: the operators are read through the scalar cache, a row per wait)
         const __attribute__((address_space(4))) unsigned long long *Bc =
             (const __attribute__((address_space(4))) unsigned long long *)(uintptr_t)(p.act_bf + (size_t)c * 256);
         double a_r = 0.0, a_i = 0.0, b_r = 0.0, b_i = 0.0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             double ur = 0.0, ui = 0.0, xr = 0.0, xi = 0.0;
-            unsigned long long q[32];                             // row i: four s_load_dwordx16, one wait, then the tests
+            unsigned long long q[32];                             // row i: four s_load_dwordx16, one wait
 #pragma unroll
             for (int j = 0; j < 32; ++j)
                 q[j] = Bc[32 * i + j];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const unsigned long long qx = q[2 * j], qy = q[2 * j + 1];
-                if (SKIP && ((qx | qy) << 1) == 0)
-                    continue;
                 const double2 b = make_double2(__longlong_as_double((long long)qx), __longlong_as_double((long long)qy));
                 ur = fma(b.x, vr[j], ur);                         // (B v)[i]
                 ur = fma(-b.y, vi[j], ur);
@@ -331,35 +337,153 @@ __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
     }
 }
 
+// The same for SPARSE control operators (at most R non-zeros per row: Pauli-type controls and their Liouville-space
+// commutators have 1..4): per control and row R (value, column) pairs, zero padded (act_bs / act_bo, staged in LDS and read
+// back as broadcasts); v_t (and w_t where b is needed) of the wave's 64 slices sits in LDS element-major, so a column is
+// one ds_read_b128 at  column offset + 16 lane.  16 (5 R + 4) vector instructions per control instead of 1100: the kernel
+// is left with reading the records.  (A per-entry zero test in the dense kernel -- scalar OR / compare / branch per entry --
+// measured slower than the dense kernel itself: 326 vs 299 us at C4.)
+template <int SAND, bool HERMB, int R>
+__global__ __launch_bounds__(64) void action_forms_sparse_kernel(const TileParams p)
+{
+    constexpr bool NEEDB = SAND && !HERMB;
+    extern __shared__ double2 s_forms[];
+    const int lane = threadIdx.x, k = blockIdx.y, y = blockIdx.z, K = p.K, N = p.N;
+    const int t = blockIdx.x * 64 + lane, tc = min(t, N - 1);
+    const size_t kw = (size_t)y * p.E + k;
+    const double2 *__restrict__ V = p.states + kw * (size_t)(N + 1) * 16;
+    const double2 *__restrict__ W = p.props + kw * (size_t)(N + 1) * 16;
+    double2 *s_v = s_forms, *s_w = s_forms + 1024;                // [16][64] each (s_w only when b is needed)
+    double2 *s_tab = s_forms + (NEEDB ? 2048 : 1024);             // [K][16][R] values
+    int *s_off = reinterpret_cast<int *>(s_tab + (size_t)K * 16 * R);   // [K][16][R] byte offsets of the column inside s_v
+    double vr[16], vi[16], wr[16], wi[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const double2 a = V[(size_t)i * (N + 1) + tc], b = W[(size_t)i * (N + 1) + tc];
+        vr[i] = a.x;
+        vi[i] = a.y;
+        wr[i] = b.x;
+        wi[i] = b.y;
+        s_v[i * 64 + lane] = a;
+        if (NEEDB)
+            s_w[i * 64 + lane] = b;
+    }
+    for (int q = lane; q < K * 16 * R; q += 64) {
+        s_tab[q] = p.act_bs[q];
+        s_off[q] = p.act_bo[q];
+    }
+    double s_re = 0.0, s_im = 0.0;                                // s = w_N' v_N (uniform)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const double2 a = V[(size_t)i * (N + 1) + N], b = W[(size_t)i * (N + 1) + N];
+        s_re = fma(b.x, a.x, fma(b.y, a.y, s_re));
+        s_im = fma(b.x, a.y, fma(-b.y, a.x, s_im));
+    }
+    __syncthreads();
+    const double gs = SAND ? -p.dt * (HERMB ? 2.0 : 1.0) : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
+    double *__restrict__ out_member = p.member_out + ((size_t)y * p.E_members + k) * ((size_t)K * N + 1);
+    const char *vcol = reinterpret_cast<const char *>(s_v + lane), *wcol = reinterpret_cast<const char *>(s_w + lane);
+    for (int c = 0; c < K; ++c) {
+        const double2 *tab = s_tab + (size_t)c * 16 * R;
+        const int *off = s_off + (size_t)c * 16 * R;
+        double a_r = 0.0, a_i = 0.0, b_r = 0.0, b_i = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double ur = 0.0, ui = 0.0, xr = 0.0, xi = 0.0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const double2 b = tab[i * R + q];
+                const int o = off[i * R + q];
+                const double2 vj = *reinterpret_cast<const double2 *>(vcol + o);
+                ur = fma(b.x, vj.x, ur);                          // (B v)[i]
+                ur = fma(-b.y, vj.y, ur);
+                ui = fma(b.x, vj.y, ui);
+                ui = fma(b.y, vj.x, ui);
+                if (NEEDB) {
+                    const double2 wj = *reinterpret_cast<const double2 *>(wcol + o);
+                    xr = fma(b.x, wj.x, xr);                      // (B w)[i]
+                    xr = fma(-b.y, wj.y, xr);
+                    xi = fma(b.x, wj.y, xi);
+                    xi = fma(b.y, wj.x, xi);
+                }
+            }
+            a_r = fma(wr[i], ur, fma(wi[i], ui, a_r));            // conj(w[i]) (B v)[i]
+            a_i = fma(wr[i], ui, fma(-wi[i], ur, a_i));
+            if (NEEDB) {
+                b_r = fma(vr[i], xr, fma(vi[i], xi, b_r));        // conj(v[i]) (B w)[i]
+                b_i = fma(vr[i], xi, fma(-vi[i], xr, b_i));
+            }
+        }
+        double val = s_re * a_i - s_im * a_r;                     // Im(conj(s) a)
+        if (NEEDB)
+            val -= s_re * b_i + s_im * b_r;                       // - Im(s b)
+        if (t < N)
+            out_member[c + (size_t)t * K] = gs * val;
+    }
+    if (blockIdx.x == 0 && lane == 0) {
+        if (SAND) {
+            const double z = (s_re * s_re + s_im * s_im) / (double)p.n;
+            out_member[(size_t)K * N] = 1.0 - z * z;
+        } else {
+            out_member[(size_t)K * N] = s_re * s_re - s_im * s_im;
+        }
+    }
+}
+
+template <int R>
+static void launch_forms_sparse(int sandwich, const TileParams &p, dim3 grid, size_t lds, hipStream_t stream)
+{
+    if (!sandwich)
+        hipLaunchKernelGGL((action_forms_sparse_kernel<0, true, R>), grid, dim3(64), lds, stream, p);
+    else if (p.herm_ctrl)
+        hipLaunchKernelGGL((action_forms_sparse_kernel<1, true, R>), grid, dim3(64), lds, stream, p);
+    else
+        hipLaunchKernelGGL((action_forms_sparse_kernel<1, false, R>), grid, dim3(64), lds, stream, p);
+}
+
 hipError_t launch_action_thin(int sandwich, const TileParams &p, hipStream_t stream)
 {
     hipLaunchKernelGGL(action_rows_kernel, dim3(p.N, p.n_x), dim3(256), 0, stream, p);
-    const size_t plan_bytes = sizeof(unsigned) * (size_t)p.N;
+    const size_t plan_bytes = sizeof(unsigned) * (size_t)p.N * kActWaves;
     if (plan_bytes > 64 * 1024)                                   // (the host layer keeps such pulses on the expm flow)
         return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL(action_thin_kernel, dim3(p.E, p.n_x), dim3(64), plan_bytes, stream, p);
+    // as many workgroups per compute unit as an even spread of the launch needs, and no more: the LDS request is the limiter
+    const long groups = (long)((p.E + kActWaves - 1) / kActWaves) * p.n_x, cus = p.cus > 0 ? p.cus : 256;
+    const long per_cu = (groups + cus - 1) / cus;
+    size_t lds = (size_t)(160 * 1024) / (size_t)per_cu;
+    lds = lds > 1024 ? (lds - 512) & ~(size_t)255 : lds;
+    if (lds < plan_bytes)
+        lds = plan_bytes;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)action_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
+    hipLaunchKernelGGL(action_thin_kernel, dim3((p.E + kActWaves - 1) / kActWaves, p.n_x), dim3(64 * kActWaves), lds, stream, p);
     if (p.ev_mid) {
         hipError_t e = hipEventRecord(p.ev_mid, stream);
         if (e != hipSuccess)
             return e;
     }
     const dim3 grid((p.N + 63) / 64, p.E, p.n_x);
-    static const bool skip = std::getenv("GRAPE_FORMS_SKIP") != nullptr;
-    if (skip) {
-        if (!sandwich)
-            hipLaunchKernelGGL((action_forms_kernel<0, true, true>), grid, dim3(64), 0, stream, p);
-        else if (p.herm_ctrl)
-            hipLaunchKernelGGL((action_forms_kernel<1, true, true>), grid, dim3(64), 0, stream, p);
-        else
-            hipLaunchKernelGGL((action_forms_kernel<1, false, true>), grid, dim3(64), 0, stream, p);
-        return hipGetLastError();
+    if (p.act_R > 0) {                                            // sparse control operators: (value, column) lists
+        const bool needb = sandwich && !p.herm_ctrl;
+        const size_t lds = sizeof(double2) * (needb ? 2048 : 1024) + (sizeof(double2) + sizeof(int)) * (size_t)p.K * 16 * p.act_R;
+        switch (lds <= 64 * 1024 ? p.act_R : 0) {
+        case 1: launch_forms_sparse<1>(sandwich, p, grid, lds, stream); return hipGetLastError();
+        case 2: launch_forms_sparse<2>(sandwich, p, grid, lds, stream); return hipGetLastError();
+        case 3: launch_forms_sparse<3>(sandwich, p, grid, lds, stream); return hipGetLastError();
+        case 4: launch_forms_sparse<4>(sandwich, p, grid, lds, stream); return hipGetLastError();
+        case 6: launch_forms_sparse<6>(sandwich, p, grid, lds, stream); return hipGetLastError();
+        default: break;
+        }
     }
     if (!sandwich)
-        hipLaunchKernelGGL((action_forms_kernel<0, true, false>), grid, dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((action_forms_kernel<0, true>), grid, dim3(64), 0, stream, p);
     else if (p.herm_ctrl)
-        hipLaunchKernelGGL((action_forms_kernel<1, true, false>), grid, dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((action_forms_kernel<1, true>), grid, dim3(64), 0, stream, p);
     else
-        hipLaunchKernelGGL((action_forms_kernel<1, false, false>), grid, dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((action_forms_kernel<1, false>), grid, dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -102,7 +102,10 @@ struct grape_ctx {
     double *d_gcn = nullptr;
     bool action = false;                       // rank-one states + member-invariant controls: exp(G) v on vectors (action_thin.hip)
     double2 *d_act_a = nullptr, *d_act_b = nullptr, *d_act_bf = nullptr, *d_act_g = nullptr;
-    double *d_act_an = nullptr, *d_act_gn = nullptr;                   // [B][N] |Gc_t|_1 bound / theta8
+    double *d_act_an = nullptr, *d_act_gn = nullptr;
+    int act_R = 0;                             // sparse rows of the control operators (0: dense forms kernel)
+    double2 *d_act_bs = nullptr;
+    int32_t *d_act_bo = nullptr;                   // [B][N] |Gc_t|_1 bound / theta8
     size_t states_bytes = 0;                   // size of d_states (vector records are smaller than state dumps)
     int tp_C = 0, tp_S = 0;                    // tile family, unitary flow, small ensembles: time chunks per unit (0 = sequential chain)
     double2 *d_tp_q = nullptr, *d_tp_r = nullptr, *d_tp_m = nullptr;   // chunk products, products after each chunk, M_N
@@ -319,7 +322,7 @@ static void free_all(grape_ctx *c)
     (void)hipFree(c->d_x_bar);
     (void)hipFree(c->d_ha); (void)hipFree(c->d_ha_norm); (void)hipFree(c->d_gc); (void)hipFree(c->d_gcn);
     (void)hipFree(c->d_act_a); (void)hipFree(c->d_act_b); (void)hipFree(c->d_act_bf); (void)hipFree(c->d_act_g);
-    (void)hipFree(c->d_act_an); (void)hipFree(c->d_act_gn);
+    (void)hipFree(c->d_act_an); (void)hipFree(c->d_act_gn); (void)hipFree(c->d_act_bs); (void)hipFree(c->d_act_bo);
     delete c;
 }
 
@@ -1080,7 +1083,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // fill the device (the chunked flows of small ensembles keep the expm kernel: they need the chunk PRODUCTS);
         // GRAPE_ACTION=0 keeps the expm + chain kernels, GRAPE_ACTION=1 forces the vector flow for any ensemble size.
         const char *ae = std::getenv("GRAPE_ACTION");
-        bool act = thin && !(ae && ae[0] == '0') && c->cfg.n_slices <= 16384;   // (the kernel's per-slice plan lives in LDS)
+        bool act = thin && !(ae && ae[0] == '0') && c->cfg.n_slices <= 4096;   // (the kernel's per-slice plans live in LDS)
         for (size_t k = 1; k < E && act; ++k)
             act = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
         if (act && !(ae && ae[0] == '1') && (c->tp_C || (long)c->EU < act_min_units(c))) act = false;
@@ -1127,6 +1130,39 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                         bf[2 * (cc * 256 + row * 16 + col)] = B[2 * (cc * nn + row + (size_t)nd * col)];
                         bf[2 * (cc * 256 + row * 16 + col) + 1] = B[2 * (cc * nn + row + (size_t)nd * col) + 1];
                     }
+            }
+            // sparse rows (Pauli-type controls, Liouville-space commutators): (value, column) lists for the forms kernel
+            int rmax = 0;
+            for (size_t cc = 0; cc < K; ++cc)
+                for (int row = 0; row < nd; ++row) {
+                    int cnt = 0;
+                    for (int col = 0; col < nd; ++col)
+                        if (bf[2 * (cc * 256 + row * 16 + col)] != 0.0 || bf[2 * (cc * 256 + row * 16 + col) + 1] != 0.0) ++cnt;
+                    rmax = std::max(rmax, cnt);
+                }
+            c->act_R = env_on("GRAPE_FORMS_DENSE") ? 0 : rmax <= 0 ? 1 : rmax <= 4 ? rmax : rmax <= 6 ? 6 : 0;
+            if (c->act_R) {
+                const size_t R = (size_t)c->act_R;
+                std::vector<double> bs(2 * K * 16 * R, 0.0);
+                std::vector<int32_t> bo(K * 16 * R, 0);
+                for (size_t cc = 0; cc < K; ++cc)
+                    for (int row = 0; row < nd; ++row) {
+                        size_t q = (cc * 16 + row) * R;
+                        for (int col = 0; col < nd; ++col) {
+                            const double re = bf[2 * (cc * 256 + row * 16 + col)], im = bf[2 * (cc * 256 + row * 16 + col) + 1];
+                            if (re == 0.0 && im == 0.0) continue;
+                            bs[2 * q] = re;
+                            bs[2 * q + 1] = im;
+                            bo[q] = 1024 * col;
+                            ++q;
+                        }
+                    }
+                (void)hipFree(c->d_act_bs); c->d_act_bs = nullptr;       // (R may change between uploads)
+                (void)hipFree(c->d_act_bo); c->d_act_bo = nullptr;
+                HIP_TRY(c, hipMalloc((void **)&c->d_act_bs, sizeof(double) * bs.size()));
+                HIP_TRY(c, hipMalloc((void **)&c->d_act_bo, sizeof(int32_t) * bo.size()));
+                HIP_TRY(c, hipMemcpy(c->d_act_bs, bs.data(), sizeof(double) * bs.size(), hipMemcpyHostToDevice));
+                HIP_TRY(c, hipMemcpy(c->d_act_bo, bo.data(), sizeof(int32_t) * bo.size(), hipMemcpyHostToDevice));
             }
             const size_t g_elems = (size_t)c->B * c->cfg.n_slices * 512;
             if (!c->d_act_a) {
@@ -1231,6 +1267,9 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.act_bf = c->d_act_bf;
     p.act_g = c->d_act_g;
     p.act_gn = c->d_act_gn;
+    p.act_R = c->action ? c->act_R : 0;
+    p.act_bs = c->d_act_bs;
+    p.act_bo = c->d_act_bo;
     return p;
 }
 

@@ -143,6 +143,9 @@ struct TileParams {
     const double *act_an;     // [unit] max(|A'_k|_1, |A'_k|_inf)
     const double2 *act_b;     // [K][2][256] row-major [B'_c | B'_c'], B'_c = (-i dt) B_c
     const double2 *act_bf;    // [K][256] row-major B_c (the gradient's bilinear forms)
+    int32_t act_R;            // > 0: every row of every B_c has at most act_R non-zeros (1, 2, 3, 4 or 6) -- the forms read
+    const double2 *act_bs;    //      [K][16][act_R] values B_c[i][j], zero padded, and
+    const int32_t *act_bo;    //      [K][16][act_R] the byte offsets 1024 j of their columns in the kernel's LDS tile
     double2 *act_g;           // [control array][slice][2][256]: [Gc_t | Gc_t'], written by the pre-pass
     double *act_gn;           // [control array][slice] max(|Gc_t|_1, |Gc_t|_inf)
     hipEvent_t ev_mid;        // timing (GRAPE_FLAG_TIME_KERNELS): recorded behind the expm kernel, in front of the chain kernels; or null

@@ -165,3 +165,54 @@ def test_nan_controls_propagate(qoc, monkeypatch):
     with qoc.GrapeEngine("CoherenceTransfer", A, B, Xi, Xt, wts, 1.0, N) as eng:
         F, G = eng.eval(x)
     assert np.isnan(F) and np.isnan(G).any()
+
+
+def _pauli_string(rng, nq=4):
+    P = [np.eye(2), np.array([[0, 1], [1, 0]]), np.array([[0, -1j], [1j, 0]]), np.array([[1, 0], [0, -1]])]
+    M = np.array([[1.0 + 0j]])
+    for _ in range(nq):
+        M = np.kron(M, P[int(rng.integers(0, 4))])
+    return M
+
+
+@pytest.mark.parametrize("terms,herm_ctrl,sys_type", [(1, True, "CoherenceTransfer"), (2, True, "CoherenceTransfer"),
+                                                      (2, False, "CoherenceTransfer"), (3, True, "StateTransfer"),
+                                                      (4, False, "StateTransfer"), (2, True, "UnitaryGate"),
+                                                      (5, False, "UnitaryGate"), (6, True, "CoherenceTransfer"),
+                                                      (7, True, "CoherenceTransfer")])
+def test_sparse_control_operators_take_the_list_kernel(qoc, oracle, monkeypatch, terms, herm_ctrl, sys_type):
+    """Controls that are sums of `terms` Pauli strings (at most `terms` non-zeros per row): the forms kernel reads
+    (value, column) lists (1, 2, 3, 4 or 6 per row); 7 and more, or GRAPE_FORMS_DENSE, take the dense kernel."""
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    n, K, N, E = 16, 3, 70, 3
+    rng = np.random.default_rng(100 * terms + herm_ctrl)
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sys_type != "UnitaryGate", False, True, seed=terms)
+    B0 = []
+    for _ in range(K):
+        M = sum(rng.uniform(0.2, 1.0) * _pauli_string(rng) for _ in range(terms))
+        if not herm_ctrl:
+            M = M * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))      # same pattern, no symmetry
+        B0.append(0.4 * M)
+    B = np.array([B0] * E)
+    F_ref, G_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.0)
+    res = []
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("GRAPE_FORMS_DENSE", "1")
+        with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.0, N) as eng:
+            assert eng.info["expm_action"] == 1
+            res.append(eng.eval(x))
+        assert_parity(res[-1][0], res[-1][1], F_ref, G_ref, n, what=f"{terms} terms, dense={dense}")
+    assert_parity(res[0][0], res[0][1], res[1][0], res[1][1], n, what="list kernel vs dense kernel")
+
+
+def test_liouville_space_ensemble(qoc, oracle, monkeypatch):
+    """C4's shape at test size: two-qubit Liouvillians with detuned members, vec(rho) states, shared control superoperators."""
+    from quoptimalcontrol_jl_amd import workloads
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    w = workloads.config("C4", E=6, N=120)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        assert eng.info["expm_action"] == 1 and eng.info["sparse_controls"] == 1
+        F, G = eng.eval(w.x)
+    assert_parity(F, G, F_ref, G_ref, w.n, what="C4 at E = 6, N = 120")
