@@ -754,13 +754,15 @@ extern "C" int grape_comm_attach(grape_ctx *c, const grape_comm_id *id, int32_t 
     return GRAPE_OK;
 }
 
-// smallest ensemble the vector flow of action_thin.hip is chosen for: one wavefront per member has to fill the SIMDs
-// (4 per compute unit) -- a member's two chains are strictly sequential in time, so a smaller ensemble leaves SIMDs idle
-// for the whole evaluation, where the expm kernel spreads (member, slice) pairs over all of them.  GRAPE_ACTION_MIN overrides.
+// smallest ensemble the vector flow of action_thin.hip is chosen for.  A member's two chains are strictly sequential in
+// time: the flow takes the same 1.3 ms at C4's shape for 128 as for 1024 members (one wavefront per member, up to one per
+// SIMD), where the expm + chain kernels spread (member, slice) pairs and time chunks over the whole device and are ahead
+// for small ensembles.  Measured crossover at C4 (N = 1000): 256 members 1.30 vs 1.27 ms, 320 members 1.31 vs 1.52 ms.
+// GRAPE_ACTION_MIN overrides.
 static long act_min_units(const grape_ctx *c)
 {
     if (const char *e = std::getenv("GRAPE_ACTION_MIN")) return std::atol(e);
-    return 4L * c->compute_units;
+    return 9L * c->compute_units / 8;
 }
 
 extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *B, const double *Xi,
