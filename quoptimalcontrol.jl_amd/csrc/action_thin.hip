@@ -47,7 +47,7 @@ __constant__ double kActInv[25] = {0.0,      1.0,      1.0 / 2,  1.0 / 3,  1.0 /
                                    1.0 / 9,  1.0 / 10, 1.0 / 11, 1.0 / 12, 1.0 / 13, 1.0 / 14, 1.0 / 15, 1.0 / 16, 1.0 / 17,
                                    1.0 / 18, 1.0 / 19, 1.0 / 20, 1.0 / 21, 1.0 / 22, 1.0 / 23, 1.0 / 24};
 constexpr double kActPiece = 1.40513;     // beyond it the generator is split: terms up to e^theta lose digits to cancellation
-constexpr int kActMaxPieces = 1 << 14;
+constexpr int kActMaxPieces = 2047;          // (11 bits of the 16-bit plan entry; |G| > 2800 per slice is not a pulse)
 
 // degree for |G| <= th: the number of table entries below th, plus one (25: beyond the table)
 GRAPE_DEV int act_degree(double th)
@@ -77,6 +77,16 @@ GRAPE_DEV void act_matvec(double &a0, double &a1, double &b0, double &b1, double
         : "v"(xr), "v"(xi), "v"(mr[0]), "v"(mr[1]), "v"(mr[2]), "v"(mr[3]), "v"(mr[4]), "v"(mr[5]), "v"(mr[6]), "v"(mr[7]),
           "v"(mi[0]), "v"(mi[1]), "v"(mi[2]), "v"(mi[3]), "v"(mi[4]), "v"(mi[5]), "v"(mi[6]), "v"(mi[7]));
 }
+// the same for the second eight columns of a 16-column half (n = 17..32): lanes 8..15 of the row
+GRAPE_DEV void act_matvec_hi(double &a0, double &a1, double &b0, double &b1, double xr, double xi, const double (&mr)[8],
+                             const double (&mi)[8])
+{
+    asm("s_nop 1\n" GRAPE_ACT_MAC(8, 6, 14) GRAPE_ACT_MAC(9, 7, 15) GRAPE_ACT_MAC(10, 8, 16) GRAPE_ACT_MAC(11, 9, 17)
+            GRAPE_ACT_MAC(12, 10, 18) GRAPE_ACT_MAC(13, 11, 19) GRAPE_ACT_MAC(14, 12, 20) GRAPE_ACT_MAC(15, 13, 21)
+        : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)
+        : "v"(xr), "v"(xi), "v"(mr[0]), "v"(mr[1]), "v"(mr[2]), "v"(mr[3]), "v"(mr[4]), "v"(mr[5]), "v"(mr[6]), "v"(mr[7]),
+          "v"(mi[0]), "v"(mi[1]), "v"(mi[2]), "v"(mi[3]), "v"(mi[4]), "v"(mi[5]), "v"(mi[6]), "v"(mi[7]));
+}
 #undef GRAPE_ACT_MAC
 
 // v_permlane16_swap on a double: the odd rows of a trade places with the even rows of b
@@ -86,6 +96,38 @@ GRAPE_DEV void swap16(double &a, double &b)
     const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
     a = __hiloint2double(hi[0], lo[0]);
     b = __hiloint2double(hi[1], lo[1]);
+}
+
+// v_permlane32_swap on a double: lanes 32..63 of a trade places with lanes 0..31 of b
+GRAPE_DEV void swap32(double &a, double &b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(hi[0], lo[0]);
+    b = __hiloint2double(hi[1], lo[1]);
+}
+
+// the plan of every step i of a chain pair (forward slice i, backward slice N-1-i): Taylor degree (low 5 bits) and number
+// of pieces from the larger of the two slices' bounds.  Worked out by all lanes at once into the wave's own LDS strip --
+// inside the chain the table search is five dependent scalar-memory round trips per slice (measured: 45 % of the kernel
+// in s_waitcnt)
+GRAPE_DEV void act_make_plan(unsigned short *s_plan, const double *__restrict__ gn, double an, int N, int forced, int lane)
+{
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        const int i = min(i0 + lane, N - 1);
+        double th = an + fmax(gn[i], gn[N - 1 - i]);
+        int pieces = 1;
+        if (forced >= 0)
+            pieces = 1 << min(forced, 10);
+        else if (th > kActPiece)
+            pieces = (int)fmin(ceil(th / kActPiece), (double)kActMaxPieces);
+        if (pieces != 1)
+            th /= (double)pieces;
+        s_plan[i] = (unsigned short)(min(act_degree(th), 24) | (pieces << 5));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // rows 1 and 3 (h = 1): rotate by 8 lanes inside the row; rows 0 and 2 keep their value
@@ -98,44 +140,49 @@ GRAPE_DEV double rot8_odd_rows(double u)
 
 }  // namespace
 
-// grid (N, n_x), 256 threads: thread e = 16 r + j forms Gc_t[r][j] and (Gc_t')[r][j]; act_b = per control [B'_c | B'_c'], row-major
+// grid (N, n_x), 256 threads: element e = NB r + j of Gc_t and of Gc_t'; act_b = per control [B'_c | B'_c'], row-major NB x NB
+template <int NB>
 __global__ __launch_bounds__(256) void action_rows_kernel(const TileParams p)
 {
-    __shared__ double s_abs[256];
-    __shared__ double s_sum[32];
-    const int e = threadIdx.x, t = blockIdx.x, y = blockIdx.y, K = p.K, N = p.N;
+    constexpr int NN = NB * NB;
+    __shared__ double s_abs[NN];
+    __shared__ double s_sum[2 * NB];
+    const int t = blockIdx.x, y = blockIdx.y, K = p.K, N = p.N;
     const double *__restrict__ x = p.x + ((size_t)y * N + t) * K;
     const double2 *__restrict__ Bb = p.act_b;
-    double2 g0, g1;
-    {
-        const double x0 = x[0];
-        const double2 b0 = Bb[e], b1 = Bb[256 + e];
-        g0 = make_double2(b0.x * x0, b0.y * x0);                  // (0 + B_1 x_1) first, timeevolution.jl:101-108
-        g1 = make_double2(b1.x * x0, b1.y * x0);
+    double2 *__restrict__ dst = p.act_g + ((size_t)y * N + t) * 2 * NN;
+    for (int e = threadIdx.x; e < NN; e += 256) {
+        double2 g0, g1;
+        {
+            const double x0 = x[0];
+            const double2 b0 = Bb[e], b1 = Bb[NN + e];
+            g0 = make_double2(b0.x * x0, b0.y * x0);              // (0 + B_1 x_1) first, timeevolution.jl:101-108
+            g1 = make_double2(b1.x * x0, b1.y * x0);
+        }
+        for (int c = 1; c < K; ++c) {
+            const double xc = x[c];
+            const double2 b0 = Bb[(size_t)c * 2 * NN + e], b1 = Bb[(size_t)c * 2 * NN + NN + e];
+            g0.x = fma(b0.x, xc, g0.x);
+            g0.y = fma(b0.y, xc, g0.y);
+            g1.x = fma(b1.x, xc, g1.x);
+            g1.y = fma(b1.y, xc, g1.y);
+        }
+        dst[e] = g0;
+        dst[NN + e] = g1;
+        s_abs[e] = fabs(g0.x) + fabs(g0.y);
     }
-    for (int c = 1; c < K; ++c) {
-        const double xc = x[c];
-        const double2 b0 = Bb[(size_t)c * 512 + e], b1 = Bb[(size_t)c * 512 + 256 + e];
-        g0.x = fma(b0.x, xc, g0.x);
-        g0.y = fma(b0.y, xc, g0.y);
-        g1.x = fma(b1.x, xc, g1.x);
-        g1.y = fma(b1.y, xc, g1.y);
-    }
-    double2 *__restrict__ dst = p.act_g + ((size_t)y * N + t) * 512;
-    dst[e] = g0;
-    dst[256 + e] = g1;
-    s_abs[e] = fabs(g0.x) + fabs(g0.y);
     __syncthreads();
-    if (e < 32) {                                                 // 16 column sums, 16 row sums
-        double s = 0.0;
-        for (int q = 0; q < 16; ++q)
-            s += e < 16 ? s_abs[q * 16 + e] : s_abs[(e - 16) * 16 + q];
-        s_sum[e] = s;
+    const int e = threadIdx.x;
+    if (e < 2 * NB) {                                             // NB column sums, NB row sums
+        double sum = 0.0;
+        for (int q = 0; q < NB; ++q)
+            sum += e < NB ? s_abs[q * NB + e] : s_abs[(e - NB) * NB + q];
+        s_sum[e] = sum;
     }
     __syncthreads();
     if (e == 0) {
         double best = 0.0;
-        for (int q = 0; q < 32; ++q)
+        for (int q = 0; q < 2 * NB; ++q)
             if (!(s_sum[q] <= best))                              // NaN-propagating
                 best = s_sum[q];
         p.act_gn[(size_t)y * N + t] = best;
@@ -183,29 +230,9 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin_kernel(const TileP
         for (int j = 0; j < 8; ++j)
             gq[j] = src[j];
     }
-    // the plan of every step i (forward slice i, backward slice N-1-i): Taylor degree and number of pieces from the larger of
-    // the two slices' bounds.  Worked out here by all lanes at once -- inside the chain the table search is five dependent
-    // scalar-memory round trips per slice (measured: 45 % of the kernel in s_waitcnt)
-    extern __shared__ unsigned s_plan_all[];
-    unsigned *s_plan = s_plan_all + (size_t)wave * N;             // this wave's own plan: no workgroup barrier anywhere
-    {
-        const int forced = p.s_forced;
-        for (int i0 = 0; i0 < N; i0 += 64) {
-            const int i = min(i0 + lane, N - 1);
-            double th = an + fmax(gn[i], gn[N - 1 - i]);
-            int pieces = 1;
-            if (forced >= 0)
-                pieces = 1 << min(forced, 14);
-            else if (th > kActPiece)
-                pieces = (int)fmin(ceil(th / kActPiece), (double)kActMaxPieces);
-            if (pieces != 1)
-                th /= (double)pieces;
-            s_plan[i] = (unsigned)min(act_degree(th), 24) | ((unsigned)pieces << 8);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    extern __shared__ unsigned short s_plan_all[];
+    unsigned short *s_plan = s_plan_all + (size_t)wave * N;       // this wave's own plan: no workgroup barrier anywhere
+    act_make_plan(s_plan, gn, an, N, p.s_forced, lane);
     // loop state: the vector as the products read it, x[(r + 8h) mod 16] (in the h = 0 rows that IS element r), and the
     // component this row updates (h = 0: real part, h = 1: imaginary part of element r)
     double xr = rot8_odd_rows(vr), xi = rot8_odd_rows(vi);
@@ -225,7 +252,7 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin_kernel(const TileP
             for (int j = 0; j < 8; ++j)
                 gq[j] = src[j];
         }
-        const int m = __builtin_amdgcn_readfirstlane(plan & 255), pieces = __builtin_amdgcn_readfirstlane(plan >> 8);
+        const int m = __builtin_amdgcn_readfirstlane(plan & 31), pieces = __builtin_amdgcn_readfirstlane(plan >> 5);
         plan = s_plan[min(i + 1, N - 1)];
         if (pieces != 1) {                                        // exp(G) = exp(G / p)^p: the pieces see G / p
             const double inv_p = 1.0 / (double)pieces;
@@ -258,18 +285,123 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin_kernel(const TileP
     }
 }
 
-// grid (ceil(N / 64), E, n_x): lane = slice.  act_bf = the K control operators B_c, row-major, zero padded to 16 x 16
-template <int SAND, bool HERMB>
+// n = 17..32: one wavefront per member AND direction (d = wave & 1; a workgroup = two members).  DPP row rho = 2 Rb + H holds in
+// lane l the 16 complex entries M[16 Rb + l][16 H .. 16 H + 15] (32 VGPRs) and x[16 H + l]: 64 FMACs per product.  The
+// column halves meet through one v_permlane16_swap of (re, im) as above -- row rho then holds the row's component
+// R_rho = (re b0, im b0, re b1, im b1) of the 16-blocks b0, b1 of the new vector -- and TWO more swaps hand every row the
+// block its columns need: v_permlane32_swap of (R, R) gives (R0 R1 R0 R1), (R2 R3 R2 R3); v_permlane16_swap of those
+// gives (R0 R2 R0 R2) = re of block H and (R1 R3 R1 R3) = im of block H.  82 vector instructions per product.
+// (Measured alternatives: both chains in one wave with whole rows per lane -- 148 instructions per product for the pair,
+// no swaps, but 256 + 158 registers and one wave per SIMD: 12.6 ms against 9.0 ms for 1024 members of 2000 slices, a
+// single wave issues FP64 instructions at about half the pipe's rate; blocks handed round by four swaps and selects
+// after an all-gather: 100 instructions, 9.0 ms.)
+__global__ __launch_bounds__(64 * kActWaves) void action_thin2_kernel(const TileParams p)
+{
+    const int lane = threadIdx.x & 63, l = lane & 15, Rb = lane >> 5, H = (lane >> 4) & 1, el = 16 * Rb + l;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), d = wave & 1;
+    const int k = blockIdx.x * (kActWaves / 2) + (wave >> 1), y = blockIdx.y, N = p.N;
+    if (k >= p.E)
+        return;
+    const size_t kw = (size_t)y * p.E + k;
+    const int off = d * 1024 + el * 32 + 16 * H;
+    const double2 *__restrict__ Ak = p.act_a + (size_t)k * 2048 + off;
+    const double2 *__restrict__ Gy = p.act_g + (size_t)y * N * 2048 + off;
+    const double *__restrict__ gn = p.act_gn + (size_t)y * N;
+    const double an = p.act_an[k];
+    // rows 0 (Rb = H = 0) and 3 (Rb = H = 1) hold, as x, the element el they also own: they write the records
+    const bool writer = Rb == H;
+    double2 *__restrict__ rec = (d ? p.props : p.states) + kw * (size_t)(N + 1) * 32 + (size_t)el * (N + 1);
+    double ar[16], ai[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double2 a = Ak[j];
+        ar[j] = a.x;
+        ai[j] = a.y;
+    }
+    double xr, xi, sel;                                           // x[16 H + l]; this row's component of element el
+    {
+        const double2 *__restrict__ v0 = p.vecs + (size_t)k * 64 + d * 32;
+        const double2 own = v0[el], col = v0[16 * H + l];
+        xr = col.x;
+        xi = col.y;
+        sel = H ? own.y : own.x;
+        if (writer)
+            rec[d ? N : 0] = own;
+    }
+    double2 gq[16];
+    {
+        const double2 *__restrict__ src = Gy + (size_t)(d ? N - 1 : 0) * 2048;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            gq[j] = src[j];
+    }
+    extern __shared__ unsigned short s_plan_all[];
+    unsigned short *s_plan = s_plan_all + (size_t)wave * N;
+    act_make_plan(s_plan, gn, an, N, p.s_forced, lane);           // (both waves of a member: the same plan)
+    unsigned plan = s_plan[0];
+    for (int i = 0; i < N; ++i) {
+        double mr[8], mi[8], nr[8], ni[8];                        // columns 0..7 and 8..15 of the half
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                             // G = Gc + A' (A last, timeevolution.jl:108)
+            mr[j] = gq[j].x + ar[j];
+            mi[j] = gq[j].y + ai[j];
+            nr[j] = gq[8 + j].x + ar[8 + j];
+            ni[j] = gq[8 + j].y + ai[8 + j];
+        }
+        {
+            const int tn = d ? max(N - 2 - i, 0) : min(i + 1, N - 1);
+            const double2 *__restrict__ src = Gy + (size_t)tn * 2048;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                gq[j] = src[j];
+        }
+        const int m = __builtin_amdgcn_readfirstlane(plan & 31), pieces = __builtin_amdgcn_readfirstlane(plan >> 5);
+        plan = s_plan[min(i + 1, N - 1)];
+        if (pieces != 1) {
+            const double inv_p = 1.0 / (double)pieces;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                mr[j] *= inv_p;
+                mi[j] *= inv_p;
+                nr[j] *= inv_p;
+                ni[j] *= inv_p;
+            }
+        }
+        auto step = [&](int kk) -> double {
+            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+            act_matvec(a0, a1, b0, b1, xr, xi, mr, mi);
+            act_matvec_hi(a0, a1, b0, b1, xr, xi, nr, ni);
+            double yr = a0 + a1, yi = b0 + b1;
+            swap16(yr, yi);                                       // H = 0 rows: both real halves; H = 1 rows: both imaginary halves
+            const double mine = fma(yr + yi, kActInv[kk], sel);   // row rho: R_rho = (re b0, im b0, re b1, im b1)
+            xr = mine;
+            xi = mine;
+            swap32(xr, xi);                                       // (R0 R1 R0 R1), (R2 R3 R2 R3)
+            swap16(xr, xi);                                       // (R0 R2 R0 R2) = re of block H, (R1 R3 R1 R3) = im of block H
+            return mine;
+        };
+        for (int piece = 0; piece < pieces; ++piece) {
+            for (int kk = m; kk >= 2; --kk)
+                (void)step(kk);
+            sel = step(1);
+        }
+        if (writer)
+            rec[d ? N - 1 - i : i + 1] = make_double2(xr, xi);
+    }
+}
+
+// grid (ceil(N / 64), E, n_x): lane = slice.  act_bf = the K control operators B_c, row-major, zero padded to NB x NB
+template <int SAND, bool HERMB, int NB>
 __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
 {
     const int lane = threadIdx.x, k = blockIdx.y, y = blockIdx.z, K = p.K, N = p.N;
     const int t = blockIdx.x * 64 + lane, tc = min(t, N - 1);
     const size_t kw = (size_t)y * p.E + k;
-    const double2 *__restrict__ V = p.states + kw * (size_t)(N + 1) * 16;
-    const double2 *__restrict__ W = p.props + kw * (size_t)(N + 1) * 16;
-    double vr[16], vi[16], wr[16], wi[16];
+    const double2 *__restrict__ V = p.states + kw * (size_t)(N + 1) * NB;
+    const double2 *__restrict__ W = p.props + kw * (size_t)(N + 1) * NB;
+    double vr[NB], vi[NB], wr[NB], wi[NB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NB; ++i) {
         const double2 a = V[(size_t)i * (N + 1) + tc], b = W[(size_t)i * (N + 1) + tc];
         vr[i] = a.x;
         vi[i] = a.y;
@@ -279,7 +411,7 @@ __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
     double s_re = 0.0, s_im = 0.0;                                // s = w_N' v_N (uniform)
     {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NB; ++i) {
             const double2 a = V[(size_t)i * (N + 1) + N], b = W[(size_t)i * (N + 1) + N];
             s_re = fma(b.x, a.x, fma(b.y, a.y, s_re));            // conj(w) v
             s_im = fma(b.x, a.y, fma(-b.y, a.x, s_im));
@@ -290,29 +422,32 @@ __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
     for (int c = 0; c < K; ++c) {
         // (constant address space: the operators are read through the scalar cache, a row per wait)
         const __attribute__((address_space(4))) unsigned long long *Bc =
-            (const __attribute__((address_space(4))) unsigned long long *)(uintptr_t)(p.act_bf + (size_t)c * 256);
+            (const __attribute__((address_space(4))) unsigned long long *)(uintptr_t)(p.act_bf + (size_t)c * NB * NB);
         double a_r = 0.0, a_i = 0.0, b_r = 0.0, b_i = 0.0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NB; ++i) {
             double ur = 0.0, ui = 0.0, xr = 0.0, xi = 0.0;
-            unsigned long long q[32];                             // row i: four s_load_dwordx16, one wait
+            unsigned long long q[32];                             // 16 entries of row i: four s_load_dwordx16, one wait
+#pragma unroll
+            for (int jb = 0; jb < NB; jb += 16) {
 #pragma unroll
             for (int j = 0; j < 32; ++j)
-                q[j] = Bc[32 * i + j];
+                q[j] = Bc[2 * (NB * i + jb) + j];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const unsigned long long qx = q[2 * j], qy = q[2 * j + 1];
                 const double2 b = make_double2(__longlong_as_double((long long)qx), __longlong_as_double((long long)qy));
-                ur = fma(b.x, vr[j], ur);                         // (B v)[i]
-                ur = fma(-b.y, vi[j], ur);
-                ui = fma(b.x, vi[j], ui);
-                ui = fma(b.y, vr[j], ui);
+                ur = fma(b.x, vr[jb + j], ur);                    // (B v)[i]
+                ur = fma(-b.y, vi[jb + j], ur);
+                ui = fma(b.x, vi[jb + j], ui);
+                ui = fma(b.y, vr[jb + j], ui);
                 if (SAND && !HERMB) {
-                    xr = fma(b.x, wr[j], xr);                     // (B w)[i]
-                    xr = fma(-b.y, wi[j], xr);
-                    xi = fma(b.x, wi[j], xi);
-                    xi = fma(b.y, wr[j], xi);
+                    xr = fma(b.x, wr[jb + j], xr);                // (B w)[i]
+                    xr = fma(-b.y, wi[jb + j], xr);
+                    xi = fma(b.x, wi[jb + j], xi);
+                    xi = fma(b.y, wr[jb + j], xi);
                 }
+            }
             }
             a_r = fma(wr[i], ur, fma(wi[i], ui, a_r));            // conj(w[i]) (B v)[i]
             a_i = fma(wr[i], ui, fma(-wi[i], ur, a_i));
@@ -343,7 +478,7 @@ __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
 // one ds_read_b128 at  column offset + 16 lane.  16 (5 R + 4) vector instructions per control instead of 1100: the kernel
 // is left with reading the records.  (A per-entry zero test in the dense kernel -- scalar OR / compare / branch per entry --
 // measured slower than the dense kernel itself: 326 vs 299 us at C4.)
-template <int SAND, bool HERMB, int R>
+template <int SAND, bool HERMB, int R, int NB>
 __global__ __launch_bounds__(64) void action_forms_sparse_kernel(const TileParams p)
 {
     constexpr bool NEEDB = SAND && !HERMB;
@@ -351,14 +486,14 @@ __global__ __launch_bounds__(64) void action_forms_sparse_kernel(const TileParam
     const int lane = threadIdx.x, k = blockIdx.y, y = blockIdx.z, K = p.K, N = p.N;
     const int t = blockIdx.x * 64 + lane, tc = min(t, N - 1);
     const size_t kw = (size_t)y * p.E + k;
-    const double2 *__restrict__ V = p.states + kw * (size_t)(N + 1) * 16;
-    const double2 *__restrict__ W = p.props + kw * (size_t)(N + 1) * 16;
-    double2 *s_v = s_forms, *s_w = s_forms + 1024;                // [16][64] each (s_w only when b is needed)
-    double2 *s_tab = s_forms + (NEEDB ? 2048 : 1024);             // [K][16][R] values
-    int *s_off = reinterpret_cast<int *>(s_tab + (size_t)K * 16 * R);   // [K][16][R] byte offsets of the column inside s_v
-    double vr[16], vi[16], wr[16], wi[16];
+    const double2 *__restrict__ V = p.states + kw * (size_t)(N + 1) * NB;
+    const double2 *__restrict__ W = p.props + kw * (size_t)(N + 1) * NB;
+    double2 *s_v = s_forms, *s_w = s_forms + 64 * NB;             // [NB][64] each (s_w only when b is needed)
+    double2 *s_tab = s_forms + (NEEDB ? 128 : 64) * NB;           // [K][NB][R] values
+    int *s_off = reinterpret_cast<int *>(s_tab + (size_t)K * NB * R);   // [K][NB][R] byte offsets of the column inside s_v
+    double vr[NB], vi[NB], wr[NB], wi[NB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NB; ++i) {
         const double2 a = V[(size_t)i * (N + 1) + tc], b = W[(size_t)i * (N + 1) + tc];
         vr[i] = a.x;
         vi[i] = a.y;
@@ -368,13 +503,13 @@ __global__ __launch_bounds__(64) void action_forms_sparse_kernel(const TileParam
         if (NEEDB)
             s_w[i * 64 + lane] = b;
     }
-    for (int q = lane; q < K * 16 * R; q += 64) {
+    for (int q = lane; q < K * NB * R; q += 64) {
         s_tab[q] = p.act_bs[q];
         s_off[q] = p.act_bo[q];
     }
     double s_re = 0.0, s_im = 0.0;                                // s = w_N' v_N (uniform)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NB; ++i) {
         const double2 a = V[(size_t)i * (N + 1) + N], b = W[(size_t)i * (N + 1) + N];
         s_re = fma(b.x, a.x, fma(b.y, a.y, s_re));
         s_im = fma(b.x, a.y, fma(-b.y, a.x, s_im));
@@ -384,11 +519,11 @@ __global__ __launch_bounds__(64) void action_forms_sparse_kernel(const TileParam
     double *__restrict__ out_member = p.member_out + ((size_t)y * p.E_members + k) * ((size_t)K * N + 1);
     const char *vcol = reinterpret_cast<const char *>(s_v + lane), *wcol = reinterpret_cast<const char *>(s_w + lane);
     for (int c = 0; c < K; ++c) {
-        const double2 *tab = s_tab + (size_t)c * 16 * R;
-        const int *off = s_off + (size_t)c * 16 * R;
+        const double2 *tab = s_tab + (size_t)c * NB * R;
+        const int *off = s_off + (size_t)c * NB * R;
         double a_r = 0.0, a_i = 0.0, b_r = 0.0, b_i = 0.0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NB; ++i) {
             double ur = 0.0, ui = 0.0, xr = 0.0, xi = 0.0;
 #pragma unroll
             for (int q = 0; q < R; ++q) {
@@ -430,36 +565,39 @@ __global__ __launch_bounds__(64) void action_forms_sparse_kernel(const TileParam
     }
 }
 
-template <int R>
+template <int R, int NB>
 static void launch_forms_sparse(int sandwich, const TileParams &p, dim3 grid, size_t lds, hipStream_t stream)
 {
     if (!sandwich)
-        hipLaunchKernelGGL((action_forms_sparse_kernel<0, true, R>), grid, dim3(64), lds, stream, p);
+        hipLaunchKernelGGL((action_forms_sparse_kernel<0, true, R, NB>), grid, dim3(64), lds, stream, p);
     else if (p.herm_ctrl)
-        hipLaunchKernelGGL((action_forms_sparse_kernel<1, true, R>), grid, dim3(64), lds, stream, p);
+        hipLaunchKernelGGL((action_forms_sparse_kernel<1, true, R, NB>), grid, dim3(64), lds, stream, p);
     else
-        hipLaunchKernelGGL((action_forms_sparse_kernel<1, false, R>), grid, dim3(64), lds, stream, p);
+        hipLaunchKernelGGL((action_forms_sparse_kernel<1, false, R, NB>), grid, dim3(64), lds, stream, p);
 }
 
-hipError_t launch_action_thin(int sandwich, const TileParams &p, hipStream_t stream)
+template <int NB>
+static hipError_t launch_action_nb(int sandwich, const TileParams &p, hipStream_t stream)
 {
-    hipLaunchKernelGGL(action_rows_kernel, dim3(p.N, p.n_x), dim3(256), 0, stream, p);
-    const size_t plan_bytes = sizeof(unsigned) * (size_t)p.N * kActWaves;
+    hipLaunchKernelGGL((action_rows_kernel<NB>), dim3(p.N, p.n_x), dim3(256), 0, stream, p);
+    const size_t plan_bytes = sizeof(unsigned short) * (size_t)p.N * kActWaves;
     if (plan_bytes > 64 * 1024)                                   // (the host layer keeps such pulses on the expm flow)
         return hipErrorInvalidConfiguration;
     // as many workgroups per compute unit as an even spread of the launch needs, and no more: the LDS request is the limiter
-    const long groups = (long)((p.E + kActWaves - 1) / kActWaves) * p.n_x, cus = p.cus > 0 ? p.cus : 256;
+    constexpr int per_group = NB == 16 ? kActWaves : kActWaves / 2;          // members of a workgroup
+    const long groups = (long)((p.E + per_group - 1) / per_group) * p.n_x, cus = p.cus > 0 ? p.cus : 256;
     const long per_cu = (groups + cus - 1) / cus;
     size_t lds = (size_t)(160 * 1024) / (size_t)per_cu;
     lds = lds > 1024 ? (lds - 512) & ~(size_t)255 : lds;
     if (lds < plan_bytes)
         lds = plan_bytes;
+    auto kern = NB == 16 ? action_thin_kernel : action_thin2_kernel;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)action_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
     }
-    hipLaunchKernelGGL(action_thin_kernel, dim3((p.E + kActWaves - 1) / kActWaves, p.n_x), dim3(64 * kActWaves), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3((p.E + per_group - 1) / per_group, p.n_x), dim3(64 * kActWaves), lds, stream, p);
     if (p.ev_mid) {
         hipError_t e = hipEventRecord(p.ev_mid, stream);
         if (e != hipSuccess)
@@ -468,23 +606,29 @@ hipError_t launch_action_thin(int sandwich, const TileParams &p, hipStream_t str
     const dim3 grid((p.N + 63) / 64, p.E, p.n_x);
     if (p.act_R > 0) {                                            // sparse control operators: (value, column) lists
         const bool needb = sandwich && !p.herm_ctrl;
-        const size_t lds = sizeof(double2) * (needb ? 2048 : 1024) + (sizeof(double2) + sizeof(int)) * (size_t)p.K * 16 * p.act_R;
-        switch (lds <= 64 * 1024 ? p.act_R : 0) {
-        case 1: launch_forms_sparse<1>(sandwich, p, grid, lds, stream); return hipGetLastError();
-        case 2: launch_forms_sparse<2>(sandwich, p, grid, lds, stream); return hipGetLastError();
-        case 3: launch_forms_sparse<3>(sandwich, p, grid, lds, stream); return hipGetLastError();
-        case 4: launch_forms_sparse<4>(sandwich, p, grid, lds, stream); return hipGetLastError();
-        case 6: launch_forms_sparse<6>(sandwich, p, grid, lds, stream); return hipGetLastError();
+        const size_t lds_f = sizeof(double2) * (needb ? 128 : 64) * NB + (sizeof(double2) + sizeof(int)) * (size_t)p.K * NB * p.act_R;
+        switch (lds_f <= 64 * 1024 ? p.act_R : 0) {
+        case 1: launch_forms_sparse<1, NB>(sandwich, p, grid, lds_f, stream); return hipGetLastError();
+        case 2: launch_forms_sparse<2, NB>(sandwich, p, grid, lds_f, stream); return hipGetLastError();
+        case 3: launch_forms_sparse<3, NB>(sandwich, p, grid, lds_f, stream); return hipGetLastError();
+        case 4: launch_forms_sparse<4, NB>(sandwich, p, grid, lds_f, stream); return hipGetLastError();
+        case 6: launch_forms_sparse<6, NB>(sandwich, p, grid, lds_f, stream); return hipGetLastError();
         default: break;
         }
     }
     if (!sandwich)
-        hipLaunchKernelGGL((action_forms_kernel<0, true>), grid, dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((action_forms_kernel<0, true, NB>), grid, dim3(64), 0, stream, p);
     else if (p.herm_ctrl)
-        hipLaunchKernelGGL((action_forms_kernel<1, true>), grid, dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((action_forms_kernel<1, true, NB>), grid, dim3(64), 0, stream, p);
     else
-        hipLaunchKernelGGL((action_forms_kernel<1, false>), grid, dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((action_forms_kernel<1, false, NB>), grid, dim3(64), 0, stream, p);
     return hipGetLastError();
+}
+
+// p.E = members (the host layer hands over member counts, not tile units); n = 9..16 -> 16 x 16 images, 17..32 -> 32 x 32
+hipError_t launch_action_thin(int sandwich, const TileParams &p, hipStream_t stream)
+{
+    return p.n <= 16 ? launch_action_nb<16>(sandwich, p, stream) : launch_action_nb<32>(sandwich, p, stream);
 }
 
 }  // namespace grape

@@ -887,27 +887,38 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     // Rank-one states in the single-tile family (n = 9..16): X_t = v_t v_t' (sandwich, Xi = v0 v0', Xt = wT wT') or
     // X_t = v_t (left multiplication of n x 1 states) -- the chain runs on vectors (sweep_thin.hip).
     // GRAPE_FLAG_FORCE_GENERAL / KEEP_COSTATES / the exact gradient keep the dense chain.
+    // n = 17..32: there is no expm-based vector chain; rank-one states count only where the vector flow of action_thin.hip
+    // takes them (shared controls, an ensemble that fills the device -- decided right here), else the dense chains stay.
     std::vector<double> vecs;
-    bool thin = c->family == 1 && c->NT == 1 && !c->pack2 && c->cfg.gradient != GRAPE_GRADIENT_EXACT &&
+    const size_t VS = 16 * (size_t)c->NT;                    // complex entries of a (zero padded) vector
+    const char *act_env = std::getenv("GRAPE_ACTION");
+    bool ctrl_shared = true;                                 // the members' control operators are identical
+    for (size_t k = 1; k < E && ctrl_shared; ++k)
+        ctrl_shared = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
+    const bool act_forced = act_env && act_env[0] == '1';
+    const bool act_ok = ctrl_shared && !(act_env && act_env[0] == '0') && c->cfg.n_slices <= 4096;   // (per-slice plans live in LDS)
+    bool thin = c->family == 1 && !c->pack2 && c->cfg.gradient != GRAPE_GRADIENT_EXACT &&
                 !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) && !env_on("GRAPE_NO_THIN");
+    if (thin && c->NT == 2)
+        thin = act_ok && (act_forced || (long)c->EU >= act_min_units(c));
     if (thin) {
         const bool sand = c->cfg.sys_type != GRAPE_UNITARY_GATE;
-        vecs.assign(E * 64, 0.0);
+        vecs.assign(E * 4 * VS, 0.0);
         if (!sand) {
             thin = c->m == 1;
             for (size_t k = 0; k < E && thin; ++k)
                 for (int i = 0; i < n; ++i)
                     for (int which = 0; which < 2; ++which) {
                         const double *M = (which ? Xt : Xi) + 2 * k * nn;      // zero padded to n x n: column 0
-                        vecs[k * 64 + which * 32 + 2 * i] = M[2 * i];
-                        vecs[k * 64 + which * 32 + 2 * i + 1] = M[2 * i + 1];
+                        vecs[(k * 2 + which) * 2 * VS + 2 * i] = M[2 * i];
+                        vecs[(k * 2 + which) * 2 * VS + 2 * i + 1] = M[2 * i + 1];
                     }
         } else {
             thin = c->m == n;
             for (size_t k = 0; k < E && thin; ++k)
                 for (int which = 0; which < 2 && thin; ++which) {
                     const double *M = (which ? Xt : Xi) + 2 * k * nn;
-                    if (!grape_host::factor_rank_one(M, n, vecs.data() + k * 64 + which * 32)) thin = false;
+                    if (!grape_host::factor_rank_one(M, n, vecs.data() + (k * 2 + which) * 2 * VS)) thin = false;
                 }
         }
     }
@@ -1084,53 +1095,51 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // exp(G_t) applied to the two chains' vectors by its Taylor series, no propagator formed or stored.  Ensembles that
         // fill the device (the chunked flows of small ensembles keep the expm kernel: they need the chunk PRODUCTS);
         // GRAPE_ACTION=0 keeps the expm + chain kernels, GRAPE_ACTION=1 forces the vector flow for any ensemble size.
-        const char *ae = std::getenv("GRAPE_ACTION");
-        bool act = thin && !(ae && ae[0] == '0') && c->cfg.n_slices <= 4096;   // (the kernel's per-slice plans live in LDS)
-        for (size_t k = 1; k < E && act; ++k)
-            act = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
-        if (act && !(ae && ae[0] == '1') && (c->tp_C || (long)c->EU < act_min_units(c))) act = false;
+        bool act = thin && act_ok;
+        if (act && c->NT == 1 && !act_forced && (c->tp_C || (long)c->EU < act_min_units(c))) act = false;
         c->action = act;
         if (act) {
             c->tp_C = c->tp_S = c->tp_G = c->tp_g = 0;
             const double dt = c->cfg.duration / c->cfg.n_slices;
             const int nd = c->cfg.n;
+            const size_t VV = VS * VS;
             std::vector<double> aa, an, bb, bf;
             try {
-                aa.assign(2 * E * 512, 0.0);
+                aa.assign(2 * E * 2 * VV, 0.0);
                 an.assign(E, 0.0);
-                bb.assign(2 * K * 512, 0.0);
-                bf.assign(2 * K * 256, 0.0);
+                bb.assign(2 * K * 2 * VV, 0.0);
+                bf.assign(2 * K * VV, 0.0);
             } catch (...) {
                 return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: out of host memory");
             }
-            // dst: [M' | M''] row-major, zero padded to 16 x 16, M' = (-i dt) M (column-major n x n input); returns max(|M'|_1, |M'|_inf)
+            // dst: [M' | M''] row-major, zero padded to VS x VS, M' = (-i dt) M (column-major n x n input); returns max(|M'|_1, |M'|_inf)
             auto images = [&](double *dst, const double *M) {
-                double colsum[16] = {0}, rowsum[16] = {0};
+                double colsum[32] = {0}, rowsum[32] = {0};
                 for (int col = 0; col < nd; ++col)
                     for (int row = 0; row < nd; ++row) {
                         const double re = dt * M[2 * (row + (size_t)nd * col) + 1], im = -dt * M[2 * (row + (size_t)nd * col)];
-                        dst[2 * (row * 16 + col)] = re;
-                        dst[2 * (row * 16 + col) + 1] = im;
-                        dst[2 * (256 + col * 16 + row)] = re;            // (M'')[col][row] = conj(M'[row][col])
-                        dst[2 * (256 + col * 16 + row) + 1] = -im;
+                        dst[2 * (row * VS + col)] = re;
+                        dst[2 * (row * VS + col) + 1] = im;
+                        dst[2 * (VV + col * VS + row)] = re;            // (M'')[col][row] = conj(M'[row][col])
+                        dst[2 * (VV + col * VS + row) + 1] = -im;
                         colsum[col] += std::fabs(re) + std::fabs(im);
                         rowsum[row] += std::fabs(re) + std::fabs(im);
                     }
                 double best = 0.0;
-                for (int q = 0; q < 16; ++q) {
+                for (int q = 0; q < 32; ++q) {
                     if (!(colsum[q] <= best)) best = colsum[q];
                     if (!(rowsum[q] <= best)) best = rowsum[q];
                 }
                 return best;
             };
             for (size_t k = 0; k < E; ++k)
-                an[k] = images(aa.data() + 2 * k * 512, A + 2 * k * nn);
+                an[k] = images(aa.data() + 2 * k * 2 * VV, A + 2 * k * nn);
             for (size_t cc = 0; cc < K; ++cc) {
-                (void)images(bb.data() + 2 * cc * 512, B + 2 * cc * nn);
+                (void)images(bb.data() + 2 * cc * 2 * VV, B + 2 * cc * nn);
                 for (int col = 0; col < nd; ++col)
                     for (int row = 0; row < nd; ++row) {
-                        bf[2 * (cc * 256 + row * 16 + col)] = B[2 * (cc * nn + row + (size_t)nd * col)];
-                        bf[2 * (cc * 256 + row * 16 + col) + 1] = B[2 * (cc * nn + row + (size_t)nd * col) + 1];
+                        bf[2 * (cc * VV + row * VS + col)] = B[2 * (cc * nn + row + (size_t)nd * col)];
+                        bf[2 * (cc * VV + row * VS + col) + 1] = B[2 * (cc * nn + row + (size_t)nd * col) + 1];
                     }
             }
             // sparse rows (Pauli-type controls, Liouville-space commutators): (value, column) lists for the forms kernel
@@ -1139,19 +1148,19 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                 for (int row = 0; row < nd; ++row) {
                     int cnt = 0;
                     for (int col = 0; col < nd; ++col)
-                        if (bf[2 * (cc * 256 + row * 16 + col)] != 0.0 || bf[2 * (cc * 256 + row * 16 + col) + 1] != 0.0) ++cnt;
+                        if (bf[2 * (cc * VV + row * VS + col)] != 0.0 || bf[2 * (cc * VV + row * VS + col) + 1] != 0.0) ++cnt;
                     rmax = std::max(rmax, cnt);
                 }
             c->act_R = env_on("GRAPE_FORMS_DENSE") ? 0 : rmax <= 0 ? 1 : rmax <= 4 ? rmax : rmax <= 6 ? 6 : 0;
             if (c->act_R) {
                 const size_t R = (size_t)c->act_R;
-                std::vector<double> bs(2 * K * 16 * R, 0.0);
-                std::vector<int32_t> bo(K * 16 * R, 0);
+                std::vector<double> bs(2 * K * VS * R, 0.0);
+                std::vector<int32_t> bo(K * VS * R, 0);
                 for (size_t cc = 0; cc < K; ++cc)
                     for (int row = 0; row < nd; ++row) {
-                        size_t q = (cc * 16 + row) * R;
+                        size_t q = (cc * VS + row) * R;
                         for (int col = 0; col < nd; ++col) {
-                            const double re = bf[2 * (cc * 256 + row * 16 + col)], im = bf[2 * (cc * 256 + row * 16 + col) + 1];
+                            const double re = bf[2 * (cc * VV + row * VS + col)], im = bf[2 * (cc * VV + row * VS + col) + 1];
                             if (re == 0.0 && im == 0.0) continue;
                             bs[2 * q] = re;
                             bs[2 * q + 1] = im;
@@ -1166,14 +1175,14 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                 HIP_TRY(c, hipMemcpy(c->d_act_bs, bs.data(), sizeof(double) * bs.size(), hipMemcpyHostToDevice));
                 HIP_TRY(c, hipMemcpy(c->d_act_bo, bo.data(), sizeof(int32_t) * bo.size(), hipMemcpyHostToDevice));
             }
-            const size_t g_elems = (size_t)c->B * c->cfg.n_slices * 512;
+            const size_t g_elems = (size_t)c->B * c->cfg.n_slices * 2 * VV;
             if (!c->d_act_a) {
-                c->bytes += sizeof(double2) * (E * 512 + K * 768 + g_elems) + sizeof(double) * (E + (size_t)c->B * c->cfg.n_slices);
-                HIP_TRY(c, hipMalloc((void **)&c->d_act_a, sizeof(double2) * E * 512));
+                c->bytes += sizeof(double2) * (E * 2 * VV + K * 3 * VV + g_elems) + sizeof(double) * (E + (size_t)c->B * c->cfg.n_slices);
+                HIP_TRY(c, hipMalloc((void **)&c->d_act_a, sizeof(double2) * E * 2 * VV));
             }
             if (!c->d_act_an) HIP_TRY(c, hipMalloc((void **)&c->d_act_an, sizeof(double) * E));
-            if (!c->d_act_b) HIP_TRY(c, hipMalloc((void **)&c->d_act_b, sizeof(double2) * K * 512));
-            if (!c->d_act_bf) HIP_TRY(c, hipMalloc((void **)&c->d_act_bf, sizeof(double2) * K * 256));
+            if (!c->d_act_b) HIP_TRY(c, hipMalloc((void **)&c->d_act_b, sizeof(double2) * K * 2 * VV));
+            if (!c->d_act_bf) HIP_TRY(c, hipMalloc((void **)&c->d_act_bf, sizeof(double2) * K * VV));
             if (!c->d_act_g) HIP_TRY(c, hipMalloc((void **)&c->d_act_g, sizeof(double2) * g_elems));
             if (!c->d_act_gn) HIP_TRY(c, hipMalloc((void **)&c->d_act_gn, sizeof(double) * (size_t)c->B * c->cfg.n_slices));
             HIP_TRY(c, hipMemcpy(c->d_act_a, aa.data(), sizeof(double) * aa.size(), hipMemcpyHostToDevice));
@@ -1185,11 +1194,11 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     if (thin) {
         c->unitary = false;                                  // the thin chain serves Hermitian generators as well
         if (!c->d_vecs) {
-            c->bytes += sizeof(double) * E * 64;
-            HIP_TRY(c, hipMalloc((void **)&c->d_vecs, sizeof(double) * E * 64));
+            c->bytes += sizeof(double) * E * 4 * VS;
+            HIP_TRY(c, hipMalloc((void **)&c->d_vecs, sizeof(double) * E * 4 * VS));
         }
-        HIP_TRY(c, hipMemcpy(c->d_vecs, vecs.data(), sizeof(double) * E * 64, hipMemcpyHostToDevice));
-        const size_t rec = sizeof(double2) * E * ((size_t)c->cfg.n_slices + 1) * 16 * c->B;
+        HIP_TRY(c, hipMemcpy(c->d_vecs, vecs.data(), sizeof(double) * E * 4 * VS, hipMemcpyHostToDevice));
+        const size_t rec = sizeof(double2) * E * ((size_t)c->cfg.n_slices + 1) * VS * c->B;
         if (c->states_bytes < rec) {                         // the forward pass's vector records: N + 1 per member
             (void)hipFree(c->d_states);
             c->d_states = nullptr;

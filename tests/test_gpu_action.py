@@ -216,3 +216,71 @@ def test_liouville_space_ensemble(qoc, oracle, monkeypatch):
         assert eng.info["expm_action"] == 1 and eng.info["sparse_controls"] == 1
         F, G = eng.eval(w.x)
     assert_parity(F, G, F_ref, G_ref, w.n, what="C4 at E = 6, N = 120")
+
+
+CASES32 = [  # n, K, N, E, sys_type, Hermitian generators (drift), Hermitian controls
+    (32, 3, 1, 2, "CoherenceTransfer", False, True), (32, 2, 2, 3, "StateTransfer", True, True),
+    (17, 2, 5, 2, "CoherenceTransfer", False, False), (24, 4, 33, 3, "StateTransfer", False, True),
+    (32, 6, 64, 2, "CoherenceTransfer", False, True), (31, 1, 70, 5, "CoherenceTransfer", True, False),
+    (32, 3, 2, 2, "UnitaryGate", False, True), (20, 2, 9, 3, "UnitaryGate", True, True),
+    (32, 4, 101, 2, "UnitaryGate", False, False), (29, 3, 40, 9, "UnitaryGate", False, True),
+]
+
+
+@pytest.mark.parametrize("n,K,N,E,sys_type,herm_gen,herm_ctrl", CASES32)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_vector_flow_17_to_32(qoc, oracle, monkeypatch, n, K, N, E, sys_type, herm_gen, herm_ctrl, variant):
+    """n = 17..32 (two tiles per side): rank-one states run on vectors where the vector flow applies; there is no
+    expm-based vector chain at these sizes, so GRAPE_ACTION=0 is the dense chain."""
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    sand = sys_type != "UnitaryGate"
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sand, herm_gen, herm_ctrl, seed=3 * n + N + K)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 0.7, variant=variant,
+                                                             per_member=True)
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 0.7, N, variant=variant, member_results=True) as eng:
+        info = eng.info
+        assert info["rank_one_chain"] == 1 and info["expm_action"] == 1 and info["kernel_family"] == 1
+        F, G = eng.eval(x)
+        foms, grads = eng.member_results()
+        F2, G2 = eng.eval(x)
+        assert F == F2 and np.array_equal(G, G2)
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k}")
+    assert_parity(F, G, F_ref, G_ref, n, what="ensemble")
+    monkeypatch.setenv("GRAPE_ACTION", "0")
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 0.7, N, variant=variant) as eng:
+        assert eng.info["rank_one_chain"] == 0 and eng.info["expm_action"] == 0
+        F_c, G_c = eng.eval(x)
+    assert_parity(F, G, F_c, G_c, n, what="vector flow vs dense chain")
+
+
+@pytest.mark.parametrize("scale,N", [(0.02, 20), (2.0, 12), (30.0, 6)])
+def test_degrees_and_pieces_32(qoc, oracle, monkeypatch, scale, N):
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    n, K, E = 32, 2, 2
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, True, True, seed=int(10 * scale) + N, scale=scale)
+    F_ref, G_ref = oracle.ensemble_eval("CoherenceTransfer", A, B, Xi, Xt, wts, x, 1.0)
+    with qoc.GrapeEngine("CoherenceTransfer", A, B, Xi, Xt, wts, 1.0, N) as eng:
+        assert eng.info["expm_action"] == 1
+        F, G = eng.eval(x)
+    assert_parity(F, G, F_ref, G_ref, n, what=f"scale {scale}")
+
+
+def test_sparse_controls_32_and_selection(qoc, oracle, monkeypatch):
+    """Five-qubit Pauli controls (one non-zero per row), n x 1 states; chosen without the switch from the threshold on,
+    the dense chains below it."""
+    monkeypatch.delenv("GRAPE_ACTION", raising=False)
+    monkeypatch.setenv("GRAPE_ACTION_MIN", "40")
+    n, K, N = 32, 3, 30
+    rng = np.random.default_rng(5)
+    for E, want in ((6, 0), (48, 1)):
+        A, B, Xi, Xt, wts, x = _problem(n, K, N, E, False, True, True, seed=E)
+        B0 = np.array([0.5 * _pauli_string(rng, nq=5) for _ in range(K)])
+        B = np.array([B0] * E)
+        with qoc.GrapeEngine("UnitaryGate", A, B, Xi, Xt, wts, 1.0, N, member_results=True) as eng:
+            assert eng.info["expm_action"] == want and eng.info["rank_one_chain"] == want
+            F, G = eng.eval(x)
+            foms, grads = eng.member_results()
+        for k in (0, E - 1):
+            f_ref, g_ref = oracle.member_eval_rect(A[k], B[k], Xi[k], Xt[k], x, 1.0)[:2]
+            assert_parity(foms[k], grads[k], f_ref, g_ref, n, what=f"E = {E}, member {k}")
