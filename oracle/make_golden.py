@@ -216,6 +216,7 @@ def main(only=None):
         ("st_4x4_ens", None),
         ("vec_4x1_liou", wl.liouville_vec(1, 3, 9, 1.0)),                 # n x 1 states, Hermitian superoperators
         ("vec_16x1_diss", wl.liouville_vec(2, 2, 4, 1.0, dissipative=True)),   # n x 1, non-Hermitian (tile kernels)
+        ("vec_32x1_5q", "vec32"),                     # n x 1 states at n = 32 (two tiles per side): five-qubit operators of C5
         ("ug_4x4_bignorm", "bignorm"),                # dt |H| ~ 10-20: expm scaling + squaring path
         ("st_8x8_pairs", "rand8"),                    # tile kernels, two members per 16x16 tile
         ("ct_16x16_nonherm", "rand16"),               # tile kernels, non-Hermitian generator
@@ -240,6 +241,18 @@ def main(only=None):
         if w == "bignorm":                             # C3 operators, T = 40 over 10 slices
             w = wl.config("C3", E=2, N=10)
             w.T = 40.0
+            variants = (0,)
+        elif w == "vec32":                             # C5's drift and controls acting on one state vector per member
+            w = wl.config("C5", E=2, N=4)
+            w.T = 0.8
+            rng = np.random.default_rng(32)
+
+            def unit():
+                v = rng.standard_normal((32, 1)) + 1j * rng.standard_normal((32, 1))
+                return v / np.linalg.norm(v)
+            w.Xi = np.array([unit(), unit()])
+            w.Xt = np.array([unit(), unit()])
+            w.wts = np.array([0.4, 0.6])
             variants = (0,)
         elif isinstance(w, str):                       # seeded random problems for the MFMA tile kernels
             n = 8 if w == "rand8" else 16

@@ -284,3 +284,20 @@ def test_sparse_controls_32_and_selection(qoc, oracle, monkeypatch):
         for k in (0, E - 1):
             f_ref, g_ref = oracle.member_eval_rect(A[k], B[k], Xi[k], Xt[k], x, 1.0)[:2]
             assert_parity(foms[k], grads[k], f_ref, g_ref, n, what=f"E = {E}, member {k}")
+
+
+@pytest.mark.parametrize("name", ["vec_16x1_diss_v0", "vec_32x1_5q_v0"])
+def test_vector_flow_against_the_mpmath_fixtures(qoc, monkeypatch, name):
+    """The 50-digit fixtures with n x 1 states and shared controls (tests/golden, oracle/make_golden.py): 16 x 1 vec(rho)
+    under a dissipative Liouvillian, 32 x 1 under the five-qubit operators of C5."""
+    import os
+    from test_oracle_golden import load_case
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    c, A, B, Xi, Xt, wts, x, exp, _ = load_case(os.path.join(os.path.dirname(__file__), "golden", name + ".json"))
+    with qoc.GrapeEngine(c["sys_type"], A, B, Xi, Xt, wts, c["T"], c["N"], variant=c["variant"], member_results=True) as eng:
+        assert eng.info["expm_action"] == 1
+        F, G = eng.eval(x)
+        foms, grads = eng.member_results()
+    assert_parity(F, G, exp["F"], np.array(exp["G"]), c["n"], what="ensemble")
+    for k in range(c["E"]):
+        assert_parity(foms[k], grads[k], exp["member_F"][k], np.array(exp["member_g"][k]), c["n"], what=f"member {k}")
