@@ -20,6 +20,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 F = qoc.engine
 fails = 0
+n_action = 0
 t0 = time.time()
 for i in range(cases):
     n = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32], p=[.1, .08, .14, .06, .06, .08, .08, .08, .12, .06, .06, .08]))
@@ -30,7 +31,7 @@ for i in range(cases):
     variant = int(rng.integers(0, 2))
     herm = bool(rng.integers(0, 2))
     sparse = bool(rng.integers(0, 2))
-    states = str(rng.choice(["pure", "mixed", "rect"]))
+    states = str(rng.choice(["pure", "mixed", "rect", "vec"]))      # vec: n x 1 states (UnitaryGate), pure states otherwise
     flag = int(rng.choice([0, 0, F.FLAG_FORCE_GENERAL, F.FLAG_KEEP_COSTATES]))
     shared_ctrl = bool(rng.random() < 0.4)             # the SAME control operators for every member: the hoisted control sum
 
@@ -59,15 +60,18 @@ for i in range(cases):
     if shared_ctrl:
         B = np.broadcast_to(B[0], B.shape).copy()
         os.environ["GRAPE_HOIST"] = "1"                # (forced for the small ensembles of a soak run; n <= 4 has no such path)
+        # rank-one states, n = 9..32: the vector flow of action_thin.hip (forced likewise), or the flows it replaces
+        os.environ["GRAPE_ACTION"] = "1" if rng.random() < 0.7 else "0"
     else:
         os.environ.pop("GRAPE_HOIST", None)
+        os.environ.pop("GRAPE_ACTION", None)
 
     def vec(m=1):
         v = rng.standard_normal((n, m)) + 1j * rng.standard_normal((n, m))
         return v / np.linalg.norm(v)
     if sys_type == "UnitaryGate":
-        if states == "rect":
-            m = int(rng.integers(1, n))
+        if states in ("rect", "vec"):
+            m = int(rng.integers(1, n)) if states == "rect" else 1
             Xi = np.array([vec(m) for _ in range(E)])
             Xt = np.array([vec(m) for _ in range(E)])
         else:
@@ -85,8 +89,8 @@ for i in range(cases):
     x = rng.uniform(-1, 1, (K, N))
     T = float(rng.uniform(0.3, 2.0))
     what = (f"case {i}: n={n} K={K} N={N} E={E} {sys_type} v{variant} herm={herm} sparse={sparse} states={states} flag={flag} "
-            f"shared_ctrl={shared_ctrl}")
-    exact = rng.random() < 0.15 and N <= 33 and states != "rect"      # (the C oracle has no exact gradient for n x m states)
+            f"shared_ctrl={shared_ctrl} action={os.environ.get('GRAPE_ACTION', '-')}")
+    exact = rng.random() < 0.15 and N <= 33 and states not in ("rect", "vec")      # (the C oracle has no exact gradient for n x m states)
     if exact:                                             # exact gradient of the figure of merit / of the C1 functional
         objective = int(rng.integers(0, 2))
         try:
@@ -107,6 +111,7 @@ for i in range(cases):
             Fv, G = eng.eval(x)
             foms, grads = eng.member_results()
             info = eng.info
+        n_action += int(info.get("expm_action", 0))
         for k in range(E):
             # a member's whole gradient can be a near-zero (K = 1, N = 1: one entry passing through zero): the norm-wise
             # bar then has no scale left, so an absolute floor of a few ulp of the O(1) traces applies
@@ -122,5 +127,5 @@ for i in range(cases):
     except Exception as exc:                          # noqa: BLE001
         fails += 1
         print("FAIL", what, "->", repr(exc)[:300], flush=True)
-print(f"soak: {cases} cases, {fails} failures, {time.time() - t0:.1f} s (seed {seed})")
+print(f"soak: {cases} cases, {fails} failures, {n_action} of them through the vector flow, {time.time() - t0:.1f} s (seed {seed})")
 sys.exit(1 if fails else 0)
