@@ -88,6 +88,26 @@ GRAPE_DEV void ttrace_ab(double &zr, double &zi, const TMat<NT> &a, const TOp<NT
     zi = wave_sum(si);
 }
 
+// sum over all elements of A .* BT, both in D layout: tr(A B) with BT the dump of B^T
+template <int NT>
+GRAPE_DEV void ttrace_elem(double &zr, double &zi, const TMat<NT> &a, const TMat<NT> &bt)
+{
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double ar = a.re[I][J][r], ai = a.im[I][J][r];
+                const double br = bt.re[I][J][r], bi = bt.im[I][J][r];
+                sr = fma(ar, br, sr); sr = fma(-ai, bi, sr);
+                si = fma(ar, bi, si); si = fma(ai, br, si);
+            }
+    zr = wave_sum(sr);
+    zi = wave_sum(si);
+}
+
 template <int NT, int SAND>
 __global__ __launch_bounds__(256) void exact_tile_kernel(const TileParams p, int objective)
 {
@@ -108,11 +128,11 @@ __global__ __launch_bounds__(256) void exact_tile_kernel(const TileParams p, int
         tload(L, p.costates + ((size_t)k * N + t + 1) * TSZ, lane);
     else
         tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);       // Xt
-    // W1^T, W2^T (as A-layout register sets) and Phi
-    TOp<NT> W1T, W2T;
+    // W1, W2 and Phi
+    TMat<NT> W1, W2;
     double phr, phi;
     {
-        TMat<NT> V, W;
+        TMat<NT> V;
         TOp<NT> XA;
         tmm(V, P, X, img, lane);                              // V = P X
         to_a_layout(XA, X, img, lane);
@@ -122,16 +142,13 @@ __global__ __launch_bounds__(256) void exact_tile_kernel(const TileParams p, int
             tmm(Z, L, P, img, lane);                          // Z = L P
             tdot<NT, true>(phr, phi, Z, V);                   // Phi = tr(L' P X P') = tr((L P)' (P X))
             to_a_layout(ZA, Z, img, lane);
-            tmm_abh(W, XA, ZA);                               // W1 = X (L P)'
-            to_a_layout(W1T, W, img, lane);
-            tmul_tn<NT, true, false>(W, V, L);                // W2 = (P X)' L
-            to_a_layout(W2T, W, img, lane);
+            tmm_abh(W1, XA, ZA);                              // W1 = X (L P)'
+            tmul_tn<NT, true, false>(W2, V, L);               // W2 = (P X)' L
         } else {
             TOp<NT> LA;
             tdot<NT, true>(phr, phi, L, V);                   // Phi = tr(L' P X)
             to_a_layout(LA, L, img, lane);
-            tmm_abh(W, XA, LA);                               // W1 = X L'
-            to_a_layout(W1T, W, img, lane);
+            tmm_abh(W1, XA, LA);                              // W1 = X L'
         }
     }
     // generator (as in prop_tile_kernel) and the shared part of the Taylor evaluation
@@ -188,17 +205,11 @@ __global__ __launch_bounds__(256) void exact_tile_kernel(const TileParams p, int
     double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * N + 1);
     const double D2 = 1.0 / ((double)p.n * (double)p.n);
     const bool c1 = SAND || objective == 1;
-    for (int c = 0; c < K; ++c) {
-        TMat<NT> E, dA2, dT1, dA4, dU, dT2, dP, tmp;
-        tload(E, ops + (size_t)(1 + c) * TSZ, lane);
-#pragma unroll
-        for (int I = 0; I < NT; ++I)
-#pragma unroll
-            for (int J = 0; J < NT; ++J) {                    // E = (-i dt sc) B_c
-                const d4 br = E.re[I][J], bi = E.im[I][J];
-                E.re[I][J] = (dt * sc) * bi;
-                E.im[I][J] = (-dt * sc) * br;
-            }
+    // one derivative per slice in the direction W1 (and W2 where the sandwich needs it) instead of one per control:
+    // tr(DF_G[B] W) = tr(DF_G[W] B) for the polynomial F the evaluation above is (exact_grad.hip); a control costs a trace
+    auto frechet = [&](TMat<NT> &dP, const TMat<NT> &W) {
+        TMat<NT> E, dA2, dT1, dA4, dU, dT2, tmp;
+        tlin2(E, sc, W, 0.0, W);
         tmm(dA2, E, G, img, lane);
         tmm(tmp, G, E, img, lane);
         tacc(dA2, 1.0, tmp);
@@ -225,14 +236,28 @@ __global__ __launch_bounds__(256) void exact_tile_kernel(const TileParams p, int
                 Pq = t2;
             }
         }
+    };
+    TMat<NT> D1, D2m;
+    frechet(D1, W1);
+    const bool second = SAND && !p.herm_states;               // Hermitian X, L: W2 == W1
+    if (second)
+        frechet(D2m, W2);
+    for (int c = 0; c < K; ++c) {
+        TMat<NT> BT;
+        tload(BT, ops + (size_t)(1 + K + c) * TSZ, lane);     // B_c^T: tr(D B_c) = sum D .* B_c^T
         double ar, ai, dr, di;
-        ttrace_ab(ar, ai, dP, W1T);
-        dr = ar;
-        di = ai;
+        ttrace_elem(ar, ai, D1, BT);
+        dr = dt * ai;                                         // B'_c = (-i dt) B_c
+        di = -dt * ar;
         if (SAND) {
-            ttrace_ab(ar, ai, dP, W2T);
-            dr += ar;
-            di -= ai;
+            if (second) {
+                ttrace_elem(ar, ai, D2m, BT);
+                dr += dt * ai;
+                di -= -dt * ar;
+            } else {
+                dr += dr;                                     // + conj of the same number
+                di = 0.0;
+            }
         }
         const double g = c1 ? -2.0 * D2 * (phr * dr + phi * di) : 2.0 * (phr * dr - phi * di);
         if (lane == 0)

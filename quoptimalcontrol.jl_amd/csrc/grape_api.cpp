@@ -1404,6 +1404,7 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
         q.s_forced = c->cfg.expm_squarings;
         q.variant = c->cfg.variant;
         q.objective = c->cfg.objective;
+        q.herm_states = c->herm_states ? 1 : 0;
         HIP_TRY(c, grape::launch_exact_grad(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, q, stream));
     }
     if (timed) HIP_TRY(c, hipEventRecord(e1, stream));

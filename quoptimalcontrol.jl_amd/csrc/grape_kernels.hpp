@@ -192,6 +192,7 @@ struct ExactParams {
     int32_t S, CH;            // workspace decomposition: slice t = L*S + j of member k at ((k*S + j)*n*n + e)*CH + L
     int32_t s_forced, variant;
     int32_t objective;        // 0: the GRAPE figure of merit (fom_func), 1: C1 functional for every system type (ADGRAPE)
+    int32_t herm_states;      // every Xi, Xt Hermitian: the sandwich's two derivative directions coincide
 };
 hipError_t launch_exact_grad(int n, int sandwich, const ExactParams &p, hipStream_t stream);
 // the same for the tile family (exact_tile.hip): reads the debug flow's props / states / costates dumps of TileParams
