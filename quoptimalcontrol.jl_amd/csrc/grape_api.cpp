@@ -887,8 +887,9 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     // Rank-one states in the single-tile family (n = 9..16): X_t = v_t v_t' (sandwich, Xi = v0 v0', Xt = wT wT') or
     // X_t = v_t (left multiplication of n x 1 states) -- the chain runs on vectors (sweep_thin.hip).
     // GRAPE_FLAG_FORCE_GENERAL / KEEP_COSTATES / the exact gradient keep the dense chain.
-    // n = 17..32: there is no expm-based vector chain; rank-one states count only where the vector flow of action_thin.hip
-    // takes them (shared controls, an ensemble that fills the device -- decided right here), else the dense chains stay.
+    // n = 5..8 (two members per tile) and n = 17..32: there is no expm-based vector chain; rank-one states count only where
+    // the vector flow of action_thin.hip takes them (shared controls, an ensemble that fills the device -- decided right
+    // here), else the dense chains stay.
     std::vector<double> vecs;
     const size_t VS = 16 * (size_t)c->NT;                    // complex entries of a (zero padded) vector
     const char *act_env = std::getenv("GRAPE_ACTION");
@@ -897,10 +898,11 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         ctrl_shared = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
     const bool act_forced = act_env && act_env[0] == '1';
     const bool act_ok = ctrl_shared && !(act_env && act_env[0] == '0') && c->cfg.n_slices <= 4096;   // (per-slice plans live in LDS)
-    bool thin = c->family == 1 && !c->pack2 && c->cfg.gradient != GRAPE_GRADIENT_EXACT &&
+    bool thin = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT &&
                 !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) && !env_on("GRAPE_NO_THIN");
-    if (thin && c->NT == 2)
-        thin = act_ok && (act_forced || (long)c->EU >= act_min_units(c));
+    const bool act_only = c->NT == 2 || c->pack2;            // n = 5..8 (two members per tile) and n = 17..32: vector flow or dense chains
+    if (thin && act_only)
+        thin = act_ok && (act_forced || (long)E >= act_min_units(c));
     if (thin) {
         const bool sand = c->cfg.sys_type != GRAPE_UNITARY_GATE;
         vecs.assign(E * 4 * VS, 0.0);
@@ -1096,7 +1098,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // fill the device (the chunked flows of small ensembles keep the expm kernel: they need the chunk PRODUCTS);
         // GRAPE_ACTION=0 keeps the expm + chain kernels, GRAPE_ACTION=1 forces the vector flow for any ensemble size.
         bool act = thin && act_ok;
-        if (act && c->NT == 1 && !act_forced && (c->tp_C || (long)c->EU < act_min_units(c))) act = false;
+        if (act && !act_only && !act_forced && (c->tp_C || (long)c->EU < act_min_units(c))) act = false;
         c->action = act;
         if (act) {
             c->tp_C = c->tp_S = c->tp_G = c->tp_g = 0;
@@ -1272,6 +1274,10 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.gc = c->d_gc;
     p.gcn = c->d_gcn;
     p.action = c->action ? 1 : 0;
+    if (c->action) {                                         // the vector flow works on members, whatever the tile packing
+        p.E = c->cfg.n_ensemble;
+        p.pack2 = 0;
+    }
     p.act_a = c->d_act_a;
     p.act_an = c->d_act_an;
     p.act_b = c->d_act_b;
