@@ -304,3 +304,19 @@ def test_vector_flow_against_the_mpmath_fixtures(qoc, monkeypatch, name):
     assert_parity(F, G, exp["F"], np.array(exp["G"]), c["n"], what="ensemble")
     for k in range(c["E"]):
         assert_parity(foms[k], grads[k], exp["member_F"][k], np.array(exp["member_g"][k]), c["n"], what=f"member {k}")
+
+
+def test_device_lbfgs_on_the_vector_flow(qoc, monkeypatch):
+    """grape_lbfgs (Hager-Zhang, batched ladder) drives the vector flow like any other context: C4's operators at test
+    size; F decreases monotonically and the returned point evaluates to the reported minimum."""
+    from quoptimalcontrol_jl_amd import workloads
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    w = workloads.config("C4", E=5, N=80)
+    for ls in ("hagerzhang", "ladder"):
+        with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, max_batch=4) as eng:
+            assert eng.info["expm_action"] == 1
+            F0, _ = eng.eval(0.2 * w.x)
+            x_min, info = eng.lbfgs(0.2 * w.x, iterations=12, line_search=ls)
+            F_min, _ = eng.eval(x_min)
+        assert info["iterations"] >= 3 and F_min < F0 - 1e-6          # (a nearly flat landscape: 1 - overlap^2 of generic states)
+        assert abs(F_min - info["minimum"]) <= 1e-12
