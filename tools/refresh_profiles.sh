@@ -19,18 +19,24 @@ stats() {   # name, env, bench args...
 stats C3_E1024 GRAPE_X=0 --steps 400 --warmup 50    # (a 36-launch run averages the cold first launches in: 78 us)
 stats C4_E1024 GRAPE_X=0 --config C4 --steps 40 --warmup 5
 stats C4dense_E1024 GRAPE_NO_THIN=1 --config C4 --steps 40 --warmup 5
+stats C4expm_E1024 GRAPE_ACTION=0 --config C4 --steps 40 --warmup 5      # the MFMA expm + vector chain the vector flow replaces at C4
 stats C5_E4096 GRAPE_X=0 --config C5 --steps 2 --warmup 1
 stats C5x1 GRAPE_X=0 --config C5 --ensemble 1 --steps 200 --warmup 20     # single problems: the chunked time axis
 stats C4x1 GRAPE_X=0 --config C4 --ensemble 1 --steps 200 --warmup 20
 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C3" > "$OUT/pmc_C3.log" 2>&1
 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C4" --config C4 > "$OUT/pmc_C4.log" 2>&1
 GRAPE_NO_THIN=1 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C4dense" --config C4 > "$OUT/pmc_C4dense.log" 2>&1
+GRAPE_ACTION=0 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C4expm" --config C4 > "$OUT/pmc_C4expm.log" 2>&1
 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C5" --config C5 --steps 2 --warmup 1 > "$OUT/pmc_C5.log" 2>&1
 cd "$ROOT"
 python3 tools/phase_profile.py --config C3 > "$OUT/C3_phase_stamps.json" 2> /dev/null
 python3 tools/group_overhead.py > "$OUT/group_overhead_C3.json" 2> /dev/null
 python3 tools/group_overhead.py --ensemble 128 > "$OUT/group_overhead_C3_E128.json" 2> /dev/null
 ./tools/ubench/pipe_mix > "$OUT/pipe_mix.txt" 2>&1
+./tools/ubench/dpp_fmac > "$OUT/dpp_fmac.txt" 2>&1
+( python3 tools/vec32_bench.py 1024 2000; python3 tools/vec32_bench.py 4096 2000 ) > "$OUT/vec32_bench.json" 2> /dev/null
+python3 tools/exact_time.py > "$OUT/exact_time.txt" 2> /dev/null
+for E in 128 256 320 512 1024 2048 4096; do for m in 1 0; do echo "E=$E GRAPE_ACTION=$m $(GRAPE_ACTION=$m python3 bench.py --config C4 --ensemble $E --steps 20 --warmup 5 --blocks 2 --no-extra --no-cpu-baseline 2> /dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "evals/s", round(d["ms_per_step"],3), "ms")')"; done; done > "$OUT/C4_flow_crossover.txt"
 for seed in 31 32 33 34 35 36 37 38; do python3 tools/soak.py 1500 $seed 2>&1 | tail -1; done > "$OUT/soak.txt"
 python3 tools/soak_api.py 600 5 2>&1 | tail -1 >> "$OUT/soak.txt"
 python3 tools/parity_report.py > "$OUT/parity.json" 2> "$OUT/parity.log"
