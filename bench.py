@@ -325,6 +325,35 @@ def run_extra_config(qoc, name, dev_index, steps, warmup):
                                  committed_mfma(f"{name}_E{w.E}"))}
 
 
+def shard_overheads(qoc, cfg_name, dev_index, sizes=(512, 256, 128)):
+    """What a GPU of an N-GPU strong-scaling run does per step, timed on this one: the config's ensemble cut to the shard
+    sizes of 2 / 4 / 8 GPUs, host -> host grape_eval, next to the shard's sweep-kernel time.  fixed_overhead_us = the part
+    that does not shrink with the shard (x upload, launches, the reduce, publication, host turnaround): an N-GPU step
+    costs at least the largest shard's ms_per_step plus the all-reduce, whatever the kernels do."""
+    import numpy as np
+    out = {}
+    for E in sizes:
+        w = qoc.workloads.config(cfg_name, E=E)
+        with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, device=dev_index,
+                             flags=qoc.engine.FLAG_TIME_KERNELS) as eng:
+            xf = np.ascontiguousarray(w.x.T)
+            call = eng.bind_eval(xf, np.empty_like(xf))
+            for _ in range(20):
+                call()
+            clock_ramp(call, 0.15)
+            eng.kernel_time(reset=True)
+            steps = 300
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                call()
+            el = time.perf_counter() - t0
+            tot_ms, _ = eng.kernel_samples()
+        k_us = float(np.mean(tot_ms) * 1e3)                  # HIP events around the sweep kernel(s) of an evaluation
+        out[f"E{E}"] = {"ms_per_step": 1e3 * el / steps, "sweep_kernel_us": k_us,
+                        "fixed_overhead_us": 1e6 * el / steps - k_us}
+    return out
+
+
 def lbfgs_rates(qoc, dev_index):
     """The library's device-resident L-BFGS (grape_lbfgs, Hager-Zhang line search as Optim's LBFGS()) next to the
     host-driven loop (SciPy L-BFGS-B calling grape_eval, the stand-in for Optim.jl on the host) on two shapes: the
@@ -621,6 +650,10 @@ def main():
             out["extra"]["lbfgs"] = lbfgs_rates(qoc, dev_index)
         except Exception as exc:                   # noqa: BLE001 -- an extra must not kill the headline
             out["extra"]["lbfgs"] = {"error": repr(exc)}
+        try:
+            out["extra"]["shard_fixed_overhead"] = shard_overheads(qoc, args.config, dev_index)
+        except Exception as exc:                   # noqa: BLE001
+            out["extra"]["shard_fixed_overhead"] = {"error": repr(exc)}
     if rank == 0 and world == 1 and not args.no_extra and args.extra_configs:
         out["extra_configs"] = []
         for name in [s for s in args.extra_configs.split(",") if s and s != args.config]:

@@ -3,7 +3,10 @@
 //   (1) semantics: src0 of lane l is read from lane 16 (l >> 4) + n of the same 16-lane row;
 //   (2) issue rate: cycles per instruction for (a) one dependent chain, (b) 2 / 4 independent accumulators,
 //       (c) the complex matrix-vector pattern of action_thin_kernel (32 FMACs into 2 + 2 accumulators),
-//       each at 1 and 2 waves per SIMD, beside plain v_fma_f64.
+//       each at 1, 2 and 4 waves per SIMD, beside plain v_fma_f64;
+//
+//   (3) the same with only lanes 0..31 active: idle passes are NOT skipped (same time).
+// The tick of s_memtime is not the shader clock: read the numbers relative to one another (peak = the 4-waves row).
 //
 // build: hipcc -O3 --offload-arch=gfx950 -o dpp_fmac dpp_fmac.hip ; run: ./dpp_fmac
 #include <hip/hip_runtime.h>
