@@ -174,8 +174,9 @@ typedef struct grape_info {
                                       member (B_gens = k -> [Sx, Sy], test/setup_tests.jl:32) in the n = 5..32 family:
                                       the control sum sum_c x[c,t] B_c of src/timeevolution.jl:105-107 is formed once per
                                       slice and evaluation instead of once per (member, slice) */
-    int32_t expm_action;           /* 1: rank-one states (rank_one_chain) AND member-invariant control operators on an
-                                      ensemble that fills the device: exp(G_t) is applied to the two chains' vectors by its
+    int32_t expm_action;           /* 1: rank-one states (rank_one_chain) on an ensemble that fills the device, with control
+                                      operators shared by the members (n = 5..32) or up to six of the members' own
+                                      (n <= 16): exp(G_t) is applied to the two chains' vectors by its
                                       Taylor series (matrix-vector products only); no propagator is formed, so
                                       grape_get_trajectory has none to return -- GRAPE_FLAG_KEEP_COSTATES keeps the dense flow */
 } grape_info;

@@ -130,6 +130,32 @@ GRAPE_DEV void act_make_plan(unsigned short *s_plan, const double *__restrict__ 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// the same for per-member control operators: |Gc|  <=  sum_c |x[c,t]| bn[c]
+GRAPE_DEV void act_make_plan_own(unsigned short *s_plan, const double *__restrict__ x, const double *__restrict__ bn, double an,
+                                 int K, int N, int forced, int lane)
+{
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        const int i = min(i0 + lane, N - 1);
+        double f = 0.0, b = 0.0;
+        for (int c = 0; c < K; ++c) {
+            f = fma(fabs(x[c + (size_t)i * K]), bn[c], f);
+            b = fma(fabs(x[c + (size_t)(N - 1 - i) * K]), bn[c], b);
+        }
+        double th = an + (f > b || f != f ? f : b);            // NaN-propagating maximum
+        int pieces = 1;
+        if (forced >= 0)
+            pieces = 1 << min(forced, 10);
+        else if (th > kActPiece)
+            pieces = (int)fmin(ceil(th / kActPiece), (double)kActMaxPieces);
+        if (pieces != 1)
+            th /= (double)pieces;
+        s_plan[i] = (unsigned short)(min(act_degree(th), 24) | (pieces << 5));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // rows 1 and 3 (h = 1): rotate by 8 lanes inside the row; rows 0 and 2 keep their value
 GRAPE_DEV double rot8_odd_rows(double u)
 {
@@ -192,7 +218,12 @@ __global__ __launch_bounds__(256) void action_rows_kernel(const TileParams p)
 // Workgroups of kActWaves members (one wave each, no communication): the launcher sizes the dynamic LDS so that exactly as
 // many workgroups fit a compute unit as an even spread needs.  With one-wave workgroups the dispatcher doubled up waves
 // on some SIMDs while others idled (1024 members: 1.99 ms, 768 and fewer: 1.33 ms).
+// SHARED = false: the members have their own control operators (amplitude-scaled controls of a robustness ensemble, ...), at
+// most kActOwnK of them: the lane keeps its half rows of every B'_kc in registers (16 per control) and forms the control sum
+// itself, in the same order; no pre-pass, the norm bound is sum_c |x_c| |B'_kc|.
 constexpr int kActWaves = 4;
+constexpr int kActOwnK = 6;
+template <bool SHARED>
 __global__ __launch_bounds__(64 * kActWaves) void action_thin_kernel(const TileParams p)
 {
     const int lane = threadIdx.x & 63, r = lane & 15, d = lane >> 5, h = (lane >> 4) & 1;
@@ -223,16 +254,35 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin_kernel(const TileP
     }
     if (h == 0)
         rec[d ? N : 0] = make_double2(vr, vi);
+    const int K = p.K;
+    const double *__restrict__ xy = p.x + (size_t)y * N * K;      // this control array, x[c + t K]
     double2 gq[8];
-    {
+    double br[kActOwnK][8], bi[kActOwnK][8], xq[kActOwnK];       // (!SHARED) own half rows of B'_kc; the next slice's controls
+    if (SHARED) {
         const double2 *__restrict__ src = Gy + (size_t)(d ? N - 1 : 0) * 512;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             gq[j] = src[j];
+    } else {
+        const double2 *__restrict__ Bk = p.act_b + (size_t)k * K * 512 + off;
+        const double *__restrict__ xs = xy + (size_t)(d ? N - 1 : 0) * K;
+#pragma unroll
+        for (int c = 0; c < kActOwnK; ++c) {
+            xq[c] = c < K ? xs[c] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double2 b = c < K ? Bk[(size_t)c * 512 + j] : make_double2(0.0, 0.0);
+                br[c][j] = b.x;
+                bi[c][j] = b.y;
+            }
+        }
     }
     extern __shared__ unsigned short s_plan_all[];
     unsigned short *s_plan = s_plan_all + (size_t)wave * N;       // this wave's own plan: no workgroup barrier anywhere
-    act_make_plan(s_plan, gn, an, N, p.s_forced, lane);
+    if (SHARED)
+        act_make_plan(s_plan, gn, an, N, p.s_forced, lane);
+    else
+        act_make_plan_own(s_plan, xy, p.act_bn + (size_t)k * K, an, K, N, p.s_forced, lane);
     // loop state: the vector as the products read it, x[(r + 8h) mod 16] (in the h = 0 rows that IS element r), and the
     // component this row updates (h = 0: real part, h = 1: imaginary part of element r)
     double xr = rot8_odd_rows(vr), xi = rot8_odd_rows(vi);
@@ -240,17 +290,42 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin_kernel(const TileP
     unsigned plan = s_plan[0];
     for (int i = 0; i < N; ++i) {
         double mr[8], mi[8];
+        const int tn = d ? max(N - 2 - i, 0) : min(i + 1, N - 1);
+        if (SHARED) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {                             // G = Gc + A' (A last, timeevolution.jl:108)
-            mr[j] = gq[j].x + ar[j];
-            mi[j] = gq[j].y + ai[j];
-        }
-        {
-            const int tn = d ? max(N - 2 - i, 0) : min(i + 1, N - 1);
+            for (int j = 0; j < 8; ++j) {                         // G = Gc + A' (A last, timeevolution.jl:108)
+                mr[j] = gq[j].x + ar[j];
+                mi[j] = gq[j].y + ai[j];
+            }
             const double2 *__restrict__ src = Gy + (size_t)tn * 512;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 gq[j] = src[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                         // (0 + B_1 x_1) first, A last
+                mr[j] = br[0][j] * xq[0];
+                mi[j] = bi[0][j] * xq[0];
+            }
+#pragma unroll
+            for (int c = 1; c < kActOwnK; ++c)
+                if (c < K) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        mr[j] = fma(br[c][j], xq[c], mr[j]);
+                        mi[j] = fma(bi[c][j], xq[c], mi[j]);
+                    }
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                mr[j] += ar[j];
+                mi[j] += ai[j];
+            }
+            const double *__restrict__ xs = xy + (size_t)tn * K;
+#pragma unroll
+            for (int c = 0; c < kActOwnK; ++c)
+                if (c < K)
+                    xq[c] = xs[c];
         }
         const int m = __builtin_amdgcn_readfirstlane(plan & 31), pieces = __builtin_amdgcn_readfirstlane(plan >> 5);
         plan = s_plan[min(i + 1, N - 1)];
@@ -422,7 +497,7 @@ __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
     for (int c = 0; c < K; ++c) {
         // (constant address space: the operators are read through the scalar cache, a row per wait)
         const __attribute__((address_space(4))) unsigned long long *Bc =
-            (const __attribute__((address_space(4))) unsigned long long *)(uintptr_t)(p.act_bf + (size_t)c * NB * NB);
+            (const __attribute__((address_space(4))) unsigned long long *)(uintptr_t)(p.act_bf + ((size_t)(p.act_shared ? 0 : k) * K + c) * NB * NB);
         double a_r = 0.0, a_i = 0.0, b_r = 0.0, b_i = 0.0;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -503,9 +578,12 @@ __global__ __launch_bounds__(64) void action_forms_sparse_kernel(const TileParam
         if (NEEDB)
             s_w[i * 64 + lane] = b;
     }
-    for (int q = lane; q < K * NB * R; q += 64) {
-        s_tab[q] = p.act_bs[q];
-        s_off[q] = p.act_bo[q];
+    {
+        const size_t sel = (size_t)(p.act_shared ? 0 : k) * K * NB * R;      // per-member lists when the controls are the member's own
+        for (int q = lane; q < K * NB * R; q += 64) {
+            s_tab[q] = p.act_bs[sel + q];
+            s_off[q] = p.act_bo[sel + q];
+        }
     }
     double s_re = 0.0, s_im = 0.0;                                // s = w_N' v_N (uniform)
 #pragma unroll
@@ -579,7 +657,10 @@ static void launch_forms_sparse(int sandwich, const TileParams &p, dim3 grid, si
 template <int NB>
 static hipError_t launch_action_nb(int sandwich, const TileParams &p, hipStream_t stream)
 {
-    hipLaunchKernelGGL((action_rows_kernel<NB>), dim3(p.N, p.n_x), dim3(256), 0, stream, p);
+    if (p.act_shared)
+        hipLaunchKernelGGL((action_rows_kernel<NB>), dim3(p.N, p.n_x), dim3(256), 0, stream, p);
+    else if (NB != 16 || p.K > kActOwnK)
+        return hipErrorInvalidConfiguration;                      // (the host layer keeps such ensembles on the expm flow)
     const size_t plan_bytes = sizeof(unsigned short) * (size_t)p.N * kActWaves;
     if (plan_bytes > 64 * 1024)                                   // (the host layer keeps such pulses on the expm flow)
         return hipErrorInvalidConfiguration;
@@ -591,7 +672,7 @@ static hipError_t launch_action_nb(int sandwich, const TileParams &p, hipStream_
     lds = lds > 1024 ? (lds - 512) & ~(size_t)255 : lds;
     if (lds < plan_bytes)
         lds = plan_bytes;
-    auto kern = NB == 16 ? action_thin_kernel : action_thin2_kernel;
+    auto kern = NB == 16 ? (p.act_shared ? action_thin_kernel<true> : action_thin_kernel<false>) : action_thin2_kernel;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)

@@ -104,6 +104,8 @@ struct grape_ctx {
     double2 *d_act_a = nullptr, *d_act_b = nullptr, *d_act_bf = nullptr, *d_act_g = nullptr;
     double *d_act_an = nullptr, *d_act_gn = nullptr;
     int act_R = 0;                             // sparse rows of the control operators (0: dense forms kernel)
+    bool act_shared = true;                    // one set of control operators for every member
+    double *d_act_bn = nullptr;                // per-member controls: [E][K] norm bounds
     double2 *d_act_bs = nullptr;
     int32_t *d_act_bo = nullptr;                   // [B][N] |Gc_t|_1 bound / theta8
     size_t states_bytes = 0;                   // size of d_states (vector records are smaller than state dumps)
@@ -322,7 +324,7 @@ static void free_all(grape_ctx *c)
     (void)hipFree(c->d_x_bar);
     (void)hipFree(c->d_ha); (void)hipFree(c->d_ha_norm); (void)hipFree(c->d_gc); (void)hipFree(c->d_gcn);
     (void)hipFree(c->d_act_a); (void)hipFree(c->d_act_b); (void)hipFree(c->d_act_bf); (void)hipFree(c->d_act_g);
-    (void)hipFree(c->d_act_an); (void)hipFree(c->d_act_gn); (void)hipFree(c->d_act_bs); (void)hipFree(c->d_act_bo);
+    (void)hipFree(c->d_act_an); (void)hipFree(c->d_act_gn); (void)hipFree(c->d_act_bs); (void)hipFree(c->d_act_bo); (void)hipFree(c->d_act_bn);
     delete c;
 }
 
@@ -897,7 +899,9 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     for (size_t k = 1; k < E && ctrl_shared; ++k)
         ctrl_shared = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
     const bool act_forced = act_env && act_env[0] == '1';
-    const bool act_ok = ctrl_shared && !(act_env && act_env[0] == '0') && c->cfg.n_slices <= 4096;   // (per-slice plans live in LDS)
+    // shared controls, or -- n <= 16 -- the members' own (at most six: a lane keeps its half rows of them in registers)
+    const bool act_ok = (ctrl_shared || (c->NT == 1 && K <= 6)) && !(act_env && act_env[0] == '0') &&
+                        c->cfg.n_slices <= 4096;             // (per-slice plans live in LDS)
     bool thin = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT &&
                 !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) && !env_on("GRAPE_NO_THIN");
     const bool act_only = c->NT == 2 || c->pack2;            // n = 5..8 (two members per tile) and n = 17..32: vector flow or dense chains
@@ -1105,12 +1109,15 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             const double dt = c->cfg.duration / c->cfg.n_slices;
             const int nd = c->cfg.n;
             const size_t VV = VS * VS;
-            std::vector<double> aa, an, bb, bf;
+            c->act_shared = ctrl_shared;
+            const size_t nb = ctrl_shared ? 1 : E;               // sets of control operators
+            std::vector<double> aa, an, bb, bf, bn;
             try {
                 aa.assign(2 * E * 2 * VV, 0.0);
                 an.assign(E, 0.0);
-                bb.assign(2 * K * 2 * VV, 0.0);
-                bf.assign(2 * K * VV, 0.0);
+                bb.assign(2 * nb * K * 2 * VV, 0.0);
+                bf.assign(2 * nb * K * VV, 0.0);
+                bn.assign(nb * K, 0.0);
             } catch (...) {
                 return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: out of host memory");
             }
@@ -1136,38 +1143,37 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             };
             for (size_t k = 0; k < E; ++k)
                 an[k] = images(aa.data() + 2 * k * 2 * VV, A + 2 * k * nn);
-            for (size_t cc = 0; cc < K; ++cc) {
-                (void)images(bb.data() + 2 * cc * 2 * VV, B + 2 * cc * nn);
-                for (int col = 0; col < nd; ++col)
-                    for (int row = 0; row < nd; ++row) {
-                        bf[2 * (cc * VV + row * VS + col)] = B[2 * (cc * nn + row + (size_t)nd * col)];
-                        bf[2 * (cc * VV + row * VS + col) + 1] = B[2 * (cc * nn + row + (size_t)nd * col) + 1];
-                    }
-            }
-            // sparse rows (Pauli-type controls, Liouville-space commutators): (value, column) lists for the forms kernel
-            int rmax = 0;
-            for (size_t cc = 0; cc < K; ++cc)
+            int rmax = 0;                                        // most non-zeros in a row of any control operator
+            for (size_t q = 0; q < nb * K; ++q) {                // q = k K + c (k = 0 only when the controls are shared)
+                const double *Bq = B + 2 * q * nn;
+                bn[q] = images(bb.data() + 2 * q * 2 * VV, Bq);
                 for (int row = 0; row < nd; ++row) {
                     int cnt = 0;
-                    for (int col = 0; col < nd; ++col)
-                        if (bf[2 * (cc * VV + row * VS + col)] != 0.0 || bf[2 * (cc * VV + row * VS + col) + 1] != 0.0) ++cnt;
+                    for (int col = 0; col < nd; ++col) {
+                        const double re = Bq[2 * (row + (size_t)nd * col)], im = Bq[2 * (row + (size_t)nd * col) + 1];
+                        bf[2 * (q * VV + row * VS + col)] = re;
+                        bf[2 * (q * VV + row * VS + col) + 1] = im;
+                        if (re != 0.0 || im != 0.0) ++cnt;
+                    }
                     rmax = std::max(rmax, cnt);
                 }
+            }
+            // sparse rows (Pauli-type controls, Liouville-space commutators): (value, column) lists for the forms kernel
             c->act_R = env_on("GRAPE_FORMS_DENSE") ? 0 : rmax <= 0 ? 1 : rmax <= 4 ? rmax : rmax <= 6 ? 6 : 0;
             if (c->act_R) {
                 const size_t R = (size_t)c->act_R;
-                std::vector<double> bs(2 * K * VS * R, 0.0);
-                std::vector<int32_t> bo(K * VS * R, 0);
-                for (size_t cc = 0; cc < K; ++cc)
+                std::vector<double> bs(2 * nb * K * VS * R, 0.0);
+                std::vector<int32_t> bo(nb * K * VS * R, 0);
+                for (size_t q = 0; q < nb * K; ++q)
                     for (int row = 0; row < nd; ++row) {
-                        size_t q = (cc * VS + row) * R;
+                        size_t o = (q * VS + row) * R;
                         for (int col = 0; col < nd; ++col) {
-                            const double re = bf[2 * (cc * VV + row * VS + col)], im = bf[2 * (cc * VV + row * VS + col) + 1];
+                            const double re = bf[2 * (q * VV + row * VS + col)], im = bf[2 * (q * VV + row * VS + col) + 1];
                             if (re == 0.0 && im == 0.0) continue;
-                            bs[2 * q] = re;
-                            bs[2 * q + 1] = im;
-                            bo[q] = 1024 * col;
-                            ++q;
+                            bs[2 * o] = re;
+                            bs[2 * o + 1] = im;
+                            bo[o] = 1024 * col;
+                            ++o;
                         }
                     }
                 (void)hipFree(c->d_act_bs); c->d_act_bs = nullptr;       // (R may change between uploads)
@@ -1179,12 +1185,17 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             }
             const size_t g_elems = (size_t)c->B * c->cfg.n_slices * 2 * VV;
             if (!c->d_act_a) {
-                c->bytes += sizeof(double2) * (E * 2 * VV + K * 3 * VV + g_elems) + sizeof(double) * (E + (size_t)c->B * c->cfg.n_slices);
+                c->bytes += sizeof(double2) * (E * 2 * VV + g_elems) + sizeof(double) * (E + (size_t)c->B * c->cfg.n_slices);
                 HIP_TRY(c, hipMalloc((void **)&c->d_act_a, sizeof(double2) * E * 2 * VV));
             }
             if (!c->d_act_an) HIP_TRY(c, hipMalloc((void **)&c->d_act_an, sizeof(double) * E));
-            if (!c->d_act_b) HIP_TRY(c, hipMalloc((void **)&c->d_act_b, sizeof(double2) * K * 2 * VV));
-            if (!c->d_act_bf) HIP_TRY(c, hipMalloc((void **)&c->d_act_bf, sizeof(double2) * K * VV));
+            (void)hipFree(c->d_act_b); c->d_act_b = nullptr;             // (one set or E sets: may change between uploads)
+            (void)hipFree(c->d_act_bf); c->d_act_bf = nullptr;
+            (void)hipFree(c->d_act_bn); c->d_act_bn = nullptr;
+            HIP_TRY(c, hipMalloc((void **)&c->d_act_b, sizeof(double) * bb.size()));
+            HIP_TRY(c, hipMalloc((void **)&c->d_act_bf, sizeof(double) * bf.size()));
+            HIP_TRY(c, hipMalloc((void **)&c->d_act_bn, sizeof(double) * bn.size()));
+            HIP_TRY(c, hipMemcpy(c->d_act_bn, bn.data(), sizeof(double) * bn.size(), hipMemcpyHostToDevice));
             if (!c->d_act_g) HIP_TRY(c, hipMalloc((void **)&c->d_act_g, sizeof(double2) * g_elems));
             if (!c->d_act_gn) HIP_TRY(c, hipMalloc((void **)&c->d_act_gn, sizeof(double) * (size_t)c->B * c->cfg.n_slices));
             HIP_TRY(c, hipMemcpy(c->d_act_a, aa.data(), sizeof(double) * aa.size(), hipMemcpyHostToDevice));
@@ -1285,6 +1296,8 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.act_g = c->d_act_g;
     p.act_gn = c->d_act_gn;
     p.act_R = c->action ? c->act_R : 0;
+    p.act_shared = c->act_shared ? 1 : 0;
+    p.act_bn = c->d_act_bn;
     p.act_bs = c->d_act_bs;
     p.act_bo = c->d_act_bo;
     return p;

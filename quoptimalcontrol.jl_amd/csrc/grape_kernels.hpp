@@ -141,6 +141,9 @@ struct TileParams {
     int32_t action;           // set by the host layer
     const double2 *act_a;     // [unit][2][256] row-major [A'_k | A'_k'] (conjugate transpose), zero padded to 16 x 16
     const double *act_an;     // [unit] max(|A'_k|_1, |A'_k|_inf)
+    int32_t act_shared;       // 1: one set of control operators for every member (pre-pass forms the control sums); 0: per member
+                              //    (n <= 16, K <= 6): act_b / act_bf / act_bs / act_bo carry a leading member index
+    const double *act_bn;     // (per-member controls) [unit][K] max(|B'_kc|_1, |B'_kc|_inf)
     const double2 *act_b;     // [K][2][256] row-major [B'_c | B'_c'], B'_c = (-i dt) B_c
     const double2 *act_bf;    // [K][256] row-major B_c (the gradient's bilinear forms)
     int32_t act_R;            // > 0: every row of every B_c has at most act_R non-zeros (1, 2, 3, 4 or 6) -- the forms read

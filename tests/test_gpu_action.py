@@ -125,7 +125,45 @@ def test_chosen_for_ensembles_that_fill_the_device(qoc, oracle, monkeypatch):
         assert abs(F - float(np.dot(wts, foms))) <= 1e-12 * max(1.0, abs(F))
 
 
-def test_per_member_controls_keep_the_expm_flow_and_uploads_switch(qoc, oracle, monkeypatch):
+OWN_CASES = [  # n, K, N, E, sys_type, Hermitian generators, Hermitian controls -- every member its own control operators
+    (16, 4, 3, 3, "CoherenceTransfer", False, True), (16, 1, 1, 2, "StateTransfer", True, True),
+    (12, 6, 33, 2, "CoherenceTransfer", False, False), (9, 2, 100, 5, "StateTransfer", False, True),
+    (16, 3, 64, 4, "UnitaryGate", False, False), (13, 5, 7, 3, "UnitaryGate", True, True),
+    (7, 2, 20, 3, "CoherenceTransfer", False, True), (16, 2, 130, 66, "CoherenceTransfer", False, True),
+]
+
+
+@pytest.mark.parametrize("n,K,N,E,sys_type,herm_gen,herm_ctrl", OWN_CASES)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_vector_flow_with_per_member_controls(qoc, oracle, monkeypatch, n, K, N, E, sys_type, herm_gen, herm_ctrl, variant):
+    """Members with their own control operators (n <= 16, at most six): the lane keeps its rows of them and forms the
+    control sum itself -- no pre-pass; seven and more controls stay on the expm flow."""
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    sand = sys_type != "UnitaryGate"
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sand, herm_gen, herm_ctrl, seed=5 * n + N + K, shared=False)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.1, variant=variant,
+                                                             per_member=True)
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.1, N, variant=variant, member_results=True) as eng:
+        assert eng.info["expm_action"] == 1 and eng.info["hoisted_controls"] == 0
+        F, G = eng.eval(x)
+        foms, grads = eng.member_results()
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k}")
+    assert_parity(F, G, F_ref, G_ref, n, what="ensemble")
+
+
+def test_many_per_member_controls_keep_the_expm_flow(qoc, oracle, monkeypatch):
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    n, K, N, E = 16, 7, 12, 2
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, False, True, seed=2, shared=False)
+    F_ref, G_ref = oracle.ensemble_eval("CoherenceTransfer", A, B, Xi, Xt, wts, x, 1.0)
+    with qoc.GrapeEngine("CoherenceTransfer", A, B, Xi, Xt, wts, 1.0, N) as eng:
+        assert eng.info["rank_one_chain"] == 1 and eng.info["expm_action"] == 0
+        F, G = eng.eval(x)
+    assert_parity(F, G, F_ref, G_ref, n, what="K = 7, own controls")
+
+
+def test_uploads_switch_between_shared_and_per_member_controls(qoc, oracle, monkeypatch):
     monkeypatch.setenv("GRAPE_ACTION", "1")
     n, K, N, E = 16, 3, 30, 3
     A, B, Xi, Xt, wts, _ = _problem(n, K, N, E, True, False, True, seed=1)
@@ -133,7 +171,7 @@ def test_per_member_controls_keep_the_expm_flow_and_uploads_switch(qoc, oracle, 
         for shared in (True, False, True):
             A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, False, True, seed=11, shared=shared)
             eng.set_operators(A, B, Xi, Xt, wts)
-            assert eng.info["rank_one_chain"] == 1 and eng.info["expm_action"] == (1 if shared else 0)
+            assert eng.info["rank_one_chain"] == 1 and eng.info["expm_action"] == 1
             F, G = eng.eval(x)
             F_ref, G_ref = oracle.ensemble_eval("CoherenceTransfer", A, B, Xi, Xt, wts, x, 1.0)
             assert_parity(F, G, F_ref, G_ref, n, what=f"shared={shared}")
@@ -320,3 +358,21 @@ def test_device_lbfgs_on_the_vector_flow(qoc, monkeypatch):
             F_min, _ = eng.eval(x_min)
         assert info["iterations"] >= 3 and F_min < F0 - 1e-6          # (a nearly flat landscape: 1 - overlap^2 of generic states)
         assert abs(F_min - info["minimum"]) <= 1e-12
+
+
+def test_amplitude_scaled_controls(qoc, oracle, monkeypatch):
+    """A robustness ensemble over control-amplitude errors: B_kc = s_k B_c (C4's sparse superoperators) -- per-member
+    operators with per-member (value, column) lists in the forms kernel."""
+    from quoptimalcontrol_jl_amd import workloads
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    w = workloads.config("C4", E=5, N=90)
+    scale = np.random.default_rng(3).uniform(0.8, 1.2, w.E)
+    B = w.B * scale[:, None, None, None]
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("GRAPE_FORMS_DENSE", "1")
+        with qoc.GrapeEngine(w.sys_type, w.A, B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+            assert eng.info["expm_action"] == 1 and eng.info["hoisted_controls"] == 0
+            F, G = eng.eval(w.x)
+        assert_parity(F, G, F_ref, G_ref, w.n, what=f"scaled controls, dense forms = {dense}")
