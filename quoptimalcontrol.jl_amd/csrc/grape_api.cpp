@@ -105,6 +105,7 @@ struct grape_ctx {
     double *d_act_an = nullptr, *d_act_gn = nullptr;
     int act_R = 0;                             // sparse rows of the control operators (0: dense forms kernel)
     bool act_shared = true;                    // one set of control operators for every member
+    size_t act_var_bytes = 0;                  // device bytes of the vector flow's operator buffers (re-sized per upload)
     double *d_act_bn = nullptr;                // per-member controls: [E][K] norm bounds
     double2 *d_act_bs = nullptr;
     int32_t *d_act_bo = nullptr;                   // [B][N] |Gc_t|_1 bound / theta8
@@ -1195,6 +1196,12 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             HIP_TRY(c, hipMalloc((void **)&c->d_act_b, sizeof(double) * bb.size()));
             HIP_TRY(c, hipMalloc((void **)&c->d_act_bf, sizeof(double) * bf.size()));
             HIP_TRY(c, hipMalloc((void **)&c->d_act_bn, sizeof(double) * bn.size()));
+            {                                                    // (buffers whose size follows the upload: keep workspace_bytes honest)
+                const size_t now = sizeof(double) * (bb.size() + bf.size() + bn.size()) +
+                                   (c->act_R ? (sizeof(double2) + sizeof(int32_t)) * nb * K * VS * (size_t)c->act_R : 0);
+                c->bytes += now - c->act_var_bytes;
+                c->act_var_bytes = now;
+            }
             HIP_TRY(c, hipMemcpy(c->d_act_bn, bn.data(), sizeof(double) * bn.size(), hipMemcpyHostToDevice));
             if (!c->d_act_g) HIP_TRY(c, hipMalloc((void **)&c->d_act_g, sizeof(double2) * g_elems));
             if (!c->d_act_gn) HIP_TRY(c, hipMalloc((void **)&c->d_act_gn, sizeof(double) * (size_t)c->B * c->cfg.n_slices));
