@@ -1302,6 +1302,12 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         if (p.unitary)
             q.tp_qt = nullptr;                                     // only the general flow's prefix scan needs Q_c^T
 
+        const bool coop = NT == 2 && coop_applies(q, sandwich, keepl);     // few units: four waves per product (sweep_coop.hip)
+        if (coop) {
+            hipError_t ec = launch_coop_chunk_product(q, stream);
+            if (ec != hipSuccess)
+                return ec;
+        } else
         hipLaunchKernelGGL((chunk_product_kernel<NT>), ugrid, block, lds_img, stream, q);
         if (!p.unitary) {
             if (q.tp_groups) {                                     // two levels: inside the groups, then over the groups
@@ -1321,11 +1327,21 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         else {
             TileParams s2 = q;                                     // what the serial scan runs over: chunks, or groups of chunks
             if (q.tp_groups) {
+                if (coop) {
+                    hipError_t ec = launch_coop_scan_group(q, stream);
+                    if (ec != hipSuccess)
+                        return ec;
+                } else
                 hipLaunchKernelGGL((chunk_scan_group_kernel<NT>), dim3(p.E, p.n_x, q.tp_groups), block, lds_img, stream, q);
                 s2.tp_chunks = q.tp_groups;
                 s2.tp_q = q.tp_a + (size_t)p.n_x * p.E * q.tp_groups * NT * NT * 256;
                 s2.tp_r = q.tp_a;
             }
+            if (coop && !sandwich) {
+                hipError_t ec = launch_coop_scan(s2, stream);
+                if (ec != hipSuccess)
+                    return ec;
+            } else
             if (sandwich) { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, NT == 1>), grid, block, lds_img, stream, s2);
                             else    hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, false>), grid, block, lds_img, stream, s2); }
             else          { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 0, NT == 1>), grid, block, lds_img, stream, s2);
@@ -1337,7 +1353,11 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     }
 #define GRAPE_LAUNCH_CHAIN(KERNEL) hipLaunchKernelGGL(KERNEL, ugrid, block, lds, stream, q)
 #define GRAPE_LAUNCH_UNI(KERNEL) hipLaunchKernelGGL(KERNEL, ugrid, block, lds, stream, q)
-    if (p.unitary && !keepl && p.sparse && !pk) {
+    if (NT == 2 && tp && p.unitary && !keepl && p.sparse && !pk && !sandwich && coop_applies(q, sandwich, keepl)) {
+        hipError_t ec = launch_coop_chain_unitary(q, stream);
+        if (ec != hipSuccess)
+            return ec;
+    } else if (p.unitary && !keepl && p.sparse && !pk) {
         // image for layout conversions | coefficients | image of M | positions
         const size_t lds_sp = sizeof(double2) * (kTileImage + 1 + (size_t)p.K * kSparseMax + 16 * NT * (16 * NT + 1)) +
                               sizeof(int32_t) * (size_t)p.K * kSparseMax;
