@@ -163,8 +163,8 @@ hipError_t launch_action_thin(int sandwich, const TileParams &p, hipStream_t str
 bool coop_applies(const TileParams &p, int sandwich, bool keepl);
 hipError_t launch_coop_chunk_product(const TileParams &q, hipStream_t stream);
 hipError_t launch_coop_scan_group(const TileParams &q, hipStream_t stream);
-hipError_t launch_coop_scan(const TileParams &q, hipStream_t stream);
-hipError_t launch_coop_chain_unitary(const TileParams &q, hipStream_t stream);
+hipError_t launch_coop_scan(int sandwich, const TileParams &q, hipStream_t stream);
+hipError_t launch_coop_chain_unitary(int sandwich, const TileParams &q, hipStream_t stream);
 int tile_count(int n);    // NT for this n (0: not a tile-family size)
 int tile_fuse_forward(const TileParams &p);   // thin: forward vector pass runs inside prop_tile_kernel for this launch?
 hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);

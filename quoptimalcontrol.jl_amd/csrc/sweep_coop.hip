@@ -215,7 +215,9 @@ __global__ __launch_bounds__(256) void coop_scan_group_kernel(const TileParams p
     coop_store(p.tp_a + ((kw + (size_t)gridDim.y * p.E) * G + j) * TSZ, tile, lane, Y);   // the group's product, behind the A_j block
 }
 
-// chunk_scan_kernel<2, 0, false>: the serial scan over the chunks (or groups), then X_N = T Xi and M_N = X_N Xt' (UnitaryGate)
+// chunk_scan_kernel<2, SAND, false>: the serial scan over the chunks (or groups), then X_N = T Xi [T'] and
+// M_N = X_N Xt' [- Xt' X_N], z = tr(X_N' Xt) (sandwich)
+template <int SAND>
 __global__ __launch_bounds__(256) void coop_scan_kernel(const TileParams p)
 {
     constexpr int TSZ = 1024;
@@ -246,12 +248,32 @@ __global__ __launch_bounds__(256) void coop_scan_kernel(const TileParams p)
         coop_load(Xi, ops + (size_t)(1 + 2 * K) * TSZ, tile, lane);
         coop_tn_ordered<false, false>(X, V, Xi, s_z, s_w, I, J, lane, true, true);          // (T^T)^T Xi
     }
+    const int rho = lane & 15, q = lane >> 4;
+    const int wr = 17 * (lane >> 4) + (lane & 15), rd = 68 * (rho >> 2) + 17 * (rho & 3) + q;
+    double2 *imgX = s_t, *imgL = s_t + 4 * kTileImage;
+    if (SAND) {                                                    // X_N = (T Xi) T' = (T Xi) conj(T^T): A-layout of T Xi, V as it is
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            imgX[tile * kTileImage + 68 * r + wr] = make_double2(X.re[r], X.im[r]);
+        coop_write(s_w, tile, lane, V);
+        __syncthreads();
+        CTile x0, x1, v0, v1;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const double2 a = imgX[(2 * I) * kTileImage + rd + 4 * kb], b = imgX[(2 * I + 1) * kTileImage + rd + 4 * kb];
+            x0.re[kb] = a.x; x0.im[kb] = a.y;
+            x1.re[kb] = b.x; x1.im[kb] = b.y;
+        }
+        coop_read(v0, s_w, J, lane);
+        coop_read(v1, s_w, 2 + J, lane);
+        __syncthreads();
+        coop_tile_prod<false, true>(Y, x0, x1, v0, v1);
+        X = Y;
+    }
     coop_load(L, ops + (size_t)(2 + 2 * K) * TSZ, tile, lane);     // L_N = Xt
     {
         // M(I, J) = sum_Kt X(I, Kt) conj(L(J, Kt))^T: both factors as A-layout operands = transposing reads of their images
-        const int rho = lane & 15, q = lane >> 4;
-        const int wr = 17 * (lane >> 4) + (lane & 15), rd = 68 * (rho >> 2) + 17 * (rho & 3) + q;
-        double2 *imgX = s_t, *imgL = s_t + 4 * kTileImage;
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -271,10 +293,37 @@ __global__ __launch_bounds__(256) void coop_scan_kernel(const TileParams p)
         }
         coop_tile_prod<false, true>(M, x0, x1, l0, l1);
     }
+    if (SAND) {
+        coop_tn_ordered<true, false>(Y, L, X, s_z, s_w, I, J, lane, true, true);           // L' X
+        M.re -= Y.re;
+        M.im -= Y.im;
+        double zz[2] = {0.0, 0.0};                                 // tr(X' L): own tile, then the four waves
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            zz[0] = fma(X.re[r], L.re[r], zz[0]);
+            zz[0] = fma(X.im[r], L.im[r], zz[0]);
+            zz[1] = fma(X.re[r], L.im[r], zz[1]);
+            zz[1] = fma(-X.im[r], L.re[r], zz[1]);
+        }
+        wave_sum_n(zz);
+        double *s_red = reinterpret_cast<double *>(s_coop);
+        __syncthreads();
+        if (lane == 0) {
+            s_red[2 * wave] = zz[0];
+            s_red[2 * wave + 1] = zz[1];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const double zr = (s_red[0] + s_red[2]) + (s_red[4] + s_red[6]), zi = (s_red[1] + s_red[3]) + (s_red[5] + s_red[7]);
+            p.tp_z[(kw * 64 + lane) * 2] = zr;
+            p.tp_z[(kw * 64 + lane) * 2 + 1] = zi;
+        }
+    }
     coop_store(p.tp_m + kw * TSZ, tile, lane, M);
 }
 
-// chain_tile_unitary_kernel<2, 0, false, true> in chunk mode: UnitaryGate, sparse control operators, grid.z = chunk
+// chain_tile_unitary_kernel<2, SAND, false, true> in chunk mode: sparse control operators, grid.z = chunk
+template <int SAND>
 __global__ __launch_bounds__(256) void coop_chain_unitary_kernel(const TileParams p)
 {
     constexpr int TSZ = 1024, NT = 2, MS = 16 * NT + 1;
@@ -307,7 +356,7 @@ __global__ __launch_bounds__(256) void coop_chain_unitary_kernel(const TileParam
     coop_load(Pm, p.tp_r + (kw * C + blockIdx.z) * TSZ, tile, lane);
     coop_tn_ordered<false, true>(Y, M, Pm, s_z, s_w, I, J, lane, true, true);              // (R' M)^T
     coop_tn_ordered<false, false>(M, Y, Pm, s_z, s_w, I, J, lane, true, false);            // R' M R
-    const double gs = p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt;
+    const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
     // z = conj(tr M), the same for every t: through the image of M the traces read anyway
     auto image_of_M = [&]() {
 #pragma unroll
@@ -316,8 +365,12 @@ __global__ __launch_bounds__(256) void coop_chain_unitary_kernel(const TileParam
         __syncthreads();
     };
     double zr = 0.0, zi = 0.0;
-    image_of_M();
-    if (wave == 0) {
+    if (SAND) {                                                    // tr(X' L), the same for every t, from the scan kernel
+        zr = p.tp_z[(kw * 64 + lane) * 2];
+        zi = p.tp_z[(kw * 64 + lane) * 2 + 1];
+    } else
+        image_of_M();
+    if (!SAND && wave == 0) {
         double zz[2] = {0.0, 0.0};
         if (lane < 32) {
             const double2 d = s_M[lane * MS + lane];
@@ -346,7 +399,7 @@ __global__ __launch_bounds__(256) void coop_chain_unitary_kernel(const TileParam
                         const double2 cf = s_coef[(c0 + cc) * kSparseMax + lane];
                         const double2 mv = s_M[s_addr[(c0 + cc) * kSparseMax + lane]];
                         const double pr = cf.x * mv.x - cf.y * mv.y, pi = cf.x * mv.y + cf.y * mv.x;
-                        q16[cc] = fma(pr, zi, pi * zr);
+                        q16[cc] = SAND ? pi : fma(pr, zi, pi * zr);
                     }
                 }
                 const double tot = reduce_scatter16(q16);
@@ -354,8 +407,14 @@ __global__ __launch_bounds__(256) void coop_chain_unitary_kernel(const TileParam
                 if ((lane & 3) == 0 && lane < 32 && c < K)
                     out[(size_t)t * K + c] = gs * tot;
             }
-            if (t == N - 1 && lane == 0)
-                out[(size_t)K * N] = zr * zr - zi * zi;
+            if (t == N - 1 && lane == 0) {
+                if (SAND) {
+                    const double inv = 1.0 / (double)p.n, ar = zr * inv, ai = zi * inv;
+                    out[(size_t)K * N] = 1.0 - (ar * ar + ai * ai);
+                } else {
+                    out[(size_t)K * N] = zr * zr - zi * zi;
+                }
+            }
         }
         Pm = Pn;
         Pn = Pnn;
@@ -369,7 +428,9 @@ bool coop_applies(const TileParams &p, int sandwich, bool keepl)
     if (off || tile_count(p.n) != 2 || !p.unitary || keepl || p.tp_chunks < 2)
         return false;
     const long waves = (long)p.E * p.n_x * p.tp_chunks, cus = p.cus > 0 ? p.cus : 256;
-    return waves <= 2 * cus && !sandwich;
+    static const char *lim = std::getenv("GRAPE_COOP_MAX");        // tuning: largest number of (unit, chunk) pairs
+    (void)sandwich;
+    return waves <= (lim ? std::atol(lim) : 3 * cus);              // measured: 668 pairs (4 units) 0.418 -> 0.350 ms, 1024 pairs (8 units) 0.603 -> 0.615
 }
 
 size_t coop_chain_lds(const TileParams &p)
@@ -390,21 +451,24 @@ hipError_t launch_coop_scan_group(const TileParams &q, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_coop_scan(const TileParams &q, hipStream_t stream)
+hipError_t launch_coop_scan(int sandwich, const TileParams &q, hipStream_t stream)
 {
-    hipLaunchKernelGGL(coop_scan_kernel, dim3(q.E, q.n_x), dim3(256), 2 * kCoopMatrix + 8 * kTileImage * 16, stream, q);
+    const size_t lds = 2 * kCoopMatrix + 8 * kTileImage * 16;
+    if (sandwich) hipLaunchKernelGGL(coop_scan_kernel<1>, dim3(q.E, q.n_x), dim3(256), lds, stream, q);
+    else          hipLaunchKernelGGL(coop_scan_kernel<0>, dim3(q.E, q.n_x), dim3(256), lds, stream, q);
     return hipGetLastError();
 }
 
-hipError_t launch_coop_chain_unitary(const TileParams &q, hipStream_t stream)
+hipError_t launch_coop_chain_unitary(int sandwich, const TileParams &q, hipStream_t stream)
 {
     const size_t lds = coop_chain_lds(q);
+    auto kern = sandwich ? coop_chain_unitary_kernel<1> : coop_chain_unitary_kernel<0>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)coop_chain_unitary_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
     }
-    hipLaunchKernelGGL(coop_chain_unitary_kernel, dim3(q.E, q.n_x, q.tp_chunks), dim3(256), lds, stream, q);
+    hipLaunchKernelGGL(kern, dim3(q.E, q.n_x, q.tp_chunks), dim3(256), lds, stream, q);
     return hipGetLastError();
 }
 

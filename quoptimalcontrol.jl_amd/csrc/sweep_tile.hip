@@ -1337,8 +1337,8 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
                 s2.tp_q = q.tp_a + (size_t)p.n_x * p.E * q.tp_groups * NT * NT * 256;
                 s2.tp_r = q.tp_a;
             }
-            if (coop && !sandwich) {
-                hipError_t ec = launch_coop_scan(s2, stream);
+            if (coop) {
+                hipError_t ec = launch_coop_scan(sandwich, s2, stream);
                 if (ec != hipSuccess)
                     return ec;
             } else
@@ -1353,8 +1353,8 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     }
 #define GRAPE_LAUNCH_CHAIN(KERNEL) hipLaunchKernelGGL(KERNEL, ugrid, block, lds, stream, q)
 #define GRAPE_LAUNCH_UNI(KERNEL) hipLaunchKernelGGL(KERNEL, ugrid, block, lds, stream, q)
-    if (NT == 2 && tp && p.unitary && !keepl && p.sparse && !pk && !sandwich && coop_applies(q, sandwich, keepl)) {
-        hipError_t ec = launch_coop_chain_unitary(q, stream);
+    if (NT == 2 && tp && p.unitary && !keepl && p.sparse && !pk && coop_applies(q, sandwich, keepl)) {
+        hipError_t ec = launch_coop_chain_unitary(sandwich, q, stream);
         if (ec != hipSuccess)
             return ec;
     } else if (p.unitary && !keepl && p.sparse && !pk) {
