@@ -1044,9 +1044,13 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             // 12 slices, 16 x 16, N = 1000: 4..5
             // general flow (a slice costs ~6 products there): (0.17 sqrt N)^(2/3), 4 at N = 1000
             long s_lat = general ? std::lround(std::pow(0.17 * std::sqrt((double)N), 2.0 / 3.0))
-                                 : std::lround(std::cbrt((double)N / 9.0) * (c->NT == 2 ? (units <= 4 ? 1.35 : 2.0) : 1.0));
-            // (32 x 32 with up to four units: the four-wave products of sweep_coop.hip -- shorter chunks pay, N = 2000:
-            //  167 / 250 / 334 chunks 0.181 / 0.174 / 0.193 ms)
+                                 : std::lround(std::cbrt((double)N / 9.0) * (c->NT == 2 ? 2.0 : 1.0));
+            if (!general && c->NT == 2) {
+                // the four-wave products of sweep_coop.hip (at most 3 x CUs (unit, chunk) pairs): shorter chunks pay while the
+                // pairs still fit -- N = 2000, one unit: 167 / 250 / 334 chunks 0.181 / 0.174 / 0.193 ms
+                const long s_coop = std::max(2L, std::lround(std::cbrt((double)N / 9.0) * 1.35));
+                if (units * ((N + s_coop - 1) / s_coop) <= 3L * c->compute_units) s_lat = s_coop;
+            }
             if (env_on("GRAPE_TP_ONE_LEVEL")) s_lat = std::lround(std::sqrt((double)N / 3.0));
             if (s_lat < 2) s_lat = 2;
             if (s_lat < 4 && N >= 64 && !env_on("GRAPE_TP_ONE_LEVEL")) s_lat = 4;

@@ -111,6 +111,36 @@ GRAPE_DEV void coop_tn_ordered(CTile &out, const CTile &z, const CTile &w, char 
     coop_tile_prod<CZ, CW>(out, z0, z1, w0, w1);
 }
 
+// the scans' step: out = Z^T W and, from the same two barriers, wt = tile (I, J) of W^T (W's tiles also go to the padded
+// images img, read back with tile.hpp's transposing pattern) -- a separate transpose would cost three more barriers per step
+GRAPE_DEV void coop_tn_and_transpose(CTile &out, CTile &wt, const CTile &z, const CTile &w, char *s_z, char *s_w, double2 *img,
+                                     int I, int J, int lane)
+{
+    const int rho = lane & 15, q = lane >> 4;
+    const int wr = 17 * (lane >> 4) + (lane & 15), rd = 68 * (rho >> 2) + 17 * (rho & 3) + q;
+    coop_write(s_z, 2 * I + J, lane, z);
+    coop_write(s_w, 2 * I + J, lane, w);
+    double2 *mine = img + (2 * I + J) * kTileImage;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        mine[68 * r + wr] = make_double2(w.re[r], w.im[r]);
+    __syncthreads();
+    CTile z0, z1, w0, w1;
+    coop_read(z0, s_z, I, lane);
+    coop_read(z1, s_z, 2 + I, lane);
+    coop_read(w0, s_w, J, lane);
+    coop_read(w1, s_w, 2 + J, lane);
+    const double2 *other = img + (2 * J + I) * kTileImage;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const double2 x = other[rd + 4 * kb];
+        wt.re[kb] = x.x;
+        wt.im[kb] = x.y;
+    }
+    __syncthreads();
+    coop_tile_prod<false, false>(out, z0, z1, w0, w1);
+}
+
 GRAPE_DEV void coop_load(CTile &t, const double2 *__restrict__ dump, int tile, int lane)
 {
 #pragma unroll
@@ -205,8 +235,7 @@ __global__ __launch_bounds__(256) void coop_scan_group_kernel(const TileParams p
     coop_load(Q, Qk + (size_t)(c_hi - 1) * TSZ, tile, lane);
     for (int c = c_hi - 1; c >= c_lo; --c) {
         coop_load(Qn, Qk + (size_t)max(c - 1, 0) * TSZ, tile, lane);
-        coop_tn_ordered<false, false>(Y, Q, V, s_z, s_w, I, J, lane, true, true);
-        coop_transpose(T, V, s_t, I, J, lane);
+        coop_tn_and_transpose(Y, T, Q, V, s_z, s_w, s_t, I, J, lane);
         coop_store(Rk + (size_t)c * TSZ, tile, lane, T);           // product of the chunks after c inside the group
         V = Y;
         Q = Qn;
@@ -235,8 +264,7 @@ __global__ __launch_bounds__(256) void coop_scan_kernel(const TileParams p)
     coop_load(Q, Qk + (size_t)(C - 1) * TSZ, tile, lane);
     for (int c = C - 1; c >= 0; --c) {
         coop_load(Qn, Qk + (size_t)max(c - 1, 0) * TSZ, tile, lane);
-        coop_tn_ordered<false, false>(Y, Q, V, s_z, s_w, I, J, lane, true, true);          // R_{c-1}^T = Q_c^T R_c^T
-        coop_transpose(T, V, s_t, I, J, lane);
+        coop_tn_and_transpose(Y, T, Q, V, s_z, s_w, s_t, I, J, lane);                        // R_{c-1}^T = Q_c^T R_c^T; T = R_c
         coop_store(Rk + (size_t)c * TSZ, tile, lane, T);           // R_c
         V = Y;
         Q = Qn;
