@@ -167,6 +167,7 @@ def test_fused_forward_pass_is_bitwise_the_separate_one(qoc, monkeypatch, sys_ty
     agree to the last bit; the round-3 kernel multiplies EVERY slice by its transposed registers (the short hand-over),
     a different tree on the even slices: agreement to rounding, each flow bitwise reproducible."""
     n, K, N = 16, 4, 37
+    monkeypatch.setenv("GRAPE_ACTION", "0")          # (ensembles of this size would take the vector flow of action_thin.hip)
     A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sys_type != "UnitaryGate", False, True, seed=5)
     for hoist in ("0", None):
         if hoist is None:
