@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin_kernel(const TileP
     const double *__restrict__ gn = p.act_gn + (size_t)y * N;
     const double an = p.act_an[k];
     // this chain's records, element-major: element r of slice t at [r][t] -- action_forms_kernel (lane = slice) reads them coalesced
-    double2 *__restrict__ rec = (d ? p.props : p.states) + kw * (size_t)(N + 1) * 16 + (size_t)r * (N + 1);
+    double2 *__restrict__ rec = (d ? p.wrec : p.states) + kw * (size_t)(N + 1) * 16 + (size_t)r * (N + 1);
     double ar[8], ai[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin2_kernel(const Tile
     const double an = p.act_an[k];
     // rows 0 (Rb = H = 0) and 3 (Rb = H = 1) hold, as x, the element el they also own: they write the records
     const bool writer = Rb == H;
-    double2 *__restrict__ rec = (d ? p.props : p.states) + kw * (size_t)(N + 1) * 32 + (size_t)el * (N + 1);
+    double2 *__restrict__ rec = (d ? p.wrec : p.states) + kw * (size_t)(N + 1) * 32 + (size_t)el * (N + 1);
     double ar[16], ai[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -465,6 +465,115 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin2_kernel(const Tile
     }
 }
 
+// The same two chains with the PROPAGATORS of the expm kernel (p.thin == 2: ensembles too small for the Taylor flow above --
+// a member's chains take N x 8 dependent products there whatever the ensemble size -- or with many per-member controls):
+// one matrix-vector product per slice.  The expm kernel stores P_t AND P_t^T (D-layout dumps, untransposed for every t): a
+// lane's operands are then entries (8h + j, r) of a dump for either chain -- 16 entries apart per lane, consecutive across
+// the 16 lanes of a row, so every load instruction reads whole 256-byte runs.  (Rows read per lane from the P_t dump alone
+// -- 128 contiguous bytes per lane, 32 cache lines per instruction -- ran at the texture addresser's rate: 1.1 us per slice
+// with four members per compute unit.)  sweep_thin.hip's chain spends ~100 vector
+// instructions per product on cross-lane sums; this one 50, with both chains in one wave.
+__global__ __launch_bounds__(64) void chain_prop_kernel(const TileParams p)
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, d = lane >> 5, h = (lane >> 4) & 1;
+    const int wave = 0;
+    const int k = blockIdx.x, y = blockIdx.y, N = p.N;
+    if (k >= p.E)
+        return;
+    const size_t kw = (size_t)y * p.E + k;
+    // entry (row, col) of a dump sits at 64 (row >> 2) + 16 (row & 3) + col.  Forward: rows of P_t = columns of the P_t^T dump,
+    // backward: rows of P_t' = conjugated columns of the P_t dump: entry (8h + j, r) of either, consecutive across the lanes r
+    const double2 *__restrict__ Pk = (d ? p.props : p.props_t) + kw * (size_t)N * 256 + 128 * h + r;
+    const double sgn = d ? -1.0 : 1.0;                            // backward: the conjugate
+    double2 *__restrict__ rec = (d ? p.wrec : p.states) + kw * (size_t)(N + 1) * 16 + (size_t)r * (N + 1);
+    double vr, vi;
+    {
+        const double2 t2 = p.vecs[(size_t)k * 32 + d * 16 + r];
+        vr = t2.x;
+        vi = t2.y;
+    }
+    rec[d ? N : 0] = make_double2(vr, vi);
+    // The dumps come from HBM (E N x 4 KB each, nothing of it cached) at ~1 us latency and the chain consumes a slice every
+    // ~0.3 us.  A register ring (32 registers per slice) holds four slices at most: 0.875 us per slice measured, 0.325 with
+    // the operands cached.  So the ring lives in LDS and is filled by LDS-DMA (global_load_lds_dwordx4: one instruction =
+    // 64 lanes x 16 B, lane-linear -- exactly one operand index j of a slice): kRing slices of 8 KB in flight per wave, no
+    // registers, and the wave reads its own bytes back with ds_read_b128.  The DMA loads are inline asm, i.e. outside the
+    // compiler's s_waitcnt bookkeeping: per step this wave issues 8 of them and ONE record store, in that order, and waits
+    // for "all but the 9 (kRing - 1) youngest" before it reads a slot.
+    typedef double d2x __attribute__((ext_vector_type(2)));
+    constexpr int kRing = 7;
+    extern __shared__ double2 s_ring_all[];
+    const unsigned ring0 = (unsigned)(size_t)s_ring_all + (unsigned)wave * (kRing * 8192);
+    auto dma = [&](int slot, int i) {                             // slice of step i -> ring slot (clamped: always eight loads)
+        const int ic = min(i, N - 1);
+        // entry j of the lane: 256 j bytes further on.  The instruction offset moves the LDS address too: M0 advances by 1024 - 256
+        const double2 *src = Pk + (size_t)(d ? N - 1 - ic : ic) * 256;
+        const unsigned dst = ring0 + (unsigned)slot * 8192u;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_add_u32 m0, m0, 0x300\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:256\n\t"
+                     "s_add_u32 m0, m0, 0x300\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:512\n\t"
+                     "s_add_u32 m0, m0, 0x300\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:768\n\t"
+                     "s_add_u32 m0, m0, 0x300\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "s_add_u32 m0, m0, 0x300\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:1280\n\t"
+                     "s_add_u32 m0, m0, 0x300\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:1536\n\t"
+                     "s_add_u32 m0, m0, 0x300\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:1792\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(dst)
+                     : "memory", "scc");
+    };
+    // prologue: the record store of v_0 / w_N above is this wave's only older vector-memory operation
+#pragma unroll
+    for (int u = 0; u < kRing; ++u) {
+        dma(u, u);
+        if (u + 1 < kRing)                                        // keep the "8 loads, 1 store" rhythm of the steady state
+            rec[d ? N : 0] = make_double2(vr, vi);
+    }
+    double xr = rot8_odd_rows(vr), xi = rot8_odd_rows(vi);
+    auto step = [&](int slot, int i) {
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(9 * (kRing - 1)) : "memory");
+        const d2x *mine = reinterpret_cast<const d2x *>(s_ring_all) + ((size_t)wave * kRing + slot) * 512 + lane;
+        double mr[8], mi[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const d2x v = mine[j * 64];
+            mr[j] = v[0];
+            mi[j] = sgn * v[1];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slot is read: it may be refilled
+        dma(slot, i + kRing);
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        act_matvec(a0, a1, b0, b1, xr, xi, mr, mi);
+        double yr = a0 + a1, yi = b0 + b1;
+        swap16(yr, yi);                                           // h = 0 rows: both real halves; h = 1 rows: both imaginary halves
+        double part = yr + yi, other = part;
+        swap16(part, other);                                      // part: real part in every row, other: imaginary part
+        rec[d ? N - 1 - i : i + 1] = make_double2(part, other);   // (element r, from both rows: the same value)
+        xr = rot8_odd_rows(part);
+        xi = rot8_odd_rows(other);
+    };
+    int i = 0;
+    for (; i + kRing <= N; i += kRing) {
+        step(0, i);
+        step(1, i + 1);
+        step(2, i + 2);
+        step(3, i + 3);
+        step(4, i + 4);
+        step(5, i + 5);
+        step(6, i + 6);
+    }
+    static_assert(kRing == 7, "unrolled by hand");
+    if (i + 0 < N) step(0, i);
+    if (i + 1 < N) step(1, i + 1);
+    if (i + 2 < N) step(2, i + 2);
+    if (i + 3 < N) step(3, i + 3);
+    if (i + 4 < N) step(4, i + 4);
+    if (i + 5 < N) step(5, i + 5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // DMA loads still in flight target this wave's LDS
+}
+
 // grid (ceil(N / 64), E, n_x): lane = slice.  act_bf = the K control operators B_c, row-major, zero padded to NB x NB
 template <int SAND, bool HERMB, int NB>
 __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
@@ -473,7 +582,7 @@ __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
     const int t = blockIdx.x * 64 + lane, tc = min(t, N - 1);
     const size_t kw = (size_t)y * p.E + k;
     const double2 *__restrict__ V = p.states + kw * (size_t)(N + 1) * NB;
-    const double2 *__restrict__ W = p.props + kw * (size_t)(N + 1) * NB;
+    const double2 *__restrict__ W = p.wrec + kw * (size_t)(N + 1) * NB;
     double vr[NB], vi[NB], wr[NB], wi[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -562,7 +671,7 @@ __global__ __launch_bounds__(64) void action_forms_sparse_kernel(const TileParam
     const int t = blockIdx.x * 64 + lane, tc = min(t, N - 1);
     const size_t kw = (size_t)y * p.E + k;
     const double2 *__restrict__ V = p.states + kw * (size_t)(N + 1) * NB;
-    const double2 *__restrict__ W = p.props + kw * (size_t)(N + 1) * NB;
+    const double2 *__restrict__ W = p.wrec + kw * (size_t)(N + 1) * NB;
     double2 *s_v = s_forms, *s_w = s_forms + 64 * NB;             // [NB][64] each (s_w only when b is needed)
     double2 *s_tab = s_forms + (NEEDB ? 128 : 64) * NB;           // [K][NB][R] values
     int *s_off = reinterpret_cast<int *>(s_tab + (size_t)K * NB * R);   // [K][NB][R] byte offsets of the column inside s_v
@@ -655,6 +764,9 @@ static void launch_forms_sparse(int sandwich, const TileParams &p, dim3 grid, si
 }
 
 template <int NB>
+static hipError_t launch_forms_nb(int sandwich, const TileParams &p, hipStream_t stream);
+
+template <int NB>
 static hipError_t launch_action_nb(int sandwich, const TileParams &p, hipStream_t stream)
 {
     if (p.act_shared)
@@ -684,6 +796,12 @@ static hipError_t launch_action_nb(int sandwich, const TileParams &p, hipStream_
         if (e != hipSuccess)
             return e;
     }
+    return launch_forms_nb<NB>(sandwich, p, stream);
+}
+
+template <int NB>
+static hipError_t launch_forms_nb(int sandwich, const TileParams &p, hipStream_t stream)
+{
     const dim3 grid((p.N + 63) / 64, p.E, p.n_x);
     if (p.act_R > 0) {                                            // sparse control operators: (value, column) lists
         const bool needb = sandwich && !p.herm_ctrl;
@@ -704,6 +822,16 @@ static hipError_t launch_action_nb(int sandwich, const TileParams &p, hipStream_
     else
         hipLaunchKernelGGL((action_forms_kernel<1, false, NB>), grid, dim3(64), 0, stream, p);
     return hipGetLastError();
+}
+
+hipError_t launch_chain_prop(int sandwich, const TileParams &p, hipStream_t stream)
+{
+    if (!p.props_t || !p.wrec)
+        return hipErrorInvalidValue;
+    // one member per workgroup: its LDS ring (7 slices x 8 KB) lets two of them share a compute unit
+    const size_t lds = 7 * 8192;
+    hipLaunchKernelGGL(chain_prop_kernel, dim3(p.E, p.n_x), dim3(64), lds, stream, p);
+    return launch_forms_nb<16>(sandwich, p, stream);
 }
 
 // p.E = members (the host layer hands over member counts, not tile units); n = 9..16 -> 16 x 16 images, 17..32 -> 32 x 32

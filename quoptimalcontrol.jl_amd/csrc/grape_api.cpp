@@ -101,6 +101,11 @@ struct grape_ctx {
     double2 *d_gc = nullptr;                   // [B][N] dumps of Gc_t
     double *d_gcn = nullptr;
     bool action = false;                       // rank-one states + member-invariant controls: exp(G) v on vectors (action_thin.hip)
+    bool thin_dpp = false;                     // rank-one states, expm kernel + chain_prop_kernel (one DPP matrix-vector product per slice)
+    double2 *d_wrec = nullptr;                 // its backward records (the vector flow keeps them in d_props)
+    size_t wrec_bytes = 0;
+    double2 *d_props_t = nullptr;              // and the P_t^T dumps the expm kernel writes beside P_t
+    size_t props_t_bytes = 0;
     double2 *d_act_a = nullptr, *d_act_b = nullptr, *d_act_bf = nullptr, *d_act_g = nullptr;
     double *d_act_an = nullptr, *d_act_gn = nullptr;
     int act_R = 0;                             // sparse rows of the control operators (0: dense forms kernel)
@@ -325,7 +330,7 @@ static void free_all(grape_ctx *c)
     (void)hipFree(c->d_x_bar);
     (void)hipFree(c->d_ha); (void)hipFree(c->d_ha_norm); (void)hipFree(c->d_gc); (void)hipFree(c->d_gcn);
     (void)hipFree(c->d_act_a); (void)hipFree(c->d_act_b); (void)hipFree(c->d_act_bf); (void)hipFree(c->d_act_g);
-    (void)hipFree(c->d_act_an); (void)hipFree(c->d_act_gn); (void)hipFree(c->d_act_bs); (void)hipFree(c->d_act_bo); (void)hipFree(c->d_act_bn);
+    (void)hipFree(c->d_act_an); (void)hipFree(c->d_act_gn); (void)hipFree(c->d_act_bs); (void)hipFree(c->d_act_bo); (void)hipFree(c->d_act_bn); (void)hipFree(c->d_wrec); (void)hipFree(c->d_props_t);
     delete c;
 }
 
@@ -765,7 +770,9 @@ extern "C" int grape_comm_attach(grape_ctx *c, const grape_comm_id *id, int32_t 
 static long act_min_units(const grape_ctx *c)
 {
     if (const char *e = std::getenv("GRAPE_ACTION_MIN")) return std::atol(e);
-    return 9L * c->compute_units / 8;
+    // 9 <= n <= 16: the expm kernel + chain_prop_kernel (one DPP matrix-vector product per slice on the stored propagators)
+    // is ahead up to ~350 members (320: 1.34 vs 1.42 ms, 384: 1.50 vs 1.43 ms)
+    return (c->NT == 1 && !c->pack2 ? 11L : 9L) * c->compute_units / 8;
 }
 
 extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *B, const double *Xi,
@@ -1109,9 +1116,22 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // fill the device (the chunked flows of small ensembles keep the expm kernel: they need the chunk PRODUCTS);
         // GRAPE_ACTION=0 keeps the expm + chain kernels, GRAPE_ACTION=1 forces the vector flow for any ensemble size.
         bool act = thin && act_ok;
-        if (act && !act_only && !act_forced && (c->tp_C || (long)c->EU < act_min_units(c))) act = false;
+        if (act && !act_only && !act_forced && (long)c->EU < act_min_units(c)) act = false;
         c->action = act;
-        if (act) {
+        // ... and where that flow does not apply (ensembles below its threshold, more than six per-member controls): the
+        // propagators of the expm kernel with the same DPP matrix-vector products, one per slice, and the same forms kernels
+        // (chain_prop_kernel).  A member's chains are then N dependent products of ~0.3 us instead of sweep_thin.hip's
+        // ~1 us ones.  GRAPE_THIN_DPP=0: sweep_thin.hip; =1: this flow for any ensemble the round-3 expm kernel serves.
+        const char *de = std::getenv("GRAPE_THIN_DPP");
+        // measured at C4's shape against sweep_thin.hip's chain (chunked time axis below 256 members): 64 members 0.42 vs 0.33 ms,
+        // 96: 0.51 vs 0.60, 128: 0.60 vs 0.70, 256: 1.03 vs 1.27, 384: 1.50 vs 1.65, 512: 1.82 vs 1.64 (that chain reads P_t
+        // once where the forward pass is fused into the expm kernel; this flow writes and reads it twice)
+        const long dpp_min = de && de[0] == '1' ? 2 : (de && de[0] != '0' ? std::atol(de) : 80);
+        // (needs the round-3 expm kernel, which writes both dumps: c->hoist != 0, i.e. at least 8 units)
+        const bool dpp = thin && !act && !act_only && c->hoist != 0 && !(de && de[0] == '0') && (long)E >= dpp_min &&
+                         ((de && de[0] == '1') || (long)E < 7L * c->compute_units / 4);
+        c->thin_dpp = dpp;
+        if (act || dpp) {
             c->tp_C = c->tp_S = c->tp_G = c->tp_g = 0;
             const double dt = c->cfg.duration / c->cfg.n_slices;
             const int nd = c->cfg.n;
@@ -1211,6 +1231,26 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             HIP_TRY(c, hipMemcpy(c->d_act_bn, bn.data(), sizeof(double) * bn.size(), hipMemcpyHostToDevice));
             if (!c->d_act_g) HIP_TRY(c, hipMalloc((void **)&c->d_act_g, sizeof(double2) * g_elems));
             if (!c->d_act_gn) HIP_TRY(c, hipMalloc((void **)&c->d_act_gn, sizeof(double) * (size_t)c->B * c->cfg.n_slices));
+            if (dpp) {
+                const size_t need = sizeof(double2) * E * ((size_t)c->cfg.n_slices + 1) * VS * c->B;
+                if (c->wrec_bytes < need) {
+                    (void)hipFree(c->d_wrec);
+                    c->d_wrec = nullptr;
+                    c->bytes += need - c->wrec_bytes;
+                    c->wrec_bytes = 0;
+                    HIP_TRY(c, hipMalloc((void **)&c->d_wrec, need));
+                    c->wrec_bytes = need;
+                }
+                const size_t need_t = sizeof(double2) * c->ws_elems * c->B;
+                if (c->props_t_bytes < need_t) {
+                    (void)hipFree(c->d_props_t);
+                    c->d_props_t = nullptr;
+                    c->bytes += need_t - c->props_t_bytes;
+                    c->props_t_bytes = 0;
+                    HIP_TRY(c, hipMalloc((void **)&c->d_props_t, need_t));
+                    c->props_t_bytes = need_t;
+                }
+            }
             HIP_TRY(c, hipMemcpy(c->d_act_a, aa.data(), sizeof(double) * aa.size(), hipMemcpyHostToDevice));
             HIP_TRY(c, hipMemcpy(c->d_act_an, an.data(), sizeof(double) * an.size(), hipMemcpyHostToDevice));
             HIP_TRY(c, hipMemcpy(c->d_act_b, bb.data(), sizeof(double) * bb.size(), hipMemcpyHostToDevice));
@@ -1270,7 +1310,7 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.dt = c->cfg.duration / c->cfg.n_slices;
     p.unitary = c->unitary ? 1 : 0;
     p.herm_states = c->herm_states ? 1 : 0;
-    p.thin = c->thin ? 1 : 0;
+    p.thin = c->thin ? (c->thin_dpp ? 2 : 1) : 0;
     p.herm_ctrl = c->herm_ctrl ? 1 : 0;
     p.vecs = c->d_vecs;
     p.cus = c->compute_units;
@@ -1308,7 +1348,9 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.act_bf = c->d_act_bf;
     p.act_g = c->d_act_g;
     p.act_gn = c->d_act_gn;
-    p.act_R = c->action ? c->act_R : 0;
+    p.act_R = (c->action || c->thin_dpp) ? c->act_R : 0;
+    p.wrec = c->thin_dpp ? c->d_wrec : c->d_props;
+    p.props_t = c->d_props_t;
     p.act_shared = c->act_shared ? 1 : 0;
     p.act_bn = c->d_act_bn;
     p.act_bs = c->d_act_bs;
@@ -2460,7 +2502,7 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
     const int n = c->cfg.n;
     const size_t nn = (size_t)n * n, N = c->cfg.n_slices, K = c->cfg.n_controls;
     std::vector<cplx> P(N * nn);
-    int rc = fetch_slab(c, c->d_props, member, P.data(), c->thin);
+    int rc = fetch_slab(c, c->d_props, member, P.data(), c->thin && !c->thin_dpp);
     if (rc) return rc;
     if (props) std::memcpy(props, P.data(), sizeof(cplx) * N * nn);
     // n x m states: the workspace holds them zero-padded to n x n; hand out the first m columns

@@ -101,8 +101,10 @@ struct TileParams {
     int32_t herm_states;  // every Xi, Xt Hermitian (density operators): [X, L'] = Y - Y' with one product
     int32_t split_at;     // set by the launcher: first slice of the second wave (chain_tile_split_kernel)
     int32_t n_x;          // control arrays evaluated by this launch (batched evaluation); x is (K, N, n_x)
-    int32_t thin;         // rank-one states (sweep_thin.hip): matrix-vector chain; the prop kernel then stores P_t
-                          // TRANSPOSED for odd t; `states` holds the forward pass's vector records (N + 1 per member)
+    int32_t thin;         // rank-one states: 1 = sweep_thin.hip's matrix-vector chain (the prop kernel then stores P_t
+                          // TRANSPOSED for odd t; `states` holds the forward pass's vector records, N + 1 per member);
+                          // 2 = chain_prop_kernel of action_thin.hip (P_t stored as it is, records element-major in
+                          // `states` / `wrec`, bilinear forms by the action_forms kernels)
     int32_t herm_ctrl;    // every control operator B_c Hermitian (thin chain: one bilinear form per control)
     const double2 *vecs;  // thin: per member [v0 | wT], 16 complex each, zero padded
     int32_t cus;          // compute units of the device
@@ -141,6 +143,8 @@ struct TileParams {
     int32_t action;           // set by the host layer
     const double2 *act_a;     // [unit][2][256] row-major [A'_k | A'_k'] (conjugate transpose), zero padded to 16 x 16
     const double *act_an;     // [unit] max(|A'_k|_1, |A'_k|_inf)
+    double2 *props_t;         // thin == 2: P_t^T dumps, same indexing as props
+    double2 *wrec;            // backward chain's records w_0 .. w_N, element-major (the vector flow: = props; thin == 2: own buffer)
     int32_t act_shared;       // 1: one set of control operators for every member (pre-pass forms the control sums); 0: per member
                               //    (n <= 16, K <= 6): act_b / act_bf / act_bs / act_bo carry a leading member index
     const double *act_bn;     // (per-member controls) [unit][K] max(|B'_kc|_1, |B'_kc|_inf)
@@ -159,6 +163,8 @@ constexpr int kSparseMax = 64;
 hipError_t launch_chain_thin(int sandwich, const TileParams &p, hipStream_t stream);
 // rank-one states, member-invariant controls: the evaluation on vectors (action_thin.hip); called by launch_sweep_tile when p.action
 hipError_t launch_action_thin(int sandwich, const TileParams &p, hipStream_t stream);
+// rank-one states, n = 9..16, propagators from the expm kernel (p.thin == 2): both vector chains on DPP FMACs, then the forms
+hipError_t launch_chain_prop(int sandwich, const TileParams &p, hipStream_t stream);
 // sweep_coop.hip: four waves per product for the chunked unitary flow of few 32 x 32 units (single problems, small ensembles)
 bool coop_applies(const TileParams &p, int sandwich, bool keepl);
 hipError_t launch_coop_chunk_product(const TileParams &q, hipStream_t stream);

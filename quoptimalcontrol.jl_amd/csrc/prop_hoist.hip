@@ -298,6 +298,9 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
     const gcptr Bk = uniform_global(p.ops + ((size_t)k * (2 * K + 3) + 1) * TSZ);      // !HOIST: this member's B_1 .. B_K dumps
     const double *__restrict__ xz = p.x + (size_t)z * K * p.N;
     const gptr props = uniform_global(p.props + ((size_t)z * p.E + k) * (size_t)p.N * TSZ);
+    // p.thin == 2 (chain_prop_kernel): P_t AND P_t^T go to memory, both as they are -- the two vector chains then read their
+    // rows lane-contiguously
+    const gptr props_t = uniform_global((p.thin == 2 ? p.props_t : p.props) + ((size_t)z * p.E + k) * (size_t)p.N * TSZ);
     const gptr V = uniform_global(FUSE ? p.states + ((size_t)z * p.E + k) * (size_t)(p.N + 1) * 16 : p.states);
     const int t_lo = FUSE ? 0 : blockIdx.x * p.prop_slices;
     const int t_hi = FUSE ? p.N : min(p.N, t_lo + p.prop_slices);
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
         }
         // P_t goes to memory through the image: read back as written for P_t itself, transposed for P_t^T (rank-one
         // chain: odd slices are stored transposed, and the fused forward pass multiplies by the transposed registers)
-        const bool transposed = p.thin && (t & 1);
+        const bool transposed = p.thin == 1 && (t & 1);
         const gptr dst = props + (size_t)t * TSZ;
         img_write_tile(wr, Pre, Pim, s > 0);
         if (HOIST) {   // the next slice's control sum: in flight during the conversions, the hand-over and the stores below
@@ -400,12 +403,18 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
             for (int r = 0; r < 4; ++r)
                 dst[r * 64 + lane] = pk.v[r];
         }
-        if (FUSE || transposed)
+        if (FUSE || transposed || p.thin == 2)
             img_read_tile(opa, rd);                                // opa.v[r] = {re, im} of P^T's D register r
         if (transposed) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 dst[r * 64 + lane] = opa.v[r];
+        }
+        if (p.thin == 2) {
+            const gptr dst_t = props_t + (size_t)t * TSZ;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                dst_t[r * 64 + lane] = opa.v[r];
         }
         if (FUSE && p.fuse_fwd == 1) {
             // the serial part of the kernel (N hand-overs per member): between the flag read and the flag write there is

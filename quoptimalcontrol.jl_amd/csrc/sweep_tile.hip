@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * kPropWaves, NT == 1 ? 4 : 1) void prop_tile_ke
         tmul_an<NT, false, false>(T, opa, P);
         P = T;
     }
-    if (NT == 1 && p.thin && (t & 1)) {
+    if (NT == 1 && p.thin == 1 && (t & 1)) {
         // rank-one chain (sweep_thin.hip): odd slices are stored transposed -- the A-operand layout of P is the
         // D layout of P^T -- so that its matrix-vector products never convert between vector formats
         conv(opa, P, img, lane);
@@ -1202,7 +1202,7 @@ bool tile_chain_is_split(const TileParams &p, bool keepl)
 // evaluation: E = 256 1.40 / 1.63, 448 2.00 / 2.11, 512 2.35 / 2.12, 1024 3.62 / 3.15, 1536 5.99 / 5.64, 4096 14.3 / 11.9.
 int tile_fuse_forward(const TileParams &p)
 {
-    if (tile_count(p.n) != 1 || !p.thin || std::getenv("GRAPE_NO_FUSE"))
+    if (tile_count(p.n) != 1 || p.thin != 1 || std::getenv("GRAPE_NO_FUSE"))
         return 0;
     if (sizeof(double2) * (4 * (size_t)kTileImage + (size_t)(p.K + 1) * 256) > 64 * 1024)   // generators not staged
         return 0;
@@ -1261,6 +1261,8 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
             if (e != hipSuccess)
                 return e;
         }
+        if (NT == 1 && p.thin == 2)
+            return launch_chain_prop(sandwich, q, stream);             // action_thin.hip: one DPP matrix-vector product per slice
         if (NT == 1 && p.thin)
             return launch_chain_thin(sandwich, q, stream);
     }

@@ -376,3 +376,70 @@ def test_amplitude_scaled_controls(qoc, oracle, monkeypatch):
             assert eng.info["expm_action"] == 1 and eng.info["hoisted_controls"] == 0
             F, G = eng.eval(w.x)
         assert_parity(F, G, F_ref, G_ref, w.n, what=f"scaled controls, dense forms = {dense}")
+
+
+PROP_CASES = [  # n, K, N, E, sys_type, Hermitian generators, Hermitian controls, shared controls
+    (16, 4, 1, 2, "CoherenceTransfer", False, True, True), (16, 3, 2, 3, "StateTransfer", True, True, False),
+    (16, 2, 6, 2, "CoherenceTransfer", False, False, True), (12, 8, 7, 3, "CoherenceTransfer", False, True, False),
+    (9, 1, 8, 2, "StateTransfer", False, False, True), (16, 5, 33, 9, "CoherenceTransfer", False, True, True),
+    (13, 3, 100, 5, "UnitaryGate", True, True, False), (16, 7, 64, 4, "UnitaryGate", False, False, False),
+    (16, 4, 257, 3, "UnitaryGate", False, True, True), (15, 2, 130, 70, "CoherenceTransfer", False, True, True),
+]
+
+
+@pytest.mark.parametrize("n,K,N,E,sys_type,herm_gen,herm_ctrl,shared", PROP_CASES)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_propagator_chain_on_dpp_products(qoc, oracle, monkeypatch, n, K, N, E, sys_type, herm_gen, herm_ctrl, shared, variant):
+    """Ensembles below the Taylor flow's threshold (or with many per-member controls): the expm kernel's propagators
+    (P_t and P_t^T dumps) and chain_prop_kernel -- one DPP matrix-vector product per slice, operands through an LDS-DMA
+    ring -- then the same forms kernels.  Forced here for the small shapes."""
+    monkeypatch.setenv("GRAPE_ACTION", "0")
+    monkeypatch.setenv("GRAPE_THIN_DPP", "1")
+    monkeypatch.setenv("GRAPE_HOIST", "1")
+    sand = sys_type != "UnitaryGate"
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sand, herm_gen, herm_ctrl, seed=11 * n + N + K, shared=shared)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.2, variant=variant,
+                                                             per_member=True)
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N, variant=variant, member_results=True, max_batch=2) as eng:
+        info = eng.info
+        assert info["rank_one_chain"] == 1 and info["expm_action"] == 0 and info["time_chunks"] == 0 and info["fused_forward"] == 0
+        F, G = eng.eval(x)
+        foms, grads = eng.member_results()
+        F2, G2 = eng.eval(x)
+        assert F == F2 and np.array_equal(G, G2)
+        P = eng.trajectory(E - 1, states=False)[0]          # this flow does form the propagators
+        Fb, Gb = eng.eval_batch(np.stack([x, 0.5 * x]))
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k}")
+    assert_parity(F, G, F_ref, G_ref, n, what="ensemble")
+    assert_parity(Fb[0], Gb[0], F_ref, G_ref, n, what="batch entry 0")
+    if sand:
+        P_ref = oracle.member_eval(sys_type, A[-1], B[-1], Xi[-1], Xt[-1], x, 1.2, variant=variant, trajectory=True)[2]
+    else:
+        P_ref = oracle.member_eval_rect(A[-1], B[-1], Xi[-1], Xt[-1], x, 1.2, variant=variant, trajectory=True)[2]
+    assert np.abs(P - P_ref).max() <= 1e-12 * max(1.0, np.abs(P_ref).max())
+    monkeypatch.setenv("GRAPE_THIN_DPP", "0")
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N, variant=variant) as eng:
+        F_c, G_c = eng.eval(x)
+    assert_parity(F, G, F_c, G_c, n, what="DPP chain vs sweep_thin.hip")
+
+
+def test_flow_by_ensemble_size(qoc, oracle, monkeypatch):
+    """9 <= n <= 16, rank-one states: chunked sweep_thin.hip chain for a handful of members, the propagator chain on DPP
+    products from 80, the Taylor flow from 11/8 x compute units (lowered here)."""
+    for name in ("GRAPE_ACTION", "GRAPE_THIN_DPP", "GRAPE_HOIST"):
+        monkeypatch.delenv(name, raising=False)
+    monkeypatch.setenv("GRAPE_ACTION_MIN", "120")
+    n, K, N = 16, 2, 40
+    seen = {}
+    for E in (4, 90, 130):
+        A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, False, True, seed=E)
+        with qoc.GrapeEngine("CoherenceTransfer", A, B, Xi, Xt, wts, 1.0, N, member_results=True) as eng:
+            info = eng.info
+            seen[E] = (info["expm_action"], info["time_chunks"] >= 2)
+            F, G = eng.eval(x)
+            foms, grads = eng.member_results()
+        for k in (0, E - 1):
+            f_ref, g_ref = oracle.member_eval("CoherenceTransfer", A[k], B[k], Xi[k], Xt[k], x, 1.0)[:2]
+            assert_parity(foms[k], grads[k], f_ref, g_ref, n, what=f"E = {E}, member {k}")
+    assert seen == {4: (0, True), 90: (0, False), 130: (1, False)}
