@@ -61,10 +61,12 @@ for i in range(cases):
         B = np.broadcast_to(B[0], B.shape).copy()
         os.environ["GRAPE_HOIST"] = "1"                # (forced for the small ensembles of a soak run; n <= 4 has no such path)
         # rank-one states, n = 9..32: the vector flow of action_thin.hip (forced likewise), or the flows it replaces
-        os.environ["GRAPE_ACTION"] = "1" if rng.random() < 0.7 else "0"
+        os.environ["GRAPE_ACTION"] = "1" if rng.random() < 0.6 else "0"
+        os.environ["GRAPE_THIN_DPP"] = "1" if rng.random() < 0.6 else "0"      # (9..16, not the Taylor flow: chain_prop_kernel / sweep_thin.hip)
     else:
         os.environ.pop("GRAPE_HOIST", None)
         os.environ.pop("GRAPE_ACTION", None)
+        os.environ.pop("GRAPE_THIN_DPP", None)
 
     def vec(m=1):
         v = rng.standard_normal((n, m)) + 1j * rng.standard_normal((n, m))
@@ -89,7 +91,7 @@ for i in range(cases):
     x = rng.uniform(-1, 1, (K, N))
     T = float(rng.uniform(0.3, 2.0))
     what = (f"case {i}: n={n} K={K} N={N} E={E} {sys_type} v{variant} herm={herm} sparse={sparse} states={states} flag={flag} "
-            f"shared_ctrl={shared_ctrl} action={os.environ.get('GRAPE_ACTION', '-')}")
+            f"shared_ctrl={shared_ctrl} action={os.environ.get('GRAPE_ACTION', '-')} dpp={os.environ.get('GRAPE_THIN_DPP', '-')}")
     exact = rng.random() < 0.15 and N <= 33 and states not in ("rect", "vec")      # (the C oracle has no exact gradient for n x m states)
     if exact:                                             # exact gradient of the figure of merit / of the C1 functional
         objective = int(rng.integers(0, 2))
