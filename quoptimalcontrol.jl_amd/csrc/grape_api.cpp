@@ -772,6 +772,9 @@ static long act_min_units(const grape_ctx *c)
     if (const char *e = std::getenv("GRAPE_ACTION_MIN")) return std::atol(e);
     // 9 <= n <= 16: the expm kernel + chain_prop_kernel (one DPP matrix-vector product per slice on the stored propagators)
     // is ahead up to ~350 members (320: 1.34 vs 1.42 ms, 384: 1.50 vs 1.43 ms)
+    // n = 17..32: the alternative is the zero-padded dense 32 x 32 chain, whose time grows with the ensemble while this flow's
+    // 4.7 ms (N = 2000) does not: 64 members 3.26 ms padded, 96: 4.77, 128: 6.07
+    if (c->NT == 2) return 3L * c->compute_units / 8;
     return (c->NT == 1 && !c->pack2 ? 11L : 9L) * c->compute_units / 8;
 }
 
