@@ -20,6 +20,7 @@ stats C3_E1024 GRAPE_X=0 --steps 400 --warmup 50    # (a 36-launch run averages 
 stats C4_E1024 GRAPE_X=0 --config C4 --steps 40 --warmup 5
 stats C4dense_E1024 GRAPE_NO_THIN=1 --config C4 --steps 40 --warmup 5
 stats C4expm_E1024 GRAPE_ACTION=0 --config C4 --steps 40 --warmup 5      # the MFMA expm + vector chain the vector flow replaces at C4
+stats C4_E128 GRAPE_X=0 --config C4 --ensemble 128 --steps 100 --warmup 10      # the per-GPU shard of an 8-GPU run: expm + chain_prop_kernel
 stats C5_E4096 GRAPE_X=0 --config C5 --steps 2 --warmup 1
 stats C5x1 GRAPE_X=0 --config C5 --ensemble 1 --steps 200 --warmup 20     # single problems: the chunked time axis
 stats C4x1 GRAPE_X=0 --config C4 --ensemble 1 --steps 200 --warmup 20
