@@ -179,6 +179,10 @@ typedef struct grape_info {
                                       (n <= 16): exp(G_t) is applied to the two chains' vectors by its
                                       Taylor series (matrix-vector products only); no propagator is formed, so
                                       grape_get_trajectory has none to return -- GRAPE_FLAG_KEEP_COSTATES keeps the dense flow */
+    int32_t prop_chain;            /* 1: rank-one states (rank_one_chain), 9 <= n <= 16, ensembles below expm_action's threshold
+                                      (down to one problem): the expm kernel stores P_t and P_t^T and both vector chains run on
+                                      them with one matrix-vector product per slice (chain_prop_kernel); with time_chunks >= 2
+                                      on a chunked time axis (a workgroup per member and chunk) */
 } grape_info;
 
 /* Opaque RCCL bootstrap token (ncclUniqueId), see grape_comm_unique_id / grape_comm_attach. */

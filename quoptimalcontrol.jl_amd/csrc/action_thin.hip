@@ -481,18 +481,31 @@ __global__ __launch_bounds__(64) void chain_prop_kernel(const TileParams p)
     if (k >= p.E)
         return;
     const size_t kw = (size_t)y * p.E + k;
+    // Small ensembles (grid.z = chunk, p.tp_chunks > 1): this workgroup walks the slices [lo, hi) only -- forward from v_lo,
+    // backward from w_hi, both handed over by the scan launch (this kernel again, with the chunk products in the place of
+    // the propagators: launch_chain_prop) in p.tp_vec: [direction][control array][unit][element][chunk boundary 0 .. C]
+    const int C = p.tp_chunks > 1 ? p.tp_chunks : 1, ch = blockIdx.z;
+    const int lo = C > 1 ? ch * p.tp_S : 0, hi = C > 1 ? min(N, lo + p.tp_S) : N, len = hi - lo;
     // entry (row, col) of a dump sits at 64 (row >> 2) + 16 (row & 3) + col.  Forward: rows of P_t = columns of the P_t^T dump,
     // backward: rows of P_t' = conjugated columns of the P_t dump: entry (8h + j, r) of either, consecutive across the lanes r
     const double2 *__restrict__ Pk = (d ? p.props : p.props_t) + kw * (size_t)N * 256 + 128 * h + r;
     const double sgn = d ? -1.0 : 1.0;                            // backward: the conjugate
     double2 *__restrict__ rec = (d ? p.wrec : p.states) + kw * (size_t)(N + 1) * 16 + (size_t)r * (N + 1);
+    double2 *rec0 = rec + (d ? N : 0);                            // where the chain's first vector is recorded
     double vr, vi;
-    {
+    if (C > 1) {
+        double2 *start = p.tp_vec + (((size_t)d * gridDim.y * p.E + kw) * 16 + r) * (size_t)(C + 1) + ch + d;
+        const double2 t2 = *start;
+        vr = t2.x;
+        vi = t2.y;
+        if (d ? ch != C - 1 : ch != 0)                            // v_lo / w_hi are recorded by the neighbouring chunk's last step:
+            rec0 = start;                                         // the prologue's stores rewrite the hand-over entry with itself
+    } else {
         const double2 t2 = p.vecs[(size_t)k * 32 + d * 16 + r];
         vr = t2.x;
         vi = t2.y;
     }
-    rec[d ? N : 0] = make_double2(vr, vi);
+    *rec0 = make_double2(vr, vi);
     // The dumps come from HBM (E N x 4 KB each, nothing of it cached) at ~1 us latency and the chain consumes a slice every
     // ~0.3 us.  A register ring (32 registers per slice) holds four slices at most: 0.875 us per slice measured, 0.325 with
     // the operands cached.  So the ring lives in LDS and is filled by LDS-DMA (global_load_lds_dwordx4: one instruction =
@@ -505,9 +518,9 @@ __global__ __launch_bounds__(64) void chain_prop_kernel(const TileParams p)
     extern __shared__ double2 s_ring_all[];
     const unsigned ring0 = (unsigned)(size_t)s_ring_all + (unsigned)wave * (kRing * 8192);
     auto dma = [&](int slot, int i) {                             // slice of step i -> ring slot (clamped: always eight loads)
-        const int ic = min(i, N - 1);
+        const int ic = min(i, len - 1);
         // entry j of the lane: 256 j bytes further on.  The instruction offset moves the LDS address too: M0 advances by 1024 - 256
-        const double2 *src = Pk + (size_t)(d ? N - 1 - ic : ic) * 256;
+        const double2 *src = Pk + (size_t)(d ? hi - 1 - ic : lo + ic) * 256;
         const unsigned dst = ring0 + (unsigned)slot * 8192u;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\t"
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(64) void chain_prop_kernel(const TileParams p)
     for (int u = 0; u < kRing; ++u) {
         dma(u, u);
         if (u + 1 < kRing)                                        // keep the "8 loads, 1 store" rhythm of the steady state
-            rec[d ? N : 0] = make_double2(vr, vi);
+            *rec0 = make_double2(vr, vi);
     }
     double xr = rot8_odd_rows(vr), xi = rot8_odd_rows(vi);
     auto step = [&](int slot, int i) {
@@ -550,12 +563,12 @@ __global__ __launch_bounds__(64) void chain_prop_kernel(const TileParams p)
         swap16(yr, yi);                                           // h = 0 rows: both real halves; h = 1 rows: both imaginary halves
         double part = yr + yi, other = part;
         swap16(part, other);                                      // part: real part in every row, other: imaginary part
-        rec[d ? N - 1 - i : i + 1] = make_double2(part, other);   // (element r, from both rows: the same value)
+        rec[d ? hi - 1 - i : lo + i + 1] = make_double2(part, other);   // (element r, from both rows: the same value)
         xr = rot8_odd_rows(part);
         xi = rot8_odd_rows(other);
     };
     int i = 0;
-    for (; i + kRing <= N; i += kRing) {
+    for (; i + kRing <= len; i += kRing) {
         step(0, i);
         step(1, i + 1);
         step(2, i + 2);
@@ -565,12 +578,12 @@ __global__ __launch_bounds__(64) void chain_prop_kernel(const TileParams p)
         step(6, i + 6);
     }
     static_assert(kRing == 7, "unrolled by hand");
-    if (i + 0 < N) step(0, i);
-    if (i + 1 < N) step(1, i + 1);
-    if (i + 2 < N) step(2, i + 2);
-    if (i + 3 < N) step(3, i + 3);
-    if (i + 4 < N) step(4, i + 4);
-    if (i + 5 < N) step(5, i + 5);
+    if (i + 0 < len) step(0, i);
+    if (i + 1 < len) step(1, i + 1);
+    if (i + 2 < len) step(2, i + 2);
+    if (i + 3 < len) step(3, i + 3);
+    if (i + 4 < len) step(4, i + 4);
+    if (i + 5 < len) step(5, i + 5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // DMA loads still in flight target this wave's LDS
 }
 
@@ -830,7 +843,24 @@ hipError_t launch_chain_prop(int sandwich, const TileParams &p, hipStream_t stre
         return hipErrorInvalidValue;
     // one member per workgroup: its LDS ring (7 slices x 8 KB) lets two of them share a compute unit
     const size_t lds = 7 * 8192;
-    hipLaunchKernelGGL(chain_prop_kernel, dim3(p.E, p.n_x), dim3(64), lds, stream, p);
+    if (p.tp_chunks > 1) {
+        // small ensembles, the time axis in chunks (the chunk products Q_c and Q_c^T are there: chunk_product_deep_kernel,
+        // launched by launch_nt): the vectors at the chunk boundaries by this kernel on the chunk products -- C dependent
+        // products -- then a workgroup per (member, chunk) on the propagators
+        if (!p.tp_q || !p.tp_qt || !p.tp_vec)
+            return hipErrorInvalidValue;
+        TileParams s = p;
+        s.props = p.tp_q;
+        s.props_t = p.tp_qt;
+        s.N = p.tp_chunks;
+        s.tp_chunks = 0;
+        s.states = p.tp_vec;
+        s.wrec = p.tp_vec + (size_t)p.n_x * p.E * 16 * (p.tp_chunks + 1);
+        hipLaunchKernelGGL(chain_prop_kernel, dim3(p.E, p.n_x), dim3(64), lds, stream, s);
+        hipLaunchKernelGGL(chain_prop_kernel, dim3(p.E, p.n_x, p.tp_chunks), dim3(64), lds, stream, p);
+    } else {
+        hipLaunchKernelGGL(chain_prop_kernel, dim3(p.E, p.n_x), dim3(64), lds, stream, p);
+    }
     return launch_forms_nb<16>(sandwich, p, stream);
 }
 

@@ -941,7 +941,32 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     }
     // ONE rank-one problem is latency-bound either way, and the dense chunked flows (two-level scan, 4-slice chunks) are
     // ahead of the vector chain's chunked mode there: 0.083 vs 0.100 ms per evaluation for C4's operators, N = 1000
-    if (thin && E == 1 && c->cfg.n_slices >= 64 && !env_on("GRAPE_NO_TP") && !env_on("GRAPE_THIN_SINGLE"))
+    // (superseded where the propagator chain of action_thin.hip runs: it takes a chunked time axis too -- below)
+    // Small ensembles of rank-one problems, down to ONE: expm kernel (P_t and P_t^T stored), chunk products, then
+    // chain_prop_kernel twice -- on the chunk products for the vectors at the chunk boundaries, on the propagators with a
+    // workgroup per (member, chunk).  GRAPE_DPP_CHUNKS=0 keeps sweep_thin.hip's chunked chain / the dense flows there.
+    const char *dpp_env = std::getenv("GRAPE_THIN_DPP"), *hoist_env = std::getenv("GRAPE_HOIST"), *dppc_env = std::getenv("GRAPE_DPP_CHUNKS");
+    const long dpp_min = dpp_env && dpp_env[0] == '1' ? 2 : (dpp_env && dpp_env[0] != '0' ? std::atol(dpp_env) : 80);
+    bool dpp_small = thin && !act_only && !act_forced && !(dpp_env && dpp_env[0] == '0') && !(hoist_env && hoist_env[0] == '0') &&
+                     !(dppc_env && dppc_env[0] == '0') && !env_on("GRAPE_NO_TP") && !env_on("GRAPE_THIN_SINGLE") &&
+                     (long)E < std::min(dpp_min, 41L) && c->cfg.n_slices >= 64;
+    if (dpp_small && !(dppc_env && dppc_env[0] == '1')) {
+        // ... where the control operators are sparse (at most six non-zeros per row: Pauli-type controls, their Liouville-space
+        // commutators): the forms kernel then reads (value, column) lists.  With dense operators its 256 complex
+        // multiply-adds per (slice, control) on the vector ALU cost more than the chain saves (16 x 16, N = 1000, K = 4,
+        // one problem / eight: 0.090 / 0.138 ms against 0.085 / 0.126 of the flows this replaces; sparse: 0.075 / 0.099).
+        int rmax = 0;
+        for (size_t q = 0; q < (ctrl_shared ? 1 : E) * K && rmax <= 6; ++q)
+            for (int row = 0; row < n && rmax <= 6; ++row) {
+                int cnt = 0;
+                for (int col = 0; col < n; ++col)
+                    cnt += (B[2 * (q * nn + row + (size_t)n * col)] != 0.0 || B[2 * (q * nn + row + (size_t)n * col) + 1] != 0.0) ? 1 : 0;
+                rmax = std::max(rmax, cnt);
+            }
+        if (rmax > 6 || env_on("GRAPE_FORMS_DENSE"))
+            dpp_small = false;
+    }
+    if (thin && E == 1 && c->cfg.n_slices >= 64 && !env_on("GRAPE_NO_TP") && !env_on("GRAPE_THIN_SINGLE") && !dpp_small)
         thin = false;
     c->thin = thin;
     {                                                        // Hermitian control operators?
@@ -986,7 +1011,10 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         for (size_t k = 1; k < E && invariant; ++k)
             invariant = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
         // (32 x 32: the new kernel is also the four-waves-per-propagator one -- single problems take it too)
-        if (hz && invariant && !(he && he[0] == '1') && c->EU < 8 && c->NT == 1) hz = false;
+        if (hz && invariant && !(he && he[0] == '1') && c->EU < 8 && c->NT == 1) {
+            if (dpp_small) invariant = false;                    // (that flow needs this kernel's two dumps: the in-kernel sum, no pre-pass)
+            else hz = false;
+        }
         c->hoist = hz ? (invariant ? 1 : 2) : 0;
         if (hz) {
             const double dt = c->cfg.duration / c->cfg.n_slices;
@@ -1071,6 +1099,18 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                 c->tp_S = (int)((N + C - 1) / C);
                 c->tp_C = (int)((N + c->tp_S - 1) / c->tp_S);
             }
+        } else if (dpp_small) {
+            // critical path: S dependent 16 x 16 products (0.6 us each) + S chain steps (0.3) + C scan steps (0.2) --
+            // S = sqrt(N / 4.5), 16 at N = 1000 (measured, one problem: 16 / 22 / 32 slices 74 / 76 / 78 us); a workgroup's LDS
+            // ring lets two share a compute unit
+            long s_lat = std::max(4L, std::lround(std::sqrt((double)N / 4.0)));
+            long C = std::min(2L * c->compute_units / units, (N + s_lat - 1) / s_lat);
+            if (const char *e = std::getenv("GRAPE_TP_CHUNKS")) C = std::atol(e);
+            if (C > N / 2) C = N / 2;
+            if (C >= 2) {
+                c->tp_S = (int)((N + C - 1) / C);
+                c->tp_C = (int)((N + c->tp_S - 1) / c->tp_S);
+            }
         } else if (small && thin && N >= 32 && 4 * units < slots) {      // C4's shape: 128 members 1.18 -> 0.87 ms, 256 members 1.39 -> 1.53
                                                                           // (and from half a device on, the fused forward pass)
             // measured optimum at C4's shape (N = 1000): 16..32 slices per chunk for 1..16 members (tools/single_open.py)
@@ -1087,7 +1127,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         }
         if (c->tp_C) {
             const size_t tsz = (size_t)c->NT * c->NT * 256, rows = (size_t)c->EU * c->B;
-            const size_t dumps = (general ? 2 : 1) * (size_t)c->tp_C;     // general flow: [Q_c | Q_c^T] and [R_c | U_c^T]
+            const size_t dumps = ((general || dpp_small) ? 2 : 1) * (size_t)c->tp_C;     // general flow: [Q_c | Q_c^T] and [R_c | U_c^T]
             auto ensure = [&](void **ptr, size_t *cap, size_t bytes) -> hipError_t {
                 if (*cap >= bytes)
                     return hipSuccess;
@@ -1103,7 +1143,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             HIP_TRY(c, ensure((void **)&c->d_tp_q, &c->tp_cap[0], sizeof(double2) * rows * tsz * dumps));
             HIP_TRY(c, ensure((void **)&c->d_tp_r, &c->tp_cap[1], sizeof(double2) * rows * tsz * dumps));
             HIP_TRY(c, ensure((void **)&c->d_tp_m, &c->tp_cap[2], sizeof(double2) * rows * tsz));
-            HIP_TRY(c, ensure((void **)&c->d_tp_vec, &c->tp_cap[3], sizeof(double2) * rows * 32 * c->tp_C));
+            HIP_TRY(c, ensure((void **)&c->d_tp_vec, &c->tp_cap[3], sizeof(double2) * rows * 32 * ((size_t)c->tp_C + 1)));
             HIP_TRY(c, ensure((void **)&c->d_tp_z, &c->tp_cap[4], sizeof(double) * rows * 128));
             // unitary flow, many chunks: two-level scan over groups of ~sqrt(C) chunks
             c->tp_G = c->tp_g = 0;
@@ -1129,13 +1169,14 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // measured at C4's shape against sweep_thin.hip's chain (chunked time axis below 256 members): 64 members 0.42 vs 0.33 ms,
         // 96: 0.51 vs 0.60, 128: 0.60 vs 0.70, 256: 1.03 vs 1.27, 384: 1.50 vs 1.65, 512: 1.82 vs 1.64 (that chain reads P_t
         // once where the forward pass is fused into the expm kernel; this flow writes and reads it twice)
-        const long dpp_min = de && de[0] == '1' ? 2 : (de && de[0] != '0' ? std::atol(de) : 80);
         // (needs the round-3 expm kernel, which writes both dumps: c->hoist != 0, i.e. at least 8 units)
-        const bool dpp = thin && !act && !act_only && c->hoist != 0 && !(de && de[0] == '0') && (long)E >= dpp_min &&
+        const bool dpp_chunked = dpp_small && c->tp_C > 1;       // (below dpp_min members: only with the chunked time axis)
+        const bool dpp = thin && !act && !act_only && c->hoist != 0 && !(de && de[0] == '0') && ((long)E >= dpp_min || dpp_chunked) &&
                          ((de && de[0] == '1') || (long)E < 7L * c->compute_units / 4);
         c->thin_dpp = dpp;
         if (act || dpp) {
-            c->tp_C = c->tp_S = c->tp_G = c->tp_g = 0;
+            if (!(dpp && dpp_chunked))
+                c->tp_C = c->tp_S = c->tp_G = c->tp_g = 0;
             const double dt = c->cfg.duration / c->cfg.n_slices;
             const int nd = c->cfg.n;
             const size_t VV = VS * VS;
@@ -1327,7 +1368,7 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.tp_groups = c->tp_C ? c->tp_G : 0;
     p.tp_gsize = c->tp_g;
     p.tp_a = c->d_tp_a;
-    if (c->tp_C && !c->unitary && !c->thin) {                // general flow: second halves of the dump buffers
+    if (c->tp_C && ((!c->unitary && !c->thin) || c->thin_dpp)) {   // general flow / chunked propagator chain: second halves of the dump buffers
         const size_t half = (size_t)c->EU * c->B * c->tp_C * c->NT * c->NT * 256;
         p.tp_qt = c->d_tp_q + half;
         p.tp_u = c->d_tp_r + half;
@@ -2683,6 +2724,7 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
         info->time_chunks = s0->tp_C;
         info->hoisted_controls = s0->hoist == 1 ? 1 : 0;
         info->expm_action = s0->action ? 1 : 0;
+        info->prop_chain = s0->thin_dpp ? 1 : 0;
     }
     return GRAPE_OK;
 }

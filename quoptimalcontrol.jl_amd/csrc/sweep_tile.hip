@@ -1035,6 +1035,44 @@ __global__ __launch_bounds__(64) void chunk_product_kernel(const TileParams p)
     tstore(p.tp_q + (kw * C + c) * TSZ, Y, lane);
 }
 
+// The same for 16 x 16 with kDeep propagators in flight (registers: 16 per dump): a chunk's products are dependent and take
+// ~0.2 us each, a dump from HBM / Infinity Cache ~1 us -- with one dump ahead the chain ran at 0.64 (one problem, 22-slice
+// chunks) .. 0.96 us (64 members, 125-slice chunks) per slice.  Used by the chunked propagator chain of action_thin.hip.
+constexpr int kDeep = 6;
+__global__ __launch_bounds__(64) void chunk_product_deep_kernel(const TileParams p)
+{
+    constexpr int TSZ = 256;
+    extern __shared__ double2 s_dynt[];
+    const int lane = threadIdx.x, k = blockIdx.x, c = blockIdx.z;
+    const int N = p.N, C = p.tp_chunks;
+    const size_t kw = (size_t)blockIdx.y * p.E + k;
+    const double2 *__restrict__ Pk = p.props + kw * N * TSZ;
+    const int t_lo = c * p.tp_S, t_hi = min(N, t_lo + p.tp_S);
+    TMat<1> V, Y, ring[kDeep];
+    tidentity(V, lane);
+#pragma unroll
+    for (int u = 0; u < kDeep; ++u) {
+        tload(ring[u], Pk + (size_t)max(t_hi - 1 - u, t_lo) * TSZ, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int t = t_hi - 1; t >= t_lo; t -= kDeep) {                // V <- P_t^T V: ends as (P_hi-1 ... P_lo)^T
+#pragma unroll
+        for (int u = 0; u < kDeep; ++u) {
+            if (t - u >= t_lo) {
+                tmul_tn<1, false, false>(Y, ring[u], V);
+                V = Y;
+            }
+            __builtin_amdgcn_sched_barrier(0);                     // (the scheduler issued the six refills youngest-first: every
+            tload(ring[u], Pk + (size_t)max(t - u - kDeep, t_lo) * TSZ, lane);   //  product then waited for all of them)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (p.tp_qt)
+        tstore(p.tp_qt + (kw * C + c) * TSZ, V, lane);
+    transpose_via_a_layout(Y, V, s_dynt, lane);
+    tstore(p.tp_q + (kw * C + c) * TSZ, Y, lane);
+}
+
 // general (non-unitary) flow: U_c = Q_c-1 ... Q_0 (handed out transposed: a free left factor) and R_c = Q_C-1 ... Q_c+1,
 // one wavefront per direction.  GROUPS: the two-level form -- blockIdx.z >> 1 is a group of tp_gsize consecutive chunks,
 // the products stay inside the group, and the suffix wavefront also hands out the group's own product (plain and
@@ -1261,8 +1299,18 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
             if (e != hipSuccess)
                 return e;
         }
-        if (NT == 1 && p.thin == 2)
-            return launch_chain_prop(sandwich, q, stream);             // action_thin.hip: one DPP matrix-vector product per slice
+        if constexpr (NT == 1) {
+            if (p.thin == 2) {
+                if (p.tp_chunks > 1) {                                 // small ensembles: Q_c and Q_c^T of every chunk of the time axis
+                    hipLaunchKernelGGL(chunk_product_deep_kernel, dim3(p.E, p.n_x, p.tp_chunks), dim3(64),
+                                       sizeof(double2) * (kTileImage + 1), stream, q);
+                    e = hipGetLastError();
+                    if (e != hipSuccess)
+                        return e;
+                }
+                return launch_chain_prop(sandwich, q, stream);         // action_thin.hip: one DPP matrix-vector product per slice
+            }
+        }
         if (NT == 1 && p.thin)
             return launch_chain_thin(sandwich, q, stream);
     }

@@ -70,7 +70,7 @@ class GrapeInfo(C.Structure):
                 ("states_stored", C.c_int32), ("rank_one_chain", C.c_int32),
                 ("sparse_controls", C.c_int32), ("fused_forward", C.c_int32),
                 ("time_chunks", C.c_int32), ("hoisted_controls", C.c_int32),
-                ("expm_action", C.c_int32)]
+                ("expm_action", C.c_int32), ("prop_chain", C.c_int32)]
 
 
 class GrapeLbfgsOptions(C.Structure):

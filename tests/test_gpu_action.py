@@ -424,6 +424,101 @@ def test_propagator_chain_on_dpp_products(qoc, oracle, monkeypatch, n, K, N, E, 
     assert_parity(F, G, F_c, G_c, n, what="DPP chain vs sweep_thin.hip")
 
 
+CHUNK_CASES = [  # n, K, N, E, sys_type, Hermitian generators, Hermitian controls, shared controls, chunks (None: the library's choice)
+    (16, 4, 64, 1, "CoherenceTransfer", False, True, True, None), (16, 4, 1000, 1, "CoherenceTransfer", False, True, True, None),
+    (16, 3, 100, 2, "StateTransfer", True, True, False, 3), (12, 2, 65, 3, "CoherenceTransfer", False, False, True, 32),
+    (9, 1, 257, 5, "UnitaryGate", False, False, True, 2), (16, 7, 130, 4, "UnitaryGate", False, False, False, 13),
+    (13, 3, 200, 40, "StateTransfer", False, True, True, None), (15, 2, 130, 33, "CoherenceTransfer", False, True, True, None),
+    (16, 2, 71, 1, "UnitaryGate", True, True, True, 10), (16, 5, 99, 9, "CoherenceTransfer", False, True, True, 7),
+]
+
+
+@pytest.mark.parametrize("n,K,N,E,sys_type,herm_gen,herm_ctrl,shared,chunks", CHUNK_CASES)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_propagator_chain_on_a_chunked_time_axis(qoc, oracle, monkeypatch, n, K, N, E, sys_type, herm_gen, herm_ctrl, shared,
+                                                 chunks, variant):
+    """Fewer than 80 rank-one members, down to ONE problem (src/solve.jl:63-143): expm kernel, chunk products, then
+    chain_prop_kernel on the chunk products (the vectors at the chunk boundaries) and on the propagators with a workgroup
+    per (member, chunk) -- ragged last chunks, chunks shorter than the operand ring, two chunks."""
+    for name in ("GRAPE_ACTION", "GRAPE_THIN_DPP", "GRAPE_HOIST"):
+        monkeypatch.delenv(name, raising=False)
+    monkeypatch.setenv("GRAPE_DPP_CHUNKS", "1")              # (dense control operators here: not the library's choice)
+    if chunks:
+        monkeypatch.setenv("GRAPE_TP_CHUNKS", str(chunks))
+    sand = sys_type != "UnitaryGate"
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sand, herm_gen, herm_ctrl, seed=7 * n + N + K, shared=shared)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.2, variant=variant,
+                                                             per_member=True)
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N, variant=variant, member_results=True, max_batch=2) as eng:
+        info = eng.info
+        assert info["rank_one_chain"] == 1 and info["prop_chain"] == 1 and info["expm_action"] == 0 and info["time_chunks"] >= 2
+        F, G = eng.eval(x)
+        foms, grads = eng.member_results()
+        F2, G2 = eng.eval(x)
+        assert F == F2 and np.array_equal(G, G2)
+        P = eng.trajectory(E - 1, states=False)[0]
+        Fb, Gb = eng.eval_batch(np.stack([0.5 * x, x]))
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k}")
+    assert_parity(F, G, F_ref, G_ref, n, what="ensemble")
+    assert_parity(Fb[1], Gb[1], F_ref, G_ref, n, what="batch entry 1")
+    if sand:
+        P_ref = oracle.member_eval(sys_type, A[-1], B[-1], Xi[-1], Xt[-1], x, 1.2, variant=variant, trajectory=True)[2]
+    else:
+        P_ref = oracle.member_eval_rect(A[-1], B[-1], Xi[-1], Xt[-1], x, 1.2, variant=variant, trajectory=True)[2]
+    assert np.abs(P - P_ref).max() <= 1e-12 * max(1.0, np.abs(P_ref).max())
+    monkeypatch.setenv("GRAPE_DPP_CHUNKS", "0")
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N, variant=variant) as eng:
+        assert eng.info["prop_chain"] == 0
+        F_c, G_c = eng.eval(x)
+    assert_parity(F, G, F_c, G_c, n, what="chunked propagator chain vs the round-2 flows")
+
+
+@pytest.mark.parametrize("terms,herm_ctrl,sys_type,E,N,chunks,shared", [
+    (1, True, "CoherenceTransfer", 1, 1000, None, True), (2, True, "CoherenceTransfer", 3, 200, None, True),
+    (2, False, "CoherenceTransfer", 2, 130, 3, True), (3, True, "StateTransfer", 5, 64, 2, False),
+    (4, False, "StateTransfer", 1, 257, 9, True), (2, True, "UnitaryGate", 4, 99, 33, False),
+    (6, False, "UnitaryGate", 2, 71, None, True), (7, True, "CoherenceTransfer", 2, 100, None, True)])
+def test_chunked_chain_with_sparse_controls(qoc, oracle, monkeypatch, terms, herm_ctrl, sys_type, E, N, chunks, shared):
+    """A handful of members with sparse control operators (sums of `terms` Pauli strings; shared or the members' own) on the
+    chunked propagator chain: the (value, column) list forms kernels and the dense one read the records of every chunk."""
+    for name in ("GRAPE_ACTION", "GRAPE_THIN_DPP", "GRAPE_HOIST", "GRAPE_DPP_CHUNKS"):
+        monkeypatch.delenv(name, raising=False)
+    if chunks:
+        monkeypatch.setenv("GRAPE_TP_CHUNKS", str(chunks))
+    n, K = 16, 3
+    rng = np.random.default_rng(10 * terms + herm_ctrl + E)
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sys_type != "UnitaryGate", False, True, seed=terms + N)
+
+    def controls():
+        out = []
+        for _ in range(K):
+            M = sum(rng.uniform(0.2, 1.0) * _pauli_string(rng) for _ in range(terms))
+            if not herm_ctrl:
+                M = M * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+            out.append(0.4 * M)
+        return out
+    B0 = controls()
+    B = np.array([B0 if shared else controls() for _ in range(E)])
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.0, per_member=True)
+    res = []
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("GRAPE_FORMS_DENSE", "1")
+        if dense or terms > 6:                               # (the library picks this flow for at most six non-zeros per row)
+            monkeypatch.setenv("GRAPE_DPP_CHUNKS", "1")
+        with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.0, N, member_results=True, max_batch=2) as eng:
+            assert eng.info["prop_chain"] == 1 and eng.info["time_chunks"] >= 2
+            res.append(eng.eval(x))
+            foms, grads = eng.member_results()
+            for k in range(E):
+                assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k}, dense={dense}")
+            Fb, Gb = eng.eval_batch(np.stack([x, -x]))
+            assert_parity(Fb[0], Gb[0], F_ref, G_ref, n, what="batch entry 0")
+        assert_parity(res[-1][0], res[-1][1], F_ref, G_ref, n, what=f"{terms} terms, dense={dense}")
+    assert_parity(res[0][0], res[0][1], res[1][0], res[1][1], n, what="list forms kernel vs dense forms kernel")
+
+
 def test_flow_by_ensemble_size(qoc, oracle, monkeypatch):
     """9 <= n <= 16, rank-one states: chunked sweep_thin.hip chain for a handful of members, the propagator chain on DPP
     products from 80, the Taylor flow from 11/8 x compute units (lowered here)."""
