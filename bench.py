@@ -160,7 +160,17 @@ def tile_kernel_models(local, info):
         return act, forms
     expm = {"name": "expm: " + ("ctrl_sum_kernel + prop_hoist kernel" if info.get("hoisted_controls") else "prop_tile_kernel"),
             "flops": units * N * 3 * prod, "bytes": units * N * tsz + (units * (N + 1) * 256 if fused else 0)}
-    if thin:
+    if thin and info.get("prop_chain"):
+        # csrc/action_thin.hip: P_t and P_t^T written by the expm kernel, each read once by its vector chain (one DPP
+        # matrix-vector product per slice and chain), the records written and read back by the forms kernel; on a chunked
+        # time axis (small ensembles) the chunk products read P_t once more and cost one matrix product per slice
+        C = int(info.get("time_chunks") or 0)
+        expm["bytes"] = 2 * units * N * tsz
+        chain = {"name": ("chunk_product_deep_kernel + chain_prop_kernel x 2 (scan, chunks)" if C > 1 else "chain_prop_kernel") +
+                         " + action_forms kernel (vector FP64)",
+                 "flops": units * N * (2 * 8 * 256 + K * 8 * (256 + 16)) + (units * N * prod if C > 1 else 0),
+                 "bytes": units * N * tsz * (3 if C > 1 else 2) + 4 * units * (N + 1) * 256 + units * K * N * 8, "pipe": "valu_fp64"}
+    elif thin:
         chain = {"name": "chain_thin_kernel (matrix-vector chain" + (", backward pass only)" if fused else ", both passes)"),
                  "flops": units * N * ((1 if fused else 2) * 8 * 256 + K * 14 * 256),
                  "bytes": units * N * tsz * (1 if fused else 2) + units * (N + 1) * 256 * (1 if fused else 2)}
@@ -301,8 +311,11 @@ def run_extra_config(qoc, name, dev_index, steps, warmup):
     if "x" in cfg_name:                                    # "C5x1": the config's shape with that many members
         cfg_name, members = cfg_name.split("x")[0], int(cfg_name.split("x")[1])
     w = qoc.workloads.config(cfg_name, E=members) if members else qoc.workloads.config(cfg_name)
+    # latency-bound lines (hundreds of ~0.1 ms steps): HIP events around one evaluation in eight, as in the headline run -- a
+    # pair of events costs ~5 us of such a call
+    sampled = qoc.engine.FLAG_TIME_SAMPLED if steps >= 100 else 0
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, device=dev_index,
-                         flags=qoc.engine.FLAG_TIME_KERNELS | (qoc.engine.FLAG_FORCE_GENERAL if dense else 0)) as eng:
+                         flags=qoc.engine.FLAG_TIME_KERNELS | sampled | (qoc.engine.FLAG_FORCE_GENERAL if dense else 0)) as eng:
         import numpy as np
         xf = np.ascontiguousarray(w.x.T)
         call = eng.bind_eval(xf, np.empty_like(xf))           # the same copy-free host->host call as the headline step

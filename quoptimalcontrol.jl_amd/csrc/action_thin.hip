@@ -32,6 +32,7 @@
 // with the (member-invariant) B_c read through scalar loads.
 #include "grape_kernels.hpp"
 #include "cmat.hpp"
+#include "tile.hpp"
 #include <cstdlib>
 
 namespace grape {
@@ -669,6 +670,111 @@ __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
     }
 }
 
+// DENSE control operators, n <= 16, on the matrix cores: the records of 16 slices ARE a 16 x 16 matrix V (element-major:
+// row = element, column = slice), so (B_c v_t) for 16 slices is one complex 16 x 16 product -- 16 v_mfma_f64_16x16x4 with
+// B_c as the A operand (lane l: B_c[l & 15][4 kb + (l >> 4)]) and the records as the B operand (lane l: element
+// 4 kb + (l >> 4) of slice l & 15, loaded as they lie) -- instead of 1024 FMAs per lane; the result's D layout puts
+// rows 4 r + (l >> 4) of column l & 15 in the lane, which is where the lane's w entries are, so conj(w_t)' (B_c v_t) is four
+// complex multiply-adds per lane and two cross-lane additions.  A wavefront serves 64 slices as four such tiles.
+template <int SAND, bool HERMB>
+__global__ __launch_bounds__(64) void action_forms_mfma_kernel(const TileParams p)
+{
+    constexpr bool NEEDB = SAND && !HERMB;
+    const int lane = threadIdx.x, k = blockIdx.y, y = blockIdx.z, K = p.K, N = p.N;
+    const int col = lane & 15, g = lane >> 4, t0 = blockIdx.x * 64;
+    const size_t kw = (size_t)y * p.E + k;
+    const double2 *__restrict__ V = p.states + kw * (size_t)(N + 1) * 16;
+    const double2 *__restrict__ W = p.wrec + kw * (size_t)(N + 1) * 16;
+    double vr[4][4], vi[4][4], wr[4][4], wi[4][4];                // [tile][kb]: element 4 kb + g at slice t0 + 16 tile + col
+#pragma unroll
+    for (int tile = 0; tile < 4; ++tile) {
+        const int tc = min(t0 + 16 * tile + col, N - 1);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const double2 a = V[(size_t)(4 * kb + g) * (N + 1) + tc], b = W[(size_t)(4 * kb + g) * (N + 1) + tc];
+            vr[tile][kb] = a.x;
+            vi[tile][kb] = a.y;
+            wr[tile][kb] = b.x;
+            wi[tile][kb] = b.y;
+        }
+    }
+    double s_re = 0.0, s_im = 0.0;                                // s = w_N' v_N (uniform)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const double2 a = V[(size_t)i * (N + 1) + N], b = W[(size_t)i * (N + 1) + N];
+        s_re = fma(b.x, a.x, fma(b.y, a.y, s_re));
+        s_im = fma(b.x, a.y, fma(-b.y, a.x, s_im));
+    }
+    const double gs = SAND ? -p.dt * (HERMB ? 2.0 : 1.0) : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
+    double *__restrict__ out_member = p.member_out + ((size_t)y * p.E_members + k) * ((size_t)K * N + 1);
+    for (int c = 0; c < K; ++c) {
+        const double2 *__restrict__ Bc = p.act_bf + ((size_t)(p.act_shared ? 0 : k) * K + c) * 256;
+        double br[4], bi[4], nbi[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const double2 b = Bc[col * 16 + 4 * kb + g];
+            br[kb] = b.x;
+            bi[kb] = b.y;
+            nbi[kb] = -b.y;
+        }
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            d4 ur = {0.0, 0.0, 0.0, 0.0}, ui = ur, zr = ur, zi = ur;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {                      // U = B_c V (and Z = B_c W)
+                ur = __builtin_amdgcn_mfma_f64_16x16x4f64(br[kb], vr[tile][kb], ur, 0, 0, 0);
+                ui = __builtin_amdgcn_mfma_f64_16x16x4f64(br[kb], vi[tile][kb], ui, 0, 0, 0);
+                if (NEEDB) {
+                    zr = __builtin_amdgcn_mfma_f64_16x16x4f64(br[kb], wr[tile][kb], zr, 0, 0, 0);
+                    zi = __builtin_amdgcn_mfma_f64_16x16x4f64(br[kb], wi[tile][kb], zi, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                ur = __builtin_amdgcn_mfma_f64_16x16x4f64(nbi[kb], vi[tile][kb], ur, 0, 0, 0);
+                ui = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[kb], vr[tile][kb], ui, 0, 0, 0);
+                if (NEEDB) {
+                    zr = __builtin_amdgcn_mfma_f64_16x16x4f64(nbi[kb], wi[tile][kb], zr, 0, 0, 0);
+                    zi = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[kb], wr[tile][kb], zi, 0, 0, 0);
+                }
+            }
+            double a_r = 0.0, a_i = 0.0, b_r = 0.0, b_i = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                         // rows 4 r + g of the lane's column
+                a_r = fma(wr[tile][r], ur[r], fma(wi[tile][r], ui[r], a_r));      // conj(w[i]) (B v)[i]
+                a_i = fma(wr[tile][r], ui[r], fma(-wi[tile][r], ur[r], a_i));
+                if (NEEDB) {
+                    b_r = fma(vr[tile][r], zr[r], fma(vi[tile][r], zi[r], b_r));  // conj(v[i]) (B w)[i]
+                    b_i = fma(vr[tile][r], zi[r], fma(-vi[tile][r], zr[r], b_i));
+                }
+            }
+            a_r += __shfl_xor(a_r, 16, 64);
+            a_i += __shfl_xor(a_i, 16, 64);
+            a_r += __shfl_xor(a_r, 32, 64);
+            a_i += __shfl_xor(a_i, 32, 64);
+            double val = s_re * a_i - s_im * a_r;                 // Im(conj(s) a)
+            if (NEEDB) {
+                b_r += __shfl_xor(b_r, 16, 64);
+                b_i += __shfl_xor(b_i, 16, 64);
+                b_r += __shfl_xor(b_r, 32, 64);
+                b_i += __shfl_xor(b_i, 32, 64);
+                val -= s_re * b_i + s_im * b_r;                   // - Im(s b)
+            }
+            const int t = t0 + 16 * tile + col;
+            if (g == 0 && t < N)
+                out_member[c + (size_t)t * K] = gs * val;
+        }
+    }
+    if (blockIdx.x == 0 && lane == 0) {
+        if (SAND) {
+            const double z = (s_re * s_re + s_im * s_im) / (double)p.n;
+            out_member[(size_t)K * N] = 1.0 - z * z;
+        } else {
+            out_member[(size_t)K * N] = s_re * s_re - s_im * s_im;
+        }
+    }
+}
+
 // The same for SPARSE control operators (at most R non-zeros per row: Pauli-type controls and their Liouville-space
 // commutators have 1..4): per control and row R (value, column) pairs, zero padded (act_bs / act_bo, staged in LDS and read
 // back as broadcasts); v_t (and w_t where b is needed) of the wave's 64 slices sits in LDS element-major, so a column is
@@ -826,6 +932,18 @@ static hipError_t launch_forms_nb(int sandwich, const TileParams &p, hipStream_t
         case 4: launch_forms_sparse<4, NB>(sandwich, p, grid, lds_f, stream); return hipGetLastError();
         case 6: launch_forms_sparse<6, NB>(sandwich, p, grid, lds_f, stream); return hipGetLastError();
         default: break;
+        }
+    }
+    if constexpr (NB == 16) {                                    // dense operators, n <= 16: the forms on the matrix cores
+        const bool valu = std::getenv("GRAPE_FORMS_VALU") != nullptr;     // (the vector-ALU kernel: tests, A/B timing)
+        if (!valu) {
+            if (!sandwich)
+                hipLaunchKernelGGL((action_forms_mfma_kernel<0, true>), grid, dim3(64), 0, stream, p);
+            else if (p.herm_ctrl)
+                hipLaunchKernelGGL((action_forms_mfma_kernel<1, true>), grid, dim3(64), 0, stream, p);
+            else
+                hipLaunchKernelGGL((action_forms_mfma_kernel<1, false>), grid, dim3(64), 0, stream, p);
+            return hipGetLastError();
         }
     }
     if (!sandwich)

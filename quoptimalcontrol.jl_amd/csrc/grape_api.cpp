@@ -950,11 +950,10 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     bool dpp_small = thin && !act_only && !act_forced && !(dpp_env && dpp_env[0] == '0') && !(hoist_env && hoist_env[0] == '0') &&
                      !(dppc_env && dppc_env[0] == '0') && !env_on("GRAPE_NO_TP") && !env_on("GRAPE_THIN_SINGLE") &&
                      (long)E < std::min(dpp_min, 41L) && c->cfg.n_slices >= 64;
-    if (dpp_small && !(dppc_env && dppc_env[0] == '1')) {
-        // ... where the control operators are sparse (at most six non-zeros per row: Pauli-type controls, their Liouville-space
-        // commutators): the forms kernel then reads (value, column) lists.  With dense operators its 256 complex
-        // multiply-adds per (slice, control) on the vector ALU cost more than the chain saves (16 x 16, N = 1000, K = 4,
-        // one problem / eight: 0.090 / 0.138 ms against 0.085 / 0.126 of the flows this replaces; sparse: 0.075 / 0.099).
+    // (dense control operators included: their forms run on the matrix cores -- action_forms_mfma_kernel; with the vector-ALU
+    // forms kernel, GRAPE_FORMS_VALU=1, this flow loses there: one problem / eight, K = 4: 0.090 / 0.141 ms against 0.086 / 0.127
+    // of the flows it replaces, 0.084 / 0.113 with the matrix-core kernel)
+    if (dpp_small && !(dppc_env && dppc_env[0] == '1') && env_on("GRAPE_FORMS_VALU")) {
         int rmax = 0;
         for (size_t q = 0; q < (ctrl_shared ? 1 : E) * K && rmax <= 6; ++q)
             for (int row = 0; row < n && rmax <= 6; ++row) {

@@ -208,6 +208,35 @@ def test_nan_controls_propagate(qoc, monkeypatch):
     assert np.isnan(F) and np.isnan(G).any()
 
 
+@pytest.mark.parametrize("n,K,N,E,sys_type,herm_ctrl,shared", [
+    (16, 3, 70, 3, "CoherenceTransfer", True, True), (16, 2, 64, 2, "StateTransfer", False, True),
+    (12, 4, 17, 4, "UnitaryGate", True, False), (9, 1, 129, 2, "CoherenceTransfer", False, False),
+    (16, 5, 1, 3, "UnitaryGate", False, True), (13, 2, 200, 5, "StateTransfer", True, True)])
+def test_dense_forms_on_the_matrix_cores(qoc, oracle, monkeypatch, n, K, N, E, sys_type, herm_ctrl, shared):
+    """Dense control operators, n <= 16: the bilinear forms as 16 x 16 products on the matrix cores
+    (action_forms_mfma_kernel: four 16-slice tiles per wavefront, ragged last tiles) against the oracle and against the
+    vector-ALU kernel (GRAPE_FORMS_VALU=1), on the Taylor flow and on the propagator chain."""
+    sand = sys_type != "UnitaryGate"
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sand, False, herm_ctrl, seed=3 * n + N, shared=shared)
+    F_ref, G_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.1)
+    for flow in ("taylor", "propagators"):
+        monkeypatch.setenv("GRAPE_ACTION", "1" if flow == "taylor" else "0")
+        monkeypatch.setenv("GRAPE_THIN_DPP", "1")
+        monkeypatch.setenv("GRAPE_HOIST", "1")
+        res = []
+        for valu in (False, True):
+            if valu:
+                monkeypatch.setenv("GRAPE_FORMS_VALU", "1")
+            else:
+                monkeypatch.delenv("GRAPE_FORMS_VALU", raising=False)
+            with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.1, N) as eng:
+                assert eng.info["expm_action"] == (1 if flow == "taylor" else 0) and eng.info["rank_one_chain"] == 1
+                res.append(eng.eval(x))
+            assert_parity(res[-1][0], res[-1][1], F_ref, G_ref, n, what=f"{flow}, vector-ALU forms={valu}")
+        assert_parity(res[0][0], res[0][1], res[1][0], res[1][1], n, what="matrix-core forms vs vector-ALU forms")
+    monkeypatch.delenv("GRAPE_FORMS_VALU", raising=False)
+
+
 def _pauli_string(rng, nq=4):
     P = [np.eye(2), np.array([[0, 1], [1, 0]]), np.array([[0, -1j], [1j, 0]]), np.array([[1, 0], [0, -1]])]
     M = np.array([[1.0 + 0j]])

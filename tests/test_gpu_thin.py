@@ -238,14 +238,23 @@ def test_rank_one_chain_time_chunks(qoc, oracle, monkeypatch, n, K, N, E, sys_ty
 
 
 @pytest.mark.parametrize("sys_type,herm_gen", [("CoherenceTransfer", False), ("StateTransfer", True), ("UnitaryGate", False)])
-def test_single_rank_one_problem_takes_the_dense_chunked_flows(qoc, oracle, sys_type, herm_gen):
-    """ONE rank-one problem of at least 64 slices is latency-bound and the dense flows with the chunked time axis are
-    the faster ones there; the library routes it to them (general flow, or unitary flow for Hermitian generators)."""
+def test_single_rank_one_problem(qoc, oracle, monkeypatch, sys_type, herm_gen):
+    """ONE rank-one problem of at least 64 slices is latency-bound: the propagator chain of action_thin.hip on a chunked
+    time axis (round 3); without it (GRAPE_DPP_CHUNKS=0) the dense flows with the chunked time axis, which are ahead of
+    sweep_thin.hip's chunked chain there (general flow, or unitary flow for Hermitian generators)."""
     n, K, N = 16, 3, 96
     A, B, Xi, Xt, wts, x = _problem(n, K, N, 1, sys_type != "UnitaryGate", herm_gen, True, seed=3)
+    F_ref, G_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.2)
+    for name in ("GRAPE_DPP_CHUNKS", "GRAPE_THIN_DPP", "GRAPE_HOIST", "GRAPE_ACTION"):
+        monkeypatch.delenv(name, raising=False)
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N) as eng:
+        info = eng.info
+        assert info["rank_one_chain"] == 1 and info["prop_chain"] == 1 and info["time_chunks"] >= 2 and info["unitary_flow"] == 0
+        F, G = eng.eval(x)
+    assert_parity(F, G, F_ref, G_ref, n, what="single rank-one problem, chunked propagator chain")
+    monkeypatch.setenv("GRAPE_DPP_CHUNKS", "0")
     with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.2, N) as eng:
         info = eng.info
         assert info["rank_one_chain"] == 0 and info["time_chunks"] >= 2 and info["unitary_flow"] == (1 if herm_gen else 0)
         F, G = eng.eval(x)
-    F_ref, G_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.2)
-    assert_parity(F, G, F_ref, G_ref, n, what="single rank-one problem")
+    assert_parity(F, G, F_ref, G_ref, n, what="single rank-one problem, dense chunked flows")

@@ -21,6 +21,7 @@ rng = np.random.default_rng(seed)
 F = qoc.engine
 fails = 0
 n_action = 0
+n_chunked = 0
 t0 = time.time()
 for i in range(cases):
     n = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32], p=[.1, .08, .14, .06, .06, .08, .08, .08, .12, .06, .06, .08]))
@@ -67,6 +68,12 @@ for i in range(cases):
         os.environ.pop("GRAPE_HOIST", None)
         os.environ.pop("GRAPE_ACTION", None)
         os.environ.pop("GRAPE_THIN_DPP", None)
+    # rank-one states, 9..16, at least 64 slices: the chunked propagator chain (forced for dense controls too), or the
+    # library's own choice
+    if rng.random() < 0.5:
+        os.environ["GRAPE_DPP_CHUNKS"] = "1"
+    else:
+        os.environ.pop("GRAPE_DPP_CHUNKS", None)
 
     def vec(m=1):
         v = rng.standard_normal((n, m)) + 1j * rng.standard_normal((n, m))
@@ -91,7 +98,7 @@ for i in range(cases):
     x = rng.uniform(-1, 1, (K, N))
     T = float(rng.uniform(0.3, 2.0))
     what = (f"case {i}: n={n} K={K} N={N} E={E} {sys_type} v{variant} herm={herm} sparse={sparse} states={states} flag={flag} "
-            f"shared_ctrl={shared_ctrl} action={os.environ.get('GRAPE_ACTION', '-')} dpp={os.environ.get('GRAPE_THIN_DPP', '-')}")
+            f"shared_ctrl={shared_ctrl} action={os.environ.get('GRAPE_ACTION', '-')} dpp={os.environ.get('GRAPE_THIN_DPP', '-')} dppc={os.environ.get('GRAPE_DPP_CHUNKS', '-')}")
     exact = rng.random() < 0.15 and N <= 33 and states not in ("rect", "vec")      # (the C oracle has no exact gradient for n x m states)
     if exact:                                             # exact gradient of the figure of merit / of the C1 functional
         objective = int(rng.integers(0, 2))
@@ -114,6 +121,7 @@ for i in range(cases):
             foms, grads = eng.member_results()
             info = eng.info
         n_action += int(info.get("expm_action", 0))
+        n_chunked += int(info.get("prop_chain", 0) and info.get("time_chunks", 0) >= 2)
         for k in range(E):
             # a member's whole gradient can be a near-zero (K = 1, N = 1: one entry passing through zero): the norm-wise
             # bar then has no scale left, so an absolute floor of a few ulp of the O(1) traces applies
@@ -129,5 +137,5 @@ for i in range(cases):
     except Exception as exc:                          # noqa: BLE001
         fails += 1
         print("FAIL", what, "->", repr(exc)[:300], flush=True)
-print(f"soak: {cases} cases, {fails} failures, {n_action} of them through the vector flow, {time.time() - t0:.1f} s (seed {seed})")
+print(f"soak: {cases} cases, {fails} failures, {n_action} of them through the vector flow, {n_chunked} through the chunked propagator chain, {time.time() - t0:.1f} s (seed {seed})")
 sys.exit(1 if fails else 0)
