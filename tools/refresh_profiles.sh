@@ -37,6 +37,8 @@ python3 tools/group_overhead.py --ensemble 128 > "$OUT/group_overhead_C3_E128.js
 ./tools/ubench/dpp_fmac > "$OUT/dpp_fmac.txt" 2>&1
 ( python3 tools/vec32_bench.py 1024 2000; python3 tools/vec32_bench.py 4096 2000 ) > "$OUT/vec32_bench.json" 2> /dev/null
 python3 tools/exact_time.py > "$OUT/exact_time.txt" 2> /dev/null
+python3 tools/dpp_chunks_time.py 1 2 8 24 40 48 2> /dev/null > "$OUT/dpp_chunks_time.txt"      # small rank-one ensembles: chunked propagator chain vs the flows it replaced
+( python3 tools/dense_forms_time.py; GRAPE_FORMS_VALU=1 python3 tools/dense_forms_time.py ) 2> /dev/null > "$OUT/dense_forms_time.txt"
 for E in 128 256 320 512 1024 2048 4096; do for m in 1 0; do echo "E=$E GRAPE_ACTION=$m $(GRAPE_ACTION=$m python3 bench.py --config C4 --ensemble $E --steps 20 --warmup 5 --blocks 2 --no-extra --no-cpu-baseline 2> /dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "evals/s", round(d["ms_per_step"],3), "ms")')"; done; done > "$OUT/C4_flow_crossover.txt"
 for seed in 31 32 33 34 35 36 37 38; do python3 tools/soak.py 1500 $seed 2>&1 | tail -1; done > "$OUT/soak.txt"
 python3 tools/soak_api.py 600 5 2>&1 | tail -1 >> "$OUT/soak.txt"
