@@ -103,7 +103,7 @@ def test_timed_event_ring_wraps(qoc):
 
 
 @pytest.mark.parametrize("name,kw,devices", [("C3", {"E": 5, "N": 70}, [0, 0]), ("C3", {"E": 7, "N": 33}, [0, 0, 0]),
-                                             ("C1", {}, [0, 0]), ("C4", {"E": 5, "N": 24}, [0, 0]),
+                                             ("C1", {}, [0, 0]), ("C4", {"E": 5, "N": 24}, [0, 0]), ("C4", {"E": 5, "N": 70}, [0, 0, 0]),
                                              ("C3", {"E": 9, "N": 40}, [0, 0, 0, 0, 0, 0, 0, 0])])
 def test_multi_shard_group_on_one_gpu_with_peer_sum(qoc, oracle, name, kw, devices):
     """SEVERAL shards behind one context on the one GPU there is (GRAPE_FLAG_GROUP_PEER_SUM lets device_ids repeat and
