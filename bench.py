@@ -276,16 +276,29 @@ def committed_mfma(key):
         return None
 
 
-def clock_ramp(step, seconds=0.35):
+def clock_ramp(step, seconds=0.35, reduce_max=None):
     """Untimed evaluations for at least `seconds` before the first timed block, whatever --warmup says: a 20-step run
     of 0.1 ms calls used to be measured on a GPU still raising its clock (round 2: 83.7 us kernels in the driver's
-    run against 72 us in every longer one)."""
+    run against 72 us in every longer one).
+    Several ranks (reduce_max given): a step holds a collective, so every rank must make the SAME number of calls -- a
+    loop on each rank's own clock left one rank a call ahead of the other about once in ten runs (a mismatched
+    all-reduce).  The ranks time a probe of 8 steps, agree on the slowest rank's figure and all run the count that follows."""
+    if reduce_max is None:
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < seconds:
+            step()
+            n += 1
+        return n
+    probe = 8
     t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < seconds:
+    for _ in range(probe):
         step()
-        n += 1
-    return n
+    per_step = reduce_max((time.perf_counter() - t0) / probe)      # identical on every rank (all-reduce MAX)
+    n = max(0, min(20000, int(seconds / max(per_step, 1e-6)) - probe))
+    for _ in range(n):
+        step()
+    return probe + n
 
 
 def time_blocks(step, steps, blocks, barrier, reduce_max):
@@ -559,7 +572,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ramp_steps = clock_ramp(step)                  # >= 0.35 s of untimed calls: the timed blocks see a warm clock
+    # >= 0.35 s of untimed calls: the timed blocks see a warm clock (N > 1: the same number of calls on every rank)
+    ramp_steps = clock_ramp(step, reduce_max=reduce_max if world > 1 else None)
     barrier()
     if sg.local is not None:
         sg.local.kernel_time(reset=True)

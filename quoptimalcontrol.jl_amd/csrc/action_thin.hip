@@ -32,6 +32,7 @@
 // with the (member-invariant) B_c read through scalar loads.
 #include "grape_kernels.hpp"
 #include "cmat.hpp"
+#include "done_signal.hpp"
 #include "tile.hpp"
 #include <cstdlib>
 
@@ -588,6 +589,24 @@ __global__ __launch_bounds__(64) void chain_prop_kernel(const TileParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // DMA loads still in flight target this wave's LDS
 }
 
+// ONE problem: the forms kernel closes the evaluation (TileParams.fold_fg) -- fg[q] = w_0 x member_out[q] exactly as
+// reduce_few_kernel forms it (fma(value, w, 0)), written where the result is wanted (the mapped host buffer when there is
+// one: a handful of single-wave workgroups with ~2 KB each -- the staging buffer + copy-out of the reduce kernels, built
+// for hundreds of workgroups, cost this kernel 6 us), then every workgroup's wave releases its stores at system scope and
+// the last one publishes the sequence number
+GRAPE_DEV void fold_store(const TileParams &p, size_t q, double v)
+{
+    if (!p.fold_fg)
+        return;
+    double *dst = p.fold_done.flag && p.fold_done.host_out ? p.fold_done.host_out : p.fold_fg;
+    dst[q] = fma(v, p.fold_wts[0], 0.0);
+}
+GRAPE_DEV void fold_publish(const TileParams &p)                  // single-wave workgroups: at the kernel's end
+{
+    if (p.fold_fg && threadIdx.x == 0)
+        signal_done(p.fold_done, gridDim.x);
+}
+
 // grid (ceil(N / 64), E, n_x): lane = slice.  act_bf = the K control operators B_c, row-major, zero padded to NB x NB
 template <int SAND, bool HERMB, int NB>
 __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
@@ -657,17 +676,23 @@ __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
         double val = s_re * a_i - s_im * a_r;                     // Im(conj(s) a)
         if (SAND && !HERMB)
             val -= s_re * b_i + s_im * b_r;                       // - Im(s b)
-        if (t < N)
+        if (t < N) {
             out_member[c + (size_t)t * K] = gs * val;
-    }
-    if (blockIdx.x == 0 && lane == 0) {
-        if (SAND) {
-            const double z = (s_re * s_re + s_im * s_im) / (double)p.n;
-            out_member[(size_t)K * N] = 1.0 - z * z;
-        } else {
-            out_member[(size_t)K * N] = s_re * s_re - s_im * s_im;
+            fold_store(p, c + (size_t)t * K, gs * val);
         }
     }
+    if (blockIdx.x == 0 && lane == 0) {
+        double Fk;
+        if (SAND) {
+            const double z = (s_re * s_re + s_im * s_im) / (double)p.n;
+            Fk = 1.0 - z * z;
+        } else {
+            Fk = s_re * s_re - s_im * s_im;
+        }
+        out_member[(size_t)K * N] = Fk;
+        fold_store(p, (size_t)K * N, Fk);
+    }
+    fold_publish(p);
 }
 
 // DENSE control operators, n <= 16, on the matrix cores: the records of 16 slices ARE a 16 x 16 matrix V (element-major:
@@ -761,18 +786,24 @@ __global__ __launch_bounds__(64) void action_forms_mfma_kernel(const TileParams 
                 val -= s_re * b_i + s_im * b_r;                   // - Im(s b)
             }
             const int t = t0 + 16 * tile + col;
-            if (g == 0 && t < N)
+            if (g == 0 && t < N) {
                 out_member[c + (size_t)t * K] = gs * val;
+                fold_store(p, c + (size_t)t * K, gs * val);
+            }
         }
     }
     if (blockIdx.x == 0 && lane == 0) {
+        double Fk;
         if (SAND) {
             const double z = (s_re * s_re + s_im * s_im) / (double)p.n;
-            out_member[(size_t)K * N] = 1.0 - z * z;
+            Fk = 1.0 - z * z;
         } else {
-            out_member[(size_t)K * N] = s_re * s_re - s_im * s_im;
+            Fk = s_re * s_re - s_im * s_im;
         }
+        out_member[(size_t)K * N] = Fk;
+        fold_store(p, (size_t)K * N, Fk);
     }
+    fold_publish(p);
 }
 
 // The same for SPARSE control operators (at most R non-zeros per row: Pauli-type controls and their Liouville-space
@@ -794,6 +825,7 @@ __global__ __launch_bounds__(64) void action_forms_sparse_kernel(const TileParam
     double2 *s_v = s_forms, *s_w = s_forms + 64 * NB;             // [NB][64] each (s_w only when b is needed)
     double2 *s_tab = s_forms + (NEEDB ? 128 : 64) * NB;           // [K][NB][R] values
     int *s_off = reinterpret_cast<int *>(s_tab + (size_t)K * NB * R);   // [K][NB][R] byte offsets of the column inside s_v
+    double *s_fold = reinterpret_cast<double *>(s_off + (size_t)K * NB * R);   // [64][K] outputs (single problems, fold_fg)
     double vr[NB], vi[NB], wr[NB], wi[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -860,15 +892,29 @@ __global__ __launch_bounds__(64) void action_forms_sparse_kernel(const TileParam
             val -= s_re * b_i + s_im * b_r;                       // - Im(s b)
         if (t < N)
             out_member[c + (size_t)t * K] = gs * val;
+        if (p.fold_fg)
+            s_fold[lane * K + c] = gs * val;
+    }
+    if (p.fold_fg) {                                              // the wave's 64 K outputs are contiguous: whole-line stores
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int base = blockIdx.x * 64 * K, total = K * N;
+        for (int i = lane; i < 64 * K; i += 64)
+            if (base + i < total)
+                fold_store(p, (size_t)(base + i), s_fold[i]);
     }
     if (blockIdx.x == 0 && lane == 0) {
+        double Fk;
         if (SAND) {
             const double z = (s_re * s_re + s_im * s_im) / (double)p.n;
-            out_member[(size_t)K * N] = 1.0 - z * z;
+            Fk = 1.0 - z * z;
         } else {
-            out_member[(size_t)K * N] = s_re * s_re - s_im * s_im;
+            Fk = s_re * s_re - s_im * s_im;
         }
+        out_member[(size_t)K * N] = Fk;
+        fold_store(p, (size_t)K * N, Fk);
     }
+    fold_publish(p);
 }
 
 template <int R, int NB>
@@ -924,7 +970,8 @@ static hipError_t launch_forms_nb(int sandwich, const TileParams &p, hipStream_t
     const dim3 grid((p.N + 63) / 64, p.E, p.n_x);
     if (p.act_R > 0) {                                            // sparse control operators: (value, column) lists
         const bool needb = sandwich && !p.herm_ctrl;
-        const size_t lds_f = sizeof(double2) * (needb ? 128 : 64) * NB + (sizeof(double2) + sizeof(int)) * (size_t)p.K * NB * p.act_R;
+        const size_t lds_f = sizeof(double2) * (needb ? 128 : 64) * NB + (sizeof(double2) + sizeof(int)) * (size_t)p.K * NB * p.act_R +
+                             (p.fold_fg ? sizeof(double) * 64 * (size_t)p.K : 0);
         switch (lds_f <= 64 * 1024 ? p.act_R : 0) {
         case 1: launch_forms_sparse<1, NB>(sandwich, p, grid, lds_f, stream); return hipGetLastError();
         case 2: launch_forms_sparse<2, NB>(sandwich, p, grid, lds_f, stream); return hipGetLastError();

@@ -1,0 +1,71 @@
+// done_signal.hpp -- device side of DoneSignal (grape_kernels.hpp): how the last kernel of an evaluation hands [G, F] to the
+// host.  Used by the reduce kernels (reduce.hip) and by the forms kernels of action_thin.hip when they close a single
+// problem's evaluation themselves.
+#pragma once
+#include "grape_kernels.hpp"
+
+namespace grape {
+
+// Host-visible completion without waiting for the kernel-end signal: the LAST workgroup of the final
+// kernel of an evaluation stores the evaluation's sequence number into coherent pinned host memory,
+// after every workgroup's result stores have been released at system scope.  Called by ONE thread per
+// workgroup whose own wave made (or, after a workgroup barrier + per-thread fence, covers) the stores.
+__device__ __forceinline__ void signal_done(DoneSignal d, unsigned nblocks)
+{
+    if (!d.flag)
+        return;
+    __threadfence_system();
+    const unsigned prev = atomicAdd(d.counter, 1u);
+    if (prev == nblocks - 1) {
+        __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch: behind this kernel
+        __threadfence_system();
+        __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Result stores of the reduce kernels when the evaluation ends in host memory.  251 workgroups each
+// pushing 64 bytes over PCIe and waiting for a system-scope fence cost ~10 us; instead every workgroup
+// stores its outputs into a DEVICE staging buffer with sc1 (write-through) stores, drains them
+// (s_waitcnt vmcnt(0)), and adds to an agent-scope counter; the workgroup whose add came last reads the
+// whole staging buffer with sc1 loads (MI355X guide, inter-workgroup hand-off table, row 1), writes it to
+// the mapped host buffer in one coalesced burst and publishes the sequence number.
+__device__ __forceinline__ void stage_store(double *stage, int i, double v)
+{
+    __hip_atomic_store(stage + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // global_store ... sc1
+}
+
+__device__ __forceinline__ void publish_via_last_block(DoneSignal d, const double *stage, int n_total, unsigned nblocks)
+{
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its own staging stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = atomicAdd(d.counter, 1u);
+        s_last = prev == nblocks - 1;
+        if (s_last)
+            __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last)
+        return;
+    for (int i0 = threadIdx.x; i0 < n_total; i0 += 8 * blockDim.x) {       // 8 sc1 loads in flight per thread
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            v[u] = i < n_total ? __hip_atomic_load(stage + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i < n_total)
+                d.host_out[i] = v[u];
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+}  // namespace grape

@@ -1409,10 +1409,23 @@ static bool states_stored(const grape_ctx *c)
     return !grape::tile_chain_is_split(tile_params(c, nullptr), false);
 }
 
-static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream, int n_x, hipEvent_t ev_mid = nullptr)
+// ONE problem whose flow ends in a forms kernel of action_thin.hip: that kernel closes the evaluation (no reduce launch)
+static bool tile_folds_reduce(const grape_ctx *c, int n_x)
+{
+    return c->family == 1 && (c->action || c->thin_dpp) && c->cfg.n_ensemble == 1 && n_x == 1 &&
+           c->cfg.gradient != GRAPE_GRADIENT_EXACT && c->direct_publish;
+}
+
+static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream, int n_x, hipEvent_t ev_mid = nullptr,
+                        double *d_fg = nullptr, grape::DoneSignal done = grape::DoneSignal())
 {
     TileParams p = tile_params(c, d_x, n_x);
     p.ev_mid = ev_mid;
+    if (d_fg && tile_folds_reduce(c, n_x)) {
+        p.fold_fg = d_fg;
+        p.fold_wts = c->d_wts;
+        p.fold_done = done;
+    }
     HIP_TRY(c, grape::launch_sweep_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE,
                                         c->d_costates != nullptr, p, stream));
     return GRAPE_OK;
@@ -1499,7 +1512,7 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
         else
             HIP_TRY(c, grape::launch_sweep_small(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, mode, p, stream));
     } else {
-        int rc = enqueue_tile(c, d_x, stream, n_x, emid);
+        int rc = enqueue_tile(c, d_x, stream, n_x, emid, d_fg, done);
         if (rc) return rc;
     }
     if (exact && c->family == 1) {
@@ -1528,8 +1541,8 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     if (exact)
         HIP_TRY(c, grape::launch_reduce(c->d_member_out, c->d_wts, c->d_partial, d_fg, p.E, (int)(KN(c) + 1), c->ksplit,
                                         stream, done));
-    else if (direct)
-        ;                                                    // the sweep kernel has written [G, F] (and the flag)
+    else if (direct || tile_folds_reduce(c, n_x))
+        ;                                                    // the sweep / forms kernel has written [G, F] (and the flag)
     else if (c->family == 0)
         HIP_TRY(c, grape::launch_reduce_rows(c->d_block_out, d_fg, c->NB, (int)(KN(c) + 1), n_x, stream, done));
     else {

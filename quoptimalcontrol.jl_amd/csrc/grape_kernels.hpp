@@ -155,6 +155,11 @@ struct TileParams {
     const int32_t *act_bo;    //      [K][16][act_R] the byte offsets 1024 j of their columns in the kernel's LDS tile
     double2 *act_g;           // [control array][slice][2][256]: [Gc_t | Gc_t'], written by the pre-pass
     double *act_gn;           // [control array][slice] max(|Gc_t|_1, |Gc_t|_inf)
+    // ONE problem (E = 1, one control array) on a flow that ends in a forms kernel of action_thin.hip: that kernel writes the
+    // weighted row [G, F] itself and its last workgroup publishes it -- no reduce launch.  fold_fg: destination / staging
+    double *fold_fg;          // nullptr: off
+    const double *fold_wts;
+    DoneSignal fold_done;
     hipEvent_t ev_mid;        // timing (GRAPE_FLAG_TIME_KERNELS): recorded behind the expm kernel, in front of the chain kernels; or null
     double dt;
 };

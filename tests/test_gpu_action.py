@@ -548,6 +548,50 @@ def test_chunked_chain_with_sparse_controls(qoc, oracle, monkeypatch, terms, her
     assert_parity(res[0][0], res[0][1], res[1][0], res[1][1], n, what="list forms kernel vs dense forms kernel")
 
 
+@pytest.mark.parametrize("flow", ["taylor", "propagators", "chunked"])
+@pytest.mark.parametrize("controls", ["sparse", "dense"])
+def test_single_problem_is_closed_by_the_forms_kernel(qoc, oracle, monkeypatch, flow, controls):
+    """ONE rank-one problem on a flow that ends in a forms kernel: that kernel writes the weighted [G, F] and its last
+    workgroup publishes it (no reduce launch) -- bitwise what the reduce kernel hands out (GRAPE_DIRECT_PUBLISH=0), on the
+    host path and through the device entry point."""
+    import torch
+    n, K, N = 16, 3, 150
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, 1, True, False, True, seed=21)
+    if controls == "sparse":
+        rng = np.random.default_rng(8)
+        B = np.array([[0.3 * (_pauli_string(rng) + _pauli_string(rng)) for _ in range(K)]])
+    wts = np.array([0.37])
+    monkeypatch.setenv("GRAPE_ACTION", "1" if flow == "taylor" else "0")
+    monkeypatch.setenv("GRAPE_HOIST", "1")
+    if flow != "chunked":
+        monkeypatch.setenv("GRAPE_THIN_DPP", "1")
+        monkeypatch.setenv("GRAPE_DPP_CHUNKS", "0")
+        monkeypatch.setenv("GRAPE_THIN_SINGLE", "1")              # (one problem: keep the vector flows)
+    F_ref, G_ref = oracle.ensemble_eval("CoherenceTransfer", A, B, Xi, Xt, wts, x, 1.0)
+    res = []
+    for direct in ("1", "0"):
+        monkeypatch.setenv("GRAPE_DIRECT_PUBLISH", direct)
+        with qoc.GrapeEngine("CoherenceTransfer", A, B, Xi, Xt, wts, 1.0, N, member_results=True) as eng:
+            info = eng.info
+            assert info["expm_action"] == (1 if flow == "taylor" else 0)
+            if flow == "chunked":
+                assert info["prop_chain"] == 1 and info["time_chunks"] >= 2
+            F, G = eng.eval(x)
+            F2, G2 = eng.eval(x)
+            foms, grads = eng.member_results()
+            xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda")
+            fg = torch.zeros(K * N + 1, dtype=torch.float64, device="cuda")
+            eng.eval_device(xd.data_ptr(), fg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            h = fg.cpu().numpy()
+        assert F == F2 and np.array_equal(G, G2)
+        assert h[-1] == F and np.array_equal(h[:-1].reshape(N, K).T, G)
+        assert F == foms[0] * wts[0] and np.array_equal(G, grads[0] * wts[0])
+        assert_parity(F, G, F_ref, G_ref, n, what=f"{flow}, direct publication {direct}")
+        res.append((F, G))
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+
+
 def test_flow_by_ensemble_size(qoc, oracle, monkeypatch):
     """9 <= n <= 16, rank-one states: chunked sweep_thin.hip chain for a handful of members, the propagator chain on DPP
     products from 80, the Taylor flow from 11/8 x compute units (lowered here)."""
