@@ -124,15 +124,18 @@ for i in range(cases):
         n_chunked += int(info.get("prop_chain", 0) and info.get("time_chunks", 0) >= 2)
         for k in range(E):
             # a member's whole gradient can be a near-zero (K = 1, N = 1: one entry passing through zero): the norm-wise
-            # bar then has no scale left, so an absolute floor of a few ulp of the O(1) traces applies
-            if np.abs(grads[k] - grads_ref[k]).max() <= 5e-14 * n and abs(foms[k] - foms_ref[k]) <= 1e-10 * max(abs(foms_ref[k]), 1e-3 * n * n):
+            # bar then has no scale left, so an absolute floor of a few ulp of the traces applies -- O(1) for unitary
+            # propagators, O(|F_k|) for the non-normal ones whose overlaps exceed 1 (seed 32, case 1233: one slice with
+            # |dt H| = 6.6, cond(P) = 104, |tr(Xt' X_N)| = 17, F_k = -11: |G - G_ref| = 3.2e-13 on terms of size 300)
+            if (np.abs(grads[k] - grads_ref[k]).max() <= 5e-14 * n * max(1.0, abs(foms_ref[k])) and
+                    abs(foms[k] - foms_ref[k]) <= 1e-10 * max(abs(foms_ref[k]), 1e-3 * n * n)):
                 continue
             assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=what + f" member {k}")
         # ensemble: members' figures of merit can cancel in the weighted sum (UnitaryGate F_k = Re(z^2) has either sign),
         # so the bar for F is taken relative to sum w_k |F_k|, the scale the members' own 1e-10 errors add up on
         scale = float(np.abs(foms_ref) @ wts)
         assert abs(Fv - F_ref) <= 1e-10 * max(scale, 1e-3 * n * n), (what, Fv, F_ref, scale)
-        if np.abs(G - G_ref).max() > 5e-14 * n:
+        if np.abs(G - G_ref).max() > 5e-14 * n * max(1.0, scale):
             assert_parity(F_ref, G, F_ref, G_ref, n, what=what)
     except Exception as exc:                          # noqa: BLE001
         fails += 1
