@@ -1099,10 +1099,10 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                 c->tp_C = (int)((N + c->tp_S - 1) / c->tp_S);
             }
         } else if (dpp_small) {
-            // critical path: S dependent 16 x 16 products (0.6 us each) + S chain steps (0.3) + C scan steps (0.2) --
-            // S = sqrt(N / 4.5), 16 at N = 1000 (measured, one problem: 16 / 22 / 32 slices 74 / 76 / 78 us); a workgroup's LDS
-            // ring lets two share a compute unit
-            long s_lat = std::max(4L, std::lround(std::sqrt((double)N / 4.0)));
+            // critical path: S / 4 + 3 dependent 16 x 16 products (0.6 us each; four waves per chunk) + S chain steps (0.3) +
+            // C scan steps (0.2) -- S = sqrt(N / 1.75), 24 at N = 1000 (measured, one problem: 16 / 21 / 24 / 32 slices
+            // 61.9 / 61.0 / 59.2 / 59.9 us); a workgroup's LDS ring lets two share a compute unit
+            long s_lat = std::max(4L, std::lround(std::sqrt((double)N / 1.75)));
             long C = std::min(2L * c->compute_units / units, (N + s_lat - 1) / s_lat);
             if (const char *e = std::getenv("GRAPE_TP_CHUNKS")) C = std::atol(e);
             if (C > N / 2) C = N / 2;

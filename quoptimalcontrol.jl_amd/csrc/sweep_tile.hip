@@ -1073,6 +1073,60 @@ __global__ __launch_bounds__(64) void chunk_product_deep_kernel(const TileParams
     tstore(p.tp_q + (kw * C + c) * TSZ, Y, lane);
 }
 
+// The same with FOUR wavefronts per chunk: the dependent chain is what a single problem waits for (16 products of 0.6 us
+// at N = 1000), so each wave multiplies a quarter of the chunk's slices, the three upper quarters go to wave 0 through LDS
+// (D-layout dumps) and wave 0 multiplies them on: S / 4 + 3 dependent products instead of S.
+__global__ __launch_bounds__(256) void chunk_product_quad_kernel(const TileParams p)
+{
+    constexpr int TSZ = 256;
+    extern __shared__ double2 s_dynt[];                            // [layout-conversion image of wave 0 | 3 dumps]
+    double2 *s_dump = s_dynt + kTileImage + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = blockIdx.x, c = blockIdx.z;
+    const int N = p.N, C = p.tp_chunks;
+    const size_t kw = (size_t)blockIdx.y * p.E + k;
+    const double2 *__restrict__ Pk = p.props + kw * N * TSZ;
+    const int t_lo = c * p.tp_S, t_hi = min(N, t_lo + p.tp_S);
+    const int sub = (t_hi - t_lo + 3) / 4;
+    const int a = min(t_hi, t_lo + wave * sub), b = min(t_hi, a + sub);      // this wave's slices (wave 0: the earliest)
+    TMat<1> V, Y, ring[kDeep];
+    tidentity(V, lane);
+#pragma unroll
+    for (int u = 0; u < kDeep; ++u) {
+        tload(ring[u], Pk + (size_t)min(max(b - 1 - u, a), N - 1) * TSZ, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int t = b - 1; t >= a; t -= kDeep) {                      // V <- P_t^T V: ends as P_a^T ... P_b-1^T
+#pragma unroll
+        for (int u = 0; u < kDeep; ++u) {
+            if (t - u >= a) {
+                tmul_tn<1, false, false>(Y, ring[u], V);
+                V = Y;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            tload(ring[u], Pk + (size_t)min(max(t - u - kDeep, a), N - 1) * TSZ, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (wave > 0)
+        tstore(s_dump + (size_t)(wave - 1) * TSZ, V, lane);
+    __syncthreads();
+    if (wave != 0)
+        return;
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {                                  // V <- V V_j+1: the quarters in time order
+        TOp<1> va;
+        TMat<1> W;
+        to_a_layout(va, V, s_dynt, lane);
+        tload(W, s_dump + (size_t)j * TSZ, lane);
+        tmul_an<1, false, false>(Y, va, W);
+        V = Y;
+    }
+    if (p.tp_qt)
+        tstore(p.tp_qt + (kw * C + c) * TSZ, V, lane);
+    transpose_via_a_layout(Y, V, s_dynt, lane);
+    tstore(p.tp_q + (kw * C + c) * TSZ, Y, lane);
+}
+
 // general (non-unitary) flow: U_c = Q_c-1 ... Q_0 (handed out transposed: a free left factor) and R_c = Q_C-1 ... Q_c+1,
 // one wavefront per direction.  GROUPS: the two-level form -- blockIdx.z >> 1 is a group of tp_gsize consecutive chunks,
 // the products stay inside the group, and the suffix wavefront also hands out the group's own product (plain and
@@ -1302,8 +1356,13 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         if constexpr (NT == 1) {
             if (p.thin == 2) {
                 if (p.tp_chunks > 1) {                                 // small ensembles: Q_c and Q_c^T of every chunk of the time axis
-                    hipLaunchKernelGGL(chunk_product_deep_kernel, dim3(p.E, p.n_x, p.tp_chunks), dim3(64),
-                                       sizeof(double2) * (kTileImage + 1), stream, q);
+                    static const bool one_wave = std::getenv("GRAPE_CHUNK_PRODUCT_1W") != nullptr;
+                    if (p.tp_S >= 8 && !one_wave)                      // four waves per chunk: S / 4 + 3 dependent products
+                        hipLaunchKernelGGL(chunk_product_quad_kernel, dim3(p.E, p.n_x, p.tp_chunks), dim3(256),
+                                           sizeof(double2) * (kTileImage + 1 + 3 * 256), stream, q);
+                    else
+                        hipLaunchKernelGGL(chunk_product_deep_kernel, dim3(p.E, p.n_x, p.tp_chunks), dim3(64),
+                                           sizeof(double2) * (kTileImage + 1), stream, q);
                     e = hipGetLastError();
                     if (e != hipSuccess)
                         return e;
