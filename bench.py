@@ -258,6 +258,10 @@ def roofline(local, info, samples, evals_per_s, n_gpus, traffic, profile=None):
                         "kernel / its HIP-event time / peak; `traffic` = HBM bytes from the committed PMC passes; the kernel "
                         "itself is vector-FP64 issue bound (DESIGN.md section 4.1)"}
     roof.update(st)
+    if info.get("kernel_family") != 1 and info.get("lane_pair") and uni:
+        ph = committed_phases(local, st["kernel_avg_us"])
+        if ph:
+            roof["phases_from_profile"] = ph
     if traffic is not None:
         roof["traffic_source"] = ("HBM bytes of the timed kernels per evaluation = (2*FETCH_SIZE + WRITE_SIZE) KiB from the rocprofv3 "
                                   "--pmc passes of this command committed under profiles/ (profiles/traffic.json names the file); "
@@ -282,6 +286,28 @@ def committed_mfma(key):
         t = json.load(open(tpath))
         v = t.get("mfma_utilisation", {}).get(key)
         return dict(v, source=t.get("_sources", {}).get(key, "profiles/")) if v else None
+    except Exception:                          # noqa: BLE001
+        return None
+
+
+def committed_phases(local, kernel_us):
+    """The lane-pair sweep kernel's phases from the committed phase-stamp profile of this config ("from profile": the
+    stamps cost a few percent, so the bench run itself does not carry them): share of the wave's cycles per phase, scaled
+    to this run's kernel time, and the rate at which the HBM-bound backward phase reads the stored propagators."""
+    path = os.path.join(ROOT, "profiles", "r03_C3_phase_stamps.json")
+    try:
+        d = json.load(open(path))
+        if local.n != 4 or d.get("E") != local.E or local.N != 500:
+            return None
+        out = {"source": "profiles/r03_C3_phase_stamps.json (tools/phase_profile.py), shares of a wave's cycles x this run's kernel time"}
+        for name, ph in d["phases"].items():
+            out[name] = {"share": ph["share"], "us": ph["share"] * kernel_us}
+        p_bytes = local.E * local.N * local.n * local.n * 16
+        t_d = out["D backward+grad"]["us"] * 1e-6
+        out["D backward+grad"].update({"bound": "hbm", "propagator_bytes_read": p_bytes, "GBs": p_bytes / t_d / 1e9,
+                                        "frac_hbm": p_bytes / t_d / 1e9 / HBM_PEAK_GBS})
+        out["A propagators"]["bound"] = "vector FP64 issue (DESIGN.md section 4.1: ~0.8 of the 4-cycle issue limit)"
+        return out
     except Exception:                          # noqa: BLE001
         return None
 
