@@ -589,24 +589,6 @@ __global__ __launch_bounds__(64) void chain_prop_kernel(const TileParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // DMA loads still in flight target this wave's LDS
 }
 
-// ONE problem: the forms kernel closes the evaluation (TileParams.fold_fg) -- fg[q] = w_0 x member_out[q] exactly as
-// reduce_few_kernel forms it (fma(value, w, 0)), written where the result is wanted (the mapped host buffer when there is
-// one: a handful of single-wave workgroups with ~2 KB each -- the staging buffer + copy-out of the reduce kernels, built
-// for hundreds of workgroups, cost this kernel 6 us), then every workgroup's wave releases its stores at system scope and
-// the last one publishes the sequence number
-GRAPE_DEV void fold_store(const TileParams &p, size_t q, double v)
-{
-    if (!p.fold_fg)
-        return;
-    double *dst = p.fold_done.flag && p.fold_done.host_out ? p.fold_done.host_out : p.fold_fg;
-    dst[q] = fma(v, p.fold_wts[0], 0.0);
-}
-GRAPE_DEV void fold_publish(const TileParams &p)                  // single-wave workgroups: at the kernel's end
-{
-    if (p.fold_fg && threadIdx.x == 0)
-        signal_done(p.fold_done, gridDim.x);
-}
-
 // grid (ceil(N / 64), E, n_x): lane = slice.  act_bf = the K control operators B_c, row-major, zero padded to NB x NB
 template <int SAND, bool HERMB, int NB>
 __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
@@ -692,7 +674,8 @@ __global__ __launch_bounds__(64) void action_forms_kernel(const TileParams p)
         out_member[(size_t)K * N] = Fk;
         fold_store(p, (size_t)K * N, Fk);
     }
-    fold_publish(p);
+    if (threadIdx.x == 0)
+        fold_publish(p);
 }
 
 // DENSE control operators, n <= 16, on the matrix cores: the records of 16 slices ARE a 16 x 16 matrix V (element-major:
@@ -803,7 +786,8 @@ __global__ __launch_bounds__(64) void action_forms_mfma_kernel(const TileParams 
         out_member[(size_t)K * N] = Fk;
         fold_store(p, (size_t)K * N, Fk);
     }
-    fold_publish(p);
+    if (threadIdx.x == 0)
+        fold_publish(p);
 }
 
 // The same for SPARSE control operators (at most R non-zeros per row: Pauli-type controls and their Liouville-space
@@ -914,7 +898,8 @@ __global__ __launch_bounds__(64) void action_forms_sparse_kernel(const TileParam
         out_member[(size_t)K * N] = Fk;
         fold_store(p, (size_t)K * N, Fk);
     }
-    fold_publish(p);
+    if (threadIdx.x == 0)
+        fold_publish(p);
 }
 
 template <int R, int NB>

@@ -68,4 +68,26 @@ __device__ __forceinline__ void publish_via_last_block(DoneSignal d, const doubl
         __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ONE problem (E = 1, one control array): the LAST kernel of the flow closes the evaluation (TileParams.fold_fg: the forms
+// kernels of action_thin.hip, the unitary chain kernels of sweep_tile.hip / sweep_coop.hip) -- fg[q] = w_0 x member_out[q]
+// exactly as reduce_few_kernel forms it (fma(value, w, 0)), written where the result is wanted (the mapped host buffer when
+// there is one: a handful of workgroups with a few KB each -- the staging buffer + copy-out of the reduce kernels, built
+// for hundreds of workgroups, cost the forms kernel 6 us), then the storing wave of every workgroup releases its stores at
+// system scope and the last one publishes the sequence number.  No reduce launch.
+__device__ __forceinline__ double *fold_dst(const TileParams &p)
+{
+    return p.fold_done.flag && p.fold_done.host_out ? p.fold_done.host_out : p.fold_fg;
+}
+__device__ __forceinline__ void fold_store(const TileParams &p, size_t q, double v)
+{
+    if (p.fold_fg)
+        fold_dst(p)[q] = fma(v, p.fold_wts[0], 0.0);
+}
+// called by ONE thread of the wave that made the workgroup's fold stores, behind them
+__device__ __forceinline__ void fold_publish(const TileParams &p)
+{
+    if (p.fold_fg)
+        signal_done(p.fold_done, gridDim.x * gridDim.y * gridDim.z);
+}
+
 }  // namespace grape

@@ -1409,11 +1409,14 @@ static bool states_stored(const grape_ctx *c)
     return !grape::tile_chain_is_split(tile_params(c, nullptr), false);
 }
 
-// ONE problem whose flow ends in a forms kernel of action_thin.hip: that kernel closes the evaluation (no reduce launch)
+// ONE problem whose flow ends in a forms kernel of action_thin.hip or in a unitary chain kernel (chain_tile_unitary_kernel,
+// coop_chain_unitary_kernel: every launch path of launch_nt with p.unitary and no stored costates): that kernel closes the
+// evaluation (no reduce launch)
 static bool tile_folds_reduce(const grape_ctx *c, int n_x)
 {
-    return c->family == 1 && (c->action || c->thin_dpp) && c->cfg.n_ensemble == 1 && n_x == 1 &&
-           c->cfg.gradient != GRAPE_GRADIENT_EXACT && c->direct_publish;
+    if (c->family != 1 || c->cfg.n_ensemble != 1 || n_x != 1 || c->cfg.gradient == GRAPE_GRADIENT_EXACT || !c->direct_publish)
+        return false;
+    return c->action || c->thin_dpp || (c->unitary && !c->thin && !c->d_costates);
 }
 
 static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream, int n_x, hipEvent_t ev_mid = nullptr,

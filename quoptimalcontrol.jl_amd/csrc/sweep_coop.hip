@@ -19,6 +19,7 @@
 
 #include "grape_kernels.hpp"
 #include "tile.hpp"
+#include "done_signal.hpp"
 
 namespace grape {
 
@@ -432,21 +433,28 @@ __global__ __launch_bounds__(256) void coop_chain_unitary_kernel(const TileParam
                 }
                 const double tot = reduce_scatter16(q16);
                 const int c = c0 + (lane >> 2);
-                if ((lane & 3) == 0 && lane < 32 && c < K)
+                if ((lane & 3) == 0 && lane < 32 && c < K) {
                     out[(size_t)t * K + c] = gs * tot;
+                    fold_store(p, (size_t)t * K + c, gs * tot);
+                }
             }
             if (t == N - 1 && lane == 0) {
+                double Fk;
                 if (SAND) {
                     const double inv = 1.0 / (double)p.n, ar = zr * inv, ai = zi * inv;
-                    out[(size_t)K * N] = 1.0 - (ar * ar + ai * ai);
+                    Fk = 1.0 - (ar * ar + ai * ai);
                 } else {
-                    out[(size_t)K * N] = zr * zr - zi * zi;
+                    Fk = zr * zr - zi * zi;
                 }
+                out[(size_t)K * N] = Fk;
+                fold_store(p, (size_t)K * N, Fk);
             }
         }
         Pm = Pn;
         Pn = Pnn;
     }
+    if (wave == 0 && lane == 0)                                    // (wave 0 made every store of this workgroup)
+        fold_publish(p);
 }
 
 // do the one-wave kernels of this launch leave most SIMDs idle?  (then four waves per product pay)

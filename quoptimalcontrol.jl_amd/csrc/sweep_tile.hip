@@ -29,6 +29,7 @@
 #include "cmat.hpp"          // Taylor-8 coefficients, squarings_for
 #include "grape_kernels.hpp"
 #include "tile.hpp"
+#include "done_signal.hpp"
 
 namespace grape {
 
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(64 * kPropWaves, NT == 1 ? 4 : 1) void prop_tile_ke
 template <int NT, int SAND>
 GRAPE_DEV void sparse_traces(const TMat<NT> &R, double2 *__restrict__ s_M, const double2 *__restrict__ s_coef,
                              const int *__restrict__ s_addr, int K, double zr, double zi, double gs,
-                             double *__restrict__ out_t, int lane, bool writer_ok)
+                             double *__restrict__ out_t, int lane, bool writer_ok, double *__restrict__ fold_t = nullptr,
+                             double fold_w = 0.0)
 {
     constexpr int MS = 16 * NT + 1;
 #pragma unroll
@@ -306,8 +308,11 @@ GRAPE_DEV void sparse_traces(const TMat<NT> &R, double2 *__restrict__ s_M, const
         }
         const double tot = reduce_scatter16(q16);
         const int c = c0 + (lane >> 2);
-        if (writer_ok && (lane & 3) == 0 && lane < 32 && c < K)
+        if (writer_ok && (lane & 3) == 0 && lane < 32 && c < K) {
             out_t[c] = gs * tot;
+            if (fold_t)                                            // one problem: this kernel closes the evaluation
+                fold_t[c] = fma(gs * tot, fold_w, 0.0);
+        }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);                            // the image is overwritten by the next slice
     __builtin_amdgcn_wave_barrier();
@@ -912,7 +917,8 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
         if (SPARSE) {
             // tr(B_c M_t) = sum over the non-zeros B_c[i][j] of B_c[i][j] M_t[j][i]; with z = conj(tr M) taken once
             // (the trace is invariant under M -> P' M P) every lane's share of g[c, t] is one real number
-            sparse_traces<NT, SAND>(M, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane, true);
+            sparse_traces<NT, SAND>(M, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane, true,
+                                    p.fold_fg ? fold_dst(p) + (size_t)t * K : nullptr, p.fold_fg ? p.fold_wts[0] : 0.0);
         } else
         for (int c0 = 0; c0 < K; c0 += 4) {
             double v[2 + 8];
@@ -952,22 +958,29 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
                 const int c = c0 + cc;
                 const double wr = v[2 + 2 * cc], wi = v[3 + 2 * cc];
                 const double im = SAND ? wi : fma(wr, zi, wi * zr);
-                if (c < K && writer)
+                if (c < K && writer) {
                     out[c + (size_t)t * K] = gs * im;
+                    fold_store(p, c + (size_t)t * K, gs * im);
+                }
             }
         }
         if (t == N - 1 && writer) {
+            double Fk;
             if (SAND) {
                 const double inv = 1.0 / (double)p.n;
                 const double ar = zr * inv, ai = zi * inv;
-                out[(size_t)K * N] = 1.0 - (ar * ar + ai * ai);
+                Fk = 1.0 - (ar * ar + ai * ai);
             } else {
-                out[(size_t)K * N] = zr * zr - zi * zi;
+                Fk = zr * zr - zi * zi;
             }
+            out[(size_t)K * N] = Fk;
+            fold_store(p, (size_t)K * N, Fk);
         }
         Pm = Pn;
         Pn = Pnn;
     }
+    if (lane == 0)                                                 // (single-wave workgroups)
+        fold_publish(p);
 }
 
 // ---------------------------------------------------------------------------------------------

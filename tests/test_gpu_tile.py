@@ -302,3 +302,50 @@ def test_general_flow_time_chunks(qoc, oracle, monkeypatch, n, sys_type, E, N, c
     assert_parity(F, G, F_ref, G_ref, n, what="ensemble")
     Fr, Gr = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, xs[1], w.T)
     assert_parity(Fb[1], Gb[1], Fr, Gr, n, what="batch entry 1")
+
+
+@pytest.mark.parametrize("n,K,N,sys_type,pauli", [
+    (5, 2, 6, "UnitaryGate", False), (8, 3, 100, "StateTransfer", False), (16, 4, 5, "UnitaryGate", True),
+    (16, 3, 300, "UnitaryGate", True), (16, 2, 129, "StateTransfer", False), (17, 2, 40, "UnitaryGate", False),
+    (32, 6, 7, "UnitaryGate", True), (32, 5, 400, "UnitaryGate", True), (32, 2, 90, "StateTransfer", False)])
+def test_single_unitary_problem_is_closed_by_the_chain_kernel(qoc, oracle, monkeypatch, n, K, N, sys_type, pauli):
+    """ONE problem with Hermitian generators (the single-`Problem` closure, src/solve.jl:63-143), n = 5..32: the unitary
+    chain kernel (one wave or four per product, chunked time axis or not, dense or list traces, member pairs for n <= 8)
+    writes the weighted [G, F] itself and its last workgroup publishes it -- bitwise what the reduce kernel hands out
+    (GRAPE_DIRECT_PUBLISH=0), on the host path and through the device entry point."""
+    import torch
+    w = _random_problem(qoc, n, K, N, 1, sys_type, seed=5 * n + N, mixed=True)
+    if pauli:                                                # sparse control operators: the (coefficient, position) lists
+        nq = {16: 4, 32: 5}[n]
+        rng = np.random.default_rng(n + K)
+        P = [np.eye(2), np.array([[0, 1], [1, 0]]), np.array([[0, -1j], [1j, 0]]), np.array([[1, 0], [0, -1]])]
+
+        def string():
+            M = np.array([[1.0 + 0j]])
+            for _ in range(nq):
+                M = np.kron(M, P[int(rng.integers(0, 4))])
+            return M
+        w.B[:] = np.array([[0.5 * string() for _ in range(K)]])
+    w.wts[:] = 0.43
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    res = []
+    for direct in ("1", "0"):
+        monkeypatch.setenv("GRAPE_DIRECT_PUBLISH", direct)
+        with _engine(qoc, w) as eng:
+            assert eng.info["unitary_flow"] == 1 and eng.info["kernel_family"] == 1
+            F, G = eng.eval(w.x)
+            F2, G2 = eng.eval(w.x)
+            foms, grads = eng.member_results()
+            xd = torch.as_tensor(np.ascontiguousarray(w.x.T), device="cuda")
+            fg = torch.zeros(K * N + 1, dtype=torch.float64, device="cuda")
+            eng.eval_device(xd.data_ptr(), fg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            h = fg.cpu().numpy()
+            F3, G3 = eng.eval(0.5 * w.x)
+        assert F == F2 and np.array_equal(G, G2)
+        assert h[-1] == F and np.array_equal(h[:-1].reshape(N, K).T, G)
+        assert F == foms[0] * w.wts[0] and np.array_equal(G, grads[0] * w.wts[0])
+        assert_parity(F, G, F_ref, G_ref, n, what=f"direct publication {direct}")
+        res.append((F, G, F3, G3))
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2] and np.array_equal(res[0][3], res[1][3])
