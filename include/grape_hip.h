@@ -160,7 +160,8 @@ typedef struct grape_info {
     int32_t rank_one_chain;        /* 1 after grape_set_operators found rank-one states in the 9 <= n <= 16 family
                                       (Xi = v v', Xt = w w' under the sandwich, or n x 1 states): the sweeps run on
                                       vectors; GRAPE_FLAG_FORCE_GENERAL keeps the dense chain */
-    int32_t sparse_controls;       /* 1: every control operator has at most 64 non-zeros (Pauli-type controls) and the
+    int32_t sparse_controls;       /* 1: every control operator has at most 64 non-zeros (Pauli-type controls; up to 256 --
+                                      sums of a few Pauli strings, global drives -- where the longer lists pay) and the
                                       kernels that support it read (coefficient, position) lists instead of dense
                                       operators for the gradient traces */
     int32_t fused_forward;         /* rank-one chain, single evaluations: 1 when the forward vector pass runs inside the

@@ -93,7 +93,9 @@ struct grape_ctx {
     bool herm_ctrl = false;                    // every B_c Hermitian
     double2 *d_vecs = nullptr;                 // thin: per member [v0 | wT], 16 complex each
     bool sparse_ctrl = false;                  // tile family: every B_c has <= kSparseMax non-zeros (sparse gradient traces)
-    double2 *d_sp_coef = nullptr;              // [E][K][kSparseMax]
+    int sp_nz = 64;                            // list length of the sparse control lists (64 .. 256)
+    size_t sp_cap = 0;                         // entries behind d_sp_coef / d_sp_addr
+    double2 *d_sp_coef = nullptr;              // [E][K][sp_nz]
     int32_t *d_sp_addr = nullptr;
     int hoist = 0;                             // tile family, prop_hoist.hip kernels: 1 member-invariant controls (control sum formed once per slice), 2 per-member controls
     double2 *d_ha = nullptr;                   // [EU] dumps of A'_k = (-i dt) A_k
@@ -976,21 +978,40 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         c->herm_ctrl = hb;
     }
     {   // sparse control operators (Pauli-type controls): lists of (B_c[i][j], position of M[j][i]) per member and control
-        constexpr int SM = grape::kSparseMax;
         bool sp = c->family == 1 && !c->pack2 && K >= 1 && K <= 16 && !env_on("GRAPE_NO_SPARSE");
+        // list length: the longest operator's non-zeros rounded up to whole wavefronts (64 for single Pauli strings up to five
+        // qubits; 128 .. 256 for sums of a few of them -- a global drive sum_i X_i on five qubits has 160), while the K
+        // lists fit the kernels' LDS budgets beside their images (K x length <= 1536 entries = 30 KB)
+        int SM = 64;
+        if (sp) {
+            size_t most = 0;
+            for (size_t m = 0; m < E * K; ++m) {
+                size_t cnt = 0;
+                for (size_t q = 0; q < nn; ++q)
+                    cnt += (B[2 * (m * nn + q)] != 0.0 || B[2 * (m * nn + q) + 1] != 0.0) ? 1 : 0;
+                most = std::max(most, cnt);
+            }
+            SM = (int)std::max<size_t>(64, (most + 63) / 64 * 64);
+            if (const char *e = std::getenv("GRAPE_SPARSE_MAX")) sp = most <= (size_t)std::atol(e);      // (tests, A/B timing)
+            if (SM > grape::kSparseMax || (size_t)K * SM > 1536) sp = false;
+        }
         std::vector<double> coef;
         std::vector<int32_t> addr;
         if (sp)
             sp = grape_host::build_sparse_lists(B, E, K, n, 16 * c->NT + 1, SM, coef, addr);
         c->sparse_ctrl = sp;
         if (sp) {
-            if (!c->d_sp_coef) {
-                HIP_TRY(c, hipMalloc((void **)&c->d_sp_coef, sizeof(double2) * E * K * SM));
-                c->bytes += sizeof(double2) * E * K * SM;
-            }
-            if (!c->d_sp_addr) {                             // (independent checks: the second allocation may fail alone)
-                HIP_TRY(c, hipMalloc((void **)&c->d_sp_addr, sizeof(int32_t) * E * K * SM));
-                c->bytes += sizeof(int32_t) * E * K * SM;
+            c->sp_nz = SM;
+            const size_t need = E * K * (size_t)SM;
+            if (c->sp_cap < need) {                          // (the list length may change between uploads)
+                (void)hipFree(c->d_sp_coef); c->d_sp_coef = nullptr;
+                (void)hipFree(c->d_sp_addr); c->d_sp_addr = nullptr;
+                c->bytes -= (sizeof(double2) + sizeof(int32_t)) * c->sp_cap;
+                c->sp_cap = 0;
+                HIP_TRY(c, hipMalloc((void **)&c->d_sp_coef, sizeof(double2) * need));
+                HIP_TRY(c, hipMalloc((void **)&c->d_sp_addr, sizeof(int32_t) * need));
+                c->sp_cap = need;
+                c->bytes += (sizeof(double2) + sizeof(int32_t)) * need;
             }
             HIP_TRY(c, hipMemcpy(c->d_sp_coef, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice));
             HIP_TRY(c, hipMemcpy(c->d_sp_addr, addr.data(), sizeof(int32_t) * addr.size(), hipMemcpyHostToDevice));
@@ -1153,6 +1174,14 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             }
         }
     }
+    // Lists longer than a wavefront where they pay: the chain kernels hold one wave per SIMD, and with more than ~40 KB of
+    // LDS per workgroup (images 21 KB at 32 x 32 + 20 B per list entry) only three of them fit a compute unit -- C5's shape
+    // with two global drives (160 non-zeros, lists of 192): 1024 members 75.6 ms against 66.8 with the dense traces, ONE
+    // problem 0.196 against 0.250 ms.  So: launches that leave LDS to spare (at most 3 workgroups per compute unit: single
+    // problems, a handful of members), or lists that keep K x length within 896 entries.  GRAPE_SPARSE_MAX=n forces.
+    if (c->sparse_ctrl && c->sp_nz > 64 && !std::getenv("GRAPE_SPARSE_MAX") && (size_t)K * c->sp_nz > 896 &&
+        (long)c->EU * std::max(1, c->tp_C) > 3L * c->compute_units)
+        c->sparse_ctrl = false;
     {   // Rank-one states with member-invariant control operators: the evaluation runs on vectors alone (action_thin.hip) --
         // exp(G_t) applied to the two chains' vectors by its Taylor series, no propagator formed or stored.  Ensembles that
         // fill the device (the chunked flows of small ensembles keep the expm kernel: they need the chunk PRODUCTS);
@@ -1373,6 +1402,7 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
         p.tp_u = c->d_tp_r + half;
     }
     p.sparse = c->sparse_ctrl ? 1 : 0;
+    p.sp_nz = c->sp_nz;
     p.sp_coef = c->d_sp_coef;
     p.sp_addr = c->d_sp_addr;
     p.hoist = c->hoist;

@@ -126,13 +126,15 @@ struct TileParams {
                           // runs the forward vector chain v_{t+1} = P_t v_t on the propagators it still holds in
                           // registers, writing the records; chain_thin_kernel then only runs its backward pass
                           // (P_t is read from HBM once instead of twice)
-    // sparse control operators (every B_c of every member has at most kSparseMax non-zeros -- Pauli-type controls):
-    // per member and control kSparseMax entries, zero padded: sp_coef = B_c[i][j], sp_addr = position of M[j][i]
+    // sparse control operators (every B_c of every member has at most kSparseMax = 256 non-zeros -- Pauli-type controls, sums of them):
+    // per member and control sp_nz entries, zero padded: sp_coef = B_c[i][j], sp_addr = position of M[j][i]
     // in the wave's LDS image of M (row j, column i, row stride 16 NT + 1).  The gradient traces tr(B_c M_t) then
     // read 64 entries instead of a dense transposed operator per control and slice.
     int32_t sparse;
-    const double2 *sp_coef;   // [unit][K][kSparseMax]
-    const int32_t *sp_addr;   // [unit][K][kSparseMax]
+    int32_t sp_nz;            // list length of this context: 64, 128, 192 or 256 (the longest operator's non-zeros, rounded up:
+                              // a lane owns sp_nz / 64 entries of every list -- sums of a few Pauli strings, global drives)
+    const double2 *sp_coef;   // [unit][K][sp_nz]
+    const int32_t *sp_addr;   // [unit][K][sp_nz]
     // member-invariant control operators (prop_hoist.hip): the control sum is formed once per slice and evaluation
     int32_t hoist;            // set by the host layer: every member has the same B_c (and the ensemble is worth a pre-pass)
     const double2 *ha;        // [unit] D-layout dumps of A'_k = (-i dt) A_k
@@ -163,7 +165,7 @@ struct TileParams {
     hipEvent_t ev_mid;        // timing (GRAPE_FLAG_TIME_KERNELS): recorded behind the expm kernel, in front of the chain kernels; or null
     double dt;
 };
-constexpr int kSparseMax = 64;
+constexpr int kSparseMax = 256;   // longest list (non-zeros of one control operator); a context's own length: TileParams.sp_nz
 // the chain over rank-one states (n = 9..16, one member per wavefront); called by launch_sweep_tile when p.thin
 hipError_t launch_chain_thin(int sandwich, const TileParams &p, hipStream_t stream);
 // rank-one states, member-invariant controls: the evaluation on vectors (action_thin.hip); called by launch_sweep_tile when p.action

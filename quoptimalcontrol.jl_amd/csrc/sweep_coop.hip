@@ -359,14 +359,14 @@ __global__ __launch_bounds__(256) void coop_chain_unitary_kernel(const TileParam
     extern __shared__ double2 s_coop[];
     char *s_z = reinterpret_cast<char *>(s_coop), *s_w = s_z + kCoopMatrix;
     double2 *s_coef = s_coop + 2 * kCoopMatrix / 16;
-    double2 *s_M = s_coef + (size_t)p.K * kSparseMax;
+    double2 *s_M = s_coef + (size_t)p.K * p.sp_nz;
     int *s_addr = reinterpret_cast<int *>(s_M + 16 * NT * MS);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, I = wave >> 1, J = wave & 1, tile = 2 * I + J;
     const int k = blockIdx.x, K = p.K, N = p.N, C = p.tp_chunks;
     {
-        const double2 *__restrict__ gc = p.sp_coef + (size_t)k * K * kSparseMax;
-        const int32_t *__restrict__ ga = p.sp_addr + (size_t)k * K * kSparseMax;
-        for (int i = threadIdx.x; i < K * kSparseMax; i += 256) {
+        const double2 *__restrict__ gc = p.sp_coef + (size_t)k * K * p.sp_nz;
+        const int32_t *__restrict__ ga = p.sp_addr + (size_t)k * K * p.sp_nz;
+        for (int i = threadIdx.x; i < K * p.sp_nz; i += 256) {
             s_coef[i] = gc[i];
             s_addr[i] = ga[i];
         }
@@ -425,10 +425,17 @@ __global__ __launch_bounds__(256) void coop_chain_unitary_kernel(const TileParam
                     q16[cc] = 0.0;
                     q16[8 + cc] = 0.0;
                     if (c0 + cc < K) {
-                        const double2 cf = s_coef[(c0 + cc) * kSparseMax + lane];
-                        const double2 mv = s_M[s_addr[(c0 + cc) * kSparseMax + lane]];
+                        const int nz = p.sp_nz;
+                        const double2 cf = s_coef[(c0 + cc) * nz + lane];
+                        const double2 mv = s_M[s_addr[(c0 + cc) * nz + lane]];
                         const double pr = cf.x * mv.x - cf.y * mv.y, pi = cf.x * mv.y + cf.y * mv.x;
                         q16[cc] = SAND ? pi : fma(pr, zi, pi * zr);
+                        for (int e = lane + 64; e < nz; e += 64) {
+                            const double2 cf2 = s_coef[(c0 + cc) * nz + e];
+                            const double2 mv2 = s_M[s_addr[(c0 + cc) * nz + e]];
+                            const double pr2 = cf2.x * mv2.x - cf2.y * mv2.y, pi2 = cf2.x * mv2.y + cf2.y * mv2.x;
+                            q16[cc] += SAND ? pi2 : fma(pr2, zi, pi2 * zr);
+                        }
                     }
                 }
                 const double tot = reduce_scatter16(q16);
@@ -471,7 +478,7 @@ bool coop_applies(const TileParams &p, int sandwich, bool keepl)
 
 size_t coop_chain_lds(const TileParams &p)
 {
-    return 2 * kCoopMatrix + sizeof(double2) * ((size_t)p.K * kSparseMax + 16 * 2 * 33) + sizeof(int32_t) * (size_t)p.K * kSparseMax;
+    return 2 * kCoopMatrix + sizeof(double2) * ((size_t)p.K * p.sp_nz + 16 * 2 * 33) + sizeof(int32_t) * (size_t)p.K * p.sp_nz;
 }
 
 hipError_t launch_coop_chunk_product(const TileParams &q, hipStream_t stream)

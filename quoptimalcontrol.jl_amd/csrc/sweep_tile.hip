@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64 * kPropWaves, NT == 1 ? 4 : 1) void prop_tile_ke
 template <int NT, int SAND>
 GRAPE_DEV void sparse_traces(const TMat<NT> &R, double2 *__restrict__ s_M, const double2 *__restrict__ s_coef,
                              const int *__restrict__ s_addr, int K, double zr, double zi, double gs,
-                             double *__restrict__ out_t, int lane, bool writer_ok, double *__restrict__ fold_t = nullptr,
+                             double *__restrict__ out_t, int lane, bool writer_ok, int nz, double *__restrict__ fold_t = nullptr,
                              double fold_w = 0.0)
 {
     constexpr int MS = 16 * NT + 1;
@@ -300,10 +300,16 @@ GRAPE_DEV void sparse_traces(const TMat<NT> &R, double2 *__restrict__ s_M, const
             q16[cc] = 0.0;
             q16[8 + cc] = 0.0;
             if (c0 + cc < K) {
-                const double2 cf = s_coef[(c0 + cc) * kSparseMax + lane];
-                const double2 mv = s_M[s_addr[(c0 + cc) * kSparseMax + lane]];
+                const double2 cf = s_coef[(c0 + cc) * nz + lane];
+                const double2 mv = s_M[s_addr[(c0 + cc) * nz + lane]];
                 const double pr = cf.x * mv.x - cf.y * mv.y, pi = cf.x * mv.y + cf.y * mv.x;
                 q16[cc] = SAND ? pi : fma(pr, zi, pi * zr);
+                for (int e = lane + 64; e < nz; e += 64) {          // lists longer than a wavefront (nz = 128, 192, 256)
+                    const double2 cf2 = s_coef[(c0 + cc) * nz + e];
+                    const double2 mv2 = s_M[s_addr[(c0 + cc) * nz + e]];
+                    const double pr2 = cf2.x * mv2.x - cf2.y * mv2.y, pi2 = cf2.x * mv2.y + cf2.y * mv2.x;
+                    q16[cc] += SAND ? pi2 : fma(pr2, zi, pi2 * zr);
+                }
             }
         }
         const double tot = reduce_scatter16(q16);
@@ -318,13 +324,13 @@ GRAPE_DEV void sparse_traces(const TMat<NT> &R, double2 *__restrict__ s_M, const
     __builtin_amdgcn_wave_barrier();
 }
 
-// sparse-list staging: [coefficients K * kSparseMax double2 | image of M | positions K * kSparseMax int]
+// sparse-list staging: [coefficients K * sp_nz double2 | image of M | positions K * sp_nz int]
 template <int NT>
 GRAPE_DEV void stage_sparse_lists(const TileParams &p, int k, int lane, int nthreads, double2 *s_coef, int *s_addr)
 {
-    const double2 *__restrict__ gc = p.sp_coef + (size_t)k * p.K * kSparseMax;
-    const int32_t *__restrict__ ga = p.sp_addr + (size_t)k * p.K * kSparseMax;
-    for (int i = lane; i < p.K * kSparseMax; i += nthreads) {
+    const double2 *__restrict__ gc = p.sp_coef + (size_t)k * p.K * p.sp_nz;
+    const int32_t *__restrict__ ga = p.sp_addr + (size_t)k * p.K * p.sp_nz;
+    for (int i = lane; i < p.K * p.sp_nz; i += nthreads) {
         s_coef[i] = gc[i];
         s_addr[i] = ga[i];
     }
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
     double2 *s_img = s_dynt;
     double2 *s_bt = s_dynt + kTileImage + 1;                       // SPARSE: coefficients | image | positions instead
     double2 *s_coef = s_bt;
-    double2 *s_M = s_coef + (size_t)p.K * kSparseMax;
+    double2 *s_M = s_coef + (size_t)p.K * p.sp_nz;
     int *s_addr = reinterpret_cast<int *>(s_M + 16 * NT * (16 * NT + 1));
     const int lane = threadIdx.x;
     const int k = blockIdx.x;
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
             }
             zr = z_keep_r;
             zi = z_keep_i;
-            sparse_traces<NT, SAND>(R, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane, member < p.E_members);
+            sparse_traces<NT, SAND>(R, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane, member < p.E_members, p.sp_nz);
         } else
         for (int c0 = 0; c0 < K; c0 += 4) {
             double v[2 + 8];
@@ -552,8 +558,8 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
     double2 *s_xch = s_dynt + 2 * (kTileImage + 1);                // [0..255] X_Nh (wave 0), [256..511] T1 (wave 1)
     double2 *s_bt = s_xch + 512;                                   // SPARSE: coefficients | two images of R | positions
     double2 *s_coef = s_bt;
-    double2 *s_M = s_coef + (size_t)p.K * kSparseMax + (size_t)half * (16 * 17);
-    int *s_addr = reinterpret_cast<int *>(s_coef + (size_t)p.K * kSparseMax + 2 * (16 * 17));
+    double2 *s_M = s_coef + (size_t)p.K * p.sp_nz + (size_t)half * (16 * 17);
+    int *s_addr = reinterpret_cast<int *>(s_coef + (size_t)p.K * p.sp_nz + 2 * (16 * 17));
     const int k = blockIdx.x;
     const int K = p.K, N = p.N, Nh = p.split_at;
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
@@ -656,7 +662,7 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
             }
             zr = z_keep_r;
             zi = z_keep_i;
-            sparse_traces<NT, SAND>(R, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane, true);
+            sparse_traces<NT, SAND>(R, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane, true, p.sp_nz);
         } else
         for (int c0 = 0; c0 < K || c0 == 0; c0 += 4) {
             double v[2 + 8];
@@ -772,7 +778,7 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
 // accumulates X_N = P_{N-1} ... P_0 Xi (UnitaryGate) or the total product T (sandwich:
 // X_N = T Xi T'), 1 product per slice; the backward pass carries M with 2 products per slice.
 // tr(X_t' L_t) is conj(tr M_t) (UnitaryGate) or t-invariant (sandwich, taken at t = N).
-// SPARSE (TileParams.sparse): every control operator has at most kSparseMax non-zeros.  The K dense transposed
+// SPARSE (TileParams.sparse): every control operator has at most kSparseMax non-zeros (lists of TileParams.sp_nz entries).  The K dense transposed
 // operators (K x 16 KB at NT = 2, re-read by every wave for every slice: 3/4 of this kernel's memory traffic at C5,
 // which made it Infinity-Cache-bound) are replaced by K x 64 (coefficient, position) entries staged in LDS; M_t is
 // written to an LDS image once per slice and the entries pick what they need.  One reduce-scatter per slice.
@@ -785,7 +791,7 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
     double2 *s_img = s_dynt;
     double2 *s_bt = s_dynt + kTileImage + 1;         // dense: transposed operators;  sparse: coefficients, M image, positions
     double2 *s_coef = s_bt;
-    double2 *s_M = s_coef + (size_t)p.K * kSparseMax;
+    double2 *s_M = s_coef + (size_t)p.K * p.sp_nz;
     int *s_addr = reinterpret_cast<int *>(s_M + 16 * NT * MS);
     const int lane = threadIdx.x;
     const int k = blockIdx.x;
@@ -917,7 +923,7 @@ __global__ __launch_bounds__(64) void chain_tile_unitary_kernel(const TileParams
         if (SPARSE) {
             // tr(B_c M_t) = sum over the non-zeros B_c[i][j] of B_c[i][j] M_t[j][i]; with z = conj(tr M) taken once
             // (the trace is invariant under M -> P' M P) every lane's share of g[c, t] is one real number
-            sparse_traces<NT, SAND>(M, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane, true,
+            sparse_traces<NT, SAND>(M, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane, true, p.sp_nz,
                                     p.fold_fg ? fold_dst(p) + (size_t)t * K : nullptr, p.fold_fg ? p.fold_wts[0] : 0.0);
         } else
         for (int c0 = 0; c0 < K; c0 += 4) {
@@ -1405,8 +1411,8 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         q.bt_in_lds = bt_b <= 24 * 1024 ? 1 : 0;                    // 4 workgroups per CU must still fit
         const size_t lds2 = sizeof(double2) * (2 * (kTileImage + 1) + 512) + (q.bt_in_lds ? bt_b : 0);
         if (p.sparse) {
-            const size_t lds_sp = sizeof(double2) * (2 * (kTileImage + 1) + 512 + (size_t)p.K * kSparseMax + 2 * 16 * 17) +
-                                  sizeof(int32_t) * (size_t)p.K * kSparseMax;
+            const size_t lds_sp = sizeof(double2) * (2 * (kTileImage + 1) + 512 + (size_t)p.K * p.sp_nz + 2 * 16 * 17) +
+                                  sizeof(int32_t) * (size_t)p.K * p.sp_nz;
             if (sandwich) hipLaunchKernelGGL((chain_tile_split_kernel<1, true>), grid, dim3(128), lds_sp, stream, q);
             else          hipLaunchKernelGGL((chain_tile_split_kernel<0, true>), grid, dim3(128), lds_sp, stream, q);
             return hipGetLastError();
@@ -1481,16 +1487,16 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
             return ec;
     } else if (p.unitary && !keepl && p.sparse && !pk) {
         // image for layout conversions | coefficients | image of M | positions
-        const size_t lds_sp = sizeof(double2) * (kTileImage + 1 + (size_t)p.K * kSparseMax + 16 * NT * (16 * NT + 1)) +
-                              sizeof(int32_t) * (size_t)p.K * kSparseMax;
+        const size_t lds_sp = sizeof(double2) * (kTileImage + 1 + (size_t)p.K * p.sp_nz + 16 * NT * (16 * NT + 1)) +
+                              sizeof(int32_t) * (size_t)p.K * p.sp_nz;
         if (sandwich) hipLaunchKernelGGL((chain_tile_unitary_kernel<NT, 1, false, true>), ugrid, block, lds_sp, stream, q);
         else          hipLaunchKernelGGL((chain_tile_unitary_kernel<NT, 0, false, true>), ugrid, block, lds_sp, stream, q);
     } else if (p.unitary && !keepl) {
         if (sandwich) { if (pk) GRAPE_LAUNCH_UNI((chain_tile_unitary_kernel<NT, 1, NT == 1>)); else GRAPE_LAUNCH_UNI((chain_tile_unitary_kernel<NT, 1, false>)); }
         else          { if (pk) GRAPE_LAUNCH_UNI((chain_tile_unitary_kernel<NT, 0, NT == 1>)); else GRAPE_LAUNCH_UNI((chain_tile_unitary_kernel<NT, 0, false>)); }
     } else if (p.sparse && !pk) {
-        const size_t lds_sp = sizeof(double2) * (kTileImage + 1 + (size_t)p.K * kSparseMax + 16 * NT * (16 * NT + 1)) +
-                              sizeof(int32_t) * (size_t)p.K * kSparseMax;
+        const size_t lds_sp = sizeof(double2) * (kTileImage + 1 + (size_t)p.K * p.sp_nz + 16 * NT * (16 * NT + 1)) +
+                              sizeof(int32_t) * (size_t)p.K * p.sp_nz;
 #define GRAPE_LAUNCH_SP(KERNEL) hipLaunchKernelGGL(KERNEL, ugrid, block, lds_sp, stream, q)
         if (sandwich) { if (keepl) GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 1, true, false, true>)); else GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 1, false, false, true>)); }
         else          { if (keepl) GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 0, true, false, true>)); else GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 0, false, false, true>)); }

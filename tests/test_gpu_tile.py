@@ -349,3 +349,43 @@ def test_single_unitary_problem_is_closed_by_the_chain_kernel(qoc, oracle, monke
         res.append((F, G, F3, G3))
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2] and np.array_equal(res[0][3], res[1][3])
+
+
+@pytest.mark.parametrize("n,sys_type,K,E,N,pairs,herm", [
+    (16, "UnitaryGate", 3, 3, 15, 40, True), (16, "StateTransfer", 6, 2, 70, 100, True), (32, "UnitaryGate", 6, 1, 120, 80, True),
+    (32, "UnitaryGate", 4, 3, 9, 120, True), (32, "StateTransfer", 2, 2, 33, 128, True), (24, "UnitaryGate", 5, 4, 21, 60, True),
+    (16, "CoherenceTransfer", 4, 3, 40, 90, False), (32, "CoherenceTransfer", 3, 2, 13, 100, False),
+    (12, "StateTransfer", 2, 5, 64, 60, False)])
+def test_control_lists_longer_than_a_wavefront(qoc, oracle, monkeypatch, n, sys_type, K, E, N, pairs, herm):
+    """Control operators with 65 .. 256 non-zeros (sums of a few Pauli strings, global drives): lists of 128 / 192 / 256
+    entries, a lane owns several of them -- unitary chain (one wave and four per product), general flow, split chain;
+    against the oracle, the dense traces (GRAPE_NO_SPARSE=1), and the 64-entry rule of rounds 1-2 (GRAPE_SPARSE_MAX=64)."""
+    w = _sparse_problem(qoc, n, K, N, E, sys_type, seed=11 + n + K + N, nnz_pairs=pairs)
+    nz = max(int(np.count_nonzero(w.B[k, c])) for k in range(E) for c in range(K))
+    assert 64 < nz <= 256, nz
+    if not herm:
+        rng = np.random.default_rng(n)
+        w.A = w.A + 0.2j * np.array([np.diag(rng.uniform(-1, 0, n)) for _ in range(E)])
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, per_member=True)
+    with _engine(qoc, w) as eng:
+        assert eng.info["sparse_controls"] == 1 and eng.info["unitary_flow"] == (1 if herm else 0)
+        F, G = eng.eval(w.x)
+        F2, G2 = eng.eval(w.x)
+        foms, grads = eng.member_results()
+    assert F == F2 and np.array_equal(G, G2)
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k}")
+    assert_parity(F, G, F_ref, G_ref, n, what="long lists")
+    monkeypatch.setenv("GRAPE_SPARSE_MAX", "64")
+    with _engine(qoc, w) as eng:
+        assert eng.info["sparse_controls"] == 0
+        F_d, G_d = eng.eval(w.x)
+    assert_parity(F, G, F_d, G_d, n, what="long lists vs dense traces")
+
+
+def test_too_many_list_entries_keep_the_dense_traces(qoc):
+    """K x list length beyond the kernels' LDS budget (1536 entries), or an operator with more than 256 non-zeros."""
+    for n, K, pairs in ((32, 8, 128), (32, 2, 200)):
+        w = _sparse_problem(qoc, n, K, 8, 2, "UnitaryGate", seed=3, nnz_pairs=pairs)
+        with _engine(qoc, w) as eng:
+            assert eng.info["sparse_controls"] == 0
