@@ -47,7 +47,8 @@ for i in range(cases):
         B = np.zeros((E, K, n, n), complex)
         for k in range(E):
             for c in range(K):
-                for _ in range(int(rng.integers(1, 14))):
+                # (now and then operators with 65 .. 256 non-zeros, n >= 12: control lists longer than a wavefront)
+                for _ in range(int(rng.integers(1, 14)) if n < 12 or rng.random() < 0.8 else int(rng.integers(36, 110))):
                     a, b = rng.integers(0, n, 2)
                     v = (rng.standard_normal() + 1j * rng.standard_normal()) * (1.0 if gscale == 1.0 else 0.5)
                     if a == b:
