@@ -1094,8 +1094,17 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // its chunks start at multiples of 8 slices (the vector formats and prefetch rings follow the slice index).
         c->tp_C = c->tp_S = c->tp_G = c->tp_g = 0;
         const long units = (long)c->EU, N = c->cfg.n_slices, slots = 4L * c->compute_units;
-        const bool small = c->family == 1 && 2 * units <= slots && !env_on("GRAPE_NO_TP");
         const bool general = !herm && !thin;                 // non-unitary propagators, full-rank states: prefix AND suffix products
+        // Single-tile chains (n <= 16, full-rank states) hold ~124 registers: four waves fit a SIMD, and one wave per SIMD
+        // hides none of its latencies -- 16 x 16 gate synthesis, N = 1000, chain kernel per member: 1024 members (one wave per
+        // SIMD) 4.17 us, 4096 members (four) 2.68 us.  So up to 32 x CUs (unit, chunk) pairs there, and for the unitary flow
+        // chunks up to 16 x CUs units (1024 members: 5.83 -> 3.98 ms per evaluation, 2048: 9.50 -> 7.96, 512: 2.43 -> 2.11;
+        // n = 8, 4096 members: 5.69 -> 4.72).  The general flow's two-wave split chain stays ahead from 2 x CUs units on
+        // (C4dense, 1024 members: 6.29 ms unchunked, 6.47 .. 6.80 chunked; 256 members 1.96 -> 1.69 with the longer cap).
+        // GRAPE_TP_SLOTS=m: m x CUs pairs for every case (tuning).
+        long pair_cap = (c->NT == 1 && !thin) ? 32L * c->compute_units : slots, small_cap = (c->NT == 1 && herm && !thin) ? pair_cap : slots;
+        if (const char *e = std::getenv("GRAPE_TP_SLOTS")) pair_cap = small_cap = std::max(1L, std::atol(e)) * c->compute_units;
+        const bool small = c->family == 1 && 2 * units <= (thin ? slots : small_cap) && !env_on("GRAPE_NO_TP");
         if (small && !thin && N >= 8) {
             // slices per chunk at the latency optimum: one-level scan 3 S + N / S dependent products (general flow),
             // two-level scan (unitary flow) 3 S + 2 sqrt(N / S); measured optima (tools/tp_sweep.py): 32 x 32, N = 2000:
@@ -1112,7 +1121,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             if (env_on("GRAPE_TP_ONE_LEVEL")) s_lat = std::lround(std::sqrt((double)N / 3.0));
             if (s_lat < 2) s_lat = 2;
             if (s_lat < 4 && N >= 64 && !env_on("GRAPE_TP_ONE_LEVEL")) s_lat = 4;
-            long C = std::min(slots / units, (N + s_lat - 1) / s_lat);
+            long C = std::min(pair_cap / units, (N + s_lat - 1) / s_lat);
             if (const char *e = std::getenv("GRAPE_TP_CHUNKS")) C = std::atol(e);
             if (C > N / 2) C = N / 2;
             if (C >= 2) {
