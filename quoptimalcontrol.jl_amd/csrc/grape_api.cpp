@@ -951,7 +951,8 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     const long dpp_min = dpp_env && dpp_env[0] == '1' ? 2 : (dpp_env && dpp_env[0] != '0' ? std::atol(dpp_env) : 80);
     bool dpp_small = thin && !act_only && !act_forced && !(dpp_env && dpp_env[0] == '0') && !(hoist_env && hoist_env[0] == '0') &&
                      !(dppc_env && dppc_env[0] == '0') && !env_on("GRAPE_NO_TP") && !env_on("GRAPE_THIN_SINGLE") &&
-                     (long)E < std::min(dpp_min, 41L) && c->cfg.n_slices >= 64;
+                     (long)E < std::min(dpp_min, std::getenv("GRAPE_DPP_SMALL_MAX") ? std::atol(std::getenv("GRAPE_DPP_SMALL_MAX")) : 41L) &&
+                     c->cfg.n_slices >= 64;
     // (dense control operators included: their forms run on the matrix cores -- action_forms_mfma_kernel; with the vector-ALU
     // forms kernel, GRAPE_FORMS_VALU=1, this flow loses there: one problem / eight, K = 4: 0.090 / 0.141 ms against 0.086 / 0.127
     // of the flows it replaces, 0.084 / 0.113 with the matrix-core kernel)
