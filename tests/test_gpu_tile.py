@@ -389,3 +389,21 @@ def test_too_many_list_entries_keep_the_dense_traces(qoc):
         w = _sparse_problem(qoc, n, K, 8, 2, "UnitaryGate", seed=3, nnz_pairs=pairs)
         with _engine(qoc, w) as eng:
             assert eng.info["sparse_controls"] == 0
+
+
+@pytest.mark.parametrize("n,sys_type,E,N", [(16, "UnitaryGate", 1100, 64), (8, "StateTransfer", 2300, 40), (12, "UnitaryGate", 3000, 33)])
+def test_single_tile_chains_are_chunked_beyond_one_wave_per_simd(qoc, oracle, n, sys_type, E, N):
+    """n <= 16, Hermitian generators, full-rank states, MORE members than SIMDs: the chains (four waves fit a SIMD) still
+    cut the time axis (round 3: up to 16 x CUs units) -- every member and the ensemble against the oracle."""
+    w = _random_problem(qoc, n, 3, N, E, sys_type, seed=n + N, mixed=True)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, per_member=True)
+    with _engine(qoc, w) as eng:
+        info = eng.info
+        assert info["unitary_flow"] == 1 and info["time_chunks"] >= 2, info
+        F, G = eng.eval(w.x)
+        F2, G2 = eng.eval(w.x)
+        foms, grads = eng.member_results()
+    assert F == F2 and np.array_equal(G, G2)
+    for k in list(range(0, E, 97)) + [E - 1]:
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k}")
+    assert_parity(F, G, F_ref, G_ref, n, what="ensemble")
