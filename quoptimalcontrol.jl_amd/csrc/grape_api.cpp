@@ -43,6 +43,9 @@
 #include "grape_host.hpp"
 #include "grape_kernels.hpp"
 
+// (hipFuncGetAttributes on it tells grape_create whether a code object of this build matches the device)
+__global__ void grape_probe_kernel() {}
+
 using grape::SweepParams;
 using grape::TileParams;
 typedef std::complex<double> cplx;
@@ -406,6 +409,16 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
                     std::string("grape_create: device is ") + prop.gcnArchName +
                         ", this library carries gfx950 code only");
 
+    {   // the code objects are built for one XNACK setting (Makefile TARGETS, default gfx950:xnack-): say so, instead of
+        // failing at the first launch, when this device runs with the other one
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, (const void *)grape_probe_kernel) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(nullptr, GRAPE_ERR_NO_DEVICE,
+                        std::string("grape_create: no code object of this library matches the device (") + prop.gcnArchName +
+                            "); rebuild with `make TARGETS=gfx950` for a device running with XNACK on");
+        }
+    }
     grape_ctx *c = new (std::nothrow) grape_ctx();
     if (!c) return fail(nullptr, GRAPE_ERR_ALLOC, "grape_create: out of host memory");
     c->cfg = *cfg;
