@@ -91,6 +91,8 @@ def test_library_carries_gfx950_code_only(qoc):
     assert b"gfx950" in blob
     for other in (b"gfx90a", b"gfx942", b"sm_80", b"nvptx"):
         assert other not in blob
+    # built for the pool's XNACK setting (csrc/Makefile TARGETS); an xnack+ object in the tree is refused by the GPU pool
+    assert b"gfx950:xnack-" in blob and b"xnack+" not in blob
 
 
 def test_header_is_plain_c():
