@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GRAPE_ABI_VERSION 3
+#define GRAPE_ABI_VERSION 4
 
 typedef enum grape_status {
     GRAPE_OK = 0,
@@ -328,6 +328,14 @@ int grape_get_kernel_time(grape_ctx *ctx, double *total_ms, int64_t *launches, i
  * src/timeevolution.jl:98-110; 0 for n <= 4, where one kernel does everything).  Multi-device contexts report the
  * first device.  *count (nullable) receives the number of durations available. */
 int grape_get_kernel_samples(grape_ctx *ctx, double *total_ms, double *first_ms, int64_t capacity, int64_t *count);
+
+/* ABI v4.  The kernels the most recent evaluation launched (grape_eval / grape_eval_device / one batch), by name and in launch
+ * order, ';'-separated and NUL-terminated in buf (at most capacity bytes; buf may be NULL): the names rocprofv3 prints, without
+ * namespace and template arguments -- e.g. "action_rows_kernel;action_parts_kernel;action_forms_sparse_kernel;reduce_stage1;
+ * reduce_stage2".  Which kernels serve src/GRAPE.jl:25-96 depends on what grape_set_operators found (grape_info) and on the
+ * ensemble size; benchmarks label their lines with this instead of guessing.  Multi-device contexts report the first device.
+ * Returns the buffer size the complete list needs (> 0), or a negative status. */
+int grape_get_kernel_names(const grape_ctx *ctx, char *buf, int32_t capacity);
 
 /* Host-side cost of the sharded grape_eval of a multi-device context (n_devices >= 2), means over the evaluations since the
  * last reset: out[0] = evaluations, then microseconds: out[1] writing x into every shard's buffer, out[2] first to last

@@ -168,8 +168,11 @@ GRAPE_DEV double rot8_odd_rows(double u)
 
 }  // namespace
 
-// grid (N, n_x), 256 threads: element e = NB r + j of Gc_t and of Gc_t'; act_b = per control [B'_c | B'_c'], row-major NB x NB
-template <int NB>
+// grid (N, n_x), 256 threads: element e = NB r + j of Gc_t and of Gc_t'; act_b = per control [B'_c | B'_c'], row-major NB x NB.
+// PLANAR (the 16 x 16 kernel below): the images are written as six planes of doubles per slice,
+//     [re Gc | im Gc | -im Gc | re Gc' | im Gc' | -im Gc'],
+// so that a lane of action_parts_kernel reads its 16 + 16 operands with the signs it multiplies with already in place (negation is exact: the sums below are the reference's, bit for bit).
+template <int NB, bool PLANAR>
 __global__ __launch_bounds__(256) void action_rows_kernel(const TileParams p)
 {
     constexpr int NN = NB * NB;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256) void action_rows_kernel(const TileParams p)
     const int t = blockIdx.x, y = blockIdx.y, K = p.K, N = p.N;
     const double *__restrict__ x = p.x + ((size_t)y * N + t) * K;
     const double2 *__restrict__ Bb = p.act_b;
-    double2 *__restrict__ dst = p.act_g + ((size_t)y * N + t) * 2 * NN;
+    double2 *__restrict__ dst = p.act_g + ((size_t)y * N + t) * (PLANAR ? 3 : 2) * NN;
     for (int e = threadIdx.x; e < NN; e += 256) {
         double2 g0, g1;
         {
@@ -195,8 +198,22 @@ __global__ __launch_bounds__(256) void action_rows_kernel(const TileParams p)
             g1.x = fma(b1.x, xc, g1.x);
             g1.y = fma(b1.y, xc, g1.y);
         }
-        dst[e] = g0;
-        dst[NN + e] = g1;
+        if (PLANAR) {
+            // inside a plane entry (r, j) sits at [j >> 1][r][j & 1]: the 16 lanes of a DPP row read one pair of columns
+            // as 256 contiguous bytes (a wave-level load touches 8 cache lines; row-major rows, 128 bytes apart per lane,
+            // were 64 lines per instruction and left the kernel waiting for the texture addresser: 2.6 ms instead of 1.4)
+            double *__restrict__ pl = reinterpret_cast<double *>(dst);
+            const int rr = e / NB, jj = e % NB, q = ((jj >> 1) * NB + rr) * 2 + (jj & 1);
+            pl[q] = g0.x;
+            pl[NN + q] = g0.y;
+            pl[2 * NN + q] = -g0.y;
+            pl[3 * NN + q] = g1.x;
+            pl[4 * NN + q] = g1.y;
+            pl[5 * NN + q] = -g1.y;
+        } else {
+            dst[e] = g0;
+            dst[NN + e] = g1;
+        }
         s_abs[e] = fabs(g0.x) + fabs(g0.y);
     }
     __syncthreads();
@@ -359,6 +376,167 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin_kernel(const TileP
         }
         if (h == 0)
             rec[d ? N - 1 - i : i + 1] = make_double2(xr, xi);
+    }
+}
+
+// ---- round 4: the shared-controls kernel on a layout whose products end in ONE cross-row exchange -------------------
+// DPP row rho = 2 d + c (d: direction, c: component of the RESULT: 0 = re, 1 = im) holds in lane r the WHOLE row r of
+// M = G_t (d = 0) or G_t' (d = 1) as the two real vectors it multiplies with,
+//     c = 0:  P = re M[r][.],  Q = -im M[r][.]      y_re[r] = sum_j P[j] x_re[j] + Q[j] x_im[j]
+//     c = 1:  P = im M[r][.],  Q =  re M[r][.]      y_im[r] = sum_j P[j] x_re[j] + Q[j] x_im[j]
+// (32 doubles, from the pre-pass's signed planes) and BOTH components of element r of the vector, x_re[r], x_im[r]: lane j
+// of a row is the broadcast source of column j for either component, no rotation.  A product is 32 FMACs into two
+// accumulators (what a lane issues alone is paced by the SIMD's issue logic, ~7 cycles per FP64 instruction, so two
+// chains cover the FMA latency), one add, the Horner update (twice: the swap needs two registers) and ONE
+// v_permlane16_swap that hands the re row its new x_im and the im row its new x_re: 39 vector instructions per product
+// pair instead of 50 and 4 dependent instructions between two products instead of 18 (tools/ubench/horner_step.hip,
+// profiles/r04_horner_step.txt: 117 against 146 ns per step with one wave per SIMD, 91 against 108 with four).
+#define GRAPE_ACT_MAC2(J, P, Q)                                                        \
+    "v_fmac_f64_dpp %0, %2, %" #P " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %1, %3, %" #Q " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n"
+GRAPE_DEV void act_matvec_parts(double &a0, double &a1, double xr, double xi, const double (&P)[16], const double (&Q)[16])
+{
+    // (the two moves are also the two wait states a DPP read needs behind the VALU write of xr / xi: no s_nop)
+    asm("v_mov_b64 %0, 0\nv_mov_b64 %1, 0\n" GRAPE_ACT_MAC2(0, 4, 12) GRAPE_ACT_MAC2(1, 5, 13) GRAPE_ACT_MAC2(2, 6, 14) GRAPE_ACT_MAC2(3, 7, 15)
+            GRAPE_ACT_MAC2(4, 8, 16) GRAPE_ACT_MAC2(5, 9, 17) GRAPE_ACT_MAC2(6, 10, 18) GRAPE_ACT_MAC2(7, 11, 19)
+        : "=&v"(a0), "=&v"(a1)
+        : "v"(xr), "v"(xi), "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]), "v"(P[4]), "v"(P[5]), "v"(P[6]), "v"(P[7]), "v"(Q[0]),
+          "v"(Q[1]), "v"(Q[2]), "v"(Q[3]), "v"(Q[4]), "v"(Q[5]), "v"(Q[6]), "v"(Q[7]));
+    asm(GRAPE_ACT_MAC2(8, 4, 12) GRAPE_ACT_MAC2(9, 5, 13) GRAPE_ACT_MAC2(10, 6, 14) GRAPE_ACT_MAC2(11, 7, 15)
+            GRAPE_ACT_MAC2(12, 8, 16) GRAPE_ACT_MAC2(13, 9, 17) GRAPE_ACT_MAC2(14, 10, 18) GRAPE_ACT_MAC2(15, 11, 19)
+        : "+v"(a0), "+v"(a1)
+        : "v"(xr), "v"(xi), "v"(P[8]), "v"(P[9]), "v"(P[10]), "v"(P[11]), "v"(P[12]), "v"(P[13]), "v"(P[14]), "v"(P[15]),
+          "v"(Q[8]), "v"(Q[9]), "v"(Q[10]), "v"(Q[11]), "v"(Q[12]), "v"(Q[13]), "v"(Q[14]), "v"(Q[15]));
+}
+#undef GRAPE_ACT_MAC2
+
+__global__ __launch_bounds__(64 * kActWaves, 2) void action_parts_kernel(const TileParams p)
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, d = lane >> 5, c = (lane >> 4) & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = blockIdx.x * kActWaves + wave, y = blockIdx.y, N = p.N;
+    if (k >= p.E)
+        return;
+    const size_t kw = (size_t)y * p.E + k;
+    // the pre-pass's planes of slice t: [re | im | -im] of Gc_t (d = 0) or Gc_t' (d = 1), 256 doubles each, row-major
+    // (entry (r, j) of a plane at [j >> 1][r][j & 1])
+    const double2 *__restrict__ Gy = p.act_g + (size_t)y * N * 768 + d * 384 + r;
+    const int offP = c ? 128 : 0, offQ = c ? 0 : 256;
+    const double *__restrict__ gn = p.act_gn + (size_t)y * N;
+    const double an = p.act_an[k];
+    double2 *__restrict__ rec = (d ? p.wrec : p.states) + kw * (size_t)(N + 1) * 16 + (size_t)r * (N + 1);
+    double aP[16], aQ[16];                                        // the member's A'_k (A'_k'), arranged and signed like P, Q
+    {
+        const double2 *__restrict__ Ak = p.act_a + (size_t)k * 512 + d * 256 + r * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double2 a = Ak[j];
+            aP[j] = c ? a.y : a.x;
+            aQ[j] = c ? a.x : -a.y;
+        }
+    }
+    double xr, xi;                                                // element r of the chain's vector, both components
+    {
+        const double2 t2 = p.vecs[(size_t)k * 32 + d * 16 + r];
+        xr = t2.x;
+        xi = t2.y;
+    }
+    rec[d ? N : 0] = make_double2(xr, xi);                        // (both rows of a chain: the same value to the same address --
+                                                                  //  an unconditional store keeps the compiler's vmcnt exact)
+    extern __shared__ unsigned short s_plan_all[];
+    unsigned short *s_plan = s_plan_all + (size_t)wave * N;       // this wave's own plan: no workgroup barrier anywhere
+    act_make_plan(s_plan, gn, an, N, p.s_forced, lane);
+    double sel = c ? xi : xr;                                     // the component this row updates
+    // Two register sets take turns: one holds G_t = Gc_t + A' (the products' operands), the other receives the planes of
+    // the next slice at the top of slice t and has A' added in place (no third set; the compiler places the additions
+    // behind the next slice's loads).  One wave per SIMD -- every ensemble up to four members per compute unit -- issues
+    // ONE instruction of any kind every ~2.6 ns, scalar ones included (tools/ubench/horner_step.hip), so the hot path is
+    // counted in instructions: the products of a slice are unrolled (degrees up to 8: a compare and a branch per step,
+    // no loop counter, no table load, 1/kk a literal), 39 vector instructions per product of which 32 FMACs.
+    // Per-lane pointers walk the pulse (forward chain up, backward chain down): the planes of the next slice and the
+    // record slot cost an addition each per slice, no index arithmetic, no clamps -- the chain prefetches ONE slice past
+    // its end of the pulse, which the host layer pads (the values are never used).
+    const double2 *gpP = Gy + (size_t)(d ? N - 1 : 0) * 768 + offP, *gpQ = Gy + (size_t)(d ? N - 1 : 0) * 768 + offQ;
+    const long gstep = d ? -768 : 768;
+    double2 *recp = rec + (d ? N - 1 : 1);
+    const long rstep = d ? -1 : 1;
+    auto fetch = [&](double (&nP)[16], double (&nQ)[16]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double2 a = gpP[16 * j], b = gpQ[16 * j];
+            nP[2 * j] = a.x;
+            nP[2 * j + 1] = a.y;
+            nQ[2 * j] = b.x;
+            nQ[2 * j + 1] = b.y;
+        }
+        gpP += gstep;
+        gpQ += gstep;
+    };
+    auto build = [&](double (&nP)[16], double (&nQ)[16]) {        // G = Gc + A' (A last, timeevolution.jl:108)
+        // every plane load was issued a whole slice ago and only the slice's record store is younger: ONE wait (the
+        // compiler, which sees the builtin, would otherwise place one in front of every second addition)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0f71);                       // vmcnt(1)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            nP[j] += aP[j];
+            nQ[j] += aQ[j];
+        }
+    };
+    unsigned plan;
+    // one Horner step u <- v + (G u) inv, inv = 1 / kk; returns this row's component of the new u
+    auto step = [&](const double (&P)[16], const double (&Q)[16], double inv) -> double {
+        double a0, a1;
+        act_matvec_parts(a0, a1, xr, xi, P, Q);
+        const double ysum = a0 + a1;
+        double mine = fma(ysum, inv, sel), other = fma(ysum, inv, sel);
+        asm volatile("" : "+v"(mine), "+v"(other));               // two registers: the swap overwrites both
+        const double keep = mine;
+        swap16(mine, other);                                      // mine: re of element r in both rows, other: im
+        xr = mine;
+        xi = other;
+        return keep;
+    };
+    auto slice = [&](double (&P)[16], double (&Q)[16], double (&nP)[16], double (&nQ)[16]) {
+        fetch(nP, nQ);
+        const int m = __builtin_amdgcn_readfirstlane(plan & 31), pieces = __builtin_amdgcn_readfirstlane(plan >> 5);
+        if (pieces == 1 && m <= 8) {                              // (every slice of a pulse whose |G_t| stays below 0.08)
+            if (m >= 8) (void)step(P, Q, 1.0 / 8);
+            if (m >= 7) (void)step(P, Q, 1.0 / 7);
+            if (m >= 6) (void)step(P, Q, 1.0 / 6);
+            if (m >= 5) (void)step(P, Q, 1.0 / 5);
+            if (m >= 4) (void)step(P, Q, 1.0 / 4);
+            if (m >= 3) (void)step(P, Q, 1.0 / 3);
+            if (m >= 2) (void)step(P, Q, 1.0 / 2);
+            sel = step(P, Q, 1.0);
+        } else {                                                  // degrees beyond 8, or the generator in pieces:
+            const double inv_p = 1.0 / (double)pieces;            // exp(G) = exp(G / p)^p, the 1 / p rides on the Horner factor
+            for (int piece = 0; piece < pieces; ++piece) {
+                for (int kk = m; kk >= 2; --kk)
+                    (void)step(P, Q, kActInv[kk] * inv_p);
+                sel = step(P, Q, inv_p);
+            }
+        }
+        *recp = make_double2(xr, xi);
+        recp += rstep;
+    };
+    double P0[16], Q0[16], P1[16], Q1[16];
+    fetch(P0, Q0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    build(P0, Q0);
+    int i = 0;
+    for (; i + 2 <= N; i += 2) {
+        plan = s_plan[i];
+        slice(P0, Q0, P1, Q1);
+        build(P1, Q1);
+        plan = s_plan[i + 1];
+        slice(P1, Q1, P0, Q0);
+        build(P0, Q0);
+    }
+    if (i < N) {
+        plan = s_plan[i];
+        slice(P0, Q0, P1, Q1);
     }
 }
 
@@ -906,11 +1084,11 @@ template <int R, int NB>
 static void launch_forms_sparse(int sandwich, const TileParams &p, dim3 grid, size_t lds, hipStream_t stream)
 {
     if (!sandwich)
-        hipLaunchKernelGGL((action_forms_sparse_kernel<0, true, R, NB>), grid, dim3(64), lds, stream, p);
+        GRAPE_LAUNCH((action_forms_sparse_kernel<0, true, R, NB>), grid, dim3(64), lds, stream, p);
     else if (p.herm_ctrl)
-        hipLaunchKernelGGL((action_forms_sparse_kernel<1, true, R, NB>), grid, dim3(64), lds, stream, p);
+        GRAPE_LAUNCH((action_forms_sparse_kernel<1, true, R, NB>), grid, dim3(64), lds, stream, p);
     else
-        hipLaunchKernelGGL((action_forms_sparse_kernel<1, false, R, NB>), grid, dim3(64), lds, stream, p);
+        GRAPE_LAUNCH((action_forms_sparse_kernel<1, false, R, NB>), grid, dim3(64), lds, stream, p);
 }
 
 template <int NB>
@@ -919,8 +1097,13 @@ static hipError_t launch_forms_nb(int sandwich, const TileParams &p, hipStream_t
 template <int NB>
 static hipError_t launch_action_nb(int sandwich, const TileParams &p, hipStream_t stream)
 {
-    if (p.act_shared)
-        hipLaunchKernelGGL((action_rows_kernel<NB>), dim3(p.N, p.n_x), dim3(256), 0, stream, p);
+    // GRAPE_ACT_LAYOUT=0: the round-3 layout (column halves) for shared controls too -- A/B timing only
+    static const bool old_layout = [] { const char *v = std::getenv("GRAPE_ACT_LAYOUT"); return v && v[0] == '0'; }();
+    const bool parts = NB == 16 && p.act_shared && !old_layout;
+    if (parts)
+        GRAPE_LAUNCH((action_rows_kernel<NB, true>), dim3(p.N, p.n_x), dim3(256), 0, stream, p);
+    else if (p.act_shared)
+        GRAPE_LAUNCH((action_rows_kernel<NB, false>), dim3(p.N, p.n_x), dim3(256), 0, stream, p);
     else if (NB != 16 || p.K > kActOwnK)
         return hipErrorInvalidConfiguration;                      // (the host layer keeps such ensembles on the expm flow)
     const size_t plan_bytes = sizeof(unsigned short) * (size_t)p.N * kActWaves;
@@ -934,13 +1117,14 @@ static hipError_t launch_action_nb(int sandwich, const TileParams &p, hipStream_
     lds = lds > 1024 ? (lds - 512) & ~(size_t)255 : lds;
     if (lds < plan_bytes)
         lds = plan_bytes;
-    auto kern = NB == 16 ? (p.act_shared ? action_thin_kernel<true> : action_thin_kernel<false>) : action_thin2_kernel;
+    auto kern = NB == 16 ? (parts ? action_parts_kernel : p.act_shared ? action_thin_kernel<true> : action_thin_kernel<false>) : action_thin2_kernel;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
     }
-    hipLaunchKernelGGL(kern, dim3((p.E + per_group - 1) / per_group, p.n_x), dim3(64 * kActWaves), lds, stream, p);
+    GRAPE_LAUNCH_AS(NB == 16 ? (parts ? "action_parts_kernel" : "action_thin_kernel") : "action_thin2_kernel", kern,
+                    dim3((p.E + per_group - 1) / per_group, p.n_x), dim3(64 * kActWaves), lds, stream, p);
     if (p.ev_mid) {
         hipError_t e = hipEventRecord(p.ev_mid, stream);
         if (e != hipSuccess)
@@ -970,20 +1154,20 @@ static hipError_t launch_forms_nb(int sandwich, const TileParams &p, hipStream_t
         const bool valu = std::getenv("GRAPE_FORMS_VALU") != nullptr;     // (the vector-ALU kernel: tests, A/B timing)
         if (!valu) {
             if (!sandwich)
-                hipLaunchKernelGGL((action_forms_mfma_kernel<0, true>), grid, dim3(64), 0, stream, p);
+                GRAPE_LAUNCH((action_forms_mfma_kernel<0, true>), grid, dim3(64), 0, stream, p);
             else if (p.herm_ctrl)
-                hipLaunchKernelGGL((action_forms_mfma_kernel<1, true>), grid, dim3(64), 0, stream, p);
+                GRAPE_LAUNCH((action_forms_mfma_kernel<1, true>), grid, dim3(64), 0, stream, p);
             else
-                hipLaunchKernelGGL((action_forms_mfma_kernel<1, false>), grid, dim3(64), 0, stream, p);
+                GRAPE_LAUNCH((action_forms_mfma_kernel<1, false>), grid, dim3(64), 0, stream, p);
             return hipGetLastError();
         }
     }
     if (!sandwich)
-        hipLaunchKernelGGL((action_forms_kernel<0, true, NB>), grid, dim3(64), 0, stream, p);
+        GRAPE_LAUNCH((action_forms_kernel<0, true, NB>), grid, dim3(64), 0, stream, p);
     else if (p.herm_ctrl)
-        hipLaunchKernelGGL((action_forms_kernel<1, true, NB>), grid, dim3(64), 0, stream, p);
+        GRAPE_LAUNCH((action_forms_kernel<1, true, NB>), grid, dim3(64), 0, stream, p);
     else
-        hipLaunchKernelGGL((action_forms_kernel<1, false, NB>), grid, dim3(64), 0, stream, p);
+        GRAPE_LAUNCH((action_forms_kernel<1, false, NB>), grid, dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -1006,10 +1190,10 @@ hipError_t launch_chain_prop(int sandwich, const TileParams &p, hipStream_t stre
         s.tp_chunks = 0;
         s.states = p.tp_vec;
         s.wrec = p.tp_vec + (size_t)p.n_x * p.E * 16 * (p.tp_chunks + 1);
-        hipLaunchKernelGGL(chain_prop_kernel, dim3(p.E, p.n_x), dim3(64), lds, stream, s);
-        hipLaunchKernelGGL(chain_prop_kernel, dim3(p.E, p.n_x, p.tp_chunks), dim3(64), lds, stream, p);
+        GRAPE_LAUNCH(chain_prop_kernel, dim3(p.E, p.n_x), dim3(64), lds, stream, s);
+        GRAPE_LAUNCH(chain_prop_kernel, dim3(p.E, p.n_x, p.tp_chunks), dim3(64), lds, stream, p);
     } else {
-        hipLaunchKernelGGL(chain_prop_kernel, dim3(p.E, p.n_x), dim3(64), lds, stream, p);
+        GRAPE_LAUNCH(chain_prop_kernel, dim3(p.E, p.n_x), dim3(64), lds, stream, p);
     }
     return launch_forms_nb<16>(sandwich, p, stream);
 }

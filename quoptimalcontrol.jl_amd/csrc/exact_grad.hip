@@ -481,8 +481,8 @@ template <int N>
 static hipError_t launch_exact_pair(int sandwich, const ExactParams &p, hipStream_t stream)
 {
     const dim3 grid((p.N + 31) / 32, p.E), block(64);
-    if (sandwich) hipLaunchKernelGGL((exact_pair_kernel<N, 1>), grid, block, 0, stream, p.ops, p.x, p);
-    else          hipLaunchKernelGGL((exact_pair_kernel<N, 0>), grid, block, 0, stream, p.ops, p.x, p);
+    if (sandwich) GRAPE_LAUNCH((exact_pair_kernel<N, 1>), grid, block, 0, stream, p.ops, p.x, p);
+    else          GRAPE_LAUNCH((exact_pair_kernel<N, 0>), grid, block, 0, stream, p.ops, p.x, p);
     return hipGetLastError();
 }
 
@@ -490,8 +490,8 @@ template <int N>
 static hipError_t launch_exact_n(int sandwich, const ExactParams &p, hipStream_t stream)
 {
     const dim3 grid((p.N + 63) / 64, p.E), block(64);
-    if (sandwich) hipLaunchKernelGGL((exact_grad_kernel<N, 1>), grid, block, 0, stream, p.ops, p.x, p);
-    else          hipLaunchKernelGGL((exact_grad_kernel<N, 0>), grid, block, 0, stream, p.ops, p.x, p);
+    if (sandwich) GRAPE_LAUNCH((exact_grad_kernel<N, 1>), grid, block, 0, stream, p.ops, p.x, p);
+    else          GRAPE_LAUNCH((exact_grad_kernel<N, 0>), grid, block, 0, stream, p.ops, p.x, p);
     return hipGetLastError();
 }
 

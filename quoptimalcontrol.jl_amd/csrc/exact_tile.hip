@@ -272,8 +272,8 @@ static hipError_t launch_exact_nt(int sandwich, const TileParams &p, int objecti
 {
     const dim3 grid((p.N + 3) / 4, p.E), block(256);
     const size_t lds = sizeof(double2) * 4 * (size_t)kTileImage;
-    if (sandwich) hipLaunchKernelGGL((exact_tile_kernel<NT, 1>), grid, block, lds, stream, p, objective);
-    else          hipLaunchKernelGGL((exact_tile_kernel<NT, 0>), grid, block, lds, stream, p, objective);
+    if (sandwich) GRAPE_LAUNCH((exact_tile_kernel<NT, 1>), grid, block, lds, stream, p, objective);
+    else          GRAPE_LAUNCH((exact_tile_kernel<NT, 0>), grid, block, lds, stream, p, objective);
     return hipGetLastError();
 }
 

@@ -129,6 +129,7 @@ struct grape_ctx {
     double2 *d_tp_a = nullptr;
     bool direct_publish = true;                // GRAPE_DIRECT_PUBLISH=0: always go through the reduce kernel
     unsigned long long seq = 0;
+    std::string kernel_log;                    // names of the kernels the last evaluation launched (grape_get_kernel_names)
     int x_upload = 1;             // 0: hipMemcpyAsync, 1: copy kernel reading the mapped staging buffer,
                                   // 2: the host writes x straight into fine-grained device memory (large BAR)
     double *d_x_bar = nullptr;    // mode 2: host-writable device buffer the sweep reads x from
@@ -164,6 +165,25 @@ struct grape_ctx {
 };
 
 static constexpr size_t kEventRing = 256;      // start/stop pairs kept before folding
+
+// where GRAPE_LAUNCH writes the names of the kernels it launches: the log of the evaluation this thread is issuing
+static thread_local std::string *g_kernel_log = nullptr;
+struct KernelLogScope {
+    explicit KernelLogScope(std::string *log) { g_kernel_log = log; if (log) log->clear(); }
+    ~KernelLogScope() { g_kernel_log = nullptr; }
+};
+namespace grape {
+void log_kernel(const char *expr)
+{
+    std::string *log = g_kernel_log;
+    if (!log || !expr) return;
+    while (*expr == '(' || *expr == ' ') ++expr;             // "(chain_tile_split_kernel<1, true>)" -> chain_tile_split_kernel
+    const char *end = expr;
+    while (*end && *end != '<' && *end != ')' && *end != ' ') ++end;
+    if (!log->empty()) log->push_back(';');
+    log->append(expr, (size_t)(end - expr));
+}
+}  // namespace grape
 
 static thread_local std::string g_create_err = "";
 
@@ -264,22 +284,42 @@ struct GroupWorker {
     grape_ctx *shard = nullptr;
     int (*job)(grape_ctx *) = nullptr;             // what to issue for this shard (set before req is bumped)
     int rc = 0;
+    // Sleep / wake handshake: the worker publishes `asleep` and THEN re-reads `req`; the poster bumps `req` and THEN reads
+    // `asleep`.  Both pairs are store -> load, which release / acquire does not order (the store can sit in the store
+    // buffer while the load runs: worker reads the old req, poster reads asleep == false, nobody notifies -- ADVICE r3).
+    // All four accesses are sequentially consistent, so at least one side sees the other's store.
     void post(int (*fn)(grape_ctx *))
     {
         job = fn;
-        req.fetch_add(1, std::memory_order_release);
-        if (asleep.load(std::memory_order_acquire)) {
+        req.fetch_add(1, std::memory_order_seq_cst);
+        if (asleep.load(std::memory_order_seq_cst)) {
             std::lock_guard<std::mutex> lk(mu);
             cv.notify_one();
         }
     }
-    int wait()                                     // the poster's side: spin until the job has been issued
+    // the poster's side: spin until the job has been issued; after `timeout_s` the shard is reported as hung
+    // (GRAPE_ERR_TIMEOUT) instead of spinning forever
+    int wait(double timeout_s)
     {
         const uint64_t want = req.load(std::memory_order_relaxed);
+        unsigned spins = 0;
+        timespec t0{0, 0};
         while (done.load(std::memory_order_acquire) != want) {
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
+            if ((++spins & 0xffff) == 0) {
+                timespec t;
+                clock_gettime(CLOCK_MONOTONIC, &t);
+                if (!t0.tv_sec && !t0.tv_nsec)
+                    t0 = t;
+                else if ((double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec) > timeout_s)
+                    return GRAPE_ERR_TIMEOUT;
+                {                                             // belt and braces: a sleeping worker with work posted is woken again
+                    std::lock_guard<std::mutex> lk(mu);
+                    cv.notify_one();
+                }
+            }
         }
         return rc;
     }
@@ -1305,7 +1345,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                 HIP_TRY(c, hipMemcpy(c->d_act_bs, bs.data(), sizeof(double) * bs.size(), hipMemcpyHostToDevice));
                 HIP_TRY(c, hipMemcpy(c->d_act_bo, bo.data(), sizeof(int32_t) * bo.size(), hipMemcpyHostToDevice));
             }
-            const size_t g_elems = (size_t)c->B * c->cfg.n_slices * 2 * VV;
+            const size_t g_elems = (size_t)c->B * c->cfg.n_slices * 3 * VV;   // (16 x 16: six planes of doubles per slice)
             if (!c->d_act_a) {
                 c->bytes += sizeof(double2) * (E * 2 * VV + g_elems) + sizeof(double) * (E + (size_t)c->B * c->cfg.n_slices);
                 HIP_TRY(c, hipMalloc((void **)&c->d_act_a, sizeof(double2) * E * 2 * VV));
@@ -1324,7 +1364,11 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                 c->act_var_bytes = now;
             }
             HIP_TRY(c, hipMemcpy(c->d_act_bn, bn.data(), sizeof(double) * bn.size(), hipMemcpyHostToDevice));
-            if (!c->d_act_g) HIP_TRY(c, hipMalloc((void **)&c->d_act_g, sizeof(double2) * g_elems));
+            // (one slice of slack in front and behind: the 16 x 16 chain kernel prefetches one slice past either end of the pulse)
+            if (!c->d_act_g) {
+                HIP_TRY(c, hipMalloc((void **)&c->d_act_g, sizeof(double2) * (g_elems + 2 * 3 * VV)));
+                HIP_TRY(c, hipMemset(c->d_act_g, 0, sizeof(double2) * (g_elems + 2 * 3 * VV)));
+            }
             if (!c->d_act_gn) HIP_TRY(c, hipMalloc((void **)&c->d_act_gn, sizeof(double) * (size_t)c->B * c->cfg.n_slices));
             if (dpp) {
                 const size_t need = sizeof(double2) * E * ((size_t)c->cfg.n_slices + 1) * VS * c->B;
@@ -1442,7 +1486,7 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.act_an = c->d_act_an;
     p.act_b = c->d_act_b;
     p.act_bf = c->d_act_bf;
-    p.act_g = c->d_act_g;
+    p.act_g = c->d_act_g ? c->d_act_g + 3 * (size_t)(c->cfg.n <= 16 ? 256 : 1024) : nullptr;
     p.act_gn = c->d_act_gn;
     p.act_R = (c->action || c->thin_dpp) ? c->act_R : 0;
     p.wrec = c->thin_dpp ? c->d_wrec : c->d_props;
@@ -1512,6 +1556,7 @@ static int fold_events(grape_ctx *c, uint64_t count)
 static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream_t stream, int n_x = 1,
                         grape::DoneSignal done = grape::DoneSignal())
 {
+    KernelLogScope log_scope(&c->kernel_log);
     SweepParams p{};
     p.ops = c->d_ops;
     p.x = d_x;
@@ -1733,9 +1778,9 @@ void GroupWorker::run()
                 const double idle = (double)(now.tv_sec - idle_since.tv_sec) + 1e-9 * (double)(now.tv_nsec - idle_since.tv_nsec);
                 if (idle > 2e-3) {
                     std::unique_lock<std::mutex> lk(mu);
-                    asleep.store(true, std::memory_order_release);
-                    cv.wait(lk, [&] { return req.load(std::memory_order_acquire) != seen || stop.load(); });
-                    asleep.store(false, std::memory_order_release);
+                    asleep.store(true, std::memory_order_seq_cst);
+                    cv.wait(lk, [&] { return req.load(std::memory_order_seq_cst) != seen || stop.load(); });
+                    asleep.store(false, std::memory_order_seq_cst);
                 }
             }
         }
@@ -1933,7 +1978,9 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
             int rc_w = GRAPE_OK;
             grape_ctx *bad = nullptr;
             for (size_t i = 1; i < c->sub.size(); ++i) {
-                const int r = c->sub[i]->worker->wait();
+                const int r = c->sub[i]->worker->wait(c->timeout_s);
+                if (r == GRAPE_ERR_TIMEOUT)                  // (the shard's own error text belongs to its thread: not touched here)
+                    return fail(c, GRAPE_ERR_TIMEOUT, "grape_eval: a shard's issuing thread did not answer within the timeout");
                 if (r && !rc_w) { rc_w = r; bad = c->sub[i]; }
             }
             if (rc) return group_fail(c, lead, rc);
@@ -2370,7 +2417,7 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
         return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: upload of x0 failed"));
     rc = run.evaluate(1);
     if (rc) return cleanup(rc);
-    HIP_TRY(c, hipSetDevice(lead->device));
+    if (hipSetDevice(lead->device) != hipSuccess) return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: hipSetDevice failed"));
     if (grape::launch_lbfgs_init(st, lead->stream, run.signal()) != hipSuccess)
         return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed"));
     rc = run.wait();
@@ -2501,7 +2548,7 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
             }
         }
     }
-    HIP_TRY(c, hipSetDevice(lead->device));
+    if (hipSetDevice(lead->device) != hipSuccess) return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: hipSetDevice failed"));
     if (hipMemcpyAsync(lead->h_fg, st.x, sizeof(double) * kn, hipMemcpyDeviceToHost, lead->stream) != hipSuccess ||
         hipStreamSynchronize(lead->stream) != hipSuccess)
         return cleanup(fail(c, GRAPE_ERR_HIP, "grape_lbfgs: download of the minimiser failed"));
@@ -2709,6 +2756,19 @@ extern "C" int grape_get_kernel_time(grape_ctx *c, double *total_ms, int64_t *la
     if (launches) *launches = c->ev_count;
     if (reset) { c->ev_total_ms = 0.0; c->ev_count = 0; c->smp_total.clear(); c->smp_first.clear(); }
     return GRAPE_OK;
+}
+
+extern "C" int grape_get_kernel_names(const grape_ctx *c, char *buf, int32_t capacity)
+{
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    const grape_ctx *s = c->is_group && !c->sub.empty() ? c->sub[0] : c;
+    const std::string &log = s->kernel_log;
+    if (buf && capacity > 0) {
+        const size_t n = std::min(log.size(), (size_t)capacity - 1);
+        std::memcpy(buf, log.data(), n);
+        buf[n] = 0;
+    }
+    return (int)log.size() + 1;
 }
 
 extern "C" int grape_get_kernel_samples(grape_ctx *c, double *total_ms, double *first_ms, int64_t capacity, int64_t *count)

@@ -7,6 +7,22 @@
 
 namespace grape {
 
+// Every kernel launch of the library goes through GRAPE_LAUNCH: the launchers' own names, in launch order, are what
+// grape_get_kernel_names reports for the last evaluation (bench.py labels its lines with them; they are the names rocprofv3
+// prints, without template arguments).  log_kernel is a no-op on threads that are not inside an evaluation's launches.
+void log_kernel(const char *expr);
+#define GRAPE_LAUNCH(KERNEL, ...)                        \
+    do {                                                 \
+        ::grape::log_kernel(#KERNEL);                    \
+        hipLaunchKernelGGL(KERNEL, __VA_ARGS__);         \
+    } while (0)
+#define GRAPE_LAUNCH_AS(NAME, KERNEL, ...)               \
+    do {                                                 \
+        ::grape::log_kernel(NAME);                       \
+        hipLaunchKernelGGL(KERNEL, __VA_ARGS__);         \
+    } while (0)
+
+
 // Scaling threshold of the expm: a generator of norm bound theta <= kTheta8 goes through the degree-8 Taylor polynomial
 // unscaled, larger ones are halved s times first and the result squared s times.  The truncation error of the
 // polynomial is theta^9 / 9! = 3.7e-16 at 0.08 (absolute, |P| ~ 1) -- the size of one rounding error of its three
@@ -155,7 +171,8 @@ struct TileParams {
     int32_t act_R;            // > 0: every row of every B_c has at most act_R non-zeros (1, 2, 3, 4 or 6) -- the forms read
     const double2 *act_bs;    //      [K][16][act_R] values B_c[i][j], zero padded, and
     const int32_t *act_bo;    //      [K][16][act_R] the byte offsets 1024 j of their columns in the kernel's LDS tile
-    double2 *act_g;           // [control array][slice][2][256]: [Gc_t | Gc_t'], written by the pre-pass
+    double2 *act_g;           // [control array][slice][2][256]: [Gc_t | Gc_t'], written by the pre-pass (16 x 16, shared controls:
+                              //    six planes of 256 doubles [re | im | -im] of Gc_t, then of Gc_t': action_parts_kernel)
     double *act_gn;           // [control array][slice] max(|Gc_t|_1, |Gc_t|_inf)
     // ONE problem (E = 1, one control array) on a flow that ends in a forms kernel of action_thin.hip: that kernel writes the
     // weighted row [G, F] itself and its last workgroup publishes it -- no reduce launch.  fold_fg: destination / staging

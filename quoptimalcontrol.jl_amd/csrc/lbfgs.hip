@@ -810,29 +810,29 @@ __global__ __launch_bounds__(kRegThreads, 2) void lbfgs_step_reg_kernel(LbfgsSta
 hipError_t launch_lbfgs_step(const LbfgsState &st, int commit, hipStream_t stream, DoneSignal done)
 {
     if (st.KN > 512 && st.KN <= kRegThreads * kRegPer && st.m <= kRegM)
-        hipLaunchKernelGGL(lbfgs_step_reg_kernel, dim3(1), dim3(kRegThreads), 0, stream, st, commit, done);
+        GRAPE_LAUNCH(lbfgs_step_reg_kernel, dim3(1), dim3(kRegThreads), 0, stream, st, commit, done);
     else if (st.KN <= 512)                           // short control arrays: one wave, no workgroup barrier
-        hipLaunchKernelGGL(lbfgs_step_kernel, dim3(1), dim3(64), sizeof(double) * ((size_t)st.KN + 64), stream, st, commit, done);
+        GRAPE_LAUNCH(lbfgs_step_kernel, dim3(1), dim3(64), sizeof(double) * ((size_t)st.KN + 64), stream, st, commit, done);
     else
-        hipLaunchKernelGGL(lbfgs_step_block_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, commit, done);
+        GRAPE_LAUNCH(lbfgs_step_block_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, commit, done);
     return hipGetLastError();
 }
 
 hipError_t launch_lbfgs_init(const LbfgsState &st, hipStream_t stream, DoneSignal done)
 {
-    hipLaunchKernelGGL(lbfgs_init_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, done);
+    GRAPE_LAUNCH(lbfgs_init_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, done);
     return hipGetLastError();
 }
 
 hipError_t launch_lbfgs_direction(const LbfgsState &st, int B, double alpha0, hipStream_t stream)
 {
-    hipLaunchKernelGGL(lbfgs_direction_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, B, alpha0);
+    GRAPE_LAUNCH(lbfgs_direction_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, B, alpha0);
     return hipGetLastError();
 }
 
 hipError_t launch_lbfgs_select(const LbfgsState &st, int B, hipStream_t stream, DoneSignal done, int mode)
 {
-    hipLaunchKernelGGL(lbfgs_select_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, B, mode, done);
+    GRAPE_LAUNCH(lbfgs_select_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, B, mode, done);
     return hipGetLastError();
 }
 
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(kLbfgsThreads) void lbfgs_trial_kernel(LbfgsState s
 
 hipError_t launch_lbfgs_trial(const LbfgsState &st, double alpha, hipStream_t stream)
 {
-    hipLaunchKernelGGL(lbfgs_trial_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, alpha);
+    GRAPE_LAUNCH(lbfgs_trial_kernel, dim3(1), dim3(kLbfgsThreads), 0, stream, st, alpha);
     return hipGetLastError();
 }
 

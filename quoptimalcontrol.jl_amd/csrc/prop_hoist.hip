@@ -765,9 +765,9 @@ hipError_t launch_ctrl_sum(int NT, const TileParams &p, hipStream_t stream)
 {
     const dim3 grid(p.N, p.n_x), block(64 * NT * NT);
     if (NT == 1)
-        hipLaunchKernelGGL((ctrl_sum_kernel<1>), grid, block, 0, stream, p);
+        GRAPE_LAUNCH((ctrl_sum_kernel<1>), grid, block, 0, stream, p);
     else
-        hipLaunchKernelGGL((ctrl_sum_kernel<2>), grid, block, 0, stream, p);
+        GRAPE_LAUNCH((ctrl_sum_kernel<2>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 
@@ -785,11 +785,11 @@ hipError_t launch_prop_hoist(int NT, const TileParams &q, hipStream_t stream)
         const size_t lds = sizeof(double2) * (kHoistWaves * (size_t)kTileImage + 33);
         const dim3 grid(q.fuse_fwd ? 1 : (q.N + q.prop_slices - 1) / q.prop_slices, q.E, q.n_x), block(64 * kHoistWaves);
         if (q.fuse_fwd) {
-            if (hoisted) hipLaunchKernelGGL((prop_hoist1_kernel<true, true>), grid, block, lds, stream, q);
-            else         hipLaunchKernelGGL((prop_hoist1_kernel<true, false>), grid, block, lds, stream, q);
+            if (hoisted) GRAPE_LAUNCH((prop_hoist1_kernel<true, true>), grid, block, lds, stream, q);
+            else         GRAPE_LAUNCH((prop_hoist1_kernel<true, false>), grid, block, lds, stream, q);
         } else {
-            if (hoisted) hipLaunchKernelGGL((prop_hoist1_kernel<false, true>), grid, block, lds, stream, q);
-            else         hipLaunchKernelGGL((prop_hoist1_kernel<false, false>), grid, block, lds, stream, q);
+            if (hoisted) GRAPE_LAUNCH((prop_hoist1_kernel<false, true>), grid, block, lds, stream, q);
+            else         GRAPE_LAUNCH((prop_hoist1_kernel<false, false>), grid, block, lds, stream, q);
         }
         return hipGetLastError();
     }
@@ -797,8 +797,8 @@ hipError_t launch_prop_hoist(int NT, const TileParams &q, hipStream_t stream)
         const size_t lds = 2 * (size_t)kImg2Matrix;
         const int per = q.prop_slices;
         const dim3 grid((q.N + per - 1) / per, q.E, q.n_x), block(256);
-        if (hoisted) hipLaunchKernelGGL(prop_hoist2_kernel<true>, grid, block, lds, stream, q);
-        else         hipLaunchKernelGGL(prop_hoist2_kernel<false>, grid, block, lds, stream, q);
+        if (hoisted) GRAPE_LAUNCH(prop_hoist2_kernel<true>, grid, block, lds, stream, q);
+        else         GRAPE_LAUNCH(prop_hoist2_kernel<false>, grid, block, lds, stream, q);
         return hipGetLastError();
     }
     return hipErrorInvalidValue;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restri
 
 hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, int n_x, hipStream_t stream, DoneSignal done)
 {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((Q + 7) / 8, n_x), dim3(256), 0, stream, rows, fg, NB, Q, done);
+    GRAPE_LAUNCH(reduce_rows_kernel, dim3((Q + 7) / 8, n_x), dim3(256), 0, stream, rows, fg, NB, Q, done);
     return hipGetLastError();
 }
 
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void copy_kernel(const double *__restrict__ sr
 
 hipError_t launch_copy(const double *src, double *dst, int n, hipStream_t stream, DoneSignal done)
 {
-    hipLaunchKernelGGL(copy_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, dst, n, done);
+    GRAPE_LAUNCH(copy_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, dst, n, done);
     return hipGetLastError();
 }
 
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void reduce_shards_kernel(ShardRows rows, doub
 
 hipError_t launch_reduce_shards(const ShardRows &rows, double *fg, int Q, hipStream_t stream, DoneSignal done)
 {
-    hipLaunchKernelGGL(reduce_shards_kernel, dim3((Q + 255) / 256), dim3(256), 0, stream, rows, fg, Q, done);
+    GRAPE_LAUNCH(reduce_shards_kernel, dim3((Q + 255) / 256), dim3(256), 0, stream, rows, fg, Q, done);
     return hipGetLastError();
 }
 
@@ -202,17 +202,17 @@ hipError_t launch_reduce(const double *member_out, const double *wts, double *pa
                          int E, int Q, int ksplit, hipStream_t stream, DoneSignal done)
 {
     if (ksplit == 1 && E <= 32) {
-        hipLaunchKernelGGL(reduce_few_kernel, dim3((Q + 255) / 256), dim3(256), 0, stream, member_out, wts, fg, E, Q, done);
+        GRAPE_LAUNCH(reduce_few_kernel, dim3((Q + 255) / 256), dim3(256), 0, stream, member_out, wts, fg, E, Q, done);
         return hipGetLastError();
     }
     const int per_split = (E + ksplit - 1) / ksplit;
     const dim3 g1((Q + kTileQ - 1) / kTileQ, ksplit), b1(kTileQ * kSubK);
-    hipLaunchKernelGGL(reduce_stage1, g1, b1, 0, stream, member_out, wts, partial, E, Q, per_split);
+    GRAPE_LAUNCH(reduce_stage1, g1, b1, 0, stream, member_out, wts, partial, E, Q, per_split);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
     const int per_block = 256 / kMaxSplit;
-    hipLaunchKernelGGL(reduce_stage2, dim3((Q + per_block - 1) / per_block), dim3(256), 0, stream, partial,
+    GRAPE_LAUNCH(reduce_stage2, dim3((Q + per_block - 1) / per_block), dim3(256), 0, stream, partial,
                        fg, Q, ksplit, done);
     return hipGetLastError();
 }

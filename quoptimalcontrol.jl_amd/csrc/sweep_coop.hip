@@ -483,13 +483,13 @@ size_t coop_chain_lds(const TileParams &p)
 
 hipError_t launch_coop_chunk_product(const TileParams &q, hipStream_t stream)
 {
-    hipLaunchKernelGGL(coop_chunk_product_kernel, dim3(q.E, q.n_x, q.tp_chunks), dim3(256), kCoopLds, stream, q);
+    GRAPE_LAUNCH(coop_chunk_product_kernel, dim3(q.E, q.n_x, q.tp_chunks), dim3(256), kCoopLds, stream, q);
     return hipGetLastError();
 }
 
 hipError_t launch_coop_scan_group(const TileParams &q, hipStream_t stream)
 {
-    hipLaunchKernelGGL(coop_scan_group_kernel, dim3(q.E, q.n_x, q.tp_groups), dim3(256),
+    GRAPE_LAUNCH(coop_scan_group_kernel, dim3(q.E, q.n_x, q.tp_groups), dim3(256),
                        2 * kCoopMatrix + 4 * kTileImage * 16, stream, q);
     return hipGetLastError();
 }
@@ -497,8 +497,8 @@ hipError_t launch_coop_scan_group(const TileParams &q, hipStream_t stream)
 hipError_t launch_coop_scan(int sandwich, const TileParams &q, hipStream_t stream)
 {
     const size_t lds = 2 * kCoopMatrix + 8 * kTileImage * 16;
-    if (sandwich) hipLaunchKernelGGL(coop_scan_kernel<1>, dim3(q.E, q.n_x), dim3(256), lds, stream, q);
-    else          hipLaunchKernelGGL(coop_scan_kernel<0>, dim3(q.E, q.n_x), dim3(256), lds, stream, q);
+    if (sandwich) GRAPE_LAUNCH(coop_scan_kernel<1>, dim3(q.E, q.n_x), dim3(256), lds, stream, q);
+    else          GRAPE_LAUNCH(coop_scan_kernel<0>, dim3(q.E, q.n_x), dim3(256), lds, stream, q);
     return hipGetLastError();
 }
 
@@ -511,7 +511,7 @@ hipError_t launch_coop_chain_unitary(int sandwich, const TileParams &q, hipStrea
         if (e != hipSuccess)
             return e;
     }
-    hipLaunchKernelGGL(kern, dim3(q.E, q.n_x, q.tp_chunks), dim3(256), lds, stream, q);
+    GRAPE_LAUNCH_AS("coop_chain_unitary_kernel", kern, dim3(q.E, q.n_x, q.tp_chunks), dim3(256), lds, stream, q);
     return hipGetLastError();
 }
 

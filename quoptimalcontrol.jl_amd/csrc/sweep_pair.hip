@@ -775,7 +775,7 @@ static hipError_t plaunch_one(const SweepParams &p0, hipStream_t stream)
         if (e != hipSuccess)
             return e;
     }
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, p.ops, p.x, p.wts, p);
+    GRAPE_LAUNCH_AS("sweep_pair_kernel", kern, grid, block, lds, stream, p.ops, p.x, p.wts, p);
     return hipGetLastError();
 }
 

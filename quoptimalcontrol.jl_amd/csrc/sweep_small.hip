@@ -589,7 +589,7 @@ static hipError_t launch_one(const SweepParams &p, hipStream_t stream)
         if (e != hipSuccess)
             return e;
     }
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, p.ops, p.x, p.wts, p);
+    GRAPE_LAUNCH_AS("sweep_small_kernel", kern, grid, block, lds, stream, p.ops, p.x, p.wts, p);
     return hipGetLastError();
 }
 

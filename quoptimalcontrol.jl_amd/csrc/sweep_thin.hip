@@ -540,9 +540,9 @@ static void launch_thin(const TileParams &q, size_t lds, hipStream_t stream)
 {
     const dim3 grid(q.E, q.n_x, q.tp_chunks ? q.tp_chunks : 1);
     if (q.bt_in_lds)
-        hipLaunchKernelGGL((chain_thin_kernel<SAND, HERMB, true>), grid, dim3(64), lds, stream, q);
+        GRAPE_LAUNCH((chain_thin_kernel<SAND, HERMB, true>), grid, dim3(64), lds, stream, q);
     else
-        hipLaunchKernelGGL((chain_thin_kernel<SAND, HERMB, false>), grid, dim3(64), 0, stream, q);
+        GRAPE_LAUNCH((chain_thin_kernel<SAND, HERMB, false>), grid, dim3(64), 0, stream, q);
 }
 
 hipError_t launch_chain_thin(int sandwich, const TileParams &p, hipStream_t stream)
@@ -550,8 +550,8 @@ hipError_t launch_chain_thin(int sandwich, const TileParams &p, hipStream_t stre
     TileParams q = p;
     if (q.tp_chunks > 1 && !q.fuse_fwd) {
         const dim3 cgrid(p.E, p.n_x, p.tp_chunks);
-        hipLaunchKernelGGL(chunk_product_thin_kernel, cgrid, dim3(64), sizeof(double2) * (kTileImage + 1), stream, q);
-        hipLaunchKernelGGL(chunk_scan_thin_kernel, dim3(p.E, p.n_x, 2), dim3(64), 0, stream, q);
+        GRAPE_LAUNCH(chunk_product_thin_kernel, cgrid, dim3(64), sizeof(double2) * (kTileImage + 1), stream, q);
+        GRAPE_LAUNCH(chunk_scan_thin_kernel, dim3(p.E, p.n_x, 2), dim3(64), 0, stream, q);
     } else {
         q.tp_chunks = 0;
     }

@@ -1361,7 +1361,7 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         if (hoisted) {                                             // member-invariant controls: prop_hoist.hip
             e = launch_prop_hoist(NT, q, stream);
         } else {
-            hipLaunchKernelGGL((prop_tile_kernel<NT>), dim3(q.fuse_fwd ? 1 : (p.N + per_block - 1) / per_block, p.E, p.n_x),
+            GRAPE_LAUNCH((prop_tile_kernel<NT>), dim3(q.fuse_fwd ? 1 : (p.N + per_block - 1) / per_block, p.E, p.n_x),
                                dim3(64 * WPB), lds, stream, q);
             e = hipGetLastError();
         }
@@ -1377,10 +1377,10 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
                 if (p.tp_chunks > 1) {                                 // small ensembles: Q_c and Q_c^T of every chunk of the time axis
                     static const bool one_wave = std::getenv("GRAPE_CHUNK_PRODUCT_1W") != nullptr;
                     if (p.tp_S >= 8 && !one_wave)                      // four waves per chunk: S / 4 + 3 dependent products
-                        hipLaunchKernelGGL(chunk_product_quad_kernel, dim3(p.E, p.n_x, p.tp_chunks), dim3(256),
+                        GRAPE_LAUNCH(chunk_product_quad_kernel, dim3(p.E, p.n_x, p.tp_chunks), dim3(256),
                                            sizeof(double2) * (kTileImage + 1 + 3 * 256), stream, q);
                     else
-                        hipLaunchKernelGGL(chunk_product_deep_kernel, dim3(p.E, p.n_x, p.tp_chunks), dim3(64),
+                        GRAPE_LAUNCH(chunk_product_deep_kernel, dim3(p.E, p.n_x, p.tp_chunks), dim3(64),
                                            sizeof(double2) * (kTileImage + 1), stream, q);
                     e = hipGetLastError();
                     if (e != hipSuccess)
@@ -1413,12 +1413,12 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         if (p.sparse) {
             const size_t lds_sp = sizeof(double2) * (2 * (kTileImage + 1) + 512 + (size_t)p.K * p.sp_nz + 2 * 16 * 17) +
                                   sizeof(int32_t) * (size_t)p.K * p.sp_nz;
-            if (sandwich) hipLaunchKernelGGL((chain_tile_split_kernel<1, true>), grid, dim3(128), lds_sp, stream, q);
-            else          hipLaunchKernelGGL((chain_tile_split_kernel<0, true>), grid, dim3(128), lds_sp, stream, q);
+            if (sandwich) GRAPE_LAUNCH((chain_tile_split_kernel<1, true>), grid, dim3(128), lds_sp, stream, q);
+            else          GRAPE_LAUNCH((chain_tile_split_kernel<0, true>), grid, dim3(128), lds_sp, stream, q);
             return hipGetLastError();
         }
-        if (sandwich) hipLaunchKernelGGL((chain_tile_split_kernel<1>), grid, dim3(128), lds2, stream, q);
-        else          hipLaunchKernelGGL((chain_tile_split_kernel<0>), grid, dim3(128), lds2, stream, q);
+        if (sandwich) GRAPE_LAUNCH((chain_tile_split_kernel<1>), grid, dim3(128), lds2, stream, q);
+        else          GRAPE_LAUNCH((chain_tile_split_kernel<0>), grid, dim3(128), lds2, stream, q);
         return hipGetLastError();
     }
     // unitary flow, small ensembles: the time axis in chunks (chunk_product_kernel / chunk_scan_kernel above), grid.z = chunk
@@ -1436,10 +1436,10 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
             if (ec != hipSuccess)
                 return ec;
         } else
-        hipLaunchKernelGGL((chunk_product_kernel<NT>), ugrid, block, lds_img, stream, q);
+        GRAPE_LAUNCH((chunk_product_kernel<NT>), ugrid, block, lds_img, stream, q);
         if (!p.unitary) {
             if (q.tp_groups) {                                     // two levels: inside the groups, then over the groups
-                hipLaunchKernelGGL((chunk_scan_general_kernel<NT, true>), dim3(p.E, p.n_x, 2 * q.tp_groups), block, lds_img, stream, q);
+                GRAPE_LAUNCH((chunk_scan_general_kernel<NT, true>), dim3(p.E, p.n_x, 2 * q.tp_groups), block, lds_img, stream, q);
                 TileParams s2 = q;
                 const size_t blk = (size_t)p.n_x * p.E * q.tp_groups * NT * NT * 256;
                 s2.tp_chunks = q.tp_groups;
@@ -1447,9 +1447,9 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
                 s2.tp_q = q.tp_a + blk;
                 s2.tp_u = q.tp_a + 2 * blk;
                 s2.tp_qt = q.tp_a + 3 * blk;
-                hipLaunchKernelGGL((chunk_scan_general_kernel<NT, false>), dim3(p.E, p.n_x, 2), block, lds_img, stream, s2);
+                GRAPE_LAUNCH((chunk_scan_general_kernel<NT, false>), dim3(p.E, p.n_x, 2), block, lds_img, stream, s2);
             } else {
-                hipLaunchKernelGGL((chunk_scan_general_kernel<NT, false>), dim3(p.E, p.n_x, 2), block, lds_img, stream, q);
+                GRAPE_LAUNCH((chunk_scan_general_kernel<NT, false>), dim3(p.E, p.n_x, 2), block, lds_img, stream, q);
             }
         }
         else {
@@ -1460,7 +1460,7 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
                     if (ec != hipSuccess)
                         return ec;
                 } else
-                hipLaunchKernelGGL((chunk_scan_group_kernel<NT>), dim3(p.E, p.n_x, q.tp_groups), block, lds_img, stream, q);
+                GRAPE_LAUNCH((chunk_scan_group_kernel<NT>), dim3(p.E, p.n_x, q.tp_groups), block, lds_img, stream, q);
                 s2.tp_chunks = q.tp_groups;
                 s2.tp_q = q.tp_a + (size_t)p.n_x * p.E * q.tp_groups * NT * NT * 256;
                 s2.tp_r = q.tp_a;
@@ -1470,17 +1470,17 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
                 if (ec != hipSuccess)
                     return ec;
             } else
-            if (sandwich) { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, NT == 1>), grid, block, lds_img, stream, s2);
-                            else    hipLaunchKernelGGL((chunk_scan_kernel<NT, 1, false>), grid, block, lds_img, stream, s2); }
-            else          { if (pk) hipLaunchKernelGGL((chunk_scan_kernel<NT, 0, NT == 1>), grid, block, lds_img, stream, s2);
-                            else    hipLaunchKernelGGL((chunk_scan_kernel<NT, 0, false>), grid, block, lds_img, stream, s2); }
+            if (sandwich) { if (pk) GRAPE_LAUNCH((chunk_scan_kernel<NT, 1, NT == 1>), grid, block, lds_img, stream, s2);
+                            else    GRAPE_LAUNCH((chunk_scan_kernel<NT, 1, false>), grid, block, lds_img, stream, s2); }
+            else          { if (pk) GRAPE_LAUNCH((chunk_scan_kernel<NT, 0, NT == 1>), grid, block, lds_img, stream, s2);
+                            else    GRAPE_LAUNCH((chunk_scan_kernel<NT, 0, false>), grid, block, lds_img, stream, s2); }
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return e;
     }
-#define GRAPE_LAUNCH_CHAIN(KERNEL) hipLaunchKernelGGL(KERNEL, ugrid, block, lds, stream, q)
-#define GRAPE_LAUNCH_UNI(KERNEL) hipLaunchKernelGGL(KERNEL, ugrid, block, lds, stream, q)
+#define GRAPE_LAUNCH_CHAIN(KERNEL) GRAPE_LAUNCH(KERNEL, ugrid, block, lds, stream, q)
+#define GRAPE_LAUNCH_UNI(KERNEL) GRAPE_LAUNCH(KERNEL, ugrid, block, lds, stream, q)
     if (NT == 2 && tp && p.unitary && !keepl && p.sparse && !pk && coop_applies(q, sandwich, keepl)) {
         hipError_t ec = launch_coop_chain_unitary(sandwich, q, stream);
         if (ec != hipSuccess)
@@ -1489,15 +1489,15 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         // image for layout conversions | coefficients | image of M | positions
         const size_t lds_sp = sizeof(double2) * (kTileImage + 1 + (size_t)p.K * p.sp_nz + 16 * NT * (16 * NT + 1)) +
                               sizeof(int32_t) * (size_t)p.K * p.sp_nz;
-        if (sandwich) hipLaunchKernelGGL((chain_tile_unitary_kernel<NT, 1, false, true>), ugrid, block, lds_sp, stream, q);
-        else          hipLaunchKernelGGL((chain_tile_unitary_kernel<NT, 0, false, true>), ugrid, block, lds_sp, stream, q);
+        if (sandwich) GRAPE_LAUNCH((chain_tile_unitary_kernel<NT, 1, false, true>), ugrid, block, lds_sp, stream, q);
+        else          GRAPE_LAUNCH((chain_tile_unitary_kernel<NT, 0, false, true>), ugrid, block, lds_sp, stream, q);
     } else if (p.unitary && !keepl) {
         if (sandwich) { if (pk) GRAPE_LAUNCH_UNI((chain_tile_unitary_kernel<NT, 1, NT == 1>)); else GRAPE_LAUNCH_UNI((chain_tile_unitary_kernel<NT, 1, false>)); }
         else          { if (pk) GRAPE_LAUNCH_UNI((chain_tile_unitary_kernel<NT, 0, NT == 1>)); else GRAPE_LAUNCH_UNI((chain_tile_unitary_kernel<NT, 0, false>)); }
     } else if (p.sparse && !pk) {
         const size_t lds_sp = sizeof(double2) * (kTileImage + 1 + (size_t)p.K * p.sp_nz + 16 * NT * (16 * NT + 1)) +
                               sizeof(int32_t) * (size_t)p.K * p.sp_nz;
-#define GRAPE_LAUNCH_SP(KERNEL) hipLaunchKernelGGL(KERNEL, ugrid, block, lds_sp, stream, q)
+#define GRAPE_LAUNCH_SP(KERNEL) GRAPE_LAUNCH(KERNEL, ugrid, block, lds_sp, stream, q)
         if (sandwich) { if (keepl) GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 1, true, false, true>)); else GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 1, false, false, true>)); }
         else          { if (keepl) GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 0, true, false, true>)); else GRAPE_LAUNCH_SP((chain_tile_kernel<NT, 0, false, false, true>)); }
 #undef GRAPE_LAUNCH_SP

@@ -28,7 +28,7 @@ FLAG_FORCE_COLLECTIVE = 32
 FLAG_TIME_SAMPLED = 64
 FLAG_GROUP_PEER_SUM = 128
 MAX_DEVICES = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID_ARG", -2: "GRAPE_ERR_UNSUPPORTED",
           -3: "GRAPE_ERR_NO_DEVICE", -4: "GRAPE_ERR_HIP", -5: "GRAPE_ERR_NOT_READY",
@@ -39,7 +39,7 @@ EXPORTS = ["grape_abi_version", "grape_create", "grape_destroy", "grape_set_oper
            "grape_comm_unique_id", "grape_comm_attach",
            "grape_eval", "grape_eval_device", "grape_eval_batch", "grape_eval_batch_device", "grape_lbfgs",
            "grape_get_member_results", "grape_get_trajectory",
-           "grape_get_kernel_time", "grape_get_kernel_samples", "grape_get_group_timing", "grape_get_phase_stamps",
+           "grape_get_kernel_time", "grape_get_kernel_samples", "grape_get_kernel_names", "grape_get_group_timing", "grape_get_phase_stamps",
            "grape_get_info",
            "grape_last_error"]
 
@@ -130,6 +130,7 @@ def load_library():
     L.grape_get_trajectory.argtypes = [vp, i32, vp, vp, vp]
     L.grape_get_kernel_time.argtypes = [vp, dp, C.POINTER(C.c_int64), i32]
     L.grape_get_kernel_samples.argtypes = [vp, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.grape_get_kernel_names.argtypes = [vp, C.c_char_p, C.c_int32]
     L.grape_get_group_timing.argtypes = [vp, vp, i32]
     L.grape_get_phase_stamps.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.grape_get_info.argtypes = [vp, C.POINTER(GrapeInfo)]
@@ -392,6 +393,16 @@ class GrapeEngine:
         if n:
             self._check(self._lib.grape_get_kernel_samples(self._h, _p(tot), _p(first), n, C.byref(cnt)))
         return tot, first
+
+    def kernel_names(self):
+        """The kernels the last evaluation launched, in launch order (grape_get_kernel_names): the names a rocprofv3
+        kernel trace shows, without namespace and template arguments."""
+        need = self._lib.grape_get_kernel_names(self._h, None, 0)
+        if need < 0:
+            self._check(need)
+        buf = C.create_string_buffer(max(int(need), 1))
+        self._check(min(self._lib.grape_get_kernel_names(self._h, buf, len(buf)), 0))
+        return [k for k in buf.value.decode().split(";") if k]
 
     def kernel_time(self, reset=False):
         ms = C.c_double()
