@@ -151,14 +151,14 @@ def tile_kernel_models(local, info):
         # flops = Horner steps x 256 complex multiply-adds x 8, the steps from the kernel's own rule (degree table on the
         # norm bound, replicated in action_steps); HBM bytes = the vector records written, then read by the forms kernel
         steps = action_steps(local)
-        act = {"name": "action_rows_kernel + action_thin_kernel (exp(G) v by Taylor series, both chains; vector FP64)",
+        act = {"name": "vector chains (exp(G) v by Taylor series, both chains; vector FP64)",
                "flops": steps * 2 * 256 * 8, "bytes": 2 * units * (N + 1) * 256, "pipe": "valu_fp64",
                "taylor_steps_per_slice": steps / (units * N)}
-        forms = {"name": "action_forms_kernel (bilinear forms w' B_c v, one lane per slice; vector FP64)",
+        forms = {"name": "forms (bilinear forms w' B_c v, one lane per slice)",
                  "flops": units * N * K * (256 + 16) * 8, "bytes": 2 * units * (N + 1) * 256 + units * K * N * 8,
                  "pipe": "valu_fp64"}
         return act, forms
-    expm = {"name": "expm: " + ("ctrl_sum_kernel + prop_hoist kernel" if info.get("hoisted_controls") else "prop_tile_kernel"),
+    expm = {"name": "expm (Taylor-8 on the matrix cores)",
             "flops": units * N * 3 * prod, "bytes": units * N * tsz + (units * (N + 1) * 256 if fused else 0)}
     if thin and info.get("prop_chain"):
         # csrc/action_thin.hip: P_t and P_t^T written by the expm kernel, each read once by its vector chain (one DPP
@@ -166,25 +166,35 @@ def tile_kernel_models(local, info):
         # time axis (small ensembles) the chunk products read P_t once more and cost one matrix product per slice
         C = int(info.get("time_chunks") or 0)
         expm["bytes"] = 2 * units * N * tsz
-        chain = {"name": ("chunk_product_deep_kernel + chain_prop_kernel x 2 (scan, chunks)" if C > 1 else "chain_prop_kernel") +
-                         " + action_forms kernel (vector FP64)",
+        chain = {"name": "propagator chain" + (" on a chunked time axis" if C > 1 else "") + " + forms (vector FP64)",
                  "flops": units * N * (2 * 8 * 256 + K * 8 * (256 + 16)) + (units * N * prod if C > 1 else 0),
                  "bytes": units * N * tsz * (3 if C > 1 else 2) + 4 * units * (N + 1) * 256 + units * K * N * 8, "pipe": "valu_fp64"}
     elif thin:
-        chain = {"name": "chain_thin_kernel (matrix-vector chain" + (", backward pass only)" if fused else ", both passes)"),
+        chain = {"name": "matrix-vector chain" + (", backward pass only" if fused else ", both passes"),
                  "flops": units * N * ((1 if fused else 2) * 8 * 256 + K * 14 * 256),
                  "bytes": units * N * tsz * (1 if fused else 2) + units * (N + 1) * 256 * (1 if fused else 2)}
     elif uni:
-        chain = {"name": "chain_tile_unitary_kernel (M_t = P' M P, forward product P^T V)", "flops": units * N * 3 * prod,
+        chain = {"name": "unitary chain (M_t = P' M P, forward product P^T V)", "flops": units * N * 3 * prod,
                  "bytes": units * N * tsz * 2}
     else:
         q = 6 if sand else 3
-        chain = {"name": "chain_tile kernels (general flow: forward states stored)", "flops": units * N * q * prod,
+        chain = {"name": "dense chain (general flow: forward states stored)", "flops": units * N * q * prod,
                  "bytes": units * N * tsz * 4}
     return expm, chain
 
 
-def roofline(local, info, samples, evals_per_s, n_gpus, traffic, profile=None):
+def split_kernels(names):
+    """The library's launch list (grape_get_kernel_names) cut where the middle HIP event sits: behind the expm kernel of the
+    n = 5..32 family, or behind the vector chains of the propagator-free flow (the pre-pass launches in front of them
+    belong to the first part, the reductions to the second)."""
+    for prefixes in (("prop_",), ("action_parts", "action_thin")):
+        for i, k in enumerate(names):
+            if k.startswith(prefixes):
+                return names[:i + 1], names[i + 1:]
+    return [], names
+
+
+def roofline(local, info, samples, evals_per_s, n_gpus, traffic, profile=None, names=()):
     """The dominant kernel of one shard (`local` = the members this rank owns) against its roof.
     samples = (total_ms[], first_ms[]) of the evaluations inside the timed region (HIP events on the launch stream)."""
     import numpy as np
@@ -202,12 +212,14 @@ def roofline(local, info, samples, evals_per_s, n_gpus, traffic, profile=None):
         expm, chain = tile_kernel_models(local, info)
         t_first = float(first_ms.mean()) * 1e-3 if first_ms.size else 0.0
         parts = []
-        for part, t in ((expm, t_first), (chain, max(sec - t_first, 0.0))):
+        k_first, k_rest = split_kernels(list(names))
+        for part, t, launched in ((expm, t_first, k_first), (chain, max(sec - t_first, 0.0), k_rest)):
             tf = part["flops"] / t / 1e12 if t > 0 else 0.0
             gb = part["bytes"] / t / 1e9 if t > 0 else 0.0
             fm, fh = tf / FP64_PEAK_TFLOPS, gb / HBM_PEAK_GBS
             pipe = part.get("pipe", "mfma")                   # "valu_fp64": vector FP64 (same 78.6 TFLOP/s peak as the matrix pipe)
-            d = {"kernel": part["name"], "avg_us": 1e6 * t, pipe + "_flops_per_launch": part["flops"],
+            d = {"kernel": ";".join(launched) or part["name"], "what": part["name"], "avg_us": 1e6 * t,
+                 pipe + "_flops_per_launch": part["flops"],
                  "hbm_bytes_per_launch": part["bytes"], "achieved_TFLOPs": tf, "achieved_GBs": gb,
                  "frac_" + pipe: fm, "frac_hbm": fh, "bound": pipe if fm >= fh else "hbm"}
             if "taylor_steps_per_slice" in part:
@@ -247,7 +259,7 @@ def roofline(local, info, samples, evals_per_s, n_gpus, traffic, profile=None):
                 "achieved": flow["achieved_GBs"] if fb >= ff else flow["achieved_TFLOPs"],
                 "peak": HBM_PEAK_GBS if fb >= ff else FP64_PEAK_TFLOPS, "unit": "GB/s" if fb >= ff else "TFLOP/s",
                 "frac": max(fb, ff), "traffic": traffic,
-                "kernel": "sweep_pair_kernel" if info.get("lane_pair") else "sweep_small_kernel",
+                "kernel": ";".join(names) or ("sweep_pair_kernel" if info.get("lane_pair") else "sweep_small_kernel"),
                 "bytes_per_launch": flow_bytes, "flow": flow,
                 "model_s_equivalent": {"algorithmic_bytes_per_launch": alg_bytes, "GBs": gbs, "frac_hbm": gbs / HBM_PEAK_GBS,
                                        "end_to_end_frac": alg_bytes * evals_per_s / 1e9 / HBM_PEAK_GBS,
@@ -258,6 +270,8 @@ def roofline(local, info, samples, evals_per_s, n_gpus, traffic, profile=None):
                         "kernel / its HIP-event time / peak; `traffic` = HBM bytes from the committed PMC passes; the kernel "
                         "itself is vector-FP64 issue bound (DESIGN.md section 4.1)"}
     roof.update(st)
+    ms_eq = roof["model_s_equivalent"]
+    roof["frac_model_s"] = ms_eq.get("frac_hbm", ms_eq.get("frac_fp64"))     # SURVEY.md 8d numerator over the same time
     if info.get("kernel_family") != 1 and info.get("lane_pair") and uni:
         ph = committed_phases(local, st["kernel_avg_us"])
         if ph:
@@ -355,7 +369,8 @@ def run_extra_config(qoc, name, dev_index, steps, warmup):
     vec(rho) vec(rho)' states allow.  "C5x1": ONE 32 x 32 problem of C5's shape -- the single-`Problem` closure
     (src/solve.jl:63-143), latency-bound: the time axis is evaluated in parallel chunks."""
     dense = name.endswith("dense")
-    cfg_name = name[:-5] if dense else name
+    expm = name.endswith("expm")                           # "C4expm": GRAPE_ACTION=0, the MFMA expm + vector chain flow
+    cfg_name = name[:-5] if dense else name[:-4] if expm else name
     members = 0
     if "x" in cfg_name:                                    # "C5x1": the config's shape with that many members
         cfg_name, members = cfg_name.split("x")[0], int(cfg_name.split("x")[1])
@@ -363,6 +378,16 @@ def run_extra_config(qoc, name, dev_index, steps, warmup):
     # latency-bound lines (hundreds of ~0.1 ms steps): HIP events around one evaluation in eight, as in the headline run -- a
     # pair of events costs ~5 us of such a call
     sampled = qoc.engine.FLAG_TIME_SAMPLED if steps >= 100 else 0
+    if expm:
+        os.environ["GRAPE_ACTION"] = "0"                   # (read by grape_set_operators)
+    try:
+        return _run_extra(qoc, name, cfg_name, w, dense, expm, sampled, dev_index, steps, warmup)
+    finally:
+        if expm:
+            os.environ.pop("GRAPE_ACTION", None)
+
+
+def _run_extra(qoc, name, cfg_name, w, dense, expm, sampled, dev_index, steps, warmup):
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, device=dev_index,
                          flags=qoc.engine.FLAG_TIME_KERNELS | sampled | (qoc.engine.FLAG_FORCE_GENERAL if dense else 0)) as eng:
         import numpy as np
@@ -378,13 +403,15 @@ def run_extra_config(qoc, name, dev_index, steps, warmup):
         el = time.perf_counter() - t0
         samples = eng.kernel_samples()
         info = eng.info
+        names = eng.kernel_names()
     evals = steps / el
-    return {"workload": f"{name}: {w.sys_type} {w.n}x{w.n}, K={w.K}, N={w.N}, E={w.E}, host->host grape_eval"
-                        + (" (dense chain forced)" if dense else ""),
+    return {"id": name,
+            "workload": f"{name}: {w.sys_type} {w.n}x{w.n}, K={w.K}, N={w.N}, E={w.E}, host->host grape_eval"
+                        + (" (dense chain forced)" if dense else " (GRAPE_ACTION=0: expm + vector chain)" if expm else ""),
             "value": evals, "unit": "gradient-evals/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
             "member_evals_per_s": evals * w.E, "F": F,
-            "roofline": roofline(w, info, samples, evals, 1, None if dense else committed_traffic(f"{cfg_name}_E{w.E}"),
-                                 committed_mfma(f"{name}_E{w.E}"))}
+            "roofline": roofline(w, info, samples, evals, 1, None if (dense or expm) else committed_traffic(f"{cfg_name}_E{w.E}"),
+                                 committed_mfma(f"{name}_E{w.E}"), names)}
 
 
 def shard_overheads(qoc, cfg_name, dev_index, sizes=(512, 256, 128)):
@@ -496,6 +523,86 @@ def lbfgs_rates(qoc, dev_index):
     return out
 
 
+def _r(v, digits=4):
+    """Numbers of the printed line: 4-5 significant digits are what the measurement has."""
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}")
+    return v
+
+
+def compact_roofline(r):
+    """bound / achieved / peak / unit / frac / traffic as the contract asks, plus frac_model_s (SURVEY.md 8d numerator over the
+    same kernel time; `frac` prices the flow actually run), the kernel names the library reported and the event times."""
+    out = {k: _r(r[k], 5) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_model_s", "traffic") if k in r}
+    out["kernel"] = r.get("kernel")
+    out["kernel_us"] = {"avg": _r(r.get("kernel_avg_us")), "min": _r(r.get("kernel_min_us")), "median": _r(r.get("kernel_median_us")),
+                        "launches": r.get("kernel_launches")}
+    if "bytes_per_launch" in r:
+        out["bytes_per_launch"] = r["bytes_per_launch"]
+        out["model_s_bytes_per_launch"] = r["model_s_equivalent"]["algorithmic_bytes_per_launch"]
+    if "kernels" in r:                          # tile family: both timed parts, priced on the flow run
+        out["parts"] = [{"kernel": k["kernel"], "us": _r(k["avg_us"]), "bound": k["bound"],
+                         "frac": _r(k.get("frac_mfma", k.get("frac_valu_fp64", 0.0)) if k["bound"] != "hbm" else k["frac_hbm"]),
+                         "frac_hbm": _r(k["frac_hbm"])} for k in r["kernels"]]
+    m = r.get("mfma_utilisation_from_profile")
+    if m:
+        out["mfma_util_from_profile"] = {k: _r(v) for k, v in m.items() if k != "source"}
+    return out
+
+
+def compact(out):
+    """The ONE printed JSON line, <= 7.5 KB: the driver keeps an 8 KB tail of stdout (round 3's 17.8 KB line lost C2, C4 and
+    the L-BFGS figures there).  Prose lives in DESIGN.md section 5; `--details FILE` / `--verbose` give the complete record."""
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype", "data") if k in out}
+    c["value"], c["ms_per_step"] = _r(out["value"], 6), _r(out["ms_per_step"], 5)
+    cfg = out["config"]
+    c["config"] = {"workload": cfg["workload"].split("; step =")[0] + "; step = host->host grape_eval", "parallelism": cfg["parallelism"]}
+    if cfg.get("collective"):
+        c["config"]["collective"] = cfg["collective"]
+    c["blocks_s"] = [_r(t) for t in out["blocks"]["seconds"]]
+    c["roofline"] = compact_roofline(out["roofline"])
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                             "sample": cb["sample"].split(" of oracle")[0] + " of the C oracle",
+                             "all_cores": {"value": _r(cb["all_cores"]["value"]), "cores": cb["all_cores"]["cores"]}}
+    if "parity" in out:
+        c["parity"] = {k: _r(v, 3) for k, v in out["parity"].items()}
+    ex = out.get("extra") or {}
+    cx = {}
+    if "device_resident_pipelined" in ex:
+        cx["device_resident_pipelined"] = _r(ex["device_resident_pipelined"]["value"], 5)
+    if "weak_scaling" in ex:
+        cx["weak_scaling"] = {k: _r(v, 5) for k, v in ex["weak_scaling"].items()
+                              if k in ("value", "ms_per_step", "ensemble_total", "scaling", "error")}
+    if isinstance(ex.get("lbfgs"), list):
+        cx["lbfgs"] = [{"problem": "reference n_ens=5 testset" if e["problem"].startswith("reference") else "C3-shaped StateTransfer E=1024",
+                        "device": [e["device_lbfgs"]["iterations"], e["device_lbfgs"]["evaluations"], _r(1e3 * e["device_lbfgs"]["seconds"]),
+                                   _r(e["device_lbfgs"]["minimum"], 7)],
+                        "host_scipy": [e["host_driven_scipy"]["iterations"], e["host_driven_scipy"]["evaluations"],
+                                       _r(1e3 * e["host_driven_scipy"]["seconds"]), _r(e["host_driven_scipy"]["minimum"], 7)]}
+                       for e in ex["lbfgs"]]
+        cx["lbfgs_columns"] = "iterations, evaluations, ms, minimum"
+    elif "lbfgs" in ex:
+        cx["lbfgs"] = ex["lbfgs"]
+    if isinstance(ex.get("shard_fixed_overhead"), dict):
+        cx["shard_ms_kernel_us"] = {k: ([_r(v["ms_per_step"]), _r(v["sweep_kernel_us"])] if "ms_per_step" in v else v)
+                                    for k, v in ex["shard_fixed_overhead"].items()}
+    if cx:
+        c["extra"] = cx
+    if "extra_configs" in out:
+        c["extra_configs"] = []
+        for e in out["extra_configs"]:
+            if "error" in e:
+                c["extra_configs"].append({"id": e.get("workload"), "error": e["error"][:120]})
+                continue
+            c["extra_configs"].append({"id": e["id"], "value": _r(e["value"], 5), "ms_per_step": _r(e["ms_per_step"], 5),
+                                       "steps": e["steps"], "roofline": compact_roofline(e["roofline"])})
+    c["F"] = out.get("F")
+    return c
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks as fresh child
     processes (nothing in THIS process has touched the GPU yet), relay their output, exit with
@@ -528,7 +635,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the device-resident loop and the extra configs")
-    ap.add_argument("--extra-configs", default="C2,C4,C4dense,C5,C5x1,C4x1")
+    ap.add_argument("--extra-configs", default="C4,C5,C4dense,C4expm,C2,C5x1,C4x1")
+    ap.add_argument("--details", default="", help="also write the complete record (every note, per-kernel model, L-BFGS traces) "
+                                                  "to this file; the printed line stays compact")
+    ap.add_argument("--verbose", action="store_true", help="print the complete record instead of the compact line")
     ap.add_argument("--backend", default="",
                     help="torch.distributed backend; default: gloo as the control plane when the data-path collective "
                          "is RCCL inside the library (--collective lib), cpu:gloo,cuda:nccl for --collective torch")
@@ -617,6 +727,7 @@ def main():
     samples = sg.local.kernel_samples() if sg.local is not None else ([], [])
     F_last, _ = step()
     info = sg.local.info if sg.local is not None else {}
+    names = sg.local.kernel_names() if sg.local is not None and hasattr(sg.local, "kernel_names") else []
     elapsed = statistics.median(block_s)
 
     # ---- the device-resident pipelined loop round 1 reported (x and [G,F] stay in HBM, one sync at the end)
@@ -665,7 +776,7 @@ def main():
         value = evals_per_s * (E_total / E_cfg)
         local = w.members(sg.lo, sg.hi)
         traffic = committed_traffic(f"{args.config}_E{local.E}")
-        roof = roofline(local, info, samples, evals_per_s, world, traffic, committed_mfma(f"{args.config}_E{local.E}"))
+        roof = roofline(local, info, samples, evals_per_s, world, traffic, committed_mfma(f"{args.config}_E{local.E}"), names)
         n_joined = sg.comm_size if (world > 1 or args.force_dist) else 1
         out = {
             "metric": "GRAPE gradient-evals/sec", "value": value, "unit": "gradient-evals/s",
@@ -720,7 +831,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra and args.extra_configs:
         out["extra_configs"] = []
         for name in [s for s in args.extra_configs.split(",") if s and s != args.config]:
-            heavy = name in ("C4", "C4dense", "C5")
+            heavy = name in ("C4", "C4dense", "C4expm", "C5")
             try:
                 out["extra_configs"].append(run_extra_config(qoc, name, dev_index, 3 if name == "C5" else (20 if heavy else 200),
                                                              1 if name == "C5" else (3 if heavy else 20)))
@@ -738,7 +849,10 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
-        print(json.dumps(out), flush=True)
+        if args.details:
+            with open(args.details, "w") as fh:
+                json.dump(out, fh, indent=1)
+        print(json.dumps(out if args.verbose else compact(out), separators=(",", ":")), flush=True)
         try:
             ctypes.CDLL(None).fflush(None)
         except Exception:                      # noqa: BLE001

@@ -35,3 +35,27 @@ def test_small_rank_one_ensemble_takes_the_propagator_chain():
     names, info = _names("C4", E=2, N=40)
     assert info["expm_action"] == 0
     assert any(n.startswith("prop_") for n in names)
+
+
+def test_bench_line_fits_the_drivers_tail_and_is_labelled_by_the_library():
+    """The printed JSON line must stay under 7.5 KB (the driver keeps an 8 KB tail: round 3's 17.8 KB line lost C4 and C2),
+    carry both fractions at the top of `roofline`, and name its kernels with what the library launched."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "3", "--cpu-seconds", "1",
+                          "--cpu-sample", "4", "--extra-configs", "C4,C2,C4x1"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = out.stdout.strip().splitlines()[-1]
+    assert len(line) <= 7680, len(line)
+    d = json.loads(line)
+    r = d["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "frac_model_s", "traffic"} <= set(r)
+    assert r["kernel"].startswith("sweep_pair_kernel") and 0 < r["frac"] <= 1.0 < 2 * r["frac_model_s"]
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port"
+    ids = [e["id"] for e in d["extra_configs"]]
+    assert ids == ["C4", "C2", "C4x1"]
+    c4 = d["extra_configs"][0]["roofline"]
+    assert "action_parts_kernel" in c4["kernel"] or any("action_parts_kernel" in q["kernel"] for q in c4["parts"])

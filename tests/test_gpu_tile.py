@@ -164,16 +164,24 @@ def test_time_chunks_ragged_and_entry_points(qoc, oracle, monkeypatch, n, sys_ty
 
 
 @pytest.mark.parametrize("name,E,members,dense", [("C4", 1024, (0, 1, 511, 1023), False), ("C4", 1024, (0, 1023), True),
+                                                  ("C4", 1024, (0, 510, 1023), "expm"),
                                                   ("C5", 1024, (0, 1023), False), ("C5", 4096, (0, 2047, 4095), False)])
-def test_full_size_spot_members(qoc, oracle, name, E, members, dense):
-    """Full BASELINE sizes (C4: E = 1024, N = 1000 -- the two-wave chain kernel the bench runs; C5: E = 1024 of
-    4096, N = 2000, the unitary tile flow, and the whole E = 4096 ensemble on ONE GPU as the bench times it -- 134 GB
-    of propagators): spot members against the oracle, the weighted sum, reproducibility.
+def test_full_size_spot_members(qoc, oracle, name, E, members, dense, monkeypatch):
+    """Full BASELINE sizes (C4: E = 1024, N = 1000 -- the vector flow the bench runs, the two-wave dense chain, and the
+    MFMA expm + fused vector chain every ensemble with more than six per-member controls takes (GRAPE_ACTION=0); C5:
+    E = 1024 of 4096, N = 2000, the unitary tile flow, and the whole E = 4096 ensemble on ONE GPU as the bench times it --
+    134 GB of propagators): spot members against the oracle, the weighted sum, reproducibility.
     The small-E parity tests above take different launch branches (E < 2048, pack2, LDS fit)."""
     w = qoc.workloads.config(name, E=E)
+    if dense == "expm":
+        monkeypatch.setenv("GRAPE_ACTION", "0")
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N,
-                         flags=qoc.engine.FLAG_FORCE_GENERAL if dense else 0) as eng:
+                         flags=qoc.engine.FLAG_FORCE_GENERAL if dense is True else 0) as eng:
         F, G = eng.eval(w.x)
+        if dense == "expm":
+            assert eng.info["expm_action"] == 0 and eng.info["rank_one_chain"] == 1 and eng.info["fused_forward"] == 1
+        elif name == "C4" and not dense:
+            assert eng.info["expm_action"] == 1
         foms, grads = eng.member_results()
         F2, G2 = eng.eval(w.x)
     assert F == F2 and np.array_equal(G, G2)
