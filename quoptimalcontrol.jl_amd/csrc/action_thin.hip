@@ -237,12 +237,12 @@ __global__ __launch_bounds__(256) void action_rows_kernel(const TileParams p)
 // Workgroups of kActWaves members (one wave each, no communication): the launcher sizes the dynamic LDS so that exactly as
 // many workgroups fit a compute unit as an even spread needs.  With one-wave workgroups the dispatcher doubled up waves
 // on some SIMDs while others idled (1024 members: 1.99 ms, 768 and fewer: 1.33 ms).
-// SHARED = false: the members have their own control operators (amplitude-scaled controls of a robustness ensemble, ...), at
-// most kActOwnK of them: the lane keeps its half rows of every B'_kc in registers (16 per control) and forms the control sum
-// itself, in the same order; no pre-pass, the norm bound is sum_c |x_c| |B'_kc|.
+// This kernel serves members with their OWN control operators (amplitude-scaled controls of a robustness ensemble, ...), at
+// most kActOwnK of them, on the round-3 layout (DPP row = (direction, column half): the lane keeps its half rows of every
+// B'_kc in registers, 16 per control, which whole rows would double) and forms the control sum itself, in the reference's
+// order; no pre-pass, the norm bound is sum_c |x_c| |B'_kc|.  Shared controls: action_parts_kernel below.
 constexpr int kActWaves = 4;
 constexpr int kActOwnK = 6;
-template <bool SHARED>
 __global__ __launch_bounds__(64 * kActWaves) void action_thin_kernel(const TileParams p)
 {
     const int lane = threadIdx.x & 63, r = lane & 15, d = lane >> 5, h = (lane >> 4) & 1;
@@ -253,8 +253,6 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin_kernel(const TileP
     const size_t kw = (size_t)y * p.E + k;
     const int off = d * 256 + r * 16 + 8 * h;
     const double2 *__restrict__ Ak = p.act_a + (size_t)k * 512 + off;
-    const double2 *__restrict__ Gy = p.act_g + (size_t)y * N * 512 + off;
-    const double *__restrict__ gn = p.act_gn + (size_t)y * N;
     const double an = p.act_an[k];
     // this chain's records, element-major: element r of slice t at [r][t] -- action_forms_kernel (lane = slice) reads them coalesced
     double2 *__restrict__ rec = (d ? p.wrec : p.states) + kw * (size_t)(N + 1) * 16 + (size_t)r * (N + 1);
@@ -275,14 +273,8 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin_kernel(const TileP
         rec[d ? N : 0] = make_double2(vr, vi);
     const int K = p.K;
     const double *__restrict__ xy = p.x + (size_t)y * N * K;      // this control array, x[c + t K]
-    double2 gq[8];
-    double br[kActOwnK][8], bi[kActOwnK][8], xq[kActOwnK];       // (!SHARED) own half rows of B'_kc; the next slice's controls
-    if (SHARED) {
-        const double2 *__restrict__ src = Gy + (size_t)(d ? N - 1 : 0) * 512;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            gq[j] = src[j];
-    } else {
+    double br[kActOwnK][8], bi[kActOwnK][8], xq[kActOwnK];       // own half rows of B'_kc; the next slice's controls
+    {
         const double2 *__restrict__ Bk = p.act_b + (size_t)k * K * 512 + off;
         const double *__restrict__ xs = xy + (size_t)(d ? N - 1 : 0) * K;
 #pragma unroll
@@ -298,10 +290,7 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin_kernel(const TileP
     }
     extern __shared__ unsigned short s_plan_all[];
     unsigned short *s_plan = s_plan_all + (size_t)wave * N;       // this wave's own plan: no workgroup barrier anywhere
-    if (SHARED)
-        act_make_plan(s_plan, gn, an, N, p.s_forced, lane);
-    else
-        act_make_plan_own(s_plan, xy, p.act_bn + (size_t)k * K, an, K, N, p.s_forced, lane);
+    act_make_plan_own(s_plan, xy, p.act_bn + (size_t)k * K, an, K, N, p.s_forced, lane);
     // loop state: the vector as the products read it, x[(r + 8h) mod 16] (in the h = 0 rows that IS element r), and the
     // component this row updates (h = 0: real part, h = 1: imaginary part of element r)
     double xr = rot8_odd_rows(vr), xi = rot8_odd_rows(vi);
@@ -310,17 +299,7 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin_kernel(const TileP
     for (int i = 0; i < N; ++i) {
         double mr[8], mi[8];
         const int tn = d ? max(N - 2 - i, 0) : min(i + 1, N - 1);
-        if (SHARED) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {                         // G = Gc + A' (A last, timeevolution.jl:108)
-                mr[j] = gq[j].x + ar[j];
-                mi[j] = gq[j].y + ai[j];
-            }
-            const double2 *__restrict__ src = Gy + (size_t)tn * 512;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                gq[j] = src[j];
-        } else {
+        {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {                         // (0 + B_1 x_1) first, A last
                 mr[j] = br[0][j] * xq[0];
@@ -410,20 +389,60 @@ GRAPE_DEV void act_matvec_parts(double &a0, double &a1, double xr, double xi, co
 }
 #undef GRAPE_ACT_MAC2
 
+// WHOLE rows: the lane computes BOTH components of its row's result -- y_re += Mr x_re - Mi x_im, y_im += Mi x_re + Mr x_im
+// over eight columns J0 .. J0 + 7, four accumulators.  No cross-row traffic at all: a DPP row is one chain, a wave carries
+// four chains (two members).
+#define GRAPE_ACT_MAC4(J, R, I)                                                        \
+    "v_fmac_f64_dpp %0, %4, %" #R " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n"  \
+    "v_fmac_f64_dpp %2, %4, %" #I " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n"  \
+    "v_fmac_f64_dpp %1, -%5, %" #I " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %3, %5, %" #R " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n"
+GRAPE_DEV void act_matvec_whole(double &a0, double &a1, double &b0, double &b1, double xr, double xi, const double (&Mr)[16],
+                                const double (&Mi)[16])
+{
+    asm("v_mov_b64 %0, 0\nv_mov_b64 %1, 0\nv_mov_b64 %2, 0\nv_mov_b64 %3, 0\n" GRAPE_ACT_MAC4(0, 6, 14) GRAPE_ACT_MAC4(1, 7, 15)
+            GRAPE_ACT_MAC4(2, 8, 16) GRAPE_ACT_MAC4(3, 9, 17) GRAPE_ACT_MAC4(4, 10, 18) GRAPE_ACT_MAC4(5, 11, 19)
+                GRAPE_ACT_MAC4(6, 12, 20) GRAPE_ACT_MAC4(7, 13, 21)
+        : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
+        : "v"(xr), "v"(xi), "v"(Mr[0]), "v"(Mr[1]), "v"(Mr[2]), "v"(Mr[3]), "v"(Mr[4]), "v"(Mr[5]), "v"(Mr[6]), "v"(Mr[7]),
+          "v"(Mi[0]), "v"(Mi[1]), "v"(Mi[2]), "v"(Mi[3]), "v"(Mi[4]), "v"(Mi[5]), "v"(Mi[6]), "v"(Mi[7]));
+    asm(GRAPE_ACT_MAC4(8, 6, 14) GRAPE_ACT_MAC4(9, 7, 15) GRAPE_ACT_MAC4(10, 8, 16) GRAPE_ACT_MAC4(11, 9, 17)
+            GRAPE_ACT_MAC4(12, 10, 18) GRAPE_ACT_MAC4(13, 11, 19) GRAPE_ACT_MAC4(14, 12, 20) GRAPE_ACT_MAC4(15, 13, 21)
+        : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)
+        : "v"(xr), "v"(xi), "v"(Mr[8]), "v"(Mr[9]), "v"(Mr[10]), "v"(Mr[11]), "v"(Mr[12]), "v"(Mr[13]), "v"(Mr[14]), "v"(Mr[15]),
+          "v"(Mi[8]), "v"(Mi[9]), "v"(Mi[10]), "v"(Mi[11]), "v"(Mi[12]), "v"(Mi[13]), "v"(Mi[14]), "v"(Mi[15]));
+}
+#undef GRAPE_ACT_MAC4
+
+// WHOLE = false: one member per wave, DPP row = (direction, component of the result) as described above -- every SIMD has a
+//                wave up to four members per compute unit.
+// WHOLE = true:  TWO members per wave, DPP row q = one chain (member q >> 1, direction q & 1), the lane computes both
+//                components of its row: 64 FMACs + 8 other vector instructions per product of two members (36 per member
+//                against 39), half the additions and loads of the G build per member, no swap.  Chosen from
+//                8 members per compute unit on (launch_action_nb): below that half the SIMDs would idle.
+//                The two members of a wave share the plan (the larger norm bound: never fewer Taylor terms).
+template <bool WHOLE>
 __global__ __launch_bounds__(64 * kActWaves, 2) void action_parts_kernel(const TileParams p)
 {
-    const int lane = threadIdx.x & 63, r = lane & 15, d = lane >> 5, c = (lane >> 4) & 1;
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int d = WHOLE ? q & 1 : q >> 1, c = WHOLE ? 0 : q & 1;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int k = blockIdx.x * kActWaves + wave, y = blockIdx.y, N = p.N;
-    if (k >= p.E)
+    const int unit = blockIdx.x * kActWaves + wave, y = blockIdx.y, N = p.N;
+    if ((WHOLE ? 2 * unit : unit) >= p.E)
         return;
+    // (an odd ensemble's last wave: its second pair of rows repeats the last member -- the same values to the same addresses)
+    const int k = WHOLE ? min(2 * unit + (q >> 1), p.E - 1) : unit;
     const size_t kw = (size_t)y * p.E + k;
-    // the pre-pass's planes of slice t: [re | im | -im] of Gc_t (d = 0) or Gc_t' (d = 1), 256 doubles each, row-major
-    // (entry (r, j) of a plane at [j >> 1][r][j & 1])
+    // the pre-pass's planes of slice t: [re | im | -im] of Gc_t (d = 0) or Gc_t' (d = 1), 256 doubles each; entry (r, j) of a
+    // plane sits at [j >> 1][r][j & 1]
     const double2 *__restrict__ Gy = p.act_g + (size_t)y * N * 768 + d * 384 + r;
-    const int offP = c ? 128 : 0, offQ = c ? 0 : 256;
+    const int offP = (!WHOLE && c) ? 128 : 0, offQ = WHOLE ? 128 : c ? 0 : 256;
     const double *__restrict__ gn = p.act_gn + (size_t)y * N;
-    const double an = p.act_an[k];
+    double an = p.act_an[k];
+    if (WHOLE) {                                                  // the wave's two members share the plan: the larger bound
+        const double other = __shfl_xor(an, 32, 64);
+        an = (an != an || other != other) ? an + other : fmax(an, other);      // (a NaN bound stays a NaN)
+    }
     double2 *__restrict__ rec = (d ? p.wrec : p.states) + kw * (size_t)(N + 1) * 16 + (size_t)r * (N + 1);
     double aP[16], aQ[16];                                        // the member's A'_k (A'_k'), arranged and signed like P, Q
     {
@@ -431,8 +450,8 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_parts_kernel(const T
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const double2 a = Ak[j];
-            aP[j] = c ? a.y : a.x;
-            aQ[j] = c ? a.x : -a.y;
+            aP[j] = (!WHOLE && c) ? a.y : a.x;
+            aQ[j] = WHOLE ? a.y : c ? a.x : -a.y;
         }
     }
     double xr, xi;                                                // element r of the chain's vector, both components
@@ -446,10 +465,9 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_parts_kernel(const T
     extern __shared__ unsigned short s_plan_all[];
     unsigned short *s_plan = s_plan_all + (size_t)wave * N;       // this wave's own plan: no workgroup barrier anywhere
     act_make_plan(s_plan, gn, an, N, p.s_forced, lane);
-    double sel = c ? xi : xr;                                     // the component this row updates
+    double sel = c ? xi : xr, sel2 = xi;                          // the component(s) of v this row updates
     // Two register sets take turns: one holds G_t = Gc_t + A' (the products' operands), the other receives the planes of
-    // the next slice at the top of slice t and has A' added in place (no third set; the compiler places the additions
-    // behind the next slice's loads).  One wave per SIMD -- every ensemble up to four members per compute unit -- issues
+    // the next slice at the top of slice t and has A' added in place (no third set).  One wave per SIMD issues
     // ONE instruction of any kind every ~2.6 ns, scalar ones included (tools/ubench/horner_step.hip), so the hot path is
     // counted in instructions: the products of a slice are unrolled (degrees up to 8: a compare and a branch per step,
     // no loop counter, no table load, 1/kk a literal), 39 vector instructions per product of which 32 FMACs.
@@ -485,37 +503,48 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_parts_kernel(const T
         }
     };
     unsigned plan;
-    // one Horner step u <- v + (G u) inv, inv = 1 / kk; returns this row's component of the new u
-    auto step = [&](const double (&P)[16], const double (&Q)[16], double inv) -> double {
-        double a0, a1;
-        act_matvec_parts(a0, a1, xr, xi, P, Q);
-        const double ysum = a0 + a1;
-        double mine = fma(ysum, inv, sel), other = fma(ysum, inv, sel);
-        asm volatile("" : "+v"(mine), "+v"(other));               // two registers: the swap overwrites both
-        const double keep = mine;
-        swap16(mine, other);                                      // mine: re of element r in both rows, other: im
-        xr = mine;
-        xi = other;
-        return keep;
+    // one Horner step u <- v + (G u) inv, inv = 1 / kk; `last`: the result is the chain's next vector v
+    auto step = [&](const double (&P)[16], const double (&Q)[16], double inv, bool last) {
+        if (WHOLE) {
+            double a0, a1, b0, b1;
+            act_matvec_whole(a0, a1, b0, b1, xr, xi, P, Q);
+            xr = fma(a0 + a1, inv, sel);
+            xi = fma(b0 + b1, inv, sel2);
+            if (last) {
+                sel = xr;
+                sel2 = xi;
+            }
+        } else {
+            double a0, a1;
+            act_matvec_parts(a0, a1, xr, xi, P, Q);
+            const double ysum = a0 + a1;
+            double mine = fma(ysum, inv, sel), other = fma(ysum, inv, sel);
+            asm volatile("" : "+v"(mine), "+v"(other));           // two registers: the swap overwrites both
+            if (last)
+                sel = mine;
+            swap16(mine, other);                                  // mine: re of element r in both rows, other: im
+            xr = mine;
+            xi = other;
+        }
     };
     auto slice = [&](double (&P)[16], double (&Q)[16], double (&nP)[16], double (&nQ)[16]) {
         fetch(nP, nQ);
         const int m = __builtin_amdgcn_readfirstlane(plan & 31), pieces = __builtin_amdgcn_readfirstlane(plan >> 5);
         if (pieces == 1 && m <= 8) {                              // (every slice of a pulse whose |G_t| stays below 0.08)
-            if (m >= 8) (void)step(P, Q, 1.0 / 8);
-            if (m >= 7) (void)step(P, Q, 1.0 / 7);
-            if (m >= 6) (void)step(P, Q, 1.0 / 6);
-            if (m >= 5) (void)step(P, Q, 1.0 / 5);
-            if (m >= 4) (void)step(P, Q, 1.0 / 4);
-            if (m >= 3) (void)step(P, Q, 1.0 / 3);
-            if (m >= 2) (void)step(P, Q, 1.0 / 2);
-            sel = step(P, Q, 1.0);
+            if (m >= 8) step(P, Q, 1.0 / 8, false);
+            if (m >= 7) step(P, Q, 1.0 / 7, false);
+            if (m >= 6) step(P, Q, 1.0 / 6, false);
+            if (m >= 5) step(P, Q, 1.0 / 5, false);
+            if (m >= 4) step(P, Q, 1.0 / 4, false);
+            if (m >= 3) step(P, Q, 1.0 / 3, false);
+            if (m >= 2) step(P, Q, 1.0 / 2, false);
+            step(P, Q, 1.0, true);
         } else {                                                  // degrees beyond 8, or the generator in pieces:
             const double inv_p = 1.0 / (double)pieces;            // exp(G) = exp(G / p)^p, the 1 / p rides on the Horner factor
             for (int piece = 0; piece < pieces; ++piece) {
                 for (int kk = m; kk >= 2; --kk)
-                    (void)step(P, Q, kActInv[kk] * inv_p);
-                sel = step(P, Q, inv_p);
+                    step(P, Q, kActInv[kk] * inv_p, false);
+                step(P, Q, inv_p, true);
             }
         }
         *recp = make_double2(xr, xi);
@@ -1097,9 +1126,7 @@ static hipError_t launch_forms_nb(int sandwich, const TileParams &p, hipStream_t
 template <int NB>
 static hipError_t launch_action_nb(int sandwich, const TileParams &p, hipStream_t stream)
 {
-    // GRAPE_ACT_LAYOUT=0: the round-3 layout (column halves) for shared controls too -- A/B timing only
-    static const bool old_layout = [] { const char *v = std::getenv("GRAPE_ACT_LAYOUT"); return v && v[0] == '0'; }();
-    const bool parts = NB == 16 && p.act_shared && !old_layout;
+    const bool parts = NB == 16 && p.act_shared;
     if (parts)
         GRAPE_LAUNCH((action_rows_kernel<NB, true>), dim3(p.N, p.n_x), dim3(256), 0, stream, p);
     else if (p.act_shared)
@@ -1109,15 +1136,26 @@ static hipError_t launch_action_nb(int sandwich, const TileParams &p, hipStream_
     const size_t plan_bytes = sizeof(unsigned short) * (size_t)p.N * kActWaves;
     if (plan_bytes > 64 * 1024)                                   // (the host layer keeps such pulses on the expm flow)
         return hipErrorInvalidConfiguration;
+    // Two members per wave (whole rows per lane) where that does not leave SIMDs idle.  With S = 4 x compute units SIMDs and at
+    // most two waves of either kernel per SIMD, measured at C4's shape (profiles/r04_C4_whole.txt, chains only): up to S members
+    // one member per wave (1024: 0.95 against 1.36 ms); S .. 2 S two per wave, one wave per SIMD (2048: 1.47 against 1.83 ms);
+    // 2 S .. 3 S one per wave again (3072: 2.73 against 2.82 -- its second round is a half-empty one-wave round); beyond that two
+    // per wave (4096: 2.96 against 3.70 ms).  GRAPE_ACT_WHOLE=0 / 1 forces either.
+    const char *whole_var = std::getenv("GRAPE_ACT_WHOLE");
+    const int whole_env = whole_var ? std::atoi(whole_var) : -1;
+    const long simds = 4 * (long)(p.cus > 0 ? p.cus : 256), units = (long)p.E * p.n_x;
+    const bool whole = parts && (whole_env >= 0 ? whole_env != 0 : (units > simds && units <= 2 * simds) || units > 3 * simds);
     // as many workgroups per compute unit as an even spread of the launch needs, and no more: the LDS request is the limiter
-    constexpr int per_group = NB == 16 ? kActWaves : kActWaves / 2;          // members of a workgroup
+    const int per_group = NB == 16 ? (whole ? 2 * kActWaves : kActWaves) : kActWaves / 2;          // members of a workgroup
     const long groups = (long)((p.E + per_group - 1) / per_group) * p.n_x, cus = p.cus > 0 ? p.cus : 256;
     const long per_cu = (groups + cus - 1) / cus;
     size_t lds = (size_t)(160 * 1024) / (size_t)per_cu;
     lds = lds > 1024 ? (lds - 512) & ~(size_t)255 : lds;
     if (lds < plan_bytes)
         lds = plan_bytes;
-    auto kern = NB == 16 ? (parts ? action_parts_kernel : p.act_shared ? action_thin_kernel<true> : action_thin_kernel<false>) : action_thin2_kernel;
+    auto kern = NB == 16 ? (parts ? (whole ? action_parts_kernel<true> : action_parts_kernel<false>)
+                                  : action_thin_kernel)
+                         : action_thin2_kernel;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)

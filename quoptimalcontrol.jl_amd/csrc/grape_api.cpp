@@ -826,11 +826,10 @@ static long act_min_units(const grape_ctx *c)
 {
     if (const char *e = std::getenv("GRAPE_ACTION_MIN")) return std::atol(e);
     // 9 <= n <= 16: the expm kernel + chain_prop_kernel (one DPP matrix-vector product per slice on the stored propagators)
-    // is ahead up to ~350 members (320: 1.34 vs 1.42 ms, 384: 1.50 vs 1.43 ms)
-    // n = 17..32: the alternative is the zero-padded dense 32 x 32 chain, whose time grows with the ensemble while this flow's
-    // 4.7 ms (N = 2000) does not: 64 members 3.26 ms padded, 96: 4.77, 128: 6.07
+    // is ahead up to ~240 members since round 4's action_parts_kernel (profiles/r04_C4_flow_crossover.txt: 192 members 0.83
+    // against 1.02 ms, 224: 1.04 / 1.02, 256: 1.03 / 1.04, 288: 1.26 / 1.02; round 3: ~350)
     if (c->NT == 2) return 3L * c->compute_units / 8;
-    return (c->NT == 1 && !c->pack2 ? 11L : 9L) * c->compute_units / 8;
+    return c->NT == 1 && !c->pack2 ? 15L * c->compute_units / 16 : 9L * c->compute_units / 8;
 }
 
 extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *B, const double *Xi,

@@ -79,6 +79,50 @@ def test_vector_flow_matches_dense_oracle(qoc, oracle, monkeypatch, n, K, N, E, 
     assert_parity(F, G, F_c, G_c, n, what="vector flow vs expm + chain")
 
 
+@pytest.mark.parametrize("n,K,N,E,sys_type,herm_gen,herm_ctrl", [c for c in CASES if c[3] != 4 or c[0] != 16])
+@pytest.mark.parametrize("whole", ["0", "1"])
+def test_both_wave_layouts_of_the_shared_controls_kernel(qoc, oracle, monkeypatch, n, K, N, E, sys_type, herm_gen, herm_ctrl, whole):
+    """action_parts_kernel<false> (one member per wave, DPP row = (direction, component)) and <true> (two members per
+    wave, whole rows per lane; odd ensembles repeat the last member in the spare rows), forced by GRAPE_ACT_WHOLE -- the
+    library picks by ensemble size (two per wave from 4 x compute units + 1 members on), which the small cases above never
+    reach.  Two members of a wave share the Taylor plan (the larger norm bound), so member results may differ in the
+    last bits between the layouts; both are held to the oracle."""
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    monkeypatch.setenv("GRAPE_ACT_WHOLE", whole)
+    sand = sys_type != "UnitaryGate"
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sand, herm_gen, herm_ctrl, seed=11 * n + N + 3 * K)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 0.9, per_member=True)
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 0.9, N, member_results=True) as eng:
+        assert eng.info["expm_action"] == 1
+        F, G = eng.eval(x)
+        foms, grads = eng.member_results()
+        assert eng.kernel_names()[:2] == ["action_rows_kernel", "action_parts_kernel"]
+        F2, G2 = eng.eval(x)
+        assert F == F2 and np.array_equal(G, G2)
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k} (whole={whole})")
+    assert_parity(F, G, F_ref, G_ref, n, what=f"ensemble (whole={whole})")
+
+
+@pytest.mark.parametrize("whole", ["0", "1"])
+def test_wave_layouts_with_large_generators(qoc, oracle, monkeypatch, whole):
+    """degrees beyond 8 and generators in pieces (the slow path of the kernel's slice loop) on both layouts, with an odd
+    ensemble whose members differ in norm by 30 x (two members of a wave share the larger plan)."""
+    monkeypatch.setenv("GRAPE_ACTION", "1")
+    monkeypatch.setenv("GRAPE_ACT_WHOLE", whole)
+    n, K, N, E = 16, 3, 12, 5
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, False, True, seed=99)
+    A = A * np.array([0.1, 3.0, 0.2, 9.0, 1.0])[:, None, None]
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval("CoherenceTransfer", A, B, Xi, Xt, wts, x, 2.0, per_member=True)
+    with qoc.GrapeEngine("CoherenceTransfer", A, B, Xi, Xt, wts, 2.0, N, member_results=True) as eng:
+        assert eng.info["expm_action"] == 1
+        F, G = eng.eval(x)
+        foms, grads = eng.member_results()
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k} (whole={whole})")
+    assert_parity(F, G, F_ref, G_ref, n, what=f"ensemble (whole={whole})")
+
+
 @pytest.mark.parametrize("scale,N,n,sys_type", [(0.01, 40, 16, "CoherenceTransfer"), (0.2, 40, 16, "CoherenceTransfer"),
                                                 (3.0, 24, 16, "CoherenceTransfer"), (3.0, 24, 11, "UnitaryGate"),
                                                 (12.0, 16, 16, "StateTransfer"), (40.0, 8, 16, "UnitaryGate")])
@@ -594,7 +638,7 @@ def test_single_problem_is_closed_by_the_forms_kernel(qoc, oracle, monkeypatch, 
 
 def test_flow_by_ensemble_size(qoc, oracle, monkeypatch):
     """9 <= n <= 16, rank-one states: chunked sweep_thin.hip chain for a handful of members, the propagator chain on DPP
-    products from 80, the Taylor flow from 11/8 x compute units (lowered here)."""
+    products from 80, the Taylor flow from 15/16 x compute units (lowered here)."""
     for name in ("GRAPE_ACTION", "GRAPE_THIN_DPP", "GRAPE_HOIST"):
         monkeypatch.delenv(name, raising=False)
     monkeypatch.setenv("GRAPE_ACTION_MIN", "120")
