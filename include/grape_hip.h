@@ -191,6 +191,11 @@ typedef struct grape_comm_id {
     char bytes[128];
 } grape_comm_id;
 
+/* Opaque handle of a rank's exchange mailbox (hipIpcMemHandle_t), see grape_ipc_export / grape_ipc_attach. */
+typedef struct grape_ipc_handle {
+    char bytes[64];
+} grape_ipc_handle;
+
 typedef struct grape_ctx grape_ctx;
 
 /* ABI version of the loaded library (== GRAPE_ABI_VERSION of the header it was built from). */
@@ -214,6 +219,19 @@ int grape_destroy(grape_ctx *ctx);
  * librccl is loaded lazily (dlopen) by these two calls and by multi-device contexts only. */
 int grape_comm_unique_id(grape_comm_id *out);
 int grape_comm_attach(grape_ctx *ctx, const grape_comm_id *id, int32_t rank, int32_t n_ranks);
+
+/* ABI v4.  The same one-process-per-GPU layout WITHOUT librccl: the K*N+1 doubles of src/solve.jl:171-191's sum travel
+ * through mailboxes in device memory that the ranks open in each other through HIP IPC.  Every rank calls
+ * grape_ipc_export(ctx, n_ranks, &h) (allocates its mailbox, returns 64 opaque bytes), the ranks exchange the handles by any
+ * means (all-gather over the launcher's control plane), then every rank calls grape_ipc_attach(ctx, handles[n_ranks], rank,
+ * n_ranks).  From then on grape_eval / grape_eval_device / grape_lbfgs on that context end in ipc_allreduce_kernel: each rank
+ * stores its row into its slot of every rank's mailbox (one hop over xGMI), waits -- bounded -- until its own mailbox holds
+ * all n_ranks rows, sums them in rank order (bitwise the sum every other rank, and an in-process group with the same
+ * shards, gets) and publishes to its host as a single-GPU evaluation does.  A rank that never shows up turns into
+ * GRAPE_ERR_COMM on the others after GRAPE_EVAL_TIMEOUT_S (5 s at least, 120 s at most), never into a hang.  Ranks may share
+ * a GPU (tests).  n_ranks <= 8; mutually exclusive with grape_comm_attach; collective like it. */
+int grape_ipc_export(grape_ctx *ctx, int32_t n_ranks, grape_ipc_handle *out);
+int grape_ipc_attach(grape_ctx *ctx, const grape_ipc_handle *handles, int32_t rank, int32_t n_ranks);
 
 /* Uploads the per-member operators once -- what init_ensemble (src/tools.jl:42-53) produces by
  * calling A_g(k), B_g(k), XiG(k), XtG(k), packed contiguously by the glue:

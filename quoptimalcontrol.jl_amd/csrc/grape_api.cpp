@@ -90,8 +90,19 @@ struct grape_ctx {
     unsigned *d_done_counter = nullptr;
     bool peer_sum = false;                     // group: [G, F] summed on the first device through peer copies (no RCCL)
     bool peer_direct = false;                  // group: the first device can read every shard's memory (peer access): the sum reads the rows in place
+    bool peer_all = false;                     // group: EVERY pair of its devices has peer access (arrive-and-sum: any shard may sum)
     double *d_gather = nullptr;                // group, peer_sum: one row of K*N+1 doubles per shard, on the first device
     hipEvent_t ev_done = nullptr;              // shard of a peer_sum group: its evaluation has finished
+    // round 4: the peer sum without stream dependencies -- every shard launches shard_arrive_kernel behind its own reduction
+    unsigned *d_arrive = nullptr;              // group: fine-grained counters on the first device (ArriveParams.arrive)
+    grape_ctx *group = nullptr;                // shard of a group: the group context
+    grape::DoneSignal group_done;              // group: how the evaluation being issued is published (same value for every shard)
+    // one process per GPU without RCCL (grape_ipc_export / grape_ipc_attach)
+    double *d_mbox = nullptr;                  // own mailbox (fine-grained device memory, IPC-exported)
+    double *ipc_mbox[grape::kMaxShards] = {};  // every rank's mailbox as this process addresses it
+    int ipc_ranks = 0;                         // > 1: attached
+    int ipc_alloc_ranks = 0;                   // ranks the own mailbox was sized for
+    unsigned long long ipc_evals = 0, ipc_count[2] = {0, 0};
     bool thin = false;                         // rank-one states: matrix-vector chain (sweep_thin.hip)
     bool herm_ctrl = false;                    // every B_c Hermitian
     double2 *d_vecs = nullptr;                 // thin: per member [v0 | wT], 16 complex each
@@ -169,7 +180,8 @@ static constexpr size_t kEventRing = 256;      // start/stop pairs kept before f
 // where GRAPE_LAUNCH writes the names of the kernels it launches: the log of the evaluation this thread is issuing
 static thread_local std::string *g_kernel_log = nullptr;
 struct KernelLogScope {
-    explicit KernelLogScope(std::string *log) { g_kernel_log = log; if (log) log->clear(); }
+    // append: the launches that close an evaluation behind its sweep kernels (copy-out, the cross-shard sum, the exchange)
+    explicit KernelLogScope(std::string *log, bool append = false) { g_kernel_log = log; if (log && !append) log->clear(); }
     ~KernelLogScope() { g_kernel_log = nullptr; }
 };
 namespace grape {
@@ -353,10 +365,14 @@ static void free_all(grape_ctx *c)
     c->sub.clear();
     if (c->is_group) {
         if (c->d_gather) { (void)hipSetDevice(c->device); (void)hipFree(c->d_gather); }
+        if (c->d_arrive) { (void)hipSetDevice(c->device); (void)hipFree(c->d_arrive); }
         delete c;
         return;
     }
     (void)hipSetDevice(c->device);
+    for (int j = 0; j < c->ipc_ranks; ++j)
+        if (c->ipc_mbox[j] && c->ipc_mbox[j] != c->d_mbox) (void)hipIpcCloseMemHandle(c->ipc_mbox[j]);
+    if (c->d_mbox) (void)hipFree(c->d_mbox);
     if (c->comm && g_rccl.handle) (void)g_rccl.CommDestroy(c->comm);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_dev) (void)hipEventDestroy(c->ev_dev);
@@ -559,7 +575,7 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
         e = alloc((void **)&c->d_stamps, sb);
         if (e == hipSuccess) e = hipMemset(c->d_stamps, 0, sb);
     }
-    const unsigned hflags = hipHostMallocMapped | hipHostMallocCoherent;
+    const unsigned hflags = hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable;   // (any shard's device may publish)
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, sizeof(double) * Q * Bn, hflags);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->d_h_stage, c->h_stage, 0);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_fg, sizeof(double) * Q * Bn, hflags);
@@ -711,6 +727,20 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
         for (int i = 0; i < G; ++i) {
             g->sub[i]->comm_rank = i;
             g->sub[i]->comm_size = G;
+            g->sub[i]->group = g;
+        }
+        // arrive-and-sum counters (one per 256 outputs + one): fine-grained, so that system-scope atomics from every shard's
+        // device meet in one place.  Without them (allocation refused) the sum keeps the stream-ordered reduction kernel.
+        if (G <= grape::kMaxShards && !env_on("GRAPE_GROUP_STREAM_SUM")) {
+            void *pa = nullptr;
+            const size_t nb = (Q + 255) / 256 + 1;
+            if (hipExtMallocWithFlags(&pa, sizeof(unsigned) * nb, hipDeviceMallocFinegrained) == hipSuccess && pa &&
+                hipMemset(pa, 0, sizeof(unsigned) * nb) == hipSuccess && hipDeviceSynchronize() == hipSuccess)
+                g->d_arrive = (unsigned *)pa;
+            else {
+                if (pa) (void)hipFree(pa);
+                (void)hipGetLastError();
+            }
         }
     } else {
         std::vector<ncclComm_t> comms(G);
@@ -728,7 +758,7 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     }
     // peer access between every pair of distinct devices of the group: x fan-out and the [G, F] rows travel device to
     // device over xGMI instead of being staged through host memory ("already enabled" is fine)
-    g->peer_direct = G <= grape::kMaxShards;
+    g->peer_direct = g->peer_all = G <= grape::kMaxShards;
     for (int i = 0; i < G; ++i)
         for (int j = 0; j < G; ++j) {
             const int di = g->sub[i]->device, dj = g->sub[j]->device;
@@ -736,6 +766,7 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, di, dj) != hipSuccess || !can) {
                 if (i == 0) g->peer_direct = false;
+                g->peer_all = false;
                 continue;
             }
             if (hipSetDevice(di) == hipSuccess) {
@@ -812,6 +843,87 @@ extern "C" int grape_comm_attach(grape_ctx *c, const grape_comm_id *id, int32_t 
     ncclUniqueId nid;
     std::memcpy(&nid, id->bytes, sizeof(nid));
     NCCL_TRY(c, api->CommInitRank(&c->comm, n_ranks, nid, rank));
+    c->comm_rank = rank;
+    c->comm_size = n_ranks;
+    return GRAPE_OK;
+}
+
+// ---- one process per GPU without RCCL: mailboxes exchanged through HIP IPC handles (ABI v4) -----------------------------------
+extern "C" int grape_ipc_export(grape_ctx *c, int32_t n_ranks, grape_ipc_handle *out)
+{
+    DeviceGuard guard;
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (!out || n_ranks < 1 || n_ranks > grape::kMaxShards)
+        return fail(c, GRAPE_ERR_INVALID_ARG, "grape_ipc_export: n_ranks must be in 1..8, out non-null");
+    if (c->is_group)
+        return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_ipc_export: the context already spans devices in-process");
+    if (c->comm || c->ipc_ranks > 1)
+        return fail(c, GRAPE_ERR_INVALID_ARG, "grape_ipc_export: a communicator is already attached");
+    if (c->B > 1)
+        return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_ipc_export: max_batch > 1 is single-device in this build");
+    static_assert(sizeof(grape_ipc_handle) >= sizeof(hipIpcMemHandle_t), "grape_ipc_handle must hold a hipIpcMemHandle_t");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->d_mbox && c->ipc_alloc_ranks != n_ranks) {
+        (void)hipFree(c->d_mbox);
+        c->d_mbox = nullptr;
+    }
+    const size_t bytes = grape::ipc_mailbox_bytes((int)(KN(c) + 1), n_ranks);
+    if (!c->d_mbox) {
+        void *pm = nullptr;
+        // fine-grained: stores and atomics of the peers' devices are visible to this device's loads (and the other way round)
+        // without cache maintenance
+        hipError_t e = hipExtMallocWithFlags(&pm, bytes, hipDeviceMallocFinegrained);
+        if (e != hipSuccess || !pm) {
+            (void)hipGetLastError();
+            return fail(c, GRAPE_ERR_ALLOC, std::string("grape_ipc_export: fine-grained device allocation failed: ") + hipGetErrorString(e));
+        }
+        c->d_mbox = (double *)pm;
+        c->ipc_alloc_ranks = n_ranks;
+        c->bytes += bytes;
+    }
+    HIP_TRY(c, hipMemset(c->d_mbox, 0, bytes));
+    HIP_TRY(c, hipDeviceSynchronize());
+    c->ipc_evals = 0;
+    c->ipc_count[0] = c->ipc_count[1] = 0;
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, c->d_mbox);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(c, GRAPE_ERR_COMM, std::string("grape_ipc_export: hipIpcGetMemHandle: ") + hipGetErrorString(e));
+    }
+    std::memset(out->bytes, 0, sizeof(out->bytes));
+    std::memcpy(out->bytes, &h, sizeof(h));
+    return GRAPE_OK;
+}
+
+extern "C" int grape_ipc_attach(grape_ctx *c, const grape_ipc_handle *handles, int32_t rank, int32_t n_ranks)
+{
+    DeviceGuard guard;
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (!handles || n_ranks < 1 || n_ranks > grape::kMaxShards || rank < 0 || rank >= n_ranks)
+        return fail(c, GRAPE_ERR_INVALID_ARG, "grape_ipc_attach: bad rank / n_ranks / handles");
+    if (!c->d_mbox || c->ipc_alloc_ranks != n_ranks)
+        return fail(c, GRAPE_ERR_NOT_READY, "grape_ipc_attach: call grape_ipc_export(ctx, n_ranks, ...) first");
+    if (c->comm || c->ipc_ranks > 1)
+        return fail(c, GRAPE_ERR_INVALID_ARG, "grape_ipc_attach: a communicator is already attached");
+    HIP_TRY(c, hipSetDevice(c->device));
+    double *opened[grape::kMaxShards] = {};
+    for (int j = 0; j < n_ranks; ++j) {
+        if (j == rank) { opened[j] = c->d_mbox; continue; }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handles[j].bytes, sizeof(h));
+        void *pj = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&pj, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess || !pj) {
+            (void)hipGetLastError();
+            for (int i = 0; i < j; ++i)
+                if (opened[i] && opened[i] != c->d_mbox) (void)hipIpcCloseMemHandle(opened[i]);
+            return fail(c, GRAPE_ERR_COMM, "grape_ipc_attach: hipIpcOpenMemHandle (rank " + std::to_string(j) + "): " + hipGetErrorString(e));
+        }
+        opened[j] = (double *)pj;
+    }
+    for (int j = 0; j < n_ranks; ++j) c->ipc_mbox[j] = opened[j];
+    c->ipc_ranks = n_ranks;
     c->comm_rank = rank;
     c->comm_size = n_ranks;
     return GRAPE_OK;
@@ -1671,6 +1783,32 @@ static int enqueue_allreduce(grape_ctx *c, const double *send, double *recv, hip
     return GRAPE_OK;
 }
 
+// One process per GPU, mailboxes attached (grape_ipc_attach): `row` (this rank's [G, F], complete on `stream`) summed over
+// the ranks into `out` (device, nullable) and, with `done`, into the host buffer -- ipc_allreduce_kernel, no RCCL.
+static int enqueue_ipc_allreduce(grape_ctx *c, const double *row, double *out, hipStream_t stream, grape::DoneSignal done)
+{
+    KernelLogScope log_scope(&c->kernel_log, true);
+    grape::IpcParams ip{};
+    ip.own_row = row;
+    ip.Q = (int)(KN(c) + 1);
+    ip.Qpad = (ip.Q + 255) / 256 * 256;
+    ip.rank = c->comm_rank;
+    ip.n_ranks = c->ipc_ranks;
+    ip.parity = (int)(c->ipc_evals & 1);
+    c->ipc_evals += 1;
+    c->ipc_count[ip.parity] += 1;
+    ip.target = (unsigned long long)c->ipc_ranks * c->ipc_count[ip.parity];
+    for (int j = 0; j < c->ipc_ranks; ++j) ip.mbox[j] = c->ipc_mbox[j];
+    // a poll is an s_sleep of ~2 k cycles (~1 us): give up after the context's timeout, 5 s at least / 120 s at most
+    const double lim = std::min(120.0, std::max(5.0, c->timeout_s));
+    ip.spin_limit = (long long)(lim * 1e6);
+    ip.out = out;
+    ip.done = done;
+    if (grape::launch_ipc_allreduce(ip, stream) != hipSuccess)
+        return fail(c, GRAPE_ERR_HIP, "ipc_allreduce_kernel: launch failed");
+    return GRAPE_OK;
+}
+
 // Blocks until `stream` has drained: busy polls for a few hundred microseconds (the optimiser is
 // sequential, so per-call latency is what the caller sees), then sleeps between polls; gives up
 // after c->timeout_s (device presumed hung).
@@ -1758,6 +1896,30 @@ static int shard_issue_group(grape_ctx *s)
     return rc;
 }
 
+// round 4: the same, ending in the shard's arrival (shard_arrive_kernel on its own stream): whichever shard's blocks arrive
+// last sum the rows and publish -- no event, no wait on the first device's stream, no separate reduction launch
+static int shard_launch_arrive(grape_ctx *s)
+{
+    KernelLogScope log_scope(&s->kernel_log, true);
+    grape_ctx *g = s->group;
+    grape::ArriveParams ap{};
+    ap.rows.n = (int)g->sub.size();
+    for (size_t i = 0; i < g->sub.size(); ++i) ap.rows.p[i] = g->sub[i]->d_fg;
+    ap.Q = (int)(KN(g) + 1);
+    ap.arrive = g->d_arrive;
+    ap.out = nullptr;
+    ap.done = g->group_done;
+    if (grape::launch_shard_arrive(ap, s->stream) != hipSuccess)
+        return fail(s, GRAPE_ERR_HIP, "shard_arrive_kernel: launch failed");
+    return GRAPE_OK;
+}
+static int shard_issue_group_arrive(grape_ctx *s)
+{
+    int rc = shard_issue(s, 1, s->d_fg, false);
+    if (rc == GRAPE_OK) rc = shard_launch_arrive(s);
+    return rc;
+}
+
 void GroupWorker::run()
 {
     (void)hipSetDevice(shard->device);
@@ -1827,8 +1989,11 @@ static int wait_flag(grape_ctx *s)
     const double spin_until = s->eval_ema_s > 1e-3 ? 1.3 * s->eval_ema_s : 500e-6;
     long nap_ns = 20000;
     for (unsigned it = 0;; ++it) {
-        if (*flag == want)
+        const unsigned long long seen = *flag;
+        if (seen == want)
             return done(elapsed(), it == 0);
+        if (seen == (want | grape::kSeqFailed))
+            return fail(s, GRAPE_ERR_COMM, "the ranks' rows did not all arrive (mailbox exchange gave up): a peer is gone or stuck");
         if ((it & 1023) != 1023) continue;
         const double el = elapsed();
         if (el < spin_until) continue;                      // spin phase
@@ -1861,7 +2026,10 @@ extern "C" int grape_eval_device(grape_ctx *c, const double *d_x, double *d_fg, 
         HIP_TRY(c, hipSetDevice(c->device));
         int rc = enqueue_eval(c, d_x, d_fg, st);
         if (rc) return rc;
-        if (c->comm) {
+        if (c->ipc_ranks > 1) {
+            rc = enqueue_ipc_allreduce(c, d_fg, d_fg, st, grape::DoneSignal());
+            if (rc) return rc;
+        } else if (c->comm) {
             rc = enqueue_allreduce(c, d_fg, d_fg, st);
             if (rc) return rc;
         }
@@ -1918,6 +2086,7 @@ static int enqueue_peer_sum(grape_ctx *g, double *target, hipStream_t lead_strea
                             grape::DoneSignal done, bool record)
 {
     grape_ctx *lead = g->sub[0];
+    KernelLogScope log_scope(&lead->kernel_log, true);
     const size_t Q = KN(g) + 1;
     grape::ShardRows rows{};
     rows.n = (int)g->sub.size();
@@ -1958,7 +2127,7 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
     const size_t kn = KN(c), Q = kn + 1;
     grape_ctx *lead = c->is_group ? c->sub[0] : c;
     int rc;
-    if (!c->is_group && !c->comm) {
+    if (!c->is_group && !c->comm && c->ipc_ranks <= 1) {
         // single GPU: the final reduce kernel writes its result straight into mapped pinned host
         // memory (no D2H copy node) and the host polls the stream
         rc = shard_enqueue_host(c, x, n_x, c->d_h_fg, true);
@@ -1972,8 +2141,15 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
             clock_gettime(CLOCK_MONOTONIC, &ts0);
             for (grape_ctx *s : c->sub) shard_stage_x(s, x, 1);
             clock_gettime(CLOCK_MONOTONIC, &ts1);
-            for (size_t i = 1; i < c->sub.size(); ++i) c->sub[i]->worker->post(shard_issue_group);
-            rc = shard_issue(lead, 1, lead->d_fg, false);
+            const bool arrive = c->peer_sum && c->d_arrive && c->peer_all;
+            if (arrive) {                                    // how this evaluation is published: the same for every shard
+                c->group_done = grape::DoneSignal();
+                c->group_done.flag = lead->d_h_flag;
+                c->group_done.seq = ++lead->seq;
+                c->group_done.host_out = lead->d_h_fg;
+            }
+            for (size_t i = 1; i < c->sub.size(); ++i) c->sub[i]->worker->post(arrive ? shard_issue_group_arrive : shard_issue_group);
+            rc = arrive ? shard_issue_group_arrive(lead) : shard_issue(lead, 1, lead->d_fg, false);
             int rc_w = GRAPE_OK;
             grape_ctx *bad = nullptr;
             for (size_t i = 1; i < c->sub.size(); ++i) {
@@ -1985,7 +2161,9 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
             if (rc) return group_fail(c, lead, rc);
             if (rc_w) return group_fail(c, bad, rc_w);
             clock_gettime(CLOCK_MONOTONIC, &ts2);
-            if (c->peer_sum) {
+            if (arrive) {
+                // nothing left to issue: the last blocks to arrive sum and publish
+            } else if (c->peer_sum) {
                 grape::DoneSignal done;                      // the reduction kernel publishes like the single-GPU path
                 done.counter = lead->d_done_counter;
                 done.flag = lead->d_h_flag;
@@ -2012,18 +2190,29 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
             c->group_tm_n += 1;
             c->group_tm[4] -= (double)ts0.tv_sec + 1e-9 * (double)ts0.tv_nsec;      // (+ the end time below)
             c->group_tm[3] -= (double)ts3.tv_sec + 1e-9 * (double)ts3.tv_nsec;
+        } else if (c->ipc_ranks > 1) {
+            rc = shard_enqueue_host(c, x, 1, c->d_fg, false);
+            if (rc) return rc;
+            grape::DoneSignal done;                          // the exchange kernel publishes like the single-GPU path
+            done.counter = c->d_done_counter;
+            done.flag = c->d_h_flag;
+            done.seq = ++c->seq;
+            done.host_out = c->d_h_fg;
+            rc = enqueue_ipc_allreduce(c, c->d_fg, nullptr, c->stream, done);
+            if (rc) return rc;
         } else {
             rc = shard_enqueue_host(c, x, 1, c->d_fg, false);
             if (rc) return rc;
             rc = enqueue_allreduce(c, c->d_fg, c->d_fg, c->stream);
             if (rc) return rc;
         }
-        if (!(c->is_group && c->peer_sum)) {
+        if (!(c->is_group && c->peer_sum) && !(c->ipc_ranks > 1)) {
             HIP_TRY(c, hipSetDevice(lead->device));
             grape::DoneSignal done;
             done.counter = lead->d_done_counter;
             done.flag = lead->d_h_flag;
             done.seq = ++lead->seq;
+            KernelLogScope log_scope(&lead->kernel_log, true);
             HIP_TRY(c, grape::launch_copy(lead->d_fg, lead->d_h_fg, (int)Q, lead->stream, done));
         }
     }
@@ -2038,8 +2227,10 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
     if (rc) return c->is_group ? group_fail(c, lead, rc) : rc;
     if (c->is_group) {
         // the other shards' streams finish with the same all-reduce; drain them so that the next call
-        // (and the accessors) find every device idle -- they are done or microseconds from it
-        for (size_t i = 1; i < c->sub.size(); ++i) {
+        // (and the accessors) find every device idle -- they are done or microseconds from it.  (Arrive-and-sum: the
+        // publication itself says that every shard's kernels have run -- only exiting blocks of their arrive kernels can be
+        // left, and seven hipStreamQuery round trips on streams that have JUST finished cost ~70 us.)
+        for (size_t i = 1; i < c->sub.size() && !(c->peer_sum && c->d_arrive && c->peer_all); ++i) {
             rc = wait_stream(c->sub[i], c->sub[i]->stream);
             if (rc) return group_fail(c, c->sub[i], rc);
         }
@@ -2132,7 +2323,8 @@ struct LbfgsRun {
         if (c->is_group)                          // fan-out of x, every shard, the grouped all-reduce / peer sum
             return grape_eval_device(c, st.xt, st.fgt, lead->stream);
         int rc = enqueue_eval(c, st.xt, st.fgt, c->stream, n_x);
-        if (rc == GRAPE_OK && c->comm) rc = enqueue_allreduce(c, st.fgt, st.fgt, c->stream);
+        if (rc == GRAPE_OK && c->ipc_ranks > 1) rc = enqueue_ipc_allreduce(c, st.fgt, st.fgt, c->stream, grape::DoneSignal());
+        else if (rc == GRAPE_OK && c->comm) rc = enqueue_allreduce(c, st.fgt, st.fgt, c->stream);
         return rc;
     }
     // phi(alpha), phi'(alpha) along the current direction; `have_trial`: slot 0 already holds x + alpha d
@@ -2342,7 +2534,7 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
     const int max_ls = o.max_linesearch > 0 ? o.max_linesearch : 50;
     if (m > 64) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_lbfgs: memory must be <= 64");
     if (o.line_search < 0 || o.line_search > 2) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_lbfgs: line_search must be 0, 1 or 2");
-    const bool multi = c->is_group || c->comm != nullptr;
+    const bool multi = c->is_group || c->comm != nullptr || c->ipc_ranks > 1;
     if (multi && o.line_search == 2)
         return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_lbfgs: the batched ladder search (line_search = 2) is single-device; "
                                               "multi-device contexts use the Hager-Zhang search");

@@ -221,6 +221,43 @@ struct ShardRows {
 };
 hipError_t launch_reduce_shards(const ShardRows &rows, double *fg, int Q, hipStream_t stream, DoneSignal done = DoneSignal());
 
+// ---- the cross-shard sum without a waiting kernel or a stream dependency (round 4) --------------------------------------
+// In-process group: every shard launches shard_arrive_kernel on its OWN stream behind its reduction (no event, no
+// hipStreamWaitEvent on the first device's stream, no reduce_shards launch).  Block b of shard g adds 1 to arrive[b]
+// (system scope; fine-grained memory on the first device); the block whose add was the G-th sums outputs
+// [256 b, 256 b + 256) over the G rows IN SHARD ORDER -- read where the shards' reductions left them (peer access; a row is
+// complete and written back at its producer's kernel boundary, before any block of that shard arrives) -- stores them to
+// `out` / the host buffer, and the last of those summing blocks publishes the evaluation.  Nobody waits for anybody:
+// several shards on one GPU (tests) cannot deadlock on a shared hardware queue.
+struct ArriveParams {
+    ShardRows rows;
+    int Q;
+    unsigned *arrive;             // [ceil(Q / 256)] arrivals per block column + [1] summing blocks that have finished
+    double *out;                  // device result on the first device (nullable)
+    DoneSignal done;              // host publication (host_out, flag, seq); counter unused
+};
+hipError_t launch_shard_arrive(const ArriveParams &p, hipStream_t stream);
+
+// One process per GPU without RCCL (grape_ipc_export / grape_ipc_attach): every rank owns a MAILBOX in fine-grained device
+// memory that its peers have opened through hipIpcOpenMemHandle -- [2 parities][n_ranks][Qpad] doubles, then
+// [2][ceil(Q / 256)] arrival counters.  Block b of rank r stores its 256 outputs of the rank's row into slot r of EVERY mailbox
+// (one xGMI hop each), releases them at system scope and adds 1 to that block column's counter in every mailbox; then
+// waits until its OWN mailbox shows the arrivals of all n_ranks (bounded spin), sums the n_ranks slots in rank order --
+// bitwise what the in-process group and every other rank get -- and stores / publishes like the single-GPU path.  Slots
+// alternate with the evaluation's parity: a rank that runs ahead writes the other half while a slow rank still reads.
+struct IpcParams {
+    const double *own_row;        // this rank's [G, F], complete (previous kernel of the stream)
+    int Q, Qpad, rank, n_ranks, parity;
+    double *mbox[kMaxShards];     // every rank's mailbox (own included), as this process addresses it
+    unsigned long long target;    // arrivals the own mailbox's counters must show: n_ranks x evaluations of this parity so far
+    long long spin_limit;         // polls (with s_sleep) before giving up: the evaluation is then published as failed
+    double *out;                  // device result (nullable)
+    DoneSignal done;              // host publication; done.counter: agent-scope block counter of this device
+};
+constexpr unsigned long long kSeqFailed = 1ull << 63;      // flag value = seq | kSeqFailed: the exchange gave up
+size_t ipc_mailbox_bytes(int Q, int n_ranks);
+hipError_t launch_ipc_allreduce(const IpcParams &p, hipStream_t stream);
+
 // ---- exact gradient / functional path (exact_grad.hip), n <= 4 ---------------------------------------
 struct ExactParams {
     const double2 *ops;       // as SweepParams.ops (prescaled generators)

@@ -198,6 +198,133 @@ hipError_t launch_reduce_shards(const ShardRows &rows, double *fg, int Q, hipStr
     return hipGetLastError();
 }
 
+// ---- arrive-and-sum (in-process groups) ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shard_arrive_kernel(const ArriveParams p)
+{
+    __shared__ int s_last;
+    const int q = blockIdx.x * 256 + threadIdx.x, G = p.rows.n;
+    if (threadIdx.x == 0) {
+        // (this shard's row: written by the previous kernel of this stream, written back at its end)
+        __threadfence_system();
+        const unsigned prev = __hip_atomic_fetch_add(p.arrive + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
+        s_last = prev == (unsigned)(G - 1);
+        if (s_last)                                               // the next evaluation's arrivals come behind its publication
+            __hip_atomic_store(p.arrive + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    if (!s_last)
+        return;
+    __threadfence_system();
+    if (q < p.Q) {
+        double v[kMaxShards];
+#pragma unroll
+        for (int g = 0; g < kMaxShards; ++g)                      // all loads in flight together; system scope: never a cached copy
+            v[g] = g < G ? __hip_atomic_load(p.rows.p[g] + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+        double acc = 0.0;
+#pragma unroll
+        for (int g = 0; g < kMaxShards; ++g)
+            acc += v[g];                                          // shard order: reduce_shards_kernel's sum, bit for bit
+        if (p.out)
+            p.out[q] = acc;
+        if (p.done.host_out)
+            p.done.host_out[q] = acc;
+    }
+    if (!p.done.flag)
+        return;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned *finished = p.arrive + gridDim.x;
+        const unsigned prev = __hip_atomic_fetch_add(finished, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (prev == gridDim.x - 1) {
+            __hip_atomic_store(finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(p.done.flag, p.done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+hipError_t launch_shard_arrive(const ArriveParams &p, hipStream_t stream)
+{
+    GRAPE_LAUNCH(shard_arrive_kernel, dim3((p.Q + 255) / 256), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// ---- mailbox all-reduce between processes ------------------------------------------------------------------------------
+size_t ipc_mailbox_bytes(int Q, int n_ranks)
+{
+    const size_t Qpad = ((size_t)Q + 255) / 256 * 256, nb = Qpad / 256;
+    return sizeof(double) * 2 * (size_t)n_ranks * Qpad + sizeof(unsigned long long) * 2 * nb;
+}
+
+__global__ __launch_bounds__(256) void ipc_allreduce_kernel(const IpcParams p)
+{
+    __shared__ int s_ok;
+    const int q = blockIdx.x * 256 + threadIdx.x, R = p.n_ranks, nb = gridDim.x;
+    const size_t slot = ((size_t)p.parity * R + p.rank) * p.Qpad + q, counters = (size_t)2 * R * p.Qpad;
+    const double mine = q < p.Q ? p.own_row[q] : 0.0;
+    for (int j = 0; j < R; ++j)                                   // my outputs into slot `rank` of every mailbox
+        __hip_atomic_store(p.mbox[j] + slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int j = 0; j < R; ++j) {
+            unsigned long long *cnt = reinterpret_cast<unsigned long long *>(p.mbox[j] + counters) + (size_t)p.parity * nb + blockIdx.x;
+            (void)__hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        const unsigned long long *own = reinterpret_cast<const unsigned long long *>(p.mbox[p.rank] + counters) + (size_t)p.parity * nb + blockIdx.x;
+        int ok = 0;
+        for (long long it = 0; it < p.spin_limit; ++it) {
+            if (__hip_atomic_load(own, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= p.target) {
+                ok = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    const int ok = s_ok;
+    if (ok) {
+        __threadfence_system();
+        if (q < p.Q) {
+            const double *base = p.mbox[p.rank] + (size_t)p.parity * R * p.Qpad + q;
+            double v[kMaxShards];
+#pragma unroll
+            for (int j = 0; j < kMaxShards; ++j)
+                v[j] = j < R ? __hip_atomic_load(base + (size_t)j * p.Qpad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < kMaxShards; ++j)
+                acc += v[j];                                      // rank order, as the in-process sum
+            if (p.out)
+                p.out[q] = acc;
+            if (p.done.host_out)
+                p.done.host_out[q] = acc;
+        }
+    }
+    if (!p.done.flag)
+        return;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // counter: low 16 bits = blocks finished, bit 16 on = some block gave up
+        const unsigned prev = atomicAdd(p.done.counter, ok ? 1u : 0x10001u);
+        if ((prev & 0xffffu) == (unsigned)nb - 1) {
+            const bool failed = ((prev >> 16) != 0) || !ok;
+            __hip_atomic_store(p.done.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(p.done.flag, failed ? (p.done.seq | kSeqFailed) : p.done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+hipError_t launch_ipc_allreduce(const IpcParams &p, hipStream_t stream)
+{
+    GRAPE_LAUNCH(ipc_allreduce_kernel, dim3(p.Qpad / 256), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_reduce(const double *member_out, const double *wts, double *partial, double *fg,
                          int E, int Q, int ksplit, hipStream_t stream, DoneSignal done)
 {

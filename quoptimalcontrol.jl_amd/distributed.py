@@ -13,6 +13,12 @@ Where the collective runs (`collective=`):
            every rank calls grape_comm_attach, and from then on grape_eval / grape_eval_device end
            in ncclAllReduce on the evaluation's own stream.  grape_eval(x) is then the complete
            host -> N GPUs -> host closure on every rank.
+  "ipc"    inside libgrape_hip.so without librccl: every rank exports a mailbox in its device memory
+           (grape_ipc_export, a HIP IPC handle), torch.distributed all-gathers the 64-byte handles, every rank
+           opens its peers' mailboxes (grape_ipc_attach), and from then on an evaluation ends in ONE kernel that
+           stores the rank's row into every mailbox, waits (bounded) for the others' and sums in rank order.
+           Works with ranks sharing a GPU -- which RCCL refuses -- so the process-per-GPU exchange is testable
+           on a one-GPU box; results are bitwise those of an in-process group with the same shards.
   "torch"  torch.distributed.all_reduce on the fg tensor (backend "nccl" == RCCL on ROCm; "gloo" in
            the CPU tests, where a stand-in evaluator replaces the GPU).  Fallback when a rank cannot
            join the library communicator (e.g. fewer members than ranks).
@@ -74,6 +80,53 @@ class ShardedGrape:
         self.attach_timeout_s = 180.0
         if collective == "lib" and (self.world > 1 or force_collective):
             self._attach_library_communicator()
+        elif collective == "ipc" and self.world > 1:
+            self._attach_ipc_mailboxes()
+
+    def _attach_ipc_mailboxes(self):
+        """Mailbox exchange (grape_ipc_export / grape_ipc_attach).  Every step is agreed by all ranks (MIN of a 0/1 flag):
+        one rank that cannot take part sends everybody to the torch.distributed fallback, nobody waits for a rank that left."""
+        torch, dist = self.torch, self.dist
+
+        def agree(flag_value):
+            flag = torch.tensor([flag_value], dtype=torch.int32)
+            if "gloo" not in dist.get_backend(self.group):
+                flag = flag.to(self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return int(flag.item())
+
+        can = int(self.local is not None and hasattr(self.local, "ipc_export") and self.world <= 8)
+        if not agree(can):
+            self.attach_error = "a rank owns no members, has no ipc_export, or there are more than 8 ranks"
+            return self._probe_torch_group()
+        ok, handle = 1, b"\0" * 64
+        try:
+            handle = self.local.ipc_export(self.world)
+        except Exception as exc:                      # noqa: BLE001 -- any failure means "fall back", consistently
+            self.attach_error = repr(exc)
+            ok = 0
+        if not agree(ok):
+            return self._probe_torch_group()
+        buf = torch.frombuffer(bytearray(handle), dtype=torch.uint8).clone()
+        on_dev = "gloo" not in dist.get_backend(self.group)
+        if on_dev:
+            buf = buf.to(self.device)
+        gathered = [torch.zeros_like(buf) for _ in range(self.world)]
+        dist.all_gather(gathered, buf, group=self.group)
+        handles = [bytes(g.cpu().numpy().tobytes()) for g in gathered]
+        try:
+            self.local.ipc_attach(handles, self.rank, self.world)
+        except Exception as exc:                      # noqa: BLE001
+            self.attach_error = repr(exc)
+            ok = 0
+        if agree(ok):
+            self.collective = "ipc"
+            self.comm_size = self.local.info["comm_size"]
+        elif ok:
+            # this rank did attach but another could not: it must not run the exchange alone -- recreate is the caller's
+            # business; evaluations here go through the torch fallback with the library's exchange switched off
+            raise RuntimeError("grape_ipc_attach succeeded here but failed on another rank; this context now expects its "
+                               "peers -- rebuild the engines with collective='torch'")
 
     def _attach_library_communicator(self):
         """Every rank joins an RCCL communicator owned by libgrape_hip.so; all ranks agree on the
@@ -129,17 +182,24 @@ class ShardedGrape:
                 self.attach_error = repr(exc)
                 ok = 0
             ok = agree(ok)
-            if stuck:
-                # the abandoned thread is still inside ncclCommInitRank ON THIS CONTEXT and may complete later: a
-                # context that can grow a communicator behind our back must not evaluate (one-sided all-reduce)
-                raise RuntimeError("grape_comm_attach timed out on this rank; its context is unusable -- aborting "
-                                   "this rank instead of evaluating on it: " + self.attach_error)
+            any_stuck = not agree(0 if stuck else 1)  # agreed as well: the job fails collectively, nobody half-continues
+            if any_stuck:
+                # the abandoned thread is still inside ncclCommInitRank ON THAT RANK'S CONTEXT and may complete later: a
+                # context that can grow a communicator behind our back must not evaluate (one-sided all-reduce), and the
+                # other ranks must not walk into a fallback collective that the stuck rank will never join
+                raise RuntimeError("grape_comm_attach timed out on " + ("this rank" if stuck else "another rank") +
+                                   "; every rank aborts instead of evaluating: " + getattr(self, "attach_error", ""))
         if ok:
             self.collective = "lib"
             self.comm_size = self.local.info["comm_size"]
-        elif self.distributed and self.world > 1 and self.device.type == "cuda" and "nccl" not in dist.get_backend(self.group):
-            # fallback on a gloo control plane: give the data path its own RCCL group (torch's) and PROBE it -- RCCL
-            # refuses, at the first collective, ranks that share a GPU; all ranks then agree to stage through the host
+        else:
+            self._probe_torch_group()
+
+    def _probe_torch_group(self):
+        """The torch.distributed fallback on a gloo control plane: give the data path its own RCCL group (torch's) and PROBE it --
+        RCCL refuses, at the first collective, ranks that share a GPU; all ranks then agree to stage through the host."""
+        torch, dist = self.torch, self.dist
+        if self.distributed and self.world > 1 and self.device.type == "cuda" and "nccl" not in dist.get_backend(self.group):
             control = self.group
             works = 1
             nccl_group = None
@@ -179,8 +239,8 @@ class ShardedGrape:
 
     def eval(self, x):
         """Host -> GPUs -> host: x (K,N) numpy -> (F, G (K,N)), the full-ensemble closure on every rank."""
-        if self.collective == "lib" or (self.world == 1 and not self.force_collective and self.local is not None
-                                        and hasattr(self.local, "eval")):
+        if self.collective in ("lib", "ipc") or (self.world == 1 and not self.force_collective and self.local is not None
+                                                 and hasattr(self.local, "eval")):
             return self.local.eval(x)                 # grape_eval: the all-reduce happens inside the library
         torch = self.torch
         xd = torch.as_tensor(np.ascontiguousarray(np.asarray(x, float).T), device=self.device)

@@ -36,7 +36,7 @@ STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID_ARG", -2: "GRAPE_ERR_UNSUPPORTED
 
 # every symbol include/grape_hip.h declares
 EXPORTS = ["grape_abi_version", "grape_create", "grape_destroy", "grape_set_operators",
-           "grape_comm_unique_id", "grape_comm_attach",
+           "grape_comm_unique_id", "grape_comm_attach", "grape_ipc_export", "grape_ipc_attach",
            "grape_eval", "grape_eval_device", "grape_eval_batch", "grape_eval_batch_device", "grape_lbfgs",
            "grape_get_member_results", "grape_get_trajectory",
            "grape_get_kernel_time", "grape_get_kernel_samples", "grape_get_kernel_names", "grape_get_group_timing", "grape_get_phase_stamps",
@@ -121,6 +121,8 @@ def load_library():
     L.grape_set_operators.argtypes = [vp] * 6
     L.grape_comm_unique_id.argtypes = [C.POINTER(GrapeCommId)]
     L.grape_comm_attach.argtypes = [vp, C.POINTER(GrapeCommId), i32, i32]
+    L.grape_ipc_export.argtypes = [vp, i32, vp]
+    L.grape_ipc_attach.argtypes = [vp, vp, i32, i32]
     L.grape_eval.argtypes = [vp, vp, dp, vp]
     L.grape_eval_device.argtypes = [vp, vp, vp, vp]
     L.grape_eval_batch.argtypes = [vp, i32, vp, vp, vp]
@@ -262,6 +264,20 @@ class GrapeEngine:
         member shard) ends in the single all-reduce of [G, F] over the ranks, inside the library."""
         cid = GrapeCommId.from_buffer_copy(bytes(token))
         self._check(self._lib.grape_comm_attach(self._h, C.byref(cid), int(rank), int(n_ranks)))
+
+    def ipc_export(self, n_ranks):
+        """64 opaque bytes naming this rank's exchange mailbox (grape_ipc_export): all-gather them, then ipc_attach."""
+        buf = C.create_string_buffer(64)
+        self._check(self._lib.grape_ipc_export(self._h, int(n_ranks), buf))
+        return buf.raw
+
+    def ipc_attach(self, handles, rank, n_ranks):
+        """handles: the n_ranks exported byte strings in rank order.  From now on every eval()/eval_device()/lbfgs() of this
+        context ends in the mailbox all-reduce of [G, F] over the ranks (no RCCL)."""
+        blob = b"".join(bytes(h) for h in handles)
+        if len(blob) != 64 * int(n_ranks):
+            raise ValueError("ipc_attach: need n_ranks handles of 64 bytes")
+        self._check(self._lib.grape_ipc_attach(self._h, C.create_string_buffer(blob, len(blob)), int(rank), int(n_ranks)))
 
     # ------------------------------------------------------------------ evaluation
     def eval(self, x, want_F=True, want_G=True):
