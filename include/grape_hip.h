@@ -263,7 +263,8 @@ int grape_eval_device(grape_ctx *ctx, const double *d_x, double *d_fg, void *str
  * n_x <= max_batch independent control arrays evaluated against the same ensemble in ONE launch.
  *   x  host f64 (K,N,n_x)      F  host f64[n_x] (nullable)      G  host f64 (K,N,n_x) (nullable)
  * Entry b is exactly what grape_eval(ctx, x[:,:,b]) returns; with n_x = 1 the two calls are the same.
- * Needs grape_config.max_batch >= n_x (the workspace is sized for max_batch control arrays). */
+ * Needs grape_config.max_batch >= n_x (the workspace is sized for max_batch control arrays).  ABI v4: multi-device contexts
+ * and attached communicators batch too -- every shard evaluates the n_x arrays, their rows cross the devices as one sum. */
 int grape_eval_batch(grape_ctx *ctx, int32_t n_x, const double *x, double *F, double *G);
 
 /* Device-pointer form: d_x (K,N,n_x), d_fg f64[(K*N + 1) * n_x] = n_x blocks of { G, F }. */
@@ -282,10 +283,12 @@ int grape_eval_batch_device(grape_ctx *ctx, int32_t n_x, const double *d_x, doub
  *      accepted without a second evaluation)
  *   2  the factor-2 ladder of ABI v2: `probes` step lengths alpha, alpha/2, ... per BATCHED launch
  *      (grape_config.max_batch >= probes), the largest with sufficient decrease (c1 = 1e-4), preferring the strong Wolfe
- *      curvature condition (c2 = 0.9); single-device contexts only
- * Multi-device contexts (n_devices >= 2) and contexts with an attached communicator run modes 0 and 1: the vectors
- * live on the first device (every rank's device), each evaluation is the sharded one with its all-reduce.  With
- * grape_comm_attach all ranks must call grape_lbfgs together (they take identical decisions on identical [G, F]).
+ *      curvature condition (c2 = 0.9)
+ * Multi-device contexts (n_devices >= 2) and contexts with an attached communicator / mailbox exchange default to modes 0
+ * and 1 (one sharded evaluation per trial step); ABI v4: with max_batch >= 2 they take mode 2 as well -- the B probes of a
+ * ladder are ONE batched sharded evaluation with ONE exchange of B rows.  The vectors live on the first device (every
+ * rank's device).  With grape_comm_attach / grape_ipc_attach all ranks must call grape_lbfgs together (they take identical
+ * decisions on identical [G, F]).
  * A Hager-Zhang search that cannot bracket -- the reference's UnitaryGate gradient is not the derivative of its figure
  * of merit -- hands that iteration to the ladder (single-device) or ends with status 3.
  * The gradient is whatever the GRAPE evaluation returns, with the reference's conventions. */

@@ -97,6 +97,7 @@ struct grape_ctx {
     unsigned *d_arrive = nullptr;              // group: fine-grained counters on the first device (ArriveParams.arrive)
     grape_ctx *group = nullptr;                // shard of a group: the group context
     grape::DoneSignal group_done;              // group: how the evaluation being issued is published (same value for every shard)
+    int group_nx = 1;                          // group: control arrays of the evaluation being issued
     // one process per GPU without RCCL (grape_ipc_export / grape_ipc_attach)
     double *d_mbox = nullptr;                  // own mailbox (fine-grained device memory, IPC-exported)
     double *ipc_mbox[grape::kMaxShards] = {};  // every rank's mailbox as this process addresses it
@@ -690,8 +691,6 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     if (!group)
         return create_shard(cfg, devs[0], out);
 
-    if (cfg->max_batch > 1)
-        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: max_batch > 1 is single-device in this build");
     if (cfg->flags & GRAPE_FLAG_PHASE_STAMPS)
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: GRAPE_FLAG_PHASE_STAMPS is single-device");
     const bool peer_sum = (cfg->flags & GRAPE_FLAG_GROUP_PEER_SUM) != 0 && cfg->n_devices >= 2;
@@ -702,6 +701,7 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
     if (!g) return fail(nullptr, GRAPE_ERR_ALLOC, "grape_create: out of host memory");
     g->cfg = *cfg;
     g->is_group = true;
+    g->B = cfg->max_batch > 1 ? cfg->max_batch : 1;       // (every shard evaluates the same n_x control arrays per call)
     shard_plan(cfg->n_ensemble, (int)devs.size(), g->sub_lo);
     const int G = (int)g->sub_lo.size() - 1;
     for (int i = 0; i < G; ++i) {
@@ -720,7 +720,7 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
         g->device = g->sub[0]->device;
         const size_t Q = (size_t)cfg->n_controls * cfg->n_slices + 1;
         if (hipSetDevice(g->device) != hipSuccess ||
-            hipMalloc((void **)&g->d_gather, sizeof(double) * Q * G) != hipSuccess) {
+            hipMalloc((void **)&g->d_gather, sizeof(double) * Q * G * (size_t)g->B) != hipSuccess) {
             free_all(g);
             return fail(nullptr, GRAPE_ERR_ALLOC, "grape_create: device allocation failed (shard gather buffer)");
         }
@@ -733,7 +733,7 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
         // device meet in one place.  Without them (allocation refused) the sum keeps the stream-ordered reduction kernel.
         if (G <= grape::kMaxShards && !env_on("GRAPE_GROUP_STREAM_SUM")) {
             void *pa = nullptr;
-            const size_t nb = (Q + 255) / 256 + 1;
+            const size_t nb = (Q * (size_t)g->B + 255) / 256 + 1;
             if (hipExtMallocWithFlags(&pa, sizeof(unsigned) * nb, hipDeviceMallocFinegrained) == hipSuccess && pa &&
                 hipMemset(pa, 0, sizeof(unsigned) * nb) == hipSuccess && hipDeviceSynchronize() == hipSuccess)
                 g->d_arrive = (unsigned *)pa;
@@ -754,6 +754,7 @@ extern "C" int grape_create(const grape_config *cfg, grape_ctx **out)
             g->sub[i]->comm = comms[i];
             g->sub[i]->comm_rank = i;
             g->sub[i]->comm_size = G;
+            g->sub[i]->group = g;
         }
     }
     // peer access between every pair of distinct devices of the group: x fan-out and the [G, F] rows travel device to
@@ -835,8 +836,6 @@ extern "C" int grape_comm_attach(grape_ctx *c, const grape_comm_id *id, int32_t 
         return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_comm_attach: the context already spans devices in-process");
     if (c->comm)
         return fail(c, GRAPE_ERR_INVALID_ARG, "grape_comm_attach: a communicator is already attached");
-    if (c->B > 1)
-        return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_comm_attach: max_batch > 1 is single-device in this build");
     RcclApi *api = rccl();
     if (!api) return fail(c, GRAPE_ERR_COMM, "grape_comm_attach: " + g_rccl.err);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -859,15 +858,13 @@ extern "C" int grape_ipc_export(grape_ctx *c, int32_t n_ranks, grape_ipc_handle 
         return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_ipc_export: the context already spans devices in-process");
     if (c->comm || c->ipc_ranks > 1)
         return fail(c, GRAPE_ERR_INVALID_ARG, "grape_ipc_export: a communicator is already attached");
-    if (c->B > 1)
-        return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_ipc_export: max_batch > 1 is single-device in this build");
     static_assert(sizeof(grape_ipc_handle) >= sizeof(hipIpcMemHandle_t), "grape_ipc_handle must hold a hipIpcMemHandle_t");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->d_mbox && c->ipc_alloc_ranks != n_ranks) {
         (void)hipFree(c->d_mbox);
         c->d_mbox = nullptr;
     }
-    const size_t bytes = grape::ipc_mailbox_bytes((int)(KN(c) + 1), n_ranks);
+    const size_t bytes = grape::ipc_mailbox_bytes((int)((KN(c) + 1) * (size_t)c->B), n_ranks);     // (n_x <= max_batch rows per call)
     if (!c->d_mbox) {
         void *pm = nullptr;
         // fine-grained: stores and atomics of the peers' devices are visible to this device's loads (and the other way round)
@@ -1777,21 +1774,22 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
 }
 
 // in-place (or send -> recv) all-reduce of one shard's [G, F] on `stream`
-static int enqueue_allreduce(grape_ctx *c, const double *send, double *recv, hipStream_t stream)
+static int enqueue_allreduce(grape_ctx *c, const double *send, double *recv, hipStream_t stream, int n_x = 1)
 {
-    NCCL_TRY(c, g_rccl.AllReduce(send, recv, KN(c) + 1, ncclDouble, ncclSum, c->comm, stream));
+    NCCL_TRY(c, g_rccl.AllReduce(send, recv, (KN(c) + 1) * (size_t)n_x, ncclDouble, ncclSum, c->comm, stream));
     return GRAPE_OK;
 }
 
 // One process per GPU, mailboxes attached (grape_ipc_attach): `row` (this rank's [G, F], complete on `stream`) summed over
 // the ranks into `out` (device, nullable) and, with `done`, into the host buffer -- ipc_allreduce_kernel, no RCCL.
-static int enqueue_ipc_allreduce(grape_ctx *c, const double *row, double *out, hipStream_t stream, grape::DoneSignal done)
+static int enqueue_ipc_allreduce(grape_ctx *c, const double *row, double *out, hipStream_t stream, grape::DoneSignal done,
+                                 int n_x = 1)
 {
     KernelLogScope log_scope(&c->kernel_log, true);
     grape::IpcParams ip{};
     ip.own_row = row;
-    ip.Q = (int)(KN(c) + 1);
-    ip.Qpad = (ip.Q + 255) / 256 * 256;
+    ip.Q = (int)((KN(c) + 1) * (size_t)n_x);                 // the n_x rows of a batched call travel as one
+    ip.Qpad = (int)(((KN(c) + 1) * (size_t)c->B + 255) / 256 * 256);     // slot size: fixed by max_batch (every block column arrives every call)
     ip.rank = c->comm_rank;
     ip.n_ranks = c->ipc_ranks;
     ip.parity = (int)(c->ipc_evals & 1);
@@ -1890,7 +1888,7 @@ static int shard_enqueue_host(grape_ctx *s, const double *x, int n_x, double *ta
 // a group shard's share of grape_eval: its launches, then the event the sum on the first device waits for
 static int shard_issue_group(grape_ctx *s)
 {
-    int rc = shard_issue(s, 1, s->d_fg, false);
+    int rc = shard_issue(s, s->group ? s->group->group_nx : 1, s->d_fg, false);
     if (rc == GRAPE_OK && s->ev_done && hipEventRecord(s->ev_done, s->stream) != hipSuccess)
         rc = fail(s, GRAPE_ERR_HIP, "hipEventRecord failed");
     return rc;
@@ -1905,8 +1903,9 @@ static int shard_launch_arrive(grape_ctx *s)
     grape::ArriveParams ap{};
     ap.rows.n = (int)g->sub.size();
     for (size_t i = 0; i < g->sub.size(); ++i) ap.rows.p[i] = g->sub[i]->d_fg;
-    ap.Q = (int)(KN(g) + 1);
+    ap.Q = (int)((KN(g) + 1) * (size_t)g->group_nx);
     ap.arrive = g->d_arrive;
+    ap.finished = g->d_arrive + ((KN(g) + 1) * (size_t)g->B + 255) / 256;
     ap.out = nullptr;
     ap.done = g->group_done;
     if (grape::launch_shard_arrive(ap, s->stream) != hipSuccess)
@@ -1915,7 +1914,7 @@ static int shard_launch_arrive(grape_ctx *s)
 }
 static int shard_issue_group_arrive(grape_ctx *s)
 {
-    int rc = shard_issue(s, 1, s->d_fg, false);
+    int rc = shard_issue(s, s->group->group_nx, s->d_fg, false);
     if (rc == GRAPE_OK) rc = shard_launch_arrive(s);
     return rc;
 }
@@ -2013,24 +2012,22 @@ static int wait_flag(grape_ctx *s)
 static int group_fail(grape_ctx *g, grape_ctx *s, int rc) { return fail(g, rc, s->err); }
 
 static int enqueue_peer_sum(grape_ctx *g, double *target, hipStream_t lead_stream, bool shard0_on_lead,
-                            grape::DoneSignal done, bool record = true);
+                            grape::DoneSignal done, bool record = true, int n_x = 1);
 
-extern "C" int grape_eval_device(grape_ctx *c, const double *d_x, double *d_fg, void *stream)
+// device pointers in, device pointers out, nothing synchronised: n_x control arrays (n_x > 1: grape_eval_batch_device) on a
+// single device, an attached communicator / mailbox exchange, or an in-process group
+static int eval_device_impl(grape_ctx *c, const double *d_x, double *d_fg, void *stream, int n_x)
 {
-    DeviceGuard guard;
-    if (!c) return GRAPE_ERR_INVALID_ARG;
-    if (!d_x || !d_fg) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval_device: null argument");
-    if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, "grape_eval_device: operators not set");
     hipStream_t st = (hipStream_t)stream;
     if (!c->is_group) {
         HIP_TRY(c, hipSetDevice(c->device));
-        int rc = enqueue_eval(c, d_x, d_fg, st);
+        int rc = enqueue_eval(c, d_x, d_fg, st, n_x);
         if (rc) return rc;
         if (c->ipc_ranks > 1) {
-            rc = enqueue_ipc_allreduce(c, d_fg, d_fg, st, grape::DoneSignal());
+            rc = enqueue_ipc_allreduce(c, d_fg, d_fg, st, grape::DoneSignal(), n_x);
             if (rc) return rc;
         } else if (c->comm) {
-            rc = enqueue_allreduce(c, d_fg, d_fg, st);
+            rc = enqueue_allreduce(c, d_fg, d_fg, st, n_x);
             if (rc) return rc;
         }
         HIP_TRY(c, hipEventRecord(c->ev_dev, st));
@@ -2039,21 +2036,21 @@ extern "C" int grape_eval_device(grape_ctx *c, const double *d_x, double *d_fg, 
     }
     // group: d_x, d_fg live on the first device; fan x out, evaluate every shard, one grouped all-reduce
     grape_ctx *s0 = c->sub[0];
-    const size_t bytes = sizeof(double) * KN(c);
+    const size_t bytes = sizeof(double) * KN(c) * (size_t)n_x;
     HIP_TRY(c, hipSetDevice(s0->device));
     if (c->sub.size() > 1) HIP_TRY(c, hipEventRecord(s0->ev_dev, st));       // x is ready at this point of `st`
-    int rc = enqueue_eval(s0, d_x, s0->d_fg, st);
+    int rc = enqueue_eval(s0, d_x, s0->d_fg, st, n_x);
     if (rc) return group_fail(c, s0, rc);
     for (size_t i = 1; i < c->sub.size(); ++i) {
         grape_ctx *s = c->sub[i];
         HIP_TRY(c, hipSetDevice(s->device));
         HIP_TRY(c, hipStreamWaitEvent(s->stream, s0->ev_dev, 0));
         HIP_TRY(c, hipMemcpyPeerAsync(s->d_x, s->device, d_x, s0->device, bytes, s->stream));
-        rc = enqueue_eval(s, s->d_x, s->d_fg, s->stream);
+        rc = enqueue_eval(s, s->d_x, s->d_fg, s->stream, n_x);
         if (rc) return group_fail(c, s, rc);
     }
     if (c->peer_sum) {
-        rc = enqueue_peer_sum(c, d_fg, st, true, grape::DoneSignal());
+        rc = enqueue_peer_sum(c, d_fg, st, true, grape::DoneSignal(), true, n_x);
         if (rc) return rc;
         HIP_TRY(c, hipSetDevice(s0->device));
         HIP_TRY(c, hipEventRecord(s0->ev_dev, st));
@@ -2064,7 +2061,7 @@ extern "C" int grape_eval_device(grape_ctx *c, const double *d_x, double *d_fg, 
     NCCL_TRY(c, g_rccl.GroupStart());
     for (size_t i = 0; i < c->sub.size(); ++i) {
         grape_ctx *s = c->sub[i];
-        const ncclResult_t r = g_rccl.AllReduce(s->d_fg, i == 0 ? d_fg : s->d_fg, KN(c) + 1, ncclDouble, ncclSum,
+        const ncclResult_t r = g_rccl.AllReduce(s->d_fg, i == 0 ? d_fg : s->d_fg, (KN(c) + 1) * (size_t)n_x, ncclDouble, ncclSum,
                                                 s->comm, i == 0 ? st : s->stream);
         if (r != ncclSuccess) {
             (void)g_rccl.GroupEnd();
@@ -2079,15 +2076,24 @@ extern "C" int grape_eval_device(grape_ctx *c, const double *d_x, double *d_fg, 
     return GRAPE_OK;
 }
 
+extern "C" int grape_eval_device(grape_ctx *c, const double *d_x, double *d_fg, void *stream)
+{
+    DeviceGuard guard;
+    if (!c) return GRAPE_ERR_INVALID_ARG;
+    if (!d_x || !d_fg) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval_device: null argument");
+    if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, "grape_eval_device: operators not set");
+    return eval_device_impl(c, d_x, d_fg, stream, 1);
+}
+
 // peer_sum group: every shard's [G, F] (K*N+1 doubles in its d_fg) is copied to the first device behind that shard's
 // own evaluation and ONE reduction kernel sums the rows in shard order into `target` (and, with `done`, publishes them
 // to the host like the single-GPU path).  `shard0_on_lead`: shard 0 was evaluated on `lead_stream` itself.
 static int enqueue_peer_sum(grape_ctx *g, double *target, hipStream_t lead_stream, bool shard0_on_lead,
-                            grape::DoneSignal done, bool record)
+                            grape::DoneSignal done, bool record, int n_x)
 {
     grape_ctx *lead = g->sub[0];
     KernelLogScope log_scope(&lead->kernel_log, true);
-    const size_t Q = KN(g) + 1;
+    const size_t Q = (KN(g) + 1) * (size_t)n_x;              // (the n_x rows of a batched call are summed as one)
     grape::ShardRows rows{};
     rows.n = (int)g->sub.size();
     const bool direct = g->peer_direct;                      // every shard's row readable from the first device
@@ -2139,7 +2145,8 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
             // not G of them
             timespec ts0, ts1, ts2, ts3;
             clock_gettime(CLOCK_MONOTONIC, &ts0);
-            for (grape_ctx *s : c->sub) shard_stage_x(s, x, 1);
+            for (grape_ctx *s : c->sub) shard_stage_x(s, x, n_x);
+            c->group_nx = n_x;
             clock_gettime(CLOCK_MONOTONIC, &ts1);
             const bool arrive = c->peer_sum && c->d_arrive && c->peer_all;
             if (arrive) {                                    // how this evaluation is published: the same for every shard
@@ -2149,7 +2156,7 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
                 c->group_done.host_out = lead->d_h_fg;
             }
             for (size_t i = 1; i < c->sub.size(); ++i) c->sub[i]->worker->post(arrive ? shard_issue_group_arrive : shard_issue_group);
-            rc = arrive ? shard_issue_group_arrive(lead) : shard_issue(lead, 1, lead->d_fg, false);
+            rc = arrive ? shard_issue_group_arrive(lead) : shard_issue(lead, n_x, lead->d_fg, false);
             int rc_w = GRAPE_OK;
             grape_ctx *bad = nullptr;
             for (size_t i = 1; i < c->sub.size(); ++i) {
@@ -2169,12 +2176,12 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
                 done.flag = lead->d_h_flag;
                 done.seq = ++lead->seq;
                 done.host_out = lead->d_h_fg;
-                rc = enqueue_peer_sum(c, lead->d_fg, lead->stream, true, done, false);
+                rc = enqueue_peer_sum(c, lead->d_fg, lead->stream, true, done, false, n_x);
                 if (rc) return rc;
             } else {
                 NCCL_TRY(c, g_rccl.GroupStart());
                 for (grape_ctx *s : c->sub) {
-                    const ncclResult_t r = g_rccl.AllReduce(s->d_fg, s->d_fg, Q, ncclDouble, ncclSum, s->comm, s->stream);
+                    const ncclResult_t r = g_rccl.AllReduce(s->d_fg, s->d_fg, Q * (size_t)n_x, ncclDouble, ncclSum, s->comm, s->stream);
                     if (r != ncclSuccess) {
                         (void)g_rccl.GroupEnd();
                         return fail(c, GRAPE_ERR_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
@@ -2191,19 +2198,19 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
             c->group_tm[4] -= (double)ts0.tv_sec + 1e-9 * (double)ts0.tv_nsec;      // (+ the end time below)
             c->group_tm[3] -= (double)ts3.tv_sec + 1e-9 * (double)ts3.tv_nsec;
         } else if (c->ipc_ranks > 1) {
-            rc = shard_enqueue_host(c, x, 1, c->d_fg, false);
+            rc = shard_enqueue_host(c, x, n_x, c->d_fg, false);
             if (rc) return rc;
             grape::DoneSignal done;                          // the exchange kernel publishes like the single-GPU path
             done.counter = c->d_done_counter;
             done.flag = c->d_h_flag;
             done.seq = ++c->seq;
             done.host_out = c->d_h_fg;
-            rc = enqueue_ipc_allreduce(c, c->d_fg, nullptr, c->stream, done);
+            rc = enqueue_ipc_allreduce(c, c->d_fg, nullptr, c->stream, done, n_x);
             if (rc) return rc;
         } else {
-            rc = shard_enqueue_host(c, x, 1, c->d_fg, false);
+            rc = shard_enqueue_host(c, x, n_x, c->d_fg, false);
             if (rc) return rc;
-            rc = enqueue_allreduce(c, c->d_fg, c->d_fg, c->stream);
+            rc = enqueue_allreduce(c, c->d_fg, c->d_fg, c->stream, n_x);
             if (rc) return rc;
         }
         if (!(c->is_group && c->peer_sum) && !(c->ipc_ranks > 1)) {
@@ -2213,7 +2220,7 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
             done.flag = lead->d_h_flag;
             done.seq = ++lead->seq;
             KernelLogScope log_scope(&lead->kernel_log, true);
-            HIP_TRY(c, grape::launch_copy(lead->d_fg, lead->d_h_fg, (int)Q, lead->stream, done));
+            HIP_TRY(c, grape::launch_copy(lead->d_fg, lead->d_h_fg, (int)(Q * (size_t)n_x), lead->stream, done));
         }
     }
     rc = wait_flag(lead);                                    // [G, F] are in host memory
@@ -2261,13 +2268,7 @@ extern "C" int grape_eval_batch_device(grape_ctx *c, int32_t n_x, const double *
     if (n_x < 1 || n_x > c->B)
         return fail(c, GRAPE_ERR_INVALID_ARG, "grape_eval_batch_device: n_x must be in 1..grape_config.max_batch");
     if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, "grape_eval_batch_device: operators not set");
-    if (n_x == 1) return grape_eval_device(c, d_x, d_fg, stream);
-    HIP_TRY(c, hipSetDevice(c->device));                    // n_x > 1 implies a single-device context
-    int rc = enqueue_eval(c, d_x, d_fg, (hipStream_t)stream, n_x);
-    if (rc) return rc;
-    HIP_TRY(c, hipEventRecord(c->ev_dev, (hipStream_t)stream));
-    c->dev_pending = true;
-    return GRAPE_OK;
+    return eval_device_impl(c, d_x, d_fg, stream, n_x);
 }
 
 // group accessors: the shard that owns `member`
@@ -2320,12 +2321,8 @@ struct LbfgsRun {
     int evaluate(int n_x)
     {
         evals += n_x;
-        if (c->is_group)                          // fan-out of x, every shard, the grouped all-reduce / peer sum
-            return grape_eval_device(c, st.xt, st.fgt, lead->stream);
-        int rc = enqueue_eval(c, st.xt, st.fgt, c->stream, n_x);
-        if (rc == GRAPE_OK && c->ipc_ranks > 1) rc = enqueue_ipc_allreduce(c, st.fgt, st.fgt, c->stream, grape::DoneSignal());
-        else if (rc == GRAPE_OK && c->comm) rc = enqueue_allreduce(c, st.fgt, st.fgt, c->stream);
-        return rc;
+        // (groups: fan-out of x, every shard, the grouped all-reduce / peer sum; communicators: the exchange behind the sweep)
+        return eval_device_impl(c, st.xt, st.fgt, lead->stream, n_x);
     }
     // phi(alpha), phi'(alpha) along the current direction; `have_trial`: slot 0 already holds x + alpha d
     int phi(double alpha, bool have_trial, double &f, double &df)
@@ -2535,12 +2532,12 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
     if (m > 64) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_lbfgs: memory must be <= 64");
     if (o.line_search < 0 || o.line_search > 2) return fail(c, GRAPE_ERR_INVALID_ARG, "grape_lbfgs: line_search must be 0, 1 or 2");
     const bool multi = c->is_group || c->comm != nullptr || c->ipc_ranks > 1;
-    if (multi && o.line_search == 2)
-        return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_lbfgs: the batched ladder search (line_search = 2) is single-device; "
-                                              "multi-device contexts use the Hager-Zhang search");
+    if (multi && o.line_search == 2 && c->B < 2)
+        return fail(c, GRAPE_ERR_UNSUPPORTED, "grape_lbfgs: the batched ladder search (line_search = 2) needs max_batch >= 2 "
+                                              "(multi-device contexts default to the Hager-Zhang search)");
     grape_ctx *lead = c->is_group ? c->sub[0] : c;
     int B = 1;
-    if (o.line_search == 2 || (!multi && o.probes > 1)) {
+    if (o.line_search == 2 || (!multi && o.probes > 1)) {        // (multi-device contexts: batched probes only on request)
         B = o.probes;
         if (B <= 0) {
             // probing several step lengths multiplies the sweep's work: free while the ensemble leaves the chip

@@ -232,7 +232,8 @@ hipError_t launch_reduce_shards(const ShardRows &rows, double *fg, int Q, hipStr
 struct ArriveParams {
     ShardRows rows;
     int Q;
-    unsigned *arrive;             // [ceil(Q / 256)] arrivals per block column + [1] summing blocks that have finished
+    unsigned *arrive;             // [ceil(Q / 256)] arrivals per block column
+    unsigned *finished;           // summing blocks that have finished (behind the counters of the largest batch)
     double *out;                  // device result on the first device (nullable)
     DoneSignal done;              // host publication (host_out, flag, seq); counter unused
 };

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void shard_arrive_kernel(const ArriveParams p)
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned *finished = p.arrive + gridDim.x;
+        unsigned *finished = p.finished;
         const unsigned prev = __hip_atomic_fetch_add(finished, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
         if (prev == gridDim.x - 1) {
             __hip_atomic_store(finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -260,7 +260,7 @@ size_t ipc_mailbox_bytes(int Q, int n_ranks)
 __global__ __launch_bounds__(256) void ipc_allreduce_kernel(const IpcParams p)
 {
     __shared__ int s_ok;
-    const int q = blockIdx.x * 256 + threadIdx.x, R = p.n_ranks, nb = gridDim.x;
+    const int q = blockIdx.x * 256 + threadIdx.x, R = p.n_ranks, nb = gridDim.x;     // (the whole mailbox: Qpad / 256 block columns)
     const size_t slot = ((size_t)p.parity * R + p.rank) * p.Qpad + q, counters = (size_t)2 * R * p.Qpad;
     const double mine = q < p.Q ? p.own_row[q] : 0.0;
     for (int j = 0; j < R; ++j)                                   // my outputs into slot `rank` of every mailbox

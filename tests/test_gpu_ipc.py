@@ -86,3 +86,53 @@ def test_group_arrive_and_sum_equals_the_stream_ordered_reduction(qoc, oracle, m
         assert F0 == F1 and np.array_equal(G0, G1)
     F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, xs[-1], w.T)
     assert_parity(got["0"][-1][0], got["0"][-1][1], F_ref, G_ref, w.n, what="arrive-and-sum")
+
+
+def test_batched_calls_over_the_mailbox_exchange(qoc, oracle, tmp_path):
+    """grape_eval_batch on attached contexts (round 3: single-device only): n_x control arrays per call, one exchange."""
+    w = qoc.workloads.config("C3", E=9, N=30)
+    res = _run_ranks(tmp_path, 2, "C3", 9, 30, env={"IPC_TEST_BATCH": "3"})
+    assert all(str(r["collective"]) == "ipc" for r in res)
+    assert np.array_equal(res[0]["Fb"], res[1]["Fb"]) and np.array_equal(res[0]["Gb"], res[1]["Gb"])
+    for b in range(3):                             # entry b of a batched call = the single call on the same x, bit for bit
+        assert res[0]["Fb"][b] == res[0]["F"][b] and np.array_equal(res[0]["Gb"][b], res[0]["G"][b])
+    assert res[0]["Fb1"][0] == res[0]["F"][1] and np.array_equal(res[0]["Gb1"][0], res[0]["G"][1])
+
+
+@pytest.mark.parametrize("mode", ["arrive", "stream", "rccl1"])
+def test_batched_calls_on_multi_device_contexts(qoc, oracle, monkeypatch, mode):
+    """max_batch > 1 on in-process groups (arrive-and-sum, the stream-ordered reduction) and on a 1-rank RCCL communicator:
+    host and device entry points against the oracle, and the batched ladder search of grape_lbfgs on a group."""
+    import torch
+    w = qoc.workloads.config("C3", E=11, N=40)
+    rng = np.random.default_rng(8)
+    X = np.array([w.x + 0.1 * rng.standard_normal(w.x.shape) for _ in range(3)])
+    monkeypatch.setenv("GRAPE_GROUP_STREAM_SUM", "1" if mode == "stream" else "0")
+    kw = dict(force_collective=True) if mode == "rccl1" else dict(devices=[0, 0, 0], flags=qoc.engine.FLAG_GROUP_PEER_SUM)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, max_batch=3, **kw) as eng:
+        Fb, Gb = eng.eval_batch(X)
+        F1, G1 = eng.eval(X[1])
+        F2, G2 = eng.eval_batch(X[:2])
+        xd = torch.as_tensor(np.ascontiguousarray(np.swapaxes(X, 1, 2)), device="cuda")
+        fg = torch.zeros(3 * (w.K * w.N + 1), dtype=torch.float64, device="cuda")
+        eng.eval_batch_device(3, xd.data_ptr(), fg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        h = fg.cpu().numpy().reshape(3, -1)
+    for b in range(3):
+        F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, X[b], w.T)
+        assert_parity(Fb[b], Gb[b], F_ref, G_ref, w.n, what=f"{mode}: batch entry {b}")
+        assert h[b, -1] == Fb[b] and np.array_equal(h[b, :-1].reshape(w.N, w.K).T, Gb[b])
+    assert F1 == Fb[1] and np.array_equal(G1, Gb[1]) and np.array_equal(F2, Fb[:2]) and np.array_equal(G2, Gb[:2])
+
+
+def test_ladder_search_on_a_group_with_batched_probes(qoc):
+    """grape_lbfgs line_search = "ladder" (B step lengths per batched launch) on a multi-device context with max_batch >= 2
+    (round 3: refused): the same iterates as on one device."""
+    w = qoc.workloads.reference_ensemble("StateTransfer", 5, 25, 5.0)
+    args = (w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N)
+    with qoc.GrapeEngine(*args, max_batch=4) as eng:
+        x1, i1 = eng.lbfgs(w.x, iterations=10, line_search="ladder", probes=4)
+    with qoc.GrapeEngine(*args, max_batch=4, devices=[0, 0], flags=qoc.engine.FLAG_GROUP_PEER_SUM) as eng:
+        x2, i2 = eng.lbfgs(w.x, iterations=10, line_search="ladder", probes=4)
+    assert i1["probes"] == i2["probes"] == 4 and i1["iterations"] == i2["iterations"] and i1["evaluations"] == i2["evaluations"]
+    assert abs(i1["minimum"] - i2["minimum"]) <= 1e-10 and np.abs(x1 - x2).max() <= 1e-7

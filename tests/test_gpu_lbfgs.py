@@ -123,7 +123,7 @@ def test_lbfgs_on_a_device_group_and_with_a_communicator(qoc):
         x3, i3 = eng.lbfgs(w.x, iterations=15)
         with pytest.raises(qoc.GrapeError) as ei:
             eng.lbfgs(w.x, line_search="ladder")
-        assert ei.value.status == -2                                # the batched ladder is single-device
+        assert ei.value.status == -2                                # the batched ladder needs max_batch >= 2 there
     with qoc.GrapeEngine(*args, force_collective=True) as eng:
         xc, ic = eng.lbfgs(w.x, iterations=15)
     for info, x in ((i3, x3), (ic, xc)):

@@ -23,7 +23,8 @@ def main():
     torch.cuda.set_device(dev)
     dist.init_process_group("gloo")
     w = qoc.workloads.reference_ensemble("StateTransfer", E, N, 5.0) if cfg == "REF" else qoc.workloads.config(cfg, E=E, N=N)
-    sg = sharded_engine(w, dev, collective="ipc")
+    batch = int(os.environ.get("IPC_TEST_BATCH", "1"))
+    sg = sharded_engine(w, dev, collective="ipc", max_batch=batch)
     res = {"collective": np.array(sg.collective), "comm_size": sg.comm_size, "error": np.array(getattr(sg, "attach_error", ""))}
     if sg.collective == "ipc":
         rng = np.random.default_rng(5)
@@ -41,6 +42,11 @@ def main():
         F6, G6 = sg.eval(xs[2])                        # host path right behind the device path
         res["F6"], res["G6"] = F6, G6
         res["names"] = np.array(";".join(sg.local.kernel_names()))
+        if batch > 1:                                  # n_x control arrays per call: every rank's rows travel as one exchange
+            Fb, Gb = sg.local.eval_batch(np.array(xs[:batch]))
+            res["Fb"], res["Gb"] = Fb, Gb
+            Fb1, Gb1 = sg.local.eval_batch(np.array(xs[1:2]))      # fewer than max_batch: the whole mailbox still takes part
+            res["Fb1"], res["Gb1"] = Fb1, Gb1
         if os.environ.get("IPC_TEST_LBFGS"):
             xm, info = sg.local.lbfgs(w.x, iterations=15)
             res["lbfgs_x"], res["lbfgs_min"], res["lbfgs_evals"] = xm, info["minimum"], info["evaluations"]
