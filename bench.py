@@ -576,6 +576,8 @@ def compact(out):
     if "weak_scaling" in ex:
         cx["weak_scaling"] = {k: _r(v, 5) for k, v in ex["weak_scaling"].items()
                               if k in ("value", "ms_per_step", "ensemble_total", "scaling", "error")}
+    if "ipc_exchange" in ex:
+        cx["ipc_exchange"] = {k: (_r(v, 5) if k != "error" else str(v)[:100]) for k, v in ex["ipc_exchange"].items() if k in ("value", "ms_per_step", "error")}
     if isinstance(ex.get("lbfgs"), list):
         cx["lbfgs"] = [{"problem": "reference n_ens=5 testset" if e["problem"].startswith("reference") else "C3-shaped StateTransfer E=1024",
                         "device": [e["device_lbfgs"]["iterations"], e["device_lbfgs"]["evaluations"], _r(1e3 * e["device_lbfgs"]["seconds"]),
@@ -642,8 +644,9 @@ def main():
     ap.add_argument("--backend", default="",
                     help="torch.distributed backend; default: gloo as the control plane when the data-path collective "
                          "is RCCL inside the library (--collective lib), cpu:gloo,cuda:nccl for --collective torch")
-    ap.add_argument("--collective", choices=["lib", "torch"], default="lib",
-                    help="lib: ncclAllReduce inside libgrape_hip.so (grape_comm_attach); torch: torch.distributed.all_reduce")
+    ap.add_argument("--collective", choices=["lib", "ipc", "torch"], default="lib",
+                    help="lib: ncclAllReduce inside libgrape_hip.so (grape_comm_attach, the north star's exchange); ipc: the "
+                         "library's mailbox exchange over HIP IPC handles (grape_ipc_attach, no RCCL); torch: torch.distributed.all_reduce")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the collective even with one rank (a 1-rank RCCL communicator)")
     ap.add_argument("--force-general", action="store_true",
@@ -679,7 +682,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(args.backend or ("gloo" if args.collective == "lib" else "cpu:gloo,cuda:nccl"))
+        dist.init_process_group(args.backend or ("gloo" if args.collective in ("lib", "ipc") else "cpu:gloo,cuda:nccl"))
 
     base = qoc.workloads.config(args.config)
     E_cfg = args.ensemble or base.E
@@ -707,7 +710,7 @@ def main():
     # the step, as a compiled caller makes it: buffers in the library's (K,N) column-major layout, allocated once
     xf = np.ascontiguousarray(w.x.T)
     Gf = np.empty_like(xf)
-    direct = sg.local is not None and (sg.collective == "lib" or (world == 1 and not args.force_dist))
+    direct = sg.local is not None and (sg.collective in ("lib", "ipc") or (world == 1 and not args.force_dist))
 
     bound = sg.local.bind_eval(xf, Gf) if direct else None
 
@@ -769,6 +772,28 @@ def main():
             extra = dict(extra or {})
             extra["weak_scaling"] = {"error": repr(exc)}
 
+    # ---- N > 1 with the RCCL exchange: the same strong-scaling step through the library's mailbox exchange (no RCCL), so that
+    # a multi-GPU run shows both side by side
+    if world > 1 and args.scaling == "strong" and not args.no_extra and args.collective == "lib":
+        try:
+            sg_i = sharded_engine(w, device, collective="ipc", flags=qoc.engine.FLAG_FORCE_GENERAL if args.force_general else 0)
+            if sg_i.collective == "ipc":
+                Gi = np.empty_like(xf)
+                bound_i = sg_i.local.bind_eval(xf, Gi)
+                for _ in range(min(args.warmup, 10)):
+                    bound_i()
+                ipc_s = statistics.median(time_blocks(bound_i, args.steps, args.blocks, barrier, reduce_max))
+                extra = dict(extra or {})
+                extra["ipc_exchange"] = {"value": args.steps / ipc_s, "unit": "gradient-evals/s", "ms_per_step": 1e3 * ipc_s / args.steps,
+                                         "what": "the same step with collective='ipc' (ipc_allreduce_kernel instead of ncclAllReduce + copy)"}
+            else:
+                extra = dict(extra or {})
+                extra["ipc_exchange"] = {"error": getattr(sg_i, "attach_error", "not attached")}
+            sg_i.close()
+        except Exception as exc:                   # noqa: BLE001 -- an extra must not kill the headline
+            extra = dict(extra or {})
+            extra["ipc_exchange"] = {"error": repr(exc)}
+
     if rank == 0:
         evals_per_s = args.steps / elapsed
         # units: with weak scaling the job evaluates world x the config's ensemble per step;
@@ -788,7 +813,7 @@ def main():
                                    f"{local.E} members/GPU), T={w.T}; step = host->host grape_eval "
                                    f"(x in host memory -> F, G in host memory, blocking)",
                        "parallelism": (f"ensemble-shard x{world}, one all-reduce of {w.K * w.N + 1} f64 per step "
-                                       f"({'ncclAllReduce inside libgrape_hip.so' if sg.collective == 'lib' else 'torch.distributed'})")
+                                       f"({'ncclAllReduce inside libgrape_hip.so' if sg.collective == 'lib' else 'mailbox exchange inside libgrape_hip.so (HIP IPC)' if sg.collective == 'ipc' else 'torch.distributed'})")
                                       if world > 1 else "single GPU",
                        "collective": sg.collective if (world > 1 or args.force_dist) else None,
                        "slices_per_lane": info.get("slices_per_lane"),

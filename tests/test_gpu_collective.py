@@ -167,6 +167,30 @@ def test_two_ranks_sharing_the_gpu_fall_back_consistently(qoc):
     # N > 1 runs carry the weak-scaling companion (every rank a full 1024-member shard) next to the strong headline
     weak = d["extra"]["weak_scaling"]
     assert weak["ensemble_total"] == 2048 and weak["value"] > 0 and weak["scaling"] == "weak", weak
+    # ... and the same strong-scaling step through the library's mailbox exchange, which ranks sharing a GPU CAN run
+    assert d["extra"]["ipc_exchange"].get("value", 0) > 0, d["extra"]["ipc_exchange"]
+    w = qoc.workloads.config("C3")
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        F, _ = eng.eval(w.x)
+    assert abs(d["F"] - F) <= 1e-12
+
+
+def test_bench_with_the_mailbox_exchange_on_two_ranks(qoc):
+    """`python bench.py --gpus 2 --collective ipc` with both ranks on the one GPU: the library's own exchange carries the
+    headline step (n_gpus = 2 ranks that joined, collective "ipc"), F equals the single-context evaluation."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRAPE_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--collective", "ipc", "--steps", "5",
+                          "--warmup", "2", "--blocks", "1", "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["config"]["collective"] == "ipc" and d["value"] > 0
+    assert d["roofline"]["kernel"].endswith("ipc_allreduce_kernel")
     w = qoc.workloads.config("C3")
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
         F, _ = eng.eval(w.x)
