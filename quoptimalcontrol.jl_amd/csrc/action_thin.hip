@@ -211,8 +211,12 @@ __global__ __launch_bounds__(256) void action_rows_kernel(const TileParams p)
             pl[4 * NN + q] = g1.y;
             pl[5 * NN + q] = -g1.y;
         } else {
-            dst[e] = g0;
-            dst[NN + e] = g1;
+            // column-major: the 16 lanes of a DPP row of action_thin2_kernel (16 consecutive matrix rows, one column) read 256
+            // contiguous bytes (row-major rows, 512 bytes apart per lane, were 64 cache lines per load instruction: the
+            // kernel ran at the texture addresser's rate)
+            const int rr = e / NB, jj = e % NB;
+            dst[jj * NB + rr] = g0;
+            dst[NN + jj * NB + rr] = g1;
         }
         s_abs[e] = fabs(g0.x) + fabs(g0.y);
     }
@@ -576,10 +580,13 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_parts_kernel(const T
 // block its columns need: v_permlane32_swap of (R, R) gives (R0 R1 R0 R1), (R2 R3 R2 R3); v_permlane16_swap of those
 // gives (R0 R2 R0 R2) = re of block H and (R1 R3 R1 R3) = im of block H.  82 vector instructions per product.
 // (Measured alternatives: both chains in one wave with whole rows per lane -- 148 instructions per product for the pair,
-// no swaps, but 256 + 158 registers and one wave per SIMD: 12.6 ms against 9.0 ms for 1024 members of 2000 slices, a
-// single wave issues FP64 instructions at about half the pipe's rate; blocks handed round by four swaps and selects
-// after an all-gather: 100 instructions, 9.0 ms.)
-__global__ __launch_bounds__(64 * kActWaves) void action_thin2_kernel(const TileParams p)
+// no swaps, but 256 + 158 registers and one wave per SIMD: 12.6 ms against 9.0 ms for 1024 members of 2000 slices;
+// blocks handed round by four swaps and selects after an all-gather: 100 instructions, 9.0 ms.)
+// Round 4: the slice loop of action_parts_kernel -- images read as whole 256-byte runs (column-major, see action_rows_kernel),
+// two register sets taking turns with A' added in place, per-lane pointers walking the pulse, every row storing the record of
+// the element it holds (two rows the same value to the same address: an unconditional store), one vmcnt wait per slice,
+// the products of a slice unrolled for degrees up to 8.
+__global__ __launch_bounds__(64 * kActWaves, 2) void action_thin2_kernel(const TileParams p)
 {
     const int lane = threadIdx.x & 63, l = lane & 15, Rb = lane >> 5, H = (lane >> 4) & 1, el = 16 * Rb + l;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), d = wave & 1;
@@ -587,21 +594,19 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin2_kernel(const Tile
     if (k >= p.E)
         return;
     const size_t kw = (size_t)y * p.E + k;
-    const int off = d * 1024 + el * 32 + 16 * H;
-    const double2 *__restrict__ Ak = p.act_a + (size_t)k * 2048 + off;
-    const double2 *__restrict__ Gy = p.act_g + (size_t)y * N * 2048 + off;
+    // entry (row, col) of an image at [col][row]: the lane's 16 entries are 32 double2 apart, the row's 16 lanes contiguous
+    const int off = d * 1024 + (16 * H) * 32 + el;
     const double *__restrict__ gn = p.act_gn + (size_t)y * N;
     const double an = p.act_an[k];
-    // rows 0 (Rb = H = 0) and 3 (Rb = H = 1) hold, as x, the element el they also own: they write the records
-    const bool writer = Rb == H;
-    double2 *__restrict__ rec = (d ? p.wrec : p.states) + kw * (size_t)(N + 1) * 32 + (size_t)el * (N + 1);
-    double ar[16], ai[16];
+    double2 a[16];
+    {
+        const double2 *__restrict__ Ak = p.act_a + (size_t)k * 2048 + d * 1024 + el * 32 + 16 * H;      // (row-major upload)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double2 a = Ak[j];
-        ar[j] = a.x;
-        ai[j] = a.y;
+        for (int j = 0; j < 16; ++j)
+            a[j] = Ak[j];
     }
+    // every row holds, as x, element 16 H + l of the vector (rows 0 and 2 the same ones, rows 1 and 3): it records that element
+    double2 *recp = (d ? p.wrec : p.states) + kw * (size_t)(N + 1) * 32 + (size_t)(16 * H + l) * (N + 1);
     double xr, xi, sel;                                           // x[16 H + l]; this row's component of element el
     {
         const double2 *__restrict__ v0 = p.vecs + (size_t)k * 64 + d * 32;
@@ -609,68 +614,92 @@ __global__ __launch_bounds__(64 * kActWaves) void action_thin2_kernel(const Tile
         xr = col.x;
         xi = col.y;
         sel = H ? own.y : own.x;
-        if (writer)
-            rec[d ? N : 0] = own;
+        recp[d ? N : 0] = col;
     }
-    double2 gq[16];
-    {
-        const double2 *__restrict__ src = Gy + (size_t)(d ? N - 1 : 0) * 2048;
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            gq[j] = src[j];
-    }
+    recp += d ? N - 1 : 1;
+    const long rstep = d ? -1 : 1, gstep = d ? -2048 : 2048;
+    const double2 *gp = p.act_g + (size_t)y * N * 2048 + (size_t)(d ? N - 1 : 0) * 2048 + off;
     extern __shared__ unsigned short s_plan_all[];
     unsigned short *s_plan = s_plan_all + (size_t)wave * N;
     act_make_plan(s_plan, gn, an, N, p.s_forced, lane);           // (both waves of a member: the same plan)
-    unsigned plan = s_plan[0];
-    for (int i = 0; i < N; ++i) {
-        double mr[8], mi[8], nr[8], ni[8];                        // columns 0..7 and 8..15 of the half
+    auto fetch = [&](double2 (&g)[16]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {                             // G = Gc + A' (A last, timeevolution.jl:108)
-            mr[j] = gq[j].x + ar[j];
-            mi[j] = gq[j].y + ai[j];
-            nr[j] = gq[8 + j].x + ar[8 + j];
-            ni[j] = gq[8 + j].y + ai[8 + j];
-        }
-        {
-            const int tn = d ? max(N - 2 - i, 0) : min(i + 1, N - 1);
-            const double2 *__restrict__ src = Gy + (size_t)tn * 2048;
+        for (int j = 0; j < 16; ++j)
+            g[j] = gp[32 * j];
+        gp += gstep;                                              // (one slice past the end of the pulse at the last step: padded)
+    };
+    auto build = [&](double2 (&g)[16]) {                          // G = Gc + A' (A last, timeevolution.jl:108)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0f71);                       // vmcnt(1): every load is a slice old, only the record store is younger
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                gq[j] = src[j];
+        for (int j = 0; j < 16; ++j) {
+            g[j].x += a[j].x;
+            g[j].y += a[j].y;
         }
+    };
+    auto step = [&](const double2 (&g)[16], double inv, bool last) {
+        double mr[8], mi[8], nr[8], ni[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mr[j] = g[j].x;
+            mi[j] = g[j].y;
+            nr[j] = g[8 + j].x;
+            ni[j] = g[8 + j].y;
+        }
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        act_matvec(a0, a1, b0, b1, xr, xi, mr, mi);
+        act_matvec_hi(a0, a1, b0, b1, xr, xi, nr, ni);
+        double yr = a0 + a1, yi = b0 + b1;
+        swap16(yr, yi);                                           // H = 0 rows: both real halves; H = 1 rows: both imaginary halves
+        const double mine = fma(yr + yi, inv, sel);               // row rho: R_rho = (re b0, im b0, re b1, im b1)
+        if (last)
+            sel = mine;
+        xr = mine;
+        xi = mine;
+        swap32(xr, xi);                                           // (R0 R1 R0 R1), (R2 R3 R2 R3)
+        swap16(xr, xi);                                           // (R0 R2 R0 R2) = re of block H, (R1 R3 R1 R3) = im of block H
+    };
+    unsigned plan;
+    auto slice = [&](const double2 (&g)[16], double2 (&gnext)[16]) {
+        fetch(gnext);
         const int m = __builtin_amdgcn_readfirstlane(plan & 31), pieces = __builtin_amdgcn_readfirstlane(plan >> 5);
-        plan = s_plan[min(i + 1, N - 1)];
-        if (pieces != 1) {
-            const double inv_p = 1.0 / (double)pieces;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                mr[j] *= inv_p;
-                mi[j] *= inv_p;
-                nr[j] *= inv_p;
-                ni[j] *= inv_p;
+        if (pieces == 1 && m <= 8) {
+            if (m >= 8) step(g, 1.0 / 8, false);
+            if (m >= 7) step(g, 1.0 / 7, false);
+            if (m >= 6) step(g, 1.0 / 6, false);
+            if (m >= 5) step(g, 1.0 / 5, false);
+            if (m >= 4) step(g, 1.0 / 4, false);
+            if (m >= 3) step(g, 1.0 / 3, false);
+            if (m >= 2) step(g, 1.0 / 2, false);
+            step(g, 1.0, true);
+        } else {                                                  // degrees beyond 8, or the generator in pieces:
+            const double inv_p = 1.0 / (double)pieces;            // exp(G) = exp(G / p)^p, the 1 / p rides on the Horner factor
+            for (int piece = 0; piece < pieces; ++piece) {
+                for (int kk = m; kk >= 2; --kk)
+                    step(g, kActInv[kk] * inv_p, false);
+                step(g, inv_p, true);
             }
         }
-        auto step = [&](int kk) -> double {
-            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-            act_matvec(a0, a1, b0, b1, xr, xi, mr, mi);
-            act_matvec_hi(a0, a1, b0, b1, xr, xi, nr, ni);
-            double yr = a0 + a1, yi = b0 + b1;
-            swap16(yr, yi);                                       // H = 0 rows: both real halves; H = 1 rows: both imaginary halves
-            const double mine = fma(yr + yi, kActInv[kk], sel);   // row rho: R_rho = (re b0, im b0, re b1, im b1)
-            xr = mine;
-            xi = mine;
-            swap32(xr, xi);                                       // (R0 R1 R0 R1), (R2 R3 R2 R3)
-            swap16(xr, xi);                                       // (R0 R2 R0 R2) = re of block H, (R1 R3 R1 R3) = im of block H
-            return mine;
-        };
-        for (int piece = 0; piece < pieces; ++piece) {
-            for (int kk = m; kk >= 2; --kk)
-                (void)step(kk);
-            sel = step(1);
-        }
-        if (writer)
-            rec[d ? N - 1 - i : i + 1] = make_double2(xr, xi);
+        *recp = make_double2(xr, xi);
+        recp += rstep;
+    };
+    double2 g0[16], g1[16];
+    fetch(g0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    build(g0);
+    int i = 0;
+    for (; i + 2 <= N; i += 2) {
+        plan = s_plan[i];
+        slice(g0, g1);
+        build(g1);
+        plan = s_plan[i + 1];
+        slice(g1, g0);
+        build(g0);
+    }
+    if (i < N) {
+        plan = s_plan[i];
+        slice(g0, g1);
     }
 }
 
