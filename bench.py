@@ -308,12 +308,13 @@ def committed_phases(local, kernel_us):
     """The lane-pair sweep kernel's phases from the committed phase-stamp profile of this config ("from profile": the
     stamps cost a few percent, so the bench run itself does not carry them): share of the wave's cycles per phase, scaled
     to this run's kernel time, and the rate at which the HBM-bound backward phase reads the stored propagators."""
-    path = os.path.join(ROOT, "profiles", "r03_C3_phase_stamps.json")
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_C3_phase_stamps.json") for r in range(9, 0, -1))
+                 if os.path.exists(q)), "")
     try:
         d = json.load(open(path))
         if local.n != 4 or d.get("E") != local.E or local.N != 500:
             return None
-        out = {"source": "profiles/r03_C3_phase_stamps.json (tools/phase_profile.py), shares of a wave's cycles x this run's kernel time"}
+        out = {"source": f"profiles/{os.path.basename(path)} (tools/phase_profile.py), shares of a wave's cycles x this run's kernel time"}
         for name, ph in d["phases"].items():
             out[name] = {"share": ph["share"], "us": ph["share"] * kernel_us}
         p_bytes = local.E * local.N * local.n * local.n * 16

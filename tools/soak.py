@@ -65,10 +65,12 @@ for i in range(cases):
         # rank-one states, n = 9..32: the vector flow of action_thin.hip (forced likewise), or the flows it replaces
         os.environ["GRAPE_ACTION"] = "1" if rng.random() < 0.6 else "0"
         os.environ["GRAPE_THIN_DPP"] = "1" if rng.random() < 0.6 else "0"      # (9..16, not the Taylor flow: chain_prop_kernel / sweep_thin.hip)
+        os.environ["GRAPE_ACT_WHOLE"] = "1" if rng.random() < 0.5 else "0"     # (round 4: one or two members per wave of action_parts_kernel)
     else:
         os.environ.pop("GRAPE_HOIST", None)
         os.environ.pop("GRAPE_ACTION", None)
         os.environ.pop("GRAPE_THIN_DPP", None)
+        os.environ.pop("GRAPE_ACT_WHOLE", None)
     # rank-one states, 9..16, at least 64 slices: the chunked propagator chain (forced for dense controls too), or the
     # library's own choice
     if rng.random() < 0.5:
@@ -99,7 +101,7 @@ for i in range(cases):
     x = rng.uniform(-1, 1, (K, N))
     T = float(rng.uniform(0.3, 2.0))
     what = (f"case {i}: n={n} K={K} N={N} E={E} {sys_type} v{variant} herm={herm} sparse={sparse} states={states} flag={flag} "
-            f"shared_ctrl={shared_ctrl} action={os.environ.get('GRAPE_ACTION', '-')} dpp={os.environ.get('GRAPE_THIN_DPP', '-')} dppc={os.environ.get('GRAPE_DPP_CHUNKS', '-')}")
+            f"shared_ctrl={shared_ctrl} action={os.environ.get('GRAPE_ACTION', '-')} whole={os.environ.get('GRAPE_ACT_WHOLE', '-')} dpp={os.environ.get('GRAPE_THIN_DPP', '-')} dppc={os.environ.get('GRAPE_DPP_CHUNKS', '-')}")
     exact = rng.random() < 0.15 and N <= 33 and states not in ("rect", "vec")      # (the C oracle has no exact gradient for n x m states)
     if exact:                                             # exact gradient of the figure of merit / of the C1 functional
         objective = int(rng.integers(0, 2))
