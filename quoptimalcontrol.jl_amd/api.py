@@ -20,6 +20,8 @@ Julia.
 from dataclasses import dataclass, field
 from typing import Any, Callable, Optional
 
+import json
+
 import numpy as np
 
 from .engine import GrapeEngine
@@ -199,6 +201,12 @@ def save(solres, file_path):
         "Xt": np.asarray(base.Xt, complex), "guess": np.asarray(base.guess, dtype=np.float64),
         "alg_kind": np.array(type(alg).__name__), "n_slices": np.array(int(alg.n_slices)),
         "isinplace": np.array(bool(getattr(alg, "isinplace", True))),
+        # the whole alg struct, as the reference's save does (src/tools.jl:59-72): a re-solve from a loaded result must use
+        # the optimiser, tolerances and devices of the saved run, not the defaults
+        "alg_fields": np.array(json.dumps({"expm_method": alg.expm_method, "optim_options": alg.optim_options,
+                                            "device": int(alg.device), "optimizer": alg.optimizer,
+                                            "devices": None if alg.devices is None else [int(v) for v in alg.devices],
+                                            "peer_sum": bool(alg.peer_sum)})),
     }
     if ens:
         members = init_ensemble(prob)
@@ -219,8 +227,9 @@ def load(file_path):
     base = Problem(B=list(d["B"]), A=d["A"], Xi=d["Xi"], Xt=d["Xt"], T=float(d["T"]), n_controls=int(d["n_controls"]),
                    guess=d["guess"], sys_type=st)
     alg_cls = ADGRAPE if str(d["alg_kind"]) == "ADGRAPE" else GRAPE
-    alg = alg_cls(n_slices=int(d["n_slices"])) if alg_cls is ADGRAPE else GRAPE(n_slices=int(d["n_slices"]),
-                                                                                  isinplace=bool(d["isinplace"]))
+    extra = json.loads(str(d["alg_fields"])) if "alg_fields" in d.files else {}      # (files of earlier rounds: defaults)
+    alg = alg_cls(n_slices=int(d["n_slices"]), **extra) if alg_cls is ADGRAPE else GRAPE(n_slices=int(d["n_slices"]),
+                                                                                           isinplace=bool(d["isinplace"]), **extra)
     if str(d["kind"]) == "ensemble":
         Am, Bm, Xim, Xtm = d["A_members"], d["B_members"], d["Xi_members"], d["Xt_members"]
         ens = EnsembleProblem(prob=base, n_ens=int(d["n_ens"]), A_g=lambda k: Am[k - 1], B_g=lambda k: list(Bm[k - 1]),

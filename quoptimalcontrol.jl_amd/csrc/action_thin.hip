@@ -12,24 +12,29 @@
 // vector records instead of 3 x 4.2 GB of propagators, and does a third of the flops.  Same mathematics as the
 // reference's exp(..) * X to rounding (the parity tests hold it to the 1e-10 bar against the oracle's dense evaluation).
 //
-// Layout.  The two chains are independent until the gradient: the wave runs BOTH, the forward chain in lanes 0..31 at
-// slice i, the backward chain in lanes 32..63 at slice N-1-i, same instruction stream.  A 16-lane DPP row
-// rho = 2 d + h (d: direction, h: column half) holds in lane r
-//     M[r][8h .. 8h+7],  M = G_t (d = 0)  or  G_t' (d = 1),  8 complex = 16 VGPRs,
-// and x[(r + 8h) mod 16] of the vector being multiplied, so that `v_fmac_f64 ... row_newbcast:j` (the one DPP control
-// the FP64 ALU takes: src0 read from lane j of the row, measured at full rate, tools/ubench/dpp_fmac.hip) feeds
-// x[8h + j] to every lane of the row: 32 FMACs per product and no reduction tree.  The two halves meet through
-// v_permlane16_swap: one swap of (re, im) leaves the complete real part in the h = 0 row and the imaginary part in the
-// h = 1 row (a reduce-scatter), one more after the Horner update hands both to both rows, and the h = 1 row rotates
-// by 8 lanes (two 32-bit DPP moves per double).  49 vector instructions per product and chain.
+// Kernels.  The two chains of a member are independent until the gradient and run side by side (forward chain at slice i,
+// backward chain at slice N-1-i, one instruction stream).  A product is `v_fmac_f64 ... row_newbcast:j` -- the one DPP control
+// the FP64 ALU takes: src0 read from lane j of the 16-lane DPP row, at the plain FMA rate (tools/ubench/dpp_fmac.hip) -- so
+// the vector's entries never leave their lanes and there is no reduction tree.  How a 16 x 16 complex matrix is laid over the
+// wave decides what a product costs besides its FMACs:
+//   action_parts_kernel<false>  shared controls, n <= 16, one member per wave: DPP row = (direction, component of the result),
+//                               the lane holds a whole row; 32 FMACs + 7, one v_permlane16_swap (the default of C4)
+//   action_parts_kernel<true>   the same, two members per wave: DPP row = one chain, the lane computes both components;
+//                               64 FMACs + 8 per two members, no swap (ensembles beyond one member per SIMD)
+//   action_thin_kernel          per-member control operators (at most six): DPP row = (direction, column half), 32 FMACs + 18
+//   action_thin2_kernel         n = 17..32: a wave per member and direction, DPP row = 16 rows x one 16-column half, 64 FMACs + 18
+//   chain_prop_kernel           the propagators of the expm kernel instead of the series (ensembles of 80..239 members, and
+//                               on a chunked time axis down to one problem): one product per slice
+// One wave per SIMD issues one instruction of ANY kind every ~2.6 ns (tools/ubench/horner_step.hip): at C4's size these
+// kernels are counted in instructions, and their slice loops are written for that count.
 //
-// Inputs: a pre-pass (action_rows_kernel) forms, per slice and control array, the row-major images [Gc_t | Gc_t'] of
-// Gc_t = (-i dt) sum_c x[c,t] B_c and max(|Gc_t|_1, |Gc_t|_inf); the member's [A'_k | A'_k'] stays in registers.  A
-// lane's operands are 128 contiguous bytes per image.  The records v_0..v_N and w_0..w_N go to HBM element-major, and
-// action_forms_kernel -- one LANE per slice, fully parallel -- evaluates the bilinear forms of sweep_thin.hip,
+// Inputs: a pre-pass (action_rows_kernel) forms, per slice and control array, the images of Gc_t = (-i dt) sum_c x[c,t] B_c and
+// of Gc_t' -- laid out so that a wave-level load reads whole 256-byte runs -- and max(|Gc_t|_1, |Gc_t|_inf); the member's
+// [A'_k | A'_k'] stays in registers.  The records v_0..v_N and w_0..w_N go to HBM element-major, and the forms kernels --
+// one LANE per slice, fully parallel -- evaluate the bilinear forms of sweep_thin.hip,
 //     a = w_t' B_c v_t,  b = v_t' B_c w_t,  s = w_N' v_N,
 //     sandwich  g[c,t] = -dt Im(conj(s) a - s b),  F = 1 - (|s|^2 / n)^2;   left mult.  g[c,t] = -/+ 2 dt Im(a conj(s)), F = Re(conj(s)^2)
-// with the (member-invariant) B_c read through scalar loads.
+// with the (member-invariant) B_c read through scalar loads, (value, column) lists, or on the matrix cores.
 #include "grape_kernels.hpp"
 #include "cmat.hpp"
 #include "done_signal.hpp"

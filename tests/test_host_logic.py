@@ -103,12 +103,15 @@ def test_solution_save_and_load_round_trip(qoc, tmp_path):
     wl = qoc.workloads
     prob = qoc.Problem(B=[wl.Sx, wl.Sy], A=wl.Sz, Xi=wl.rho_init, Xt=wl.rho_fin, T=1.0, n_controls=2, guess=wl.controls(2, 10),
                        sys_type=qoc.StateTransfer())
-    sol = qoc.SolutionResult(object(), 0.7512, np.arange(20.0).reshape(2, 10), prob, qoc.GRAPE(n_slices=10, isinplace=False))
+    alg = qoc.GRAPE(n_slices=10, isinplace=False, optim_options={"iterations": 17, "g_tol": 1e-6, "line_search": "optim"},
+                    optimizer="device", device=0, devices=[0, 0], peer_sum=True)
+    sol = qoc.SolutionResult(object(), 0.7512, np.arange(20.0).reshape(2, 10), prob, alg)
     f = str(tmp_path / "sol.npz")
     qoc.save(sol, f)
     back = qoc.load(f)
     assert isinstance(back, qoc.SolutionResult) and back.result is None and back.fidelity == 0.7512
     assert np.array_equal(back.opti_pulses, sol.opti_pulses) and back.alg.n_slices == 10 and back.alg.isinplace is False
+    assert back.alg == alg                                   # every field of the alg struct survives the round trip
     assert np.array_equal(back.problem.A, wl.Sz) and np.array_equal(np.array(back.problem.B), np.array([wl.Sx, wl.Sy]))
     assert type(back.problem.sys_type).__name__ == "StateTransfer" and back.problem.T == 1.0
     ens = qoc.EnsembleProblem(prob=prob, n_ens=3, A_g=lambda k: k * wl.Sz, B_g=lambda k: [wl.Sx, wl.Sy],
