@@ -137,6 +137,29 @@ function fom_and_gradient!(ctx::GrapeContext, G, x::Matrix{Float64}; want_F = tr
     F[]
 end
 
+"The kernels the last evaluation launched, in launch order (grape_get_kernel_names, ABI v4)."
+function kernel_names(ctx::GrapeContext)
+    need = ccall((:grape_get_kernel_names, libgrape), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint), ctx.handle, C_NULL, 0)
+    need > 0 || return String[]
+    buf = Vector{UInt8}(undef, need)
+    ccall((:grape_get_kernel_names, libgrape), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint), ctx.handle, buf, need)
+    filter(!isempty, split(unsafe_string(pointer(buf)), ';'))
+end
+
+"""
+One process per GPU without librccl (ABI v4): `allgather` is any function that returns every rank's 64 bytes in rank
+order as one `Vector{UInt8}` (e.g. `h -> MPI.Allgather(h, comm)`).  Afterwards `fom_and_gradient!` on every rank returns
+the full-ensemble F and G: the ranks' rows meet in mailboxes in device memory (src/solve.jl:171-191's sum).
+"""
+function attach_ipc!(ctx::GrapeContext, rank::Integer, nranks::Integer, allgather)
+    h = Vector{UInt8}(undef, 64)
+    check(ctx, ccall((:grape_ipc_export, libgrape), Cint, (Ptr{Cvoid}, Cint, Ptr{UInt8}), ctx.handle, nranks, h))
+    all = allgather(h)
+    length(all) == 64 * nranks || error("attach_ipc!: allgather must return 64 * nranks bytes")
+    check(ctx, ccall((:grape_ipc_attach, libgrape), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), ctx.handle, all, rank, nranks))
+    ctx
+end
+
 # the (F, G, x) protocol of Optim.only_fg!, as in src/solve.jl:94-99 and :189-195
 function make_topt(ctx::GrapeContext)
     (F, G, x) -> begin
