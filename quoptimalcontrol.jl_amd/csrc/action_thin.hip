@@ -488,6 +488,10 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_parts_kernel(const T
     double2 *recp = rec + (d ? N - 1 : 1);
     const long rstep = d ? -1 : 1;
     auto fetch = [&](double (&nP)[16], double (&nQ)[16]) {
+#if defined(GRAPE_ACT_ABL) && (GRAPE_ACT_ABL & 1)                  // timing ablation (wrong results): no plane loads
+        if (N > 0 && gstep != 0 && lane >= 0)
+            return;
+#endif
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const double2 a = gpP[16 * j], b = gpQ[16 * j];
@@ -536,9 +540,10 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_parts_kernel(const T
             xi = other;
         }
     };
-    auto slice = [&](double (&P)[16], double (&Q)[16], double (&nP)[16], double (&nQ)[16]) {
+    auto slice = [&](double (&P)[16], double (&Q)[16], double (&nP)[16], double (&nQ)[16], const unsigned short *next_plan) {
         fetch(nP, nQ);
         const int m = __builtin_amdgcn_readfirstlane(plan & 31), pieces = __builtin_amdgcn_readfirstlane(plan >> 5);
+        plan = *next_plan;
         if (pieces == 1 && m <= 8) {                              // (every slice of a pulse whose |G_t| stays below 0.08)
             if (m >= 8) step(P, Q, 1.0 / 8, false);
             if (m >= 7) step(P, Q, 1.0 / 7, false);
@@ -556,26 +561,26 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_parts_kernel(const T
                 step(P, Q, inv_p, true);
             }
         }
+#if !(defined(GRAPE_ACT_ABL) && (GRAPE_ACT_ABL & 2))              // timing ablation: no record stores
         *recp = make_double2(xr, xi);
+#endif
         recp += rstep;
     };
     double P0[16], Q0[16], P1[16], Q1[16];
     fetch(P0, Q0);
     __builtin_amdgcn_s_waitcnt(0x0f70);
     build(P0, Q0);
+    // (the plan of slice t + 1 is read at the top of slice t: read where it is used, every slice waited ~50 ns for LDS)
+    plan = s_plan[0];
     int i = 0;
     for (; i + 2 <= N; i += 2) {
-        plan = s_plan[i];
-        slice(P0, Q0, P1, Q1);
+        slice(P0, Q0, P1, Q1, s_plan + i + 1);
         build(P1, Q1);
-        plan = s_plan[i + 1];
-        slice(P1, Q1, P0, Q0);
+        slice(P1, Q1, P0, Q0, s_plan + min(i + 2, N - 1));
         build(P0, Q0);
     }
-    if (i < N) {
-        plan = s_plan[i];
-        slice(P0, Q0, P1, Q1);
-    }
+    if (i < N)
+        slice(P0, Q0, P1, Q1, s_plan + i);
 }
 
 // n = 17..32: one wavefront per member AND direction (d = wave & 1; a workgroup = two members).  DPP row rho = 2 Rb + H holds in
@@ -666,9 +671,10 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_thin2_kernel(const T
         swap16(xr, xi);                                           // (R0 R2 R0 R2) = re of block H, (R1 R3 R1 R3) = im of block H
     };
     unsigned plan;
-    auto slice = [&](const double2 (&g)[16], double2 (&gnext)[16]) {
+    auto slice = [&](const double2 (&g)[16], double2 (&gnext)[16], const unsigned short *next_plan) {
         fetch(gnext);
         const int m = __builtin_amdgcn_readfirstlane(plan & 31), pieces = __builtin_amdgcn_readfirstlane(plan >> 5);
+        plan = *next_plan;
         if (pieces == 1 && m <= 8) {
             if (m >= 8) step(g, 1.0 / 8, false);
             if (m >= 7) step(g, 1.0 / 7, false);
@@ -693,19 +699,16 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_thin2_kernel(const T
     fetch(g0);
     __builtin_amdgcn_s_waitcnt(0x0f70);
     build(g0);
+    plan = s_plan[0];                                            // (the next slice's plan is read a slice ahead)
     int i = 0;
     for (; i + 2 <= N; i += 2) {
-        plan = s_plan[i];
-        slice(g0, g1);
+        slice(g0, g1, s_plan + i + 1);
         build(g1);
-        plan = s_plan[i + 1];
-        slice(g1, g0);
+        slice(g1, g0, s_plan + min(i + 2, N - 1));
         build(g0);
     }
-    if (i < N) {
-        plan = s_plan[i];
-        slice(g0, g1);
-    }
+    if (i < N)
+        slice(g0, g1, s_plan + i);
 }
 
 // The same two chains with the PROPAGATORS of the expm kernel (p.thin == 2: ensembles too small for the Taylor flow above --
