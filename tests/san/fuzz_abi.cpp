@@ -76,6 +76,11 @@ int main(int argc, char **argv)
     bad |= grape_get_info(nullptr, &inf) != GRAPE_ERR_INVALID_ARG;
     bad |= grape_comm_attach(nullptr, &id, 0, 1) != GRAPE_ERR_INVALID_ARG;
     bad |= grape_comm_unique_id(nullptr) != GRAPE_ERR_INVALID_ARG;
+    grape_ipc_handle ih;
+    char names[8];
+    bad |= grape_ipc_export(nullptr, 2, &ih) != GRAPE_ERR_INVALID_ARG;
+    bad |= grape_ipc_attach(nullptr, &ih, 0, 1) != GRAPE_ERR_INVALID_ARG;
+    bad |= grape_get_kernel_names(nullptr, names, 8) != GRAPE_ERR_INVALID_ARG;
     bad |= grape_lbfgs(nullptr, x, nullptr, G, nullptr) != GRAPE_ERR_INVALID_ARG;
     bad |= grape_abi_version() != GRAPE_ABI_VERSION;
     if (bad) { std::fprintf(stderr, "a null-argument call returned the wrong status\n"); return 3; }

@@ -12,6 +12,9 @@ hipError_t launch_reduce(const double *, const double *, double *, double *, int
 hipError_t launch_reduce_rows(const double *, double *, int, int, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
 hipError_t launch_copy(const double *, double *, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
 hipError_t launch_reduce_shards(const ShardRows &, double *, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
+hipError_t launch_shard_arrive(const ArriveParams &, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_ipc_allreduce(const IpcParams &, hipStream_t) { return hipErrorNoDevice; }
+size_t ipc_mailbox_bytes(int Q, int n_ranks) { const size_t Qpad = ((size_t)Q + 255) / 256 * 256; return 8 * 2 * (size_t)n_ranks * Qpad + 8 * 2 * (Qpad / 256); }
 int sweep_small_max_waves(int n) { return n == 2 ? 16 : (n == 3 ? 8 : (n == 4 ? 4 : 0)); }
 int sweep_pair_max_waves(int n) { return n == 2 ? 16 : (n == 4 ? 8 : 0); }
 size_t sweep_small_lds_bytes(int n, int MPB, int LT, int S, int K, bool x) { return 16 * (size_t)n * n * 32 + (x ? 8 * ((size_t)MPB * LT * ((size_t)S * K + 1) + MPB) : 0); }
