@@ -774,26 +774,37 @@ def main():
             extra["weak_scaling"] = {"error": repr(exc)}
 
     # ---- N > 1 with the RCCL exchange: the same strong-scaling step through the library's mailbox exchange (no RCCL), so that
-    # a multi-GPU run shows both side by side
-    if world > 1 and args.scaling == "strong" and not args.no_extra and args.collective == "lib":
-        try:
-            sg_i = sharded_engine(w, device, collective="ipc", flags=qoc.engine.FLAG_FORCE_GENERAL if args.force_general else 0)
-            if sg_i.collective == "ipc":
-                Gi = np.empty_like(xf)
-                bound_i = sg_i.local.bind_eval(xf, Gi)
-                for _ in range(min(args.warmup, 10)):
-                    bound_i()
-                ipc_s = statistics.median(time_blocks(bound_i, args.steps, args.blocks, barrier, reduce_max))
-                extra = dict(extra or {})
-                extra["ipc_exchange"] = {"value": args.steps / ipc_s, "unit": "gradient-evals/s", "ms_per_step": 1e3 * ipc_s / args.steps,
-                                         "what": "the same step with collective='ipc' (ipc_allreduce_kernel instead of ncclAllReduce + copy)"}
-            else:
-                extra = dict(extra or {})
-                extra["ipc_exchange"] = {"error": getattr(sg_i, "attach_error", "not attached")}
-            sg_i.close()
-        except Exception as exc:                   # noqa: BLE001 -- an extra must not kill the headline
-            extra = dict(extra or {})
-            extra["ipc_exchange"] = {"error": repr(exc)}
+    # a multi-GPU run shows both side by side.  It runs in a watched thread: the headline above is already measured, and
+    # a companion that gets stuck on hardware nobody has tried it on must not take the line with it (after 90 s the ranks
+    # print what they have and leave through os._exit).
+    companion_stuck = False
+    if world > 1 and args.scaling == "strong" and not args.no_extra and args.collective == "lib" \
+            and os.environ.get("GRAPE_BENCH_IPC_COMPANION", "1") != "0":
+        import threading
+        box = {}
+
+        def _companion():
+            try:
+                sg_i = sharded_engine(w, device, collective="ipc", flags=qoc.engine.FLAG_FORCE_GENERAL if args.force_general else 0)
+                if sg_i.collective == "ipc":
+                    Gi = np.empty_like(xf)
+                    bound_i = sg_i.local.bind_eval(xf, Gi)
+                    for _ in range(min(args.warmup, 10)):
+                        bound_i()
+                    ipc_s = statistics.median(time_blocks(bound_i, args.steps, args.blocks, barrier, reduce_max))
+                    box["res"] = {"value": args.steps / ipc_s, "unit": "gradient-evals/s", "ms_per_step": 1e3 * ipc_s / args.steps,
+                                  "what": "the same step with collective='ipc' (ipc_allreduce_kernel instead of ncclAllReduce + copy)"}
+                else:
+                    box["res"] = {"error": getattr(sg_i, "attach_error", "not attached")}
+                sg_i.close()
+            except Exception as exc:               # noqa: BLE001 -- an extra must not kill the headline
+                box["res"] = {"error": repr(exc)}
+        th = threading.Thread(target=_companion, daemon=True)
+        th.start()
+        th.join(90.0)
+        companion_stuck = th.is_alive()
+        extra = dict(extra or {})
+        extra["ipc_exchange"] = {"error": "did not finish within 90 s"} if companion_stuck else box.get("res", {"error": "no result"})
 
     if rank == 0:
         evals_per_s = args.steps / elapsed
@@ -871,6 +882,10 @@ def main():
     except Exception:                          # noqa: BLE001
         pass
     sys.stdout.flush()
+    if companion_stuck:                            # a thread of this process is wedged in a collective: no orderly teardown
+        if out is not None:
+            print(json.dumps(out if args.verbose else compact(out), separators=(",", ":")), flush=True)
+        os._exit(0)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
