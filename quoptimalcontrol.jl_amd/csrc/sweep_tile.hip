@@ -405,8 +405,8 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
         tload(Pm, Pk + (size_t)t_lo * TSZ, lane);
         for (int t = t_lo; t < t_hi; ++t) {
             tstore(Xk + (size_t)t * TSZ, X, lane);
-            if (t + 2 < t_hi)
-                tload(Pn, Pk + (size_t)(t + 1) * TSZ, lane);       // next slice's P in flight
+            tload(Pn, Pk + (size_t)min(t + 1, t_hi - 1) * TSZ, lane);   // next slice's P in flight (clamped, not branched round:
+                                                                        //  chain_tile_split_kernel's note)
             if (t + 1 < t_hi) {                                    // the state after the last slice is never read
                 to_a_layout(PA, Pm, s_img, lane);
                 if (SAND) {
@@ -445,9 +445,10 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
     tload(Pm, Pk + (size_t)(t_hi - 1) * TSZ, lane);
     tload(X, Xk + (size_t)(t_hi - 1) * TSZ, lane);
     for (int t = t_hi - 1; t >= t_lo; --t) {
-        if (t > t_lo) {                                            // next slice's P, X in flight
-            tload(Pn, Pk + (size_t)(t - 1) * TSZ, lane);
-            tload(Xn, Xk + (size_t)(t - 1) * TSZ, lane);
+        {                                                          // next slice's P, X in flight (clamped at the first slice)
+            const int tp = max(t - 1, t_lo);
+            tload(Pn, Pk + (size_t)tp * TSZ, lane);
+            tload(Xn, Xk + (size_t)tp * TSZ, lane);
         }
         if (SAND) {
             tmul_tn<NT, false, true>(Y, L, Pm);                    // (P' L)^T
@@ -548,6 +549,10 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
 // Nh balances the two waves' product counts.  When Xi, Xt are Hermitian (checked on the host; density
 // operators), X_t and L_t stay Hermitian under P X P' / P' L P, so [X, L'] = Y - Y' with Y = X L': the
 // second commutator product becomes one layout conversion (to_a_layout of Y IS the D layout of Y^T).
+// Round 4: every prefetch load is issued unconditionally with a CLAMPED slice index.  Behind `if (t + 1 < N) load` the
+// compiler's s_waitcnt pass must cover the path that issued nothing: at the join it waited for `vmcnt(7) .. vmcnt(0)` -- i.e.
+// for the prefetch it had just issued -- before the first product of every slice (wait_any 0.46 of the wave cycles in
+// profiles/r04_C4dense_E1024_pmc.json): the prefetch prefetched nothing.
 template <int SAND, bool SPARSE = false>
 __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams p)
 {
@@ -585,8 +590,7 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
         tload(Pm, Pk, lane);
         for (int t = 0; t < Nh; ++t) {
             tstore(Xk + (size_t)t * TSZ, X, lane);
-            if (t + 1 < Nh)
-                tload(Pn, Pk + (size_t)(t + 1) * TSZ, lane);
+            tload(Pn, Pk + (size_t)min(t + 1, Nh - 1) * TSZ, lane);   // (clamped, never branched round: see the note above the kernel)
             to_a_layout(PA, Pm, s_img, lane);
             if (SAND) {
                 tmul_tb<NT, false, false>(Y, X, PA);               // (P X)^T
@@ -610,8 +614,7 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
             tload(Pm, Pk + (size_t)Nh * TSZ, lane);
         for (int t = Nh; t < N; ++t) {
             tstore(Xk + (size_t)t * TSZ, V, lane);                 // V_{t-Nh}: X_t = V X_Nh V'
-            if (t + 1 < N)
-                tload(Pn, Pk + (size_t)(t + 1) * TSZ, lane);
+            tload(Pn, Pk + (size_t)min(t + 1, N - 1) * TSZ, lane);
             to_a_layout(PA, Pm, s_img, lane);
             tmul_an<NT, false, false>(Y, PA, V);                   // P V
             V = Y;
@@ -724,9 +727,10 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
             tload(Pm, Pk + (size_t)(N - 1) * TSZ, lane);
             tload(V, Xk + (size_t)(N - 1) * TSZ, lane);
             for (int t = N - 1; t >= Nh; --t) {
-                if (t > Nh) {                                      // next slice's P, V in flight
-                    tload(Pn, Pk + (size_t)(t - 1) * TSZ, lane);
-                    tload(Vn, Xk + (size_t)(t - 1) * TSZ, lane);
+                {                                                  // next slice's P, V in flight (clamped at the part's first slice)
+                    const int tp = max(t - 1, Nh);
+                    tload(Pn, Pk + (size_t)tp * TSZ, lane);
+                    tload(Vn, Xk + (size_t)tp * TSZ, lane);
                 }
                 pull_back();
                 if (t > Nh) {                                      // X_t = V X_Nh [V']
@@ -759,9 +763,10 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
             tload(X, Xk + (size_t)(Nh - 1) * TSZ, lane);
         }
         for (int t = Nh - 1; t >= 0; --t) {
-            if (t > 0) {
-                tload(Pn, Pk + (size_t)(t - 1) * TSZ, lane);
-                tload(Xn, Xk + (size_t)(t - 1) * TSZ, lane);
+            {
+                const int tp = max(t - 1, 0);
+                tload(Pn, Pk + (size_t)tp * TSZ, lane);
+                tload(Xn, Xk + (size_t)tp * TSZ, lane);
             }
             pull_back();
             emit(t);
