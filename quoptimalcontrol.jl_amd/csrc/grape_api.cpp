@@ -1793,9 +1793,7 @@ static int enqueue_ipc_allreduce(grape_ctx *c, const double *row, double *out, h
     ip.rank = c->comm_rank;
     ip.n_ranks = c->ipc_ranks;
     ip.parity = (int)(c->ipc_evals & 1);
-    c->ipc_evals += 1;
-    c->ipc_count[ip.parity] += 1;
-    ip.target = (unsigned long long)c->ipc_ranks * c->ipc_count[ip.parity];
+    ip.target = (unsigned long long)c->ipc_ranks * (c->ipc_count[ip.parity] + 1);
     for (int j = 0; j < c->ipc_ranks; ++j) ip.mbox[j] = c->ipc_mbox[j];
     // a poll is an s_sleep of ~2 k cycles (~1 us): give up after the context's timeout, 5 s at least / 120 s at most
     const double lim = std::min(120.0, std::max(5.0, c->timeout_s));
@@ -1804,6 +1802,8 @@ static int enqueue_ipc_allreduce(grape_ctx *c, const double *row, double *out, h
     ip.done = done;
     if (grape::launch_ipc_allreduce(ip, stream) != hipSuccess)
         return fail(c, GRAPE_ERR_HIP, "ipc_allreduce_kernel: launch failed");
+    c->ipc_evals += 1;                                       // (counted once the exchange is in the stream: the peers count launches too)
+    c->ipc_count[ip.parity] += 1;
     return GRAPE_OK;
 }
 
