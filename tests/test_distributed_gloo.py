@@ -131,3 +131,62 @@ def test_unique_id_broadcast_reaches_the_other_rank(tmp_path):
     out = str(tmp_path / "tok.bin")
     mp.spawn(_bcast_worker, args=(2, 29600 + (os.getpid() + 173) % 300, out), nprocs=2, join=True)
     assert open(out, "rb").read() == bytes(range(128))
+
+
+class MailboxLocal(OracleLocal):
+    """a stand-in with the ipc_export / ipc_attach pair: records what the wiring hands it.  `fail_on`: the rank whose attach
+    raises (a peer's handle it cannot open)."""
+    fail_on = -1
+
+    def ipc_export(self, n_ranks):
+        self.exported = n_ranks
+        return bytes([self.lo % 251]) * 64
+
+    def ipc_attach(self, handles, rank, n_ranks):
+        self.handles = list(handles)
+        if rank == MailboxLocal.fail_on:
+            raise RuntimeError("cannot open a peer's mailbox")
+
+    @property
+    def info(self):
+        return {"comm_size": self.exported}
+
+
+def _ipc_worker(rank, world, port, E, out, fail_on):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import quoptimalcontrol_jl_amd as qoc
+    from quoptimalcontrol_jl_amd.distributed import ShardedGrape
+    MailboxLocal.fail_on = fail_on
+    w = qoc.workloads.config("C3", E=E, N=30)
+    res = {"rank": rank}
+    try:
+        sg = ShardedGrape(w.E, w.K, w.N, lambda lo, hi: MailboxLocal(w, lo, hi, w.K, w.N), torch.device("cpu"), collective="ipc")
+        res["collective"] = sg.collective
+        if sg.local is not None and hasattr(sg.local, "handles"):
+            res["handles"] = [h[0] for h in sg.local.handles]          # every rank's 64 bytes, in rank order
+    except RuntimeError as exc:
+        res["raised"] = str(exc)
+    np.save(f"{out}.{rank}.npy", np.array([repr(res)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("E,world,fail_on", [(6, 2, -1), (9, 3, -1), (1, 2, -1), (6, 2, 1)])
+def test_mailbox_handles_are_all_gathered_and_every_step_is_agreed(tmp_path, qoc, E, world, fail_on):
+    """collective='ipc' on the CPU control plane: every rank's 64-byte handle reaches every rank in rank order; a rank without
+    members sends everybody to the torch fallback before anything is exported; a rank whose attach fails takes the whole group down with
+    the same error on every rank (the contexts that did attach expect their peers at every evaluation)."""
+    out = str(tmp_path / "ipc")
+    mp.spawn(_ipc_worker, args=(world, 29600 + (os.getpid() + 37 * E + world) % 300, E, out, fail_on), nprocs=world, join=True)
+    res = [eval(str(np.load(f"{out}.{r}.npy")[0])) for r in range(world)]      # noqa: S307 -- our own repr of a dict
+    per = -(-E // world)
+    if E < world:
+        assert all(r["collective"] == "torch" and "handles" not in r for r in res)
+    elif fail_on >= 0:
+        assert all("raised" in r for r in res)                      # nobody carries on alone
+        assert "this rank" in res[fail_on]["raised"] and all("another rank" in r["raised"] for i, r in enumerate(res) if i != fail_on)
+    else:
+        assert all(r["collective"] == "ipc" for r in res)
+        want = [(i * per) % 251 for i in range(world)]
+        assert all(r["handles"] == want for r in res)
