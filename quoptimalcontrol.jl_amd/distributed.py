@@ -128,6 +128,73 @@ class ShardedGrape:
             raise RuntimeError("grape_ipc_attach failed on " + ("this rank: " + self.attach_error if not ok else "another rank") +
                                "; rebuild the engines with collective='torch' (or 'lib')")
 
+    def _attach_library_communicator(self):
+        """Every rank joins an RCCL communicator owned by libgrape_hip.so; all ranks agree on the
+        outcome (one failed rank sends everybody to the torch.distributed fallback)."""
+        torch, dist = self.torch, self.dist
+
+        def agree(flag_value):
+            """MIN over the ranks of a 0/1 flag (every rank calls it at the same point)."""
+            if not (self.distributed and self.world > 1):
+                return flag_value
+            flag = torch.tensor([flag_value], dtype=torch.int32)
+            if "gloo" not in dist.get_backend(self.group):
+                flag = flag.to(self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return int(flag.item())
+
+        # 1. feasibility, agreed BEFORE any broadcast or attach: a rank without members (E = 5 on 4 ranks, E < world)
+        #    or without a library evaluator cannot join, and the others must not wait in ncclCommInitRank for it
+        can = int(self.local is not None and hasattr(self.local, "comm_attach"))
+        if not can:
+            self.attach_error = "this rank owns no members (E < world size) or its evaluator has no comm_attach"
+        if not agree(can):
+            ok = 0
+            if can:
+                self.attach_error = "another rank cannot join the library communicator"
+        else:
+            # 2. every rank can: rank 0's unique id to everybody, then ncclCommInitRank on every rank
+            ok, stuck = 1, False
+            try:
+                token = self.local.comm_unique_id() if self.rank == 0 else None
+                if self.distributed and self.world > 1:
+                    token = _bcast_bytes(dist, token, 128, self.group)
+                # ncclCommInitRank blocks until every rank has joined; should the bootstrap wedge (no route between
+                # ranks, a rank that died), do not hang the job: give up after attach_timeout_s
+                import threading
+                box = {}
+
+                def _attach():
+                    try:
+                        self.local.comm_attach(token, self.rank, self.world)
+                        box["ok"] = True
+                    except Exception as exc:          # noqa: BLE001
+                        box["err"] = exc
+                th = threading.Thread(target=_attach, daemon=True)
+                th.start()
+                th.join(self.attach_timeout_s)
+                if th.is_alive():
+                    stuck = True
+                    raise TimeoutError(f"grape_comm_attach did not return within {self.attach_timeout_s} s")
+                if "err" in box:
+                    raise box["err"]
+            except Exception as exc:                  # noqa: BLE001 -- any failure means "fall back", consistently
+                self.attach_error = repr(exc)
+                ok = 0
+            ok = agree(ok)
+            any_stuck = not agree(0 if stuck else 1)  # agreed as well: the job fails collectively, nobody half-continues
+            if any_stuck:
+                # the abandoned thread is still inside ncclCommInitRank ON THAT RANK'S CONTEXT and may complete later: a
+                # context that can grow a communicator behind our back must not evaluate (one-sided all-reduce), and the
+                # other ranks must not walk into a fallback collective that the stuck rank will never join
+                raise RuntimeError("grape_comm_attach timed out on " + ("this rank" if stuck else "another rank") +
+                                   "; every rank aborts instead of evaluating: " + getattr(self, "attach_error", ""))
+        if ok:
+            self.collective = "lib"
+            self.comm_size = self.local.info["comm_size"]
+        else:
+            self._probe_torch_group()
+
     def _probe_torch_group(self):
         """The torch.distributed fallback on a gloo control plane: give the data path its own RCCL group (torch's) and PROBE it --
         RCCL refuses, at the first collective, ranks that share a GPU; all ranks then agree to stage through the host."""
