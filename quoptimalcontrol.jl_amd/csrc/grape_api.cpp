@@ -1996,8 +1996,19 @@ static int wait_flag(grape_ctx *s)
         if ((it & 1023) != 1023) continue;
         const double el = elapsed();
         if (el < spin_until) continue;                      // spin phase
-        const hipError_t q = hipStreamQuery(s->stream);     // a failed kernel never publishes: ask the runtime
+        hipError_t q = hipStreamQuery(s->stream);           // a failed kernel never publishes: ask the runtime
         if (q != hipSuccess && q != hipErrorNotReady) HIP_TRY(s, q);
+        if (q == hipSuccess && s->group && s->group->peer_all && *flag != want) {
+            // arrive-and-sum: the LAST shard to arrive publishes, from its own stream -- this one being idle says nothing
+            // before every other shard's stream is idle too
+            for (grape_ctx *o : s->group->sub) {
+                if (o == s) continue;
+                const hipError_t qo = hipStreamQuery(o->stream);
+                if (qo != hipSuccess && qo != hipErrorNotReady) HIP_TRY(s, qo);
+                if (qo == hipErrorNotReady) { q = qo; break; }
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
         if (q == hipSuccess && *flag != want)
             return fail(s, GRAPE_ERR_HIP, "evaluation finished without publishing its completion flag");
         if (el > s->timeout_s)

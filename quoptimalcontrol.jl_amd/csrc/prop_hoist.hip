@@ -305,30 +305,35 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
     const int t_lo = FUSE ? 0 : blockIdx.x * p.prop_slices;
     const int t_hi = FUSE ? p.N : min(p.N, t_lo + p.prop_slices);
     int t = t_lo + wave;
+    // The loop is ROTATED (see prop_hoist2_kernel): the next slice's generator is formed at the END of the body, where the
+    // wait for its loads has one history -- the loads, then this slice's stores -- and is counted; at the top of the body it
+    // also covered the entry path, whose loads are the last vector-memory operations, and waited for the stores' acks.
     d2v gnext[4];
-    if (HOIST && t < t_hi) {
-        const gcptr g0 = gc + (size_t)t * TSZ;
+    double bnext = 0.0;                                            // HOIST: the next slice's norm bound, FIRST of its prefetch
+    d4 Gre, Gim;
+    double bound = 0.0;
+    auto prefetch = [&](int tn) {
+        if (!HOIST) return;
+        const gcptr g1 = gc + (size_t)tn * TSZ;
+        bnext = gcn[tn];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            gnext[r] = g0[r * 64 + lane];
-    }
-    for (; t < t_hi; t += WPB) {
-        rotate_priority();
-        d4 Gre, Gim;
-        double bound;
+            gnext[r] = g1[r * 64 + lane];
+    };
+    auto form_generator = [&](int tn) {
         if (HOIST) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 Gre[r] = Are[r] + gnext[r][0];
                 Gim[r] = Aim[r] + gnext[r][1];
             }
-            bound = nA + gcn[t];
+            bound = nA + bnext;
         } else {
             Gre = Are;
             Gim = Aim;
             bound = nA;
             for (int c = 0; c < K; ++c) {
-                const double xv = xz[c + (size_t)t * K], sx = p.dt * xv;
+                const double xv = xz[c + (size_t)tn * K], sx = p.dt * xv;
                 bound = fma(fabs(xv), p.ha_norm[(size_t)k * nstride + 1 + c], bound);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -338,6 +343,13 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
                 }
             }
         }
+    };
+    if (t < t_hi) {
+        prefetch(t);
+        form_generator(t);
+    }
+    for (; t < t_hi; t += WPB) {
+        rotate_priority();
         const int s = p.s_forced >= 0 ? p.s_forced : squarings_from_ratio(bound);          // bounds are stored / theta8
         if (s > 0) {
             const double sc = ldexp(1.0, -s);
@@ -376,6 +388,10 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
             Pim[r] = fma(kX2, Pim[r], fma(kY2, A2im[r], Gim[r]));
             Pre[r] = add_masked(Pre[r], 1.0, dmask[r]);
         }
+        // the next slice's control sum: in flight during the squarings (G, A2 and A4' are dead by now), the conversions, the
+        // hand-over and the stores below
+        const int tn = min(t + WPB, t_hi - 1);                     // (clamped: no branch around the loads)
+        prefetch(tn);
         for (int i = 0; i < s; ++i) {
             img_write_tile(wr, Pre, Pim, i > 0);
             img_read_tile(opa, rd);
@@ -389,13 +405,6 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
         const bool transposed = p.thin == 1 && (t & 1);
         const gptr dst = props + (size_t)t * TSZ;
         img_write_tile(wr, Pre, Pim, s > 0);
-        if (HOIST) {   // the next slice's control sum: in flight during the conversions, the hand-over and the stores below
-            const int tn = min(t + WPB, t_hi - 1);                 // (clamped: no branch around the loads)
-            const gcptr g1 = gc + (size_t)tn * TSZ;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                gnext[r] = g1[r * 64 + lane];
-        }
         if (!transposed) {
             AOp pk;
             img_read_rows(pk, wr);
@@ -446,6 +455,7 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
                     V[(size_t)p.N * 16 + c] = (d2v){acc[0], acc[1]};
             }
         }
+        form_generator(tn);
     }
 }
 
@@ -605,26 +615,31 @@ __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
     const double *__restrict__ xz = p.x + (size_t)z * K * p.N;
     const gptr props = uniform_global(p.props + ((size_t)z * p.E + k) * (size_t)p.N * TSZ + tile * 256);
     const int t_lo = blockIdx.x * p.prop_slices, t_hi = min(p.N, t_lo + p.prop_slices);
+    // The loop is ROTATED: slice t + 1's generator tile G (and its norm bound) is formed at the END of slice t's body, from
+    // loads issued before slice t's squarings.  Its s_waitcnt then sits in one place with one history -- eight loads, then
+    // P_t's four stores -- and waits with vmcnt(4); formed at the top of the body (rounds 2-3) the same wait had to cover
+    // the entry path too, whose loads are the LAST vector-memory operations, and waited with vmcnt(0): for the stores' acks.
     d2v gnext[4], anext[4];
-    if (t_lo < t_hi) {
-        const gcptr g0 = gc + (size_t)t_lo * TSZ;
+    double bnext = 0.0;                                            // HOIST: the next slice's norm bound, FIRST of its prefetch
+    Tile3 G;
+    double bound = 0.0;
+    auto prefetch = [&](int tn) {
+        const gcptr g1 = gc + (size_t)tn * TSZ;
+        if (HOIST) bnext = gcn[tn];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (HOIST) gnext[r] = g0[r * 64 + lane];
+            if (HOIST) gnext[r] = g1[r * 64 + lane];
             anext[r] = ha[r * 64 + lane];
         }
-    }
-    for (int t = t_lo; t < t_hi; ++t) {
-        rotate_priority();
-        Tile3 G;
-        double bound;
+    };
+    auto form_generator = [&](int tn) {
         if (HOIST) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 G.re[r] = anext[r][0] + gnext[r][0];
                 G.im[r] = anext[r][1] + gnext[r][1];
             }
-            bound = nA + gcn[t];
+            bound = nA + bnext;
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -633,7 +648,7 @@ __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
             }
             bound = nA;
             for (int c = 0; c < K; ++c) {
-                const double xv = xz[c + (size_t)t * K], sx = p.dt * xv;
+                const double xv = xz[c + (size_t)tn * K], sx = p.dt * xv;
                 bound = fma(fabs(xv), p.ha_norm[(size_t)k * nstride + 1 + c], bound);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -643,6 +658,13 @@ __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
                 }
             }
         }
+    };
+    if (t_lo < t_hi) {
+        prefetch(t_lo);
+        form_generator(t_lo);
+    }
+    for (int t = t_lo; t < t_hi; ++t) {
+        rotate_priority();
         const int s = p.s_forced >= 0 ? p.s_forced : squarings_from_ratio(bound);
         if (s > 0) {
             const double sc = ldexp(1.0, -s);
@@ -711,6 +733,11 @@ __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
             P.im[r] = fma(kX2, P.im[r], fma(kY2, A2im[r], G.im[r]));
             P.re[r] = add_masked(P.re[r], 1.0, dmask[r]);
         }
+        // ---- next slice's control sum in flight BEFORE the squarings (G, A2 and A4' are dead by now: the 32 registers cost
+        //      nothing; behind the squarings -- rounds 2-3 -- the loads were issued ~40 instructions ahead of their first use).
+        //      The bound goes first: loads return in order.
+        const int tn = min(t + 1, t_hi - 1);
+        prefetch(tn);
         for (int i = 0; i < s; ++i) {                              // P <- P P
             P.sm = P.re + P.im;
             __builtin_amdgcn_sched_barrier(0);
@@ -726,17 +753,8 @@ __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
             P.re = Q.re;
             P.im = Q.im;
         }
-        // ---- next slice's control sum in flight; P_t's tile packed through the wave's own region of image Y (nobody reads
-        //      image Y before the next slice's second product) and stored
-        {
-            const int tn = min(t + 1, t_hi - 1);
-            const gcptr g1 = gc + (size_t)tn * TSZ;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (HOIST) gnext[r] = g1[r * 64 + lane];
-                anext[r] = ha[r * 64 + lane];
-            }
-        }
+        // ---- P_t's tile packed through the wave's own region of image Y (nobody reads image Y before the next slice's
+        //      second product) and stored
         if (s > 0)
             asm volatile("s_nop 15\n\ts_nop 2" ::: "memory");      // P.im is a raw MFMA result after a squaring
         {
@@ -757,6 +775,7 @@ __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
             for (int r = 0; r < 4; ++r)
                 dst[r * 64 + lane] = pk.v[r];
         }
+        form_generator(tn);
     }
 }
 

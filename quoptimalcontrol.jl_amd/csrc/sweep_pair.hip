@@ -597,6 +597,12 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
         } else {
             pload_ws(PA, Pw + (size_t)(S - 1) * NN * stride, stride, par);
         }
+        // (Round 4, ISA: the compiler's s_waitcnt pass waits with vmcnt(0) in front of BOTH steps -- for the prefetch it has
+        // just issued -- because the second load sits behind `if (j >= 2)` and PA enters the loop from LDS on one path and
+        // from HBM on the other.  With both removed the waits are counted, vmcnt(15) .. vmcnt(8), the two buffers really
+        // overlap -- and the kernel is 3 us SLOWER (74.3 vs 71.4 us, build/abl variants pd0..pd3, profiles/r04_C3_phaseD.txt):
+        // sixteen 1 KB loads in flight per wave instead of eight, 128 KB per CU against a 32 KB L1.  The drain is what
+        // paces phase D at the rate HBM delivers; left as it was.)
         int j = S - 1;
         for (; j >= 1; j -= 2) {
             if (!(GRAPE_ABL & 8)) pload_ws(PB, Pw + (size_t)(j - 1) * NN * stride, stride, par);
