@@ -553,28 +553,36 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
 // compiler's s_waitcnt pass must cover the path that issued nothing: at the join it waited for `vmcnt(7) .. vmcnt(0)` -- i.e.
 // for the prefetch it had just issued -- before the first product of every slice (wait_any 0.46 of the wave cycles in
 // profiles/r04_C4dense_E1024_pmc.json): the prefetch prefetched nothing.
-template <int SAND, bool SPARSE = false>
-__global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams p)
+// Round 4: PARTS wavefronts per member (2, or 3 behind GRAPE_TILE_PARTS=3: measured slower, see the launcher; parts
+// 1 .. PARTS-1 all play the second wave's role, each over its own range [part_lo[q], part_lo[q + 1]) of the time axis).
+// The exchange goes through the waves' own
+// LDS images (nobody converts a layout between the two workgroup barriers around it):
+//   wave 0 -> X at part_lo[1];  wave q >= 1 -> T_q = the product of its part's propagators;
+//   wave q >= 1 then rebuilds X at part_lo[q] = T_{q-1} .. T_1 X [T_1' .. T_{q-1}'] and, every wave, the costate at the
+//   end of its part = T_{q+1}' .. T_{PARTS-1}' Xt [T_{PARTS-1} .. T_{q+1}]  -- at most 2 (PARTS - 2) + 2 (PARTS - 1) products.
+template <int SAND, bool SPARSE = false, int PARTS = 2>
+__global__ __launch_bounds__(64 * PARTS, PARTS) void chain_tile_split_kernel(const TileParams p)
 {
     constexpr int NT = 1, TSZ = 256;
     extern __shared__ double2 s_dynt[];
-    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double2 *s_img = s_dynt + (size_t)half * (kTileImage + 1);
-    double2 *s_xch = s_dynt + 2 * (kTileImage + 1);                // [0..255] X_Nh (wave 0), [256..511] T1 (wave 1)
-    double2 *s_bt = s_xch + 512;                                   // SPARSE: coefficients | two images of R | positions
+    const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double2 *s_img = s_dynt + (size_t)part * (kTileImage + 1);
+    auto xch = [&](int q) { return s_dynt + (size_t)q * (kTileImage + 1); };   // wave q's image, lent for the exchange
+    double2 *s_bt = s_dynt + (size_t)PARTS * (kTileImage + 1);     // SPARSE: coefficients | one image of R per wave | positions
     double2 *s_coef = s_bt;
-    double2 *s_M = s_coef + (size_t)p.K * p.sp_nz + (size_t)half * (16 * 17);
-    int *s_addr = reinterpret_cast<int *>(s_coef + (size_t)p.K * p.sp_nz + 2 * (16 * 17));
+    double2 *s_M = s_coef + (size_t)p.K * p.sp_nz + (size_t)part * (16 * 17);
+    int *s_addr = reinterpret_cast<int *>(s_coef + (size_t)p.K * p.sp_nz + PARTS * (16 * 17));
     const int k = blockIdx.x;
-    const int K = p.K, N = p.N, Nh = p.split_at;
+    const int K = p.K, N = p.N;
+    const int lo = p.part_lo[part], hi = p.part_lo[part + 1];      // this wave's slices
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
     const double2 *__restrict__ opBT = ops + (size_t)(1 + K) * TSZ;
     const bool bt_lds = p.bt_in_lds != 0;
     const bool herm = SAND && p.herm_states != 0;
     if (SPARSE) {
-        stage_sparse_lists<NT>(p, k, (int)threadIdx.x, 128, s_coef, s_addr);
+        stage_sparse_lists<NT>(p, k, (int)threadIdx.x, 64 * PARTS, s_coef, s_addr);
     } else if (bt_lds) {
-        for (int i = threadIdx.x; i < K * TSZ; i += 128)
+        for (int i = threadIdx.x; i < K * TSZ; i += 64 * PARTS)
             s_bt[i] = opBT[i];
     }
     const size_t kw = (size_t)blockIdx.y * p.E + k;                // workspace row: (control array, member)
@@ -583,14 +591,15 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
     double *__restrict__ out = p.member_out + kw * ((size_t)K * N + 1);
 
     // ------------------------------------------------------------ pass 1
-    if (half == 0) {
+    TMat<1> keep;                                                  // what this wave hands over: X at hi (wave 0), T_part (others)
+    if (part == 0) {
         TMat<1> X, Pm, Pn, Y;
         TOp<1> PA;
         tload(X, ops + (size_t)(1 + 2 * K) * TSZ, lane);           // Xi
         tload(Pm, Pk, lane);
-        for (int t = 0; t < Nh; ++t) {
+        for (int t = 0; t < hi; ++t) {
             tstore(Xk + (size_t)t * TSZ, X, lane);
-            tload(Pn, Pk + (size_t)min(t + 1, Nh - 1) * TSZ, lane);   // (clamped, never branched round: see the note above the kernel)
+            tload(Pn, Pk + (size_t)min(t + 1, hi - 1) * TSZ, lane);   // (clamped, never branched round: see the note above the kernel)
             to_a_layout(PA, Pm, s_img, lane);
             if (SAND) {
                 tmul_tb<NT, false, false>(Y, X, PA);               // (P X)^T
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
             }
             Pm = Pn;
         }
-        tstore(s_xch, X, lane);                                    // X_Nh
+        keep = X;
     } else {
         TMat<1> V, Pm, Pn, Y;
         TOp<1> PA;
@@ -610,28 +619,39 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
         for (int r = 0; r < 4; ++r)
             if (4 * r + (lane >> 4) == (lane & 15))
                 V.re[0][0][r] = 1.0;
-        if (Nh < N)
-            tload(Pm, Pk + (size_t)Nh * TSZ, lane);
-        for (int t = Nh; t < N; ++t) {
-            tstore(Xk + (size_t)t * TSZ, V, lane);                 // V_{t-Nh}: X_t = V X_Nh V'
-            tload(Pn, Pk + (size_t)min(t + 1, N - 1) * TSZ, lane);
+        if (lo < hi)
+            tload(Pm, Pk + (size_t)lo * TSZ, lane);
+        for (int t = lo; t < hi; ++t) {
+            tstore(Xk + (size_t)t * TSZ, V, lane);                 // V_{t-lo}: X_t = V X_lo V'
+            tload(Pn, Pk + (size_t)min(t + 1, hi - 1) * TSZ, lane);
             to_a_layout(PA, Pm, s_img, lane);
             tmul_an<NT, false, false>(Y, PA, V);                   // P V
             V = Y;
             Pm = Pn;
         }
-        tstore(s_xch + 256, V, lane);                              // T1
+        keep = V;
     }
+    tstore(s_img, keep, lane);                                     // (its own image: this wave's conversions are behind it)
     __syncthreads();
 
     // ------------------------------------------------------------ pass 2: backward sweep + gradient
     const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
-    TMat<1> L, Pm, Pn, X, Xn, Y, R;
+    TMat<1> L, Pm, X, Y, R;
     TOp<1> XA, LA;
     bool z_known = false;
     double z_keep_r = 0.0, z_keep_i = 0.0;
     // gradient entries + figure of merit of one slice from X_t, L_t (costate after pulling back through slice t)
     auto emit = [&](int t) {
+        if (SPARSE && !z_known) {
+            // tr(X_t' L_t) is the same for every t (also for non-unitary P): taken at the first slice this wave emits --
+            // and BEFORE the conversions, so that X is dead once its A-operand image exists
+            double zz[2];
+            tdot_partial<NT, true>(zz[0], zz[1], X, L);
+            wave_sum_n(zz);
+            z_keep_r = zz[0];
+            z_keep_i = zz[1];
+            z_known = true;
+        }
         to_a_layout(XA, X, s_img, lane);
         to_a_layout(LA, L, s_img, lane);
         tprod<NT, false, true>(
@@ -654,18 +674,13 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
         }
         double zr = 0.0, zi = 0.0;
         if (SPARSE) {
-            // tr(X_t' L_t) is the same for every t (also for non-unitary P): taken at the first slice this wave emits
-            if (!z_known) {
-                double zz[2];
-                tdot_partial<NT, true>(zz[0], zz[1], X, L);
-                wave_sum_n(zz);
-                z_keep_r = zz[0];
-                z_keep_i = zz[1];
-                z_known = true;
-            }
             zr = z_keep_r;
             zi = z_keep_i;
-            sparse_traces<NT, SAND>(R, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane, true, p.sp_nz);
+            // (the lane number behind an empty asm: the per-lane addresses of the entry lists are recomputed here, a dozen
+            // vector instructions, instead of being hoisted out of the slice loop and spilled to scratch at 168 registers)
+            int lane_here = lane;
+            asm volatile("" : "+v"(lane_here));
+            sparse_traces<NT, SAND>(R, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane_here, true, p.sp_nz);
         } else
         for (int c0 = 0; c0 < K || c0 == 0; c0 += 4) {
             double v[2 + 8];
@@ -718,60 +733,75 @@ __global__ __launch_bounds__(128) void chain_tile_split_kernel(const TileParams 
             L = Y;
         }
     };
-    if (half == 1) {
-        if (Nh < N) {
-            TMat<1> Xh, V, Vn;
-            TOp<1> VA;
-            tload(Xh, s_xch, lane);                                // X_Nh
-            tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);       // Xt
-            tload(Pm, Pk + (size_t)(N - 1) * TSZ, lane);
-            tload(V, Xk + (size_t)(N - 1) * TSZ, lane);
-            for (int t = N - 1; t >= Nh; --t) {
-                {                                                  // next slice's P, V in flight (clamped at the part's first slice)
-                    const int tp = max(t - 1, Nh);
-                    tload(Pn, Pk + (size_t)tp * TSZ, lane);
-                    tload(Vn, Xk + (size_t)tp * TSZ, lane);
-                }
+    // ---- the exchange: every operand is copied out of the lent images BEFORE the barrier that gives them back
+    TMat<1> Xh;                                                    // parts >= 1: X at lo
+    {
+        TMat<1> T[PARTS > 1 ? PARTS - 1 : 1];                      // T_1 .. T_{PARTS-1}
+        tload(Xh, xch(0), lane);
+#pragma unroll
+        for (int q = 1; q < PARTS; ++q)
+            tload(T[q - 1], xch(q), lane);
+        tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);           // Xt
+        __syncthreads();                                           // the images are the waves' own again
+#pragma unroll
+        for (int q = PARTS - 1; q >= 1; --q)                       // costate at hi: through every later part
+            if (q > part) {
+                Pm = T[q - 1];
                 pull_back();
-                if (t > Nh) {                                      // X_t = V X_Nh [V']
+            }
+#pragma unroll
+        for (int q = 1; q < PARTS - 1; ++q)                        // X at lo: through every earlier part but the first
+            if (q < part) {
+                TOp<1> VA;
+                to_a_layout(VA, T[q - 1], s_img, lane);
+                if (SAND) {
+                    tmul_tb<NT, false, false>(Y, Xh, VA);
+                    tmul_tb<NT, false, true>(X, Y, VA);
+                    Xh = X;
+                } else {
+                    tmul_an<NT, false, false>(X, VA, Xh);
+                    Xh = X;
+                }
+            }
+    }
+    // (No second register buffer in these loops -- three waves per SIMD leave 168 registers: slice t's state is loaded at the
+    // top of its iteration and arrives under the two products of the pull-back; P_{t-1} goes into Pm as soon as the pull-back
+    // has read P_t, and arrives under the products of the rebuild and the gradient.)
+    if (part >= 1) {
+        if (lo < hi) {
+            // X_lo lives in the workspace slot of V_0 (the identity: never needed) and is re-read from L2 with every slice's
+            // V_j -- sixteen registers less across the gradient's products
+            tstore(Xk + (size_t)lo * TSZ, Xh, lane);
+            TMat<1> V, X0;
+            TOp<1> VA;
+            tload(Pm, Pk + (size_t)(hi - 1) * TSZ, lane);
+            for (int t = hi - 1; t >= lo; --t) {
+                tload(V, Xk + (size_t)t * TSZ, lane);
+                tload(X0, Xk + (size_t)lo * TSZ, lane);
+                pull_back();
+                tload(Pm, Pk + (size_t)max(t - 1, lo) * TSZ, lane);   // (clamped at the part's first slice: no branch round a load)
+                if (t > lo) {                                      // X_t = V X_lo [V']
                     to_a_layout(VA, V, s_img, lane);
                     if (SAND) {
-                        tmul_tb<NT, false, false>(Y, Xh, VA);      // (V X_Nh)^T
-                        tmul_tb<NT, false, true>(X, Y, VA);        // (V X_Nh) V'
+                        tmul_tb<NT, false, false>(Y, X0, VA);      // (V X_lo)^T
+                        tmul_tb<NT, false, true>(X, Y, VA);        // (V X_lo) V'
                     } else {
-                        tmul_an<NT, false, false>(X, VA, Xh);
+                        tmul_an<NT, false, false>(X, VA, X0);
                     }
                 } else {
-                    X = Xh;
+                    X = X0;
                 }
                 emit(t);
-                Pm = Pn;
-                V = Vn;
             }
         }
     } else {
-        {                                                          // L_Nh = T1' Xt [T1]
-            TMat<1> T1;
-            tload(T1, s_xch + 256, lane);
-            tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);       // Xt
-            Pm = T1;
-            if (Nh < N)
-                pull_back();
-        }
-        if (Nh > 0) {
-            tload(Pm, Pk + (size_t)(Nh - 1) * TSZ, lane);
-            tload(X, Xk + (size_t)(Nh - 1) * TSZ, lane);
-        }
-        for (int t = Nh - 1; t >= 0; --t) {
-            {
-                const int tp = max(t - 1, 0);
-                tload(Pn, Pk + (size_t)tp * TSZ, lane);
-                tload(Xn, Xk + (size_t)tp * TSZ, lane);
-            }
+        if (hi > 0)
+            tload(Pm, Pk + (size_t)(hi - 1) * TSZ, lane);
+        for (int t = hi - 1; t >= 0; --t) {
+            tload(X, Xk + (size_t)t * TSZ, lane);
             pull_back();
+            tload(Pm, Pk + (size_t)max(t - 1, 0) * TSZ, lane);
             emit(t);
-            Pm = Pn;
-            X = Xn;
         }
     }
 }
@@ -1407,23 +1437,49 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         // one member per wave would leave every SIMD with a single wave: two waves per member, each owning a
         // part of the time axis, split so that their product counts balance (see chain_tile_split_kernel)
         const int c0 = sandwich ? (p.herm_states ? 5 : 6) : 3, c1 = c0 + 1;
-        q.split_at = (int)(((long long)p.N * c1 + (c0 + c1) / 2) / (c0 + c1));
+        // Two waves per member.  Three (GRAPE_TILE_PARTS=3: 168 registers, no spills in the slice loops, 4 workgroups and
+        // 3/3/3/3 waves per SIMD resident on every CU -- tools/ubench/wave_placement) are SLOWER at C4dense: 5.19 ms against
+        // 4.46 ms, matrix pipe busy 35 % against 40 %, +13 % memory reads (profiles/r04_C4dense_parts.txt).  Kept for
+        // the tests and for the next look at what the waves of this kernel wait for.
+        int parts = 2;
+        if (const char *sp = std::getenv("GRAPE_TILE_PARTS"))
+            parts = std::atoi(sp) == 3 ? 3 : 2;
+        if (p.N < 2 * parts) parts = 2;
+        // part 0 costs c0 products per slice, every other part c1: n0 c0 = n_q c1
+        int n0 = (int)(((long long)p.N * c1 + (c1 + (parts - 1) * c0) / 2) / (c1 + (parts - 1) * c0));
         if (const char *sp = std::getenv("GRAPE_TILE_SPLIT_PERMILLE"))
-            q.split_at = (int)((long long)p.N * std::atoi(sp) / 1000);
-        if (q.split_at < 1) q.split_at = 1;
-        if (q.split_at > p.N - 1) q.split_at = p.N - 1;
+            n0 = (int)((long long)p.N * std::atoi(sp) / 1000);
+        if (n0 < 1) n0 = 1;
+        if (n0 > p.N - (parts - 1)) n0 = p.N - (parts - 1);
+        q.part_lo[0] = 0;
+        q.part_lo[1] = n0;
+        for (int i = 2; i <= parts; ++i)                           // the rest in equal shares
+            q.part_lo[i] = n0 + (int)((long long)(p.N - n0) * (i - 1) / (parts - 1));
+        q.split_at = n0;
         const size_t bt_b = sizeof(double2) * (size_t)p.K * 256;
-        q.bt_in_lds = bt_b <= 24 * 1024 ? 1 : 0;                    // 4 workgroups per CU must still fit
-        const size_t lds2 = sizeof(double2) * (2 * (kTileImage + 1) + 512) + (q.bt_in_lds ? bt_b : 0);
+        const size_t img_b = sizeof(double2) * (size_t)parts * (kTileImage + 1);
+        q.bt_in_lds = img_b + bt_b <= 40 * 1024 ? 1 : 0;           // 4 workgroups per CU must still fit
+        const size_t lds2 = img_b + (q.bt_in_lds ? bt_b : 0);
+        const dim3 blk(64 * parts);
         if (p.sparse) {
-            const size_t lds_sp = sizeof(double2) * (2 * (kTileImage + 1) + 512 + (size_t)p.K * p.sp_nz + 2 * 16 * 17) +
+            const size_t lds_sp = img_b + sizeof(double2) * ((size_t)p.K * p.sp_nz + (size_t)parts * 16 * 17) +
                                   sizeof(int32_t) * (size_t)p.K * p.sp_nz;
-            if (sandwich) GRAPE_LAUNCH((chain_tile_split_kernel<1, true>), grid, dim3(128), lds_sp, stream, q);
-            else          GRAPE_LAUNCH((chain_tile_split_kernel<0, true>), grid, dim3(128), lds_sp, stream, q);
+            if (parts == 3) {
+                if (sandwich) GRAPE_LAUNCH((chain_tile_split_kernel<1, true, 3>), grid, blk, lds_sp, stream, q);
+                else          GRAPE_LAUNCH((chain_tile_split_kernel<0, true, 3>), grid, blk, lds_sp, stream, q);
+            } else {
+                if (sandwich) GRAPE_LAUNCH((chain_tile_split_kernel<1, true, 2>), grid, blk, lds_sp, stream, q);
+                else          GRAPE_LAUNCH((chain_tile_split_kernel<0, true, 2>), grid, blk, lds_sp, stream, q);
+            }
             return hipGetLastError();
         }
-        if (sandwich) GRAPE_LAUNCH((chain_tile_split_kernel<1>), grid, dim3(128), lds2, stream, q);
-        else          GRAPE_LAUNCH((chain_tile_split_kernel<0>), grid, dim3(128), lds2, stream, q);
+        if (parts == 3) {
+            if (sandwich) GRAPE_LAUNCH((chain_tile_split_kernel<1, false, 3>), grid, blk, lds2, stream, q);
+            else          GRAPE_LAUNCH((chain_tile_split_kernel<0, false, 3>), grid, blk, lds2, stream, q);
+        } else {
+            if (sandwich) GRAPE_LAUNCH((chain_tile_split_kernel<1, false, 2>), grid, blk, lds2, stream, q);
+            else          GRAPE_LAUNCH((chain_tile_split_kernel<0, false, 2>), grid, blk, lds2, stream, q);
+        }
         return hipGetLastError();
     }
     // unitary flow, small ensembles: the time axis in chunks (chunk_product_kernel / chunk_scan_kernel above), grid.z = chunk

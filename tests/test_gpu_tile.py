@@ -118,6 +118,28 @@ def test_c4_liouvillian_parity(qoc, oracle, dense):
     assert_parity(F, G, F_ref, G_ref, w.n, what="C4")
 
 
+@pytest.mark.parametrize("sys_type,n,K,N,E,mixed", [("CoherenceTransfer", 16, 4, 41, 3, False), ("StateTransfer", 12, 3, 7, 2, True),
+                                                    ("UnitaryGate", 9, 2, 6, 2, False), ("StateTransfer", 16, 17, 9, 2, True)])
+def test_three_waves_per_member_split_chain(qoc, oracle, monkeypatch, sys_type, n, K, N, E, mixed):
+    """chain_tile_split_kernel with THREE parts of the time axis (GRAPE_TILE_PARTS=3; the product runs two: measured faster):
+    sandwich and left-multiplication flows, sparse and dense operator lists, Hermitian and general states, N barely above the
+    number of parts, K beyond the LDS cache -- against the oracle and against the two-part run of the same engine."""
+    if sys_type == "CoherenceTransfer":
+        w = qoc.workloads.config("C4", E=E, N=N)
+    else:
+        w = _random_problem(qoc, n, K, N, E, sys_type, seed=11, mixed=mixed)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    with _engine(qoc, w, flags=qoc.engine.FLAG_FORCE_GENERAL) as eng:
+        F2, G2 = eng.eval(w.x)
+        names2 = eng.kernel_names()
+        monkeypatch.setenv("GRAPE_TILE_PARTS", "3")
+        F3, G3 = eng.eval(w.x)
+    assert_parity(F3, G3, F_ref, G_ref, w.n, what="three parts")
+    assert_parity(F2, G2, F_ref, G_ref, w.n, what="two parts")
+    if any("chain_tile_split_kernel" in k for k in names2):      # (otherwise another chain ran: nothing was split)
+        assert np.max(np.abs(np.asarray(G3) - np.asarray(G2))) <= 1e-10 * max(1.0, np.max(np.abs(G2)))
+
+
 @pytest.mark.parametrize("chain", ["chunked", "sequential"])
 def test_c5_five_qubit_parity(qoc, oracle, monkeypatch, chain):
     """BASELINE config 5 at parity size: 32x32 UnitaryGate, K=6, N=2000 (2 members): the chunked time axis small
