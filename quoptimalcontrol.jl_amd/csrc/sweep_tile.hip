@@ -560,6 +560,9 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
 //   wave 0 -> X at part_lo[1];  wave q >= 1 -> T_q = the product of its part's propagators;
 //   wave q >= 1 then rebuilds X at part_lo[q] = T_{q-1} .. T_1 X [T_1' .. T_{q-1}'] and, every wave, the costate at the
 //   end of its part = T_{q+1}' .. T_{PARTS-1}' Xt [T_{PARTS-1} .. T_{q+1}]  -- at most 2 (PARTS - 2) + 2 (PARTS - 1) products.
+#ifndef GRAPE_SPLIT_ABL
+#define GRAPE_SPLIT_ABL 0
+#endif
 template <int SAND, bool SPARSE = false, int PARTS = 2>
 __global__ __launch_bounds__(64 * PARTS, PARTS) void chain_tile_split_kernel(const TileParams p)
 {
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) void chain_tile_split_kernel(con
         tload(X, ops + (size_t)(1 + 2 * K) * TSZ, lane);           // Xi
         tload(Pm, Pk, lane);
         for (int t = 0; t < hi; ++t) {
-            tstore(Xk + (size_t)t * TSZ, X, lane);
+            if (!(GRAPE_SPLIT_ABL & 1)) tstore(Xk + (size_t)t * TSZ, X, lane);
             tload(Pn, Pk + (size_t)min(t + 1, hi - 1) * TSZ, lane);   // (clamped, never branched round: see the note above the kernel)
             to_a_layout(PA, Pm, s_img, lane);
             if (SAND) {
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) void chain_tile_split_kernel(con
         if (lo < hi)
             tload(Pm, Pk + (size_t)lo * TSZ, lane);
         for (int t = lo; t < hi; ++t) {
-            tstore(Xk + (size_t)t * TSZ, V, lane);                 // V_{t-lo}: X_t = V X_lo V'
+            if (!(GRAPE_SPLIT_ABL & 1)) tstore(Xk + (size_t)t * TSZ, V, lane);                 // V_{t-lo}: X_t = V X_lo V'
             tload(Pn, Pk + (size_t)min(t + 1, hi - 1) * TSZ, lane);
             to_a_layout(PA, Pm, s_img, lane);
             tmul_an<NT, false, false>(Y, PA, V);                   // P V
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) void chain_tile_split_kernel(con
             TOp<1> VA;
             tload(Pm, Pk + (size_t)(hi - 1) * TSZ, lane);
             for (int t = hi - 1; t >= lo; --t) {
-                tload(V, Xk + (size_t)t * TSZ, lane);
+                if (!(GRAPE_SPLIT_ABL & 2) || t == hi - 1) tload(V, Xk + (size_t)t * TSZ, lane);
                 tload(X0, Xk + (size_t)lo * TSZ, lane);
                 pull_back();
                 tload(Pm, Pk + (size_t)max(t - 1, lo) * TSZ, lane);   // (clamped at the part's first slice: no branch round a load)
@@ -798,7 +801,7 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) void chain_tile_split_kernel(con
         if (hi > 0)
             tload(Pm, Pk + (size_t)(hi - 1) * TSZ, lane);
         for (int t = hi - 1; t >= 0; --t) {
-            tload(X, Xk + (size_t)t * TSZ, lane);
+            if (!(GRAPE_SPLIT_ABL & 2) || t == hi - 1) tload(X, Xk + (size_t)t * TSZ, lane);
             pull_back();
             tload(Pm, Pk + (size_t)max(t - 1, 0) * TSZ, lane);
             emit(t);
