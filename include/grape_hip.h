@@ -264,7 +264,9 @@ int grape_eval_device(grape_ctx *ctx, const double *d_x, double *d_fg, void *str
  *   x  host f64 (K,N,n_x)      F  host f64[n_x] (nullable)      G  host f64 (K,N,n_x) (nullable)
  * Entry b is exactly what grape_eval(ctx, x[:,:,b]) returns; with n_x = 1 the two calls are the same.
  * Needs grape_config.max_batch >= n_x (the workspace is sized for max_batch control arrays).  ABI v4: multi-device contexts
- * and attached communicators batch too -- every shard evaluates the n_x arrays, their rows cross the devices as one sum. */
+ * and attached communicators batch too -- every shard evaluates the n_x arrays, their rows cross the devices as one sum.
+ * gradient = GRAPE_GRADIENT_EXACT batches as well: the stored trajectory is one control array's, so the arrays run one behind
+ * the other on the stream (same results, one call, one completion). */
 int grape_eval_batch(grape_ctx *ctx, int32_t n_x, const double *x, double *F, double *G);
 
 /* Device-pointer form: d_x (K,N,n_x), d_fg f64[(K*N + 1) * n_x] = n_x blocks of { G, F }. */

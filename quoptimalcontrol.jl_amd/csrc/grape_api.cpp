@@ -437,8 +437,6 @@ static int validate_config(const grape_config *cfg)
     if (cfg->objective == GRAPE_OBJECTIVE_C1 && cfg->gradient != GRAPE_GRADIENT_EXACT)
         return fail(nullptr, GRAPE_ERR_INVALID_ARG,
                     "grape_create: the C1 functional (ADGRAPE path) comes with the exact gradient: set gradient = 1");
-    if (cfg->gradient == GRAPE_GRADIENT_EXACT && cfg->max_batch > 1)
-        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: exact gradient and max_batch > 1 do not combine in this build");
     if ((cfg->flags & GRAPE_FLAG_PHASE_STAMPS) && wmax == 0)
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: GRAPE_FLAG_PHASE_STAMPS exists for n <= 4 only (the tile kernels write no stamps)");
     return GRAPE_OK;
@@ -1664,6 +1662,22 @@ static int fold_events(grape_ctx *c, uint64_t count)
 static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream_t stream, int n_x = 1,
                         grape::DoneSignal done = grape::DoneSignal())
 {
+    if (c->cfg.gradient == GRAPE_GRADIENT_EXACT && n_x > 1) {
+        // the stored trajectory (every X_t and L_t of the debug flow) is ONE control array's: the arrays of a batch run one
+        // behind the other on the stream, each through the whole chain; the last reduction publishes them all
+        const size_t Qs = KN(c) + 1;
+        for (int b = 0; b < n_x; ++b) {
+            grape::DoneSignal db;
+            if (b == n_x - 1 && done.flag) {
+                db = done;
+                db.stage_base = d_fg;
+                db.n_total = (int)(Qs * n_x);
+            }
+            const int rc = enqueue_eval(c, d_x + (size_t)b * KN(c), d_fg + (size_t)b * Qs, stream, 1, db);
+            if (rc) return rc;
+        }
+        return GRAPE_OK;
+    }
     KernelLogScope log_scope(&c->kernel_log);
     SweepParams p{};
     p.ops = c->d_ops;

@@ -102,6 +102,24 @@ def test_timed_event_ring_wraps(qoc):
         assert n2 == 1 and ms2 < ms
 
 
+@pytest.mark.parametrize("name,kw,objective,devices", [("C3", {"E": 7, "N": 33}, "fom", [0, 0, 0]), ("C3", {"E": 5, "N": 20}, "c1", [0, 0]),
+                                                       ("C4", {"E": 5, "N": 12}, "fom", [0, 0]), ("C1", {}, "c1", [0, 0])])
+def test_exact_gradient_on_multi_shard_group(qoc, oracle, name, kw, objective, devices):
+    """gradient = exact (and the C1 functional of the ADGRAPE path) on a context that spans several shards: every shard runs
+    its debug-flow sweep + exact kernel on its block of members, the rows meet in the group's sum like any other evaluation."""
+    w = qoc.workloads.config(name, **kw)
+    F_ref, G_ref = oracle.ensemble_exact(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, variant=1,
+                                         objective=0 if objective == "fom" else 1)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, variant=1, gradient="exact", objective=objective,
+                         devices=devices, flags=qoc.engine.FLAG_GROUP_PEER_SUM) as eng:
+        per = -(-w.E // len(devices))
+        assert eng.info["n_devices"] == min(len(devices), -(-w.E // per))
+        F, G = eng.eval(w.x)
+        F2, G2 = eng.eval(w.x)
+    assert_parity(F, G, F_ref, G_ref, w.n, what=f"{name} exact {objective} on {len(devices)} shards")
+    assert F == F2 and np.array_equal(G, G2)
+
+
 @pytest.mark.parametrize("name,kw,devices", [("C3", {"E": 5, "N": 70}, [0, 0]), ("C3", {"E": 7, "N": 33}, [0, 0, 0]),
                                              ("C1", {}, [0, 0]), ("C4", {"E": 5, "N": 24}, [0, 0]), ("C4", {"E": 5, "N": 70}, [0, 0, 0]),
                                              ("C3", {"E": 9, "N": 40}, [0, 0, 0, 0, 0, 0, 0, 0])])

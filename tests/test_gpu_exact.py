@@ -102,9 +102,29 @@ def test_exact_argument_rules(qoc):
     with pytest.raises(qoc.GrapeError) as ei:
         qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, objective="c1")     # C1 functional needs exact
     assert ei.value.status == -1
-    with pytest.raises(qoc.GrapeError) as ei:
-        qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, gradient="exact", max_batch=2)
-    assert ei.value.status == -2                                                                # no batching with it
+
+
+@pytest.mark.parametrize("name,kw,objective,devices", [("C3", {"E": 9, "N": 41}, "fom", None), ("C2", {"N": 57}, "c1", None),
+                                                       ("C4", {"E": 3, "N": 10}, "c1", None), ("C3", {"E": 6, "N": 24}, "c1", [0, 0])])
+def test_exact_gradient_in_batches(qoc, oracle, name, kw, objective, devices):
+    """gradient = exact with max_batch > 1 (multi-start / the ladder's probes on the ADGRAPE path): entry b of the batch is
+    bitwise what eval(X[b]) returns -- the arrays run one behind the other through the one stored trajectory -- on one
+    device and on a group of shards."""
+    w = qoc.workloads.config(name, **kw)
+    rng = np.random.default_rng(3)
+    X = np.stack([w.x, w.x + 0.1 * rng.standard_normal(w.x.shape), 0.5 * w.x])
+    extra = dict(devices=devices, flags=qoc.engine.FLAG_GROUP_PEER_SUM) if devices else {}
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, variant=1, gradient="exact", objective=objective,
+                         max_batch=3, **extra) as eng:
+        Fb, Gb = eng.eval_batch(X)
+        singles = [eng.eval(X[b]) for b in range(3)]
+        F2, G2 = eng.eval_batch(X[:2])
+    for b in range(3):
+        F_ref, G_ref = oracle.ensemble_exact(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, X[b], w.T, variant=1,
+                                             objective=0 if objective == "fom" else 1)
+        assert_parity(Fb[b], Gb[b], F_ref, G_ref, w.n, what=f"{name} exact batch entry {b}")
+        assert Fb[b] == singles[b][0] and np.array_equal(Gb[b], singles[b][1])
+    assert np.array_equal(F2, Fb[:2]) and np.array_equal(G2, Gb[:2])
 
 
 def _problem(qoc, sys_type, N, T):
