@@ -48,6 +48,47 @@ __device__ __forceinline__ void publish_via_last_block(DoneSignal d, const doubl
     __syncthreads();
     if (!s_last)
         return;
+    if (d.probe_out) {
+        // the line search's probe (grape_lbfgs): phi = F, phi' = G . dir -- in lbfgs_select_kernel's summation order (1024
+        // partial sums idx = v, v + 1024, ...; a 64-lane xor tree per group of 64; the sixteen groups in order), so the
+        // iterates do not depend on which kernel formed the scalars
+        __shared__ double s_pw[16];
+        const int KNp = n_total - 1, nw = (int)(blockDim.x >> 6), l = (int)(threadIdx.x & 63);
+        for (int vw = (int)(threadIdx.x >> 6); vw < 16; vw += nw) {
+            // (all loads of a partial sum in flight together, then the multiply-adds in the kernel's order: one at a time
+            // the sc1 loads cost a trip to L2 each -- 5 us more per evaluation than the separate kernel they replace)
+            double gv[kLbfgsMaxPer], dv[kLbfgsMaxPer];
+#pragma unroll
+            for (int k = 0; k < kLbfgsMaxPer; ++k) {
+                const int idx = vw * 64 + l + 1024 * k;
+                gv[k] = idx < KNp ? __hip_atomic_load(stage + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                dv[k] = idx < KNp ? d.probe_dir[idx] : 0.0;
+            }
+            double part = 0.0;
+#pragma unroll
+            for (int k = 0; k < kLbfgsMaxPer; ++k)
+                if (vw * 64 + l + 1024 * k < KNp)
+                    part = fma(gv[k], dv[k], part);
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1)
+                part += __shfl_xor(part, dd, 64);
+            if (l == 0)
+                s_pw[vw] = part;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w)
+                t += s_pw[w];
+            d.probe_out[0] = __hip_atomic_load(stage + KNp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d.probe_out[1] = t;
+            d.probe_out[2] = d.probe_sc[2];
+            __threadfence_system();
+            __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     for (int i0 = threadIdx.x; i0 < n_total; i0 += 8 * blockDim.x) {       // 8 sc1 loads in flight per thread
         double v[8];
 #pragma unroll

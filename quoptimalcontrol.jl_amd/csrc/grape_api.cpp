@@ -1622,6 +1622,14 @@ static bool tile_folds_reduce(const grape_ctx *c, int n_x)
     return c->action || c->thin_dpp || (c->unitary && !c->thin && !c->d_costates);
 }
 
+// a single-device evaluation of ONE control array whose last launch is one of the reduce kernels (reduce.hip): those can
+// close grape_lbfgs' line-search probe themselves (DoneSignal::probe_out) -- the others keep lbfgs_select_kernel behind them
+static bool eval_ends_in_reduce(const grape_ctx *c)
+{
+    if (c->is_group || c->comm || c->ipc_ranks > 1) return false;
+    return c->family == 0 ? true : !tile_folds_reduce(c, 1);
+}
+
 static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream, int n_x, hipEvent_t ev_mid = nullptr,
                         double *d_fg = nullptr, grape::DoneSignal done = grape::DoneSignal())
 {
@@ -1722,7 +1730,7 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     const bool exact = c->cfg.gradient == GRAPE_GRADIENT_EXACT;
     if (exact) p.member_out = nullptr;                       // the sweep's first-order rows are not wanted
     // one workgroup holds the whole ensemble (single problems): its row is [G, F], no reduce launch
-    const bool direct = c->family == 0 && c->NB == 1 && n_x == 1 && !exact && c->direct_publish;
+    const bool direct = c->family == 0 && c->NB == 1 && n_x == 1 && !exact && c->direct_publish && !done.probe_out;
     if (direct) {
         p.direct_dst = done.flag && done.host_out ? done.host_out : d_fg;
         p.direct_flag = done.flag;
@@ -2041,12 +2049,14 @@ static int enqueue_peer_sum(grape_ctx *g, double *target, hipStream_t lead_strea
 
 // device pointers in, device pointers out, nothing synchronised: n_x control arrays (n_x > 1: grape_eval_batch_device) on a
 // single device, an attached communicator / mailbox exchange, or an in-process group
-static int eval_device_impl(grape_ctx *c, const double *d_x, double *d_fg, void *stream, int n_x)
+// (`done`: single-device contexts without a communicator only -- grape_lbfgs' fused probe, see eval_ends_in_reduce)
+static int eval_device_impl(grape_ctx *c, const double *d_x, double *d_fg, void *stream, int n_x,
+                            grape::DoneSignal done = grape::DoneSignal())
 {
     hipStream_t st = (hipStream_t)stream;
     if (!c->is_group) {
         HIP_TRY(c, hipSetDevice(c->device));
-        int rc = enqueue_eval(c, d_x, d_fg, st, n_x);
+        int rc = enqueue_eval(c, d_x, d_fg, st, n_x, c->ipc_ranks > 1 || c->comm ? grape::DoneSignal() : done);
         if (rc) return rc;
         if (c->ipc_ranks > 1) {
             rc = enqueue_ipc_allreduce(c, d_fg, d_fg, st, grape::DoneSignal(), n_x);
@@ -2328,6 +2338,7 @@ struct LbfgsRun {
     double *h_sc = nullptr;
     int evals = 0;
     bool hung = false;                            // a wait timed out: the device is presumed hung, nothing is synchronised any more
+    bool fused_probe = false;                     // phi / phi' of a trial step come from the evaluation's reduce kernel
 
     grape::DoneSignal signal()
     {
@@ -2349,17 +2360,35 @@ struct LbfgsRun {
         // (groups: fan-out of x, every shard, the grouped all-reduce / peer sum; communicators: the exchange behind the sweep)
         return eval_device_impl(c, st.xt, st.fgt, lead->stream, n_x);
     }
+    // trial slot 0: evaluate, publish phi, phi' (and phi'(0)) behind it -- nothing is waited for
+    int probe()
+    {
+        if (fused_probe) {
+            // the evaluation's own reduction publishes the scalars (same bits as lbfgs_select_kernel's): one launch less
+            // on the dependent chain of every trial step
+            grape::DoneSignal d = signal();
+            d.counter = lead->d_done_counter;
+            d.probe_dir = st.d;
+            d.probe_sc = st.sc;
+            d.probe_out = st.host_sc + 8;
+            evals += 1;
+            return eval_device_impl(c, st.xt, st.fgt, lead->stream, 1, d);
+        }
+        int rc = evaluate(1);
+        if (rc) return rc;
+        HIP_TRY(c, hipSetDevice(lead->device));
+        if (grape::launch_lbfgs_select(st, 1, lead->stream, signal(), 1) != hipSuccess)
+            return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
+        return GRAPE_OK;
+    }
     // phi(alpha), phi'(alpha) along the current direction; `have_trial`: slot 0 already holds x + alpha d
     int phi(double alpha, bool have_trial, double &f, double &df)
     {
         HIP_TRY(c, hipSetDevice(lead->device));
         if (!have_trial && grape::launch_lbfgs_trial(st, alpha, lead->stream) != hipSuccess)
             return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
-        int rc = evaluate(1);
+        int rc = probe();
         if (rc) return rc;
-        HIP_TRY(c, hipSetDevice(lead->device));
-        if (grape::launch_lbfgs_select(st, 1, lead->stream, signal(), 1) != hipSuccess)
-            return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
         rc = wait();
         if (rc) return rc;
         f = h_sc[8];
@@ -2594,6 +2623,10 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
     run.c = c;
     run.lead = lead;
     run.h_sc = h_sc;
+    {
+        const char *fp = std::getenv("GRAPE_LBFGS_FUSED_PROBE");   // 0: lbfgs_select_kernel behind every trial evaluation (A/B, tests)
+        run.fused_probe = eval_ends_in_reduce(c) && !(fp && fp[0] == '0');
+    }
     grape::LbfgsState &st = run.st;
     double *p = buf;
     st.x = p; p += kn;
@@ -2675,14 +2708,7 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
             return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
         return GRAPE_OK;
     };
-    auto launch_probe = [&]() -> int {                       // trial slot 0: evaluate, publish phi, phi' (and phi'(0))
-        int r = run.evaluate(1);
-        if (r) return r;
-        HIP_TRY(c, hipSetDevice(lead->device));
-        if (grape::launch_lbfgs_select(st, 1, lead->stream, run.signal(), 1) != hipSuccess)
-            return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
-        return GRAPE_OK;
-    };
+    auto launch_probe = [&]() -> int { return run.probe(); };  // trial slot 0: evaluate, publish phi, phi' (and phi'(0))
     if (o.line_search == 2) {
         while (status == 2 && it < max_it) {
             const double F_prev = F;

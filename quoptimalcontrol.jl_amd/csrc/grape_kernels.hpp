@@ -43,6 +43,11 @@ struct DoneSignal {
                                                // workgroup copies out in one coalesced burst before publishing
     const double *stage_base = nullptr;        // reduce_stage2 of a batched evaluation: start of the whole staging
     int n_total = 0;                           // buffer and its length (all n_x blocks), copied by the last launch
+    // grape_lbfgs' line-search probe closed by the reduction itself (done_signal.hpp): instead of copying [G, F] out, the
+    // last workgroup publishes phi = F and phi' = G . probe_dir (and phi'(0) = probe_sc[2]) in probe_out[0..2]
+    const double *probe_dir = nullptr;         // device: the search direction (K N doubles)
+    const double *probe_sc = nullptr;          // device: the L-BFGS scalars (LbfgsState::sc)
+    double *probe_out = nullptr;               // mapped host memory (device address): LbfgsState::host_sc + 8
 };
 
 constexpr int kStampSlots = 8;   // [0..4] shader clock at phase boundaries, [5],[6] 100 MHz real time

@@ -95,12 +95,12 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restri
 #pragma unroll
         for (int i = 1; i < 32; ++i)
             s += s_acc[i][ql];
-        if (done.flag && done.host_out)
+        if (done.flag && (done.host_out || done.probe_out))
             stage_store(fg, q, s);
         else
             fg[q] = s;
     }
-    if (done.flag && done.host_out)                    // fg - blockIdx.y * Q: the staging buffer of all n_x reductions
+    if (done.flag && (done.host_out || done.probe_out)) // fg - blockIdx.y * Q: the staging buffer of all n_x reductions
         publish_via_last_block(done, fg - (size_t)blockIdx.y * Q, Q * (int)gridDim.y, gridDim.x * gridDim.y);
     else if (done.flag && threadIdx.x == 0)            // fg IS the mapped host buffer: every workgroup pushed its own 64 bytes
         signal_done(done, gridDim.x * gridDim.y);

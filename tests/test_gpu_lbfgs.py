@@ -111,6 +111,53 @@ def test_hager_zhang_is_a_wolfe_line_search(qoc, mode):
     assert info["minimum"] - F0 <= 0.7 * (res.minimum - F0)
 
 
+@pytest.mark.parametrize("case", ["pair", "lane", "tile", "tile_one", "exact", "single_block"])
+@pytest.mark.parametrize("mode", ["hagerzhang", "optim"])
+def test_probe_closed_by_the_reduction_is_the_probe_kernel(qoc, monkeypatch, case, mode):
+    """phi and phi' of a trial step come out of the evaluation's own reduce kernel (DoneSignal::probe_out) where the
+    evaluation ends in one -- every kernel family, the exact gradient too -- and out of lbfgs_select_kernel elsewhere
+    (GRAPE_LBFGS_FUSED_PROBE=0: everywhere): the same scalars to the last bit, hence the same iterates."""
+    rng = np.random.default_rng(17)
+    kw = {}
+    if case in ("pair", "exact"):
+        w = qoc.workloads.config("C3", E=24, N=64)                                 # 4 x 4 on lane pairs
+        args = (w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N)
+        x0 = w.x
+        if case == "exact":
+            kw = dict(gradient="exact", variant=1)
+    elif case == "single_block":
+        w = qoc.workloads.config("C2", N=96)                                        # one workgroup: the sweep publishes itself
+        args = (w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N)
+        x0 = w.x
+    elif case == "lane":
+        w = qoc.workloads.reference_ensemble("StateTransfer", 7, 30, 5.0)           # 2 x 2: lane kernel
+        args = (w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N)
+        x0 = w.x
+    else:
+        n, E, K, N = 12, (1 if case == "tile_one" else 5), 3, 14
+
+        def herm():
+            M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+            return (M + M.conj().T) / 2
+        A = np.array([herm() for _ in range(E)]) * 0.4
+        B = np.array([[herm() for _ in range(K)] for _ in range(E)]) * 0.4
+        Xi = np.array([herm() for _ in range(E)])
+        Xt = np.array([herm() for _ in range(E)])
+        args = ("StateTransfer", A, B, Xi, Xt, np.ones(E) / E, 1.5, N)
+        x0 = rng.uniform(-1, 1, (K, N))
+    runs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("GRAPE_LBFGS_FUSED_PROBE", fused)
+        with qoc.GrapeEngine(*args, **kw) as eng:
+            x, info = eng.lbfgs(x0, iterations=8, line_search=mode)
+            names = eng.kernel_names()
+        runs.append((x, info, names))
+    (xa, ia, na), (xb, ib, nb) = runs
+    assert ia["evaluations"] == ib["evaluations"] and ia["iterations"] == ib["iterations"]
+    assert ia["minimum"] == ib["minimum"] and np.array_equal(xa, xb)
+    assert ia["evaluations"] >= 3
+
+
 def test_lbfgs_on_a_device_group_and_with_a_communicator(qoc):
     """Multi-device contexts run the Hager-Zhang search (vectors on the first device, every evaluation the sharded one):
     three shards on GPU 0 through the peer sum, and a 1-rank RCCL communicator, against the single-device run."""
