@@ -127,7 +127,10 @@ typedef struct grape_config {
     int32_t device_ids[GRAPE_MAX_DEVICES];   /* HIP ordinals, used when n_devices >= 2 */
     int32_t gradient;          /* grape_gradient: 0 = the reference's first-order grad_func! (src/GRAPE.jl:261-303),
                                   1 = exact derivative of the objective (what ADGRAPE gets from Zygote,
-                                  src/GRAPE.jl:12-20; cf. expm_exact_gradient, src/grape_tools.jl:26-57) */
+                                  src/GRAPE.jl:12-20; cf. expm_exact_gradient, src/grape_tools.jl:26-57).  Runs behind the
+                                  debug flow (every X_t, L_t stored: grape_get_trajectory returns them), except for
+                                  UnitaryGate problems with Hermitian generators at n = 4, which take the unitary flow
+                                  (grape_info.unitary_flow = 1, states_stored = 0) unless GRAPE_FLAG_KEEP_COSTATES is set */
     int32_t objective;         /* grape_objective: 0 = fom_func (src/cost_functions.jl:99-111),
                                   1 = the ADGRAPE functional C1(Xt, U Xi [U']) for every system type
                                   (src/solve.jl:268-291, :317-361); needs gradient = 1 */

@@ -294,7 +294,10 @@ GRAPE_DEV void ptrace_elem(double &zr, double &zi, const PMat<N> &a, const PMat<
     zi = si + pair_swap(si);
 }
 
-template <int N, int SAND>
+// W1IN (UnitaryGate, Hermitian generators -- round 4): the backward sweep of the unitary flow has left W_t = X_t L_{t+1}' in
+// `states` and Phi = tr(L' X) per member in `zphi` (SweepParams::dump_w1): no P_t / X_t / L_{t+1} loads, two products less,
+// and a sweep of 0.09 instead of 0.16 ms in front of this kernel.
+template <int N, int SAND, bool W1IN = false>
 __global__ __launch_bounds__(64) void exact_pair_kernel(const double2 *__restrict__ ops_all, const double *__restrict__ x_all,
                                                         const ExactParams p)
 {
@@ -337,7 +340,11 @@ __global__ __launch_bounds__(64) void exact_pair_kernel(const double2 *__restric
     };
     PMat<N> W1, W2;
     double phr, phi;
-    {
+    if (W1IN) {
+        ws_load(W1, p.states, tt);
+        phr = p.zphi[2 * (size_t)k];
+        phi = p.zphi[2 * (size_t)k + 1];
+    } else {
         PMat<N> P, X, Ln, Lp, tmp, tp;
         ws_load(P, p.props, tt);
         ws_load(X, p.states, tt);
@@ -481,8 +488,10 @@ template <int N>
 static hipError_t launch_exact_pair(int sandwich, const ExactParams &p, hipStream_t stream)
 {
     const dim3 grid((p.N + 31) / 32, p.E), block(64);
-    if (sandwich) GRAPE_LAUNCH((exact_pair_kernel<N, 1>), grid, block, 0, stream, p.ops, p.x, p);
-    else          GRAPE_LAUNCH((exact_pair_kernel<N, 0>), grid, block, 0, stream, p.ops, p.x, p);
+    if (p.w1_in && sandwich) return hipErrorInvalidConfiguration;
+    if (p.w1_in)       GRAPE_LAUNCH_AS("exact_pair_kernel", (exact_pair_kernel<N, 0, true>), grid, block, 0, stream, p.ops, p.x, p);
+    else if (sandwich) GRAPE_LAUNCH((exact_pair_kernel<N, 1>), grid, block, 0, stream, p.ops, p.x, p);
+    else               GRAPE_LAUNCH((exact_pair_kernel<N, 0>), grid, block, 0, stream, p.ops, p.x, p);
     return hipGetLastError();
 }
 
@@ -497,7 +506,9 @@ static hipError_t launch_exact_n(int sandwich, const ExactParams &p, hipStream_t
 
 hipError_t launch_exact_grad(int n, int sandwich, const ExactParams &p, hipStream_t stream)
 {
-    static const bool lane_kernel = std::getenv("GRAPE_EXACT_LANE") != nullptr;       // (the round-2 mapping, for comparison)
+    static const bool lane_env = std::getenv("GRAPE_EXACT_LANE") != nullptr;          // (the round-2 mapping, for comparison)
+    const bool lane_kernel = lane_env && !p.w1_in;
+    if (p.w1_in && n != 2 && n != 4) return hipErrorInvalidConfiguration;
     switch (n) {
     case 2: return lane_kernel ? launch_exact_n<2>(sandwich, p, stream) : launch_exact_pair<2>(sandwich, p, stream);
     case 3: return launch_exact_n<3>(sandwich, p, stream);

@@ -77,6 +77,8 @@ struct grape_ctx {
     double *d_x = nullptr;
     double *d_fg = nullptr;
     double2 *d_props = nullptr, *d_states = nullptr, *d_costates = nullptr;
+    double *d_zphi = nullptr;                  // exact gradient, unitary flow: tr M per member and control array
+    bool exact_w1 = false;                     // exact gradient from the unitary flow's W_t dump (UnitaryGate, Hermitian generators, pair kernel)
     double *d_member_out = nullptr;
     double *d_partial = nullptr;
     unsigned long long *d_stamps = nullptr;
@@ -346,6 +348,13 @@ static bool env_on(const char *name)
     return v && v[0] && !(v[0] == '0' && !v[1]);
 }
 
+// ... and the ones that switch a default off: set to exactly "0"
+static bool env_off(const char *name)
+{
+    const char *v = std::getenv(name);
+    return v && v[0] == '0' && !v[1];
+}
+
 static size_t KN(const grape_ctx *c) { return (size_t)c->cfg.n_controls * c->cfg.n_slices; }
 
 static void free_all(grape_ctx *c)
@@ -380,7 +389,7 @@ static void free_all(grape_ctx *c)
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     (void)hipFree(c->d_ops); (void)hipFree(c->d_wts); (void)hipFree(c->d_x); (void)hipFree(c->d_fg);
-    (void)hipFree(c->d_props); (void)hipFree(c->d_states); (void)hipFree(c->d_costates);
+    (void)hipFree(c->d_props); (void)hipFree(c->d_states); (void)hipFree(c->d_costates); (void)hipFree(c->d_zphi);
     (void)hipFree(c->d_member_out); (void)hipFree(c->d_partial); (void)hipFree(c->d_stamps); (void)hipFree(c->d_block_out); (void)hipFree(c->d_xg_scratch);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_fg) (void)hipHostFree(c->h_fg);
@@ -562,6 +571,7 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     if (e == hipSuccess) e = alloc((void **)&c->d_fg, sizeof(double) * Q * Bn);
     if (e == hipSuccess) e = alloc((void **)&c->d_props, sizeof(double2) * c->ws_elems * Bn);
     if (e == hipSuccess && keepl) e = alloc((void **)&c->d_costates, sizeof(double2) * c->ws_elems * Bn);
+    if (e == hipSuccess && exact && c->family == 0) e = alloc((void **)&c->d_zphi, sizeof(double) * 2 * E * Bn);
     const bool want_rows = c->family == 1 || (cfg->flags & GRAPE_FLAG_MEMBER_RESULTS) || exact;
     if (e == hipSuccess && want_rows) e = alloc((void **)&c->d_member_out, sizeof(double) * E * Q * Bn);
     if (e == hipSuccess) e = alloc((void **)&c->d_partial, sizeof(double) * c->ksplit * Q);
@@ -1051,6 +1061,21 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         for (size_t m = 0; m < K + 1 && herm; ++m)
             herm = grape_host::hermitian_to_rounding((m == 0) ? A + 2 * k * nn : B + 2 * (k * K + (m - 1)) * nn, n);
     c->unitary = herm;
+    // Exact gradient of a UnitaryGate problem on lane pairs: with Hermitian generators the UNITARY flow provides all the
+    // exact-gradient kernel needs of the trajectory -- W_t = X_t L_{t+1}' = M_t P_t' per slice and tr M per member -- at
+    // 0.09 instead of 0.16 ms for the debug flow that dumps X_t and L_t (C3), and the kernel behind it loads one matrix
+    // per slice instead of three.  GRAPE_EXACT_W1=0 / GRAPE_FLAG_KEEP_COSTATES / FORCE_GENERAL keep the debug flow.
+    c->exact_w1 = false;
+    if (c->cfg.gradient == GRAPE_GRADIENT_EXACT && c->family == 0 && c->pair && c->d_zphi &&
+        c->cfg.sys_type == GRAPE_UNITARY_GATE && c->m == c->cfg.n &&
+        !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) && !env_off("GRAPE_EXACT_W1")) {
+        bool hg = true;
+        for (size_t k = 0; k < E && hg; ++k)
+            for (size_t mm = 0; mm < K + 1 && hg; ++mm)
+                hg = grape_host::hermitian_to_rounding((mm == 0) ? A + 2 * k * nn : B + 2 * (k * K + (mm - 1)) * nn, n);
+        c->exact_w1 = hg;
+        if (hg) c->unitary = true;
+    }
     {                                                        // Hermitian initial / target operators (square states only)
         bool hs = c->m == c->cfg.n;
         for (size_t k = 0; k < E && hs; ++k)
@@ -1518,7 +1543,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             HIP_TRY(c, hipMalloc((void **)&c->d_states, rec));
             c->states_bytes = rec;
         }
-    } else if (!herm && c->states_bytes < sizeof(double2) * c->ws_elems * c->B) {
+    } else if ((!herm || c->exact_w1) && c->states_bytes < sizeof(double2) * c->ws_elems * c->B) {
         const size_t full = sizeof(double2) * c->ws_elems * c->B;
         (void)hipFree(c->d_states);
         c->d_states = nullptr;
@@ -1607,6 +1632,7 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
 // forward states X_t available to grape_get_trajectory without the debug flow?
 static bool states_stored(const grape_ctx *c)
 {
+    if (c->exact_w1) return false;                           // exact gradient behind the unitary flow: W_t where the states would be
     if (c->d_costates) return true;                          // debug flow stores everything
     if (c->family == 0 || c->unitary || c->thin) return false;   // fast small-n flows / unitary / rank-one flows rebuild them
     return !grape::tile_chain_is_split(tile_params(c, nullptr), false);
@@ -1710,6 +1736,8 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     p.s_forced = c->cfg.expm_squarings;
     p.variant = c->cfg.variant;
     p.dt = c->cfg.duration / c->cfg.n_slices;                 // src/GRAPE.jl:42
+    p.dump_w1 = c->exact_w1 ? 1 : 0;
+    p.zphi = c->d_zphi;
     bool timed = (c->cfg.flags & GRAPE_FLAG_TIME_KERNELS) != 0;
     if (timed && (c->cfg.flags & GRAPE_FLAG_TIME_SAMPLED) && (c->launches++ & 7) != 0)
         timed = false;
@@ -1766,6 +1794,8 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
         q.variant = c->cfg.variant;
         q.objective = c->cfg.objective;
         q.herm_states = c->herm_states ? 1 : 0;
+        q.w1_in = c->exact_w1 ? 1 : 0;
+        q.zphi = c->d_zphi;
         HIP_TRY(c, grape::launch_exact_grad(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, q, stream));
     }
     if (timed) HIP_TRY(c, hipEventRecord(e1, stream));
@@ -2884,9 +2914,10 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
         const int rc = grape_get_trajectory(s, local, props, states, costates);
         return rc ? group_fail(c, s, rc) : GRAPE_OK;
     }
-    if (costates && !c->d_costates)
+    if ((costates && !c->d_costates) || ((costates || states) && c->exact_w1))
         return fail(c, GRAPE_ERR_NOT_READY,
-                    "grape_get_trajectory: costates need GRAPE_FLAG_KEEP_COSTATES at grape_create");
+                    "grape_get_trajectory: costates need GRAPE_FLAG_KEEP_COSTATES at grape_create (this exact-gradient flow "
+                    "stores neither states nor costates)");
     if (props && c->action)
         return fail(c, GRAPE_ERR_NOT_READY,
                     "grape_get_trajectory: this flow applies exp(G_t) to vectors and forms no propagators; create the "

@@ -86,6 +86,11 @@ struct SweepParams {
     double *direct_dst;
     unsigned long long *direct_flag;
     unsigned long long direct_seq;
+    // exact gradient of a UnitaryGate problem with Hermitian generators (pair kernel, unitary flow): the backward sweep also
+    // stores W_t = X_t L_{t+1}' = M_t P_t' per slice into `states` (unused by this flow) and tr(M) per member into `zphi`
+    // -- all that exact_pair_kernel needs of the trajectory (no debug flow, no X_t / L_t dumps)
+    int32_t dump_w1;
+    double *zphi;         // (2 per member and control array) Phi = tr(L' X) = tr M
 };
 
 // sandwich == 0: UnitaryGate chain; 1: State/CoherenceTransfer sandwich chain.
@@ -276,6 +281,8 @@ struct ExactParams {
     int32_t s_forced, variant;
     int32_t objective;        // 0: the GRAPE figure of merit (fom_func), 1: C1 functional for every system type (ADGRAPE)
     int32_t herm_states;      // every Xi, Xt Hermitian: the sandwich's two derivative directions coincide
+    int32_t w1_in;            // UnitaryGate, pair kernel: `states` holds W_t = X_t L_{t+1}' (SweepParams::dump_w1), `zphi` Phi
+    const double *zphi;
 };
 hipError_t launch_exact_grad(int n, int sandwich, const ExactParams &p, hipStream_t stream);
 // the same for the tile family (exact_tile.hip): reads the debug flow's props / states / costates dumps of TileParams

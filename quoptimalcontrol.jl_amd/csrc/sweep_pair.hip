@@ -163,7 +163,7 @@ GRAPE_DEV void pwrite_gradient(double *out, const double2 *s_bt, int K, const PM
     }
 }
 
-template <int N, int SAND, int MODE, int MAXT, bool XGLDS>
+template <int N, int SAND, int MODE, int MAXT, bool XGLDS, bool DUMPW = false>
 __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restrict__ ops_all,
                                                           const double *__restrict__ x_all,
                                                           const double *__restrict__ wts_all,
@@ -581,6 +581,15 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
                     zr = tr_r;
                     zi = -tr_i;
                 }
+                if (DUMPW) {                         // exact gradient: W_t = X_t L_{t+1}' = M_t P_t' (P_t unitary), Phi = tr M
+                    fetch_partner(Mp, M);
+                    pmul_a_bh(tmp, M, Mp, P, Pp);
+                    pstore_ws(Xw + (size_t)j * NN * stride, stride, tmp, par);
+                    if (t == Nsl - 1 && par == 0) {
+                        p.zphi[2 * (size_t)k] = zr;
+                        p.zphi[2 * (size_t)k + 1] = -zi;
+                    }
+                }
                 if (GRAPE_ABL & 16) { if (par == 0) xg[j * K] = M.re[0] + zr; } else
                 pwrite_gradient<N, SAND>(xg + j * K, sBT, K, M, zr, zi, gs, par);
                 if (t == Nsl - 1 && par == 0)
@@ -775,6 +784,20 @@ static hipError_t plaunch_one(const SweepParams &p0, hipStream_t stream)
             lds = with;
         }
     }
+    if constexpr (MODE == PMODE_UNITARY && SAND == 0) {
+        if (p.dump_w1) {
+            auto kern_w = sweep_pair_kernel<N, SAND, MODE, MAXT, XGLDS, true>;
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void *)kern_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess)
+                    return e;
+            }
+            GRAPE_LAUNCH_AS("sweep_pair_kernel", kern_w, grid, block, lds, stream, p.ops, p.x, p.wts, p);
+            return hipGetLastError();
+        }
+    }
+    if (p.dump_w1)
+        return hipErrorInvalidConfiguration;
     auto kern = sweep_pair_kernel<N, SAND, MODE, MAXT, XGLDS>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
