@@ -10,7 +10,7 @@ for f in C3_E1024 C4_E1024 C4_E2048 C4_E128 C4dense_E1024 C4expm_E1024 C4x1 C5_E
   [ -f "$O/${f}_kernel_stats.csv" ] && cp "$O/${f}_kernel_stats.csv" "$P/${TAG}_${f}_kernel_stats.csv"
 done
 for f in C3_phase_stamps.json C4_flow_crossover.txt dpp_fmac.txt exact_time.txt group_overhead_C3.json group_overhead_C3_E128.json \
-         parity.json pipe_mix.txt horner_step.txt C4_whole.txt bench_C3_1gpu_details.json vec32_bench.json dpp_chunks_time.txt dense_forms_time.txt soak.txt \
+         parity.json pipe_mix.txt horner_step.txt wave_placement.txt lbfgs_time.txt C4_whole.txt bench_C3_1gpu_details.json vec32_bench.json dpp_chunks_time.txt dense_forms_time.txt soak.txt \
          bench_C3_1gpu.json bench_C3_1gpu_driver_args.json bench_C3_1gpu_forced_1rank_collective.json \
          bench_C3_general_flow_1gpu.json bench_C3_shard_E128.json bench_C3_shard_E256.json bench_C3_shard_E512.json; do
   [ -s "$O/$f" ] && cp "$O/$f" "$P/${TAG}_$f"
