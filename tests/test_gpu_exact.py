@@ -97,13 +97,15 @@ def test_exact_with_squarings(qoc, oracle):
     assert_parity(F, G, F_ref, G_ref, w.n, what="exact, squaring path")
 
 
-@pytest.mark.parametrize("name,kw", [("C3", {"E": 37, "N": 83}), ("C3", {"E": 3, "N": 500}), ("ref2x2", {})])
+@pytest.mark.parametrize("name,kw", [("C3", {"E": 37, "N": 83}), ("C3", {"E": 3, "N": 500}), ("ref2x2", {}), ("ref2x2_pairs", {})])
 @pytest.mark.parametrize("objective", ["fom", "c1"])
 def test_exact_gradient_from_the_unitary_flow(qoc, oracle, monkeypatch, name, kw, objective):
     """UnitaryGate, Hermitian generators, lane-pair kernel: the exact gradient runs behind the UNITARY flow, whose backward
     sweep leaves W_t = X_t L_{t+1}' = M_t P_t' and tr M -- no debug flow, no X_t / L_t dumps (C3: 0.44 -> 0.28 ms).  Against
     the oracle, against the debug-flow path (GRAPE_EXACT_W1=0) and with the flags that keep the debug flow."""
-    w = qoc.workloads.config(name, **kw) if name != "ref2x2" else qoc.workloads.reference_ensemble("UnitaryGate", 5, 25, 5.0)
+    if name == "ref2x2_pairs":
+        monkeypatch.setenv("GRAPE_SMALL_KERNEL", "pair")            # 2 x 2 on lane pairs: takes the new flow as well
+    w = qoc.workloads.config(name, **kw) if name[:6] != "ref2x2" else qoc.workloads.reference_ensemble("UnitaryGate", 5, 25, 5.0)
     assert w.sys_type == "UnitaryGate"
     F_ref, G_ref = oracle.ensemble_exact(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, variant=0,
                                          objective=0 if objective == "fom" else 1)
@@ -125,7 +127,7 @@ def test_exact_gradient_from_the_unitary_flow(qoc, oracle, monkeypatch, name, kw
         Fk, Gk = eng.eval(w.x)
         assert eng.info["unitary_flow"] == 0
         eng.trajectory(0, costates=True)
-    assert flow_old == 0 and flow_new == (1 if w.n == 4 else flow_new)      # (2 x 2 runs the lane kernel unless asked otherwise)
+    assert flow_old == 0 and flow_new == (1 if w.n == 4 or name == "ref2x2_pairs" else 0)   # (2 x 2 runs the lane kernel unless asked otherwise)
     assert_parity(F, G, F_ref, G_ref, w.n, what=f"{name} exact ({objective}) from the unitary flow")
     assert_parity(F0, G0, F_ref, G_ref, w.n, what=f"{name} exact ({objective}) from the debug flow")
     assert np.max(np.abs(G - G0)) <= 1e-10 * max(1.0, np.max(np.abs(G0))) and abs(F - F0) <= 1e-12
