@@ -53,7 +53,7 @@ __device__ __forceinline__ void publish_via_last_block(DoneSignal d, const doubl
         // partial sums idx = v, v + 1024, ...; a 64-lane xor tree per group of 64; the sixteen groups in order), so the
         // iterates do not depend on which kernel formed the scalars
         __shared__ double s_pw[16];
-        const int KNp = n_total - 1, nw = (int)(blockDim.x >> 6), l = (int)(threadIdx.x & 63);
+        const int KNp = n_total - 1, nw = (int)(blockDim.x >> 6) > 0 ? (int)(blockDim.x >> 6) : 1, l = (int)(threadIdx.x & 63);
         for (int vw = (int)(threadIdx.x >> 6); vw < 16; vw += nw) {
             // (all loads of a partial sum in flight together, then the multiply-adds in the kernel's order: one at a time
             // the sc1 loads cost a trip to L2 each -- 5 us more per evaluation than the separate kernel they replace)
