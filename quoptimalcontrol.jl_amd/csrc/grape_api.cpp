@@ -2371,6 +2371,7 @@ struct LbfgsRun {
     int evals = 0;
     bool hung = false;                            // a wait timed out: the device is presumed hung, nothing is synchronised any more
     bool fused_probe = false;                     // phi / phi' of a trial step come from the evaluation's reduce kernel
+    bool mb = false;                              // accepted steps run on many workgroups (lbfgs_dots_kernel + lbfgs_step_mb_kernel)
 
     grape::DoneSignal signal()
     {
@@ -2404,12 +2405,22 @@ struct LbfgsRun {
             d.probe_sc = st.sc;
             d.probe_out = st.host_sc + 8;
             evals += 1;
-            return eval_device_impl(c, st.xt, st.fgt, lead->stream, 1, d);
+            const int rc = eval_device_impl(c, st.xt, st.fgt, lead->stream, 1, d);
+            return rc ? rc : dots();
         }
         int rc = evaluate(1);
         if (rc) return rc;
         HIP_TRY(c, hipSetDevice(lead->device));
         if (grape::launch_lbfgs_select(st, 1, lead->stream, signal(), 1) != hipSuccess)
+            return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
+        return dots();
+    }
+    // every dot product an accepted step can need, behind the evaluation and off the critical path (nobody waits for it)
+    int dots()
+    {
+        if (!mb) return GRAPE_OK;
+        HIP_TRY(c, hipSetDevice(lead->device));
+        if (grape::launch_lbfgs_dots(st, lead->stream) != hipSuccess)
             return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
         return GRAPE_OK;
     }
@@ -2641,7 +2652,8 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
         lead->dev_pending = false;
     }
     // workspace (freed on return): vectors + history + trial points/results + scalars
-    const size_t n_dbl = 3 * kn + 2 * (size_t)m * kn + m + (size_t)B * kn + (size_t)B * Q + grape::kLbfgsMaxProbes + 8;
+    const size_t n_dbl = 3 * kn + 2 * (size_t)m * kn + m + (size_t)B * kn + (size_t)B * Q + grape::kLbfgsMaxProbes + 8 +
+                         8 + 2 * (size_t)m * m + (size_t)grape::kLbfgsDotBlocks * grape::kLbfgsDotStride;
     double *buf = nullptr, *h_sc = nullptr, *d_h_sc = nullptr;
     HIP_TRY(c, hipMalloc((void **)&buf, sizeof(double) * n_dbl));
     hipError_t he = hipHostMalloc((void **)&h_sc, sizeof(double) * 16, hipHostMallocMapped | hipHostMallocCoherent);
@@ -2670,8 +2682,15 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
     st.xt = p; p += (size_t)B * kn;
     st.fgt = p; p += (size_t)B * Q;
     st.alphas = p; p += grape::kLbfgsMaxProbes;
-    st.sc = p;
+    st.sc = p; p += 8;
+    st.sc_out = p; p += 8;
+    st.gram = p; p += 2 * (size_t)m * m;
+    st.dots = p;
     st.host_sc = d_h_sc;
+    {
+        const char *me = std::getenv("GRAPE_LBFGS_MB");              // 0: the single-workgroup step kernels throughout (A/B, tests)
+        run.mb = o.line_search != 2 && m <= grape::kLbfgsMbM && !(me && me[0] == '0');
+    }
     st.c1 = 1e-4;
     st.c2 = 0.9;
     st.KN = (int32_t)kn;
@@ -2734,9 +2753,17 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
         }
         return GRAPE_OK;
     };
-    auto launch_step = [&](int commit, bool with_signal) -> int {
+    auto launch_step = [&](int commit, bool with_signal, double alpha_acc = 1.0) -> int {
         HIP_TRY(c, hipSetDevice(lead->device));
-        if (grape::launch_lbfgs_step(st, commit, lead->stream, with_signal ? run.signal() : grape::DoneSignal()) != hipSuccess)
+        const grape::DoneSignal ds = with_signal ? run.signal() : grape::DoneSignal();
+        if (commit && run.mb) {
+            // (the dot products of the accepted trial point are in st.dots: lbfgs_dots_kernel ran behind its evaluation)
+            if (grape::launch_lbfgs_step_mb(st, alpha_acc, lead->stream, ds) != hipSuccess)
+                return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
+            std::swap(st.sc, st.sc_out);                      // the new iterate's scalars: what every later launch reads
+            return GRAPE_OK;
+        }
+        if (grape::launch_lbfgs_step(st, commit, lead->stream, ds) != hipSuccess)
             return fail(c, GRAPE_ERR_HIP, "grape_lbfgs: launch failed");
         return GRAPE_OK;
     };
@@ -2793,15 +2820,16 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
                 ++it;
                 committed = true;
                 if (it >= max_it) {                                // the last iterate: commit, wait, no further trial
-                    rc = launch_step(1, true);
+                    rc = launch_step(1, true, alpha);
                     if (rc) return cleanup(rc);
                     continue;                                      // (the wait at the top reads its F and |g|)
                 }
-                rc = launch_step(1, false);
+                rc = launch_step(1, false, alpha);
                 if (rc == GRAPE_OK) rc = launch_probe();
                 if (rc) return cleanup(rc);
             } else {                                               // no bracket: the ladder search takes this iteration
                 ++hz_fallbacks;
+                run.mb = false;                                    // the ladder's pair will have no Gram row: single-workgroup steps from here on
                 bool accepted = false;
                 if (multi) { status = 3; break; }
                 rc = ladder(accepted);

@@ -300,6 +300,10 @@ struct LbfgsState {
     double *alphas;           // B trial step lengths
     double *sc;               // 8 scalars: F, |g|_inf, g'd, gamma, accepted alpha, status (1: no acceptable probe), n_hist, head
     double *host_sc;          // mapped host mirror of sc (8 doubles) + [8] phi, [9] phi' of the last probe
+    // the multi-workgroup step (lbfgs_dots_kernel + lbfgs_step_mb_kernel; nullptr: not in use)
+    double *sc_out;           // the step writes the scalars of the NEXT iterate here (the host swaps sc and sc_out behind it)
+    double *gram;             // S'Y then Y'Y, m x m each, by physical row: grown by the committed pair's row and column
+    double *dots;             // kLbfgsDotBlocks x kLbfgsDotStride partial sums of the last trial point's dot products
     double c1, c2;
     int32_t KN, m;
 };
@@ -307,6 +311,13 @@ hipError_t launch_lbfgs_init(const LbfgsState &st, hipStream_t stream, DoneSigna
 hipError_t launch_lbfgs_direction(const LbfgsState &st, int B, double alpha0, hipStream_t stream);
 hipError_t launch_lbfgs_select(const LbfgsState &st, int B, hipStream_t stream, DoneSignal done, int mode = 0);
 hipError_t launch_lbfgs_trial(const LbfgsState &st, double alpha, hipStream_t stream);
+// the multi-workgroup step: every dot product of {g_t, g, d} with {s_j, y_j, d, g} (+ g_t.g_t, |g_t|_inf) behind an
+// evaluation, by kLbfgsDotBlocks workgroups (nobody waits for it) ...
+constexpr int kLbfgsDotBlocks = 16, kLbfgsDotStride = 128, kLbfgsMbM = 10;
+hipError_t launch_lbfgs_dots(const LbfgsState &st, hipStream_t stream);
+// ... and the commit + next direction + next trial point from those numbers and the Gram matrices: scalars recomputed by
+// every workgroup, vectors element-wise -- no reduction, no hand-off between workgroups
+hipError_t launch_lbfgs_step_mb(const LbfgsState &st, double alpha, hipStream_t stream, DoneSignal done = DoneSignal());
 // one wave: commit trial slot 0 (commit != 0), then the next direction, phi'(0) and the trial point x + d
 hipError_t launch_lbfgs_step(const LbfgsState &st, int commit, hipStream_t stream, DoneSignal done = DoneSignal());
 

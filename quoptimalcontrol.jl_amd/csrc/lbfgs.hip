@@ -836,6 +836,314 @@ hipError_t launch_lbfgs_select(const LbfgsState &st, int B, hipStream_t stream, 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: the accepted step on MANY workgroups (K N up to 16384, m <= 10).  lbfgs_step_reg_kernel spends 21 us per
+// iteration at C3 (rocprofv3, tools/lbfgs_time.py): ONE workgroup pulls the 320 KB of history another workgroup wrote
+// through one CU, and the two-loop recursion's 2 m + 4 reductions run one after the other.  Here
+//   * lbfgs_dots_kernel runs behind EVERY trial evaluation, off the critical path (the host is reading phi, phi' over PCIe
+//     meanwhile): sixteen workgroups form every dot product the step can need -- {g_t, g, d} x {s_j, y_j, d, g}, g_t.g_t,
+//     max |g_t| -- as sixteen rows of partial sums;
+//   * lbfgs_step_mb_kernel commits: every workgroup adds the sixteen rows (fixed order), runs the recursion ON SCALARS --
+//     s_r.q and y_r.r are linear combinations of s_j.g, y_j.g and the Gram matrices S'Y, Y'Y, which grow by the committed
+//     pair's row and column (s.y_j = alpha d.y_j, s_j.y = s_j.g_t - s_j.g, y.y_j = y_j.g_t - y_j.g: all direct dot
+//     products of vectors in memory) -- and writes its slice of s, y, x, g, d = -(gamma (g - sum a_r y_r) + sum c_r s_r)
+//     and x + d.  No reduction, no hand-off between workgroups; phi'(0) = g.d comes out of the same scalars.
+// A pair pushed by lbfgs_select_kernel (the ladder an unbracketed search falls back to) has no Gram row: the host goes back
+// to the single-workgroup kernels for the rest of that run.
+constexpr int kMbVecs = 2 * kLbfgsMbM + 2;          // s_0 .. s_9, y_0 .. y_9, d, g
+constexpr int kMbSums = 3 * kMbVecs + 1;            // {g_t, g, d} x vectors, then g_t.g_t        (67; slot 67: max |g_t|)
+constexpr int kMbThreads = 256;
+
+// v[0..63] per lane -> lane l holds the wave's sum of v[l]: pairwise halving, 32 + 16 + ... + 1 shuffles; one function per
+// level keeps every register index a compile-time constant
+template <int HALF>
+__device__ __forceinline__ void mb_reduce_scatter(double (&v)[kMbSums], int lane)
+{
+    const bool up = (lane & HALF) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+        const double send = up ? v[i] : v[i + HALF];
+        const double keep = up ? v[i + HALF] : v[i];
+        v[i] = keep + __shfl_xor(send, HALF, 64);
+    }
+}
+
+__global__ __launch_bounds__(kMbThreads) void lbfgs_dots_kernel(LbfgsState st)
+{
+    __shared__ double s_red[kMbThreads / 64][kLbfgsDotStride];
+    const int KN = st.KN, m = st.m, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (KN + kLbfgsDotBlocks - 1) / kLbfgsDotBlocks;
+    const int lo = blockIdx.x * per, hi = min(KN, lo + per);
+    double acc[kMbSums], amax = 0.0;
+#pragma unroll
+    for (int k = 0; k < kMbSums; ++k)
+        acc[k] = 0.0;
+    for (int e = lo + threadIdx.x; e < hi; e += kMbThreads) {
+        double vec[kMbVecs];
+#pragma unroll
+        for (int j = 0; j < kLbfgsMbM; ++j) {
+            const size_t at = (size_t)(j < m ? j : 0) * KN + e;
+            vec[j] = st.S[at];
+            vec[kLbfgsMbM + j] = st.Y[at];
+        }
+        const double gt = st.fgt[e], g = st.g[e], d = st.d[e];
+        vec[2 * kLbfgsMbM] = d;
+        vec[2 * kLbfgsMbM + 1] = g;
+#pragma unroll
+        for (int v = 0; v < kMbVecs; ++v) {
+            acc[v] = fma(gt, vec[v], acc[v]);
+            acc[kMbVecs + v] = fma(g, vec[v], acc[kMbVecs + v]);
+            acc[2 * kMbVecs + v] = fma(d, vec[v], acc[2 * kMbVecs + v]);
+        }
+        acc[3 * kMbVecs] = fma(gt, gt, acc[3 * kMbVecs]);
+        amax = fmax(amax, fabs(gt));
+    }
+    // wave sums: a reduce-scatter for the first 64 (lane l ends up with sum l: 63 shuffles, no branch between them -- one
+    // butterfly per value with its `if (lane == 0)` store each ran the 67 shuffle chains one behind the other: 19 us),
+    // butterflies for the last three and the maximum
+    {
+        double tail[kMbSums - 64 + 1];
+#pragma unroll
+        for (int k = 64; k < kMbSums; ++k)
+            tail[k - 64] = acc[k];
+        tail[kMbSums - 64] = amax;
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+#pragma unroll
+            for (int k = 0; k < kMbSums - 64; ++k)
+                tail[k] += __shfl_xor(tail[k], dd, 64);
+            tail[kMbSums - 64] = fmax(tail[kMbSums - 64], __shfl_xor(tail[kMbSums - 64], dd, 64));
+        }
+        mb_reduce_scatter<32>(acc, lane);
+        mb_reduce_scatter<16>(acc, lane);
+        mb_reduce_scatter<8>(acc, lane);
+        mb_reduce_scatter<4>(acc, lane);
+        mb_reduce_scatter<2>(acc, lane);
+        mb_reduce_scatter<1>(acc, lane);
+        s_red[wave][lane] = acc[0];
+#pragma unroll
+        for (int k = 64; k <= kMbSums; ++k)
+            s_red[wave][k] = tail[k - 64];           // (every lane holds the same value)
+    }
+    __syncthreads();
+    if (threadIdx.x <= kMbSums) {
+        double t = s_red[0][threadIdx.x];
+        for (int w = 1; w < kMbThreads / 64; ++w)
+            t = threadIdx.x == kMbSums ? fmax(t, s_red[w][threadIdx.x]) : t + s_red[w][threadIdx.x];
+        st.dots[(size_t)blockIdx.x * kLbfgsDotStride + threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(kMbThreads) void lbfgs_step_mb_kernel(LbfgsState st, double alpha, DoneSignal done)
+{
+    constexpr int M = kLbfgsMbM, LR = M + 1;
+    __shared__ double s_tot[kLbfgsDotStride];
+    __shared__ double s_SY[M][M], s_YY[M][M], s_rho[M];
+    __shared__ double s_coef[2 * LR + 8];            // a_r, c_r by LOGICAL row (0: the committed pair), then the scalars below
+    const int KN = st.KN, m = st.m, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- one batch of loads: nothing here waits for another load
+    const double sc_gamma = st.sc[3], sc_n = st.sc[6], sc_head = st.sc[7];
+    const double F_trial = st.fgt[KN];                            // (alpha: the accepted step length, from the host -- this kernel
+    const int e = blockIdx.x * kMbThreads + threadIdx.x;           //  writes nothing another of its workgroups may still read)
+    const bool in = e < KN;
+    const int ce = in ? e : 0;
+    const double gt = st.fgt[ce], g_old = st.g[ce], d_old = st.d[ce], x_new = st.xt[ce];
+    double Sr[M], Yr[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const size_t at = (size_t)(j < m ? j : 0) * KN + ce;
+        Sr[j] = st.S[at];
+        Yr[j] = st.Y[at];
+    }
+    if (threadIdx.x <= kMbSums) {
+        double part[kLbfgsDotBlocks];
+#pragma unroll
+        for (int b = 0; b < kLbfgsDotBlocks; ++b)
+            part[b] = st.dots[(size_t)b * kLbfgsDotStride + threadIdx.x];
+        double t = part[0];
+#pragma unroll
+        for (int b = 1; b < kLbfgsDotBlocks; ++b)
+            t = threadIdx.x == kMbSums ? fmax(t, part[b]) : t + part[b];
+        s_tot[threadIdx.x] = t;
+    }
+    for (int q = threadIdx.x; q < 2 * m * m; q += kMbThreads) {
+        const int which = q / (m * m), rem = q - which * m * m;
+        (which ? s_YY : s_SY)[rem / m][rem % m] = st.gram[q];
+    }
+    if ((int)threadIdx.x < m)
+        s_rho[threadIdx.x] = st.rho[threadIdx.x];
+    __syncthreads();
+    const int n_old = (int)sc_n, head_old = (int)sc_head;
+    auto row_of = [&](int h) { const int j = head_old - h; return j < 0 ? j + m : j; };    // logical stored row h (0 = newest) -> physical
+    // products of the three vectors with the history (physical rows), d and g
+    auto P = [&](int a, int v) { return s_tot[a * kMbVecs + v]; };        // a: 0 g_t, 1 g, 2 d;  v: j | M + j | 2M (d) | 2M+1 (g)
+    const double gtgt = s_tot[3 * kMbVecs];
+    const double sy = alpha * (P(0, 2 * M) - P(1, 2 * M));
+    const double yy = gtgt - 2.0 * P(0, 2 * M + 1) + P(1, 2 * M + 1);
+    const double ss = alpha * alpha * P(2, 2 * M);
+    const bool push = sy > 1e-10 * sqrt(ss * yy) && yy > 0.0;
+    const int head = push ? (n_old == 0 ? 0 : (head_old + 1 == m ? 0 : head_old + 1)) : head_old;
+    const int n_hist = push ? (n_old < m ? n_old + 1 : m) : n_old;
+    const int n_rows = push ? (n_old < m ? n_old : m - 1) : n_old;        // stored rows in the recursion (a full buffer drops its oldest)
+    const double gamma = push ? sy / yy : sc_gamma, rho_new = push ? 1.0 / sy : 0.0;
+    const int off = push ? 1 : 0, R = n_rows + off;
+    // the Gram entries, rho and the products with g_t by LOGICAL row (0: the committed pair, then the stored rows newest first;
+    // zero beyond the R rows in use): one entry per thread, so that the recursion below reads LDS at constant indices
+    __shared__ double s_LSY[LR][LR], s_LYY[LR][LR], s_lrho[LR], s_lsg[LR], s_lyg[LR];
+    for (int q = threadIdx.x; q < LR * LR; q += kMbThreads) {
+        const int r1 = q / LR, r2 = q - r1 * LR;
+        double vsy = 0.0, vyy = 0.0;
+        if (r1 < R && r2 < R) {
+            if (r1 < off && r2 < off) {
+                vsy = sy;
+                vyy = yy;
+            } else if (r1 < off) {
+                const int j = row_of(r2 - off);
+                vsy = alpha * P(2, M + j);                                 // s.y_j = alpha d.y_j
+                vyy = P(0, M + j) - P(1, M + j);                           // y.y_j = y_j.g_t - y_j.g
+            } else if (r2 < off) {
+                const int j = row_of(r1 - off);
+                vsy = P(0, j) - P(1, j);                                   // s_j.y = s_j.g_t - s_j.g
+                vyy = P(0, M + j) - P(1, M + j);
+            } else {
+                vsy = s_SY[row_of(r1 - off)][row_of(r2 - off)];
+                vyy = s_YY[row_of(r1 - off)][row_of(r2 - off)];
+            }
+        }
+        s_LSY[r1][r2] = vsy;
+        s_LYY[r1][r2] = vyy;
+        if (r2 == 0) {
+            const bool on = r1 < R, fresh = r1 < off;
+            const int j = on && !fresh ? row_of(r1 - off) : 0;
+            s_lrho[r1] = !on ? 0.0 : (fresh ? rho_new : s_rho[j]);
+            s_lsg[r1] = !on ? 0.0 : (fresh ? alpha * P(0, 2 * M) : P(0, j));                 // s_r . g_t
+            s_lyg[r1] = !on ? 0.0 : (fresh ? gtgt - P(0, 2 * M + 1) : P(0, M + j));          // y_r . g_t
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double a_r[LR], c_r[LR];
+#pragma unroll
+        for (int r = 0; r < LR; ++r) {               // newest -> oldest: a_r = rho_r s_r.q_r,  s_r.q_r = s_r.g - sum_{i<r} a_i s_r.y_i
+            double t = s_lsg[r];
+#pragma unroll
+            for (int i = 0; i < r; ++i)
+                t = fma(-a_r[i], s_LSY[r][i], t);
+            a_r[r] = s_lrho[r] * t;                  // (rows beyond R: rho = 0)
+        }
+#pragma unroll
+        for (int r = LR - 1; r >= 0; --r) {          // oldest -> newest: b_r = rho_r y_r.r,  c_r = a_r - b_r
+            double t = s_lyg[r];
+#pragma unroll
+            for (int i = 0; i < LR; ++i)
+                t = fma(-a_r[i], s_LYY[r][i], t);                  // y_r.q_n,  q_n = g - sum a_i y_i
+            t *= gamma;
+#pragma unroll
+            for (int i = LR - 1; i > r; --i)
+                t = fma(c_r[i], s_LSY[i][r], t);                   // + sum_{i older} c_i s_i.y_r
+            c_r[r] = a_r[r] - s_lrho[r] * t;                       // (zero beyond R: a_r = 0, rho = 0)
+        }
+        // phi'(0) of the next search: g.d = -(gamma (g.g - sum a_r y_r.g) + sum c_r s_r.g)
+        double w = gtgt, u = 0.0;
+#pragma unroll
+        for (int r = 0; r < LR; ++r) {
+            w = fma(-a_r[r], s_lyg[r], w);
+            u = fma(c_r[r], s_lsg[r], u);
+        }
+        double dg = -fma(gamma, w, u);
+        const bool reset = !(dg < 0.0);              // not a descent direction (or NaN): steepest descent, the history is dropped
+        if (reset) dg = -gtgt;
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < LR; ++r) {
+                s_coef[r] = reset ? 0.0 : a_r[r];
+                s_coef[LR + r] = reset ? 0.0 : c_r[r];
+            }
+            s_coef[2 * LR] = dg;
+            s_coef[2 * LR + 1] = reset ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+    const double dg = s_coef[2 * LR];
+    const bool reset = s_coef[2 * LR + 1] != 0.0;
+    // ---- this workgroup's elements
+    if (in) {
+        const double s_e = alpha * d_old, y_e = gt - g_old;
+        double wv = gt, uv = 0.0;
+        if (push) {
+            wv = fma(-s_coef[0], y_e, wv);
+            uv = s_coef[LR] * s_e;
+        }
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const int hq = head_old - (j < m ? j : 0), h = hq < 0 ? hq + m : hq;    // physical row j -> logical stored row
+            const bool on = j < m && h < n_rows && !(push && j == head);
+            const double ar = on ? s_coef[h + off] : 0.0, cr = on ? s_coef[LR + h + off] : 0.0;
+            wv = fma(-ar, on ? Yr[j] : 0.0, wv);
+            uv = fma(cr, on ? Sr[j] : 0.0, uv);
+        }
+        const double q = reset ? gt : fma(gamma, wv, uv);
+        if (push) {
+            st.S[(size_t)head * KN + e] = s_e;
+            st.Y[(size_t)head * KN + e] = y_e;
+        }
+        st.x[e] = x_new;
+        st.g[e] = gt;
+        st.d[e] = -q;
+        st.xt[e] = x_new - q;
+    }
+    if (blockIdx.x == 0) {
+        // the committed pair's row and column of the Gram matrices (entries against rows that have left the history are never
+        // read again), rho, the scalars of the new iterate -- into sc_out: the other workgroups may still be reading sc
+        if (push && (int)threadIdx.x < m) {
+            const int j = threadIdx.x, hq = head_old - j, h = hq < 0 ? hq + m : hq;
+            double *GSY = st.gram, *GYY = st.gram + (size_t)m * m;
+            if (j == head) {
+                GSY[(size_t)head * m + head] = sy;
+                GYY[(size_t)head * m + head] = yy;
+                st.rho[head] = rho_new;
+            } else if (h < n_rows) {
+                GSY[(size_t)head * m + j] = alpha * P(2, M + j);
+                GSY[(size_t)j * m + head] = P(0, j) - P(1, j);
+                GYY[(size_t)head * m + j] = P(0, M + j) - P(1, M + j);
+                GYY[(size_t)j * m + head] = P(0, M + j) - P(1, M + j);
+            }
+        }
+        if (threadIdx.x == 64) {
+            double o[8];
+            o[0] = F_trial;
+            o[1] = s_tot[kMbSums];                   // |g|_inf of the new iterate
+            o[2] = dg;
+            o[3] = gamma;
+            o[4] = alpha;
+            o[5] = 0.0;
+            o[6] = reset ? 0.0 : (double)n_hist;
+            o[7] = (double)head;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                st.sc_out[i] = o[i];
+                st.host_sc[i] = o[i];
+            }
+            if (done.flag) {
+                __threadfence_system();
+                __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
+hipError_t launch_lbfgs_dots(const LbfgsState &st, hipStream_t stream)
+{
+    GRAPE_LAUNCH(lbfgs_dots_kernel, dim3(kLbfgsDotBlocks), dim3(kMbThreads), 0, stream, st);
+    return hipGetLastError();
+}
+
+hipError_t launch_lbfgs_step_mb(const LbfgsState &st, double alpha, hipStream_t stream, DoneSignal done)
+{
+    GRAPE_LAUNCH(lbfgs_step_mb_kernel, dim3((st.KN + kMbThreads - 1) / kMbThreads), dim3(kMbThreads), 0, stream, st, alpha, done);
+    return hipGetLastError();
+}
+
 // trial slot 0 <- x + alpha d
 __global__ __launch_bounds__(kLbfgsThreads) void lbfgs_trial_kernel(LbfgsState st, double alpha)
 {

@@ -26,6 +26,8 @@ hipError_t launch_lbfgs_init(const LbfgsState &, hipStream_t, DoneSignal) { retu
 hipError_t launch_lbfgs_direction(const LbfgsState &, int, double, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_lbfgs_select(const LbfgsState &, int, hipStream_t, DoneSignal, int) { return hipErrorNoDevice; }
 hipError_t launch_lbfgs_trial(const LbfgsState &, double, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_lbfgs_dots(const LbfgsState &, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_lbfgs_step_mb(const LbfgsState &, double, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
 hipError_t launch_lbfgs_step(const LbfgsState &, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
 hipError_t launch_exact_grad(int, int, const ExactParams &, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_exact_tile(int, int, const TileParams &, int, hipStream_t) { return hipErrorNoDevice; }

@@ -158,6 +158,60 @@ def test_probe_closed_by_the_reduction_is_the_probe_kernel(qoc, monkeypatch, cas
     assert ia["evaluations"] >= 3
 
 
+@pytest.mark.parametrize("problem", ["c3_state_transfer", "c3_unitary_gate", "far_start", "tile", "small", "group"])
+@pytest.mark.parametrize("mode", ["hagerzhang", "optim"])
+def test_accepted_steps_on_many_workgroups(qoc, monkeypatch, problem, mode):
+    """An accepted step is committed by lbfgs_dots_kernel (every dot product, behind the evaluation) + lbfgs_step_mb_kernel
+    (recursion on scalars, vectors element-wise, no reduction) instead of one workgroup walking the history: the same
+    algorithm in exact arithmetic -- the iterates agree to rounding for several iterations, the runs reach the same minimum;
+    a UnitaryGate problem mixes in ladder iterations (single-workgroup steps from the first one on)."""
+    rng = np.random.default_rng(23)
+    kw = {}
+    if problem in ("c3_state_transfer", "far_start", "group"):
+        w = qoc.workloads.config("C3", E=16, N=200 if problem != "far_start" else 90)
+        rho0 = np.zeros((4, 4), complex); rho0[0, 0] = 1
+        psi = np.array([1, 1j, -1, 0.5]) / np.linalg.norm([1, 1j, -1, 0.5])
+        Xi = np.broadcast_to(rho0, (w.E, 4, 4)).copy()
+        Xt = np.broadcast_to(np.outer(psi, psi.conj()), (w.E, 4, 4)).copy()
+        args = ("StateTransfer", w.A, w.B, Xi, Xt, w.wts, w.T, w.N)
+        x0 = w.x if problem != "far_start" else 4.0 * w.x
+        if problem == "group":
+            kw = dict(devices=[0, 0, 0], flags=qoc.engine.FLAG_GROUP_PEER_SUM)
+    elif problem == "c3_unitary_gate":
+        w = qoc.workloads.config("C3", E=16, N=150)
+        args = (w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N)
+        x0 = w.x
+    elif problem == "small":
+        w = qoc.workloads.reference_ensemble("StateTransfer", 5, 25, 5.0)          # K N = 50
+        args = (w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N)
+        x0 = w.x
+    else:
+        n, E, K, N = 12, 4, 3, 300                                                # K N = 900, MFMA tile kernels
+
+        def herm():
+            M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+            return (M + M.conj().T) / 2
+        A = np.array([herm() for _ in range(E)]) * 0.4
+        B = np.array([[herm() for _ in range(K)] for _ in range(E)]) * 0.4
+        Xi = np.array([herm() for _ in range(E)])
+        Xt = np.array([herm() for _ in range(E)])
+        args = ("StateTransfer", A, B, Xi, Xt, np.ones(E) / E, 1.5, N)
+        x0 = 0.3 * rng.uniform(-1, 1, (K, N))
+    out = {}
+    for mb in ("1", "0"):
+        monkeypatch.setenv("GRAPE_LBFGS_MB", mb)
+        with qoc.GrapeEngine(*args, **kw) as eng:
+            x4, i4 = eng.lbfgs(x0, iterations=4, line_search=mode)
+            x25, i25 = eng.lbfgs(x0, iterations=25, line_search=mode)
+            F25, _ = eng.eval(x25)
+        out[mb] = (x4, i4, x25, i25, F25)
+    (xa4, ia4, xa, ia, Fa), (xb4, ib4, xb, ib, Fb) = out["1"], out["0"]
+    assert ia4["evaluations"] == ib4["evaluations"] and ia4["iterations"] == ib4["iterations"]
+    assert np.abs(xa4 - xb4).max() <= 1e-8 * max(1.0, np.abs(xb4).max())          # four iterations: rounding only
+    assert abs(Fa - ia["minimum"]) <= 1e-12 and abs(Fb - ib["minimum"]) <= 1e-12   # the returned point IS the reported minimum
+    assert abs(ia["minimum"] - ib["minimum"]) <= 5e-3 * max(abs(ib["minimum"]), 1e-3) + 1e-6
+
+
 def test_lbfgs_on_a_device_group_and_with_a_communicator(qoc):
     """Multi-device contexts run the Hager-Zhang search (vectors on the first device, every evaluation the sharded one):
     three shards on GPU 0 through the peer sum, and a 1-rank RCCL communicator, against the single-device run."""

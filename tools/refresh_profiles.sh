@@ -39,7 +39,7 @@ python3 tools/group_overhead.py --ensemble 128 > "$OUT/group_overhead_C3_E128.js
 ./tools/ubench/dpp_fmac > "$OUT/dpp_fmac.txt" 2>&1
 ./tools/ubench/horner_step > "$OUT/horner_step.txt" 2>&1
 ./tools/ubench/wave_placement > "$OUT/wave_placement.txt" 2>&1
-( python3 tools/lbfgs_time.py 30; python3 tools/lbfgs_time.py 30 optim; GRAPE_LBFGS_FUSED_PROBE=0 python3 tools/lbfgs_time.py 30 optim ) > "$OUT/lbfgs_time.txt" 2> /dev/null
+( python3 tools/lbfgs_time.py 30; python3 tools/lbfgs_time.py 30 optim; GRAPE_LBFGS_MB=0 python3 tools/lbfgs_time.py 30; GRAPE_LBFGS_MB=0 python3 tools/lbfgs_time.py 30 optim; GRAPE_LBFGS_MB=0 GRAPE_LBFGS_FUSED_PROBE=0 python3 tools/lbfgs_time.py 30 optim ) > "$OUT/lbfgs_time.txt" 2> /dev/null
 for E in 1024 1536 2048 3072 4096; do for W in 0 1; do
   echo "E=$E whole=$W $(GRAPE_ACTION=1 GRAPE_ACT_WHOLE=$W python3 bench.py --config C4 --ensemble $E --steps 20 --warmup 5 --blocks 2 --no-extra --no-cpu-baseline --verbose 2>/dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "evals/s", round(d["ms_per_step"],3), "ms", [round(k["avg_us"],1) for k in d["roofline"]["kernels"]])')"
 done; done > "$OUT/C4_whole.txt"
