@@ -158,7 +158,7 @@ def test_probe_closed_by_the_reduction_is_the_probe_kernel(qoc, monkeypatch, cas
     assert ia["evaluations"] >= 3
 
 
-@pytest.mark.parametrize("problem", ["c3_state_transfer", "c3_unitary_gate", "far_start", "tile", "small", "group"])
+@pytest.mark.parametrize("problem", ["c3_state_transfer", "c3_unitary_gate", "far_start", "tile", "small", "group", "long"])
 @pytest.mark.parametrize("mode", ["hagerzhang", "optim"])
 def test_accepted_steps_on_many_workgroups(qoc, monkeypatch, problem, mode):
     """An accepted step is committed by lbfgs_dots_kernel (every dot product, behind the evaluation) + lbfgs_step_mb_kernel
@@ -167,8 +167,8 @@ def test_accepted_steps_on_many_workgroups(qoc, monkeypatch, problem, mode):
     a UnitaryGate problem mixes in ladder iterations (single-workgroup steps from the first one on)."""
     rng = np.random.default_rng(23)
     kw = {}
-    if problem in ("c3_state_transfer", "far_start", "group"):
-        w = qoc.workloads.config("C3", E=16, N=200 if problem != "far_start" else 90)
+    if problem in ("c3_state_transfer", "far_start", "group", "long"):
+        w = qoc.workloads.config("C3", E=16, N={"far_start": 90, "long": 1100}.get(problem, 200))      # long: K N = 4400
         rho0 = np.zeros((4, 4), complex); rho0[0, 0] = 1
         psi = np.array([1, 1j, -1, 0.5]) / np.linalg.norm([1, 1j, -1, 0.5])
         Xi = np.broadcast_to(rho0, (w.E, 4, 4)).copy()
