@@ -105,9 +105,9 @@ def _stats_us(ms):
     import numpy as np
     a = np.asarray(ms, dtype=float) * 1e3
     if a.size == 0:
-        return {"kernel_avg_us": 0.0, "kernel_min_us": 0.0, "kernel_median_us": 0.0, "kernel_launches": 0}
+        return {"kernel_avg_us": 0.0, "kernel_min_us": 0.0, "kernel_median_us": 0.0, "kernel_max_us": 0.0, "kernel_launches": 0}
     return {"kernel_avg_us": float(a.mean()), "kernel_min_us": float(a.min()), "kernel_median_us": float(np.median(a)),
-            "kernel_launches": int(a.size)}
+            "kernel_max_us": float(a.max()), "kernel_launches": int(a.size)}
 
 
 _ACT_TOL = 3.7e-16
@@ -327,6 +327,43 @@ def committed_phases(local, kernel_us):
         return None
 
 
+def box_record(qoc, w, dev_index, kernel_us, evals=40):
+    """Which box, at which clock: the record a reader needs to tell a slower kernel from a slower machine.
+    Right behind the timed blocks the same workload runs `evals` times on a context built with GRAPE_FLAG_PHASE_STAMPS: every
+    wave of the sweep kernel stamps the shader-cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) at
+    its start and end, so  clock = cycles / real time  is the clock the SWEEP KERNEL ITSELF ran at (a one-wave probe kernel
+    would see the idle boost clock instead).  kernel_cycles = kernel_us x clock is the box-independent figure
+    tests/test_gpu_perf_gate.py holds the kernel to."""
+    import numpy as np
+    import torch
+    prop = torch.cuda.get_device_properties(dev_index)
+    rec = {"arch": getattr(prop, "gcnArchName", ""), "name": prop.name, "cus": int(prop.multi_processor_count),
+           "hbm_gib": round(prop.total_memory / 2 ** 30, 1)}
+    if w.n > 4:
+        return rec                                     # the stamps live in the lane / lane-pair kernels
+    try:
+        with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, device=dev_index,
+                             flags=qoc.engine.FLAG_PHASE_STAMPS) as eng:
+            clocks, cyc = [], []
+            for i in range(evals):
+                eng.eval(w.x)
+                if i >= evals // 2 and i % 4 == 0:
+                    st = eng.phase_stamps().astype(np.int64)
+                    real_ns = (st[:, 6] - st[:, 5]) * 10.0
+                    tot = st[:, 4] - st[:, 0]
+                    ok = real_ns > 0
+                    clocks.append(float(np.median(tot[ok] / real_ns[ok])))
+                    cyc.append(float(np.median(tot[ok])))
+        rec["clock_ghz"] = float(np.median(clocks))
+        rec["clock_ghz_min_max"] = [float(min(clocks)), float(max(clocks))]
+        rec["wave_cycles_median"] = float(np.median(cyc))          # one wave's start-to-end cycle count (stamped build)
+        rec["kernel_cycles"] = {k: kernel_us[k] * 1e3 * rec["clock_ghz"] for k in ("min", "median", "max") if kernel_us.get(k)}
+        rec["how"] = "clock = s_memtime cycles / s_memrealtime (100 MHz) over every wave of the sweep kernel, stamped build, right after the timed blocks; kernel_cycles = kernel_us x clock"
+    except Exception as exc:                           # noqa: BLE001 -- a record must not kill the headline
+        rec["clock_error"] = repr(exc)[:200]
+    return rec
+
+
 def clock_ramp(step, seconds=0.35, reduce_max=None):
     """Untimed evaluations for at least `seconds` before the first timed block, whatever --warmup says: a 20-step run
     of 0.1 ms calls used to be measured on a GPU still raising its clock (round 2: 83.7 us kernels in the driver's
@@ -425,7 +462,7 @@ def shard_overheads(qoc, cfg_name, dev_index, sizes=(512, 256, 128)):
     for E in sizes:
         w = qoc.workloads.config(cfg_name, E=E)
         with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, device=dev_index,
-                             flags=qoc.engine.FLAG_TIME_KERNELS) as eng:
+                             flags=qoc.engine.FLAG_TIME_KERNELS | qoc.engine.FLAG_TIME_SAMPLED) as eng:   # (an event pair costs ~5 us: every 8th call, as the headline)
             xf = np.ascontiguousarray(w.x.T)
             call = eng.bind_eval(xf, np.empty_like(xf))
             for _ in range(20):
@@ -539,7 +576,7 @@ def compact_roofline(r):
     out = {k: _r(r[k], 5) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_model_s", "traffic") if k in r}
     out["kernel"] = r.get("kernel")
     out["kernel_us"] = {"avg": _r(r.get("kernel_avg_us")), "min": _r(r.get("kernel_min_us")), "median": _r(r.get("kernel_median_us")),
-                        "launches": r.get("kernel_launches")}
+                        "max": _r(r.get("kernel_max_us")), "launches": r.get("kernel_launches")}
     if "bytes_per_launch" in r:
         out["bytes_per_launch"] = r["bytes_per_launch"]
         out["model_s_bytes_per_launch"] = r["model_s_equivalent"]["algorithmic_bytes_per_launch"]
@@ -565,6 +602,9 @@ def compact(out):
         c["config"]["collective"] = cfg["collective"]
     c["blocks_s"] = [_r(t) for t in out["blocks"]["seconds"]]
     c["roofline"] = compact_roofline(out["roofline"])
+    if "box" in out:
+        c["box"] = {k: (_r(v, 5) if not isinstance(v, (dict, list)) else ({kk: _r(vv, 6) for kk, vv in v.items()} if isinstance(v, dict) else [_r(x, 5) for x in v]))
+                    for k, v in out["box"].items() if k != "how"}
     cb = out.get("cpu_baseline")
     if cb:
         c["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
@@ -817,6 +857,8 @@ def main():
         traffic = committed_traffic(f"{args.config}_E{local.E}")
         roof = roofline(local, info, samples, evals_per_s, world, traffic, committed_mfma(f"{args.config}_E{local.E}"), names)
         n_joined = sg.comm_size if (world > 1 or args.force_dist) else 1
+        box = box_record(qoc, local, dev_index, {"min": roof["kernel_min_us"], "median": roof["kernel_median_us"],
+                                                 "max": roof["kernel_max_us"]})
         out = {
             "metric": "GRAPE gradient-evals/sec", "value": value, "unit": "gradient-evals/s",
             "n_gpus": n_joined, "steps": args.steps, "warmup": args.warmup,
@@ -836,6 +878,7 @@ def main():
                        "untimed_ramp_steps": ramp_steps},
             "member_evals_per_s": evals_per_s * E_total,
             "roofline": roof,
+            "box": box,
             "F": float(F_last),
         }
         if extra is not None:

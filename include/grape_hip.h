@@ -129,8 +129,9 @@ typedef struct grape_config {
                                   1 = exact derivative of the objective (what ADGRAPE gets from Zygote,
                                   src/GRAPE.jl:12-20; cf. expm_exact_gradient, src/grape_tools.jl:26-57).  Runs behind the
                                   debug flow (every X_t, L_t stored: grape_get_trajectory returns them), except for
-                                  UnitaryGate problems with Hermitian generators at n = 4, which take the unitary flow
-                                  (grape_info.unitary_flow = 1, states_stored = 0) unless GRAPE_FLAG_KEEP_COSTATES is set */
+                                  UnitaryGate problems with Hermitian generators at n = 2 or 4 (the lane-pair kernel),
+                                  which take the unitary flow (grape_info.unitary_flow = 1, states_stored = 0:
+                                  grape_get_trajectory serves propagators only) unless GRAPE_FLAG_KEEP_COSTATES is set */
     int32_t objective;         /* grape_objective: 0 = fom_func (src/cost_functions.jl:99-111),
                                   1 = the ADGRAPE functional C1(Xt, U Xi [U']) for every system type
                                   (src/solve.jl:268-291, :317-361); needs gradient = 1 */
@@ -231,7 +232,11 @@ int grape_comm_attach(grape_ctx *ctx, const grape_comm_id *id, int32_t rank, int
  * stores its row into its slot of every rank's mailbox (one hop over xGMI), waits -- bounded -- until its own mailbox holds
  * all n_ranks rows, sums them in rank order (bitwise the sum every other rank, and an in-process group with the same
  * shards, gets) and publishes to its host as a single-GPU evaluation does.  A rank that never shows up turns into
- * GRAPE_ERR_COMM on the others after GRAPE_EVAL_TIMEOUT_S (5 s at least, 120 s at most), never into a hang.  Ranks may share
+ * GRAPE_ERR_COMM on the others after GRAPE_EVAL_TIMEOUT_S (5 s at least, 120 s at most), never into a hang.  The blocking
+ * entry points return that code themselves; the device-pointer entry points (grape_eval_device, grape_eval_batch_device, the
+ * evaluations inside grape_lbfgs) cannot -- for them an exchange that gave up writes NaN over [G, F] (never a partial sum)
+ * and sets a host-visible word: grape_lbfgs stops with GRAPE_ERR_COMM at its next wait, and every later call on the context
+ * returns GRAPE_ERR_COMM (the peers are out of step: the context is retired).  Ranks may share
  * a GPU (tests).  n_ranks <= 8; mutually exclusive with grape_comm_attach; collective like it. */
 int grape_ipc_export(grape_ctx *ctx, int32_t n_ranks, grape_ipc_handle *out);
 int grape_ipc_attach(grape_ctx *ctx, const grape_ipc_handle *handles, int32_t rank, int32_t n_ranks);

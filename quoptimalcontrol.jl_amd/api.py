@@ -183,6 +183,18 @@ def fom_and_gradient(prob, alg, x, engine=None):
             eng.close()
 
 
+def _json_default(v):
+    """Values `json` does not know inside alg.optim_options: NumPy scalars / arrays become numbers / lists, anything else
+    (callables, objects) its repr -- a solve that succeeded must stay savable (the reference's BSON takes any value)."""
+    if isinstance(v, np.generic):
+        return v.item()
+    if isinstance(v, np.ndarray):
+        return v.tolist()
+    if isinstance(v, (set, frozenset, tuple)):
+        return list(v)
+    return repr(v)
+
+
 def save(solres, file_path):
     """src/tools.jl:59-72: every field of a SolutionResult / EnsembleSolutionResult but the optimiser's own result object
     (the reference drops it too: `fieldnames(...)[2:end]`) into one file -- NumPy's .npz here instead of BSON.  The
@@ -206,7 +218,7 @@ def save(solres, file_path):
         "alg_fields": np.array(json.dumps({"expm_method": alg.expm_method, "optim_options": alg.optim_options,
                                             "device": int(alg.device), "optimizer": alg.optimizer,
                                             "devices": None if alg.devices is None else [int(v) for v in alg.devices],
-                                            "peer_sum": bool(alg.peer_sum)})),
+                                            "peer_sum": bool(alg.peer_sum)}, default=_json_default)),
     }
     if ens:
         members = init_ensemble(prob)

@@ -88,7 +88,10 @@ struct grape_ctx {
     double *h_fg = nullptr;       // pinned + device-mapped, K*N + 1 doubles: the reduce kernel writes [G, F] here
     double *d_h_fg = nullptr;     // device address of h_fg
     // host-visible completion of an evaluation: the final kernel's last workgroup publishes `seq` in h_flag
+    // ([1]: set by a mailbox exchange of the device-pointer path that gave up; [8 ..]: one flag per workgroup of
+    // reduce_rows_mf_kernel, the publication without a device-side fan-in -- mf_wait of them belong to the evaluation in flight)
     unsigned long long *h_flag = nullptr, *d_h_flag = nullptr;
+    int mf_wait = 0;
     unsigned *d_done_counter = nullptr;
     bool peer_sum = false;                     // group: [G, F] summed on the first device through peer copies (no RCCL)
     bool peer_direct = false;                  // group: the first device can read every shard's memory (peer access): the sum reads the rows in place
@@ -106,6 +109,7 @@ struct grape_ctx {
     int ipc_ranks = 0;                         // > 1: attached
     int ipc_alloc_ranks = 0;                   // ranks the own mailbox was sized for
     unsigned long long ipc_evals = 0, ipc_count[2] = {0, 0};
+    bool broken = false;                       // a partial failure left counters / peers out of step: every further evaluation is refused
     bool thin = false;                         // rank-one states: matrix-vector chain (sweep_thin.hip)
     bool herm_ctrl = false;                    // every B_c Hermitian
     double2 *d_vecs = nullptr;                 // thin: per member [v0 | wT], 16 complex each
@@ -142,6 +146,7 @@ struct grape_ctx {
     int tp_G = 0, tp_g = 0;                    // two-level scan: groups, chunks per group
     double2 *d_tp_a = nullptr;
     bool direct_publish = true;                // GRAPE_DIRECT_PUBLISH=0: always go through the reduce kernel
+    bool mf_publish = true;                    // GRAPE_MF_PUBLISH=0: reduce_rows_kernel's staged publication instead of per-workgroup host flags
     unsigned long long seq = 0;
     std::string kernel_log;                    // names of the kernels the last evaluation launched (grape_get_kernel_names)
     int x_upload = 1;             // 0: hipMemcpyAsync, 1: copy kernel reading the mapped staging buffer,
@@ -589,13 +594,14 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->d_h_stage, c->h_stage, 0);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_fg, sizeof(double) * Q * Bn, hflags);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->d_h_fg, c->h_fg, 0);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_flag, 64, hflags);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_flag, 64 + sizeof(unsigned long long) * grape::kMaxMflags, hflags);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->d_h_flag, c->h_flag, 0);
-    if (e == hipSuccess) { *c->h_flag = 0; e = alloc((void **)&c->d_done_counter, 64); }
+    if (e == hipSuccess) { std::memset(c->h_flag, 0, 64 + sizeof(unsigned long long) * grape::kMaxMflags); e = alloc((void **)&c->d_done_counter, 64); }
     if (e == hipSuccess) e = hipMemset(c->d_done_counter, 0, 64);
     {
         const char *dp = std::getenv("GRAPE_DIRECT_PUBLISH");
         c->direct_publish = !(dp && dp[0] == '0');
+        c->mf_publish = !env_off("GRAPE_MF_PUBLISH");
     }
     {
         // x upload path.  Default: if the device exposes its memory to the CPU (large BAR), the host
@@ -1075,6 +1081,18 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                 hg = grape_host::hermitian_to_rounding((mm == 0) ? A + 2 * k * nn : B + 2 * (k * K + (mm - 1)) * nn, n);
         c->exact_w1 = hg;
         if (hg) c->unitary = true;
+    }
+    if (c->cfg.gradient == GRAPE_GRADIENT_EXACT && c->family == 0 && !(c->cfg.flags & GRAPE_FLAG_KEEP_COSTATES)) {
+        // the W_t flow writes no costates: their E N n^2 16 B bytes go back (and return if a later upload needs the debug flow)
+        const size_t cb = sizeof(double2) * c->ws_elems * (size_t)c->B;
+        if (c->exact_w1 && c->d_costates) {
+            (void)hipFree(c->d_costates);
+            c->d_costates = nullptr;
+            c->bytes -= cb;
+        } else if (!c->exact_w1 && !c->d_costates) {
+            HIP_TRY(c, hipMalloc((void **)&c->d_costates, cb));
+            c->bytes += cb;
+        }
     }
     {                                                        // Hermitian initial / target operators (square states only)
         bool hs = c->m == c->cfg.n;
@@ -1715,6 +1733,7 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
         return GRAPE_OK;
     }
     KernelLogScope log_scope(&c->kernel_log);
+    c->mf_wait = 0;
     SweepParams p{};
     p.ops = c->d_ops;
     p.x = d_x;
@@ -1806,8 +1825,11 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
                                         stream, done));
     else if (direct || tile_folds_reduce(c, n_x))
         ;                                                    // the sweep / forms kernel has written [G, F] (and the flag)
-    else if (c->family == 0)
+    else if (c->family == 0) {
+        if (done.mflags && done.flag && done.host_out && !done.probe_out)
+            c->mf_wait = grape::reduce_rows_mflags((int)(KN(c) + 1), n_x);       // (the launch takes the same decision)
         HIP_TRY(c, grape::launch_reduce_rows(c->d_block_out, d_fg, c->NB, (int)(KN(c) + 1), n_x, stream, done));
+    }
     else {
         // one weighted reduction per control array (each reuses d_partial, in stream order); with a host
         // destination only the last one publishes -- it copies out the whole staging buffer
@@ -1854,10 +1876,29 @@ static int enqueue_ipc_allreduce(grape_ctx *c, const double *row, double *out, h
     ip.spin_limit = (long long)(lim * 1e6);
     ip.out = out;
     ip.done = done;
+    ip.fail_word = c->d_h_flag + 1;                          // mapped host word: set when a block gives up (device path: nobody reads the flag)
     if (grape::launch_ipc_allreduce(ip, stream) != hipSuccess)
         return fail(c, GRAPE_ERR_HIP, "ipc_allreduce_kernel: launch failed");
     c->ipc_evals += 1;                                       // (counted once the exchange is in the stream: the peers count launches too)
     c->ipc_count[ip.parity] += 1;
+    return GRAPE_OK;
+}
+
+// A mailbox exchange that gave up (a peer never arrived) has no completion flag to report through when it was issued by the
+// device-pointer entry points: ipc_allreduce_kernel then sets the word behind the completion flag (and poisons its output
+// with NaN).  Checked wherever the host next touches the context; sticky -- the peers are out of step for good.
+static int ipc_check(grape_ctx *c)
+{
+    if (c->broken)
+        return fail(c, GRAPE_ERR_COMM, "the context is unusable: an earlier multi-device evaluation failed part-way (see the error it returned)");
+    if (c->ipc_ranks > 1 && c->h_flag) {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (((volatile unsigned long long *)c->h_flag)[1] != 0) {
+            c->broken = true;
+            return fail(c, GRAPE_ERR_COMM, "a mailbox exchange issued through the device-pointer path gave up (a peer is gone or stuck): "
+                                           "its [G, F] were poisoned with NaN; the context is unusable");
+        }
+    }
     return GRAPE_OK;
 }
 
@@ -1928,6 +1969,7 @@ static int shard_issue(grape_ctx *s, int n_x, double *target, bool signal)
         done.flag = s->d_h_flag;
         done.seq = ++s->seq;
         done.host_out = target;
+        if (s->mf_publish) done.mflags = s->d_h_flag + 8;
         target = s->d_fg;
     }
     return enqueue_eval(s, d_x, target, s->stream, n_x, done);
@@ -2012,6 +2054,12 @@ static int wait_flag(grape_ctx *s)
 {
     volatile unsigned long long *flag = s->h_flag;
     const unsigned long long want = s->seq;
+    const int mf = s->mf_wait;                               // > 0: one flag per workgroup of the final kernel (h_flag[8 ..])
+    auto all_flags = [&]() {
+        for (int i = 0; i < mf; ++i)
+            if (flag[8 + i] != want) return false;
+        return true;
+    };
     timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     auto elapsed = [&]() {
@@ -2042,7 +2090,7 @@ static int wait_flag(grape_ctx *s)
     const double spin_until = s->eval_ema_s > 1e-3 ? 1.3 * s->eval_ema_s : 500e-6;
     long nap_ns = 20000;
     for (unsigned it = 0;; ++it) {
-        const unsigned long long seen = *flag;
+        const unsigned long long seen = mf ? (all_flags() ? want : 0ull) : *flag;
         if (seen == want)
             return done(elapsed(), it == 0);
         if (seen == (want | grape::kSeqFailed))
@@ -2063,7 +2111,7 @@ static int wait_flag(grape_ctx *s)
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
         }
-        if (q == hipSuccess && *flag != want)
+        if (q == hipSuccess && (mf ? !all_flags() : *flag != want))
             return fail(s, GRAPE_ERR_HIP, "evaluation finished without publishing its completion flag");
         if (el > s->timeout_s)
             return fail(s, GRAPE_ERR_TIMEOUT, "evaluation did not finish within " + std::to_string(s->timeout_s) +
@@ -2086,6 +2134,7 @@ static int eval_device_impl(grape_ctx *c, const double *d_x, double *d_fg, void 
                             grape::DoneSignal done = grape::DoneSignal())
 {
     hipStream_t st = (hipStream_t)stream;
+    if (int rc0 = ipc_check(c)) return rc0;
     if (!c->is_group) {
         HIP_TRY(c, hipSetDevice(c->device));
         int rc = enqueue_eval(c, d_x, d_fg, st, n_x, c->ipc_ranks > 1 || c->comm ? grape::DoneSignal() : done);
@@ -2199,7 +2248,8 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
     if (!c->ops_set) return fail(c, GRAPE_ERR_NOT_READY, std::string(who) + ": operators not set");
     const size_t kn = KN(c), Q = kn + 1;
     grape_ctx *lead = c->is_group ? c->sub[0] : c;
-    int rc;
+    int rc = ipc_check(c);
+    if (rc) return rc;
     if (!c->is_group && !c->comm && c->ipc_ranks <= 1) {
         // single GPU: the final reduce kernel writes its result straight into mapped pinned host
         // memory (no D2H copy node) and the host polls the stream
@@ -2226,11 +2276,28 @@ static int eval_host(grape_ctx *c, int n_x, const double *x, double *F, double *
             rc = arrive ? shard_issue_group_arrive(lead) : shard_issue(lead, n_x, lead->d_fg, false);
             int rc_w = GRAPE_OK;
             grape_ctx *bad = nullptr;
+            bool worker_hung = false;
             for (size_t i = 1; i < c->sub.size(); ++i) {
                 const int r = c->sub[i]->worker->wait(c->timeout_s);
-                if (r == GRAPE_ERR_TIMEOUT)                  // (the shard's own error text belongs to its thread: not touched here)
-                    return fail(c, GRAPE_ERR_TIMEOUT, "grape_eval: a shard's issuing thread did not answer within the timeout");
+                if (r == GRAPE_ERR_TIMEOUT) { worker_hung = true; continue; }   // (the shard's own error text belongs to its thread: not touched here)
                 if (r && !rc_w) { rc_w = r; bad = c->sub[i]; }
+            }
+            if (worker_hung) {
+                // a thread is still issuing on its shard: nothing can be drained or reset safely -- the group is retired
+                c->broken = true;
+                return fail(c, GRAPE_ERR_TIMEOUT, "grape_eval: a shard's issuing thread did not answer within the timeout; the context is unusable");
+            }
+            if ((rc || rc_w) && arrive) {
+                // Some shards have arrived, others never will: the counters would stay below G and the NEXT evaluation's first
+                // arrivals would read as the last ones (rows summed before they exist).  Drain every shard, then
+                // zero the counters (the `finished` word included); if that cannot be done the group is retired.
+                bool clean = true;
+                for (grape_ctx *s : c->sub)
+                    clean = clean && hipSetDevice(s->device) == hipSuccess && wait_stream(s, s->stream) == GRAPE_OK;
+                const size_t nb = ((KN(c) + 1) * (size_t)c->B + 255) / 256 + 1;
+                clean = clean && hipSetDevice(lead->device) == hipSuccess &&
+                        hipMemset(c->d_arrive, 0, sizeof(unsigned) * nb) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+                if (!clean) { (void)hipGetLastError(); c->broken = true; }
             }
             if (rc) return group_fail(c, lead, rc);
             if (rc_w) return group_fail(c, bad, rc_w);
@@ -2382,8 +2449,9 @@ struct LbfgsRun {
     }
     int wait()
     {
-        const int rc = wait_flag(lead);
+        int rc = wait_flag(lead);
         if (rc == GRAPE_ERR_TIMEOUT) hung = true;
+        if (!rc) rc = ipc_check(c);                   // an exchange of the device path that gave up (its [G, F] are NaN)
         return rc ? (c->is_group ? group_fail(c, lead, rc) : rc) : GRAPE_OK;
     }
     // [G, F] of the n_x control arrays in st.xt -> st.fgt, on the lead stream, nothing synchronised

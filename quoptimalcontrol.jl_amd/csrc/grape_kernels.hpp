@@ -48,7 +48,13 @@ struct DoneSignal {
     const double *probe_dir = nullptr;         // device: the search direction (K N doubles)
     const double *probe_sc = nullptr;          // device: the L-BFGS scalars (LbfgsState::sc)
     double *probe_out = nullptr;               // mapped host memory (device address): LbfgsState::host_sc + 8
+    // round 5: publication WITHOUT a device-side fan-in (reduce_rows_mf_kernel): workgroup b writes its outputs straight to
+    // host_out, fences at system scope and stores `seq` into mflags[b] (mapped host memory); the host waits for all of them
+    unsigned long long *mflags = nullptr;
 };
+constexpr int kMaxMflags = 1000;               // flags behind grape_ctx::h_flag (8 KB: [0] flag, [1] exchange failure, [8..] these)
+// workgroups (= host flags) reduce_rows_mf_kernel publishes with for Q outputs x n_x control arrays; 0: not applicable
+int reduce_rows_mflags(int Q, int n_x);
 
 constexpr int kStampSlots = 8;   // [0..4] shader clock at phase boundaries, [5],[6] 100 MHz real time
 
@@ -265,6 +271,8 @@ struct IpcParams {
     long long spin_limit;         // polls (with s_sleep) before giving up: the evaluation is then published as failed
     double *out;                  // device result (nullable)
     DoneSignal done;              // host publication; done.counter: agent-scope block counter of this device
+    unsigned long long *fail_word;    // mapped host memory (nullable): set non-zero by a block that gave up -- the only failure
+                                      // channel of the device-pointer path, which publishes no flag; `out` is NaN then
 };
 constexpr unsigned long long kSeqFailed = 1ull << 63;      // flag value = seq | kSeqFailed: the exchange gave up
 size_t ipc_mailbox_bytes(int Q, int n_ranks);

@@ -851,7 +851,9 @@ hipError_t launch_lbfgs_select(const LbfgsState &st, int B, hipStream_t stream, 
 // A pair pushed by lbfgs_select_kernel (the ladder an unbracketed search falls back to) has no Gram row: the host goes back
 // to the single-workgroup kernels for the rest of that run.
 constexpr int kMbVecs = 2 * kLbfgsMbM + 2;          // s_0 .. s_9, y_0 .. y_9, d, g
-constexpr int kMbSums = 3 * kMbVecs + 1;            // {g_t, g, d} x vectors, then g_t.g_t        (67; slot 67: max |g_t|)
+constexpr int kMbSums = 3 * kMbVecs + 3;            // {g_t, g, d} x vectors, then g_t.g_t, y.y, d.y with y = g_t - g formed per
+                                                    // element (69; slot 69: max |g_t|) -- y.y and s.y = alpha d.y from differences
+                                                    // of the big dot products lose eps |g|^2 / |y|^2 on short steps
 constexpr int kMbThreads = 256;
 
 // v[0..63] per lane -> lane l holds the wave's sum of v[l]: pairwise halving, 32 + 16 + ... + 1 shuffles; one function per
@@ -896,6 +898,9 @@ __global__ __launch_bounds__(kMbThreads) void lbfgs_dots_kernel(LbfgsState st)
             acc[2 * kMbVecs + v] = fma(d, vec[v], acc[2 * kMbVecs + v]);
         }
         acc[3 * kMbVecs] = fma(gt, gt, acc[3 * kMbVecs]);
+        const double yv = gt - g;
+        acc[3 * kMbVecs + 1] = fma(yv, yv, acc[3 * kMbVecs + 1]);
+        acc[3 * kMbVecs + 2] = fma(d, yv, acc[3 * kMbVecs + 2]);
         amax = fmax(amax, fabs(gt));
     }
     // wave sums: a reduce-scatter for the first 64 (lane l ends up with sum l: 63 shuffles, no branch between them -- one
@@ -978,8 +983,8 @@ __global__ __launch_bounds__(kMbThreads) void lbfgs_step_mb_kernel(LbfgsState st
     // products of the three vectors with the history (physical rows), d and g
     auto P = [&](int a, int v) { return s_tot[a * kMbVecs + v]; };        // a: 0 g_t, 1 g, 2 d;  v: j | M + j | 2M (d) | 2M+1 (g)
     const double gtgt = s_tot[3 * kMbVecs];
-    const double sy = alpha * (P(0, 2 * M) - P(1, 2 * M));
-    const double yy = gtgt - 2.0 * P(0, 2 * M + 1) + P(1, 2 * M + 1);
+    const double sy = alpha * s_tot[3 * kMbVecs + 2];           // s.y = alpha d.(g_t - g), y.y: summed from per-element differences
+    const double yy = s_tot[3 * kMbVecs + 1];
     const double ss = alpha * alpha * P(2, 2 * M);
     const bool push = sy > 1e-10 * sqrt(ss * yy) && yy > 0.0;
     const int head = push ? (n_old == 0 ? 0 : (head_old + 1 == m ? 0 : head_old + 1)) : head_old;

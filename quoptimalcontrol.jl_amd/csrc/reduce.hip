@@ -106,8 +106,63 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restri
         signal_done(done, gridDim.x * gridDim.y);
 }
 
+// The same sums in the same order (32 row-lanes per output, rows b = bl, bl + 32, ... ascending, then the 32 partial sums in
+// order: bitwise reduce_rows_kernel's results), 32 outputs per workgroup of 1024 threads -- and NO hand-off between
+// workgroups: each writes its 256 bytes straight into the mapped host buffer, fences at system scope and stores the
+// evaluation's sequence number into ITS OWN host flag; the host waits until every flag shows it.  reduce_rows_kernel's
+// publication (staging stores drained, a 251 -> 1 fan-in on a counter, the last workgroup's sc1 loads + copy-out + fence)
+// was four dependent trips to memory, 5.5 of its 8.7 us (profiles/r04_C3_phaseD.txt); this one has none of them.
+constexpr int kMfOut = 32;
+__global__ __launch_bounds__(1024) void reduce_rows_mf_kernel(const double *__restrict__ rows, double *__restrict__ fg, int NB,
+                                                              int Q, DoneSignal done)
+{
+    __shared__ double s_acc[32][kMfOut + 1];
+    const int ql = threadIdx.x & (kMfOut - 1), bl = threadIdx.x / kMfOut;
+    const int q = blockIdx.x * kMfOut + ql;
+    rows += (size_t)blockIdx.y * NB * Q;
+    double acc = 0.0;
+    if (q < Q) {
+        for (int b0 = bl; b0 < NB; b0 += 256) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 32 * u;
+                v[u] = b < NB ? rows[(size_t)b * Q + q] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                acc += v[u];
+        }
+    }
+    s_acc[bl][ql] = acc;
+    __syncthreads();
+    if (bl == 0) {                                   // lanes 0..31 of the first wave
+        if (q < Q) {
+            double s = s_acc[0][ql];
+#pragma unroll
+            for (int i = 1; i < 32; ++i)
+                s += s_acc[i][ql];
+            fg[(size_t)blockIdx.y * Q + q] = s;
+            done.host_out[(size_t)blockIdx.y * Q + q] = s;
+        }
+        __threadfence_system();                      // the wave's host stores are visible before its flag
+        if (ql == 0)
+            __hip_atomic_store(done.mflags + blockIdx.y * gridDim.x + blockIdx.x, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int reduce_rows_mflags(int Q, int n_x)
+{
+    const long long g = (long long)((Q + kMfOut - 1) / kMfOut) * n_x;
+    return g >= 1 && g <= kMaxMflags ? (int)g : 0;
+}
+
 hipError_t launch_reduce_rows(const double *rows, double *fg, int NB, int Q, int n_x, hipStream_t stream, DoneSignal done)
 {
+    if (done.flag && done.host_out && done.mflags && !done.probe_out && reduce_rows_mflags(Q, n_x)) {
+        GRAPE_LAUNCH(reduce_rows_mf_kernel, dim3((Q + kMfOut - 1) / kMfOut, n_x), dim3(1024), 0, stream, rows, fg, NB, Q, done);
+        return hipGetLastError();
+    }
     GRAPE_LAUNCH(reduce_rows_kernel, dim3((Q + 7) / 8, n_x), dim3(256), 0, stream, rows, fg, NB, Q, done);
     return hipGetLastError();
 }
@@ -302,6 +357,13 @@ __global__ __launch_bounds__(256) void ipc_allreduce_kernel(const IpcParams p)
             if (p.done.host_out)
                 p.done.host_out[q] = acc;
         }
+    } else {
+        // gave up: a partial sum must never pass for a result -- NaN where the sum was expected, and the host word
+        // the device-pointer path has instead of a completion flag
+        if (q < p.Q && p.out)
+            p.out[q] = __builtin_nan("");
+        if (threadIdx.x == 0 && p.fail_word)
+            __hip_atomic_store(p.fail_word, p.target, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (!p.done.flag)
         return;

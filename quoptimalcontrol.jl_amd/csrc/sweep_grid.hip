@@ -1,0 +1,421 @@
+// sweep_grid.hip -- the GRAPE hot path for operators beyond one wavefront's registers: n = 33 .. 64 (NT = 3, 4 tiles of 16
+// per side; `_fom_and_gradient_GRAPE!` src/GRAPE.jl:25-96 is size-generic, and :101 sends "too large" systems to it).
+//
+// A 64 x 64 ComplexF64 matrix is 64 KB -- 256 registers per lane of ONE wave.  Here a WORKGROUP of NT x NT waves owns every
+// matrix, wave (I, J) its 16 x 16 tile (I, J) in the FP64 matrix cores' accumulator ("D") layout of tile.hpp: 16 registers
+// per matrix and wave.  Element-wise work (the H build, the Taylor combinations, the traces) never leaves the owner.  A
+// product  C = op(A) op(B)  goes through two plain row-major images in LDS (re plane | im plane, row pitch 16 NT + 4):
+//     barrier -- owners write their tiles of A and B -- barrier -- wave (I, J) reads the fragments of row I of op(A) and of
+//     column J of op(B) as MFMA operands (a conjugate transpose is index arithmetic on the image) and runs
+//     4 NT k-blocks x 3 v_mfma_f64_16x16x4 (the three-product complex multiplication of tile.hpp, operand sums formed in
+//     registers).
+// An operand that is still in its image from the previous product is not written again (P in  P' (L P),  X and L in the
+// commutator).  LDS: 4 planes x 16 NT x (16 NT + 4) doubles = 136 KB at NT = 4: one workgroup of 16 waves per compute unit,
+// four waves per SIMD, whose MFMA phases cover each other's LDS phases.
+//
+// Data flow = the reference's own (general) flow for every system type and both formula variants: grid_prop_kernel forms
+// G_t = (-i dt)(A + sum_c x[c,t] B_c) in the reference's association and P_t = exp(G_t) (degree-8 Taylor polynomial in three
+// products + squarings, cmat.hpp's constants, theta8 = 0.08) for a block of slices per workgroup; grid_chain_kernel, one
+// workgroup per member, stores the forward states X_t (src/GRAPE.jl:53-63), pulls the costates back (:65-75) and takes the
+// gradient traces of :261-303 and the figure of merit at t = N (:77, :94) from  R_t = X_t L_t'  [- L_t' X_t].
+// Workspace and operator format: tile.hpp's D-layout dumps, element (tile, r, lane) at ((I NT + J) 4 + r) 64 + lane -- the
+// host packing, the reduction kernels and grape_get_trajectory are the tile family's.
+#include "cmat.hpp"
+#include "grape_kernels.hpp"
+#include "tile.hpp"
+
+namespace grape {
+
+struct GT {                        // this wave's tile of a matrix, D layout
+    d4 re, im;
+};
+
+template <int NT>
+struct GridGeom {
+    static constexpr int DIM = 16 * NT;
+    static constexpr int P = DIM + 4;             // row pitch (doubles): rows 4 apart land 32 banks apart
+    static constexpr int PLANE = DIM * P;         // doubles per plane; an image is [re plane | im plane]
+    static constexpr int WAVES = NT * NT;
+    static constexpr int TSZ = NT * NT * 256;     // double2 per matrix dump
+};
+
+constexpr int kGridGroup = 4;                     // controls per trace reduction
+constexpr int kGridRed = 2 + 2 * kGridGroup;      // doubles a wave contributes per reduction: z, then (re, im) per control
+
+size_t grid_lds_bytes(int NT, bool chain)
+{
+    const size_t dim = 16 * (size_t)NT, plane = dim * (dim + 4);
+    return sizeof(double) * (4 * plane + (chain ? 2 * (size_t)NT * NT * kGridRed : (size_t)NT * dim));
+}
+
+GRAPE_DEV GT gt_load(const double2 *__restrict__ dump, int tile, int lane)
+{
+    GT t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double2 v = dump[(tile * 4 + r) * 64 + lane];
+        t.re[r] = v.x;
+        t.im[r] = v.y;
+    }
+    return t;
+}
+
+GRAPE_DEV void gt_store(double2 *__restrict__ dump, int tile, int lane, const GT &t)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        dump[(tile * 4 + r) * 64 + lane] = make_double2(t.re[r], t.im[r]);
+}
+
+// own tile -> image: element (16 I + 4 r + (lane >> 4), 16 J + (lane & 15))
+template <int NT>
+GRAPE_DEV void grid_put(double *__restrict__ img, const GT &t, int I, int J, int lane)
+{
+    constexpr int P = GridGeom<NT>::P, PLANE = GridGeom<NT>::PLANE;
+    const int at = (16 * I + (lane >> 4)) * P + 16 * J + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        img[at + 4 * r * P] = t.re[r];
+        img[PLANE + at + 4 * r * P] = t.im[r];
+    }
+}
+
+// tile (I, J) of op(A) op(B) from the images of A and B; HA / HB: the conjugate transpose of that operand.
+// A fragment of k-block (Kt, kb), lane l:  op(A)[16 I + (l & 15)][kk],  B fragment:  op(B)[kk][16 J + (l & 15)],
+// kk = 16 Kt + 4 kb + (l >> 4).  (x + i sa y)(u + i sb v): re = xu - sa sb yv, im = (x + sa y)(u + sb v) - xu - sa sb yv.
+template <int NT, bool HA, bool HB>
+GRAPE_DEV GT grid_mma(const double *__restrict__ ia, const double *__restrict__ ib, int I, int J, int lane)
+{
+    constexpr int P = GridGeom<NT>::P, PLANE = GridGeom<NT>::PLANE;
+    const int lo = lane & 15, hi = lane >> 4;
+    const int a0 = HA ? hi * P + 16 * I + lo : (16 * I + lo) * P + hi;
+    const int b0 = HB ? (16 * J + lo) * P + hi : hi * P + 16 * J + lo;
+    constexpr int astep = HA ? 4 * P : 4, bstep = HB ? 4 : 4 * P;         // one k-block further
+    d4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0}, t3 = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4 * NT; ++q) {
+        const double ar = ia[a0 + q * astep], ai = ia[PLANE + a0 + q * astep];
+        const double br = ib[b0 + q * bstep], bi = ib[PLANE + b0 + q * bstep];
+        const double as = HA ? ar - ai : ar + ai;
+        const double bs = HB ? br - bi : br + bi;
+        t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, t1, 0, 0, 0);
+        t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, t2, 0, 0, 0);
+        t3 = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bs, t3, 0, 0, 0);
+    }
+    GT out;
+    if (HA != HB) {
+        out.re = t1 + t2;
+        out.im = t3 - t1 + t2;
+    } else {
+        out.re = t1 - t2;
+        out.im = t3 - t1 - t2;
+    }
+    return out;
+}
+
+GRAPE_DEV void gt_add_identity(GT &t, double c, int I, int J, int lane)
+{
+    if (I == J) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * r + (lane >> 4) == (lane & 15))
+                t.re[r] += c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// P_t = exp((-i dt) H_t) for the slices [blockIdx.x * prop_slices, ...) of member blockIdx.y, control array blockIdx.z
+template <int NT>
+__global__ __launch_bounds__(64 * NT * NT) void grid_prop_kernel(const TileParams p)
+{
+    using G_ = GridGeom<NT>;
+    constexpr int TSZ = G_::TSZ, PLANE = G_::PLANE, DIM = G_::DIM;
+    extern __shared__ double s_grid[];
+    double *img0 = s_grid, *img1 = s_grid + 2 * PLANE, *s_col = s_grid + 4 * PLANE;      // s_col[I][column]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, I = wave / NT, J = wave % NT, tile = I * NT + J;
+    const int k = blockIdx.y, K = p.K;
+    const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;             // [A | B_c | B_c^T | Xi | Xt]
+    const double *__restrict__ x = p.x + (size_t)blockIdx.z * K * p.N;
+    const int t_lo = blockIdx.x * p.prop_slices, t_hi = min(p.N, t_lo + p.prop_slices);
+    const double dt = p.dt;
+    for (int t = t_lo; t < t_hi; ++t) {
+        // H in the reference's association: in-place variant sum_c B_c x_c first, then + A (src/timeevolution.jl:101-108);
+        // static variant A first (:49-52)
+        GT G;
+        if (p.variant == 0) {
+            G.re = (d4){0, 0, 0, 0};
+            G.im = (d4){0, 0, 0, 0};
+        } else {
+            G = gt_load(ops, tile, lane);
+        }
+        for (int c = 0; c < K; ++c) {
+            const double xv = x[c + (size_t)t * K];
+            const GT B = gt_load(ops + (size_t)(1 + c) * TSZ, tile, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                G.re[r] = fma(B.re[r], xv, G.re[r]);
+                G.im[r] = fma(B.im[r], xv, G.im[r]);
+            }
+        }
+        if (p.variant == 0) {
+            const GT A = gt_load(ops, tile, lane);
+            G.re += A.re;
+            G.im += A.im;
+        }
+        double cs = 0.0;                               // this tile's share of its columns' sums of |re| + |im|
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double hr = G.re[r], hi = G.im[r];
+            G.re[r] = dt * hi;                         // (-i dt)(hr + i hi)
+            G.im[r] = -dt * hr;
+            cs += fabs(G.re[r]) + fabs(G.im[r]);
+        }
+        cs = swap16_add(cs, cs);
+        cs = swap32_add(cs, cs);
+        __syncthreads();                               // the previous slice's readers are done
+        grid_put<NT>(img0, G, I, J, lane);
+        if (lane < 16)
+            s_col[I * DIM + 16 * J + lane] = cs;
+        __syncthreads();
+        double colmax = 0.0;
+        if (lane < DIM) {
+#pragma unroll
+            for (int ii = 0; ii < NT; ++ii)
+                colmax += s_col[ii * DIM + lane];
+        }
+        colmax = wave_max_fast(colmax);                // the same number in every wave: upper bound of |G|_1
+        const int s = p.s_forced >= 0 ? p.s_forced : squarings_for(colmax);
+        // A2 = G G on the unscaled generator, then the power-of-two scaling (exact) on both
+        GT A2 = grid_mma<NT, false, false>(img0, img0, I, J, lane);
+        if (s > 0) {
+            const double sc = ldexp(1.0, -s), sc2 = ldexp(1.0, -2 * s);
+            G.re *= sc;
+            G.im *= sc;
+            A2.re *= sc2;
+            A2.im *= sc2;
+        }
+        GT T;
+        T.re = kX1 * G.re + kX2 * A2.re;
+        T.im = kX1 * G.im + kX2 * A2.im;
+        __syncthreads();
+        grid_put<NT>(img0, A2, I, J, lane);
+        grid_put<NT>(img1, T, I, J, lane);
+        __syncthreads();
+        const GT A4 = grid_mma<NT, false, false>(img0, img1, I, J, lane);      // A4 = A2 (x1 G + x2 A2)
+        GT U;
+        U.re = kX3 * A2.re + A4.re;
+        U.im = kX3 * A2.im + A4.im;
+        T.re = kX5 * G.re + kX6 * A2.re + kX7 * A4.re;
+        T.im = kX5 * G.im + kX6 * A2.im + kX7 * A4.im;
+        gt_add_identity(T, kX4, I, J, lane);
+        __syncthreads();
+        grid_put<NT>(img0, U, I, J, lane);
+        grid_put<NT>(img1, T, I, J, lane);
+        __syncthreads();
+        GT Pm = grid_mma<NT, false, false>(img0, img1, I, J, lane);            // A8
+        Pm.re += G.re + kY2 * A2.re;
+        Pm.im += G.im + kY2 * A2.im;
+        gt_add_identity(Pm, 1.0, I, J, lane);
+        for (int i = 0; i < s; ++i) {                  // undo the scaling
+            __syncthreads();
+            grid_put<NT>(img0, Pm, I, J, lane);
+            __syncthreads();
+            Pm = grid_mma<NT, false, false>(img0, img0, I, J, lane);
+        }
+        gt_store(p.props + (((size_t)blockIdx.z * p.E + k) * p.N + t) * TSZ, tile, lane, Pm);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// one workgroup per (member, control array): forward states, costates, gradient, figure of merit
+template <int NT, int SAND, bool KEEPL>
+__global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TileParams p)
+{
+    using G_ = GridGeom<NT>;
+    constexpr int TSZ = G_::TSZ, PLANE = G_::PLANE, WAVES = G_::WAVES;
+    extern __shared__ double s_grid[];
+    double *img0 = s_grid, *img1 = s_grid + 2 * PLANE, *s_red = s_grid + 4 * PLANE;      // s_red[2][WAVES][kGridRed]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, I = wave / NT, J = wave % NT, tile = I * NT + J;
+    const int k = blockIdx.x, K = p.K, N = p.N;
+    const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
+    const double2 *__restrict__ opBT = ops + (size_t)(1 + K) * TSZ;
+    const size_t kw = (size_t)blockIdx.y * p.E + k;
+    const double2 *__restrict__ Pk = p.props + kw * N * TSZ;
+    double2 *__restrict__ Xk = p.states + kw * N * TSZ;
+    double *__restrict__ out = p.member_out + ((size_t)blockIdx.y * p.E_members + k) * ((size_t)K * N + 1);
+
+    // ------------------------------------------------------------ forward sweep, src/GRAPE.jl:53-63
+    {
+        GT X = gt_load(ops + (size_t)(1 + 2 * K) * TSZ, tile, lane);            // Xi
+        GT Pt = gt_load(Pk, tile, lane);
+        for (int t = 0; t < N; ++t) {
+            gt_store(Xk + (size_t)t * TSZ, tile, lane, X);
+            if (t + 1 < N) {                           // (the state behind the last slice is never read)
+                __syncthreads();
+                grid_put<NT>(img0, Pt, I, J, lane);
+                grid_put<NT>(img1, X, I, J, lane);
+                __syncthreads();
+                Pt = gt_load(Pk + (size_t)(t + 1) * TSZ, tile, lane);           // next slice's tile in flight under the products
+                if (SAND) {
+                    const GT Y = grid_mma<NT, false, false>(img0, img1, I, J, lane);      // P X            (:245-246 as (P X) P')
+                    __syncthreads();
+                    grid_put<NT>(img1, Y, I, J, lane);
+                    __syncthreads();
+                    X = grid_mma<NT, false, true>(img1, img0, I, J, lane);      // (P X) P'
+                } else {
+                    X = grid_mma<NT, false, false>(img0, img1, I, J, lane);     // P X            (:226)
+                }
+            }
+        }
+    }
+    // ------------------------------------------------------------ backward sweep + gradient, :65-92
+    const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
+    GT L = gt_load(ops + (size_t)(2 + 2 * K) * TSZ, tile, lane);                // Xt
+    GT Pt = gt_load(Pk + (size_t)(N - 1) * TSZ, tile, lane);
+    GT X = gt_load(Xk + (size_t)(N - 1) * TSZ, tile, lane);
+    int buf = 0;
+    for (int t = N - 1; t >= 0; --t) {
+        const int tp = max(t - 1, 0);
+        __syncthreads();
+        grid_put<NT>(img0, Pt, I, J, lane);
+        grid_put<NT>(img1, L, I, J, lane);
+        __syncthreads();
+        Pt = gt_load(Pk + (size_t)tp * TSZ, tile, lane);
+        if (SAND) {
+            const GT Y = grid_mma<NT, false, false>(img1, img0, I, J, lane);    // L P             (:248)
+            __syncthreads();
+            grid_put<NT>(img1, Y, I, J, lane);
+            __syncthreads();
+            L = grid_mma<NT, true, false>(img0, img1, I, J, lane);              // P' (L P)        (:249)
+        } else {
+            L = grid_mma<NT, true, false>(img0, img1, I, J, lane);              // P' L            (:228)
+        }
+        if (KEEPL)
+            gt_store(p.costates + (kw * N + t) * TSZ, tile, lane, L);
+        double zr_p = 0.0, zi_p = 0.0;                  // this lane's share of tr(X' L)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            zr_p = fma(X.re[r], L.re[r], zr_p);
+            zr_p = fma(X.im[r], L.im[r], zr_p);
+            zi_p = fma(X.re[r], L.im[r], zi_p);
+            zi_p = fma(-X.im[r], L.re[r], zi_p);
+        }
+        __syncthreads();
+        grid_put<NT>(img0, X, I, J, lane);
+        grid_put<NT>(img1, L, I, J, lane);
+        __syncthreads();
+        X = gt_load(Xk + (size_t)tp * TSZ, tile, lane);
+        GT R = grid_mma<NT, false, true>(img0, img1, I, J, lane);               // X L'
+        if (SAND) {
+            const GT R2 = grid_mma<NT, true, false>(img1, img0, I, J, lane);    // L' X           ([X, L'], src/tools.jl:17-19)
+            R.re -= R2.re;
+            R.im -= R2.im;
+        }
+        // traces: sum_ij B_c[i][j] R[j][i] = sum over the elements of (B_c^T .* R); kGridGroup controls per reduction, the
+        // workgroup's sum in wave order (deterministic)
+        for (int c0 = 0; c0 < K; c0 += kGridGroup) {
+            double v[kGridRed];
+            v[0] = zr_p;
+            v[1] = zi_p;
+#pragma unroll
+            for (int cc = 0; cc < kGridGroup; ++cc) {
+                double wr = 0.0, wi = 0.0;
+                if (c0 + cc < K) {
+                    const GT BT = gt_load(opBT + (size_t)(c0 + cc) * TSZ, tile, lane);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        wr = fma(BT.re[r], R.re[r], wr);
+                        wr = fma(-BT.im[r], R.im[r], wr);
+                        wi = fma(BT.re[r], R.im[r], wi);
+                        wi = fma(BT.im[r], R.re[r], wi);
+                    }
+                }
+                v[2 + 2 * cc] = wr;
+                v[3 + 2 * cc] = wi;
+            }
+            wave_sum_n(v);
+            double *red = s_red + (size_t)buf * WAVES * kGridRed;
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < kGridRed; ++q)
+                    red[wave * kGridRed + q] = v[q];
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < kGridGroup && c0 + (int)threadIdx.x < K) {
+                const int cc = threadIdx.x;
+                double zr = 0.0, zi = 0.0, wr = 0.0, wi = 0.0;
+                for (int w = 0; w < WAVES; ++w) {
+                    zr += red[w * kGridRed];
+                    zi += red[w * kGridRed + 1];
+                    wr += red[w * kGridRed + 2 + 2 * cc];
+                    wi += red[w * kGridRed + 3 + 2 * cc];
+                }
+                const double im = SAND ? wi : fma(wr, zi, wi * zr);
+                out[c0 + cc + (size_t)t * K] = gs * im;
+                if (t == N - 1 && c0 + cc == 0) {       // figure of merit at t = N (:77, :94)
+                    if (SAND) {
+                        const double inv = 1.0 / (double)p.n;
+                        const double ar = zr * inv, ai = zi * inv;
+                        out[(size_t)K * N] = 1.0 - (ar * ar + ai * ai);          // src/cost_functions.jl:13-17
+                    } else {
+                        out[(size_t)K * N] = zr * zr - zi * zi;                  // Re(z^2), :99-101
+                    }
+                }
+            }
+            buf ^= 1;                                   // (two buffers: the next group's writes meet no reader)
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+static hipError_t launch_grid_nt(int sandwich, bool keepl, const TileParams &p, hipStream_t stream)
+{
+    TileParams q = p;
+    const size_t lds_p = grid_lds_bytes(NT, false), lds_c = grid_lds_bytes(NT, true);
+    // slices per workgroup of the expm kernel: about two rounds of workgroups over the device, at most 64 slices
+    const long cus = p.cus > 0 ? p.cus : 256, total = (long)p.N * p.E * p.n_x;
+    q.prop_slices = (int)std::min<long>(64, std::max<long>(1, (total + 2 * cus - 1) / (2 * cus)));
+    hipError_t e = hipFuncSetAttribute((const void *)grid_prop_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+    if (e != hipSuccess)
+        return e;
+    GRAPE_LAUNCH((grid_prop_kernel<NT>), dim3((p.N + q.prop_slices - 1) / q.prop_slices, p.E, p.n_x), dim3(64 * NT * NT), lds_p,
+                 stream, q);
+    e = hipGetLastError();
+    if (e != hipSuccess)
+        return e;
+    if (p.ev_mid) {
+        e = hipEventRecord(p.ev_mid, stream);
+        if (e != hipSuccess)
+            return e;
+    }
+    const dim3 grid(p.E, p.n_x), block(64 * NT * NT);
+#define GRAPE_GRID_CHAIN(S, KL)                                                                                          \
+    {                                                                                                                    \
+        e = hipFuncSetAttribute((const void *)grid_chain_kernel<NT, S, KL>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                (int)lds_c);                                                                             \
+        if (e != hipSuccess)                                                                                             \
+            return e;                                                                                                    \
+        GRAPE_LAUNCH((grid_chain_kernel<NT, S, KL>), grid, block, lds_c, stream, q);                                     \
+    }
+    if (sandwich) {
+        if (keepl) GRAPE_GRID_CHAIN(1, true) else GRAPE_GRID_CHAIN(1, false)
+    } else {
+        if (keepl) GRAPE_GRID_CHAIN(0, true) else GRAPE_GRID_CHAIN(0, false)
+    }
+#undef GRAPE_GRID_CHAIN
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep_grid(int NT, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream)
+{
+    switch (NT) {
+    case 1: return launch_grid_nt<1>(sandwich, keep_costates, p, stream);     // (GRAPE_GRID=1: the small sizes through these
+    case 2: return launch_grid_nt<2>(sandwich, keep_costates, p, stream);     //  kernels, for cross-checks against the tile family)
+    case 3: return launch_grid_nt<3>(sandwich, keep_costates, p, stream);
+    case 4: return launch_grid_nt<4>(sandwich, keep_costates, p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace grape

@@ -123,3 +123,9 @@ def test_solution_save_and_load_round_trip(qoc, tmp_path):
     members = qoc.init_ensemble(eback.problem)
     assert [np.array_equal(m.A, k * wl.Sz) for k, m in enumerate(members, 1)] == [True] * 3
     assert np.allclose(eback.problem.wts, 1 / 3)
+    # optim_options with values json does not know (NumPy scalars / arrays, a callable): still savable
+    odd = qoc.GRAPE(n_slices=10, optim_options={"iterations": np.int64(9), "g_tol": np.float64(1e-7), "x_abstol": np.array([1e-3, 2e-3]),
+                                                "callback": len})
+    qoc.save(qoc.SolutionResult(None, 0.5, np.ones((2, 10)), prob, odd), f)
+    oback = qoc.load(f).alg.optim_options
+    assert oback["iterations"] == 9 and oback["g_tol"] == 1e-7 and oback["x_abstol"] == [1e-3, 2e-3] and "len" in oback["callback"]
