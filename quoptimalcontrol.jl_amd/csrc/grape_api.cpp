@@ -60,6 +60,8 @@ struct grape_ctx {
     int NT = 0;                   // tile family: tiles per dimension (padded n = 16 NT)
     size_t TSZ = 0;               // tile family: double2 per matrix dump
     bool pack2 = false;           // tile family, n <= 8: two members per 16x16 tile (block diagonal)
+    bool grid = false;            // tile family, n = 33..64 (NT = 3, 4): a workgroup of NT x NT waves per matrix (sweep_grid.hip) -- the
+                                  // reference's general flow only; GRAPE_GRID=1 sends smaller sizes there too (cross-checks)
     int EU = 0;                   // tile family: wavefront-level units = members, or member pairs when pack2
     int S = 0, W = 0, LT = 0;
     bool pair = false;            // small family: lane-pair kernel (sweep_pair.hip), a time chunk per two lanes
@@ -441,7 +443,9 @@ static int validate_config(const grape_config *cfg)
     if (wmax == 0 && nt == 0)
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED,
                     "grape_create: operator dimension n=" + std::to_string(cfg->n) +
-                        " has no kernel in this build (supported: 2..32)");
+                        " has no kernel in this build (supported: 2..64)");
+    if (nt > 2 && cfg->gradient == GRAPE_GRADIENT_EXACT)
+        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: the exact gradient exists for n <= 32 (n = 33..64 run the reference's first-order flow)");
     const int m = cfg->n_state_cols ? cfg->n_state_cols : cfg->n;
     if (m != cfg->n && cfg->sys_type != GRAPE_UNITARY_GATE)
         return fail(nullptr, GRAPE_ERR_INVALID_ARG,
@@ -510,6 +514,8 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     c->TSZ = (size_t)nt * nt * 256;
     c->pack2 = (c->family == 1 && cfg->n <= 8 && !std::getenv("GRAPE_TILE_NOPACK") &&
                 cfg->gradient != GRAPE_GRADIENT_EXACT);        // the exact-gradient kernel works on whole tiles
+    c->grid = c->family == 1 && (nt > 2 || (env_on("GRAPE_GRID") && cfg->gradient != GRAPE_GRADIENT_EXACT));
+    if (c->grid) c->pack2 = false;
     c->EU = c->pack2 ? (E + 1) / 2 : E;
     c->pair = pair && c->family == 0;
     const int cpw = c->pair ? 32 : 64;                           // time chunks per wave
@@ -1061,7 +1067,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     // Data-flow choice: if every generator is Hermitian to rounding, every propagator is
     // unitary and the sweep can carry M_t = P_t' M_{t+1} P_t instead of storing X_t.
     bool herm = !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) &&
-                c->cfg.gradient != GRAPE_GRADIENT_EXACT;
+                c->cfg.gradient != GRAPE_GRADIENT_EXACT && !c->grid;     // (sweep_grid.hip: the reference's general flow only)
     const int n = c->cfg.n;
     for (size_t k = 0; k < E && herm; ++k)
         for (size_t m = 0; m < K + 1 && herm; ++m)
@@ -1117,7 +1123,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     // shared controls, or -- n <= 16 -- the members' own (at most six: a lane keeps its half rows of them in registers)
     const bool act_ok = (ctrl_shared || (c->NT == 1 && K <= 6)) && !(act_env && act_env[0] == '0') &&
                         c->cfg.n_slices <= 4096;             // (per-slice plans live in LDS)
-    bool thin = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT &&
+    bool thin = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT && !c->grid &&
                 !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) && !env_on("GRAPE_NO_THIN");
     const bool act_only = c->NT == 2 || c->pack2;            // n = 5..8 (two members per tile) and n = 17..32: vector flow or dense chains
     if (thin && act_only)
@@ -1181,7 +1187,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         c->herm_ctrl = hb;
     }
     {   // sparse control operators (Pauli-type controls): lists of (B_c[i][j], position of M[j][i]) per member and control
-        bool sp = c->family == 1 && !c->pack2 && K >= 1 && K <= 16 && !env_on("GRAPE_NO_SPARSE");
+        bool sp = c->family == 1 && !c->pack2 && !c->grid && K >= 1 && K <= 16 && !env_on("GRAPE_NO_SPARSE");
         // list length: the longest operator's non-zeros rounded up to whole wavefronts (64 for single Pauli strings up to five
         // qubits; 128 .. 256 for sums of a few of them -- a global drive sum_i X_i on five qubits has 160), while the K
         // lists fit the kernels' LDS budgets beside their images (K x length <= 1536 entries = 30 KB)
@@ -1227,7 +1233,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // robustness ensemble, ...): the same kernels form the sum themselves.  16 x 16 with shared controls: from 8 units
         // on (below, the pre-pass launch costs more than it saves and the round-2 kernel stays).  GRAPE_HOIST=0 keeps
         // prop_tile_kernel, GRAPE_HOIST=1 forces the new kernels for any ensemble size.
-        bool hz = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT;
+        bool hz = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT && !c->grid;
         const char *he = std::getenv("GRAPE_HOIST");
         if (he && he[0] == '0') hz = false;
         bool invariant = hz && !c->pack2;                        // (block-diagonal member pairs, n <= 8: always the in-kernel sum)
@@ -1309,7 +1315,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // GRAPE_TP_SLOTS=m: m x CUs pairs for every case (tuning).
         long pair_cap = (c->NT == 1 && !thin) ? 32L * c->compute_units : slots, small_cap = (c->NT == 1 && herm && !thin) ? pair_cap : slots;
         if (const char *e = std::getenv("GRAPE_TP_SLOTS")) pair_cap = small_cap = std::max(1L, std::atol(e)) * c->compute_units;
-        const bool small = c->family == 1 && 2 * units <= (thin ? slots : small_cap) && !env_on("GRAPE_NO_TP");
+        const bool small = c->family == 1 && !c->grid && 2 * units <= (thin ? slots : small_cap) && !env_on("GRAPE_NO_TP");
         if (small && !thin && N >= 8) {
             // slices per chunk at the latency optimum: one-level scan 3 S + N / S dependent products (general flow),
             // two-level scan (unitary flow) 3 S + 2 sqrt(N / S); measured optima (tools/tp_sweep.py): 32 x 32, N = 2000:
@@ -1655,6 +1661,7 @@ static bool states_stored(const grape_ctx *c)
     if (c->exact_w1) return false;                           // exact gradient behind the unitary flow: W_t where the states would be
     if (c->d_costates) return true;                          // debug flow stores everything
     if (c->family == 0 || c->unitary || c->thin) return false;   // fast small-n flows / unitary / rank-one flows rebuild them
+    if (c->grid) return true;                                // sweep_grid.hip stores every X_t
     return !grape::tile_chain_is_split(tile_params(c, nullptr), false);
 }
 
@@ -1686,8 +1693,11 @@ static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream, int
         p.fold_wts = c->d_wts;
         p.fold_done = done;
     }
-    HIP_TRY(c, grape::launch_sweep_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE,
-                                        c->d_costates != nullptr, p, stream));
+    if (c->grid)
+        HIP_TRY(c, grape::launch_sweep_grid(c->NT, c->cfg.sys_type != GRAPE_UNITARY_GATE, c->d_costates != nullptr, p, stream));
+    else
+        HIP_TRY(c, grape::launch_sweep_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE,
+                                            c->d_costates != nullptr, p, stream));
     return GRAPE_OK;
 }
 

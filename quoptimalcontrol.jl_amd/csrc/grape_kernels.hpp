@@ -215,6 +215,8 @@ hipError_t launch_coop_chain_unitary(int sandwich, const TileParams &q, hipStrea
 int tile_count(int n);    // NT for this n (0: not a tile-family size)
 int tile_fuse_forward(const TileParams &p);   // thin: forward vector pass runs inside prop_tile_kernel for this launch?
 hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
+// n = 33..64 (NT = 3, 4; sweep_grid.hip): a workgroup of NT x NT waves per matrix, the reference's general flow
+hipError_t launch_sweep_grid(int NT, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
 // prop_hoist.hip: control-sum pre-pass + the expm kernel on A'_k + Gc_t; q = the launcher's parameters (prop_slices, fuse_fwd set)
 hipError_t launch_prop_hoist(int NT, const TileParams &q, hipStream_t stream);
 bool tile_chain_is_split(const TileParams &p, bool keep_costates);   // the two-wave time-split chain: no full X_t store

@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(64) void chunk_scan_kernel(const TileParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
-int tile_count(int n) { return n <= 4 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : 0)); }
+int tile_count(int n) { return n <= 4 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 48 ? 3 : (n <= 64 ? 4 : 0)))); }
 
 static bool tile_chain_env(const char *what)                       // GRAPE_TILE_CHAIN=split|1w: tuning / ablation
 {

@@ -1,0 +1,141 @@
+"""GPU: operators beyond one wavefront's registers, n = 33 .. 64 (sweep_grid.hip: a workgroup of NT x NT waves per matrix,
+NT = 3, 4; `_fom_and_gradient_GRAPE!` src/GRAPE.jl:25-96 is size-generic) against the oracle at the 1e-10 bar -- every
+member's (F_k, g_k), the ensemble sums, and the stored propagators / states / costates; both formula variants, all three
+system types, Hermitian and non-Hermitian generators, the squaring path of the expm, batches, n x m states, in-process
+groups.  GRAPE_GRID=1 sends the small sizes through the same kernels (NT = 1, 2), where the tile family cross-checks them."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+from test_gpu_tile import _engine, _random_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(qoc, oracle, w, variant=0, traj=True, **kw):
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
+                                                            variant=variant, per_member=True)
+    flags = qoc.engine.FLAG_KEEP_COSTATES if traj else 0
+    with _engine(qoc, w, variant=variant, flags=flags, **kw) as eng:
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+        info = eng.info
+        names = eng.kernel_names()
+        if traj:
+            P, X, L = eng.trajectory(w.E - 1, costates=True)
+    assert info["kernel_family"] == 1 and info["states_stored"] == 1
+    assert any(k.startswith("grid_prop_kernel") for k in names) and any(k.startswith("grid_chain_kernel") for k in names), names
+    if traj:
+        k = w.E - 1
+        _, _, Pr, Xr, Lr = oracle.member_eval(w.sys_type, w.A[k], w.B[k], w.Xi[k], w.Xt[k], w.x, w.T, variant=variant,
+                                              trajectory=True)
+        for got, want, what in ((P, Pr, "propagators"), (X, Xr, "states"), (L, Lr, "costates")):
+            assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), what
+    for k in range(w.E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], w.n, what=f"n={w.n} member {k}")
+    assert_parity(F, G, F_ref, G_ref, w.n, what=f"n={w.n}")
+    return F, G
+
+
+@pytest.mark.parametrize("n", [33, 48, 64])
+@pytest.mark.parametrize("sys_type,herm", [("UnitaryGate", True), ("UnitaryGate", False), ("StateTransfer", True),
+                                           ("StateTransfer", False), ("CoherenceTransfer", False)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_grid_family_random(qoc, oracle, n, sys_type, herm, variant):
+    w = _random_problem(qoc, n, 3, 10, 3, sys_type, seed=700 + n, hermitian=herm, mixed=True)
+    # (norms as the BASELINE configs have them: dt |H| of a few hundredths .. tenths)
+    w.A *= 0.25
+    w.B *= 0.25
+    _check(qoc, oracle, w, variant=variant)
+
+
+@pytest.mark.parametrize("n", [40, 57])
+def test_grid_family_odd_sizes_many_controls(qoc, oracle, n):
+    """padding inside the last tile row / column; K beyond one trace group (4) and not a multiple of it"""
+    w = _random_problem(qoc, n, 7, 6, 2, "StateTransfer", seed=811 + n, hermitian=True, mixed=True)
+    w.A *= 0.2
+    w.B *= 0.2
+    _check(qoc, oracle, w)
+
+
+@pytest.mark.parametrize("scale", [1.0, 6.0])
+def test_grid_family_squaring_path(qoc, oracle, scale):
+    """dt |H|_1 far above theta8 = 0.08: several squarings per slice"""
+    w = _random_problem(qoc, 48, 2, 8, 2, "UnitaryGate", seed=99, hermitian=True)
+    w.A *= scale
+    w.B *= scale
+    _check(qoc, oracle, w)
+
+
+def test_grid_family_single_problem_and_one_slice(qoc, oracle):
+    w = _random_problem(qoc, 64, 2, 1, 1, "StateTransfer", seed=5, hermitian=True, mixed=True)
+    w.A *= 0.2
+    w.B *= 0.2
+    _check(qoc, oracle, w)
+    w = _random_problem(qoc, 33, 1, 5, 1, "UnitaryGate", seed=6, hermitian=False)
+    w.A *= 0.2
+    w.B *= 0.2
+    _check(qoc, oracle, w, variant=1)
+
+
+def test_grid_family_batches_and_reproducibility(qoc, oracle):
+    w = _random_problem(qoc, 48, 3, 9, 4, "StateTransfer", seed=31, hermitian=True, mixed=True)
+    w.A *= 0.2
+    w.B *= 0.2
+    rng = np.random.default_rng(3)
+    xs = [w.x, rng.uniform(-1, 1, w.x.shape), rng.uniform(0, 2, w.x.shape)]
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, max_batch=3) as eng:
+        Fb, Gb = eng.eval_batch(np.array(xs))
+        singles = [eng.eval(x) for x in xs]
+        again = eng.eval(xs[1])
+    for b, x in enumerate(xs):
+        F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, x, w.T)
+        assert_parity(Fb[b], Gb[b], F_ref, G_ref, w.n, what=f"batch entry {b}")
+        assert Fb[b] == singles[b][0] and np.array_equal(Gb[b], singles[b][1])          # a batch = its single evaluations, bitwise
+    assert again[0] == singles[1][0] and np.array_equal(again[1], singles[1][1])         # run to run: bitwise
+
+
+def test_grid_family_rectangular_states(qoc, oracle):
+    """64 x 1 states (vec(rho) of a three-qubit system under a Liouvillian, test/liou.jl:38-48 one size up): zero-padded"""
+    rng = np.random.default_rng(17)
+    n, K, N, E = 64, 2, 6, 2
+    A = np.array([0.15 * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) for _ in range(E)])
+    B = np.array([[0.1 * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) for _ in range(K)]] * E)
+    Xi = rng.standard_normal((E, n, 1)) + 1j * rng.standard_normal((E, n, 1))
+    Xt = rng.standard_normal((E, n, 1)) + 1j * rng.standard_normal((E, n, 1))
+    x = rng.uniform(0, 1, (K, N))
+    wts = np.array([0.3, 0.7])
+    F_ref, G_ref = oracle.ensemble_eval("UnitaryGate", A, B, Xi, Xt, wts, x, 1.0)
+    with qoc.GrapeEngine("UnitaryGate", A, B, Xi, Xt, wts, 1.0, N) as eng:
+        F, G = eng.eval(x)
+    assert_parity(F, G, F_ref, G_ref, n, what="64 x 1 states")
+
+
+def test_grid_family_on_a_group(qoc, oracle):
+    """three shards on one GPU (peer sum): the ensemble axis splits as for every other family"""
+    w = _random_problem(qoc, 40, 2, 7, 5, "UnitaryGate", seed=77, hermitian=True)
+    w.A *= 0.2
+    w.B *= 0.2
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, devices=[0, 0, 0],
+                         flags=qoc.engine.FLAG_GROUP_PEER_SUM) as eng:
+        F, G = eng.eval(w.x)
+    assert_parity(F, G, F_ref, G_ref, w.n, what="group of three shards")
+
+
+@pytest.mark.parametrize("n,sys_type,herm", [(7, "StateTransfer", True), (16, "CoherenceTransfer", False), (29, "UnitaryGate", True)])
+def test_small_sizes_through_the_grid_kernels(qoc, oracle, monkeypatch, n, sys_type, herm):
+    """GRAPE_GRID=1: NT = 1, 2 instances of the same kernels, against the oracle and against the tile family's result"""
+    w = _random_problem(qoc, n, 3, 11, 3, sys_type, seed=400 + n, hermitian=herm, mixed=True)
+    with _engine(qoc, w) as eng:
+        F_tile, G_tile = eng.eval(w.x)
+    monkeypatch.setenv("GRAPE_GRID", "1")
+    F, G = _check(qoc, oracle, w)
+    assert abs(F - F_tile) <= 1e-12 * max(1.0, abs(F_tile)) and np.abs(G - G_tile).max() <= 1e-12 * max(1.0, np.abs(G_tile).max())
+
+
+def test_exact_gradient_is_refused_beyond_32(qoc):
+    w = _random_problem(qoc, 40, 1, 4, 1, "UnitaryGate", seed=1)
+    with pytest.raises(Exception) as ei:
+        qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, gradient="exact")
+    assert "n <= 32" in str(ei.value)
