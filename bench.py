@@ -140,7 +140,7 @@ def tile_kernel_models(local, info):
     the padded D-layout dumps each kernel writes / reads.  Squarings (data dependent, none at the BASELINE configs with
     theta8 = 0.08) are not counted."""
     n, K, N, E = local.n, local.K, local.N, local.E
-    NT = 1 if n <= 16 else 2
+    NT = (n + 15) // 16                                    # (NT = 3, 4: sweep_grid.hip, n = 33..64)
     units = (E + 1) // 2 if n <= 8 else E                  # n <= 8: two members share a tile
     tsz = (16 * NT) ** 2 * 16                              # bytes of one matrix dump
     prod = 12 * NT ** 3 * 2048                             # flops of one complex tile-matrix product
@@ -187,7 +187,7 @@ def split_kernels(names):
     """The library's launch list (grape_get_kernel_names) cut where the middle HIP event sits: behind the expm kernel of the
     n = 5..32 family, or behind the vector chains of the propagator-free flow (the pre-pass launches in front of them
     belong to the first part, the reductions to the second)."""
-    for prefixes in (("prop_",), ("action_parts", "action_thin")):
+    for prefixes in (("prop_", "grid_prop"), ("action_parts", "action_thin")):
         for i, k in enumerate(names):
             if k.startswith(prefixes):
                 return names[:i + 1], names[i + 1:]
@@ -680,7 +680,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the device-resident loop and the extra configs")
-    ap.add_argument("--extra-configs", default="C4,C5,C4dense,C4expm,C2,C5x1,C4x1")
+    ap.add_argument("--extra-configs", default="C4,C5,C4dense,C4expm,C6,C2,C5x1,C4x1")
     ap.add_argument("--details", default="", help="also write the complete record (every note, per-kernel model, L-BFGS traces) "
                                                   "to this file; the printed line stays compact")
     ap.add_argument("--verbose", action="store_true", help="print the complete record instead of the compact line")
@@ -913,10 +913,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra and args.extra_configs:
         out["extra_configs"] = []
         for name in [s for s in args.extra_configs.split(",") if s and s != args.config]:
-            heavy = name in ("C4", "C4dense", "C4expm", "C5")
+            heavy = name in ("C4", "C4dense", "C4expm", "C5", "C6")
+            slow = name in ("C5", "C6")
             try:
-                out["extra_configs"].append(run_extra_config(qoc, name, dev_index, 3 if name == "C5" else (20 if heavy else 200),
-                                                             1 if name == "C5" else (3 if heavy else 20)))
+                out["extra_configs"].append(run_extra_config(qoc, name, dev_index, 3 if slow else (20 if heavy else 200),
+                                                             1 if slow else (3 if heavy else 20)))
             except Exception as exc:               # noqa: BLE001 -- an extra line must not kill the headline
                 out["extra_configs"].append({"workload": name, "error": repr(exc)})
     # the JSON line must be the LAST thing on stdout: flush what native libraries (RCCL prints a version banner

@@ -4,14 +4,19 @@
 // A 64 x 64 ComplexF64 matrix is 64 KB -- 256 registers per lane of ONE wave.  Here a WORKGROUP of NT x NT waves owns every
 // matrix, wave (I, J) its 16 x 16 tile (I, J) in the FP64 matrix cores' accumulator ("D") layout of tile.hpp: 16 registers
 // per matrix and wave.  Element-wise work (the H build, the Taylor combinations, the traces) never leaves the owner.  A
-// product  C = op(A) op(B)  goes through two plain row-major images in LDS (re plane | im plane, row pitch 16 NT + 4):
+// product  C = op(A) op(B)  goes through two images in LDS (re plane | im plane each):
 //     barrier -- owners write their tiles of A and B -- barrier -- wave (I, J) reads the fragments of row I of op(A) and of
-//     column J of op(B) as MFMA operands (a conjugate transpose is index arithmetic on the image) and runs
-//     4 NT k-blocks x 3 v_mfma_f64_16x16x4 (the three-product complex multiplication of tile.hpp, operand sums formed in
-//     registers).
-// An operand that is still in its image from the previous product is not written again (P in  P' (L P),  X and L in the
-// commutator).  LDS: 4 planes x 16 NT x (16 NT + 4) doubles = 136 KB at NT = 4: one workgroup of 16 waves per compute unit,
-// four waves per SIMD, whose MFMA phases cover each other's LDS phases.
+//     column J of op(B) as MFMA operands and runs 4 NT k-blocks x 3 v_mfma_f64_16x16x4 (the three-product complex
+//     multiplication of tile.hpp, operand sums formed in registers).
+// The images are written K-CONTIGUOUS for their role: the left operand as [output row][k], the right operand as [output
+// column][k] (a plain or a transposed write of the owner's tile; a conjugate transpose swaps which of the two it is), and a
+// k-block takes the k values 16 Kt + 4 (lane >> 4) + kb -- any assignment of k to (k-block, lane group) will do as long as
+// both operands use the same one -- so a lane's operands of FOUR k-blocks are 32 contiguous bytes: two ds_read_b128 per
+// plane where the MFMA's native k order needs four ds_read_b64 (the first version: 3.1 LDS instructions per MFMA, matrix pipe
+// 0.43 / 0.56 busy at C6).  Row pitch 16 NT + 2 doubles: (pitch / 2) odd spreads the 64 lanes' 16-byte reads evenly over
+// the bank groups.  An operand that is still in its image from the previous product is not written again (P in P' (L P)).
+// LDS: 4 planes x 16 NT x (16 NT + 2) doubles = 132 KB at NT = 4: one workgroup of 16 waves per compute unit, four waves
+// per SIMD, whose MFMA phases cover each other's LDS phases.
 //
 // Data flow = the reference's own (general) flow for every system type and both formula variants: grid_prop_kernel forms
 // G_t = (-i dt)(A + sum_c x[c,t] B_c) in the reference's association and P_t = exp(G_t) (degree-8 Taylor polynomial in three
@@ -33,7 +38,7 @@ struct GT {                        // this wave's tile of a matrix, D layout
 template <int NT>
 struct GridGeom {
     static constexpr int DIM = 16 * NT;
-    static constexpr int P = DIM + 4;             // row pitch (doubles): rows 4 apart land 32 banks apart
+    static constexpr int P = DIM + 2;             // row pitch (doubles): P / 2 odd -- 16-byte reads of 16 rows x 4 groups hit every bank group 4 times
     static constexpr int PLANE = DIM * P;         // doubles per plane; an image is [re plane | im plane]
     static constexpr int WAVES = NT * NT;
     static constexpr int TSZ = NT * NT * 256;     // double2 per matrix dump
@@ -44,7 +49,7 @@ constexpr int kGridRed = 2 + 2 * kGridGroup;      // doubles a wave contributes 
 
 size_t grid_lds_bytes(int NT, bool chain)
 {
-    const size_t dim = 16 * (size_t)NT, plane = dim * (dim + 4);
+    const size_t dim = 16 * (size_t)NT, plane = dim * (dim + 2);
     return sizeof(double) * (4 * plane + (chain ? 2 * (size_t)NT * NT * kGridRed : (size_t)NT * dim));
 }
 
@@ -67,43 +72,53 @@ GRAPE_DEV void gt_store(double2 *__restrict__ dump, int tile, int lane, const GT
         dump[(tile * 4 + r) * 64 + lane] = make_double2(t.re[r], t.im[r]);
 }
 
-// own tile -> image: element (16 I + 4 r + (lane >> 4), 16 J + (lane & 15))
-template <int NT>
+// own tile -> image, element (row, col) = (16 I + 4 r + (lane >> 4), 16 J + (lane & 15)) of the matrix at [row][col]
+// (TRANS = false) or at [col][row] (TRANS = true)
+template <int NT, bool TRANS>
 GRAPE_DEV void grid_put(double *__restrict__ img, const GT &t, int I, int J, int lane)
 {
     constexpr int P = GridGeom<NT>::P, PLANE = GridGeom<NT>::PLANE;
-    const int at = (16 * I + (lane >> 4)) * P + 16 * J + (lane & 15);
+    const int row = 16 * I + (lane >> 4), col = 16 * J + (lane & 15);
+    const int at = TRANS ? col * P + row : row * P + col;
+    constexpr int step = TRANS ? 4 : 4 * P;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        img[at + 4 * r * P] = t.re[r];
-        img[PLANE + at + 4 * r * P] = t.im[r];
+        img[at + r * step] = t.re[r];
+        img[PLANE + at + r * step] = t.im[r];
     }
 }
 
-// tile (I, J) of op(A) op(B) from the images of A and B; HA / HB: the conjugate transpose of that operand.
-// A fragment of k-block (Kt, kb), lane l:  op(A)[16 I + (l & 15)][kk],  B fragment:  op(B)[kk][16 J + (l & 15)],
-// kk = 16 Kt + 4 kb + (l >> 4).  (x + i sa y)(u + i sb v): re = xu - sa sb yv, im = (x + sa y)(u + sb v) - xu - sa sb yv.
-template <int NT, bool HA, bool HB>
+// tile (I, J) of C = L R for a left operand given as ia[i][k] = L[i][k] and a right operand given as ib[j][k] = R[k][j];
+// CA / CB: that operand is to be conjugated (so  A'  as the left operand = the TRANSPOSED image of A with CA, and  B'  as the
+// right operand = the PLAIN image of B with CB).  k-block (Kt, kb) of lane l covers k = 16 Kt + 4 (l >> 4) + kb.
+// (x + i sa y)(u + i sb v): re = xu - sa sb yv, im = (x + sa y)(u + sb v) - xu - sa sb yv.
+template <int NT, bool CA, bool CB>
 GRAPE_DEV GT grid_mma(const double *__restrict__ ia, const double *__restrict__ ib, int I, int J, int lane)
 {
     constexpr int P = GridGeom<NT>::P, PLANE = GridGeom<NT>::PLANE;
     const int lo = lane & 15, hi = lane >> 4;
-    const int a0 = HA ? hi * P + 16 * I + lo : (16 * I + lo) * P + hi;
-    const int b0 = HB ? (16 * J + lo) * P + hi : hi * P + 16 * J + lo;
-    constexpr int astep = HA ? 4 * P : 4, bstep = HB ? 4 : 4 * P;         // one k-block further
+    const double2 *__restrict__ ar2 = reinterpret_cast<const double2 *>(ia + (16 * I + lo) * P + 4 * hi);
+    const double2 *__restrict__ ai2 = reinterpret_cast<const double2 *>(ia + PLANE + (16 * I + lo) * P + 4 * hi);
+    const double2 *__restrict__ br2 = reinterpret_cast<const double2 *>(ib + (16 * J + lo) * P + 4 * hi);
+    const double2 *__restrict__ bi2 = reinterpret_cast<const double2 *>(ib + PLANE + (16 * J + lo) * P + 4 * hi);
     d4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0}, t3 = {0, 0, 0, 0};
 #pragma unroll
-    for (int q = 0; q < 4 * NT; ++q) {
-        const double ar = ia[a0 + q * astep], ai = ia[PLANE + a0 + q * astep];
-        const double br = ib[b0 + q * bstep], bi = ib[PLANE + b0 + q * bstep];
-        const double as = HA ? ar - ai : ar + ai;
-        const double bs = HB ? br - bi : br + bi;
-        t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, t1, 0, 0, 0);
-        t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, t2, 0, 0, 0);
-        t3 = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bs, t3, 0, 0, 0);
+    for (int Kt = 0; Kt < NT; ++Kt) {
+        const double2 a0 = ar2[8 * Kt], a1 = ar2[8 * Kt + 1], c0 = ai2[8 * Kt], c1 = ai2[8 * Kt + 1];
+        const double2 b0 = br2[8 * Kt], b1 = br2[8 * Kt + 1], e0 = bi2[8 * Kt], e1 = bi2[8 * Kt + 1];
+        const double ar[4] = {a0.x, a0.y, a1.x, a1.y}, ai[4] = {c0.x, c0.y, c1.x, c1.y};
+        const double br[4] = {b0.x, b0.y, b1.x, b1.y}, bi[4] = {e0.x, e0.y, e1.x, e1.y};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const double as = CA ? ar[kb] - ai[kb] : ar[kb] + ai[kb];
+            const double bs = CB ? br[kb] - bi[kb] : br[kb] + bi[kb];
+            t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[kb], br[kb], t1, 0, 0, 0);
+            t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[kb], bi[kb], t2, 0, 0, 0);
+            t3 = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bs, t3, 0, 0, 0);
+        }
     }
     GT out;
-    if (HA != HB) {
+    if (CA != CB) {
         out.re = t1 + t2;
         out.im = t3 - t1 + t2;
     } else {
@@ -173,7 +188,8 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_prop_kernel(const TileParam
         cs = swap16_add(cs, cs);
         cs = swap32_add(cs, cs);
         __syncthreads();                               // the previous slice's readers are done
-        grid_put<NT>(img0, G, I, J, lane);
+        grid_put<NT, false>(img0, G, I, J, lane);
+        grid_put<NT, true>(img1, G, I, J, lane);
         if (lane < 16)
             s_col[I * DIM + 16 * J + lane] = cs;
         __syncthreads();
@@ -186,7 +202,7 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_prop_kernel(const TileParam
         colmax = wave_max_fast(colmax);                // the same number in every wave: upper bound of |G|_1
         const int s = p.s_forced >= 0 ? p.s_forced : squarings_for(colmax);
         // A2 = G G on the unscaled generator, then the power-of-two scaling (exact) on both
-        GT A2 = grid_mma<NT, false, false>(img0, img0, I, J, lane);
+        GT A2 = grid_mma<NT, false, false>(img0, img1, I, J, lane);
         if (s > 0) {
             const double sc = ldexp(1.0, -s), sc2 = ldexp(1.0, -2 * s);
             G.re *= sc;
@@ -198,8 +214,8 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_prop_kernel(const TileParam
         T.re = kX1 * G.re + kX2 * A2.re;
         T.im = kX1 * G.im + kX2 * A2.im;
         __syncthreads();
-        grid_put<NT>(img0, A2, I, J, lane);
-        grid_put<NT>(img1, T, I, J, lane);
+        grid_put<NT, false>(img0, A2, I, J, lane);
+        grid_put<NT, true>(img1, T, I, J, lane);
         __syncthreads();
         const GT A4 = grid_mma<NT, false, false>(img0, img1, I, J, lane);      // A4 = A2 (x1 G + x2 A2)
         GT U;
@@ -209,8 +225,8 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_prop_kernel(const TileParam
         T.im = kX5 * G.im + kX6 * A2.im + kX7 * A4.im;
         gt_add_identity(T, kX4, I, J, lane);
         __syncthreads();
-        grid_put<NT>(img0, U, I, J, lane);
-        grid_put<NT>(img1, T, I, J, lane);
+        grid_put<NT, false>(img0, U, I, J, lane);
+        grid_put<NT, true>(img1, T, I, J, lane);
         __syncthreads();
         GT Pm = grid_mma<NT, false, false>(img0, img1, I, J, lane);            // A8
         Pm.re += G.re + kY2 * A2.re;
@@ -218,9 +234,10 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_prop_kernel(const TileParam
         gt_add_identity(Pm, 1.0, I, J, lane);
         for (int i = 0; i < s; ++i) {                  // undo the scaling
             __syncthreads();
-            grid_put<NT>(img0, Pm, I, J, lane);
+            grid_put<NT, false>(img0, Pm, I, J, lane);
+            grid_put<NT, true>(img1, Pm, I, J, lane);
             __syncthreads();
-            Pm = grid_mma<NT, false, false>(img0, img0, I, J, lane);
+            Pm = grid_mma<NT, false, false>(img0, img1, I, J, lane);
         }
         gt_store(p.props + (((size_t)blockIdx.z * p.E + k) * p.N + t) * TSZ, tile, lane, Pm);
     }
@@ -252,14 +269,14 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
             gt_store(Xk + (size_t)t * TSZ, tile, lane, X);
             if (t + 1 < N) {                           // (the state behind the last slice is never read)
                 __syncthreads();
-                grid_put<NT>(img0, Pt, I, J, lane);
-                grid_put<NT>(img1, X, I, J, lane);
+                grid_put<NT, false>(img0, Pt, I, J, lane);                      // P plain: the left operand of P X, the right one of . P'
+                grid_put<NT, true>(img1, X, I, J, lane);
                 __syncthreads();
                 Pt = gt_load(Pk + (size_t)(t + 1) * TSZ, tile, lane);           // next slice's tile in flight under the products
                 if (SAND) {
                     const GT Y = grid_mma<NT, false, false>(img0, img1, I, J, lane);      // P X            (:245-246 as (P X) P')
                     __syncthreads();
-                    grid_put<NT>(img1, Y, I, J, lane);
+                    grid_put<NT, false>(img1, Y, I, J, lane);
                     __syncthreads();
                     X = grid_mma<NT, false, true>(img1, img0, I, J, lane);      // (P X) P'
                 } else {
@@ -277,14 +294,14 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
     for (int t = N - 1; t >= 0; --t) {
         const int tp = max(t - 1, 0);
         __syncthreads();
-        grid_put<NT>(img0, Pt, I, J, lane);
-        grid_put<NT>(img1, L, I, J, lane);
+        grid_put<NT, true>(img0, Pt, I, J, lane);                               // P transposed: P' as a left operand, P as a right one
+        grid_put<NT, SAND == 0>(img1, L, I, J, lane);                           // L: left operand of L P (plain) / right operand of P' L (transposed)
         __syncthreads();
         Pt = gt_load(Pk + (size_t)tp * TSZ, tile, lane);
         if (SAND) {
             const GT Y = grid_mma<NT, false, false>(img1, img0, I, J, lane);    // L P             (:248)
             __syncthreads();
-            grid_put<NT>(img1, Y, I, J, lane);
+            grid_put<NT, true>(img1, Y, I, J, lane);
             __syncthreads();
             L = grid_mma<NT, true, false>(img0, img1, I, J, lane);              // P' (L P)        (:249)
         } else {
@@ -301,16 +318,20 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
             zi_p = fma(-X.im[r], L.re[r], zi_p);
         }
         __syncthreads();
-        grid_put<NT>(img0, X, I, J, lane);
-        grid_put<NT>(img1, L, I, J, lane);
+        grid_put<NT, false>(img0, X, I, J, lane);
+        grid_put<NT, false>(img1, L, I, J, lane);
         __syncthreads();
-        X = gt_load(Xk + (size_t)tp * TSZ, tile, lane);
         GT R = grid_mma<NT, false, true>(img0, img1, I, J, lane);               // X L'
         if (SAND) {
+            __syncthreads();
+            grid_put<NT, true>(img0, X, I, J, lane);
+            grid_put<NT, true>(img1, L, I, J, lane);
+            __syncthreads();
             const GT R2 = grid_mma<NT, true, false>(img1, img0, I, J, lane);    // L' X           ([X, L'], src/tools.jl:17-19)
             R.re -= R2.re;
             R.im -= R2.im;
         }
+        X = gt_load(Xk + (size_t)tp * TSZ, tile, lane);                         // (in flight under the traces)
         // traces: sum_ij B_c[i][j] R[j][i] = sum over the elements of (B_c^T .* R); kGridGroup controls per reduction, the
         // workgroup's sum in wave order (deterministic)
         for (int c0 = 0; c0 < K; c0 += kGridGroup) {

@@ -250,9 +250,9 @@ def _haar_unitary(n):
     return q * ph[None, :]
 
 
-def five_qubit_unitary(E=4096, N=2000, T=10.0):
-    """C5: 32x32 UnitaryGate, K=6."""
-    nq, K = 5, 6
+def five_qubit_unitary(E=4096, N=2000, T=10.0, nq=5):
+    """C5: 32x32 UnitaryGate, K=6 (nq = 6: the same chain one qubit longer, 64 x 64 -- "C6")."""
+    K = 6
     d = detunings(E)
     Z, X, Y = 2 * Sz, 2 * Sx, 2 * Sy
     H0 = sum(0.25 * site_op(Z, q, nq) @ site_op(Z, q + 1, nq) for q in range(nq - 1))
@@ -262,8 +262,9 @@ def five_qubit_unitary(E=4096, N=2000, T=10.0):
     for q in (0, 2, 4):
         Bs += [0.5 * site_op(X, q, nq), 0.5 * site_op(Y, q, nq)]
     Bs = np.array(Bs)
-    return Workload("C5", "UnitaryGate", 32, K, N, E, T, A, _bcast(Bs, E),
-                    _bcast(np.eye(32, dtype=complex), E), _bcast(_haar_unitary(32), E),
+    n = 2 ** nq
+    return Workload("C5" if nq == 5 else f"C{nq}", "UnitaryGate", n, K, N, E, T, A, _bcast(Bs, E),
+                    _bcast(np.eye(n, dtype=complex), E), _bcast(_haar_unitary(n), E),
                     np.full(E, 1.0 / E), controls(K, N))
 
 
@@ -284,6 +285,11 @@ def config(name, E=None, N=None, **extra):
         return two_qubit_liouvillian(**kw)
     if name == "C5":
         return five_qubit_unitary(**kw)
+    if name == "C6":                                   # beyond BASELINE.json: the first size past one wavefront's registers
+        kw.setdefault("E", 256)                        # (6-qubit gate, 64 x 64, K = 6, N = 500, E = 256)
+        kw.setdefault("N", 500)
+        kw.setdefault("T", 2.5)
+        return five_qubit_unitary(nq=6, **kw)
     raise KeyError(name)
 
 
