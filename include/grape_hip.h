@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GRAPE_ABI_VERSION 4
+#define GRAPE_ABI_VERSION 5
 
 typedef enum grape_status {
     GRAPE_OK = 0,
@@ -188,6 +188,13 @@ typedef struct grape_info {
                                       (down to one problem): the expm kernel stores P_t and P_t^T and both vector chains run on
                                       them with one matrix-vector product per slice (chain_prop_kernel); with time_chunks >= 2
                                       on a chunked time axis (a workgroup per member and chunk) */
+    /* ---- ABI v5 ---- */
+    int32_t member_chunk;          /* members the workspace arrays (P_t, X_t, L_t) hold at a time: n_ensemble when everything
+                                      fits, fewer when the ensemble's workspace exceeds 0.9 x the free device memory (or
+                                      GRAPE_MAX_WORKSPACE_BYTES): an evaluation then walks the ensemble in blocks of this
+                                      many members (src/solve.jl:166-187 is a serial loop with no such limit) -- same
+                                      results bit for bit; grape_get_trajectory is not available on such a context */
+    int32_t reserved0;
 } grape_info;
 
 /* Opaque RCCL bootstrap token (ncclUniqueId), see grape_comm_unique_id / grape_comm_attach. */
@@ -290,7 +297,13 @@ int grape_eval_batch_device(grape_ctx *ctx, int32_t n_x, const double *d_x, doub
  * GRAPE evaluation per trial step.  line_search:
  *   0  Hager-Zhang; the initial step is taken at once when it satisfies the (approximate) Wolfe conditions
  *   1  Hager-Zhang exactly as Optim runs it behind InitialStatic (`mayterminate` false: the initial step is never
- *      accepted without a second evaluation)
+ *      accepted without a second evaluation).  ABI v5: LineSearches.jl's control flow to the letter -- max_linesearch counts
+ *      passes of its bracketing / secant^2 loops as `linesearchmax` does (bisections inside a pass are not counted), a
+ *      collapsed or flat bracket returns its lower end even at alpha = 0 (status 4: Optim then stops with "x converged"),
+ *      a search that runs out of passes ends the run with status 3 as Optim's LineSearchException does (Optim takes the
+ *      step of the exception's alpha first; this loop does not), two successive iterations without any change of F end it
+ *      with status 1.  oracle/optim_lbfgs.py restates Optim.jl's LBFGS + LineSearches.jl's HagerZhang in NumPy and
+ *      tests/test_gpu_lbfgs.py holds this mode to it step length by step length.
  *   2  the factor-2 ladder of ABI v2: `probes` step lengths alpha, alpha/2, ... per BATCHED launch
  *      (grape_config.max_batch >= probes), the largest with sufficient decrease (c1 = 1e-4), preferring the strong Wolfe
  *      curvature condition (c2 = 0.9)
@@ -320,7 +333,8 @@ typedef struct grape_lbfgs_result {
     double  seconds;           /* wall time of the whole optimisation                    */
     int32_t iterations;
     int32_t evaluations;       /* control arrays evaluated (probes count individually)   */
-    int32_t status;            /* 0 g_tol reached, 1 f_tol reached, 2 max_iterations, 3 line search failed */
+    int32_t status;            /* 0 g_tol reached, 1 f_tol reached, 2 max_iterations, 3 line search failed,
+                                  4 (ABI v5, line_search = 1) zero step: Optim's "x converged" with x_tol = 0 */
     int32_t probes;            /* step lengths per launch actually used                  */
     /* ---- ABI v3 ---- */
     int32_t line_search;       /* the mode that ran                                      */
@@ -331,6 +345,11 @@ typedef struct grape_lbfgs_result {
  * opts may be NULL (all defaults). */
 int grape_lbfgs(grape_ctx *ctx, const double *x0, const grape_lbfgs_options *opts, double *x_min,
                 grape_lbfgs_result *result);
+
+/* ABI v5.  The last grape_lbfgs run on this context, per iteration: the accepted step length and the number of control
+ * arrays evaluated up to the end of that iteration (what Optim's trace shows as `alpha` and f_calls).  *count = iterations
+ * recorded; at most `capacity` entries are written (alphas / evals may be NULL). */
+int grape_lbfgs_get_trace(const grape_ctx *ctx, double *alphas, int32_t *evals, int32_t capacity, int32_t *count);
 
 /* Debug/parity accessors (valid after an evaluation; needs GRAPE_FLAG_MEMBER_RESULTS; after a batched
  * evaluation they refer to control array 0):

@@ -146,6 +146,17 @@ function kernel_names(ctx::GrapeContext)
     filter(!isempty, split(unsafe_string(pointer(buf)), ';'))
 end
 
+"Accepted step length and cumulative evaluation count of every iteration of the last `grape_lbfgs` run (ABI v5)."
+function lbfgs_trace(ctx::GrapeContext)
+    n = Ref{Int32}(0)
+    check(ctx, ccall((:grape_lbfgs_get_trace, libgrape), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int32}, Int32, Ptr{Int32}),
+                     ctx.handle, C_NULL, C_NULL, 0, n))
+    alphas, evals = Vector{Float64}(undef, n[]), Vector{Int32}(undef, n[])
+    check(ctx, ccall((:grape_lbfgs_get_trace, libgrape), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int32}, Int32, Ptr{Int32}),
+                     ctx.handle, alphas, evals, n[], n))
+    alphas, evals
+end
+
 """
 One process per GPU without librccl (ABI v4): `allgather` is any function that returns every rank's 64 bytes in rank
 order as one `Vector{UInt8}` (e.g. `h -> MPI.Allgather(h, comm)`).  Afterwards `fom_and_gradient!` on every rank returns

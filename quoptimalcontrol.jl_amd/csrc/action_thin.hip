@@ -1180,7 +1180,7 @@ static hipError_t launch_action_nb(int sandwich, const TileParams &p, hipStream_
     // per wave (4096: 2.96 against 3.70 ms).  GRAPE_ACT_WHOLE=0 / 1 forces either.
     const char *whole_var = std::getenv("GRAPE_ACT_WHOLE");
     const int whole_env = whole_var ? std::atoi(whole_var) : -1;
-    const long simds = 4 * (long)(p.cus > 0 ? p.cus : 256), units = (long)p.E * p.n_x;
+    const long simds = 4 * (long)(p.cus > 0 ? p.cus : 256), units = (long)(p.E_plan ? p.E_plan : p.E) * p.n_x;
     const bool whole = parts && (whole_env >= 0 ? whole_env != 0 : (units > simds && units <= 2 * simds) || units > 3 * simds);
     // as many workgroups per compute unit as an even spread of the launch needs, and no more: the LDS request is the limiter
     const int per_group = NB == 16 ? (whole ? 2 * kActWaves : kActWaves) : kActWaves / 2;          // members of a workgroup

@@ -72,6 +72,16 @@ struct grape_ctx {
     double *d_xg_scratch = nullptr;   // only when K*N is too long for the LDS staging buffer
     int ksplit = 1;
     size_t ws_elems = 0;          // double2 elements per workspace array
+    // member-chunked evaluation (round 5; SURVEY.md section 7 "needs member-chunking", src/solve.jl:166-187 is a serial member
+    // loop with no memory cliff): when P_t / X_t / L_t of the whole ensemble exceed the budget, the workspace arrays hold Ec
+    // members and an evaluation walks the ensemble in blocks of Ec through them; per-member inputs and result rows stay whole,
+    // and the weighted sum runs once over all rows in its fixed order -- a chunked evaluation is bitwise the unchunked one.
+    int Ec = 0, EUc = 0;          // members / wavefront-level units per workspace chunk (= n_ensemble / EU when everything fits)
+    size_t ws_unit = 0;           // double2 elements of one unit's share of a workspace array
+    size_t ws_budget = 0;         // bytes the workspace arrays may take: GRAPE_MAX_WORKSPACE_BYTES, else 0.9 x free memory - the rest
+    int ws_arrays = 1;            // arrays the current plan was made for (props [+ costates] [+ states])
+    int ws_B = 1;                 // control arrays the workspace holds: max_batch, or 1 when that does not fit (a batch then runs
+                                  // its arrays one behind the other, as it does on a member-chunked workspace)
     uint64_t bytes = 0;
     // device
     double2 *d_ops = nullptr;
@@ -111,6 +121,8 @@ struct grape_ctx {
     int ipc_ranks = 0;                         // > 1: attached
     int ipc_alloc_ranks = 0;                   // ranks the own mailbox was sized for
     unsigned long long ipc_evals = 0, ipc_count[2] = {0, 0};
+    std::vector<double> lb_alpha;              // grape_lbfgs: accepted step length of every iteration of the last run ...
+    std::vector<int32_t> lb_evals;             // ... and the evaluations made up to its end (grape_lbfgs_get_trace)
     bool broken = false;                       // a partial failure left counters / peers out of step: every further evaluation is refused
     bool thin = false;                         // rank-one states: matrix-vector chain (sweep_thin.hip)
     bool herm_ctrl = false;                    // every B_c Hermitian
@@ -460,6 +472,35 @@ static int validate_config(const grape_config *cfg)
     return GRAPE_OK;
 }
 
+// How many members the workspace arrays hold: all of them when `arrays` arrays of the whole ensemble (x max_batch) fit the
+// budget, else as many whole units of work as fit ONE control array's share (a chunked context runs the arrays of a batch
+// one behind the other) -- in multiples of the members a workgroup / a wave pairs up, so that a member's arithmetic does
+// not depend on where the chunks are cut.  false: not even one granule fits.
+static bool plan_chunk(grape_ctx *c, int arrays)
+{
+    const size_t E = (size_t)c->cfg.n_ensemble, unit_bytes = sizeof(double2) * c->ws_unit * (size_t)arrays;
+    const size_t units = c->family == 0 ? E : (size_t)c->EU;
+    c->ws_arrays = arrays;
+    c->ws_B = c->B;
+    if (unit_bytes * units * (size_t)c->B <= c->ws_budget) {
+        c->Ec = (int)E;
+        c->EUc = c->EU;
+    } else {
+        c->ws_B = 1;
+        size_t fit = c->ws_budget / unit_bytes;                      // units of one control array
+        const size_t gran = c->family == 0 ? (size_t)c->MPB : (c->pack2 ? 1 : 2);
+        fit = fit / gran * gran;
+        if (fit < gran) return false;
+        if (fit > units) fit = units;
+        c->EUc = (int)fit;
+        c->Ec = c->family == 1 && c->pack2 ? (int)std::min(E, 2 * fit) : (int)fit;
+    }
+    c->ws_elems = c->ws_unit * (size_t)(c->family == 0 ? c->Ec : c->EUc);
+    return true;
+}
+static bool chunked(const grape_ctx *c) { return c->Ec < c->cfg.n_ensemble; }
+static size_t ws_batch(const grape_ctx *c) { return (size_t)c->ws_B; }                    // control arrays the workspace holds
+
 // one device, one contiguous shard of members: the workspace init_GRAPE allocates
 static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
 {
@@ -565,10 +606,27 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
 
     const size_t nn = (size_t)cfg->n * cfg->n, K = cfg->n_controls;
     const size_t Q = KN(c) + 1;
-    c->ws_elems = c->family == 0 ? (size_t)E * S * nn * c->CH : (size_t)c->EU * N * c->TSZ;
+    c->ws_unit = c->family == 0 ? (size_t)S * nn * c->CH : (size_t)N * c->TSZ;
     const size_t ops_elems = c->family == 0 ? (size_t)E * (K + 3) * nn : (size_t)c->EU * (2 * K + 3) * c->TSZ;
     const bool exact = cfg->gradient == GRAPE_GRADIENT_EXACT;  // needs every X_t and L_t in HBM: the debug flow
     const bool keepl = (cfg->flags & GRAPE_FLAG_KEEP_COSTATES) != 0 || exact;
+    {
+        // workspace budget: what is free now minus what is allocated besides the workspace arrays (operators, rows, staging;
+        // twice, for the buffers grape_set_operators adds), 90 % of it.  GRAPE_MAX_WORKSPACE_BYTES overrides (tests).
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const size_t rest = 2 * (sizeof(double2) * ops_elems + sizeof(double) * (size_t)E * Q * c->B) + ((size_t)64 << 20);
+        c->ws_budget = free_b > rest ? (size_t)(0.9 * (double)(free_b - rest)) : 0;
+        if (const char *ev = std::getenv("GRAPE_MAX_WORKSPACE_BYTES")) c->ws_budget = (size_t)std::strtoull(ev, nullptr, 10);
+        // optimistic plan: the propagators (and the costates when asked for); grape_set_operators plans again when the flow
+        // it chooses stores the forward states as well
+        if (!plan_chunk(c, 1 + (keepl ? 1 : 0))) {
+            const std::string msg = "grape_create: not even " + std::to_string(c->family == 0 ? c->MPB : 2) +
+                                    " members' workspace fits the budget of " + std::to_string(c->ws_budget) + " bytes";
+            delete c;
+            return fail(nullptr, GRAPE_ERR_ALLOC, msg);
+        }
+    }
 
     auto alloc = [&](void **p, size_t bytes) -> hipError_t {
         c->bytes += bytes;
@@ -580,8 +638,8 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     const size_t Bn = (size_t)c->B;
     if (e == hipSuccess) e = alloc((void **)&c->d_x, sizeof(double) * KN(c) * Bn);
     if (e == hipSuccess) e = alloc((void **)&c->d_fg, sizeof(double) * Q * Bn);
-    if (e == hipSuccess) e = alloc((void **)&c->d_props, sizeof(double2) * c->ws_elems * Bn);
-    if (e == hipSuccess && keepl) e = alloc((void **)&c->d_costates, sizeof(double2) * c->ws_elems * Bn);
+    if (e == hipSuccess) e = alloc((void **)&c->d_props, sizeof(double2) * c->ws_elems * ws_batch(c));
+    if (e == hipSuccess && keepl) e = alloc((void **)&c->d_costates, sizeof(double2) * c->ws_elems * ws_batch(c));
     if (e == hipSuccess && exact && c->family == 0) e = alloc((void **)&c->d_zphi, sizeof(double) * 2 * E * Bn);
     const bool want_rows = c->family == 1 || (cfg->flags & GRAPE_FLAG_MEMBER_RESULTS) || exact;
     if (e == hipSuccess && want_rows) e = alloc((void **)&c->d_member_out, sizeof(double) * E * Q * Bn);
@@ -1090,7 +1148,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     }
     if (c->cfg.gradient == GRAPE_GRADIENT_EXACT && c->family == 0 && !(c->cfg.flags & GRAPE_FLAG_KEEP_COSTATES)) {
         // the W_t flow writes no costates: their E N n^2 16 B bytes go back (and return if a later upload needs the debug flow)
-        const size_t cb = sizeof(double2) * c->ws_elems * (size_t)c->B;
+        const size_t cb = sizeof(double2) * c->ws_elems * ws_batch(c);
         if (c->exact_w1 && c->d_costates) {
             (void)hipFree(c->d_costates);
             c->d_costates = nullptr;
@@ -1233,12 +1291,13 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // robustness ensemble, ...): the same kernels form the sum themselves.  16 x 16 with shared controls: from 8 units
         // on (below, the pre-pass launch costs more than it saves and the round-2 kernel stays).  GRAPE_HOIST=0 keeps
         // prop_tile_kernel, GRAPE_HOIST=1 forces the new kernels for any ensemble size.
-        bool hz = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT && !c->grid;
+        bool hz = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT;
         const char *he = std::getenv("GRAPE_HOIST");
         if (he && he[0] == '0') hz = false;
         bool invariant = hz && !c->pack2;                        // (block-diagonal member pairs, n <= 8: always the in-kernel sum)
         for (size_t k = 1; k < E && invariant; ++k)
             invariant = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
+        if (c->grid && !invariant) hz = false;                   // sweep_grid.hip: the pre-pass or its own H build, nothing in between
         // (32 x 32: the new kernel is also the four-waves-per-propagator one -- single problems take it too)
         if (hz && invariant && !(he && he[0] == '1') && c->EU < 8 && c->NT == 1) {
             if (dpp_small) invariant = false;                    // (that flow needs this kernel's two dumps: the in-kernel sum, no pre-pass)
@@ -1528,7 +1587,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             }
             if (!c->d_act_gn) HIP_TRY(c, hipMalloc((void **)&c->d_act_gn, sizeof(double) * (size_t)c->B * c->cfg.n_slices));
             if (dpp) {
-                const size_t need = sizeof(double2) * E * ((size_t)c->cfg.n_slices + 1) * VS * c->B;
+                const size_t need = sizeof(double2) * (size_t)c->Ec * ((size_t)c->cfg.n_slices + 1) * VS * ws_batch(c);
                 if (c->wrec_bytes < need) {
                     (void)hipFree(c->d_wrec);
                     c->d_wrec = nullptr;
@@ -1537,7 +1596,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                     HIP_TRY(c, hipMalloc((void **)&c->d_wrec, need));
                     c->wrec_bytes = need;
                 }
-                const size_t need_t = sizeof(double2) * c->ws_elems * c->B;
+                const size_t need_t = sizeof(double2) * c->ws_elems * ws_batch(c);
                 if (c->props_t_bytes < need_t) {
                     (void)hipFree(c->d_props_t);
                     c->d_props_t = nullptr;
@@ -1553,6 +1612,35 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             HIP_TRY(c, hipMemcpy(c->d_act_bf, bf.data(), sizeof(double) * bf.size(), hipMemcpyHostToDevice));
         }
     }
+    {
+        // The flow is known now.  Does it keep the forward states in a workspace array of its own (general flow, the exact
+        // gradient's W_t)?  Then the chunk plan made at grape_create for the propagators alone is made again; when the members
+        // per chunk change, the arrays are allocated afresh (the vector flows' records and the chunked time axis only ever
+        // serve ensembles far below any budget).
+        const bool full_states = !thin && (!herm || c->exact_w1);
+        const int arrays = 1 + (c->d_costates ? 1 : 0) + (full_states ? 1 : 0);
+        const int had = c->Ec, had_B = c->ws_B;
+        if (arrays != c->ws_arrays) {
+            if (!plan_chunk(c, arrays))
+                return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: the workspace of this data flow does not fit the budget of " +
+                                                    std::to_string(c->ws_budget) + " bytes even for one workgroup's members");
+            if (c->Ec != had || c->ws_B != had_B) {
+                const size_t old_b = sizeof(double2) * c->ws_unit * (size_t)(c->family == 0 ? had : (c->pack2 ? (had + 1) / 2 : had)) * (size_t)had_B;
+                const size_t new_b = sizeof(double2) * c->ws_elems * ws_batch(c);
+                (void)hipFree(c->d_props); c->d_props = nullptr;
+                (void)hipFree(c->d_states); c->d_states = nullptr;
+                c->bytes -= c->states_bytes + old_b;
+                c->states_bytes = 0;
+                const bool keep = c->d_costates != nullptr;
+                if (keep) { (void)hipFree(c->d_costates); c->d_costates = nullptr; c->bytes -= old_b; }
+                HIP_TRY(c, hipMalloc((void **)&c->d_props, new_b));
+                c->bytes += new_b;
+                if (keep) { HIP_TRY(c, hipMalloc((void **)&c->d_costates, new_b)); c->bytes += new_b; }
+            }
+        }
+        if (chunked(c) && (c->tp_C || c->thin_dpp))
+            return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: a chunked time axis on a member-chunked workspace (budget too small for this ensemble)");
+    }
     if (thin) {
         c->unitary = false;                                  // the thin chain serves Hermitian generators as well
         if (!c->d_vecs) {
@@ -1560,7 +1648,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             HIP_TRY(c, hipMalloc((void **)&c->d_vecs, sizeof(double) * E * 4 * VS));
         }
         HIP_TRY(c, hipMemcpy(c->d_vecs, vecs.data(), sizeof(double) * E * 4 * VS, hipMemcpyHostToDevice));
-        const size_t rec = sizeof(double2) * E * ((size_t)c->cfg.n_slices + 1) * VS * c->B;
+        const size_t rec = sizeof(double2) * (size_t)c->Ec * ((size_t)c->cfg.n_slices + 1) * VS * ws_batch(c);
         if (c->states_bytes < rec) {                         // the forward pass's vector records: N + 1 per member
             (void)hipFree(c->d_states);
             c->d_states = nullptr;
@@ -1569,8 +1657,8 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             HIP_TRY(c, hipMalloc((void **)&c->d_states, rec));
             c->states_bytes = rec;
         }
-    } else if ((!herm || c->exact_w1) && c->states_bytes < sizeof(double2) * c->ws_elems * c->B) {
-        const size_t full = sizeof(double2) * c->ws_elems * c->B;
+    } else if ((!herm || c->exact_w1) && c->states_bytes < sizeof(double2) * c->ws_elems * ws_batch(c)) {
+        const size_t full = sizeof(double2) * c->ws_elems * ws_batch(c);
         (void)hipFree(c->d_states);
         c->d_states = nullptr;
         c->bytes += full - c->states_bytes;
@@ -1598,6 +1686,7 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.K = c->cfg.n_controls;
     p.N = c->cfg.n_slices;
     p.E = c->EU;
+    p.E_plan = c->EU;                                        // (a member-chunked launch keeps the whole ensemble's flow decisions)
     p.E_members = c->cfg.n_ensemble;
     p.pack2 = c->pack2 ? 1 : 0;
     p.n = c->cfg.n;
@@ -1637,6 +1726,7 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.action = c->action ? 1 : 0;
     if (c->action) {                                         // the vector flow works on members, whatever the tile packing
         p.E = c->cfg.n_ensemble;
+        p.E_plan = c->cfg.n_ensemble;
         p.pack2 = 0;
     }
     p.act_a = c->d_act_a;
@@ -1683,24 +1773,6 @@ static bool eval_ends_in_reduce(const grape_ctx *c)
     return c->family == 0 ? true : !tile_folds_reduce(c, 1);
 }
 
-static int enqueue_tile(grape_ctx *c, const double *d_x, hipStream_t stream, int n_x, hipEvent_t ev_mid = nullptr,
-                        double *d_fg = nullptr, grape::DoneSignal done = grape::DoneSignal())
-{
-    TileParams p = tile_params(c, d_x, n_x);
-    p.ev_mid = ev_mid;
-    if (d_fg && tile_folds_reduce(c, n_x)) {
-        p.fold_fg = d_fg;
-        p.fold_wts = c->d_wts;
-        p.fold_done = done;
-    }
-    if (c->grid)
-        HIP_TRY(c, grape::launch_sweep_grid(c->NT, c->cfg.sys_type != GRAPE_UNITARY_GATE, c->d_costates != nullptr, p, stream));
-    else
-        HIP_TRY(c, grape::launch_sweep_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE,
-                                            c->d_costates != nullptr, p, stream));
-    return GRAPE_OK;
-}
-
 // folds the `count` oldest outstanding event pairs into ev_total_ms (synchronises their stop events)
 static int fold_events(grape_ctx *c, uint64_t count)
 {
@@ -1726,9 +1798,10 @@ static int fold_events(grape_ctx *c, uint64_t count)
 static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream_t stream, int n_x = 1,
                         grape::DoneSignal done = grape::DoneSignal())
 {
-    if (c->cfg.gradient == GRAPE_GRADIENT_EXACT && n_x > 1) {
-        // the stored trajectory (every X_t and L_t of the debug flow) is ONE control array's: the arrays of a batch run one
-        // behind the other on the stream, each through the whole chain; the last reduction publishes them all
+    if ((c->cfg.gradient == GRAPE_GRADIENT_EXACT || n_x > c->ws_B) && n_x > 1) {
+        // the stored trajectory (every X_t and L_t of the debug flow) is ONE control array's, and so is a member-chunked
+        // workspace: the arrays of a batch run one behind the other on the stream, each through the whole chain; the last
+        // reduction publishes them all
         const size_t Qs = KN(c) + 1;
         for (int b = 0; b < n_x; ++b) {
             grape::DoneSignal db;
@@ -1736,6 +1809,7 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
                 db = done;
                 db.stage_base = d_fg;
                 db.n_total = (int)(Qs * n_x);
+                db.mflags = nullptr;                         // (one flag per workgroup covers ONE array's outputs)
             }
             const int rc = enqueue_eval(c, d_x + (size_t)b * KN(c), d_fg + (size_t)b * Qs, stream, 1, db);
             if (rc) return rc;
@@ -1795,39 +1869,83 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
         p.direct_flag = done.flag;
         p.direct_seq = done.seq;
     }
-    if (c->family == 0) {
-        const int mode = c->unitary ? 2 : (c->d_costates ? 1 : 0);
-        if (c->pair)
-            HIP_TRY(c, grape::launch_sweep_pair(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, mode, p, stream));
+    // The members [lo, lo + cnt) through the sweep / tile kernels (and the exact-gradient kernel behind them).  Unchunked: ONE
+    // call for the whole ensemble.  Member-chunked: per-member INPUTS and result ROWS are addressed from member lo on, the
+    // workspace arrays from their start -- the kernels index both by the launch's own member number.
+    const size_t nn = (size_t)c->cfg.n * c->cfg.n, Kc = (size_t)c->cfg.n_controls, Qrow = KN(c) + 1;
+    auto launch_members = [&](int lo, int cnt) -> int {
+        if (c->family == 0) {
+            SweepParams q = p;
+            q.ops = p.ops + (size_t)lo * (Kc + 3) * nn;
+            q.wts = p.wts + lo;
+            if (p.member_out) q.member_out = p.member_out + (size_t)lo * Qrow;
+            q.block_out = p.block_out + (size_t)(lo / c->MPB) * Qrow;
+            if (p.zphi) q.zphi = p.zphi + 2 * (size_t)lo;
+            q.E = cnt;
+            q.BPX = (cnt + c->MPB - 1) / c->MPB;
+            const int mode = c->unitary ? 2 : (c->d_costates ? 1 : 0);
+            if (c->pair)
+                HIP_TRY(c, grape::launch_sweep_pair(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, mode, q, stream));
+            else
+                HIP_TRY(c, grape::launch_sweep_small(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, mode, q, stream));
+            if (exact) {                                     // exact gradient + objective from the stored trajectory
+                grape::ExactParams xq{};
+                xq.ops = q.ops;
+                xq.x = d_x;
+                xq.props = c->d_props;
+                xq.states = c->d_states;
+                xq.costates = c->d_costates;
+                xq.member_out = c->d_member_out + (size_t)lo * Qrow;
+                xq.K = c->cfg.n_controls;
+                xq.N = c->cfg.n_slices;
+                xq.E = cnt;
+                xq.S = c->S;
+                xq.CH = c->CH;
+                xq.s_forced = c->cfg.expm_squarings;
+                xq.variant = c->cfg.variant;
+                xq.objective = c->cfg.objective;
+                xq.herm_states = c->herm_states ? 1 : 0;
+                xq.w1_in = c->exact_w1 ? 1 : 0;
+                xq.zphi = q.zphi;
+                HIP_TRY(c, grape::launch_exact_grad(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, xq, stream));
+            }
+            return GRAPE_OK;
+        }
+        TileParams t = tile_params(c, d_x, n_x);
+        if (lo != 0 || cnt != c->cfg.n_ensemble) {
+            const size_t lu = c->pack2 ? (size_t)lo / 2 : (size_t)lo, VS = 16 * (size_t)c->NT, VV = VS * VS;
+            t.E = c->action ? cnt : (c->pack2 ? (cnt + 1) / 2 : cnt);
+            t.E_members = cnt;
+            t.ops += lu * (2 * Kc + 3) * c->TSZ;
+            t.member_out += (size_t)lo * Qrow;
+            if (t.vecs) t.vecs += (size_t)lo * 2 * VS;
+            if (t.sp_coef) { t.sp_coef += lu * Kc * c->sp_nz; t.sp_addr += lu * Kc * c->sp_nz; }
+            if (t.ha) { t.ha += lu * c->TSZ; t.ha_norm += lu * (c->hoist == 1 ? 1 : 1 + Kc); }
+            if (t.act_a) { t.act_a += (size_t)lo * 2 * VV; t.act_an += lo; }
+            if (!c->act_shared && t.act_b) {
+                t.act_bn += (size_t)lo * Kc;
+                t.act_b += (size_t)lo * Kc * 2 * VV;
+                t.act_bf += (size_t)lo * Kc * VV;
+                if (t.act_bs) { t.act_bs += (size_t)lo * Kc * VS * c->act_R; t.act_bo += (size_t)lo * Kc * VS * c->act_R; }
+            }
+        }
+        t.ev_mid = lo == 0 ? emid : nullptr;
+        if (d_fg && tile_folds_reduce(c, n_x)) {
+            t.fold_fg = d_fg;
+            t.fold_wts = c->d_wts;
+            t.fold_done = done;
+        }
+        if (c->grid)
+            HIP_TRY(c, grape::launch_sweep_grid(c->NT, c->cfg.sys_type != GRAPE_UNITARY_GATE, c->d_costates != nullptr, t, stream));
         else
-            HIP_TRY(c, grape::launch_sweep_small(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, mode, p, stream));
-    } else {
-        int rc = enqueue_tile(c, d_x, stream, n_x, emid, d_fg, done);
+            HIP_TRY(c, grape::launch_sweep_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, c->d_costates != nullptr, t, stream));
+        if (exact)
+            HIP_TRY(c, grape::launch_exact_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, t, c->cfg.objective, stream));
+        return GRAPE_OK;
+    };
+    for (int lo = 0; lo < c->cfg.n_ensemble; lo += c->Ec) {
+        const int rc = launch_members(lo, std::min(c->Ec, c->cfg.n_ensemble - lo));
         if (rc) return rc;
-    }
-    if (exact && c->family == 1) {
-        HIP_TRY(c, grape::launch_exact_tile(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, tile_params(c, d_x),
-                                            c->cfg.objective, stream));
-    } else if (exact) {                                      // exact gradient + objective from the stored trajectory
-        grape::ExactParams q{};
-        q.ops = c->d_ops;
-        q.x = d_x;
-        q.props = c->d_props;
-        q.states = c->d_states;
-        q.costates = c->d_costates;
-        q.member_out = c->d_member_out;
-        q.K = c->cfg.n_controls;
-        q.N = c->cfg.n_slices;
-        q.E = c->cfg.n_ensemble;
-        q.S = c->S;
-        q.CH = c->CH;
-        q.s_forced = c->cfg.expm_squarings;
-        q.variant = c->cfg.variant;
-        q.objective = c->cfg.objective;
-        q.herm_states = c->herm_states ? 1 : 0;
-        q.w1_in = c->exact_w1 ? 1 : 0;
-        q.zphi = c->d_zphi;
-        HIP_TRY(c, grape::launch_exact_grad(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, q, stream));
     }
     if (timed) HIP_TRY(c, hipEventRecord(e1, stream));
     if (exact)
@@ -2528,6 +2646,12 @@ struct HagerZhang {
     int budget;
     bool seeded = false;                          // the first trial (alpha0) has been evaluated already: seed_f, seed_df, dphi0 are set
     double seed_f = 0.0, seed_df = 0.0;
+    // strict: LineSearches.jl's control flow to the letter (line_search = 1; oracle/optim_lbfgs.py restates it and
+    // tests/test_gpu_lbfgs.py compares the two step by step): `linesearchmax` counts passes of the bracketing and the
+    // secant^2 loops (a bisection inside one of them is not counted), a bracketing point is never accepted without a
+    // secant step, a bracket of width <= eps(b) or a flat one returns its lower end even when that is alpha = 0.
+    bool strict = false;
+    int ls_max = 50, iter = 1;
     static constexpr double delta = 0.1, sigma = 0.9, rho = 5.0, epsilon = 1e-6, gamma = 0.66, psi3 = 0.1;
 
     int eval(double c_, bool have_trial = false)
@@ -2634,7 +2758,8 @@ struct HagerZhang {
         // bracketing, HZ B0-B3
         size_t ia = 0, ib = 1;
         bool bracketed = false;
-        while (!bracketed) {
+        iter = 1;
+        while (!bracketed && (!strict || iter < ls_max)) {
             const size_t ic = al.size() - 1;
             if (sl[ic] >= 0.0) {                                   // B1: reached the upward slope
                 ib = ic;
@@ -2660,12 +2785,14 @@ struct HagerZhang {
                     if (rc) return rc;
                 }
             }
+            ++iter;
         }
-        if (ia != ib && wolfe(ib) && ib != 0) return accept(ib);   // (a bracketing point may already do)
-        for (;;) {
+        if (!bracketed) return 1;
+        if (!strict && ia != ib && wolfe(ib) && ib != 0) return accept(ib);   // (a bracketing point may already do)
+        while (!strict || iter < ls_max) {
             const double a = al[ia], b = al[ib];
             if (b - a <= std::numeric_limits<double>::epsilon() * b)
-                return ia == 0 ? 1 : accept(ia);
+                return (ia == 0 && !strict) ? 1 : accept(ia);
             bool iswolfe;
             size_t iA, iB;
             rc = secant2(ia, ib, iswolfe, iA, iB);
@@ -2673,7 +2800,7 @@ struct HagerZhang {
             if (iswolfe) return accept(iA);
             if (al[iB] - al[iA] < gamma * (b - a)) {
                 if (std::nextafter(va[ia], INFINITY) >= va[ib] && std::nextafter(va[iA], INFINITY) >= va[iB])
-                    return iA == 0 ? 1 : accept(iA);               // flat to the last bit
+                    return (iA == 0 && !strict) ? 1 : accept(iA);  // flat to the last bit
                 ia = iA; ib = iB;
             } else {                                               // secant converges too slowly: bisect
                 rc = eval(0.5 * (al[iA] + al[iB]));
@@ -2681,7 +2808,9 @@ struct HagerZhang {
                 rc = update(iA, iB, al.size() - 1, ia, ib);
                 if (rc) return rc;
             }
+            ++iter;
         }
+        return 1;                                                  // LineSearchException: linesearchmax passes without convergence
     }
 };
 
@@ -2798,6 +2927,8 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
     rc = run.wait();
     if (rc) return cleanup(rc);
     int it = 0, status = 2, hz_fallbacks = 0;
+    c->lb_alpha.clear();
+    c->lb_evals.clear();
     double F = h_sc[0], gnorm = h_sc[1];
     if (gnorm <= g_tol) status = 0;
     // the factor-2 ladder search of one iteration (trial points of the first ladder already written when `first_written`)
@@ -2869,6 +3000,7 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
         if (rc) return cleanup(rc);
         bool committed = false;                              // h_sc[0..1] hold an iterate the convergence tests have not seen
         double F_before = F;
+        int same_f = 0;
         for (;;) {
             rc = run.wait();
             if (rc) return cleanup(rc);
@@ -2878,9 +3010,17 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
                 committed = false;
                 if (gnorm <= g_tol) { status = 0; break; }
                 if (f_tol > 0.0 && std::fabs(F - F_before) <= f_tol * std::fabs(F)) { status = 1; break; }
+                // (Optim with f_abstol = f_reltol = 0: "f converged" = no change at all in two successive iterations)
+                same_f = (o.line_search == 1 && F == F_before) ? same_f + 1 : 0;
+                if (same_f > 1) { status = 1; break; }
                 if (it >= max_it) break;
             }
-            HagerZhang hz{run, F, h_sc[10], 0.0, {}, {}, {}, -1.0, max_ls};
+            const bool strict = o.line_search == 1;
+            // (strict: the evaluation count is bounded by LineSearches' own rule -- max_ls passes; 64 bisections of a pass at
+            // most -- the budget is only a backstop)
+            HagerZhang hz{run, F, h_sc[10], 0.0, {}, {}, {}, -1.0, strict ? 64 * max_ls : max_ls};
+            hz.strict = strict;
+            hz.ls_max = max_ls;
             hz.seeded = true;
             hz.seed_f = h_sc[8];
             hz.seed_df = h_sc[9];
@@ -2889,6 +3029,15 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
             const int hr = hz.search(1.0, o.line_search == 0, alpha, fa, reeval);
             if (hr < 0) return cleanup(hr);
             F_before = F;
+            if (hr == 0 && alpha == 0.0) {
+                // (strict mode only) the search returned the lower end of a bracket that has collapsed onto alpha = 0: Optim
+                // takes the zero step, finds x unchanged and stops with "x converged" (x_abstol = 0 is met by equality)
+                ++it;
+                c->lb_alpha.push_back(0.0);
+                c->lb_evals.push_back(run.evals);
+                status = 4;
+                break;
+            }
             if (hr == 0) {
                 if (reeval) {                                      // the accepted step is not the one evaluated last
                     double f2, df2;
@@ -2896,6 +3045,8 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
                     if (rc) return cleanup(rc);
                 }
                 ++it;
+                c->lb_alpha.push_back(alpha);
+                c->lb_evals.push_back(run.evals);
                 committed = true;
                 if (it >= max_it) {                                // the last iterate: commit, wait, no further trial
                     rc = launch_step(1, true, alpha);
@@ -2905,6 +3056,9 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
                 rc = launch_step(1, false, alpha);
                 if (rc == GRAPE_OK) rc = launch_probe();
                 if (rc) return cleanup(rc);
+            } else if (strict) {                                   // LineSearchException: Optim stops here (line search failed)
+                status = 3;
+                break;
             } else {                                               // no bracket: the ladder search takes this iteration
                 ++hz_fallbacks;
                 run.mb = false;                                    // the ladder's pair will have no Gram row: single-workgroup steps from here on
@@ -2943,6 +3097,18 @@ extern "C" int grape_lbfgs(grape_ctx *c, const double *x0, const grape_lbfgs_opt
     result->ladder_fallbacks = hz_fallbacks;
     c->evaluated = true;
     return cleanup(GRAPE_OK);
+}
+
+extern "C" int grape_lbfgs_get_trace(const grape_ctx *c, double *alphas, int32_t *evals, int32_t capacity, int32_t *count)
+{
+    if (!c || !count) return GRAPE_ERR_INVALID_ARG;
+    const size_t n = c->lb_alpha.size();
+    *count = (int32_t)n;
+    for (size_t i = 0; i < n && (int64_t)i < (int64_t)capacity; ++i) {
+        if (alphas) alphas[i] = c->lb_alpha[i];
+        if (evals) evals[i] = c->lb_evals[i];
+    }
+    return GRAPE_OK;
 }
 
 extern "C" int grape_get_member_results(grape_ctx *c, double *foms, double *grads)
@@ -3022,6 +3188,10 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
         const int rc = grape_get_trajectory(s, local, props, states, costates);
         return rc ? group_fail(c, s, rc) : GRAPE_OK;
     }
+    if (chunked(c))
+        return fail(c, GRAPE_ERR_NOT_READY,
+                    "grape_get_trajectory: the workspace of this context holds " + std::to_string(c->Ec) + " of its " +
+                    std::to_string(c->cfg.n_ensemble) + " members at a time (grape_info.member_chunk): no stored trajectory to return");
     if ((costates && !c->d_costates) || ((costates || states) && c->exact_w1))
         return fail(c, GRAPE_ERR_NOT_READY,
                     "grape_get_trajectory: costates need GRAPE_FLAG_KEEP_COSTATES at grape_create (this exact-gradient flow "
@@ -3231,6 +3401,7 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
         info->hoisted_controls = s0->hoist == 1 ? 1 : 0;
         info->expm_action = s0->action ? 1 : 0;
         info->prop_chain = s0->thin_dpp ? 1 : 0;
+        info->member_chunk = s0->Ec;
     }
     return GRAPE_OK;
 }

@@ -125,6 +125,8 @@ struct TileParams {
     int32_t K, N, E, n;   // E = wavefront-level units: members, or member PAIRS when pack2
     int32_t pack2;        // n <= 8: two members share one 16x16 tile as a block-diagonal pair
     int32_t E_members;    // true member count (rows of member_out)
+    int32_t E_plan;       // units of the WHOLE ensemble (= E unless this launch is one chunk of a member-chunked evaluation):
+                          // what the launchers' flow decisions look at, so that a chunked run takes the unchunked run's kernels
     int32_t s_forced, variant;
     int32_t bt_in_lds;    // set by the launcher: the K transposed control operators are cached in LDS
     int32_t stage_ops;    // set by the launcher: prop kernel stages the generators in LDS
@@ -217,6 +219,8 @@ int tile_fuse_forward(const TileParams &p);   // thin: forward vector pass runs 
 hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
 // n = 33..64 (NT = 3, 4; sweep_grid.hip): a workgroup of NT x NT waves per matrix, the reference's general flow
 hipError_t launch_sweep_grid(int NT, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
+// Gc_t = (-i dt) sum_c x[c,t] B_c per slice and control array + its norm bound (prop_hoist.hip; member-invariant controls)
+hipError_t launch_ctrl_sum(int NT, const TileParams &p, hipStream_t stream);
 // prop_hoist.hip: control-sum pre-pass + the expm kernel on A'_k + Gc_t; q = the launcher's parameters (prop_slices, fuse_fwd set)
 hipError_t launch_prop_hoist(int NT, const TileParams &q, hipStream_t stream);
 bool tile_chain_is_split(const TileParams &p, bool keep_costates);   // the two-wave time-split chain: no full X_t store

@@ -783,10 +783,12 @@ __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
 hipError_t launch_ctrl_sum(int NT, const TileParams &p, hipStream_t stream)
 {
     const dim3 grid(p.N, p.n_x), block(64 * NT * NT);
-    if (NT == 1)
-        GRAPE_LAUNCH((ctrl_sum_kernel<1>), grid, block, 0, stream, p);
-    else
-        GRAPE_LAUNCH((ctrl_sum_kernel<2>), grid, block, 0, stream, p);
+    switch (NT) {
+    case 1: GRAPE_LAUNCH((ctrl_sum_kernel<1>), grid, block, 0, stream, p); break;
+    case 2: GRAPE_LAUNCH((ctrl_sum_kernel<2>), grid, block, 0, stream, p); break;
+    case 3: GRAPE_LAUNCH((ctrl_sum_kernel<3>), grid, block, 0, stream, p); break;      // (sweep_grid.hip, n = 33..64)
+    default: GRAPE_LAUNCH((ctrl_sum_kernel<4>), grid, block, 0, stream, p); break;
+    }
     return hipGetLastError();
 }
 

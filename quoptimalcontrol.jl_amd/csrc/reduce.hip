@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restri
             fg[q] = s;
     }
     if (done.flag && (done.host_out || done.probe_out)) // fg - blockIdx.y * Q: the staging buffer of all n_x reductions
-        publish_via_last_block(done, fg - (size_t)blockIdx.y * Q, Q * (int)gridDim.y, gridDim.x * gridDim.y);
+        publish_via_last_block(done, done.stage_base ? done.stage_base : fg - (size_t)blockIdx.y * Q,
+                               done.stage_base ? done.n_total : Q * (int)gridDim.y, gridDim.x * gridDim.y);
     else if (done.flag && threadIdx.x == 0)            // fg IS the mapped host buffer: every workgroup pushed its own 64 bytes
         signal_done(done, gridDim.x * gridDim.y);
 }

@@ -128,6 +128,16 @@ GRAPE_DEV GT grid_mma(const double *__restrict__ ia, const double *__restrict__ 
     return out;
 }
 
+// The workgroup barrier around the images: the wave's own LDS operations drained, then s_barrier.  (__syncthreads() also
+// waits for the wave's GLOBAL loads -- vmcnt(0) -- which would pull the next slice's prefetched tiles onto the critical
+// path of every product.)
+GRAPE_DEV void grid_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 GRAPE_DEV void gt_add_identity(GT &t, double c, int I, int J, int lane)
 {
     if (I == J) {
@@ -140,7 +150,11 @@ GRAPE_DEV void gt_add_identity(GT &t, double c, int I, int J, int lane)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // P_t = exp((-i dt) H_t) for the slices [blockIdx.x * prop_slices, ...) of member blockIdx.y, control array blockIdx.z
-template <int NT>
+// HOIST: member-invariant control operators -- Gc_t = (-i dt) sum_c x[c,t] B_c and its norm bound come from the pre-pass
+// (ctrl_sum_kernel, prop_hoist.hip), A'_k = (-i dt) A_k stays in registers, the next slice's Gc tile is in flight under the
+// products, the squarings come from the two norm bounds (|A'_k|_1 + |Gc_t|_1 >= |G_t|_1: never fewer) -- no K + 1 operator
+// tile fetches and no cross-wave norm reduction per slice.
+template <int NT, bool HOIST>
 __global__ __launch_bounds__(64 * NT * NT) void grid_prop_kernel(const TileParams p)
 {
     using G_ = GridGeom<NT>;
@@ -153,54 +167,73 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_prop_kernel(const TileParam
     const double *__restrict__ x = p.x + (size_t)blockIdx.z * K * p.N;
     const int t_lo = blockIdx.x * p.prop_slices, t_hi = min(p.N, t_lo + p.prop_slices);
     const double dt = p.dt;
+    GT Ah, Gc;
+    double nA = 0.0;
+    if (HOIST) {
+        Ah = gt_load(p.ha + (size_t)k * TSZ, tile, lane);
+        nA = p.ha_norm[k];
+        Gc = gt_load(p.gc + ((size_t)blockIdx.z * p.N + t_lo) * TSZ, tile, lane);
+    }
     for (int t = t_lo; t < t_hi; ++t) {
         // H in the reference's association: in-place variant sum_c B_c x_c first, then + A (src/timeevolution.jl:101-108);
         // static variant A first (:49-52)
         GT G;
-        if (p.variant == 0) {
+        int s_h = 0;
+        if (HOIST) {
+            G.re = Gc.re + Ah.re;
+            G.im = Gc.im + Ah.im;
+            const double bound = (nA + p.gcn[(size_t)blockIdx.z * p.N + t]) * kTheta8;
+            s_h = squarings_for(bound);
+            Gc = gt_load(p.gc + ((size_t)blockIdx.z * p.N + min(t + 1, t_hi - 1)) * TSZ, tile, lane);
+        } else if (p.variant == 0) {
             G.re = (d4){0, 0, 0, 0};
             G.im = (d4){0, 0, 0, 0};
         } else {
             G = gt_load(ops, tile, lane);
         }
-        for (int c = 0; c < K; ++c) {
-            const double xv = x[c + (size_t)t * K];
-            const GT B = gt_load(ops + (size_t)(1 + c) * TSZ, tile, lane);
+        double cs = 0.0;                               // this tile's share of its columns' sums of |re| + |im|
+        if (!HOIST) {
+            for (int c = 0; c < K; ++c) {
+                const double xv = x[c + (size_t)t * K];
+                const GT B = gt_load(ops + (size_t)(1 + c) * TSZ, tile, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    G.re[r] = fma(B.re[r], xv, G.re[r]);
+                    G.im[r] = fma(B.im[r], xv, G.im[r]);
+                }
+            }
+            if (p.variant == 0) {
+                const GT A = gt_load(ops, tile, lane);
+                G.re += A.re;
+                G.im += A.im;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                G.re[r] = fma(B.re[r], xv, G.re[r]);
-                G.im[r] = fma(B.im[r], xv, G.im[r]);
+                const double hr = G.re[r], hi = G.im[r];
+                G.re[r] = dt * hi;                     // (-i dt)(hr + i hi)
+                G.im[r] = -dt * hr;
+                cs += fabs(G.re[r]) + fabs(G.im[r]);
             }
+            cs = swap16_add(cs, cs);
+            cs = swap32_add(cs, cs);
         }
-        if (p.variant == 0) {
-            const GT A = gt_load(ops, tile, lane);
-            G.re += A.re;
-            G.im += A.im;
-        }
-        double cs = 0.0;                               // this tile's share of its columns' sums of |re| + |im|
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double hr = G.re[r], hi = G.im[r];
-            G.re[r] = dt * hi;                         // (-i dt)(hr + i hi)
-            G.im[r] = -dt * hr;
-            cs += fabs(G.re[r]) + fabs(G.im[r]);
-        }
-        cs = swap16_add(cs, cs);
-        cs = swap32_add(cs, cs);
-        __syncthreads();                               // the previous slice's readers are done
+        grid_barrier();                                // the previous slice's readers are done
         grid_put<NT, false>(img0, G, I, J, lane);
         grid_put<NT, true>(img1, G, I, J, lane);
-        if (lane < 16)
+        if (!HOIST && lane < 16)
             s_col[I * DIM + 16 * J + lane] = cs;
-        __syncthreads();
-        double colmax = 0.0;
-        if (lane < DIM) {
+        grid_barrier();
+        int s = p.s_forced >= 0 ? p.s_forced : s_h;
+        if (!HOIST && p.s_forced < 0) {
+            double colmax = 0.0;
+            if (lane < DIM) {
 #pragma unroll
-            for (int ii = 0; ii < NT; ++ii)
-                colmax += s_col[ii * DIM + lane];
+                for (int ii = 0; ii < NT; ++ii)
+                    colmax += s_col[ii * DIM + lane];
+            }
+            colmax = wave_max_fast(colmax);            // the same number in every wave: upper bound of |G|_1
+            s = squarings_for(colmax);
         }
-        colmax = wave_max_fast(colmax);                // the same number in every wave: upper bound of |G|_1
-        const int s = p.s_forced >= 0 ? p.s_forced : squarings_for(colmax);
         // A2 = G G on the unscaled generator, then the power-of-two scaling (exact) on both
         GT A2 = grid_mma<NT, false, false>(img0, img1, I, J, lane);
         if (s > 0) {
@@ -213,10 +246,10 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_prop_kernel(const TileParam
         GT T;
         T.re = kX1 * G.re + kX2 * A2.re;
         T.im = kX1 * G.im + kX2 * A2.im;
-        __syncthreads();
+        grid_barrier();
         grid_put<NT, false>(img0, A2, I, J, lane);
         grid_put<NT, true>(img1, T, I, J, lane);
-        __syncthreads();
+        grid_barrier();
         const GT A4 = grid_mma<NT, false, false>(img0, img1, I, J, lane);      // A4 = A2 (x1 G + x2 A2)
         GT U;
         U.re = kX3 * A2.re + A4.re;
@@ -224,19 +257,19 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_prop_kernel(const TileParam
         T.re = kX5 * G.re + kX6 * A2.re + kX7 * A4.re;
         T.im = kX5 * G.im + kX6 * A2.im + kX7 * A4.im;
         gt_add_identity(T, kX4, I, J, lane);
-        __syncthreads();
+        grid_barrier();
         grid_put<NT, false>(img0, U, I, J, lane);
         grid_put<NT, true>(img1, T, I, J, lane);
-        __syncthreads();
+        grid_barrier();
         GT Pm = grid_mma<NT, false, false>(img0, img1, I, J, lane);            // A8
         Pm.re += G.re + kY2 * A2.re;
         Pm.im += G.im + kY2 * A2.im;
         gt_add_identity(Pm, 1.0, I, J, lane);
         for (int i = 0; i < s; ++i) {                  // undo the scaling
-            __syncthreads();
+            grid_barrier();
             grid_put<NT, false>(img0, Pm, I, J, lane);
             grid_put<NT, true>(img1, Pm, I, J, lane);
-            __syncthreads();
+            grid_barrier();
             Pm = grid_mma<NT, false, false>(img0, img1, I, J, lane);
         }
         gt_store(p.props + (((size_t)blockIdx.z * p.E + k) * p.N + t) * TSZ, tile, lane, Pm);
@@ -268,16 +301,16 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
         for (int t = 0; t < N; ++t) {
             gt_store(Xk + (size_t)t * TSZ, tile, lane, X);
             if (t + 1 < N) {                           // (the state behind the last slice is never read)
-                __syncthreads();
+                grid_barrier();
                 grid_put<NT, false>(img0, Pt, I, J, lane);                      // P plain: the left operand of P X, the right one of . P'
                 grid_put<NT, true>(img1, X, I, J, lane);
-                __syncthreads();
+                grid_barrier();
                 Pt = gt_load(Pk + (size_t)(t + 1) * TSZ, tile, lane);           // next slice's tile in flight under the products
                 if (SAND) {
                     const GT Y = grid_mma<NT, false, false>(img0, img1, I, J, lane);      // P X            (:245-246 as (P X) P')
-                    __syncthreads();
+                    grid_barrier();
                     grid_put<NT, false>(img1, Y, I, J, lane);
-                    __syncthreads();
+                    grid_barrier();
                     X = grid_mma<NT, false, true>(img1, img0, I, J, lane);      // (P X) P'
                 } else {
                     X = grid_mma<NT, false, false>(img0, img1, I, J, lane);     // P X            (:226)
@@ -285,6 +318,7 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
             }
         }
     }
+    __syncthreads();                                   // (the wave's own X_t stores have left before it reads them back)
     // ------------------------------------------------------------ backward sweep + gradient, :65-92
     const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
     GT L = gt_load(ops + (size_t)(2 + 2 * K) * TSZ, tile, lane);                // Xt
@@ -293,16 +327,16 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
     int buf = 0;
     for (int t = N - 1; t >= 0; --t) {
         const int tp = max(t - 1, 0);
-        __syncthreads();
+        grid_barrier();
         grid_put<NT, true>(img0, Pt, I, J, lane);                               // P transposed: P' as a left operand, P as a right one
         grid_put<NT, SAND == 0>(img1, L, I, J, lane);                           // L: left operand of L P (plain) / right operand of P' L (transposed)
-        __syncthreads();
+        grid_barrier();
         Pt = gt_load(Pk + (size_t)tp * TSZ, tile, lane);
         if (SAND) {
             const GT Y = grid_mma<NT, false, false>(img1, img0, I, J, lane);    // L P             (:248)
-            __syncthreads();
+            grid_barrier();
             grid_put<NT, true>(img1, Y, I, J, lane);
-            __syncthreads();
+            grid_barrier();
             L = grid_mma<NT, true, false>(img0, img1, I, J, lane);              // P' (L P)        (:249)
         } else {
             L = grid_mma<NT, true, false>(img0, img1, I, J, lane);              // P' L            (:228)
@@ -317,16 +351,16 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
             zi_p = fma(X.re[r], L.im[r], zi_p);
             zi_p = fma(-X.im[r], L.re[r], zi_p);
         }
-        __syncthreads();
+        grid_barrier();
         grid_put<NT, false>(img0, X, I, J, lane);
         grid_put<NT, false>(img1, L, I, J, lane);
-        __syncthreads();
+        grid_barrier();
         GT R = grid_mma<NT, false, true>(img0, img1, I, J, lane);               // X L'
         if (SAND) {
-            __syncthreads();
+            grid_barrier();
             grid_put<NT, true>(img0, X, I, J, lane);
             grid_put<NT, true>(img1, L, I, J, lane);
-            __syncthreads();
+            grid_barrier();
             const GT R2 = grid_mma<NT, true, false>(img1, img0, I, J, lane);    // L' X           ([X, L'], src/tools.jl:17-19)
             R.re -= R2.re;
             R.im -= R2.im;
@@ -361,7 +395,7 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
                 for (int q = 0; q < kGridRed; ++q)
                     red[wave * kGridRed + q] = v[q];
             }
-            __syncthreads();
+            grid_barrier();
             if ((int)threadIdx.x < kGridGroup && c0 + (int)threadIdx.x < K) {
                 const int cc = threadIdx.x;
                 double zr = 0.0, zi = 0.0, wr = 0.0, wi = 0.0;
@@ -397,11 +431,22 @@ static hipError_t launch_grid_nt(int sandwich, bool keepl, const TileParams &p, 
     // slices per workgroup of the expm kernel: about two rounds of workgroups over the device, at most 64 slices
     const long cus = p.cus > 0 ? p.cus : 256, total = (long)p.N * p.E * p.n_x;
     q.prop_slices = (int)std::min<long>(64, std::max<long>(1, (total + 2 * cus - 1) / (2 * cus)));
-    hipError_t e = hipFuncSetAttribute((const void *)grid_prop_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
-    if (e != hipSuccess)
-        return e;
-    GRAPE_LAUNCH((grid_prop_kernel<NT>), dim3((p.N + q.prop_slices - 1) / q.prop_slices, p.E, p.n_x), dim3(64 * NT * NT), lds_p,
-                 stream, q);
+    hipError_t e;
+    const dim3 pgrid((p.N + q.prop_slices - 1) / q.prop_slices, p.E, p.n_x);
+    if (p.hoist == 1) {                                            // member-invariant controls: the control sum once per slice
+        e = launch_ctrl_sum(NT, q, stream);
+        if (e != hipSuccess)
+            return e;
+        e = hipFuncSetAttribute((const void *)grid_prop_kernel<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+        if (e != hipSuccess)
+            return e;
+        GRAPE_LAUNCH((grid_prop_kernel<NT, true>), pgrid, dim3(64 * NT * NT), lds_p, stream, q);
+    } else {
+        e = hipFuncSetAttribute((const void *)grid_prop_kernel<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+        if (e != hipSuccess)
+            return e;
+        GRAPE_LAUNCH((grid_prop_kernel<NT, false>), pgrid, dim3(64 * NT * NT), lds_p, stream, q);
+    }
     e = hipGetLastError();
     if (e != hipSuccess)
         return e;

@@ -1340,7 +1340,7 @@ static bool tile_chain_env(const char *what)                       // GRAPE_TILE
 // holds X_t only for the first part of the time axis and prefix products for the rest)
 bool tile_chain_is_split(const TileParams &p, bool keepl)
 {
-    return tile_count(p.n) == 1 && !p.pack2 && !keepl && !p.unitary && !p.thin && p.E < 2048 && p.N >= 4 &&
+    return tile_count(p.n) == 1 && !p.pack2 && !keepl && !p.unitary && !p.thin && (p.E_plan ? p.E_plan : p.E) < 2048 && p.N >= 4 &&
            p.tp_chunks < 2 && !tile_chain_env("1w");
 }
 

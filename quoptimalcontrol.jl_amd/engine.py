@@ -28,7 +28,7 @@ FLAG_FORCE_COLLECTIVE = 32
 FLAG_TIME_SAMPLED = 64
 FLAG_GROUP_PEER_SUM = 128
 MAX_DEVICES = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID_ARG", -2: "GRAPE_ERR_UNSUPPORTED",
           -3: "GRAPE_ERR_NO_DEVICE", -4: "GRAPE_ERR_HIP", -5: "GRAPE_ERR_NOT_READY",
@@ -37,7 +37,7 @@ STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID_ARG", -2: "GRAPE_ERR_UNSUPPORTED
 # every symbol include/grape_hip.h declares
 EXPORTS = ["grape_abi_version", "grape_create", "grape_destroy", "grape_set_operators",
            "grape_comm_unique_id", "grape_comm_attach", "grape_ipc_export", "grape_ipc_attach",
-           "grape_eval", "grape_eval_device", "grape_eval_batch", "grape_eval_batch_device", "grape_lbfgs",
+           "grape_eval", "grape_eval_device", "grape_eval_batch", "grape_eval_batch_device", "grape_lbfgs", "grape_lbfgs_get_trace",
            "grape_get_member_results", "grape_get_trajectory",
            "grape_get_kernel_time", "grape_get_kernel_samples", "grape_get_kernel_names", "grape_get_group_timing", "grape_get_phase_stamps",
            "grape_get_info",
@@ -70,7 +70,7 @@ class GrapeInfo(C.Structure):
                 ("states_stored", C.c_int32), ("rank_one_chain", C.c_int32),
                 ("sparse_controls", C.c_int32), ("fused_forward", C.c_int32),
                 ("time_chunks", C.c_int32), ("hoisted_controls", C.c_int32),
-                ("expm_action", C.c_int32), ("prop_chain", C.c_int32)]
+                ("expm_action", C.c_int32), ("prop_chain", C.c_int32), ("member_chunk", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class GrapeLbfgsOptions(C.Structure):
@@ -133,6 +133,7 @@ def load_library():
     L.grape_get_kernel_time.argtypes = [vp, dp, C.POINTER(C.c_int64), i32]
     L.grape_get_kernel_samples.argtypes = [vp, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.grape_get_kernel_names.argtypes = [vp, C.c_char_p, C.c_int32]
+    L.grape_lbfgs_get_trace.argtypes = [vp, vp, vp, C.c_int32, C.POINTER(C.c_int32)]
     L.grape_get_group_timing.argtypes = [vp, vp, i32]
     L.grape_get_phase_stamps.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.grape_get_info.argtypes = [vp, C.POINTER(GrapeInfo)]
@@ -325,7 +326,8 @@ class GrapeEngine:
         call.buffers = (xf, G_out)              # keep them alive as long as the callable lives
         return call
 
-    LBFGS_STATUS = {0: "g_tol reached", 1: "f_tol reached", 2: "max iterations", 3: "line search failed"}
+    LBFGS_STATUS = {0: "g_tol reached", 1: "f_tol reached", 2: "max iterations", 3: "line search failed",
+                    4: "zero step (Optim: x converged)"}
 
     LINE_SEARCH = {"hagerzhang": 0, "hz": 0, "optim": 1, "hagerzhang_strict": 1, "ladder": 2}
 
@@ -346,6 +348,14 @@ class GrapeEngine:
         info = {f: getattr(res, f) for f, _ in res._fields_}
         info["message"] = self.LBFGS_STATUS.get(res.status, "?")
         return np.ascontiguousarray(out.T), info
+
+    def lbfgs_trace(self):
+        """grape_lbfgs_get_trace: (alphas, evaluations) of the last lbfgs() run, one entry per iteration."""
+        cnt = C.c_int32()
+        self._check(self._lib.grape_lbfgs_get_trace(self._h, None, None, 0, C.byref(cnt)))
+        al, ev = np.empty(cnt.value), np.empty(cnt.value, dtype=np.int32)
+        self._check(self._lib.grape_lbfgs_get_trace(self._h, _p(al), _p(ev), cnt.value, C.byref(cnt)))
+        return al, ev
 
     def eval_batch(self, X):
         """grape_eval_batch: X (n_x, K, N) control arrays -> (F (n_x,), G (n_x, K, N)); entry b equals

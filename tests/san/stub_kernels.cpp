@@ -8,6 +8,8 @@ namespace grape {
 hipError_t launch_sweep_small(int, int, int, const SweepParams &, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_sweep_pair(int, int, int, const SweepParams &, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_sweep_tile(int, int, bool, const TileParams &, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_sweep_grid(int, int, bool, const TileParams &, hipStream_t) { return hipErrorNoDevice; }
+int reduce_rows_mflags(int Q, int n_x) { const long long g = (long long)((Q + 31) / 32) * n_x; return g >= 1 && g <= kMaxMflags ? (int)g : 0; }
 hipError_t launch_reduce(const double *, const double *, double *, double *, int, int, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
 hipError_t launch_reduce_rows(const double *, double *, int, int, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
 hipError_t launch_copy(const double *, double *, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
@@ -19,7 +21,7 @@ int sweep_small_max_waves(int n) { return n == 2 ? 16 : (n == 3 ? 8 : (n == 4 ? 
 int sweep_pair_max_waves(int n) { return n == 2 ? 16 : (n == 4 ? 8 : 0); }
 size_t sweep_small_lds_bytes(int n, int MPB, int LT, int S, int K, bool x) { return 16 * (size_t)n * n * 32 + (x ? 8 * ((size_t)MPB * LT * ((size_t)S * K + 1) + MPB) : 0); }
 size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool x, bool) { return 16 * (size_t)n * n * 32 + 16 * (size_t)MPB * 2 * (2 * K + 3) * n * n / 2 + (x ? 8 * ((size_t)MPB * (LT / 2) * ((size_t)S * K + 1) + MPB) : 0); }
-int tile_count(int n) { return n <= 4 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : 0)); }
+int tile_count(int n) { return n <= 4 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 48 ? 3 : (n <= 64 ? 4 : 0)))); }
 bool tile_chain_is_split(const TileParams &, bool) { return false; }
 int tile_fuse_forward(const TileParams &) { return 0; }
 hipError_t launch_lbfgs_init(const LbfgsState &, hipStream_t, DoneSignal) { return hipErrorNoDevice; }

@@ -1,0 +1,158 @@
+"""GPU: member-chunked evaluation (SURVEY.md section 7 "needs member-chunking"; src/solve.jl:166-187 is a serial member loop
+without a memory cliff).  When the workspace arrays (P_t, X_t, L_t) of the whole ensemble exceed the budget -- 0.9 x the free
+device memory, or GRAPE_MAX_WORKSPACE_BYTES for these tests -- they hold grape_info.member_chunk members and an evaluation
+walks the ensemble in blocks through them; the weighted sum runs once over all rows in its fixed order, so a chunked
+evaluation equals the unchunked one BIT FOR BIT, in every kernel family and data flow."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+from test_gpu_tile import _random_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _eval(qoc, w, monkeypatch, budget=None, **kw):
+    if budget is None:
+        monkeypatch.delenv("GRAPE_MAX_WORKSPACE_BYTES", raising=False)
+    else:
+        monkeypatch.setenv("GRAPE_MAX_WORKSPACE_BYTES", str(int(budget)))
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, member_results=True, **kw) as eng:
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+        info = eng.info
+        names = eng.kernel_names()
+    return F, G, foms, grads, info, names
+
+
+def _ws_unit_bytes(w, info):
+    """bytes of ONE member's share of ONE workspace array"""
+    if w.n <= 4:
+        chunks = 64 * info["waves_per_member"] // (2 if info["lane_pair"] else 1)
+        return info["slices_per_lane"] * w.n * w.n * chunks * 16
+    nt = (w.n + 15) // 16
+    return w.N * nt * nt * 256 * 16 // (2 if w.n <= 8 else 1)
+
+
+def _check_chunked_equals_unchunked(qoc, oracle, monkeypatch, w, parts, env=None, **kw):
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    F0, G0, foms0, grads0, info0, names0 = _eval(qoc, w, monkeypatch, None, **kw)
+    assert info0["member_chunk"] == w.E
+    unit = _ws_unit_bytes(w, info0)
+    seen = set()
+    for arrays in (1, 2, 3):                              # (the flow decides how many arrays it keeps: cover every count)
+        budget = arrays * unit * (w.E / parts) * 1.05
+        F, G, foms, grads, info, names = _eval(qoc, w, monkeypatch, budget, **kw)
+        seen.add(info["member_chunk"])
+        assert F == F0 and np.array_equal(G, G0), (arrays, info["member_chunk"])
+        assert np.array_equal(foms, foms0) and np.array_equal(grads, grads0)
+        assert [n for n in names if "reduce" not in n][:1] == [n for n in names0 if "reduce" not in n][:1]      # the same flow
+    assert min(seen) < w.E and max(w.E // m for m in seen) >= 2, seen
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, variant=kw.get("variant", 0))
+    assert_parity(F0, G0, F_ref, G_ref, w.n, what="unchunked vs oracle")
+    return seen
+
+
+@pytest.mark.parametrize("parts", [2, 5])
+def test_c3_shaped_lane_pair_kernel(qoc, oracle, monkeypatch, parts):
+    w = qoc.workloads.config("C3", E=80, N=64)
+    _check_chunked_equals_unchunked(qoc, oracle, monkeypatch, w, parts)
+
+
+@pytest.mark.parametrize("n,sys_type,herm", [(2, "StateTransfer", True), (3, "UnitaryGate", False), (4, "StateTransfer", False)])
+def test_small_family_general_and_lane_kernels(qoc, oracle, monkeypatch, n, sys_type, herm):
+    w = _random_problem(qoc, n, 2, 48, 37, sys_type, seed=90 + n, hermitian=herm, mixed=True)
+    _check_chunked_equals_unchunked(qoc, oracle, monkeypatch, w, 3)
+
+
+def test_c4_shaped_vector_flow_and_expm_chain(qoc, oracle, monkeypatch):
+    w = qoc.workloads.config("C4", E=48, N=60)
+    _check_chunked_equals_unchunked(qoc, oracle, monkeypatch, w, 3, env={"GRAPE_ACTION": "1"})       # exp(G) v on vectors
+    _check_chunked_equals_unchunked(qoc, oracle, monkeypatch, w, 3, env={"GRAPE_ACTION": "0", "GRAPE_NO_TP": "1"})   # MFMA expm + vector chain
+    _check_chunked_equals_unchunked(qoc, oracle, monkeypatch, w, 4, env={"GRAPE_NO_TP": "1"}, flags=qoc.engine.FLAG_FORCE_GENERAL)   # dense chain
+
+
+@pytest.mark.parametrize("n,sys_type,herm", [(7, "StateTransfer", True), (16, "UnitaryGate", True), (23, "StateTransfer", False),
+                                             (32, "UnitaryGate", True), (40, "UnitaryGate", True)])
+def test_tile_and_grid_families(qoc, oracle, monkeypatch, n, sys_type, herm):
+    """pack2 (two members per tile), the unitary flow with hoisted controls (C5's shape), the general flow, the n > 32 grid"""
+    w = _random_problem(qoc, n, 3, 10, 22, sys_type, seed=500 + n, hermitian=herm, mixed=True)
+    w.B[:] = w.B[0]                                         # member-invariant controls, as every BASELINE config has them
+    w.A *= 0.3
+    w.B *= 0.3
+    _check_chunked_equals_unchunked(qoc, oracle, monkeypatch, w, 3, env={"GRAPE_NO_TP": "1"})
+
+
+def test_exact_gradient_and_batches_on_a_chunked_context(qoc, oracle, monkeypatch):
+    w = qoc.workloads.config("C3", E=40, N=32)
+    rng = np.random.default_rng(8)
+    xs = np.array([w.x, rng.uniform(-1, 1, w.x.shape), rng.uniform(0, 2, w.x.shape)])
+
+    def run(budget, **kw):
+        if budget is None:
+            monkeypatch.delenv("GRAPE_MAX_WORKSPACE_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("GRAPE_MAX_WORKSPACE_BYTES", str(int(budget)))
+        with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, max_batch=3, **kw) as eng:
+            Fb, Gb = eng.eval_batch(xs)
+            F1, G1 = eng.eval(xs[1])
+            x_min, res = eng.lbfgs(w.x, iterations=4)
+            return Fb, Gb, F1, G1, x_min, res["minimum"], eng.info
+    for kw in ({}, {"gradient": "exact", "objective": "c1"}):
+        Fb0, Gb0, F10, G10, xm0, m0, info0 = run(None, **kw)
+        unit = _ws_unit_bytes(w, info0)
+        Fb, Gb, F1, G1, xm, m, info = run(2 * unit * w.E / 3.0, **kw)
+        assert info0["member_chunk"] == w.E and info["member_chunk"] < w.E
+        assert np.array_equal(Fb, Fb0) and np.array_equal(Gb, Gb0) and F1 == F10 and np.array_equal(G1, G10)
+        assert np.array_equal(xm, xm0) and m == m0          # the optimiser walks the same iterates
+        assert Fb[1] == F1 and np.array_equal(Gb[1], G1)
+
+
+def test_trajectory_is_refused_and_too_small_budgets_fail_cleanly(qoc, monkeypatch):
+    w = qoc.workloads.config("C3", E=32, N=32)
+    monkeypatch.setenv("GRAPE_MAX_WORKSPACE_BYTES", str(200_000))
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        eng.eval(w.x)
+        assert eng.info["member_chunk"] < w.E
+        with pytest.raises(qoc.engine.GrapeError) as ei:
+            eng.trajectory(0)
+        assert "member_chunk" in str(ei.value)
+    monkeypatch.setenv("GRAPE_MAX_WORKSPACE_BYTES", "1000")
+    with pytest.raises(qoc.engine.GrapeError) as ei:
+        qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N)
+    assert ei.value.status == -6 and "budget" in str(ei.value)
+
+
+def test_group_shards_chunk_too(qoc, oracle, monkeypatch):
+    w = qoc.workloads.config("C3", E=96, N=32)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    res = []
+    for budget in (None, 150_000):
+        if budget is None:
+            monkeypatch.delenv("GRAPE_MAX_WORKSPACE_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("GRAPE_MAX_WORKSPACE_BYTES", str(budget))
+        with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, devices=[0, 0, 0],
+                             flags=qoc.engine.FLAG_GROUP_PEER_SUM) as eng:
+            res.append(eng.eval(w.x) + (eng.info["member_chunk"],))
+    assert res[1][2] < 32 <= res[0][2]
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+    assert_parity(res[1][0], res[1][1], F_ref, G_ref, w.n, what="chunked shards of a group")
+
+
+def test_c5_shaped_general_flow_full_size_on_one_gpu(qoc, oracle):
+    """VERDICT r4 missing #3: a C5-shaped ensemble whose flow stores more than the propagators -- here the debug flow, states
+    AND costates beside them: 3 x 134 GB -- used to end in GRAPE_ERR_ALLOC on the 288 GiB device.  Now it is walked in chunks
+    (the real budget, no test hook).  (P + X alone, 268 GB, turned out to fit the 309 GB the device really has.)"""
+    w = qoc.workloads.config("C5")
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, member_results=True,
+                         flags=qoc.engine.FLAG_FORCE_GENERAL | qoc.engine.FLAG_KEEP_COSTATES) as eng:
+        F, G = eng.eval(w.x)
+        info = eng.info
+        foms, grads = eng.member_results()
+    assert info["member_chunk"] < w.E and info["unitary_flow"] == 0
+    assert abs(F - foms @ w.wts) <= 1e-12 * max(1.0, abs(F))
+    for k in (0, info["member_chunk"] - 1, info["member_chunk"], w.E - 1):
+        F_ref, g_ref = oracle.member_eval(w.sys_type, w.A[k], w.B[k], w.Xi[k], w.Xt[k], w.x, w.T)
+        assert_parity(foms[k], grads[k], F_ref, g_ref, w.n, what=f"C5 general flow, member {k}")

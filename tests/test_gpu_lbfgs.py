@@ -244,6 +244,86 @@ def test_solve_shards_over_devices(qoc):
         assert sol.result.minimum - 0.75 < 1e-5
 
 
+def _ensemble_case(qoc, name):
+    wl = qoc.workloads
+    if name == "c3_state_transfer":
+        w = wl.config("C3")
+        rho0 = np.zeros((4, 4), complex)
+        rho0[0, 0] = 1
+        psi = np.array([1, 1j, -1, 0.5]) / np.linalg.norm([1, 1j, -1, 0.5])
+        Xi = np.broadcast_to(rho0, (w.E, 4, 4)).copy()
+        Xt = np.broadcast_to(np.outer(psi, psi.conj()), (w.E, 4, 4)).copy()
+        return ("StateTransfer", w.A, w.B, Xi, Xt, w.wts, w.T, w.N), w.x, 0
+    sys_type, N, T, variant = {"st_inplace": ("StateTransfer", 25, 5.0, 0), "st_static": ("StateTransfer", 25, 5.0, 1),
+                               "ug_inplace": ("UnitaryGate", 100, 5.0, 0), "ug_static": ("UnitaryGate", 100, 10.0, 1)}[name]
+    w = wl.reference_ensemble(sys_type, 5, N, T)
+    return (w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N), w.x, variant
+
+
+@pytest.mark.parametrize("case", ["st_inplace", "st_static", "ug_inplace", "ug_static", "c3_state_transfer"])
+def test_iterates_match_the_host_restatement(qoc, case):
+    """grape_lbfgs(line_search = 1) against oracle/optim_lbfgs.py -- Optim.jl's LBFGS() + LineSearches.jl's HagerZhang
+    behind InitialStatic restated in NumPy (src/solve.jl:138, :244 is the call being stood in for), driven by the SAME
+    device evaluation -- on the reference's four n_ens = 5 ensemble testsets (state_transfer_tests.jl:42-100,
+    unitary_gate_tests.jl:41-112) and the C3-shaped StateTransfer ensemble: iteration by iteration the accepted step length,
+    the number of evaluations made, and the iterate itself.  (The two sides differ in how they sum their dot products, so
+    the comparison runs over the first iterations, before those roundings have been amplified by the recursion.)"""
+    from oracle import optim_lbfgs
+    args, x0, variant = _ensemble_case(qoc, case)
+    n_it = 10
+    with qoc.GrapeEngine(*args, variant=variant) as eng:
+        ref = optim_lbfgs.lbfgs(lambda x: eng.eval(x), x0, iterations=n_it)
+        xs = []
+        for k in range(1, n_it + 1):
+            xk, info = eng.lbfgs(x0, iterations=k, line_search="optim")
+            xs.append(xk)
+            if info["status"] != 2:                          # converged / stopped before k iterations: the trace ends here
+                break
+        al, ev = eng.lbfgs_trace()
+    tr = ref["trace"]
+    assert len(al) == len(xs) and len(al) >= min(len(tr), n_it) and len(al) > 3
+    per_dev = np.diff(np.concatenate([[1], ev]))
+    per_ref = np.diff([1] + [t["evaluations"] for t in tr])
+    compared = 0
+    for i in range(len(al)):
+        a_ref, x_ref = tr[i]["alpha"], tr[i]["x"].reshape(np.shape(x0))
+        assert abs(al[i] - a_ref) <= 1e-6 * abs(a_ref), (case, i, al[i], a_ref)
+        assert np.abs(xs[i] - x_ref).max() <= 1e-9 * max(1.0, np.abs(x_ref).max()), (case, i)
+        compared += 1
+        if per_ref[i] <= 15:
+            assert per_dev[i] == per_ref[i], (case, i, list(per_dev), list(per_ref))
+        else:
+            # A bisection down to eps(b): the UnitaryGate gradient is not the derivative of the figure of merit (SURVEY.md
+            # App. C #2), so the approximate Wolfe test is never met.  Which of the ~60 halvings first sees phi' >= 0 is decided
+            # by the last bits of g . d -- both sides must be IN such a search and accept the same step to six digits; their
+            # evaluation counts agree to a few halvings.  Behind such a step (alpha ~ 1e-8: y = g_new - g is rounding noise to
+            # eight digits) the two histories are no longer the same computation: the comparison ends here.
+            assert per_dev[i] > 30 and abs(int(per_dev[i]) - int(per_ref[i])) <= 12, (case, i, list(per_dev), list(per_ref))
+            break
+    assert compared >= (1 if case.startswith("ug") else 8), (case, compared)
+
+
+def test_strict_line_search_explains_the_slow_ensemble_testset(qoc):
+    """on the reference's n_ens = 5 StateTransfer testset the Optim-conformant loop needs hundreds of
+    evaluations for 40 iterations and ends at 0.75005, where SciPy's L-BFGS-B reaches 0.75 in ~26.  The restatement of
+    Optim shows the same: the reference's gradient is a first-order approximation, not the derivative of its figure of
+    merit, and once the iterate is close Hager-Zhang's approximate-Wolfe test can no longer be met -- the search bisects its
+    bracket down to eps(b), ~55 evaluations per iteration.  Both sides agree on WHICH iterations those are."""
+    from oracle import optim_lbfgs
+    args, x0, variant = _ensemble_case(qoc, "st_inplace")
+    with qoc.GrapeEngine(*args, variant=variant) as eng:
+        ref = optim_lbfgs.lbfgs(lambda x: eng.eval(x), x0, iterations=40)
+        _, info = eng.lbfgs(x0, iterations=40, line_search="optim")
+        al, ev = eng.lbfgs_trace()
+    per_ref = np.diff([1] + [t["evaluations"] for t in ref["trace"]])
+    per_dev = np.diff(np.concatenate([[1], ev]))
+    assert info["status"] == 2 and ref["status"] == "max_iterations"
+    assert info["minimum"] - 0.75 < 1e-3 and ref["minimum"] - 0.75 < 1e-3
+    assert per_ref.max() > 40 and per_dev.max() > 40             # machine-precision bisections exist on both sides ...
+    assert (per_ref[:20] < 12).all() and (per_dev[:20] < 12).all()     # ... and none of them in the first twenty iterations
+    assert 0.5 < info["evaluations"] / ref["evaluations"] < 2.0
+
+
 def test_lbfgs_argument_errors(qoc):
     w = qoc.workloads.config("C1")
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
