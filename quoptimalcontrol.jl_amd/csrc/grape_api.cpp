@@ -1245,7 +1245,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         c->herm_ctrl = hb;
     }
     {   // sparse control operators (Pauli-type controls): lists of (B_c[i][j], position of M[j][i]) per member and control
-        bool sp = c->family == 1 && !c->pack2 && !c->grid && K >= 1 && K <= 16 && !env_on("GRAPE_NO_SPARSE");
+        bool sp = c->family == 1 && !c->pack2 && (!c->grid || c->NT >= 2) && K >= 1 && K <= 16 && !env_on("GRAPE_NO_SPARSE");
         // list length: the longest operator's non-zeros rounded up to whole wavefronts (64 for single Pauli strings up to five
         // qubits; 128 .. 256 for sums of a few of them -- a global drive sum_i X_i on five qubits has 160), while the K
         // lists fit the kernels' LDS budgets beside their images (K x length <= 1536 entries = 30 KB)
@@ -1265,7 +1265,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         std::vector<double> coef;
         std::vector<int32_t> addr;
         if (sp)
-            sp = grape_host::build_sparse_lists(B, E, K, n, 16 * c->NT + 1, SM, coef, addr);
+            sp = grape_host::build_sparse_lists(B, E, K, n, c->grid ? 16 * c->NT + 2 : 16 * c->NT + 1, SM, coef, addr);   // (sweep_grid.hip's images: pitch 16 NT + 2)
         c->sparse_ctrl = sp;
         if (sp) {
             c->sp_nz = SM;
@@ -1458,7 +1458,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     // with two global drives (160 non-zeros, lists of 192): 1024 members 75.6 ms against 66.8 with the dense traces, ONE
     // problem 0.196 against 0.250 ms.  So: launches that leave LDS to spare (at most 3 workgroups per compute unit: single
     // problems, a handful of members), or lists that keep K x length within 896 entries.  GRAPE_SPARSE_MAX=n forces.
-    if (c->sparse_ctrl && c->sp_nz > 64 && !std::getenv("GRAPE_SPARSE_MAX") && (size_t)K * c->sp_nz > 896 &&
+    if (c->sparse_ctrl && !c->grid && c->sp_nz > 64 && !std::getenv("GRAPE_SPARSE_MAX") && (size_t)K * c->sp_nz > 896 &&
         (long)c->EU * std::max(1, c->tp_C) > 3L * c->compute_units)
         c->sparse_ctrl = false;
     {   // Rank-one states with member-invariant control operators: the evaluation runs on vectors alone (action_thin.hip) --

@@ -219,6 +219,7 @@ int tile_fuse_forward(const TileParams &p);   // thin: forward vector pass runs 
 hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
 // n = 33..64 (NT = 3, 4; sweep_grid.hip): a workgroup of NT x NT waves per matrix, the reference's general flow
 hipError_t launch_sweep_grid(int NT, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
+hipError_t launch_grid_prop(int NT, const TileParams &p, hipStream_t stream);     // its expm launches alone (P_t dumps as the tile family's)
 // Gc_t = (-i dt) sum_c x[c,t] B_c per slice and control array + its norm bound (prop_hoist.hip; member-invariant controls)
 hipError_t launch_ctrl_sum(int NT, const TileParams &p, hipStream_t stream);
 // prop_hoist.hip: control-sum pre-pass + the expm kernel on A'_k + Gc_t; q = the launcher's parameters (prop_slices, fuse_fwd set)

@@ -278,11 +278,20 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_prop_kernel(const TileParam
 
 // ---------------------------------------------------------------------------------------------------------------------
 // one workgroup per (member, control array): forward states, costates, gradient, figure of merit
-template <int NT, int SAND, bool KEEPL>
+// SPARSE (NT >= 3): control operators with few non-zeros (Pauli-type controls: TileParams.sp_coef / sp_addr hold, per
+// control, sp_nz entries (B_c[i][j], position of R[j][i] in a plain image of pitch 16 NT + 2)).  R_t goes to image 0 once
+// and WAVE c forms control c's trace itself from its list (held in registers for the whole sweep) and tr R from the image's
+// diagonal: no K operator-tile fetches per slice, no cross-wave reduction, the gradient entry leaves from the wave that
+// summed it.
+// SPNE: list entries a lane holds per control -- 0 dense traces, 1 lists of 64 (single Pauli strings), 4 up to 256.
+template <int NT, int SAND, bool KEEPL, int SPNE>
 __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TileParams p)
 {
     using G_ = GridGeom<NT>;
-    constexpr int TSZ = G_::TSZ, PLANE = G_::PLANE, WAVES = G_::WAVES;
+    constexpr int TSZ = G_::TSZ, PLANE = G_::PLANE, WAVES = G_::WAVES, DIM = G_::DIM, P = G_::P;
+    constexpr bool SPARSE = SPNE > 0;
+    constexpr int NCW = SPARSE ? (16 + WAVES - 1) / WAVES : 1;        // controls a wave may own (K <= 16)
+    constexpr int NEM = SPARSE ? SPNE : 1;
     extern __shared__ double s_grid[];
     double *img0 = s_grid, *img1 = s_grid + 2 * PLANE, *s_red = s_grid + 4 * PLANE;      // s_red[2][WAVES][kGridRed]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, I = wave / NT, J = wave % NT, tile = I * NT + J;
@@ -325,6 +334,21 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
     GT Pt = gt_load(Pk + (size_t)(N - 1) * TSZ, tile, lane);
     GT X = gt_load(Xk + (size_t)(N - 1) * TSZ, tile, lane);
     int buf = 0;
+    double2 sp_c[NCW][NEM];
+    int sp_a[NCW][NEM];
+    const int sp_ne = SPARSE ? p.sp_nz >> 6 : 0;                    // list entries per lane (1 .. 4)
+    if (SPARSE) {
+#pragma unroll
+        for (int ci = 0; ci < NCW; ++ci)
+#pragma unroll
+            for (int e = 0; e < NEM; ++e) {
+                const int c = wave + ci * WAVES;
+                const bool on = c < K && e < sp_ne;
+                const size_t at = ((size_t)k * K + (on ? c : 0)) * p.sp_nz + (on ? e : 0) * 64 + lane;
+                sp_c[ci][e] = on ? p.sp_coef[at] : make_double2(0.0, 0.0);
+                sp_a[ci][e] = on ? p.sp_addr[at] : 0;
+            }
+    }
     for (int t = N - 1; t >= 0; --t) {
         const int tp = max(t - 1, 0);
         grid_barrier();
@@ -366,6 +390,58 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
             R.im -= R2.im;
         }
         X = gt_load(Xk + (size_t)tp * TSZ, tile, lane);                         // (in flight under the traces)
+        if (SPARSE) {
+            grid_barrier();                             // every wave has read its operands of R
+            grid_put<NT, false>(img0, R, I, J, lane);
+            grid_barrier();
+#pragma unroll
+            for (int ci = 0; ci < NCW; ++ci) {
+                const int c = wave + ci * WAVES;
+                if (c < K) {                            // (wave-uniform)
+                    double v[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int e = 0; e < NEM; ++e)
+                        if (e < sp_ne) {
+                            const double rr = img0[sp_a[ci][e]], ri = img0[PLANE + sp_a[ci][e]];
+                            v[0] = fma(sp_c[ci][e].x, rr, v[0]);
+                            v[0] = fma(-sp_c[ci][e].y, ri, v[0]);
+                            v[1] = fma(sp_c[ci][e].x, ri, v[1]);
+                            v[1] = fma(sp_c[ci][e].y, rr, v[1]);
+                        }
+                    if (!SAND && lane < (DIM < 64 ? DIM : 64)) {          // tr R = conj(tr(X' L))
+                        v[2] = img0[lane * P + lane];
+                        v[3] = img0[PLANE + lane * P + lane];
+                    }
+                    wave_sum_n(v);
+                    if (lane == 0) {
+                        const double zr = v[2], zi = -v[3];
+                        const double im = SAND ? v[1] : fma(v[0], zi, v[1] * zr);
+                        out[c + (size_t)t * K] = gs * im;
+                        if (!SAND && t == N - 1 && c == 0)
+                            out[(size_t)K * N] = zr * zr - zi * zi;              // Re(z^2), src/cost_functions.jl:99-101
+                    }
+                }
+            }
+            if (SAND && t == N - 1) {                   // the figure of merit's tr(X' L): this slice only, over the workgroup
+                double v2[2] = {zr_p, zi_p};
+                wave_sum_n(v2);
+                if (lane == 0) {
+                    s_red[2 * wave] = v2[0];
+                    s_red[2 * wave + 1] = v2[1];
+                }
+                grid_barrier();
+                if (threadIdx.x == 0) {
+                    double zr = 0.0, zi = 0.0;
+                    for (int w = 0; w < WAVES; ++w) {
+                        zr += s_red[2 * w];
+                        zi += s_red[2 * w + 1];
+                    }
+                    const double inv = 1.0 / (double)p.n;
+                    const double ar = zr * inv, ai = zi * inv;
+                    out[(size_t)K * N] = 1.0 - (ar * ar + ai * ai);              // src/cost_functions.jl:13-17
+                }
+            }
+        } else
         // traces: sum_ij B_c[i][j] R[j][i] = sum over the elements of (B_c^T .* R); kGridGroup controls per reduction, the
         // workgroup's sum in wave order (deterministic)
         for (int c0 = 0; c0 < K; c0 += kGridGroup) {
@@ -423,11 +499,12 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// the expm launches: [ctrl_sum_kernel +] grid_prop_kernel
 template <int NT>
-static hipError_t launch_grid_nt(int sandwich, bool keepl, const TileParams &p, hipStream_t stream)
+static hipError_t launch_grid_prop_nt(const TileParams &p, hipStream_t stream)
 {
     TileParams q = p;
-    const size_t lds_p = grid_lds_bytes(NT, false), lds_c = grid_lds_bytes(NT, true);
+    const size_t lds_p = grid_lds_bytes(NT, false);
     // slices per workgroup of the expm kernel: about two rounds of workgroups over the device, at most 64 slices
     const long cus = p.cus > 0 ? p.cus : 256, total = (long)p.N * p.E * p.n_x;
     q.prop_slices = (int)std::min<long>(64, std::max<long>(1, (total + 2 * cus - 1) / (2 * cus)));
@@ -447,7 +524,28 @@ static hipError_t launch_grid_nt(int sandwich, bool keepl, const TileParams &p, 
             return e;
         GRAPE_LAUNCH((grid_prop_kernel<NT, false>), pgrid, dim3(64 * NT * NT), lds_p, stream, q);
     }
-    e = hipGetLastError();
+    return hipGetLastError();
+}
+
+// (called by the tile family's launcher too: at 32 x 32 with member-invariant controls and an ensemble that fills the device
+// this expm kernel runs C5's 8.2 M propagators in 85.5 ms at 0.72 of the matrix pipe, prop_hoist2_kernel in 96-97 ms at 0.64)
+hipError_t launch_grid_prop(int NT, const TileParams &p, hipStream_t stream)
+{
+    switch (NT) {
+    case 1: return launch_grid_prop_nt<1>(p, stream);
+    case 2: return launch_grid_prop_nt<2>(p, stream);
+    case 3: return launch_grid_prop_nt<3>(p, stream);
+    case 4: return launch_grid_prop_nt<4>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int NT>
+static hipError_t launch_grid_nt(int sandwich, bool keepl, const TileParams &p, hipStream_t stream)
+{
+    TileParams q = p;
+    const size_t lds_c = grid_lds_bytes(NT, true);
+    hipError_t e = launch_grid_prop_nt<NT>(p, stream);
     if (e != hipSuccess)
         return e;
     if (p.ev_mid) {
@@ -456,18 +554,39 @@ static hipError_t launch_grid_nt(int sandwich, bool keepl, const TileParams &p, 
             return e;
     }
     const dim3 grid(p.E, p.n_x), block(64 * NT * NT);
-#define GRAPE_GRID_CHAIN(S, KL)                                                                                          \
+#define GRAPE_GRID_CHAIN(S, KL, SP)                                                                                      \
     {                                                                                                                    \
-        e = hipFuncSetAttribute((const void *)grid_chain_kernel<NT, S, KL>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+        e = hipFuncSetAttribute((const void *)grid_chain_kernel<NT, S, KL, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds_c);                                                                             \
         if (e != hipSuccess)                                                                                             \
             return e;                                                                                                    \
-        GRAPE_LAUNCH((grid_chain_kernel<NT, S, KL>), grid, block, lds_c, stream, q);                                     \
+        GRAPE_LAUNCH((grid_chain_kernel<NT, S, KL, SP>), grid, block, lds_c, stream, q);                                 \
+    }
+    const int spne = (p.sparse && p.K <= 16 && p.sp_nz <= 256 && NT >= 2) ? (p.sp_nz <= 64 ? 1 : 4) : 0;
+    if constexpr (NT >= 2) {
+        if (spne == 1) {
+            if (sandwich) {
+                if (keepl) GRAPE_GRID_CHAIN(1, true, 1) else GRAPE_GRID_CHAIN(1, false, 1)
+            } else {
+                if (keepl) GRAPE_GRID_CHAIN(0, true, 1) else GRAPE_GRID_CHAIN(0, false, 1)
+            }
+            return hipGetLastError();
+        }
+    }
+    if constexpr (NT >= 3) {
+        if (spne == 4) {
+            if (sandwich) {
+                if (keepl) GRAPE_GRID_CHAIN(1, true, 4) else GRAPE_GRID_CHAIN(1, false, 4)
+            } else {
+                if (keepl) GRAPE_GRID_CHAIN(0, true, 4) else GRAPE_GRID_CHAIN(0, false, 4)
+            }
+            return hipGetLastError();
+        }
     }
     if (sandwich) {
-        if (keepl) GRAPE_GRID_CHAIN(1, true) else GRAPE_GRID_CHAIN(1, false)
+        if (keepl) GRAPE_GRID_CHAIN(1, true, 0) else GRAPE_GRID_CHAIN(1, false, 0)
     } else {
-        if (keepl) GRAPE_GRID_CHAIN(0, true) else GRAPE_GRID_CHAIN(0, false)
+        if (keepl) GRAPE_GRID_CHAIN(0, true, 0) else GRAPE_GRID_CHAIN(0, false, 0)
     }
 #undef GRAPE_GRID_CHAIN
     return hipGetLastError();

@@ -1396,7 +1396,13 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
                 return ea;
         }
         hipError_t e;
-        if (hoisted) {                                             // member-invariant controls: prop_hoist.hip
+        // 32 x 32, member-invariant controls, an ensemble that fills the device (C5): sweep_grid.hip's expm kernel -- a workgroup
+        // per propagator as prop_hoist2_kernel, but operand sums formed in registers and k-contiguous ds_read_b128 pairs instead
+        // of a third LDS plane: 85.5 against 96-97 ms at C5, matrix pipe 0.72 against 0.64.  GRAPE_HOIST2=1 keeps prop_hoist2.
+        const bool keep_hoist2 = std::getenv("GRAPE_HOIST2") != nullptr;
+        if (hoisted && NT == 2 && p.hoist == 1 && !keep_hoist2 && (long)p.E * p.n_x >= (long)(p.cus > 0 ? p.cus : 256)) {
+            e = launch_grid_prop(2, q, stream);
+        } else if (hoisted) {                                      // member-invariant controls: prop_hoist.hip
             e = launch_prop_hoist(NT, q, stream);
         } else {
             GRAPE_LAUNCH((prop_tile_kernel<NT>), dim3(q.fuse_fwd ? 1 : (p.N + per_block - 1) / per_block, p.E, p.n_x),

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import assert_parity
-from test_gpu_tile import _engine, _random_problem
+from test_gpu_tile import _engine, _random_problem, _sparse_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -65,6 +65,31 @@ def test_grid_family_squaring_path(qoc, oracle, scale):
     w.A *= scale
     w.B *= scale
     _check(qoc, oracle, w)
+
+
+@pytest.mark.parametrize("n,sys_type,K,pairs", [(40, "UnitaryGate", 3, 12), (48, "StateTransfer", 11, 20), (64, "UnitaryGate", 6, 30),
+                                                (64, "StateTransfer", 16, 12), (57, "UnitaryGate", 4, 100)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_grid_family_sparse_control_operators(qoc, oracle, monkeypatch, n, sys_type, K, pairs, variant):
+    """control operators with few non-zeros (Pauli-type controls, as C6 has them): wave c of the workgroup forms control c's
+    trace from its (coefficient, position) list and tr R from the image's diagonal -- lists of 64 .. 256 entries, more
+    controls than waves (K = 11 on 9 waves), the hoisted H build where the members share them; same numbers as the oracle and
+    as the dense traces (GRAPE_NO_SPARSE=1)."""
+    w = _sparse_problem(qoc, n, K, 9, 3, sys_type, seed=60 + n + K, nnz_pairs=pairs)
+    w.A *= 0.25
+    w.B *= 0.25
+    if K == 6:
+        w.B[:] = w.B[0]                                   # member-invariant controls: ctrl_sum_kernel + grid_prop_kernel<., true>
+    with _engine(qoc, w, variant=variant) as eng:
+        F_sp, G_sp = eng.eval(w.x)
+        assert eng.info["sparse_controls"] == 1 and eng.info["hoisted_controls"] == (1 if K == 6 else 0)
+        names = eng.kernel_names()
+    assert ("ctrl_sum_kernel" in names) == (K == 6)
+    monkeypatch.setenv("GRAPE_NO_SPARSE", "1")
+    F, G = _check(qoc, oracle, w, variant=variant)
+    assert abs(F - F_sp) <= 1e-12 * max(1.0, abs(F)) and np.abs(G - G_sp).max() <= 1e-12 * max(1.0, np.abs(G).max())
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, variant=variant)
+    assert_parity(F_sp, G_sp, F_ref, G_ref, w.n, what=f"sparse traces n={n} K={K}")
 
 
 def test_grid_family_single_problem_and_one_slice(qoc, oracle):

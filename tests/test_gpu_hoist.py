@@ -177,3 +177,36 @@ def test_per_member_controls_run_the_new_kernels_too(qoc, oracle, monkeypatch, n
         assert_parity(F, G, F_ref, G_ref, n, what=f"ensemble (GRAPE_HOIST={hoist})")
         res[hoist] = (F, G)
     assert np.abs(res[None][1] - res["0"][1]).max() <= 1e-12 * np.abs(res["0"][1]).max() + 1e-15
+
+
+@pytest.mark.parametrize("n,sys_type,herm_gen,N,scale", [(32, "UnitaryGate", True, 9, 0.6), (21, "StateTransfer", False, 5, 0.6),
+                                                        (32, "StateTransfer", True, 3, 8.0)])
+def test_device_filling_32x32_ensembles_take_the_grid_expm_kernel(qoc, oracle, monkeypatch, n, sys_type, herm_gen, N, scale):
+    """Round 5: at 32 x 32 (two tiles per side) with member-invariant controls and at least one unit per compute unit -- C5's
+    shape -- the expm runs in sweep_grid.hip's grid_prop_kernel (a workgroup of four waves per propagator, operands through
+    k-contiguous LDS images: 85.5 ms against prop_hoist2_kernel's 96-97 at C5) and hands the same P_t dumps to the tile
+    family's chains; GRAPE_HOIST2=1 keeps prop_hoist2_kernel.  Against the oracle, and the two kernels against each other,
+    incl. the squaring path (scale 8)."""
+    import torch
+    E = torch.cuda.get_device_properties(0).multi_processor_count + 3
+    A, B, Xi, Xt, wts, x = _problem(n, 3, N, E, sys_type != "UnitaryGate", herm_gen, seed=7 * n + N, rank_one=False, scale=scale)
+    res = {}
+    for keep in (None, "1"):
+        if keep is None:
+            monkeypatch.delenv("GRAPE_HOIST2", raising=False)
+        else:
+            monkeypatch.setenv("GRAPE_HOIST2", keep)
+        with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.0, N, member_results=True) as eng:
+            F, G = eng.eval(x)
+            foms, grads = eng.member_results()
+            names = eng.kernel_names()
+            assert eng.info["hoisted_controls"] == 1
+        res[keep] = (F, G, names)
+    assert "grid_prop_kernel" in res[None][2] and "ctrl_sum_kernel" in res[None][2]
+    assert "prop_hoist2_kernel" in res["1"][2] and "grid_prop_kernel" not in res["1"][2]
+    assert abs(res[None][0] - res["1"][0]) <= 1e-12 * max(1.0, abs(res["1"][0]))
+    assert np.abs(res[None][1] - res["1"][1]).max() <= 1e-12 * max(1.0, np.abs(res["1"][1]).max())
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.0, per_member=True)
+    for k in (0, 1, E // 2, E - 1):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k}")
+    assert_parity(res[None][0], res[None][1], F_ref, G_ref, n, what="ensemble, grid expm kernel")
