@@ -272,6 +272,14 @@ def roofline(local, info, samples, evals_per_s, n_gpus, traffic, profile=None, n
     roof.update(st)
     ms_eq = roof["model_s_equivalent"]
     roof["frac_model_s"] = ms_eq.get("frac_hbm", ms_eq.get("frac_fp64"))     # SURVEY.md 8d numerator over the same time
+    # ... where it means something: a flow that does less than half of model S's work (the vector flow of C4 does ~1/12 of
+    # its flops) makes that ratio a multiple of the peak -- printed as null, the flow's own fraction is `frac`
+    if info.get("kernel_family") == 1:
+        done = sum(k.get("mfma_flops_per_launch", k.get("valu_fp64_flops_per_launch", 0.0)) for k in roof.get("kernels", []))
+        if done < 0.5 * alg_flops:
+            roof["frac_model_s"] = None
+    elif roof.get("bytes_per_launch", alg_bytes) < 0.5 * alg_bytes:
+        roof["frac_model_s"] = None
     if info.get("kernel_family") != 1 and info.get("lane_pair") and uni:
         ph = committed_phases(local, st["kernel_avg_us"])
         if ph:

@@ -1,12 +1,16 @@
-"""GPU: performance gate of the headline kernel (VERDICT r4 #1c).  The C3 sweep kernel's cost is held in CYCLES -- the
-box-independent figure: boxes of the pool differ by several percent in the clock they sustain under this load, which is what
-moved the driver's headline between rounds 3 and 4 while the kernel was the same (profiles/r05_C3_ab.txt).
+"""GPU: performance gate of the headline kernel (VERDICT r4 #1c).  The C3 sweep kernel's cost is held in CYCLES: boxes of the
+pool differ by several percent in the clock they sustain under this load, which is what moved the driver's headline between
+rounds 3 and 4 while the kernel was the same (profiles/r05_C3_ab.txt).  Every wave of sweep_pair_kernel stamps the
+shader-cycle counter at its phase boundaries (GRAPE_FLAG_PHASE_STAMPS):
 
-  * wave cycles: every wave of sweep_pair_kernel stamps the shader-cycle counter at its start and end
-    (GRAPE_FLAG_PHASE_STAMPS); the median over the 2048 waves must stay within 3 % of the committed count;
-  * kernel cycles: HIP-event time of the launch x the clock measured inside the kernel (cycles / 100 MHz real time) --
-    includes launch ramp and tail, and carries the noise of two measurements: within 8 %.
-The committed numbers live in profiles/perf_gate.json (measured on the MI355X at the commit that last touched the kernel)."""
+  * phase A (H build, expm, chunk product: vector-FP64 issue bound) and phase B (scan) cost a number of cycles that does not
+    depend on the clock: the median over the 2048 waves must stay within 3 % of the committed count -- any change of the
+    instruction stream (register allocation, a larger kernarg struct, a new template argument) shows here;
+  * phase D reads the stored propagators at HBM's rate: its CYCLE count grows with the clock (26 us are 51 k cycles at 1.97 GHz
+    and 57 k at 2.2 GHz), so the whole wave is held to 1.03 x the committed count only after scaling its memory-bound share
+    to the committed clock;
+  * kernel time by HIP events (product build, warm clock): within 10 % of the committed microseconds -- the gross check.
+Committed numbers: profiles/perf_gate.json (MI355X, the commit that last touched the kernel)."""
 import json
 import os
 
@@ -20,34 +24,36 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_c3_sweep_kernel_cycles_within_the_committed_count(qoc):
     gate = json.load(open(os.path.join(ROOT, "profiles", "perf_gate.json")))["C3_E1024"]
     w = qoc.workloads.config("C3")
-    # clock + wave cycles from the stamped build
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, flags=qoc.engine.FLAG_PHASE_STAMPS) as eng:
-        clocks, cyc = [], []
-        for i in range(300):
+        rows = []
+        for i in range(1200):                                # (a warm clock: the first hundreds of calls run at the boost clock)
             eng.eval(w.x)
-            if i >= 200 and i % 10 == 0:
+            if i >= 900 and i % 20 == 0:
                 st = eng.phase_stamps().astype(np.int64)
                 real_ns = (st[:, 6] - st[:, 5]) * 10.0
-                tot = st[:, 4] - st[:, 0]
                 ok = real_ns > 0
-                clocks.append(float(np.median(tot[ok] / real_ns[ok])))
-                cyc.append(float(np.median(tot[ok])))
-    clock_ghz, wave_cycles = float(np.median(clocks)), float(np.median(cyc))
-    # kernel time from HIP events on the product build
+                d = np.diff(st[:, :5], axis=1)[ok]
+                rows.append([np.median(d[:, 0]), np.median(d[:, 1]), np.median(d[:, 3]), np.median((st[:, 4] - st[:, 0])[ok]),
+                             np.median((st[:, 4] - st[:, 0])[ok] / real_ns[ok])])
+    a_cyc, b_cyc, d_cyc, wave_cyc, clock = (float(v) for v in np.median(np.array(rows), axis=0))
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N,
                          flags=qoc.engine.FLAG_TIME_KERNELS | qoc.engine.FLAG_TIME_SAMPLED) as eng:
         xf = np.ascontiguousarray(w.x.T)
         call = eng.bind_eval(xf, np.empty_like(xf))
-        for _ in range(1500):                                # clock ramp
+        for _ in range(1500):
             call()
         eng.kernel_time(reset=True)
         for _ in range(800):
             call()
         tot_ms, _ = eng.kernel_samples()
     kernel_us = float(np.median(tot_ms) * 1e3)
-    kernel_cycles = kernel_us * 1e3 * clock_ghz
-    print(f"perf gate: clock {clock_ghz:.3f} GHz, wave cycles {wave_cycles:.0f} (committed {gate['wave_cycles']}), "
-          f"kernel {kernel_us:.2f} us = {kernel_cycles:.0f} cycles (committed {gate['kernel_cycles']})")
-    assert 1.2 < clock_ghz < 2.6, clock_ghz
-    assert wave_cycles <= 1.03 * gate["wave_cycles"], (wave_cycles, gate["wave_cycles"])
-    assert kernel_cycles <= 1.08 * gate["kernel_cycles"], (kernel_cycles, gate["kernel_cycles"])
+    d_scaled = d_cyc * gate["clock_ghz"] / clock              # the HBM-bound phase at the committed clock
+    wave_scaled = wave_cyc - d_cyc + d_scaled
+    print(f"perf gate: clock {clock:.3f} GHz; cycles A {a_cyc:.0f} (committed {gate['phase_a_cycles']}), B {b_cyc:.0f} "
+          f"({gate['phase_b_cycles']}), D {d_cyc:.0f} -> {d_scaled:.0f} at {gate['clock_ghz']} GHz ({gate['phase_d_cycles']}), "
+          f"wave {wave_cyc:.0f} -> {wave_scaled:.0f} ({gate['wave_cycles']}); kernel {kernel_us:.2f} us ({gate['kernel_us']})")
+    assert 1.2 < clock < 2.6, clock
+    assert a_cyc <= 1.03 * gate["phase_a_cycles"], (a_cyc, gate["phase_a_cycles"])
+    assert b_cyc <= 1.03 * gate["phase_b_cycles"], (b_cyc, gate["phase_b_cycles"])
+    assert wave_scaled <= 1.03 * gate["wave_cycles"], (wave_scaled, gate["wave_cycles"])
+    assert kernel_us <= 1.10 * gate["kernel_us"], (kernel_us, gate["kernel_us"])

@@ -3,7 +3,7 @@
 #   tools/refresh_profiles.sh <tag>      -> gpurun_out/prof_<tag>/...   (copy what is to be judged into profiles/)
 # rocprofv3 runs the program itself after `--` (python3 bench.py ...), PMC passes are separate kernel-trace-only runs.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -23,6 +23,7 @@ stats C4expm_E1024 GRAPE_ACTION=0 --config C4 --steps 40 --warmup 5      # the M
 stats C4_E2048 GRAPE_X=0 --config C4 --ensemble 2048 --steps 30 --warmup 5     # two members per wave (action_parts_kernel<true>)
 stats C4_E128 GRAPE_X=0 --config C4 --ensemble 128 --steps 100 --warmup 10      # the per-GPU shard of an 8-GPU run: expm + chain_prop_kernel
 stats C5_E4096 GRAPE_X=0 --config C5 --steps 2 --warmup 1
+stats C6_E256 GRAPE_X=0 --config C6 --steps 3 --warmup 1       # 64 x 64 (sweep_grid.hip)
 stats C5x1 GRAPE_X=0 --config C5 --ensemble 1 --steps 200 --warmup 20     # single problems: the chunked time axis
 stats C4x1 GRAPE_X=0 --config C4 --ensemble 1 --steps 200 --warmup 20
 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C3" > "$OUT/pmc_C3.log" 2>&1
@@ -31,6 +32,7 @@ bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C4_E2048" --config C4 --ensemble 2048 >
 GRAPE_NO_THIN=1 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C4dense" --config C4 > "$OUT/pmc_C4dense.log" 2>&1
 GRAPE_ACTION=0 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C4expm" --config C4 > "$OUT/pmc_C4expm.log" 2>&1
 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C5" --config C5 --steps 2 --warmup 1 > "$OUT/pmc_C5.log" 2>&1
+bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C6" --config C6 --steps 3 --warmup 1 > "$OUT/pmc_C6.log" 2>&1
 cd "$ROOT"
 python3 tools/phase_profile.py --config C3 > "$OUT/C3_phase_stamps.json" 2> /dev/null
 python3 tools/group_overhead.py > "$OUT/group_overhead_C3.json" 2> /dev/null
@@ -48,7 +50,8 @@ python3 tools/exact_time.py > "$OUT/exact_time.txt" 2> /dev/null
 python3 tools/dpp_chunks_time.py 1 2 8 24 40 48 2> /dev/null > "$OUT/dpp_chunks_time.txt"      # small rank-one ensembles: chunked propagator chain vs the flows it replaced
 ( python3 tools/dense_forms_time.py; GRAPE_FORMS_VALU=1 python3 tools/dense_forms_time.py ) 2> /dev/null > "$OUT/dense_forms_time.txt"
 for E in 128 192 224 256 288 320 512 1024 2048 4096; do for m in 1 0; do echo "E=$E GRAPE_ACTION=$m $(GRAPE_ACTION=$m python3 bench.py --config C4 --ensemble $E --steps 20 --warmup 5 --blocks 2 --no-extra --no-cpu-baseline 2> /dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "evals/s", round(d["ms_per_step"],3), "ms")')"; done; done > "$OUT/C4_flow_crossover.txt"
-for seed in 31 32 33 34 35 36 37 38; do python3 tools/soak.py 1500 $seed 2>&1 | tail -1; done > "$OUT/soak.txt"
+for seed in 51 52 53 54 55 56 57 58; do python3 tools/soak.py 1500 $seed 2>&1 | tail -1; done > "$OUT/soak.txt"
+python3 -m pytest tests/test_gpu_perf_gate.py -q -s 2>&1 | grep -E "perf gate|passed|failed" > "$OUT/perf_gate.txt"
 python3 tools/soak_api.py 600 5 2>&1 | tail -1 >> "$OUT/soak.txt"
 python3 tools/parity_report.py > "$OUT/parity.json" 2> "$OUT/parity.log"
 python3 bench.py --details "$OUT/bench_C3_1gpu_details.json" 2> /dev/null | tail -1 > "$OUT/bench_C3_1gpu.json"
