@@ -56,10 +56,13 @@ struct grape_ctx {
     int compute_units = 0;
     char arch[32] = {0};
     int m = 0;                    // state columns (Xi, Xt are n x m); m < n runs zero-padded to n x n
-    int family = 0;               // 0: register-resident small-n kernels, 1: MFMA tile kernels
+    int family = 0;               // 0: register-resident small-n kernels, 1: MFMA tile kernels (tile + grid), 2: the size-generic
+                                  // kernel of sweep_any.hip (n = 1, n > 64)
     int NT = 0;                   // tile family: tiles per dimension (padded n = 16 NT)
     size_t TSZ = 0;               // tile family: double2 per matrix dump
     bool pack2 = false;           // tile family, n <= 8: two members per 16x16 tile (block diagonal)
+    double2 *d_scratch = nullptr; // family 2 (sweep_any.hip): 6 matrices per (control array, member of the workspace chunk)
+    size_t scratch_bytes = 0;
     bool grid = false;            // tile family, n = 33..64 (NT = 3, 4): a workgroup of NT x NT waves per matrix (sweep_grid.hip) -- the
                                   // reference's general flow only; GRAPE_GRID=1 sends smaller sizes there too (cross-checks)
     int EU = 0;                   // tile family: wavefront-level units = members, or member pairs when pack2
@@ -414,6 +417,7 @@ static void free_all(grape_ctx *c)
     if (c->h_fg) (void)hipHostFree(c->h_fg);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     (void)hipFree(c->d_done_counter);
+    (void)hipFree(c->d_scratch);
     (void)hipFree(c->d_vecs);
     (void)hipFree(c->d_sp_coef); (void)hipFree(c->d_sp_addr);
     (void)hipFree(c->d_tp_q); (void)hipFree(c->d_tp_r); (void)hipFree(c->d_tp_m); (void)hipFree(c->d_tp_z); (void)hipFree(c->d_tp_vec); (void)hipFree(c->d_tp_a);
@@ -452,12 +456,11 @@ static int validate_config(const grape_config *cfg)
         return fail(nullptr, GRAPE_ERR_INVALID_ARG, "grape_create: n_controls * n_slices overflows int32");
     const int wmax = grape::sweep_small_max_waves(cfg->n);
     const int nt = grape::tile_count(cfg->n);
-    if (wmax == 0 && nt == 0)
+    if ((uint64_t)cfg->n > 2048)
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED,
-                    "grape_create: operator dimension n=" + std::to_string(cfg->n) +
-                        " has no kernel in this build (supported: 2..64)");
-    if (nt > 2 && cfg->gradient == GRAPE_GRADIENT_EXACT)
-        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: the exact gradient exists for n <= 32 (n = 33..64 run the reference's first-order flow)");
+                    "grape_create: operator dimension n=" + std::to_string(cfg->n) + " is beyond what this build indexes (n <= 2048)");
+    if ((nt > 2 || (wmax == 0 && nt == 0)) && cfg->gradient == GRAPE_GRADIENT_EXACT)
+        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: the exact gradient exists for 2 <= n <= 32 (other sizes run the reference's first-order flow)");
     const int m = cfg->n_state_cols ? cfg->n_state_cols : cfg->n;
     if (m != cfg->n && cfg->sys_type != GRAPE_UNITARY_GATE)
         return fail(nullptr, GRAPE_ERR_INVALID_ARG,
@@ -549,7 +552,7 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     // Aim for one wave per SIMD across the chip; more waves per member only when the
     // ensemble alone cannot fill it.
     const int N = cfg->n_slices, E = cfg->n_ensemble;
-    c->family = wmax > 0 ? 0 : 1;
+    c->family = wmax > 0 ? 0 : (nt > 0 ? 1 : 2);              // 2: n = 1 or n > 64 -- the size-generic kernel (sweep_any.hip)
     c->B = cfg->max_batch > 1 ? cfg->max_batch : 1;
     c->NT = nt;
     c->TSZ = (size_t)nt * nt * 256;
@@ -574,7 +577,7 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
                                  // costs more than the shorter chunks save (single qubit, N = 1000: 15.2 vs 18.1 us)
     }
     if (wmax > 0 && W > wmax) W = wmax;
-    if (W < 1 || c->family == 1) W = 1;
+    if (W < 1 || c->family != 0) W = 1;
     int S = cfg->slices_per_lane;
     const int smin = (N + cpw * W - 1) / (cpw * W);
     if (S < smin) S = smin;
@@ -606,8 +609,8 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
 
     const size_t nn = (size_t)cfg->n * cfg->n, K = cfg->n_controls;
     const size_t Q = KN(c) + 1;
-    c->ws_unit = c->family == 0 ? (size_t)S * nn * c->CH : (size_t)N * c->TSZ;
-    const size_t ops_elems = c->family == 0 ? (size_t)E * (K + 3) * nn : (size_t)c->EU * (2 * K + 3) * c->TSZ;
+    c->ws_unit = c->family == 0 ? (size_t)S * nn * c->CH : (c->family == 1 ? (size_t)N * c->TSZ : (size_t)N * nn);
+    const size_t ops_elems = c->family != 1 ? (size_t)E * (K + 3) * nn : (size_t)c->EU * (2 * K + 3) * c->TSZ;
     const bool exact = cfg->gradient == GRAPE_GRADIENT_EXACT;  // needs every X_t and L_t in HBM: the debug flow
     const bool keepl = (cfg->flags & GRAPE_FLAG_KEEP_COSTATES) != 0 || exact;
     {
@@ -641,7 +644,7 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     if (e == hipSuccess) e = alloc((void **)&c->d_props, sizeof(double2) * c->ws_elems * ws_batch(c));
     if (e == hipSuccess && keepl) e = alloc((void **)&c->d_costates, sizeof(double2) * c->ws_elems * ws_batch(c));
     if (e == hipSuccess && exact && c->family == 0) e = alloc((void **)&c->d_zphi, sizeof(double) * 2 * E * Bn);
-    const bool want_rows = c->family == 1 || (cfg->flags & GRAPE_FLAG_MEMBER_RESULTS) || exact;
+    const bool want_rows = c->family != 0 || (cfg->flags & GRAPE_FLAG_MEMBER_RESULTS) || exact;
     if (e == hipSuccess && want_rows) e = alloc((void **)&c->d_member_out, sizeof(double) * E * Q * Bn);
     if (e == hipSuccess) e = alloc((void **)&c->d_partial, sizeof(double) * c->ksplit * Q);
     if (e == hipSuccess && c->family == 0) e = alloc((void **)&c->d_block_out, sizeof(double) * c->NB * Q * Bn);
@@ -1070,7 +1073,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     }
     std::vector<double> packed;
     try {
-        packed.assign(c->family == 0 ? 2 * E * (K + 3) * nn : 2 * (size_t)c->EU * (2 * K + 3) * c->TSZ, 0.0);
+        packed.assign(c->family != 1 ? 2 * E * (K + 3) * nn : 2 * (size_t)c->EU * (2 * K + 3) * c->TSZ, 0.0);
     } catch (...) {
         return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: out of host memory");
     }
@@ -1089,6 +1092,15 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             double *dst = packed.data() + 2 * k * (K + 3) * nn;
             scaled(dst, A + 2 * k * nn, nn);
             scaled(dst + 2 * nn, B + 2 * k * K * nn, K * nn);
+            std::memcpy(dst + 2 * (1 + K) * nn, Xi + 2 * k * nn, sizeof(double) * 2 * nn);
+            std::memcpy(dst + 2 * (2 + K) * nn, Xt + 2 * k * nn, sizeof(double) * 2 * nn);
+        }
+    } else if (c->family == 2) {
+        // per member: [A | B_0..B_{K-1} | Xi | Xt] as they are (sweep_any.hip applies (-i dt) itself)
+        for (size_t k = 0; k < E; ++k) {
+            double *dst = packed.data() + 2 * k * (K + 3) * nn;
+            std::memcpy(dst, A + 2 * k * nn, sizeof(double) * 2 * nn);
+            std::memcpy(dst + 2 * nn, B + 2 * k * K * nn, sizeof(double) * 2 * K * nn);
             std::memcpy(dst + 2 * (1 + K) * nn, Xi + 2 * k * nn, sizeof(double) * 2 * nn);
             std::memcpy(dst + 2 * (2 + K) * nn, Xt + 2 * k * nn, sizeof(double) * 2 * nn);
         }
@@ -1125,7 +1137,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     // Data-flow choice: if every generator is Hermitian to rounding, every propagator is
     // unitary and the sweep can carry M_t = P_t' M_{t+1} P_t instead of storing X_t.
     bool herm = !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) &&
-                c->cfg.gradient != GRAPE_GRADIENT_EXACT && !c->grid;     // (sweep_grid.hip: the reference's general flow only)
+                c->cfg.gradient != GRAPE_GRADIENT_EXACT && !c->grid && c->family != 2;     // (sweep_grid.hip, sweep_any.hip: the reference's general flow only)
     const int n = c->cfg.n;
     for (size_t k = 0; k < E && herm; ++k)
         for (size_t m = 0; m < K + 1 && herm; ++m)
@@ -1641,6 +1653,17 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         if (chunked(c) && (c->tp_C || c->thin_dpp))
             return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: a chunked time axis on a member-chunked workspace (budget too small for this ensemble)");
     }
+    if (c->family == 2) {
+        const size_t need = sizeof(double2) * 6 * nn * (size_t)c->Ec * ws_batch(c);
+        if (c->scratch_bytes < need) {
+            (void)hipFree(c->d_scratch);
+            c->d_scratch = nullptr;
+            c->bytes += need - c->scratch_bytes;
+            c->scratch_bytes = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_scratch, need));
+            c->scratch_bytes = need;
+        }
+    }
     if (thin) {
         c->unitary = false;                                  // the thin chain serves Hermitian generators as well
         if (!c->d_vecs) {
@@ -1750,6 +1773,7 @@ static bool states_stored(const grape_ctx *c)
 {
     if (c->exact_w1) return false;                           // exact gradient behind the unitary flow: W_t where the states would be
     if (c->d_costates) return true;                          // debug flow stores everything
+    if (c->family == 2) return true;                         // sweep_any.hip stores every X_t
     if (c->family == 0 || c->unitary || c->thin) return false;   // fast small-n flows / unitary / rank-one flows rebuild them
     if (c->grid) return true;                                // sweep_grid.hip stores every X_t
     return !grape::tile_chain_is_split(tile_params(c, nullptr), false);
@@ -1909,6 +1933,28 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
                 xq.zphi = q.zphi;
                 HIP_TRY(c, grape::launch_exact_grad(c->cfg.n, c->cfg.sys_type != GRAPE_UNITARY_GATE, xq, stream));
             }
+            return GRAPE_OK;
+        }
+        if (c->family == 2) {
+            grape::AnyParams a{};
+            a.ops = c->d_ops + (size_t)lo * (Kc + 3) * nn;
+            a.x = d_x;
+            a.props = c->d_props;
+            a.states = c->d_states;
+            a.costates = c->d_costates;
+            a.scratch = c->d_scratch;
+            a.member_out = c->d_member_out + (size_t)lo * Qrow;
+            a.n = c->cfg.n;
+            a.K = c->cfg.n_controls;
+            a.N = c->cfg.n_slices;
+            a.E = cnt;
+            a.E_rows = c->cfg.n_ensemble;
+            a.n_x = n_x;
+            a.sand = c->cfg.sys_type != GRAPE_UNITARY_GATE ? 1 : 0;
+            a.s_forced = c->cfg.expm_squarings;
+            a.variant = c->cfg.variant;
+            a.dt = c->cfg.duration / c->cfg.n_slices;
+            HIP_TRY(c, grape::launch_sweep_any(a, stream));
             return GRAPE_OK;
         }
         TileParams t = tile_params(c, d_x, n_x);
@@ -3162,6 +3208,11 @@ static int fetch_slab(grape_ctx *c, const double2 *d_ws, int member, cplx *out, 
                         }
         return GRAPE_OK;
     }
+    if (c->family == 2) {                                    // plain N x (n x n) per member
+        const size_t nn2 = (size_t)c->cfg.n * c->cfg.n, N2 = c->cfg.n_slices;
+        HIP_TRY(c, hipMemcpy(out, d_ws + (size_t)member * N2 * nn2, sizeof(cplx) * N2 * nn2, hipMemcpyDeviceToHost));
+        return GRAPE_OK;
+    }
     const size_t nn = (size_t)c->cfg.n * c->cfg.n, S = c->S, LT = c->CH, N = c->cfg.n_slices;   // LT: chunks per member
     std::vector<cplx> h(S * nn * LT);
     HIP_TRY(c, hipMemcpy(h.data(), d_ws + (size_t)member * S * nn * LT, sizeof(cplx) * h.size(),
@@ -3253,7 +3304,7 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
         cplx *Lc = reinterpret_cast<cplx *>(costates);
         rc = fetch_slab(c, c->d_costates, member, Lc);
         if (rc) return rc;
-        if (c->family == 0) {
+        if (c->family != 1) {
             HIP_TRY(c, hipMemcpy(Lc + N * nn, c->d_ops + (size_t)member * (K + 3) * nn + (K + 2) * nn,
                                  sizeof(cplx) * nn, hipMemcpyDeviceToHost));
         } else {

@@ -217,6 +217,19 @@ hipError_t launch_coop_chain_unitary(int sandwich, const TileParams &q, hipStrea
 int tile_count(int n);    // NT for this n (0: not a tile-family size)
 int tile_fuse_forward(const TileParams &p);   // thin: forward vector pass runs inside prop_tile_kernel for this launch?
 hipError_t launch_sweep_tile(int n, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
+// ---- any other operator dimension (n = 1, n > 64): sweep_any.hip, plain vector FP64, the reference's general flow ----------
+struct AnyParams {
+    const double2 *ops;       // per member [A | B_1..B_K | Xi | Xt], n x n column-major each
+    const double *x;          // (K, N, n_x)
+    double2 *props, *states;  // N matrices per (control array, member)
+    double2 *costates;        // nullable (GRAPE_FLAG_KEEP_COSTATES)
+    double2 *scratch;         // 6 matrices per (control array, member)
+    double *member_out;       // rows of K N + 1 doubles; row of (control array z, member k) at (z * E_rows + k)
+    int32_t n, K, N, E, E_rows, n_x, sand, s_forced, variant;
+    double dt;
+};
+hipError_t launch_sweep_any(const AnyParams &p, hipStream_t stream);
+
 // n = 33..64 (NT = 3, 4; sweep_grid.hip): a workgroup of NT x NT waves per matrix, the reference's general flow
 hipError_t launch_sweep_grid(int NT, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
 hipError_t launch_grid_prop(int NT, const TileParams &p, hipStream_t stream);     // its expm launches alone (P_t dumps as the tile family's)

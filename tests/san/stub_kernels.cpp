@@ -10,6 +10,7 @@ hipError_t launch_sweep_pair(int, int, int, const SweepParams &, hipStream_t) { 
 hipError_t launch_sweep_tile(int, int, bool, const TileParams &, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_sweep_grid(int, int, bool, const TileParams &, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_grid_prop(int, const TileParams &, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_sweep_any(const AnyParams &, hipStream_t) { return hipErrorNoDevice; }
 int reduce_rows_mflags(int Q, int n_x) { const long long g = (long long)((Q + 31) / 32) * n_x; return g >= 1 && g <= kMaxMflags ? (int)g : 0; }
 hipError_t launch_reduce(const double *, const double *, double *, double *, int, int, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
 hipError_t launch_reduce_rows(const double *, double *, int, int, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }

@@ -111,9 +111,9 @@ def test_argument_validation(qoc):
     assert b"sys_type" in lib.grape_last_error(None)
     cfg = qoc.engine.GrapeConfig(0, 0, 2, 0, 10, 1, 1.0, -1, 0, 0, 0, -1, 0)
     assert lib.grape_create(C.byref(cfg), C.byref(h)) == -1                        # K = 0
-    cfg = qoc.engine.GrapeConfig(0, 0, 65, 2, 10, 1, 1.0, -1, 0, 0, 0, -1, 0)
-    assert lib.grape_create(C.byref(cfg), C.byref(h)) == -2                        # n = 65 unsupported (2..64 have kernels)
-    assert b"n=65" in lib.grape_last_error(None)
+    cfg = qoc.engine.GrapeConfig(0, 0, 5000, 2, 10, 1, 1.0, -1, 0, 0, 0, -1, 0)
+    assert lib.grape_create(C.byref(cfg), C.byref(h)) == -2                        # n = 5000: beyond the generic kernel's indexing
+    assert b"n=5000" in lib.grape_last_error(None)
     cfg = qoc.engine.GrapeConfig(0, 0, 4, 2, 10, 1, 1.0, -1, 0, 0, 0, -1, 0, 5)
     assert lib.grape_create(C.byref(cfg), C.byref(h)) == -1                        # n_state_cols > n
     cfg = qoc.engine.GrapeConfig(1, 0, 4, 2, 10, 1, 1.0, -1, 0, 0, 0, -1, 0, 1)

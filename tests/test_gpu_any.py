@@ -1,0 +1,83 @@
+"""GPU: the size-generic path (sweep_any.hip) for operator dimensions outside the specialised families -- n = 1 and n > 64.
+`_fom_and_gradient_GRAPE!` (src/GRAPE.jl:25-96) takes matrices of any size; so does grape_create now.  Correct at the 1e-10 bar
+(every member's (F_k, g_k), the ensemble sums, propagators / states / costates to 1e-12), not fast: plain vector FP64, the
+reference's general flow."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+from test_gpu_tile import _engine, _random_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(qoc, oracle, w, variant=0, **kw):
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T,
+                                                            variant=variant, per_member=True)
+    with _engine(qoc, w, variant=variant, flags=qoc.engine.FLAG_KEEP_COSTATES, **kw) as eng:
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+        info = eng.info
+        names = eng.kernel_names()
+        k = w.E - 1
+        P, X, L = eng.trajectory(k, costates=True)
+        F2, G2 = eng.eval(w.x)
+    assert info["kernel_family"] == 2 and info["states_stored"] == 1 and "any_sweep_kernel" in names
+    assert F == F2 and np.array_equal(G, G2)                 # bitwise reproducible
+    _, _, Pr, Xr, Lr = oracle.member_eval(w.sys_type, w.A[k], w.B[k], w.Xi[k], w.Xt[k], w.x, w.T, variant=variant, trajectory=True)
+    for got, want, what in ((P, Pr, "propagators"), (X, Xr, "states"), (L, Lr, "costates")):
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), what
+    for m in range(w.E):
+        assert_parity(foms[m], grads[m], foms_ref[m], grads_ref[m], w.n, what=f"n={w.n} member {m}")
+    assert_parity(F, G, F_ref, G_ref, w.n, what=f"n={w.n}")
+    return F, G
+
+
+@pytest.mark.parametrize("n", [1, 65, 80, 100])
+@pytest.mark.parametrize("sys_type,herm", [("UnitaryGate", True), ("StateTransfer", False), ("CoherenceTransfer", True)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_any_size_random(qoc, oracle, n, sys_type, herm, variant):
+    w = _random_problem(qoc, n, 2, 5, 2, sys_type, seed=900 + n, hermitian=herm, mixed=True)
+    s = 0.6 if n == 1 else 2.0 / n
+    w.A *= s
+    w.B *= s
+    _check(qoc, oracle, w, variant=variant)
+
+
+def test_any_size_squarings_batches_chunks_groups(qoc, oracle, monkeypatch):
+    w = _random_problem(qoc, 70, 3, 4, 5, "UnitaryGate", seed=12, hermitian=True)
+    w.A *= 0.2                                               # dt |H|_1 of a few units: several squarings per slice
+    w.B *= 0.2
+    F0, G0 = _check(qoc, oracle, w)
+    rng = np.random.default_rng(4)
+    xs = np.array([w.x, rng.uniform(-1, 1, w.x.shape)])
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, max_batch=2) as eng:
+        Fb, Gb = eng.eval_batch(xs)
+    assert Fb[0] == F0 and np.array_equal(Gb[0], G0)
+    Fr, Gr = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, xs[1], w.T)
+    assert_parity(Fb[1], Gb[1], Fr, Gr, w.n, what="batch entry 1")
+    monkeypatch.setenv("GRAPE_MAX_WORKSPACE_BYTES", str(2 * 2 * w.N * 70 * 70 * 16 + 1000))       # two members' P_t and X_t
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        Fc, Gc = eng.eval(w.x)
+        assert eng.info["member_chunk"] == 2
+    assert Fc == F0 and np.array_equal(Gc, G0)               # member-chunked = unchunked, bit for bit
+    monkeypatch.delenv("GRAPE_MAX_WORKSPACE_BYTES")
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, devices=[0, 0],
+                         flags=qoc.engine.FLAG_GROUP_PEER_SUM) as eng:
+        Fg, Gg = eng.eval(w.x)
+    assert_parity(Fg, Gg, F0, G0, w.n, what="two shards")
+
+
+def test_scalar_problem_through_solve(qoc):
+    """n = 1: a one-level 'system' only collects a phase; UnitaryGate with Xt = e^{i phi}: F = Re(z^2) is minimised at -1."""
+    prob = qoc.Problem(B=[np.array([[1.0 + 0j]])], A=np.array([[0.3 + 0j]]), Xi=np.array([[1.0 + 0j]]), Xt=np.array([[1j]]),
+                       T=1.0, n_controls=1, guess=np.full((1, 6), 0.1), sys_type=qoc.UnitaryGate())
+    sol = qoc.solve(prob, qoc.GRAPE(n_slices=6))
+    assert sol.result.minimum <= 1.0
+
+
+def test_exact_gradient_is_refused_outside_2_to_32(qoc):
+    w = _random_problem(qoc, 70, 1, 3, 1, "UnitaryGate", seed=1)
+    with pytest.raises(Exception) as ei:
+        qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, gradient="exact")
+    assert "2 <= n <= 32" in str(ei.value)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Randomised differential soak: many random problems of every kernel family (n = 2..32, all system types, both
+"""Randomised differential soak: many random problems of every kernel family (n = 2..64, all system types, both
 variants, Hermitian / non-Hermitian generators, pure / mixed / rectangular states, dense / sparse controls, the data-flow
-flags) through the C ABI against the CPU oracle at the 1e-10 parity bar.  usage: tools/soak.py [cases] [seed]"""
+flags; round 5: the n = 33..64 grid family and a workspace budget that forces member-chunked evaluation as further random
+dimensions) through the C ABI against the CPU oracle at the 1e-10 parity bar.  usage: tools/soak.py [cases] [seed]"""
 import os
 import sys
 import time
@@ -22,12 +23,18 @@ F = qoc.engine
 fails = 0
 n_action = 0
 n_chunked = 0
+n_grid = 0
+n_member_chunked = 0
 t0 = time.time()
 for i in range(cases):
-    n = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32], p=[.1, .08, .14, .06, .06, .08, .08, .08, .12, .06, .06, .08]))
+    n = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32, 33, 40, 48, 57, 64],
+                       p=[.1, .08, .13, .06, .05, .07, .07, .07, .1, .05, .05, .07, .02, .02, .02, .02, .02]))
     K = int(rng.integers(1, 9))
-    N = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 64, 100, 257])) if n <= 16 else int(rng.choice([1, 2, 5, 9, 20]))
+    N = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 64, 100, 257])) if n <= 16 else int(rng.choice([1, 2, 5, 9, 20] if n <= 32 else [1, 2, 5, 9]))
     E = int(rng.choice([1, 2, 3, 5, 9, 17])) if n <= 16 else int(rng.choice([1, 2, 3]))
+    # a workspace budget of a few members' arrays: the evaluation walks the ensemble in blocks (bitwise the unchunked result,
+    # tests/test_gpu_chunked.py; here against the oracle like every other case)
+    chunk_budget = bool(E >= 3 and rng.random() < 0.2)
     sys_type = str(rng.choice(["UnitaryGate", "StateTransfer", "CoherenceTransfer"]))
     variant = int(rng.integers(0, 2))
     herm = bool(rng.integers(0, 2))
@@ -102,7 +109,14 @@ for i in range(cases):
     T = float(rng.uniform(0.3, 2.0))
     what = (f"case {i}: n={n} K={K} N={N} E={E} {sys_type} v{variant} herm={herm} sparse={sparse} states={states} flag={flag} "
             f"shared_ctrl={shared_ctrl} action={os.environ.get('GRAPE_ACTION', '-')} whole={os.environ.get('GRAPE_ACT_WHOLE', '-')} dpp={os.environ.get('GRAPE_THIN_DPP', '-')} dppc={os.environ.get('GRAPE_DPP_CHUNKS', '-')}")
-    exact = rng.random() < 0.15 and N <= 33 and states not in ("rect", "vec")      # (the C oracle has no exact gradient for n x m states)
+    exact = rng.random() < 0.15 and N <= 33 and n <= 32 and states not in ("rect", "vec")      # (the C oracle has no exact gradient for n x m states)
+    if chunk_budget:
+        nt = (n + 15) // 16
+        # one member's share of one workspace array: n <= 4 S x chunks <= N + 512 slices' worth of n x n matrices; tiles: N dumps
+        unit = (N + 512) * 16 * n * n if n <= 4 else N * nt * nt * 256 * 16
+        os.environ["GRAPE_MAX_WORKSPACE_BYTES"] = str(int(unit * (max(8, E // 2) if n <= 4 else 2 * max(2, E // 2))))
+    else:
+        os.environ.pop("GRAPE_MAX_WORKSPACE_BYTES", None)
     if exact:                                             # exact gradient of the figure of merit / of the C1 functional
         objective = int(rng.integers(0, 2))
         try:
@@ -125,6 +139,8 @@ for i in range(cases):
             info = eng.info
         n_action += int(info.get("expm_action", 0))
         n_chunked += int(info.get("prop_chain", 0) and info.get("time_chunks", 0) >= 2)
+        n_grid += int(n > 32)
+        n_member_chunked += int(info.get("member_chunk", E) < E)
         for k in range(E):
             # a member's whole gradient can be a near-zero (K = 1, N = 1: one entry passing through zero): the norm-wise
             # bar then has no scale left, so an absolute floor of a few ulp of the traces applies -- O(1) for unitary
@@ -143,5 +159,6 @@ for i in range(cases):
     except Exception as exc:                          # noqa: BLE001
         fails += 1
         print("FAIL", what, "->", repr(exc)[:300], flush=True)
-print(f"soak: {cases} cases, {fails} failures, {n_action} of them through the vector flow, {n_chunked} through the chunked propagator chain, {time.time() - t0:.1f} s (seed {seed})")
+print(f"soak: {cases} cases, {fails} failures, {n_action} of them through the vector flow, {n_chunked} through the chunked propagator chain, "
+      f"{n_grid} through the n > 32 grid family, {n_member_chunked} member-chunked, {time.time() - t0:.1f} s (seed {seed})")
 sys.exit(1 if fails else 0)
