@@ -103,7 +103,9 @@ enum {
 typedef struct grape_config {
     int32_t sys_type;          /* grape_sys_type                                     */
     int32_t variant;           /* grape_variant                                      */
-    int32_t n;                 /* operator dimension (d, or d*d for Liouvillians)    */
+    int32_t n;                 /* operator dimension (d, or d*d for Liouvillians): any n >= 1 (ABI v5; src/GRAPE.jl:25-96 is
+                                  size-generic).  n = 2..4 run in registers, 5..32 and 33..64 on the FP64 matrix cores, n = 1 and
+                                  n > 64 (up to 2048) through a plain size-generic kernel: correct, not fast */
     int32_t n_controls;        /* K                                                  */
     int32_t n_slices;          /* N                                                  */
     int32_t n_ensemble;        /* E owned by this context (1 for a plain Problem)    */
@@ -147,7 +149,7 @@ typedef struct grape_info {
     int32_t slices_per_lane;       /* S in use                                          */
     int32_t waves_per_member;      /* W in use                                          */
     int32_t expm_squarings;        /* forced s, or -1 = per slice from the generator norm */
-    int32_t kernel_family;         /* 0 = register-resident small-n, 1 = LDS/MFMA tile  */
+    int32_t kernel_family;         /* 0 = register-resident small-n, 1 = LDS/MFMA tile (n = 5..64), 2 = size-generic (n = 1, n > 64) */
     int32_t unitary_flow;          /* 1 after grape_set_operators found every A_k, B_jk Hermitian
                                       (propagators unitary): no forward-state round trip  */
     double  expm_theta;            /* norm threshold below which no scaling/squaring is done */

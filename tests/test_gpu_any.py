@@ -27,6 +27,12 @@ def _check(qoc, oracle, w, variant=0, **kw):
     _, _, Pr, Xr, Lr = oracle.member_eval(w.sys_type, w.A[k], w.B[k], w.Xi[k], w.Xt[k], w.x, w.T, variant=variant, trajectory=True)
     for got, want, what in ((P, Pr, "propagators"), (X, Xr, "states"), (L, Lr, "costates")):
         assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), what
+    if np.abs(grads_ref).max() < 1e-13:
+        # (n = 1 with a real control operator: g = 2 Re(i dt b |x|^2 |l|^2) is zero identically -- both sides return rounding
+        # noise of 1e-17, which no relative bar can compare)
+        assert np.abs(grads).max() < 1e-13 and np.abs(G).max() < 1e-13
+        assert np.abs(foms - foms_ref).max() <= 1e-10 * max(1.0, np.abs(foms_ref).max()) and abs(F - F_ref) <= 1e-10 * max(1.0, abs(F_ref))
+        return F, G
     for m in range(w.E):
         assert_parity(foms[m], grads[m], foms_ref[m], grads_ref[m], w.n, what=f"n={w.n} member {m}")
     assert_parity(F, G, F_ref, G_ref, w.n, what=f"n={w.n}")
