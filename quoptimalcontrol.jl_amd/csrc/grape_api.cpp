@@ -502,6 +502,14 @@ static bool plan_chunk(grape_ctx *c, int arrays)
     return true;
 }
 static bool chunked(const grape_ctx *c) { return c->Ec < c->cfg.n_ensemble; }
+// Could ANY flow of this context end up member-chunked (three arrays of the whole ensemble exceed the budget)?  The chunked
+// time axis and the small-ensemble propagator chain keep per-(unit, chunk) buffers of the whole ensemble: they are not chosen
+// then (a question that only arises under a test budget: ensembles small enough for those flows are far below any real one).
+static bool may_chunk(const grape_ctx *c)
+{
+    const size_t units = c->family == 0 ? (size_t)c->cfg.n_ensemble : (size_t)c->EU;
+    return sizeof(double2) * c->ws_unit * 3 * units * (size_t)c->B > c->ws_budget;
+}
 static size_t ws_batch(const grape_ctx *c) { return (size_t)c->ws_B; }                    // control arrays the workspace holds
 
 // one device, one contiguous shard of members: the workspace init_GRAPE allocates
@@ -1230,7 +1238,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     bool dpp_small = thin && !act_only && !act_forced && !(dpp_env && dpp_env[0] == '0') && !(hoist_env && hoist_env[0] == '0') &&
                      !(dppc_env && dppc_env[0] == '0') && !env_on("GRAPE_NO_TP") && !env_on("GRAPE_THIN_SINGLE") &&
                      (long)E < std::min(dpp_min, std::getenv("GRAPE_DPP_SMALL_MAX") ? std::atol(std::getenv("GRAPE_DPP_SMALL_MAX")) : 41L) &&
-                     c->cfg.n_slices >= 64;
+                     c->cfg.n_slices >= 64 && !may_chunk(c);
     // (dense control operators included: their forms run on the matrix cores -- action_forms_mfma_kernel; with the vector-ALU
     // forms kernel, GRAPE_FORMS_VALU=1, this flow loses there: one problem / eight, K = 4: 0.090 / 0.141 ms against 0.086 / 0.127
     // of the flows it replaces, 0.084 / 0.113 with the matrix-core kernel)
@@ -1386,7 +1394,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // GRAPE_TP_SLOTS=m: m x CUs pairs for every case (tuning).
         long pair_cap = (c->NT == 1 && !thin) ? 32L * c->compute_units : slots, small_cap = (c->NT == 1 && herm && !thin) ? pair_cap : slots;
         if (const char *e = std::getenv("GRAPE_TP_SLOTS")) pair_cap = small_cap = std::max(1L, std::atol(e)) * c->compute_units;
-        const bool small = c->family == 1 && !c->grid && 2 * units <= (thin ? slots : small_cap) && !env_on("GRAPE_NO_TP");
+        const bool small = c->family == 1 && !c->grid && 2 * units <= (thin ? slots : small_cap) && !env_on("GRAPE_NO_TP") && !may_chunk(c);
         if (small && !thin && N >= 8) {
             // slices per chunk at the latency optimum: one-level scan 3 S + N / S dependent products (general flow),
             // two-level scan (unitary flow) 3 S + 2 sqrt(N / S); measured optima (tools/tp_sweep.py): 32 x 32, N = 2000:
@@ -1490,7 +1498,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // once where the forward pass is fused into the expm kernel; this flow writes and reads it twice)
         // (needs the round-3 expm kernel, which writes both dumps: c->hoist != 0, i.e. at least 8 units)
         const bool dpp_chunked = dpp_small && c->tp_C > 1;       // (below dpp_min members: only with the chunked time axis)
-        const bool dpp = thin && !act && !act_only && c->hoist != 0 && !(de && de[0] == '0') && ((long)E >= dpp_min || dpp_chunked) &&
+        const bool dpp = thin && !act && !act_only && c->hoist != 0 && !may_chunk(c) && !(de && de[0] == '0') && ((long)E >= dpp_min || dpp_chunked) &&
                          ((de && de[0] == '1') || (long)E < 7L * c->compute_units / 4);
         c->thin_dpp = dpp;
         if (act || dpp) {

@@ -114,7 +114,7 @@ for i in range(cases):
         nt = (n + 15) // 16
         # one member's share of one workspace array: n <= 4 S x chunks <= N + 512 slices' worth of n x n matrices; tiles: N dumps
         unit = (N + 512) * 16 * n * n if n <= 4 else N * nt * nt * 256 * 16
-        os.environ["GRAPE_MAX_WORKSPACE_BYTES"] = str(int(unit * (max(8, E // 2) if n <= 4 else 2 * max(2, E // 2))))
+        os.environ["GRAPE_MAX_WORKSPACE_BYTES"] = str(int(unit * (max(8, E // 2) if n <= 4 else 3 * max(2, E // 2))))
     else:
         os.environ.pop("GRAPE_MAX_WORKSPACE_BYTES", None)
     if exact:                                             # exact gradient of the figure of merit / of the C1 functional
