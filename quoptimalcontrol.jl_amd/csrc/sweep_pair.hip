@@ -767,6 +767,21 @@ size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool xg_in_lds
     return b;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device) instead of once per launch: the
+// call sits on the host's critical path in front of every evaluation's first launch
+static hipError_t ensure_dynamic_lds(const void *fn, size_t lds, int (&have)[16])
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16)
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if ((int)lds <= have[dev])
+        return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+        have[dev] = (int)lds;
+    return e;
+}
+
 template <int N, int SAND, int MODE, bool XGLDS>
 static hipError_t plaunch_one(const SweepParams &p0, hipStream_t stream)
 {
@@ -788,7 +803,8 @@ static hipError_t plaunch_one(const SweepParams &p0, hipStream_t stream)
         if (p.dump_w1) {
             auto kern_w = sweep_pair_kernel<N, SAND, MODE, MAXT, XGLDS, true>;
             if (lds > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute((const void *)kern_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                static int have_w[16] = {0};
+                hipError_t e = ensure_dynamic_lds((const void *)kern_w, lds, have_w);
                 if (e != hipSuccess)
                     return e;
             }
@@ -800,7 +816,8 @@ static hipError_t plaunch_one(const SweepParams &p0, hipStream_t stream)
         return hipErrorInvalidConfiguration;
     auto kern = sweep_pair_kernel<N, SAND, MODE, MAXT, XGLDS>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static int have[16] = {0};
+        hipError_t e = ensure_dynamic_lds((const void *)kern, lds, have);
         if (e != hipSuccess)
             return e;
     }
