@@ -129,7 +129,7 @@ typedef struct grape_config {
     int32_t device_ids[GRAPE_MAX_DEVICES];   /* HIP ordinals, used when n_devices >= 2 */
     int32_t gradient;          /* grape_gradient: 0 = the reference's first-order grad_func! (src/GRAPE.jl:261-303),
                                   1 = exact derivative of the objective (what ADGRAPE gets from Zygote,
-                                  src/GRAPE.jl:12-20; cf. expm_exact_gradient, src/grape_tools.jl:26-57).  Runs behind the
+                                  src/GRAPE.jl:12-20; cf. expm_exact_gradient, src/grape_tools.jl:26-57); 2 <= n <= 64.  Runs behind the
                                   debug flow (every X_t, L_t stored: grape_get_trajectory returns them), except for
                                   UnitaryGate problems with Hermitian generators at n = 2 or 4 (the lane-pair kernel),
                                   which take the unitary flow (grape_info.unitary_flow = 1, states_stored = 0:

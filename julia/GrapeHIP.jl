@@ -44,7 +44,7 @@ struct GrapeConfig
     n_state_cols::Int32              # ABI v2: 0 = square states
     n_devices::Int32                 # ABI v2: 0/1 = one GPU; 2..8 = in-library sharding + RCCL all-reduce
     device_ids::NTuple{8,Int32}
-    gradient::Int32                  # 0 = reference first-order gradient, 1 = exact (n <= 32)
+    gradient::Int32                  # 0 = reference first-order gradient, 1 = exact (2 <= n <= 64)
     objective::Int32                 # 0 = fom_func, 1 = C1 functional of the ADGRAPE path
 end
 

@@ -282,6 +282,8 @@ hipError_t launch_exact_tile(int n, int sandwich, const TileParams &p, int objec
     switch (tile_count(n)) {
     case 1: return launch_exact_nt<1>(sandwich, p, objective, stream);
     case 2: return launch_exact_nt<2>(sandwich, p, objective, stream);
+    case 3: return launch_grid_exact(3, sandwich, p, objective, stream);       // n = 33..64: sweep_grid.hip
+    case 4: return launch_grid_exact(4, sandwich, p, objective, stream);
     default: return hipErrorInvalidValue;
     }
 }

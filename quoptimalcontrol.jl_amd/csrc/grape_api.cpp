@@ -459,8 +459,8 @@ static int validate_config(const grape_config *cfg)
     if ((uint64_t)cfg->n > 2048)
         return fail(nullptr, GRAPE_ERR_UNSUPPORTED,
                     "grape_create: operator dimension n=" + std::to_string(cfg->n) + " is beyond what this build indexes (n <= 2048)");
-    if ((nt > 2 || (wmax == 0 && nt == 0)) && cfg->gradient == GRAPE_GRADIENT_EXACT)
-        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: the exact gradient exists for 2 <= n <= 32 (other sizes run the reference's first-order flow)");
+    if (wmax == 0 && nt == 0 && cfg->gradient == GRAPE_GRADIENT_EXACT)
+        return fail(nullptr, GRAPE_ERR_UNSUPPORTED, "grape_create: the exact gradient exists for 2 <= n <= 64 (other sizes run the reference's first-order flow)");
     const int m = cfg->n_state_cols ? cfg->n_state_cols : cfg->n;
     if (m != cfg->n && cfg->sys_type != GRAPE_UNITARY_GATE)
         return fail(nullptr, GRAPE_ERR_INVALID_ARG,

@@ -232,7 +232,8 @@ hipError_t launch_sweep_any(const AnyParams &p, hipStream_t stream);
 
 // n = 33..64 (NT = 3, 4; sweep_grid.hip): a workgroup of NT x NT waves per matrix, the reference's general flow
 hipError_t launch_sweep_grid(int NT, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);
-hipError_t launch_grid_prop(int NT, const TileParams &p, hipStream_t stream);     // its expm launches alone (P_t dumps as the tile family's)
+hipError_t launch_grid_prop(int NT, const TileParams &p, hipStream_t stream);
+hipError_t launch_grid_exact(int NT, int sandwich, const TileParams &p, int objective, hipStream_t stream);   // exact gradient, n = 33..64     // its expm launches alone (P_t dumps as the tile family's)
 // Gc_t = (-i dt) sum_c x[c,t] B_c per slice and control array + its norm bound (prop_hoist.hip; member-invariant controls)
 hipError_t launch_ctrl_sum(int NT, const TileParams &p, hipStream_t stream);
 // prop_hoist.hip: control-sum pre-pass + the expm kernel on A'_k + Gc_t; q = the launcher's parameters (prop_slices, fuse_fwd set)

@@ -499,6 +499,262 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Exact control gradient / ADGRAPE functional for n = 33..64: exact_tile.hip's algorithm (read its header and exact_grad.hip's)
+// on the workgroup-owned matrices -- from the debug flow's stored P_t, X_t, L_{t+1}:
+//     dPhi/dx[c,t] = tr(dP_t[c] W1) [+ conj(tr(dP_t[c] W2))],  UnitaryGate W1 = X_t L_{t+1}',  sandwich W1 = X_t (L_{t+1} P_t)',
+//     W2 = (P_t X_t)' L_{t+1};  tr(DF_G[B] W) = tr(DF_G[W] B) for the Taylor-8 + squaring polynomial F: ONE forward-mode
+//     derivative per slice in the direction W1 (W2), a control costs a trace.  One workgroup per (member, slice).
+template <int NT, bool HA, bool HB>
+GRAPE_DEV GT grid_prod(double *img0, double *img1, const GT &a, const GT &b, int I, int J, int lane)
+{
+    grid_barrier();
+    grid_put<NT, HA>(img0, a, I, J, lane);               // left operand [row][k]: plain, or transposed for a conjugate transpose
+    grid_put<NT, !HB>(img1, b, I, J, lane);              // right operand [column][k]: transposed, or plain for a conjugate transpose
+    grid_barrier();
+    return grid_mma<NT, HA, HB>(img0, img1, I, J, lane);
+}
+
+// sum over the workgroup of M complex values per wave (wave-summed here), wave order: every thread gets the totals
+template <int NT, int M>
+GRAPE_DEV void grid_block_sum(double (&v)[M], double *s_red, int wave, int lane)
+{
+    constexpr int WAVES = NT * NT;
+    wave_sum_n(v);
+    grid_barrier();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < M; ++q)
+            s_red[wave * M + q] = v[q];
+    }
+    grid_barrier();
+#pragma unroll
+    for (int q = 0; q < M; ++q) {
+        double t = 0.0;
+        for (int w = 0; w < WAVES; ++w)
+            t += s_red[w * M + q];
+        v[q] = t;
+    }
+}
+
+GRAPE_DEV void gt_axpy(GT &o, double a, const GT &x)
+{
+    o.re += a * x.re;
+    o.im += a * x.im;
+}
+GRAPE_DEV GT gt_lin2(double a, const GT &x, double b, const GT &y)
+{
+    GT o;
+    o.re = a * x.re + b * y.re;
+    o.im = a * x.im + b * y.im;
+    return o;
+}
+
+template <int NT, int SAND>
+__global__ __launch_bounds__(64 * NT * NT) void grid_exact_kernel(const TileParams p, int objective)
+{
+    using G_ = GridGeom<NT>;
+    constexpr int TSZ = G_::TSZ, PLANE = G_::PLANE, DIM = G_::DIM;
+    extern __shared__ double s_grid[];
+    double *img0 = s_grid, *img1 = s_grid + 2 * PLANE, *s_red = s_grid + 4 * PLANE;      // s_red[WAVES][kGridRed]; s_col behind it
+    double *s_col = s_red + NT * NT * kGridRed;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, I = wave / NT, J = wave % NT, tile = I * NT + J;
+    const int k = blockIdx.y, t = blockIdx.x, K = p.K, N = p.N;
+    const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;             // [A | B_c | B_c^T | Xi | Xt]
+    auto prod = [&](const GT &a, const GT &b) { return grid_prod<NT, false, false>(img0, img1, a, b, I, J, lane); };
+    const GT P = gt_load(p.props + ((size_t)k * N + t) * TSZ, tile, lane);
+    const GT X = gt_load(p.states + ((size_t)k * N + t) * TSZ, tile, lane);
+    const GT L = t + 1 < N ? gt_load(p.costates + ((size_t)k * N + t + 1) * TSZ, tile, lane)
+                           : gt_load(ops + (size_t)(2 + 2 * K) * TSZ, tile, lane);      // Xt
+    // W1, W2 and Phi
+    GT W1, W2;
+    double ph[2];
+    {
+        const GT V = prod(P, X);                                                         // V = P X
+        if (SAND) {
+            const GT Z = prod(L, P);                                                     // Z = L P
+            ph[0] = 0.0;
+            ph[1] = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                                // Phi = tr((L P)' (P X))
+                ph[0] = fma(Z.re[r], V.re[r], ph[0]);
+                ph[0] = fma(Z.im[r], V.im[r], ph[0]);
+                ph[1] = fma(Z.re[r], V.im[r], ph[1]);
+                ph[1] = fma(-Z.im[r], V.re[r], ph[1]);
+            }
+            W1 = grid_prod<NT, false, true>(img0, img1, X, Z, I, J, lane);               // W1 = X (L P)'
+            W2 = grid_prod<NT, true, false>(img0, img1, V, L, I, J, lane);               // W2 = (P X)' L
+        } else {
+            ph[0] = 0.0;
+            ph[1] = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                                // Phi = tr(L' P X)
+                ph[0] = fma(L.re[r], V.re[r], ph[0]);
+                ph[0] = fma(L.im[r], V.im[r], ph[0]);
+                ph[1] = fma(L.re[r], V.im[r], ph[1]);
+                ph[1] = fma(-L.im[r], V.re[r], ph[1]);
+            }
+            W1 = grid_prod<NT, false, true>(img0, img1, X, L, I, J, lane);               // W1 = X L'
+            W2 = W1;
+        }
+        grid_block_sum<NT, 2>(ph, s_red, wave, lane);
+    }
+    const double phr = ph[0], phi = ph[1];
+    // generator (as grid_prop_kernel's own build) and the shared part of the Taylor evaluation
+    GT G;
+    if (p.variant == 0) {
+        G.re = (d4){0, 0, 0, 0};
+        G.im = (d4){0, 0, 0, 0};
+    } else {
+        G = gt_load(ops, tile, lane);
+    }
+    for (int c = 0; c < K; ++c) {
+        const double xv = p.x[c + (size_t)t * K];
+        const GT B = gt_load(ops + (size_t)(1 + c) * TSZ, tile, lane);
+        gt_axpy(G, xv, B);
+    }
+    if (p.variant == 0) {
+        const GT A = gt_load(ops, tile, lane);
+        gt_axpy(G, 1.0, A);
+    }
+    const double dt = p.dt;
+    double cs = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double hr = G.re[r], hi = G.im[r];
+        G.re[r] = dt * hi;
+        G.im[r] = -dt * hr;
+        cs += fabs(G.re[r]) + fabs(G.im[r]);
+    }
+    cs = swap16_add(cs, cs);
+    cs = swap32_add(cs, cs);
+    grid_barrier();
+    if (lane < 16)
+        s_col[I * DIM + 16 * J + lane] = cs;
+    grid_barrier();
+    double colmax = 0.0;
+    if (lane < DIM) {
+#pragma unroll
+        for (int ii = 0; ii < NT; ++ii)
+            colmax += s_col[ii * DIM + lane];
+    }
+    colmax = wave_max_fast(colmax);
+    const int s = p.s_forced >= 0 ? p.s_forced : squarings_for(colmax);
+    const double sc = s > 0 ? ldexp(1.0, -s) : 1.0;
+    if (s > 0) {
+        G.re *= sc;
+        G.im *= sc;
+    }
+    const GT A2 = prod(G, G);
+    const GT T1 = gt_lin2(kX1, G, kX2, A2);
+    const GT A4 = prod(A2, T1);
+    const GT U = gt_lin2(kX3, A2, 1.0, A4);
+    GT T2 = gt_lin2(kX5, G, kX6, A2);
+    gt_axpy(T2, kX7, A4);
+    gt_add_identity(T2, kX4, I, J, lane);
+    GT Ps;
+    if (s > 0) {                                                   // value at the scaled point, for the squaring chain rule
+        Ps = prod(U, T2);
+        gt_axpy(Ps, 1.0, G);
+        gt_axpy(Ps, kY2, A2);
+        gt_add_identity(Ps, 1.0, I, J, lane);
+    }
+    auto frechet = [&](const GT &W) {
+        const GT E = gt_lin2(sc, W, 0.0, W);
+        GT dA2 = prod(E, G);
+        gt_axpy(dA2, 1.0, prod(G, E));
+        const GT dT1 = gt_lin2(kX1, E, kX2, dA2);
+        GT dA4 = prod(dA2, T1);
+        gt_axpy(dA4, 1.0, prod(A2, dT1));
+        const GT dU = gt_lin2(kX3, dA2, 1.0, dA4);
+        GT dT2 = gt_lin2(kX5, E, kX6, dA2);
+        gt_axpy(dT2, kX7, dA4);
+        GT dP = prod(dU, T2);
+        gt_axpy(dP, 1.0, prod(U, dT2));
+        gt_axpy(dP, 1.0, E);
+        gt_axpy(dP, kY2, dA2);
+        if (s > 0) {
+            GT Pq = Ps;
+            for (int i = 0; i < s; ++i) {
+                GT tmp = prod(dP, Pq);
+                gt_axpy(tmp, 1.0, prod(Pq, dP));
+                dP = tmp;
+                Pq = prod(Pq, Pq);
+            }
+        }
+        return dP;
+    };
+    const GT D1 = frechet(W1);
+    const bool second = SAND && !p.herm_states;                    // Hermitian X, L: W2 == W1
+    GT D2m = D1;
+    if (second)
+        D2m = frechet(W2);
+    double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * N + 1);
+    const double Dn2 = 1.0 / ((double)p.n * (double)p.n);
+    const bool c1 = SAND || objective == 1;
+    for (int c = 0; c < K; ++c) {
+        const GT BT = gt_load(ops + (size_t)(1 + K + c) * TSZ, tile, lane);              // B_c^T: tr(D B_c) = sum D .* B_c^T
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[0] = fma(D1.re[r], BT.re[r], v[0]);
+            v[0] = fma(-D1.im[r], BT.im[r], v[0]);
+            v[1] = fma(D1.re[r], BT.im[r], v[1]);
+            v[1] = fma(D1.im[r], BT.re[r], v[1]);
+            v[2] = fma(D2m.re[r], BT.re[r], v[2]);
+            v[2] = fma(-D2m.im[r], BT.im[r], v[2]);
+            v[3] = fma(D2m.re[r], BT.im[r], v[3]);
+            v[3] = fma(D2m.im[r], BT.re[r], v[3]);
+        }
+        grid_block_sum<NT, 4>(v, s_red, wave, lane);
+        double dr = dt * v[1], di = -dt * v[0];                                          // B'_c = (-i dt) B_c
+        if (SAND) {
+            if (second) {
+                dr += dt * v[3];
+                di -= -dt * v[2];
+            } else {
+                dr += dr;                                                                // + conj of the same number
+                di = 0.0;
+            }
+        }
+        const double g = c1 ? -2.0 * Dn2 * (phr * dr + phi * di) : 2.0 * (phr * dr - phi * di);
+        if (threadIdx.x == 0)
+            out[c + (size_t)t * K] = g;
+    }
+    if (t == N - 1 && threadIdx.x == 0)
+        out[(size_t)K * N] = c1 ? 1.0 - Dn2 * (phr * phr + phi * phi) : phr * phr - phi * phi;
+}
+
+template <int NT>
+static hipError_t launch_grid_exact_nt(int sandwich, const TileParams &p, int objective, hipStream_t stream)
+{
+    const size_t dim = 16 * (size_t)NT;
+    const size_t lds = sizeof(double) * (4 * dim * (dim + 2) + (size_t)NT * NT * kGridRed + (size_t)NT * dim);
+    const dim3 grid(p.N, p.E), block(64 * NT * NT);
+    hipError_t e;
+    if (sandwich) {
+        e = hipFuncSetAttribute((const void *)grid_exact_kernel<NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        GRAPE_LAUNCH((grid_exact_kernel<NT, 1>), grid, block, lds, stream, p, objective);
+    } else {
+        e = hipFuncSetAttribute((const void *)grid_exact_kernel<NT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        GRAPE_LAUNCH((grid_exact_kernel<NT, 0>), grid, block, lds, stream, p, objective);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_grid_exact(int NT, int sandwich, const TileParams &p, int objective, hipStream_t stream)
+{
+    switch (NT) {
+    case 3: return launch_grid_exact_nt<3>(sandwich, p, objective, stream);
+    case 4: return launch_grid_exact_nt<4>(sandwich, p, objective, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // the expm launches: [ctrl_sum_kernel +] grid_prop_kernel
 template <int NT>
 static hipError_t launch_grid_prop_nt(const TileParams &p, hipStream_t stream)

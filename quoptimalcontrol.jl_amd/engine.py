@@ -166,7 +166,7 @@ class GrapeEngine:
                  devices=None, force_collective=False, gradient="reference", objective="fom"):
         """devices: list of HIP ordinals -> the library shards the ensemble over them itself
         (grape_config.n_devices / device_ids) and all-reduces [G, F] with RCCL once per evaluation.
-        gradient: "reference" (the first-order grad_func!) or "exact" (derivative of the objective, n <= 4);
+        gradient: "reference" (the first-order grad_func!) or "exact" (derivative of the objective, 2 <= n <= 64);
         objective: "fom" (fom_func) or "c1" (the ADGRAPE functional C1(Xt, U Xi [U']); needs gradient="exact")."""
         self._h = None
         self._lib = load_library()

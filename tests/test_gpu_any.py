@@ -86,4 +86,4 @@ def test_exact_gradient_is_refused_outside_2_to_32(qoc):
     w = _random_problem(qoc, 70, 1, 3, 1, "UnitaryGate", seed=1)
     with pytest.raises(Exception) as ei:
         qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, gradient="exact")
-    assert "2 <= n <= 32" in str(ei.value)
+    assert "2 <= n <= 64" in str(ei.value)

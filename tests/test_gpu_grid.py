@@ -159,8 +159,20 @@ def test_small_sizes_through_the_grid_kernels(qoc, oracle, monkeypatch, n, sys_t
     assert abs(F - F_tile) <= 1e-12 * max(1.0, abs(F_tile)) and np.abs(G - G_tile).max() <= 1e-12 * max(1.0, np.abs(G_tile).max())
 
 
-def test_exact_gradient_is_refused_beyond_32(qoc):
-    w = _random_problem(qoc, 40, 1, 4, 1, "UnitaryGate", seed=1)
-    with pytest.raises(Exception) as ei:
-        qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, gradient="exact")
-    assert "n <= 32" in str(ei.value)
+@pytest.mark.parametrize("n,herm,sys_type,scale", [(40, True, "UnitaryGate", 0.25), (48, False, "StateTransfer", 0.25),
+                                                    (64, True, "CoherenceTransfer", 0.2), (33, True, "UnitaryGate", 4.0)])
+@pytest.mark.parametrize("objective", ["fom", "c1"])
+def test_grid_family_exact_gradient(qoc, oracle, n, herm, sys_type, scale, objective):
+    """the exact gradient / ADGRAPE functional at n = 33..64 (grid_exact_kernel: exact_tile.hip's one-derivative-per-slice
+    algorithm on workgroup-owned matrices) against the oracle's independent restatement (block-triangular Pade), incl. the
+    squaring path (scale 4) and the mixed states whose W2 differs from W1."""
+    w = _random_problem(qoc, n, 2, 4, 2, sys_type, seed=1300 + n, hermitian=herm, mixed=True)
+    w.A *= scale
+    w.B *= scale
+    obj = 0 if objective == "fom" else 1
+    F_ref, G_ref = oracle.ensemble_exact(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, variant=1, objective=obj)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, variant=1, gradient="exact", objective=objective) as eng:
+        F, G = eng.eval(w.x)
+        names = eng.kernel_names()
+    assert "grid_exact_kernel" in names
+    assert_parity(F, G, F_ref, G_ref, n, what=f"exact gradient n={n} {objective}")
