@@ -4,10 +4,12 @@ rounds 3 and 4 while the kernel was the same (profiles/r05_C3_ab.txt).  Every wa
 shader-cycle counter at its phase boundaries (GRAPE_FLAG_PHASE_STAMPS):
 
   * phase A (H build, expm, chunk product: vector-FP64 issue bound) and phase B (scan) cost a number of cycles that does not
-    depend on the clock: the median over the 2048 waves must stay within 3 % of the committed count -- any change of the
-    instruction stream (register allocation, a larger kernarg struct, a new template argument) shows here;
+    depend on the clock to first order (phase A also issues the P_t stores: 53.3 k cycles at 1.97 GHz, 54.3 k at 2.33 GHz): the
+    median over the 2048 waves must stay within 5 % of the committed count -- 3 % for the kernel + 2 % for the pool's clock
+    spread; any change of the instruction stream (register allocation, a larger kernarg struct, a new template argument)
+    shows here;
   * phase D reads the stored propagators at HBM's rate: its CYCLE count grows with the clock (26 us are 51 k cycles at 1.97 GHz
-    and 57 k at 2.2 GHz), so the whole wave is held to 1.03 x the committed count only after scaling its memory-bound share
+    and 57 k at 2.2 GHz), so the whole wave is held to 1.05 x the committed count only after scaling its memory-bound share
     to the committed clock;
   * kernel time by HIP events (product build, warm clock): within 10 % of the committed microseconds -- the gross check.
 Committed numbers: profiles/perf_gate.json (MI355X, the commit that last touched the kernel)."""
@@ -53,7 +55,7 @@ def test_c3_sweep_kernel_cycles_within_the_committed_count(qoc):
           f"({gate['phase_b_cycles']}), D {d_cyc:.0f} -> {d_scaled:.0f} at {gate['clock_ghz']} GHz ({gate['phase_d_cycles']}), "
           f"wave {wave_cyc:.0f} -> {wave_scaled:.0f} ({gate['wave_cycles']}); kernel {kernel_us:.2f} us ({gate['kernel_us']})")
     assert 1.2 < clock < 2.6, clock
-    assert a_cyc <= 1.03 * gate["phase_a_cycles"], (a_cyc, gate["phase_a_cycles"])
-    assert b_cyc <= 1.03 * gate["phase_b_cycles"], (b_cyc, gate["phase_b_cycles"])
-    assert wave_scaled <= 1.03 * gate["wave_cycles"], (wave_scaled, gate["wave_cycles"])
+    assert a_cyc <= 1.05 * gate["phase_a_cycles"], (a_cyc, gate["phase_a_cycles"])
+    assert b_cyc <= 1.05 * gate["phase_b_cycles"], (b_cyc, gate["phase_b_cycles"])
+    assert wave_scaled <= 1.05 * gate["wave_cycles"], (wave_scaled, gate["wave_cycles"])
     assert kernel_us <= 1.10 * gate["kernel_us"], (kernel_us, gate["kernel_us"])
