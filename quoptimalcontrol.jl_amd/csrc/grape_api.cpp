@@ -1201,7 +1201,8 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     // shared controls, or -- n <= 16 -- the members' own (at most six: a lane keeps its half rows of them in registers)
     const bool act_ok = (ctrl_shared || (c->NT == 1 && K <= 6)) && !(act_env && act_env[0] == '0') &&
                         c->cfg.n_slices <= 4096;             // (per-slice plans live in LDS)
-    bool thin = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT && !c->grid &&
+    // (n = 33..64: grid_thin_kernel of sweep_grid.hip, sparse control operators only -- decided below the list build)
+    bool thin = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT && (!c->grid || c->NT >= 3) &&
                 !(c->cfg.flags & (GRAPE_FLAG_FORCE_GENERAL | GRAPE_FLAG_KEEP_COSTATES)) && !env_on("GRAPE_NO_THIN");
     const bool act_only = c->NT == 2 || c->pack2;            // n = 5..8 (two members per tile) and n = 17..32: vector flow or dense chains
     if (thin && act_only)
@@ -1235,7 +1236,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     // workgroup per (member, chunk).  GRAPE_DPP_CHUNKS=0 keeps sweep_thin.hip's chunked chain / the dense flows there.
     const char *dpp_env = std::getenv("GRAPE_THIN_DPP"), *hoist_env = std::getenv("GRAPE_HOIST"), *dppc_env = std::getenv("GRAPE_DPP_CHUNKS");
     const long dpp_min = dpp_env && dpp_env[0] == '1' ? 2 : (dpp_env && dpp_env[0] != '0' ? std::atol(dpp_env) : 80);
-    bool dpp_small = thin && !act_only && !act_forced && !(dpp_env && dpp_env[0] == '0') && !(hoist_env && hoist_env[0] == '0') &&
+    bool dpp_small = thin && !c->grid && !act_only && !act_forced && !(dpp_env && dpp_env[0] == '0') && !(hoist_env && hoist_env[0] == '0') &&
                      !(dppc_env && dppc_env[0] == '0') && !env_on("GRAPE_NO_TP") && !env_on("GRAPE_THIN_SINGLE") &&
                      (long)E < std::min(dpp_min, std::getenv("GRAPE_DPP_SMALL_MAX") ? std::atol(std::getenv("GRAPE_DPP_SMALL_MAX")) : 41L) &&
                      c->cfg.n_slices >= 64 && !may_chunk(c);
@@ -1254,7 +1255,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         if (rmax > 6 || env_on("GRAPE_FORMS_DENSE"))
             dpp_small = false;
     }
-    if (thin && E == 1 && c->cfg.n_slices >= 64 && !env_on("GRAPE_NO_TP") && !env_on("GRAPE_THIN_SINGLE") && !dpp_small)
+    if (thin && !c->grid && E == 1 && c->cfg.n_slices >= 64 && !env_on("GRAPE_NO_TP") && !env_on("GRAPE_THIN_SINGLE") && !dpp_small)
         thin = false;
     c->thin = thin;
     {                                                        // Hermitian control operators?
@@ -1302,6 +1303,10 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             }
             HIP_TRY(c, hipMemcpy(c->d_sp_coef, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice));
             HIP_TRY(c, hipMemcpy(c->d_sp_addr, addr.data(), sizeof(int32_t) * addr.size(), hipMemcpyHostToDevice));
+        }
+        if (c->grid && thin && !(sp && SM <= 256)) {             // grid_thin_kernel takes its forms from the lists: dense controls keep
+            thin = false;                                        // the dense chain
+            c->thin = false;
         }
     }
     {   // The expm kernels of prop_hoist.hip (n = 5..32, one member per tile).  hoist = 1: member-invariant control operators
@@ -1485,7 +1490,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // exp(G_t) applied to the two chains' vectors by its Taylor series, no propagator formed or stored.  Ensembles that
         // fill the device (the chunked flows of small ensembles keep the expm kernel: they need the chunk PRODUCTS);
         // GRAPE_ACTION=0 keeps the expm + chain kernels, GRAPE_ACTION=1 forces the vector flow for any ensemble size.
-        bool act = thin && act_ok;
+        bool act = thin && act_ok && !c->grid;
         if (act && !act_only && !act_forced && (long)c->EU < act_min_units(c)) act = false;
         c->action = act;
         // ... and where that flow does not apply (ensembles below its threshold, more than six per-member controls): the
@@ -1498,7 +1503,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // once where the forward pass is fused into the expm kernel; this flow writes and reads it twice)
         // (needs the round-3 expm kernel, which writes both dumps: c->hoist != 0, i.e. at least 8 units)
         const bool dpp_chunked = dpp_small && c->tp_C > 1;       // (below dpp_min members: only with the chunked time axis)
-        const bool dpp = thin && !act && !act_only && c->hoist != 0 && !may_chunk(c) && !(de && de[0] == '0') && ((long)E >= dpp_min || dpp_chunked) &&
+        const bool dpp = thin && !c->grid && !act && !act_only && c->hoist != 0 && !may_chunk(c) && !(de && de[0] == '0') && ((long)E >= dpp_min || dpp_chunked) &&
                          ((de && de[0] == '1') || (long)E < 7L * c->compute_units / 4);
         c->thin_dpp = dpp;
         if (act || dpp) {
@@ -1783,7 +1788,7 @@ static bool states_stored(const grape_ctx *c)
     if (c->d_costates) return true;                          // debug flow stores everything
     if (c->family == 2) return true;                         // sweep_any.hip stores every X_t
     if (c->family == 0 || c->unitary || c->thin) return false;   // fast small-n flows / unitary / rank-one flows rebuild them
-    if (c->grid) return true;                                // sweep_grid.hip stores every X_t
+    if (c->grid && !c->thin) return true;                    // sweep_grid.hip stores every X_t (rank-one states: vector records)
     return !grape::tile_chain_is_split(tile_params(c, nullptr), false);
 }
 
@@ -3268,7 +3273,7 @@ extern "C" int grape_get_trajectory(grape_ctx *c, int32_t member, double *props,
     const int n = c->cfg.n;
     const size_t nn = (size_t)n * n, N = c->cfg.n_slices, K = c->cfg.n_controls;
     std::vector<cplx> P(N * nn);
-    int rc = fetch_slab(c, c->d_props, member, P.data(), c->thin && !c->thin_dpp);
+    int rc = fetch_slab(c, c->d_props, member, P.data(), c->thin && !c->thin_dpp && !c->grid);
     if (rc) return rc;
     if (props) std::memcpy(props, P.data(), sizeof(cplx) * N * nn);
     // n x m states: the workspace holds them zero-padded to n x n; hand out the first m columns

@@ -499,6 +499,176 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Rank-one states at n = 33..64 (sparse control operators): the chain on VECTORS.  X_t = v_t v_t', L_t = w_t w_t' under the
+// sandwich (pure-state density operators, the vec(rho) vec(rho)' operands of a Liouville-space transfer -- a three-qubit
+// Liouvillian is 64 x 64), or X_t = v_t, L_t = w_t for n x 1 states under left multiplication (test/liou.jl:38-48):
+//     v_{t+1} = P_t v_t,   w_t = P_t' w_{t+1},   s = w_t' v_t (the same for every t),   a_c = w_t' B_c v_t,   b_c = v_t' B_c w_t,
+//     sandwich  g[c,t] = -dt Im(conj(s) a_c - s b_c),  F = 1 - (|s|^2 / n)^2;   left multiplication  g = -/+ 2 dt Im(a_c conj(s)),
+//     F = Re(conj(s)^2)      (src/GRAPE.jl:261-303, src/cost_functions.jl:13-17, :99-111 with the rank-one factors put in)
+// -- the numbers of the dense formulas up to rounding (tests compare with the oracle's DENSE evaluation), for two
+// matrix-vector products per slice instead of six (three) matrix products: the chain is bound by reading P_t twice.
+// One workgroup per (member, control array), wave (I, J) owns tile (I, J) of P_t: a partial product per wave, summed over
+// the tile row / column through LDS.  Controls: (coefficient, position) lists as in the dense chain, wave c owns control c.
+template <int NT, int SAND>
+__global__ __launch_bounds__(64 * NT * NT) void grid_thin_kernel(const TileParams p)
+{
+    using G_ = GridGeom<NT>;
+    constexpr int TSZ = G_::TSZ, DIM = G_::DIM, WAVES = G_::WAVES, P = G_::P;
+    __shared__ double2 s_v[2][DIM], s_w[2][DIM], s_part[NT][DIM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, I = wave / NT, J = wave % NT, tile = I * NT + J;
+    const int lo = lane & 15, hi = lane >> 4, tid = threadIdx.x;
+    const int k = blockIdx.x, K = p.K, N = p.N;
+    const size_t kw = (size_t)blockIdx.y * p.E + k;
+    const double2 *__restrict__ Pk = p.props + kw * N * TSZ;
+    double2 *__restrict__ V = p.states + kw * (size_t)(N + 1) * DIM;              // records v_0 .. v_N
+    double *__restrict__ out = p.member_out + ((size_t)blockIdx.y * p.E_members + k) * ((size_t)K * N + 1);
+    const double2 *__restrict__ v0 = p.vecs + (size_t)k * 2 * DIM, *__restrict__ wT = v0 + DIM;
+    // ------------------------------------------------------------ forward: v_{t+1} = P_t v_t
+    if (tid < DIM) {
+        s_v[0][tid] = v0[tid];
+        V[tid] = v0[tid];
+    }
+    GT Pt = gt_load(Pk, tile, lane);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < N; ++t) {
+        const double2 vj = s_v[cur][16 * J + lo];
+        double acc[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                          // row 16 I + 4 r + hi, column 16 J + lo
+            acc[2 * r] = fma(Pt.re[r], vj.x, -Pt.im[r] * vj.y);
+            acc[2 * r + 1] = fma(Pt.re[r], vj.y, Pt.im[r] * vj.x);
+        }
+        Pt = gt_load(Pk + (size_t)min(t + 1, N - 1) * TSZ, tile, lane);       // next slice in flight
+        row_sum_n(acc);                                                        // over the 16 columns of the tile
+        if (lo == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                s_part[J][16 * I + 4 * r + hi] = make_double2(acc[2 * r], acc[2 * r + 1]);
+        }
+        grid_barrier();
+        if (tid < DIM) {
+            double yr = 0.0, yi = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj) {
+                yr += s_part[jj][tid].x;
+                yi += s_part[jj][tid].y;
+            }
+            s_v[cur ^ 1][tid] = make_double2(yr, yi);
+            V[(size_t)(t + 1) * DIM + tid] = make_double2(yr, yi);
+        }
+        grid_barrier();
+        cur ^= 1;
+    }
+    // ------------------------------------------------------------ backward: w_t = P_t' w_{t+1}, forms, gradient
+    constexpr int NCW = (16 + WAVES - 1) / WAVES;                              // controls a wave may own (K <= 16)
+    double2 sp_c[NCW][4];
+    int sp_i[NCW][4], sp_j[NCW][4];
+    const int sp_ne = p.sp_nz >> 6;
+#pragma unroll
+    for (int ci = 0; ci < NCW; ++ci)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = wave + ci * WAVES;
+            const bool on = c < K && e < sp_ne;
+            const size_t at = ((size_t)k * K + (on ? c : 0)) * p.sp_nz + (on ? e : 0) * 64 + lane;
+            sp_c[ci][e] = on ? p.sp_coef[at] : make_double2(0.0, 0.0);
+            const int addr = on ? p.sp_addr[at] : 0;                           // position of R[j][i] in an image of pitch P
+            sp_j[ci][e] = addr / P;
+            sp_i[ci][e] = addr - (addr / P) * P;
+        }
+    const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
+    __syncthreads();                                   // (the forward pass's records have left: this workgroup reads them back)
+    if (tid < DIM)
+        s_w[0][tid] = wT[tid];
+    Pt = gt_load(Pk + (size_t)(N - 1) * TSZ, tile, lane);
+    double2 v_next = tid < DIM ? V[(size_t)(N - 1) * DIM + tid] : make_double2(0.0, 0.0);
+    grid_barrier();
+    int wc = 0;
+    for (int t = N - 1; t >= 0; --t) {
+        if (tid < DIM) {
+            s_v[t & 1][tid] = v_next;                                          // v_t for the forms (double-buffered by slice parity)
+            v_next = V[(size_t)max(t - 1, 0) * DIM + tid];                     // (this thread stored it in the forward pass)
+        }
+        double ar = 0.0, ai = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                          // conj(P[row][col]) w[row], summed over the tile's rows
+            const double2 wv = s_w[wc][16 * I + 4 * r + hi];
+            ar = fma(Pt.re[r], wv.x, ar);
+            ar = fma(Pt.im[r], wv.y, ar);
+            ai = fma(Pt.re[r], wv.y, ai);
+            ai = fma(-Pt.im[r], wv.x, ai);
+        }
+        Pt = gt_load(Pk + (size_t)max(t - 1, 0) * TSZ, tile, lane);
+        double acc[2] = {ar, ai};
+        col_sum_n(acc);                                                        // over the four lane groups (rows 4 r + hi)
+        if (hi == 0)
+            s_part[I][16 * J + lo] = make_double2(acc[0], acc[1]);
+        grid_barrier();
+        if (tid < DIM) {
+            double yr = 0.0, yi = 0.0;
+#pragma unroll
+            for (int ii = 0; ii < NT; ++ii) {
+                yr += s_part[ii][tid].x;
+                yi += s_part[ii][tid].y;
+            }
+            s_w[wc ^ 1][tid] = make_double2(yr, yi);
+        }
+        grid_barrier();
+        wc ^= 1;
+        const double2 *vt = s_v[t & 1], *wt = s_w[wc];
+#pragma unroll
+        for (int ci = 0; ci < NCW; ++ci) {
+            const int c = wave + ci * WAVES;
+            if (c < K) {                               // (wave-uniform)
+                double v6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};                  // a, b, s
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < sp_ne) {
+                        const double2 b = sp_c[ci][e];
+                        const double2 wi_ = wt[sp_i[ci][e]], vj_ = vt[sp_j[ci][e]], vi_ = vt[sp_i[ci][e]], wj_ = wt[sp_j[ci][e]];
+                        // a += conj(w_i) B_ij v_j
+                        const double t1r = b.x * vj_.x - b.y * vj_.y, t1i = b.x * vj_.y + b.y * vj_.x;
+                        v6[0] = fma(wi_.x, t1r, v6[0]);
+                        v6[0] = fma(wi_.y, t1i, v6[0]);
+                        v6[1] = fma(wi_.x, t1i, v6[1]);
+                        v6[1] = fma(-wi_.y, t1r, v6[1]);
+                        // b += conj(v_i) B_ij w_j
+                        const double t2r = b.x * wj_.x - b.y * wj_.y, t2i = b.x * wj_.y + b.y * wj_.x;
+                        v6[2] = fma(vi_.x, t2r, v6[2]);
+                        v6[2] = fma(vi_.y, t2i, v6[2]);
+                        v6[3] = fma(vi_.x, t2i, v6[3]);
+                        v6[3] = fma(-vi_.y, t2r, v6[3]);
+                    }
+                if (lane < (DIM < 64 ? DIM : 64)) {     // s = w' v
+                    const double2 wv = wt[lane], vv = vt[lane];
+                    v6[4] = wv.x * vv.x + wv.y * vv.y;
+                    v6[5] = wv.x * vv.y - wv.y * vv.x;
+                }
+                wave_sum_n(v6);
+                if (lane == 0) {
+                    const double sr = v6[4], si = v6[5];
+                    double im;
+                    if (SAND)                           // Im(conj(s) a - s b)
+                        im = (sr * v6[1] - si * v6[0]) - (sr * v6[3] + si * v6[2]);
+                    else                                // Im(a conj(s))
+                        im = v6[1] * sr - v6[0] * si;
+                    out[c + (size_t)t * K] = gs * im;
+                    if (t == N - 1 && c == 0) {
+                        if (SAND) {
+                            const double q = (sr * sr + si * si) / (double)p.n;
+                            out[(size_t)K * N] = 1.0 - q * q;
+                        } else {
+                            out[(size_t)K * N] = sr * sr - si * si;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Exact control gradient / ADGRAPE functional for n = 33..64: exact_tile.hip's algorithm (read its header and exact_grad.hip's)
 // on the workgroup-owned matrices -- from the debug flow's stored P_t, X_t, L_{t+1}:
 //     dPhi/dx[c,t] = tr(dP_t[c] W1) [+ conj(tr(dP_t[c] W2))],  UnitaryGate W1 = X_t L_{t+1}',  sandwich W1 = X_t (L_{t+1} P_t)',
@@ -810,6 +980,13 @@ static hipError_t launch_grid_nt(int sandwich, bool keepl, const TileParams &p, 
             return e;
     }
     const dim3 grid(p.E, p.n_x), block(64 * NT * NT);
+    if constexpr (NT >= 3) {
+        if (p.thin && p.sparse && p.K <= 16 && p.sp_nz <= 256) {       // rank-one states: the chain on vectors
+            if (sandwich) GRAPE_LAUNCH((grid_thin_kernel<NT, 1>), grid, block, 0, stream, q);
+            else          GRAPE_LAUNCH((grid_thin_kernel<NT, 0>), grid, block, 0, stream, q);
+            return hipGetLastError();
+        }
+    }
 #define GRAPE_GRID_CHAIN(S, KL, SP)                                                                                      \
     {                                                                                                                    \
         e = hipFuncSetAttribute((const void *)grid_chain_kernel<NT, S, KL, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, \

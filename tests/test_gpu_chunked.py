@@ -84,6 +84,18 @@ def test_tile_and_grid_families(qoc, oracle, monkeypatch, n, sys_type, herm):
     _check_chunked_equals_unchunked(qoc, oracle, monkeypatch, w, 3, env={"GRAPE_NO_TP": "1"})
 
 
+def test_grid_family_vector_chain(qoc, oracle, monkeypatch):
+    """rank-one states at n = 48 with sparse controls (grid_thin_kernel): vector records per chunk"""
+    from test_gpu_grid import _rank_one_sparse_problem
+    n, K, N, E = 48, 3, 12, 10
+    A, B, Xi, Xt, wts, x = _rank_one_sparse_problem(n, K, N, E, "CoherenceTransfer", False, 20, seed=4, shared=True)
+    w = qoc.workloads.Workload("rank1", "CoherenceTransfer", n, K, N, E, 1.0, A, B, Xi, Xt, wts, x)
+    _check_chunked_equals_unchunked(qoc, oracle, monkeypatch, w, 3)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        eng.eval(w.x)
+        assert eng.info["rank_one_chain"] == 1 and "grid_thin_kernel" in eng.kernel_names()
+
+
 def test_exact_gradient_and_batches_on_a_chunked_context(qoc, oracle, monkeypatch):
     w = qoc.workloads.config("C3", E=40, N=32)
     rng = np.random.default_rng(8)

@@ -136,6 +136,90 @@ def test_grid_family_rectangular_states(qoc, oracle):
     assert_parity(F, G, F_ref, G_ref, n, what="64 x 1 states")
 
 
+def _rank_one_sparse_problem(n, K, N, E, sys_type, herm, pairs, seed, shared):
+    """pure states (sandwich: Xi = v v', Xt = w w'; left multiplication: n x 1 columns), control operators with a few
+    symmetric pairs of non-zeros -- the shape of a three-qubit Liouville-space transfer (64 x 64, Pauli-type controls)"""
+    rng = np.random.default_rng(seed)
+
+    def gen():
+        M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        return 0.2 * ((M + M.conj().T) / 2 if herm else M)
+    A = np.array([gen() for _ in range(E)])
+    B = np.zeros((E, K, n, n), complex)
+    for k in range(E):
+        for c in range(K):
+            for _ in range(pairs):
+                i, j = rng.integers(0, n, 2)
+                v = rng.standard_normal() + 1j * rng.standard_normal()
+                if i == j:
+                    B[k, c, i, i] = v.real
+                elif herm:
+                    B[k, c, i, j], B[k, c, j, i] = v, np.conj(v)
+                else:
+                    B[k, c, i, j] = v
+    if shared:
+        B[:] = B[0]
+
+    def vec():
+        v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        return v / np.linalg.norm(v)
+    if sys_type == "UnitaryGate":
+        Xi = np.array([vec().reshape(n, 1) for _ in range(E)])
+        Xt = np.array([vec().reshape(n, 1) for _ in range(E)])
+    else:
+        Xi = np.array([np.outer(v, v.conj()) for v in (vec() for _ in range(E))])
+        Xt = np.array([np.outer(v, v.conj()) for v in (vec() for _ in range(E))])
+    return A, B, Xi, Xt, rng.uniform(0.2, 1.0, E), rng.uniform(-1, 1, (K, N))
+
+
+@pytest.mark.parametrize("n,sys_type,K,N,E,pairs,herm,shared", [
+    (64, "CoherenceTransfer", 6, 40, 3, 30, False, True), (48, "StateTransfer", 11, 7, 2, 20, True, False),
+    (33, "UnitaryGate", 3, 1, 2, 12, True, False), (64, "UnitaryGate", 16, 33, 3, 60, False, True),
+    (57, "StateTransfer", 4, 2, 2, 100, True, True), (40, "UnitaryGate", 1, 101, 1, 5, False, False),
+    (64, "StateTransfer", 2, 64, 5, 126, False, False)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_grid_family_rank_one_states_run_on_vectors(qoc, oracle, monkeypatch, n, sys_type, K, N, E, pairs, herm, shared, variant):
+    """grid_thin_kernel: v_{t+1} = P_t v_t, w_t = P_t' w_{t+1}, the gradient from the controls' (coefficient, position)
+    lists -- against the oracle's DENSE evaluation of the same inputs at the 1e-10 bar, member by member, and against the
+    library's own dense chain (GRAPE_NO_THIN=1); dense control operators keep the dense chain."""
+    A, B, Xi, Xt, wts, x = _rank_one_sparse_problem(n, K, N, E, sys_type, herm, pairs, seed=11 * n + K + N, shared=shared)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 1.1, variant=variant, per_member=True)
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.1, N, variant=variant, member_results=True, max_batch=2) as eng:
+        info = eng.info
+        F, G = eng.eval(x)
+        foms, grads = eng.member_results()
+        names = eng.kernel_names()
+        P = eng.trajectory(E - 1, states=False)[0]
+        Fb, Gb = eng.eval_batch(np.array([0.5 * x, x]))
+    assert info["rank_one_chain"] == 1 and info["sparse_controls"] == 1 and info["states_stored"] == 0, info
+    assert any(k.startswith("grid_thin_kernel") for k in names) and not any(k.startswith("grid_chain_kernel") for k in names), names
+    for k in range(E):
+        assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k}")
+    assert_parity(F, G, F_ref, G_ref, n, what="ensemble")
+    assert Fb[1] == F and np.array_equal(Gb[1], G)
+    if sys_type == "UnitaryGate":
+        P_ref = oracle.member_eval_rect(A[-1], B[-1], Xi[-1], Xt[-1], x, 1.1, variant=variant, trajectory=True)[2]
+    else:
+        P_ref = oracle.member_eval(sys_type, A[-1], B[-1], Xi[-1], Xt[-1], x, 1.1, variant=variant, trajectory=True)[2]
+    assert np.abs(P - P_ref).max() <= 1e-12 * max(1.0, np.abs(P_ref).max())
+    monkeypatch.setenv("GRAPE_NO_THIN", "1")
+    with qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 1.1, N, variant=variant) as eng:
+        assert eng.info["rank_one_chain"] == 0
+        F_d, G_d = eng.eval(x)
+    assert_parity(F, G, F_d, G_d, n, what="vector chain vs dense chain")
+
+
+def test_grid_family_rank_one_states_with_dense_controls_keep_the_dense_chain(qoc, oracle):
+    w = _random_problem(qoc, 40, 2, 6, 2, "StateTransfer", seed=3, hermitian=True)       # pure states, dense B
+    w.A *= 0.2
+    w.B *= 0.2
+    with _engine(qoc, w) as eng:
+        assert eng.info["rank_one_chain"] == 0 and eng.info["states_stored"] == 1
+        F, G = eng.eval(w.x)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    assert_parity(F, G, F_ref, G_ref, w.n, what="dense controls")
+
+
 def test_grid_family_on_a_group(qoc, oracle):
     """three shards on one GPU (peer sum): the ensemble axis splits as for every other family"""
     w = _random_problem(qoc, 40, 2, 7, 5, "UnitaryGate", seed=77, hermitian=True)
