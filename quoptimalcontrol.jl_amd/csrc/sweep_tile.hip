@@ -563,11 +563,41 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
 #ifndef GRAPE_SPLIT_ABL
 #define GRAPE_SPLIT_ABL 0
 #endif
-template <int SAND, bool SPARSE = false, int PARTS = 2>
-__global__ __launch_bounds__(64 * PARTS, PARTS) void chain_tile_split_kernel(const TileParams p)
+#ifndef GRAPE_SPLIT_EU
+#define GRAPE_SPLIT_EU
+#endif
+template <int SAND, int SPARSE = 0, int PARTS = 2, int HERM = 0>
+__global__ __launch_bounds__(64 * PARTS, PARTS) GRAPE_SPLIT_EU void chain_tile_split_kernel(const TileParams p)
 {
     constexpr int NT = 1, TSZ = 256;
     extern __shared__ double2 s_dynt[];
+#ifdef GRAPE_SPLIT_PAD
+    if constexpr (PARTS == 2)
+        asm volatile("" ::: "v175");
+#endif
+#ifdef GRAPE_SPLIT_STAMP            // diagnostic build (tools/split_stamps.py): cycles between points of the slice loops, summed per wave
+    long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+#define ST_BEGIN() st_last = __builtin_readcyclecounter()
+#define ST_MARK(i)                                            \
+    {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                    \
+        const long long now_ = __builtin_readcyclecounter();  \
+        __builtin_amdgcn_sched_barrier(0);                    \
+        st_acc[i] += now_ - st_last;                          \
+        st_last = now_;                                       \
+    }
+#define ST_DEP(x)                                              \
+    {                                                          \
+        int lo_ = __double2loint(x);                           \
+        __builtin_amdgcn_sched_barrier(0);                     \
+        asm volatile("v_mov_b32 %0, %0" : "+v"(lo_));          \
+        __builtin_amdgcn_sched_barrier(0);                     \
+    }
+#else
+#define ST_BEGIN()
+#define ST_MARK(i)
+#define ST_DEP(x)
+#endif
     const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double2 *s_img = s_dynt + (size_t)part * (kTileImage + 1);
     auto xch = [&](int q) { return s_dynt + (size_t)q * (kTileImage + 1); };   // wave q's image, lent for the exchange
@@ -581,7 +611,14 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) void chain_tile_split_kernel(con
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
     const double2 *__restrict__ opBT = ops + (size_t)(1 + K) * TSZ;
     const bool bt_lds = p.bt_in_lds != 0;
-    const bool herm = SAND && p.herm_states != 0;
+#ifndef GRAPE_SPLIT_VAR
+#define GRAPE_SPLIT_VAR 0
+#endif
+    // HERM (sandwich): 1 = Hermitian Xi, Xt (density operators), 2 = ... and Hermitian control operators -- template
+    // arguments, not flags: a branch inside the slice loops makes the compiler wait for the prefetched loads at its join
+    constexpr bool herm = SAND && HERM >= 1;
+    constexpr bool herm2 = SAND && HERM == 2 && !(GRAPE_SPLIT_VAR & 1);
+    constexpr bool hermx = herm && !(GRAPE_SPLIT_VAR & 2);
     if (SPARSE) {
         stage_sparse_lists<NT>(p, k, (int)threadIdx.x, 64 * PARTS, s_coef, s_addr);
     } else if (bt_lds) {
@@ -594,60 +631,88 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) void chain_tile_split_kernel(con
     double *__restrict__ out = p.member_out + kw * ((size_t)K * N + 1);
 
     // ------------------------------------------------------------ pass 1
+    // Every load of the slice loops is issued RG - 1 slices ahead of its use into a ring of RG register buffers (the loops are
+    // unrolled RG times: a buffer is a fixed set of registers).  tools/split_stamps.py (the waves' own cycle counts) showed
+    // the round-4 loops -- one slice ahead, `Pm = Pn` at the end of an iteration, i.e. a wait for the load issued one product
+    // earlier -- spending 23-29 % of their cycles waiting for P_t to arrive (HBM answers in ~5 k cycles under this load, a
+    // slice of pass 1 computes for ~2.3 k).  No vector-memory instruction of these loops sits behind a branch: at the join
+    // the compiler's s_waitcnt pass has to assume the path that issued nothing and waits for the YOUNGEST load.  The first
+    // (count mod RG) slices of a range run one at a time (load, wait, use).
+    constexpr int RG = PARTS == 2 ? 4 : 2;                         // pass 1;  pass 2 keeps more matrices live
+    constexpr int RB = PARTS == 2 ? 3 : 2;
     TMat<1> keep;                                                  // what this wave hands over: X at hi (wave 0), T_part (others)
-    if (part == 0) {
-        TMat<1> X, Pm, Pn, Y;
+    {
+        TMat<1> X, Y, Pb[RG];
         TOp<1> PA;
-        tload(X, ops + (size_t)(1 + 2 * K) * TSZ, lane);           // Xi
-        tload(Pm, Pk, lane);
-        for (int t = 0; t < hi; ++t) {
-            if (!(GRAPE_SPLIT_ABL & 1)) tstore(Xk + (size_t)t * TSZ, X, lane);
-            tload(Pn, Pk + (size_t)min(t + 1, hi - 1) * TSZ, lane);   // (clamped, never branched round: see the note above the kernel)
-            to_a_layout(PA, Pm, s_img, lane);
-            if (SAND) {
+        if (part == 0) {
+            tload(X, ops + (size_t)(1 + 2 * K) * TSZ, lane);       // Xi
+        } else {
+            tzero(X);                                              // V_0 = 1 (X plays V: prefix products of this part's propagators)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * r + (lane >> 4) == (lane & 15))
+                    X.re[0][0][r] = 1.0;
+        }
+        const bool first = part == 0;
+        auto step = [&](int t, const TMat<1> &Pt) {
+            if (!(GRAPE_SPLIT_ABL & 1)) tstore(Xk + (size_t)t * TSZ, X, lane);   // X_t (wave 0) / V_{t-lo}: X_t = V X_lo V'
+            ST_MARK(9)
+            to_a_layout(PA, Pt, s_img, lane);
+            ST_DEP(PA.im[0][0][3])
+            ST_MARK(0)
+            if (SAND && first) {
                 tmul_tb<NT, false, false>(Y, X, PA);               // (P X)^T
                 tmul_tb<NT, false, true>(X, Y, PA);                // (P X) P'
             } else {
-                tmul_an<NT, false, false>(Y, PA, X);
+                tmul_an<NT, false, false>(Y, PA, X);               // P X  /  P V
                 X = Y;
             }
-            Pm = Pn;
+            ST_DEP(X.im[0][0][3])
+            ST_MARK(1)
+        };
+        int t = lo;
+        ST_BEGIN();
+        for (const int head_end = lo + (hi - lo) % RG; t < head_end; ++t) {
+            tload(Pb[0], Pk + (size_t)t * TSZ, lane);
+            step(t, Pb[0]);
+        }
+        if (t < hi) {
+#pragma unroll
+            for (int i = 0; i < RG - 1; ++i)
+                tload(Pb[i], Pk + (size_t)min(t + i, hi - 1) * TSZ, lane);
+            for (; t < hi; t += RG) {
+#pragma unroll
+                for (int i = 0; i < RG; ++i) {
+                    tload(Pb[(i + RG - 1) % RG], Pk + (size_t)min(t + i + RG - 1, hi - 1) * TSZ, lane);   // (clamped: re-reads the last slice)
+                    step(t + i, Pb[i]);
+                }
+            }
         }
         keep = X;
-    } else {
-        TMat<1> V, Pm, Pn, Y;
-        TOp<1> PA;
-        tzero(V);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * r + (lane >> 4) == (lane & 15))
-                V.re[0][0][r] = 1.0;
-        if (lo < hi)
-            tload(Pm, Pk + (size_t)lo * TSZ, lane);
-        for (int t = lo; t < hi; ++t) {
-            if (!(GRAPE_SPLIT_ABL & 1)) tstore(Xk + (size_t)t * TSZ, V, lane);                 // V_{t-lo}: X_t = V X_lo V'
-            tload(Pn, Pk + (size_t)min(t + 1, hi - 1) * TSZ, lane);
-            to_a_layout(PA, Pm, s_img, lane);
-            tmul_an<NT, false, false>(Y, PA, V);                   // P V
-            V = Y;
-            Pm = Pn;
-        }
-        keep = V;
     }
     tstore(s_img, keep, lane);                                     // (its own image: this wave's conversions are behind it)
     __syncthreads();
+    ST_MARK(2)                                                     // waiting for the other wave's pass 1
 
     // ------------------------------------------------------------ pass 2: backward sweep + gradient
-    const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
-    TMat<1> L, Pm, X, Y, R;
-    TOp<1> XA, LA;
+    const double gs = SAND ? (herm2 ? -2.0 * p.dt : -p.dt) : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
+    TMat<1> L, Y, R;
     bool z_known = false;
     double z_keep_r = 0.0, z_keep_i = 0.0;
-    // gradient entries + figure of merit of one slice from X_t, L_t (costate after pulling back through slice t)
-    auto emit = [&](int t) {
+    // SPARSE == 2 (K = 4 lists of 64 entries: C4's shape): a lane keeps its four list entries in registers
+    double2 cf4[4];
+    int ad4[4];
+    if constexpr (SPARSE == 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            cf4[c] = s_coef[c * 64 + lane];
+            ad4[c] = s_addr[c * 64 + lane];
+        }
+    }
+    // gradient entries of one slice from X_t, L_t (costate after pulling back through slice t)
+    auto emit = [&](int t, const TMat<1> &X) {
         if (SPARSE && !z_known) {
-            // tr(X_t' L_t) is the same for every t (also for non-unitary P): taken at the first slice this wave emits --
-            // and BEFORE the conversions, so that X is dead once its A-operand image exists
+            // tr(X_t' L_t) is the same for every t (also for non-unitary P): taken at the first slice this wave emits
             double zz[2];
             tdot_partial<NT, true>(zz[0], zz[1], X, L);
             wave_sum_n(zz);
@@ -655,13 +720,26 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) void chain_tile_split_kernel(con
             z_keep_i = zz[1];
             z_known = true;
         }
-        to_a_layout(XA, X, s_img, lane);
-        to_a_layout(LA, L, s_img, lane);
-        tprod<NT, false, true>(
-            R, [&](int I, int Kt, int kb, double &r, double &i) { r = XA.re[I][Kt][kb]; i = XA.im[I][Kt][kb]; },
-            [&](int Kt, int J, int kb, double &r, double &i) { r = LA.re[J][Kt][kb]; i = LA.im[J][Kt][kb]; });   // X L'
-        if (SAND) {
-            if (herm) {                                            // [X, L'] = Y - Y',  Y' = conj(Y^T)
+        if constexpr (hermx) {
+            // Hermitian X_t, L_t (to rounding, as Y - Y' below already takes them): the A-operand image of X is the D layout of
+            // X^T = conj(X), and L' = L is a right operand as it stands -- no layout conversion for this product
+            tprod<NT, true, false>(
+                R, [&](int, int, int kb, double &r, double &i) { r = X.re[0][0][kb]; i = X.im[0][0][kb]; },
+                [&](int, int, int kb, double &r, double &i) { r = L.re[0][0][kb]; i = L.im[0][0][kb]; });        // X L
+        } else {
+            TOp<1> XA, LA;
+            to_a_layout(XA, X, s_img, lane);
+            to_a_layout(LA, L, s_img, lane);
+            tprod<NT, false, true>(
+                R, [&](int I, int Kt, int kb, double &r, double &i) { r = XA.re[I][Kt][kb]; i = XA.im[I][Kt][kb]; },
+                [&](int Kt, int J, int kb, double &r, double &i) { r = LA.re[J][Kt][kb]; i = LA.im[J][Kt][kb]; });   // X L'
+        }
+        ST_DEP(R.im[0][0][3])
+        ST_MARK(6)
+        if constexpr (SAND) {
+            if constexpr (herm2) {
+                // ... and Hermitian control operators: tr(B Y') = conj(tr(B Y)), so Im tr(B [X, L]) = 2 Im tr(B Y) -- Y' is never formed
+            } else if constexpr (herm) {                           // [X, L'] = Y - Y',  Y' = conj(Y^T)
                 TOp<1> RT;
                 to_a_layout(RT, R, s_img, lane);                   // D layout of Y^T
 #pragma unroll
@@ -675,8 +753,29 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) void chain_tile_split_kernel(con
                 R.im[0][0] -= Y.im[0][0];
             }
         }
+        ST_MARK(7)
         double zr = 0.0, zi = 0.0;
-        if (SPARSE) {
+        if constexpr (SPARSE == 2) {
+            // R to the wave's image, four picks, a reduce-scatter over the four lane rows + one row sum: row c holds control
+            // c's trace in all its 16 lanes, and EVERY lane stores it (16 lanes the same 8 bytes: no branch round the store)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                s_M[(4 * r + (lane >> 4)) * 17 + (lane & 15)] = make_double2(R.re[0][0][r], R.im[0][0][r]);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            double q4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double2 mv = s_M[ad4[c]];
+                const double pr = cf4[c].x * mv.x - cf4[c].y * mv.y, pi = cf4[c].x * mv.y + cf4[c].y * mv.x;
+                q4[c] = SAND ? pi : fma(pr, z_keep_i, pi * z_keep_r);
+            }
+            double b1[1] = {swap16_add(swap32_add(q4[0], q4[2]), swap32_add(q4[1], q4[3]))};   // row r keeps control r
+            row_sum_n(b1);
+            out[(size_t)t * 4 + (lane >> 4)] = gs * b1[0];
+            __builtin_amdgcn_s_waitcnt(0xc07f);                    // the image is overwritten by the next slice
+            __builtin_amdgcn_wave_barrier();
+        } else if constexpr (SPARSE == 1) {
             zr = z_keep_r;
             zi = z_keep_i;
             // (the lane number behind an empty asm: the per-lane addresses of the entry lists are recomputed here, a dozen
@@ -684,55 +783,52 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) void chain_tile_split_kernel(con
             int lane_here = lane;
             asm volatile("" : "+v"(lane_here));
             sparse_traces<NT, SAND>(R, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane_here, true, p.sp_nz);
-        } else
-        for (int c0 = 0; c0 < K || c0 == 0; c0 += 4) {
-            double v[2 + 8];
-            v[0] = 0.0;
-            v[1] = 0.0;
-            if (!SAND || t == N - 1)
-                tdot_partial<NT, true>(v[0], v[1], X, L);          // tr(X' L)
+        } else {
+            for (int c0 = 0; c0 < K || c0 == 0; c0 += 4) {
+                double v[2 + 8];
+                v[0] = 0.0;
+                v[1] = 0.0;
+                if (!SAND || t == N - 1)
+                    tdot_partial<NT, true>(v[0], v[1], X, L);      // tr(X' L)
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int c = c0 + cc;
-                v[2 + 2 * cc] = 0.0;
-                v[3 + 2 * cc] = 0.0;
-                if (c < K) {
-                    TMat<NT> BT;
-                    if (bt_lds)
-                        tload(BT, s_bt + (size_t)c * TSZ, lane);
-                    else
-                        tload(BT, opBT + (size_t)c * TSZ, lane);
-                    tdot_partial<NT, false>(v[2 + 2 * cc], v[3 + 2 * cc], BT, R);
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = c0 + cc;
+                    v[2 + 2 * cc] = 0.0;
+                    v[3 + 2 * cc] = 0.0;
+                    if (c < K) {
+                        TMat<NT> BT;
+                        if (bt_lds)
+                            tload(BT, s_bt + (size_t)c * TSZ, lane);
+                        else
+                            tload(BT, opBT + (size_t)c * TSZ, lane);
+                        tdot_partial<NT, false>(v[2 + 2 * cc], v[3 + 2 * cc], BT, R);
+                    }
+                }
+                wave_sum_n(v);
+                zr = v[0];
+                zi = v[1];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = c0 + cc;
+                    const double wr = v[2 + 2 * cc], wi = v[3 + 2 * cc];
+                    const double im = SAND ? wi : fma(wr, zi, wi * zr);
+                    if (c < K && lane == 0)
+                        out[c + (size_t)t * K] = gs * im;
                 }
             }
-            wave_sum_n(v);
-            zr = v[0];
-            zi = v[1];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int c = c0 + cc;
-                const double wr = v[2 + 2 * cc], wi = v[3 + 2 * cc];
-                const double im = SAND ? wi : fma(wr, zi, wi * zr);
-                if (c < K && lane == 0)
-                    out[c + (size_t)t * K] = gs * im;
+            if (t == N - 1) {
+                z_keep_r = zr;
+                z_keep_i = zi;
             }
         }
-        if (t == N - 1 && lane == 0) {
-            if (SAND) {
-                const double inv = 1.0 / (double)p.n;
-                const double ar = zr * inv, ai = zi * inv;
-                out[(size_t)K * N] = 1.0 - (ar * ar + ai * ai);
-            } else {
-                out[(size_t)K * N] = zr * zr - zi * zi;
-            }
-        }
+        ST_MARK(8)
     };
-    auto pull_back = [&]() {                                       // L <- P' L [P]
+    auto pull_back = [&](const TMat<1> &Pt) {                      // L <- P' L [P]
         if (SAND) {
-            tmul_tn<NT, false, true>(Y, L, Pm);                    // (P' L)^T
-            tmul_tn<NT, false, false>(L, Y, Pm);                   // P' L P
+            tmul_tn<NT, false, true>(Y, L, Pt);                    // (P' L)^T
+            tmul_tn<NT, false, false>(L, Y, Pt);                   // P' L P
         } else {
-            tmul_tn<NT, true, false>(Y, Pm, L);                    // P' L
+            tmul_tn<NT, true, false>(Y, Pt, L);                    // P' L
             L = Y;
         }
     };
@@ -748,14 +844,13 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) void chain_tile_split_kernel(con
         __syncthreads();                                           // the images are the waves' own again
 #pragma unroll
         for (int q = PARTS - 1; q >= 1; --q)                       // costate at hi: through every later part
-            if (q > part) {
-                Pm = T[q - 1];
-                pull_back();
-            }
+            if (q > part)
+                pull_back(T[q - 1]);
 #pragma unroll
         for (int q = 1; q < PARTS - 1; ++q)                        // X at lo: through every earlier part but the first
             if (q < part) {
                 TOp<1> VA;
+                TMat<1> X;
                 to_a_layout(VA, T[q - 1], s_img, lane);
                 if (SAND) {
                     tmul_tb<NT, false, false>(Y, Xh, VA);
@@ -767,45 +862,71 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) void chain_tile_split_kernel(con
                 }
             }
     }
-    // (No second register buffer in these loops -- three waves per SIMD leave 168 registers: slice t's state is loaded at the
-    // top of its iteration and arrives under the two products of the pull-back; P_{t-1} goes into Pm as soon as the pull-back
-    // has read P_t, and arrives under the products of the rebuild and the gradient.)
-    if (part >= 1) {
-        if (lo < hi) {
-            // X_lo lives in the workspace slot of V_0 (the identity: never needed) and is re-read from L2 with every slice's
-            // V_j -- sixteen registers less across the gradient's products
-            tstore(Xk + (size_t)lo * TSZ, Xh, lane);
-            TMat<1> V, X0;
-            TOp<1> VA;
-            tload(Pm, Pk + (size_t)(hi - 1) * TSZ, lane);
-            for (int t = hi - 1; t >= lo; --t) {
-                if (!(GRAPE_SPLIT_ABL & 2) || t == hi - 1) tload(V, Xk + (size_t)t * TSZ, lane);
-                tload(X0, Xk + (size_t)lo * TSZ, lane);
-                pull_back();
-                tload(Pm, Pk + (size_t)max(t - 1, lo) * TSZ, lane);   // (clamped at the part's first slice: no branch round a load)
-                if (t > lo) {                                      // X_t = V X_lo [V']
-                    to_a_layout(VA, V, s_img, lane);
-                    if (SAND) {
-                        tmul_tb<NT, false, false>(Y, X0, VA);      // (V X_lo)^T
-                        tmul_tb<NT, false, true>(X, Y, VA);        // (V X_lo) V'
-                    } else {
-                        tmul_an<NT, false, false>(X, VA, X0);
-                    }
+    ST_MARK(3)
+    // Backward loops: rings of RB buffers for P_t and for the stored state (X_t: wave 0; V_j: the others), loads RB - 1
+    // slices ahead; X at lo stays in registers for the rebuilds X_t = V X_lo [V'] (round 4 re-read it with every slice).
+    if (lo < hi) {
+        TMat<1> Pb[RB], Sb[RB];
+        const bool rebuild = part >= 1;
+        auto step = [&](int t, const TMat<1> &Pt, const TMat<1> &St) {
+            pull_back(Pt);
+            ST_DEP(L.im[0][0][3])
+            ST_MARK(4)
+            TMat<1> X;
+            if (rebuild && t > lo) {                               // X_t = V X_lo [V']  (no vector-memory instruction in here)
+                TOp<1> VA;
+                to_a_layout(VA, St, s_img, lane);
+                if (SAND) {
+                    tmul_tb<NT, false, false>(Y, Xh, VA);          // (V X_lo)^T
+                    tmul_tb<NT, false, true>(X, Y, VA);            // (V X_lo) V'
                 } else {
-                    X = X0;
+                    tmul_an<NT, false, false>(X, VA, Xh);
                 }
-                emit(t);
+            } else if (rebuild) {
+                X = Xh;
+            } else {
+                X = St;
+            }
+            ST_DEP(X.im[0][0][3])
+            ST_MARK(5)
+            emit(t, X);
+        };
+        int t = hi - 1;
+        for (const int head_end = hi - 1 - (hi - lo) % RB; t > head_end; --t) {
+            tload(Pb[0], Pk + (size_t)t * TSZ, lane);
+            tload(Sb[0], Xk + (size_t)t * TSZ, lane);
+            step(t, Pb[0], Sb[0]);
+        }
+        if (t >= lo) {
+#pragma unroll
+            for (int i = 0; i < RB - 1; ++i) {
+                tload(Pb[i], Pk + (size_t)max(t - i, lo) * TSZ, lane);
+                tload(Sb[i], Xk + (size_t)max(t - i, lo) * TSZ, lane);
+            }
+            for (; t >= lo; t -= RB) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    tload(Pb[(i + RB - 1) % RB], Pk + (size_t)max(t - i - (RB - 1), lo) * TSZ, lane);   // (clamped: re-reads the first slice)
+                    if (!(GRAPE_SPLIT_ABL & 2)) tload(Sb[(i + RB - 1) % RB], Xk + (size_t)max(t - i - (RB - 1), lo) * TSZ, lane);
+                    step(t - i, Pb[i], Sb[i]);
+                }
             }
         }
-    } else {
-        if (hi > 0)
-            tload(Pm, Pk + (size_t)(hi - 1) * TSZ, lane);
-        for (int t = hi - 1; t >= 0; --t) {
-            if (!(GRAPE_SPLIT_ABL & 2) || t == hi - 1) tload(X, Xk + (size_t)t * TSZ, lane);
-            pull_back();
-            tload(Pm, Pk + (size_t)max(t - 1, 0) * TSZ, lane);
-            emit(t);
+        if (hi == N && lane == 0) {                                // the figure of merit: tr(X' L) at t = N - 1
+            const double zr = z_keep_r, zi = z_keep_i;
+            if (SAND) {
+                const double inv = 1.0 / (double)p.n;
+                const double ar = zr * inv, ai = zi * inv;
+                out[(size_t)K * N] = 1.0 - (ar * ar + ai * ai);
+            } else {
+                out[(size_t)K * N] = zr * zr - zi * zi;
+            }
         }
+#ifdef GRAPE_SPLIT_STAMP
+        if (lane == 0)
+            for (int i = 0; i < 10; ++i)
+                out[(size_t)K * lo + i] = (double)st_acc[i];
+#endif
     }
 }
 
@@ -1456,6 +1577,11 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         if (p.N < 2 * parts) parts = 2;
         // part 0 costs c0 products per slice, every other part c1: n0 c0 = n_q c1
         int n0 = (int)(((long long)p.N * c1 + (c1 + (parts - 1) * c0) / 2) / (c1 + (parts - 1) * c0));
+        // ... measured (round 5, after the loads of both passes went into register rings): pass 1 is bound by HBM (its X_t / V_j
+        // stores), not by products, and the later parts' pass 2 (rebuild: conversion + 2 products on top) weighs more than its
+        // count -- Hermitian sandwich, two parts: 5.61 / 5.44 / 5.41 / 5.62 ms per C4dense evaluation at 545 / 600 / 650 / 720 permille
+        if (parts == 2 && sandwich && p.herm_states)
+            n0 = (int)((long long)p.N * 650 / 1000);
         if (const char *sp = std::getenv("GRAPE_TILE_SPLIT_PERMILLE"))
             n0 = (int)((long long)p.N * std::atoi(sp) / 1000);
         if (n0 < 1) n0 = 1;
@@ -1470,25 +1596,25 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         q.bt_in_lds = img_b + bt_b <= 40 * 1024 ? 1 : 0;           // 4 workgroups per CU must still fit
         const size_t lds2 = img_b + (q.bt_in_lds ? bt_b : 0);
         const dim3 blk(64 * parts);
+        const int hm = !sandwich || !p.herm_states ? 0 : (p.herm_ctrl ? 2 : 1);      // (see HERM at the kernel)
+        const bool lists4 = p.sparse && p.K == 4 && p.sp_nz == 64 && !std::getenv("GRAPE_SPLIT_LISTS_LDS");   // SPARSE = 2
+#define GRAPE_SPLIT_GO(SP, PT, LDS)                                                                              \
+    {                                                                                                            \
+        if (!sandwich)    GRAPE_LAUNCH((chain_tile_split_kernel<0, SP, PT, 0>), grid, blk, LDS, stream, q);      \
+        else if (hm == 2) GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, PT, 2>), grid, blk, LDS, stream, q);      \
+        else if (hm == 1) GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, PT, 1>), grid, blk, LDS, stream, q);      \
+        else              GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, PT, 0>), grid, blk, LDS, stream, q);      \
+    }
         if (p.sparse) {
             const size_t lds_sp = img_b + sizeof(double2) * ((size_t)p.K * p.sp_nz + (size_t)parts * 16 * 17) +
                                   sizeof(int32_t) * (size_t)p.K * p.sp_nz;
-            if (parts == 3) {
-                if (sandwich) GRAPE_LAUNCH((chain_tile_split_kernel<1, true, 3>), grid, blk, lds_sp, stream, q);
-                else          GRAPE_LAUNCH((chain_tile_split_kernel<0, true, 3>), grid, blk, lds_sp, stream, q);
-            } else {
-                if (sandwich) GRAPE_LAUNCH((chain_tile_split_kernel<1, true, 2>), grid, blk, lds_sp, stream, q);
-                else          GRAPE_LAUNCH((chain_tile_split_kernel<0, true, 2>), grid, blk, lds_sp, stream, q);
-            }
+            if (parts == 3) GRAPE_SPLIT_GO(1, 3, lds_sp)
+            else if (lists4) GRAPE_SPLIT_GO(2, 2, lds_sp)
+            else GRAPE_SPLIT_GO(1, 2, lds_sp)
             return hipGetLastError();
         }
-        if (parts == 3) {
-            if (sandwich) GRAPE_LAUNCH((chain_tile_split_kernel<1, false, 3>), grid, blk, lds2, stream, q);
-            else          GRAPE_LAUNCH((chain_tile_split_kernel<0, false, 3>), grid, blk, lds2, stream, q);
-        } else {
-            if (sandwich) GRAPE_LAUNCH((chain_tile_split_kernel<1, false, 2>), grid, blk, lds2, stream, q);
-            else          GRAPE_LAUNCH((chain_tile_split_kernel<0, false, 2>), grid, blk, lds2, stream, q);
-        }
+        if (parts == 3) GRAPE_SPLIT_GO(0, 3, lds2) else GRAPE_SPLIT_GO(0, 2, lds2)
+#undef GRAPE_SPLIT_GO
         return hipGetLastError();
     }
     // unitary flow, small ensembles: the time axis in chunks (chunk_product_kernel / chunk_scan_kernel above), grid.z = chunk
