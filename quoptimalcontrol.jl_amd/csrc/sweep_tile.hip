@@ -536,45 +536,40 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Two wavefronts per member, each owning one PART OF THE TIME AXIS (n <= 16, general flow, ensembles too small
-// to put two members on every SIMD -- C4).  v_mfma_f64_16x16x4 issues every ~150 cycles from one wave per
-// SIMD and every ~105 when two waves share it.  (Round 1 bought the second wave by splitting every product's
-// real / imaginary part over two waves, at a barrier + LDS swap per product: 10.1 ms per C4 evaluation against
-// 6.9 ms for this kernel; removed.)  Here the two waves run INDEPENDENT product chains and meet once:
-//   wave 0 (slices [0, Nh)):  pass 1  forward sweep, X_t stored                      (2 products / slice, UG 1)
-//                             pass 2  L_Nh = T1' Xt T1, then the reference's backward sweep + gradient
-//   wave 1 (slices [Nh, N)):  pass 1  prefix products V_j = P_{Nh+j-1} ... P_Nh stored (1 product / slice)
-//                             pass 2  backward sweep from Xt, X_t = V_j X_Nh V_j' rebuilt on the fly
-//   exchange (LDS, one workgroup barrier): wave 0 -> X_Nh, wave 1 -> T1 = P_{N-1} ... P_Nh.
-// Nh balances the two waves' product counts.  When Xi, Xt are Hermitian (checked on the host; density
-// operators), X_t and L_t stay Hermitian under P X P' / P' L P, so [X, L'] = Y - Y' with Y = X L': the
-// second commutator product becomes one layout conversion (to_a_layout of Y IS the D layout of Y^T).
-// Round 4: every prefetch load is issued unconditionally with a CLAMPED slice index.  Behind `if (t + 1 < N) load` the
-// compiler's s_waitcnt pass must cover the path that issued nothing: at the join it waited for `vmcnt(7) .. vmcnt(0)` -- i.e.
-// for the prefetch it had just issued -- before the first product of every slice (wait_any 0.46 of the wave cycles in
-// profiles/r04_C4dense_E1024_pmc.json): the prefetch prefetched nothing.
-// Round 4: PARTS wavefronts per member (2, or 3 behind GRAPE_TILE_PARTS=3: measured slower, see the launcher; parts
-// 1 .. PARTS-1 all play the second wave's role, each over its own range [part_lo[q], part_lo[q + 1]) of the time axis).
-// The exchange goes through the waves' own
-// LDS images (nobody converts a layout between the two workgroup barriers around it):
-//   wave 0 -> X at part_lo[1];  wave q >= 1 -> T_q = the product of its part's propagators;
-//   wave q >= 1 then rebuilds X at part_lo[q] = T_{q-1} .. T_1 X [T_1' .. T_{q-1}'] and, every wave, the costate at the
-//   end of its part = T_{q+1}' .. T_{PARTS-1}' Xt [T_{PARTS-1} .. T_{q+1}]  -- at most 2 (PARTS - 2) + 2 (PARTS - 1) products.
+// Two wavefronts per member that MEET IN THE MIDDLE of the time axis (n <= 16, general flow, ensembles too small to put two
+// members on every SIMD -- C4 with full-rank states).  The costate chain L_t = P_t' L_{t+1} [P_t] needs no forward state, so
+// it can start at t = N while the forward chain starts at t = 0:
+//   phase 1   wave 0: t = 0 .. Nh-1      X_t stored, X_{t+1} = P_t X_t [P_t']                       (2 products / slice, UG 1)
+//             wave 1: t = N-1 .. Nh      L_t = P_t' L_{t+1} [P_t], L_t stored                       (2 products / slice, UG 1)
+//   (one workgroup barrier: the stored states are visible; nothing is exchanged -- each wave keeps its own chain)
+//   phase 2   wave 0: t = Nh .. N-1      L_t loaded, gradient from (X_t, L_t), X_{t+1} = P_t X_t [P_t']
+//             wave 1: t = Nh-1 .. 0      X_t loaded, L_t = P_t' L_{t+1} [P_t], gradient from (X_t, L_t)
+// -- the reference's general flow (src/GRAPE.jl:216-287) product for product: 5 per slice (UG 3), the same for both waves, so
+// Nh = N / 2.  (Rounds 2-4 split the axis differently: the second wave stored prefix products V_j of its part and rebuilt
+// X_t = V_j X_Nh V_j' -- 5.45 products per slice, an exchange of two matrices, a third wave measured slower; round 1 split
+// every product's real / imaginary part over two waves at a barrier + LDS swap per product: 10.1 ms per C4dense evaluation.)
+// When Xi, Xt are Hermitian (checked on the host; density operators), X_t and L_t stay Hermitian under P X P' / P' L P:
+//   * the A-operand image of X is the D layout of X^T = conj(X) and L' = L is a right operand as it stands: the product
+//     Y = X L takes both from the registers they are in (no LDS layout conversion);
+//   * [X, L'] = Y - Y', one conversion (to_a_layout of Y IS the D layout of Y^T) instead of a second product -- and with
+//     Hermitian control operators tr(B Y') = conj(tr(B Y)), i.e. Im tr(B [X, L]) = 2 Im tr(B Y): Y' is never formed.
+// HERM / SPARSE are template arguments, and no vector-memory instruction of the slice loops sits behind a branch: at the join
+// the compiler's s_waitcnt pass has to assume the path that issued nothing, i.e. it waits for the YOUNGEST load in flight --
+// the prefetch it has just issued (round 4 found this for `if (t + 1 < N) load`; round 5 for the `if (lane == 0) store` of
+// the gradient entries and the figure of merit, and for run-time `herm` branches).  Every load is issued RG - 1 (RB - 1)
+// slices ahead of its use into a ring of register buffers; the loops are unrolled by the ring size (a buffer is a fixed set
+// of registers; `Pm = Pn` at the end of an iteration is a wait for the load issued one product earlier).  The waves' own
+// cycle counts (tools/split_stamps.py, profiles/r05_split_stamps.txt) before / after: 23-29 % of a wave's cycles waiting
+// for P_t in pass 1, 3.7 k cycles per slice in the generic list traces.  What is left: phase 1 is bound by HBM (8 KB per
+// slice and wave, half of it stores).
 #ifndef GRAPE_SPLIT_ABL
 #define GRAPE_SPLIT_ABL 0
 #endif
-#ifndef GRAPE_SPLIT_EU
-#define GRAPE_SPLIT_EU
-#endif
-template <int SAND, int SPARSE = 0, int PARTS = 2, int HERM = 0>
-__global__ __launch_bounds__(64 * PARTS, PARTS) GRAPE_SPLIT_EU void chain_tile_split_kernel(const TileParams p)
+template <int SAND, int SPARSE = 0, int HERM = 0>
+__global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TileParams p)
 {
-    constexpr int NT = 1, TSZ = 256;
+    constexpr int NT = 1, TSZ = 256, PARTS = 2;
     extern __shared__ double2 s_dynt[];
-#ifdef GRAPE_SPLIT_PAD
-    if constexpr (PARTS == 2)
-        asm volatile("" ::: "v175");
-#endif
 #ifdef GRAPE_SPLIT_STAMP            // diagnostic build (tools/split_stamps.py): cycles between points of the slice loops, summed per wave
     long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
 #define ST_BEGIN() st_last = __builtin_readcyclecounter()
@@ -600,25 +595,18 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) GRAPE_SPLIT_EU void chain_tile_s
 #endif
     const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double2 *s_img = s_dynt + (size_t)part * (kTileImage + 1);
-    auto xch = [&](int q) { return s_dynt + (size_t)q * (kTileImage + 1); };   // wave q's image, lent for the exchange
     double2 *s_bt = s_dynt + (size_t)PARTS * (kTileImage + 1);     // SPARSE: coefficients | one image of R per wave | positions
     double2 *s_coef = s_bt;
     double2 *s_M = s_coef + (size_t)p.K * p.sp_nz + (size_t)part * (16 * 17);
     int *s_addr = reinterpret_cast<int *>(s_coef + (size_t)p.K * p.sp_nz + PARTS * (16 * 17));
     const int k = blockIdx.x;
     const int K = p.K, N = p.N;
-    const int lo = p.part_lo[part], hi = p.part_lo[part + 1];      // this wave's slices
+    const int Nh = p.split_at;                                     // wave 0 stores X_t for t < Nh, wave 1 stores L_t for t >= Nh
     const double2 *__restrict__ ops = p.ops + (size_t)k * (2 * K + 3) * TSZ;
     const double2 *__restrict__ opBT = ops + (size_t)(1 + K) * TSZ;
     const bool bt_lds = p.bt_in_lds != 0;
-#ifndef GRAPE_SPLIT_VAR
-#define GRAPE_SPLIT_VAR 0
-#endif
-    // HERM (sandwich): 1 = Hermitian Xi, Xt (density operators), 2 = ... and Hermitian control operators -- template
-    // arguments, not flags: a branch inside the slice loops makes the compiler wait for the prefetched loads at its join
     constexpr bool herm = SAND && HERM >= 1;
-    constexpr bool herm2 = SAND && HERM == 2 && !(GRAPE_SPLIT_VAR & 1);
-    constexpr bool hermx = herm && !(GRAPE_SPLIT_VAR & 2);
+    constexpr bool herm2 = SAND && HERM == 2;
     if (SPARSE) {
         stage_sparse_lists<NT>(p, k, (int)threadIdx.x, 64 * PARTS, s_coef, s_addr);
     } else if (bt_lds) {
@@ -627,76 +615,80 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) GRAPE_SPLIT_EU void chain_tile_s
     }
     const size_t kw = (size_t)blockIdx.y * p.E + k;                // workspace row: (control array, member)
     const double2 *__restrict__ Pk = p.props + kw * N * TSZ;
-    double2 *__restrict__ Xk = p.states + kw * N * TSZ;
+    double2 *__restrict__ Sk = p.states + kw * N * TSZ;            // slot t: X_t (t < Nh) or L_t (t >= Nh)
     double *__restrict__ out = p.member_out + kw * ((size_t)K * N + 1);
+    constexpr int RG = 4, RB = 3;                                  // ring sizes of phase 1 / phase 2 (which keeps more matrices live)
+    const bool fwd = part == 0;
 
-    // ------------------------------------------------------------ pass 1
-    // Every load of the slice loops is issued RG - 1 slices ahead of its use into a ring of RG register buffers (the loops are
-    // unrolled RG times: a buffer is a fixed set of registers).  tools/split_stamps.py (the waves' own cycle counts) showed
-    // the round-4 loops -- one slice ahead, `Pm = Pn` at the end of an iteration, i.e. a wait for the load issued one product
-    // earlier -- spending 23-29 % of their cycles waiting for P_t to arrive (HBM answers in ~5 k cycles under this load, a
-    // slice of pass 1 computes for ~2.3 k).  No vector-memory instruction of these loops sits behind a branch: at the join
-    // the compiler's s_waitcnt pass has to assume the path that issued nothing and waits for the YOUNGEST load.  The first
-    // (count mod RG) slices of a range run one at a time (load, wait, use).
-    constexpr int RG = PARTS == 2 ? 4 : 2;                         // pass 1;  pass 2 keeps more matrices live
-    constexpr int RB = PARTS == 2 ? 3 : 2;
-    TMat<1> keep;                                                  // what this wave hands over: X at hi (wave 0), T_part (others)
-    {
-        TMat<1> X, Y, Pb[RG];
+    TMat<1> C, Y;                                                  // this wave's chain: X (wave 0) / L (wave 1)
+    tload(C, ops + (size_t)(fwd ? 1 + 2 * K : 2 + 2 * K) * TSZ, lane);      // Xi / Xt
+    auto push = [&](const TMat<1> &Pt) {                           // X <- P X [P']
         TOp<1> PA;
-        if (part == 0) {
-            tload(X, ops + (size_t)(1 + 2 * K) * TSZ, lane);       // Xi
+        to_a_layout(PA, Pt, s_img, lane);
+        if (SAND) {
+            tmul_tb<NT, false, false>(Y, C, PA);                   // (P X)^T
+            tmul_tb<NT, false, true>(C, Y, PA);                    // (P X) P'
         } else {
-            tzero(X);                                              // V_0 = 1 (X plays V: prefix products of this part's propagators)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * r + (lane >> 4) == (lane & 15))
-                    X.re[0][0][r] = 1.0;
+            tmul_an<NT, false, false>(Y, PA, C);
+            C = Y;
         }
-        const bool first = part == 0;
+    };
+    auto pull = [&](const TMat<1> &Pt) {                           // L <- P' L [P]
+        if (SAND) {
+            tmul_tn<NT, false, true>(Y, C, Pt);                    // (P' L)^T
+            tmul_tn<NT, false, false>(C, Y, Pt);                   // P' L P
+        } else {
+            tmul_tn<NT, true, false>(Y, Pt, C);                    // P' L
+            C = Y;
+        }
+    };
+    // slices a, a + d, ..., (cnt of them; d = +1 / -1) through rings: body(t, P_t [, S_t]) with every load R - 1 slices ahead
+    const int d = fwd ? 1 : -1;
+
+    // ------------------------------------------------------------ phase 1
+    {
+        TMat<1> Pb[RG];
+        const int a = fwd ? 0 : N - 1, cnt = fwd ? Nh : N - Nh, last = a + d * (cnt - 1);
+        auto clampt = [&](int t) { return fwd ? min(t, last) : max(t, last); };
         auto step = [&](int t, const TMat<1> &Pt) {
-            if (!(GRAPE_SPLIT_ABL & 1)) tstore(Xk + (size_t)t * TSZ, X, lane);   // X_t (wave 0) / V_{t-lo}: X_t = V X_lo V'
-            ST_MARK(9)
-            to_a_layout(PA, Pt, s_img, lane);
-            ST_DEP(PA.im[0][0][3])
-            ST_MARK(0)
-            if (SAND && first) {
-                tmul_tb<NT, false, false>(Y, X, PA);               // (P X)^T
-                tmul_tb<NT, false, true>(X, Y, PA);                // (P X) P'
+            if (fwd) {
+                if (!(GRAPE_SPLIT_ABL & 1)) tstore(Sk + (size_t)t * TSZ, C, lane);      // X_t
+                ST_MARK(9)
+                push(Pt);
             } else {
-                tmul_an<NT, false, false>(Y, PA, X);               // P X  /  P V
-                X = Y;
+                pull(Pt);
+                ST_DEP(C.im[0][0][3])
+                ST_MARK(9)
+                if (!(GRAPE_SPLIT_ABL & 1)) tstore(Sk + (size_t)t * TSZ, C, lane);      // L_t
             }
-            ST_DEP(X.im[0][0][3])
+            ST_DEP(C.im[0][0][3])
             ST_MARK(1)
         };
-        int t = lo;
+        int t = a, left = cnt;
         ST_BEGIN();
-        for (const int head_end = lo + (hi - lo) % RG; t < head_end; ++t) {
+        for (; left % RG; --left, t += d) {                        // the first (cnt mod RG) slices one at a time
             tload(Pb[0], Pk + (size_t)t * TSZ, lane);
             step(t, Pb[0]);
         }
-        if (t < hi) {
+        if (left > 0) {
 #pragma unroll
             for (int i = 0; i < RG - 1; ++i)
-                tload(Pb[i], Pk + (size_t)min(t + i, hi - 1) * TSZ, lane);
-            for (; t < hi; t += RG) {
+                tload(Pb[i], Pk + (size_t)clampt(t + d * i) * TSZ, lane);
+            for (; left > 0; left -= RG, t += d * RG) {
 #pragma unroll
                 for (int i = 0; i < RG; ++i) {
-                    tload(Pb[(i + RG - 1) % RG], Pk + (size_t)min(t + i + RG - 1, hi - 1) * TSZ, lane);   // (clamped: re-reads the last slice)
-                    step(t + i, Pb[i]);
+                    tload(Pb[(i + RG - 1) % RG], Pk + (size_t)clampt(t + d * (i + RG - 1)) * TSZ, lane);   // (clamped: re-reads the last slice)
+                    step(t + d * i, Pb[i]);
                 }
             }
         }
-        keep = X;
     }
-    tstore(s_img, keep, lane);                                     // (its own image: this wave's conversions are behind it)
-    __syncthreads();
-    ST_MARK(2)                                                     // waiting for the other wave's pass 1
+    __syncthreads();                                               // the other wave's stored states are complete (and visible: one CU)
+    ST_MARK(2)
 
-    // ------------------------------------------------------------ pass 2: backward sweep + gradient
+    // ------------------------------------------------------------ phase 2: the rest of the chain + gradient
     const double gs = SAND ? (herm2 ? -2.0 * p.dt : -p.dt) : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
-    TMat<1> L, Y, R;
+    TMat<1> R;
     bool z_known = false;
     double z_keep_r = 0.0, z_keep_i = 0.0;
     // SPARSE == 2 (K = 4 lists of 64 entries: C4's shape): a lane keeps its four list entries in registers
@@ -710,7 +702,7 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) GRAPE_SPLIT_EU void chain_tile_s
         }
     }
     // gradient entries of one slice from X_t, L_t (costate after pulling back through slice t)
-    auto emit = [&](int t, const TMat<1> &X) {
+    auto emit = [&](int t, const TMat<1> &X, const TMat<1> &L) {
         if (SPARSE && !z_known) {
             // tr(X_t' L_t) is the same for every t (also for non-unitary P): taken at the first slice this wave emits
             double zz[2];
@@ -720,9 +712,7 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) GRAPE_SPLIT_EU void chain_tile_s
             z_keep_i = zz[1];
             z_known = true;
         }
-        if constexpr (hermx) {
-            // Hermitian X_t, L_t (to rounding, as Y - Y' below already takes them): the A-operand image of X is the D layout of
-            // X^T = conj(X), and L' = L is a right operand as it stands -- no layout conversion for this product
+        if constexpr (herm) {
             tprod<NT, true, false>(
                 R, [&](int, int, int kb, double &r, double &i) { r = X.re[0][0][kb]; i = X.im[0][0][kb]; },
                 [&](int, int, int kb, double &r, double &i) { r = L.re[0][0][kb]; i = L.im[0][0][kb]; });        // X L
@@ -738,7 +728,7 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) GRAPE_SPLIT_EU void chain_tile_s
         ST_MARK(6)
         if constexpr (SAND) {
             if constexpr (herm2) {
-                // ... and Hermitian control operators: tr(B Y') = conj(tr(B Y)), so Im tr(B [X, L]) = 2 Im tr(B Y) -- Y' is never formed
+                // (Hermitian states and controls: 2 Im tr(B Y), see above)
             } else if constexpr (herm) {                           // [X, L'] = Y - Y',  Y' = conj(Y^T)
                 TOp<1> RT;
                 to_a_layout(RT, R, s_img, lane);                   // D layout of Y^T
@@ -754,7 +744,6 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) GRAPE_SPLIT_EU void chain_tile_s
             }
         }
         ST_MARK(7)
-        double zr = 0.0, zi = 0.0;
         if constexpr (SPARSE == 2) {
             // R to the wave's image, four picks, a reduce-scatter over the four lane rows + one row sum: row c holds control
             // c's trace in all its 16 lanes, and EVERY lane stores it (16 lanes the same 8 bytes: no branch round the store)
@@ -776,13 +765,11 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) GRAPE_SPLIT_EU void chain_tile_s
             __builtin_amdgcn_s_waitcnt(0xc07f);                    // the image is overwritten by the next slice
             __builtin_amdgcn_wave_barrier();
         } else if constexpr (SPARSE == 1) {
-            zr = z_keep_r;
-            zi = z_keep_i;
             // (the lane number behind an empty asm: the per-lane addresses of the entry lists are recomputed here, a dozen
-            // vector instructions, instead of being hoisted out of the slice loop and spilled to scratch at 168 registers)
+            // vector instructions, instead of being hoisted out of the slice loop)
             int lane_here = lane;
             asm volatile("" : "+v"(lane_here));
-            sparse_traces<NT, SAND>(R, s_M, s_coef, s_addr, K, zr, zi, gs, out + (size_t)t * K, lane_here, true, p.sp_nz);
+            sparse_traces<NT, SAND>(R, s_M, s_coef, s_addr, K, z_keep_r, z_keep_i, gs, out + (size_t)t * K, lane_here, true, p.sp_nz);
         } else {
             for (int c0 = 0; c0 < K || c0 == 0; c0 += 4) {
                 double v[2 + 8];
@@ -805,114 +792,65 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) GRAPE_SPLIT_EU void chain_tile_s
                     }
                 }
                 wave_sum_n(v);
-                zr = v[0];
-                zi = v[1];
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
                     const int c = c0 + cc;
                     const double wr = v[2 + 2 * cc], wi = v[3 + 2 * cc];
-                    const double im = SAND ? wi : fma(wr, zi, wi * zr);
+                    const double im = SAND ? wi : fma(wr, v[1], wi * v[0]);
                     if (c < K && lane == 0)
                         out[c + (size_t)t * K] = gs * im;
                 }
-            }
-            if (t == N - 1) {
-                z_keep_r = zr;
-                z_keep_i = zi;
+                if (t == N - 1) {
+                    z_keep_r = v[0];
+                    z_keep_i = v[1];
+                }
             }
         }
         ST_MARK(8)
     };
-    auto pull_back = [&](const TMat<1> &Pt) {                      // L <- P' L [P]
-        if (SAND) {
-            tmul_tn<NT, false, true>(Y, L, Pt);                    // (P' L)^T
-            tmul_tn<NT, false, false>(L, Y, Pt);                   // P' L P
-        } else {
-            tmul_tn<NT, true, false>(Y, Pt, L);                    // P' L
-            L = Y;
-        }
-    };
-    // ---- the exchange: every operand is copied out of the lent images BEFORE the barrier that gives them back
-    TMat<1> Xh;                                                    // parts >= 1: X at lo
     {
-        TMat<1> T[PARTS > 1 ? PARTS - 1 : 1];                      // T_1 .. T_{PARTS-1}
-        tload(Xh, xch(0), lane);
-#pragma unroll
-        for (int q = 1; q < PARTS; ++q)
-            tload(T[q - 1], xch(q), lane);
-        tload(L, ops + (size_t)(2 + 2 * K) * TSZ, lane);           // Xt
-        __syncthreads();                                           // the images are the waves' own again
-#pragma unroll
-        for (int q = PARTS - 1; q >= 1; --q)                       // costate at hi: through every later part
-            if (q > part)
-                pull_back(T[q - 1]);
-#pragma unroll
-        for (int q = 1; q < PARTS - 1; ++q)                        // X at lo: through every earlier part but the first
-            if (q < part) {
-                TOp<1> VA;
-                TMat<1> X;
-                to_a_layout(VA, T[q - 1], s_img, lane);
-                if (SAND) {
-                    tmul_tb<NT, false, false>(Y, Xh, VA);
-                    tmul_tb<NT, false, true>(X, Y, VA);
-                    Xh = X;
-                } else {
-                    tmul_an<NT, false, false>(X, VA, Xh);
-                    Xh = X;
-                }
-            }
-    }
-    ST_MARK(3)
-    // Backward loops: rings of RB buffers for P_t and for the stored state (X_t: wave 0; V_j: the others), loads RB - 1
-    // slices ahead; X at lo stays in registers for the rebuilds X_t = V X_lo [V'] (round 4 re-read it with every slice).
-    if (lo < hi) {
         TMat<1> Pb[RB], Sb[RB];
-        const bool rebuild = part >= 1;
+        const int a = fwd ? Nh : Nh - 1, cnt = fwd ? N - Nh : Nh, last = a + d * (cnt - 1);
+        auto clampt = [&](int t) { return fwd ? min(t, last) : max(t, last); };
         auto step = [&](int t, const TMat<1> &Pt, const TMat<1> &St) {
-            pull_back(Pt);
-            ST_DEP(L.im[0][0][3])
-            ST_MARK(4)
-            TMat<1> X;
-            if (rebuild && t > lo) {                               // X_t = V X_lo [V']  (no vector-memory instruction in here)
-                TOp<1> VA;
-                to_a_layout(VA, St, s_img, lane);
-                if (SAND) {
-                    tmul_tb<NT, false, false>(Y, Xh, VA);          // (V X_lo)^T
-                    tmul_tb<NT, false, true>(X, Y, VA);            // (V X_lo) V'
-                } else {
-                    tmul_an<NT, false, false>(X, VA, Xh);
-                }
-            } else if (rebuild) {
-                X = Xh;
+            if (fwd) {
+                ST_DEP(St.im[0][0][3])
+                ST_MARK(5)
+                emit(t, C, St);                                    // (X_t, L_t)
+                push(Pt);                                          // X_{t+1}  (the one past N - 1 is not used)
+                ST_DEP(C.im[0][0][3])
+                ST_MARK(4)
             } else {
-                X = St;
+                pull(Pt);                                          // L_t
+                ST_DEP(C.im[0][0][3])
+                ST_MARK(4)
+                ST_DEP(St.im[0][0][3])
+                ST_MARK(5)
+                emit(t, St, C);
             }
-            ST_DEP(X.im[0][0][3])
-            ST_MARK(5)
-            emit(t, X);
         };
-        int t = hi - 1;
-        for (const int head_end = hi - 1 - (hi - lo) % RB; t > head_end; --t) {
+        int t = a, left = cnt;
+        for (; left % RB; --left, t += d) {
             tload(Pb[0], Pk + (size_t)t * TSZ, lane);
-            tload(Sb[0], Xk + (size_t)t * TSZ, lane);
+            tload(Sb[0], Sk + (size_t)t * TSZ, lane);
             step(t, Pb[0], Sb[0]);
         }
-        if (t >= lo) {
+        if (left > 0) {
 #pragma unroll
             for (int i = 0; i < RB - 1; ++i) {
-                tload(Pb[i], Pk + (size_t)max(t - i, lo) * TSZ, lane);
-                tload(Sb[i], Xk + (size_t)max(t - i, lo) * TSZ, lane);
+                tload(Pb[i], Pk + (size_t)clampt(t + d * i) * TSZ, lane);
+                tload(Sb[i], Sk + (size_t)clampt(t + d * i) * TSZ, lane);
             }
-            for (; t >= lo; t -= RB) {
+            for (; left > 0; left -= RB, t += d * RB) {
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
-                    tload(Pb[(i + RB - 1) % RB], Pk + (size_t)max(t - i - (RB - 1), lo) * TSZ, lane);   // (clamped: re-reads the first slice)
-                    if (!(GRAPE_SPLIT_ABL & 2)) tload(Sb[(i + RB - 1) % RB], Xk + (size_t)max(t - i - (RB - 1), lo) * TSZ, lane);
-                    step(t - i, Pb[i], Sb[i]);
+                    tload(Pb[(i + RB - 1) % RB], Pk + (size_t)clampt(t + d * (i + RB - 1)) * TSZ, lane);
+                    if (!(GRAPE_SPLIT_ABL & 2)) tload(Sb[(i + RB - 1) % RB], Sk + (size_t)clampt(t + d * (i + RB - 1)) * TSZ, lane);
+                    step(t + d * i, Pb[i], Sb[i]);
                 }
             }
         }
-        if (hi == N && lane == 0) {                                // the figure of merit: tr(X' L) at t = N - 1
+        if (fwd && cnt > 0 && lane == 0) {                         // the figure of merit: tr(X' L) (wave 0 ends at t = N - 1)
             const double zr = z_keep_r, zi = z_keep_i;
             if (SAND) {
                 const double inv = 1.0 / (double)p.n;
@@ -925,7 +863,7 @@ __global__ __launch_bounds__(64 * PARTS, PARTS) GRAPE_SPLIT_EU void chain_tile_s
 #ifdef GRAPE_SPLIT_STAMP
         if (lane == 0)
             for (int i = 0; i < 10; ++i)
-                out[(size_t)K * lo + i] = (double)st_acc[i];
+                out[(size_t)K * (fwd ? Nh : 0) + i] = (double)st_acc[i];     // (rows of this wave's own slices)
 #endif
     }
 }
@@ -1461,7 +1399,11 @@ static bool tile_chain_env(const char *what)                       // GRAPE_TILE
 // holds X_t only for the first part of the time axis and prefix products for the rest)
 bool tile_chain_is_split(const TileParams &p, bool keepl)
 {
-    return tile_count(p.n) == 1 && !p.pack2 && !keepl && !p.unitary && !p.thin && (p.E_plan ? p.E_plan : p.E) < 2048 && p.N >= 4 &&
+    // (any ensemble size: past 1024 members the workgroups queue for the 2 x 1024 wave slots, and the two-wave kernel is still
+    // ahead of one wave per member -- C4dense-shaped, E = 2048 / 4096: 10.3 / 19.6 ms against 11.2 / 22.3; GRAPE_SPLIT_MAX_E
+    // restores a limit for comparisons)
+    static const long e_max = std::getenv("GRAPE_SPLIT_MAX_E") ? std::atol(std::getenv("GRAPE_SPLIT_MAX_E")) : (1L << 40);
+    return tile_count(p.n) == 1 && !p.pack2 && !keepl && !p.unitary && !p.thin && (p.E_plan ? p.E_plan : p.E) < e_max && p.N >= 4 &&
            p.tp_chunks < 2 && !tile_chain_env("1w");
 }
 
@@ -1564,33 +1506,15 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
     const dim3 grid(p.E, p.n_x), block(64);                        // y: control array of a batched evaluation
     const bool pk = (NT == 1) && p.pack2;
     if (tile_chain_is_split(p, keepl)) {
-        // one member per wave would leave every SIMD with a single wave: two waves per member, each owning a
-        // part of the time axis, split so that their product counts balance (see chain_tile_split_kernel)
-        const int c0 = sandwich ? (p.herm_states ? 5 : 6) : 3, c1 = c0 + 1;
-        // Two waves per member.  Three (GRAPE_TILE_PARTS=3: 168 registers, no spills in the slice loops, 4 workgroups and
-        // 3/3/3/3 waves per SIMD resident on every CU -- tools/ubench/wave_placement) are SLOWER at C4dense: 5.19 ms against
-        // 4.46 ms, matrix pipe busy 35 % against 40 %, +13 % memory reads (profiles/r04_C4dense_parts.txt).  Kept for
-        // the tests and for the next look at what the waves of this kernel wait for.
-        int parts = 2;
-        if (const char *sp = std::getenv("GRAPE_TILE_PARTS"))
-            parts = std::atoi(sp) == 3 ? 3 : 2;
-        if (p.N < 2 * parts) parts = 2;
-        // part 0 costs c0 products per slice, every other part c1: n0 c0 = n_q c1
-        int n0 = (int)(((long long)p.N * c1 + (c1 + (parts - 1) * c0) / 2) / (c1 + (parts - 1) * c0));
-        // ... measured (round 5, after the loads of both passes went into register rings): pass 1 is bound by HBM (its X_t / V_j
-        // stores), not by products, and the later parts' pass 2 (rebuild: conversion + 2 products on top) weighs more than its
-        // count -- Hermitian sandwich, two parts: 5.61 / 5.44 / 5.41 / 5.62 ms per C4dense evaluation at 545 / 600 / 650 / 720 permille
-        if (parts == 2 && sandwich && p.herm_states)
-            n0 = (int)((long long)p.N * 650 / 1000);
+        // one member per wave would leave every SIMD with a single wave: two waves per member that meet in the middle of the
+        // time axis (see chain_tile_split_kernel; both waves do the same work per slice, so the middle is N / 2)
+        int n0 = p.N / 2;
         if (const char *sp = std::getenv("GRAPE_TILE_SPLIT_PERMILLE"))
             n0 = (int)((long long)p.N * std::atoi(sp) / 1000);
-        if (n0 < 1) n0 = 1;
-        if (n0 > p.N - (parts - 1)) n0 = p.N - (parts - 1);
-        q.part_lo[0] = 0;
-        q.part_lo[1] = n0;
-        for (int i = 2; i <= parts; ++i)                           // the rest in equal shares
-            q.part_lo[i] = n0 + (int)((long long)(p.N - n0) * (i - 1) / (parts - 1));
+        if (n0 < 0) n0 = 0;                                        // (N = 1: wave 1 owns the slice's costate, wave 0 its gradient)
+        if (n0 > p.N - 1) n0 = p.N - 1;                            // (wave 0 always ends at t = N - 1: it writes the figure of merit)
         q.split_at = n0;
+        constexpr int parts = 2;
         const size_t bt_b = sizeof(double2) * (size_t)p.K * 256;
         const size_t img_b = sizeof(double2) * (size_t)parts * (kTileImage + 1);
         q.bt_in_lds = img_b + bt_b <= 40 * 1024 ? 1 : 0;           // 4 workgroups per CU must still fit
@@ -1598,22 +1522,20 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         const dim3 blk(64 * parts);
         const int hm = !sandwich || !p.herm_states ? 0 : (p.herm_ctrl ? 2 : 1);      // (see HERM at the kernel)
         const bool lists4 = p.sparse && p.K == 4 && p.sp_nz == 64 && !std::getenv("GRAPE_SPLIT_LISTS_LDS");   // SPARSE = 2
-#define GRAPE_SPLIT_GO(SP, PT, LDS)                                                                              \
-    {                                                                                                            \
-        if (!sandwich)    GRAPE_LAUNCH((chain_tile_split_kernel<0, SP, PT, 0>), grid, blk, LDS, stream, q);      \
-        else if (hm == 2) GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, PT, 2>), grid, blk, LDS, stream, q);      \
-        else if (hm == 1) GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, PT, 1>), grid, blk, LDS, stream, q);      \
-        else              GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, PT, 0>), grid, blk, LDS, stream, q);      \
+#define GRAPE_SPLIT_GO(SP, LDS)                                                                              \
+    {                                                                                                        \
+        if (!sandwich)    GRAPE_LAUNCH((chain_tile_split_kernel<0, SP, 0>), grid, blk, LDS, stream, q);      \
+        else if (hm == 2) GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, 2>), grid, blk, LDS, stream, q);      \
+        else if (hm == 1) GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, 1>), grid, blk, LDS, stream, q);      \
+        else              GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, 0>), grid, blk, LDS, stream, q);      \
     }
         if (p.sparse) {
             const size_t lds_sp = img_b + sizeof(double2) * ((size_t)p.K * p.sp_nz + (size_t)parts * 16 * 17) +
                                   sizeof(int32_t) * (size_t)p.K * p.sp_nz;
-            if (parts == 3) GRAPE_SPLIT_GO(1, 3, lds_sp)
-            else if (lists4) GRAPE_SPLIT_GO(2, 2, lds_sp)
-            else GRAPE_SPLIT_GO(1, 2, lds_sp)
+            if (lists4) GRAPE_SPLIT_GO(2, lds_sp) else GRAPE_SPLIT_GO(1, lds_sp)
             return hipGetLastError();
         }
-        if (parts == 3) GRAPE_SPLIT_GO(0, 3, lds2) else GRAPE_SPLIT_GO(0, 2, lds2)
+        GRAPE_SPLIT_GO(0, lds2)
 #undef GRAPE_SPLIT_GO
         return hipGetLastError();
     }

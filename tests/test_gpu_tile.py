@@ -119,25 +119,39 @@ def test_c4_liouvillian_parity(qoc, oracle, dense):
 
 
 @pytest.mark.parametrize("sys_type,n,K,N,E,mixed", [("CoherenceTransfer", 16, 4, 41, 3, False), ("StateTransfer", 12, 3, 7, 2, True),
-                                                    ("UnitaryGate", 9, 2, 6, 2, False), ("StateTransfer", 16, 17, 9, 2, True)])
-def test_three_waves_per_member_split_chain(qoc, oracle, monkeypatch, sys_type, n, K, N, E, mixed):
-    """chain_tile_split_kernel with THREE parts of the time axis (GRAPE_TILE_PARTS=3; the product runs two: measured faster):
-    sandwich and left-multiplication flows, sparse and dense operator lists, Hermitian and general states, N barely above the
-    number of parts, K beyond the LDS cache -- against the oracle and against the two-part run of the same engine."""
+                                                    ("UnitaryGate", 9, 2, 6, 2, False), ("StateTransfer", 16, 17, 9, 2, True),
+                                                    ("StateTransfer", 16, 4, 4, 2, False), ("CoherenceTransfer", 16, 4, 64, 2, False)])
+def test_two_wave_chain_meets_anywhere_on_the_time_axis(qoc, oracle, monkeypatch, sys_type, n, K, N, E, mixed):
+    """chain_tile_split_kernel (wave 0 forward from t = 0, wave 1 backward from t = N, meeting at N / 2): sandwich and
+    left-multiplication flows, the three Hermitian specialisations (mixed / pure density operators with Hermitian controls,
+    general states), list traces in registers (K = 4 x 64 entries), in LDS and dense operators (K beyond the LDS cache), slice
+    counts that are / are not multiples of the prefetch rings -- and the meeting point moved to both ends and off-centre
+    (GRAPE_TILE_SPLIT_PERMILLE): every placement gives the oracle's numbers."""
+    monkeypatch.setenv("GRAPE_NO_TP", "1")
     if sys_type == "CoherenceTransfer":
         w = qoc.workloads.config("C4", E=E, N=N)
     else:
         w = _random_problem(qoc, n, K, N, E, sys_type, seed=11, mixed=mixed)
-    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
-    with _engine(qoc, w, flags=qoc.engine.FLAG_FORCE_GENERAL) as eng:
-        F2, G2 = eng.eval(w.x)
-        names2 = eng.kernel_names()
-        monkeypatch.setenv("GRAPE_TILE_PARTS", "3")
-        F3, G3 = eng.eval(w.x)
-    assert_parity(F3, G3, F_ref, G_ref, w.n, what="three parts")
-    assert_parity(F2, G2, F_ref, G_ref, w.n, what="two parts")
-    if any("chain_tile_split_kernel" in k for k in names2):      # (otherwise another chain ran: nothing was split)
-        assert np.max(np.abs(np.asarray(G3) - np.asarray(G2))) <= 1e-10 * max(1.0, np.max(np.abs(G2)))
+        if K == 4:
+            w.B[:] = np.triu(w.B) * (np.abs(w.B) > 0.45)          # few non-zeros, not Hermitian: HERM = 1 with lists in registers
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, per_member=True)
+    res = []
+    for permille in (None, 0, 1000, 333, 800):
+        if permille is None:
+            monkeypatch.delenv("GRAPE_TILE_SPLIT_PERMILLE", raising=False)
+        else:
+            monkeypatch.setenv("GRAPE_TILE_SPLIT_PERMILLE", str(permille))
+        with _engine(qoc, w, flags=qoc.engine.FLAG_FORCE_GENERAL) as eng:
+            F, G = eng.eval(w.x)
+            foms, grads = eng.member_results()
+            assert any("chain_tile_split_kernel" in k for k in eng.kernel_names()), eng.kernel_names()
+            assert eng.info["states_stored"] == 0
+        for k in range(w.E):
+            assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], w.n, what=f"meeting at {permille} permille, member {k}")
+        assert_parity(F, G, F_ref, G_ref, w.n, what=f"meeting at {permille} permille")
+        res.append(G)
+    for G in res[1:]:
+        assert np.max(np.abs(G - res[0])) <= 1e-10 * max(1.0, np.max(np.abs(res[0])))
 
 
 @pytest.mark.parametrize("chain", ["chunked", "sequential"])
