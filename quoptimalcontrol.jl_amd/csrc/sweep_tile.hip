@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "cmat.hpp"          // Taylor-8 coefficients, squarings_for
 #include "grape_kernels.hpp"
@@ -565,6 +566,57 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
 #ifndef GRAPE_SPLIT_ABL
 #define GRAPE_SPLIT_ABL 0
 #endif
+// A Hermitian 16 x 16 state in 3 KB instead of 4: rows 0..7 as they are (D registers 0, 1), of rows 8..15 only columns 8..15
+// -- register 2's upper half-rows in the lanes that hold them, register 3's rotated into the other lanes (row_ror:8) -- and the
+// block (rows 8..15, columns 0..7) comes back as the conjugate transpose of (rows 0..7, columns 8..15) through the wave's LDS
+// image (two writes, two reads).  The stored states are a quarter of the split chain's HBM bytes, which is what bounds it.
+struct HState {
+    double re[3], im[3];
+};
+GRAPE_DEV double ror8(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x128, 0xF, 0xF, true);      // row_ror:8
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x128, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+GRAPE_DEV void hstore(double2 *__restrict__ dst, const TMat<1> &m, int lane)
+{
+    const bool up = (lane & 8) != 0;                               // column >= 8
+    const double qr = ror8(m.re[0][0][3]), qi = ror8(m.im[0][0][3]);
+    dst[lane] = make_double2(m.re[0][0][0], m.im[0][0][0]);
+    dst[64 + lane] = make_double2(m.re[0][0][1], m.im[0][0][1]);
+    dst[128 + lane] = make_double2(up ? m.re[0][0][2] : qr, up ? m.im[0][0][2] : qi);
+}
+GRAPE_DEV void hload(HState &h, const double2 *__restrict__ src, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double2 v = src[r * 64 + lane];
+        h.re[r] = v.x;
+        h.im[r] = v.y;
+    }
+}
+GRAPE_DEV void hunpack(TMat<1> &m, const HState &h, double2 *__restrict__ img, int lane)
+{
+    const int hi = lane >> 4, col = lane & 15;
+    const bool up = (lane & 8) != 0;
+    img[(hi) * 17 + col] = make_double2(h.re[0], h.im[0]);         // rows 0..3
+    img[(4 + hi) * 17 + col] = make_double2(h.re[1], h.im[1]);     // rows 4..7
+    const double qr = ror8(h.re[2]), qi = ror8(h.im[2]);           // (lanes with column >= 8: register 3's entry)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const double2 t2 = img[(col & 7) * 17 + 8 + hi], t3 = img[(col & 7) * 17 + 12 + hi];      // X[col][8 + hi], X[col][12 + hi]
+    m.re[0][0][0] = h.re[0];
+    m.im[0][0][0] = h.im[0];
+    m.re[0][0][1] = h.re[1];
+    m.im[0][0][1] = h.im[1];
+    m.re[0][0][2] = up ? h.re[2] : t2.x;
+    m.im[0][0][2] = up ? h.im[2] : -t2.y;
+    m.re[0][0][3] = up ? qr : t3.x;
+    m.im[0][0][3] = up ? qi : -t3.y;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+}
 template <int SAND, int SPARSE = 0, int HERM = 0>
 __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TileParams p)
 {
@@ -642,8 +694,18 @@ __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TilePara
             C = Y;
         }
     };
-    // slices a, a + d, ..., (cnt of them; d = +1 / -1) through rings: body(t, P_t [, S_t]) with every load R - 1 slices ahead
-    const int d = fwd ? 1 : -1;
+    const int d = fwd ? 1 : -1;                                    // this wave's direction on the time axis
+    // stored states: Hermitian ones packed (3 KB of the 4 KB slot)
+    constexpr bool hpack = herm && !(GRAPE_SPLIT_ABL & 4);
+    using SState = typename std::conditional<hpack, HState, TMat<1>>::type;
+    auto sstore = [&](double2 *dst, const TMat<1> &m) {
+        if constexpr (hpack) hstore(dst, m, lane);
+        else tstore(dst, m, lane);
+    };
+    auto sload = [&](SState &h, const double2 *src) {
+        if constexpr (hpack) hload(h, src, lane);
+        else tload(h, src, lane);
+    };
 
     // ------------------------------------------------------------ phase 1
     {
@@ -652,14 +714,14 @@ __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TilePara
         auto clampt = [&](int t) { return fwd ? min(t, last) : max(t, last); };
         auto step = [&](int t, const TMat<1> &Pt) {
             if (fwd) {
-                if (!(GRAPE_SPLIT_ABL & 1)) tstore(Sk + (size_t)t * TSZ, C, lane);      // X_t
+                if (!(GRAPE_SPLIT_ABL & 1)) sstore(Sk + (size_t)t * TSZ, C);            // X_t
                 ST_MARK(9)
                 push(Pt);
             } else {
                 pull(Pt);
                 ST_DEP(C.im[0][0][3])
                 ST_MARK(9)
-                if (!(GRAPE_SPLIT_ABL & 1)) tstore(Sk + (size_t)t * TSZ, C, lane);      // L_t
+                if (!(GRAPE_SPLIT_ABL & 1)) sstore(Sk + (size_t)t * TSZ, C);            // L_t
             }
             ST_DEP(C.im[0][0][3])
             ST_MARK(1)
@@ -809,10 +871,14 @@ __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TilePara
         ST_MARK(8)
     };
     {
-        TMat<1> Pb[RB], Sb[RB];
+        TMat<1> Pb[RB];
+        SState Sb[RB];
         const int a = fwd ? Nh : Nh - 1, cnt = fwd ? N - Nh : Nh, last = a + d * (cnt - 1);
         auto clampt = [&](int t) { return fwd ? min(t, last) : max(t, last); };
-        auto step = [&](int t, const TMat<1> &Pt, const TMat<1> &St) {
+        auto step = [&](int t, const TMat<1> &Pt, const SState &Ss) {
+            TMat<1> St;
+            if constexpr (hpack) hunpack(St, Ss, s_img, lane);
+            else St = Ss;
             if (fwd) {
                 ST_DEP(St.im[0][0][3])
                 ST_MARK(5)
@@ -832,20 +898,20 @@ __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TilePara
         int t = a, left = cnt;
         for (; left % RB; --left, t += d) {
             tload(Pb[0], Pk + (size_t)t * TSZ, lane);
-            tload(Sb[0], Sk + (size_t)t * TSZ, lane);
+            sload(Sb[0], Sk + (size_t)t * TSZ);
             step(t, Pb[0], Sb[0]);
         }
         if (left > 0) {
 #pragma unroll
             for (int i = 0; i < RB - 1; ++i) {
                 tload(Pb[i], Pk + (size_t)clampt(t + d * i) * TSZ, lane);
-                tload(Sb[i], Sk + (size_t)clampt(t + d * i) * TSZ, lane);
+                sload(Sb[i], Sk + (size_t)clampt(t + d * i) * TSZ);
             }
             for (; left > 0; left -= RB, t += d * RB) {
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     tload(Pb[(i + RB - 1) % RB], Pk + (size_t)clampt(t + d * (i + RB - 1)) * TSZ, lane);
-                    if (!(GRAPE_SPLIT_ABL & 2)) tload(Sb[(i + RB - 1) % RB], Sk + (size_t)clampt(t + d * (i + RB - 1)) * TSZ, lane);
+                    if (!(GRAPE_SPLIT_ABL & 2)) sload(Sb[(i + RB - 1) % RB], Sk + (size_t)clampt(t + d * (i + RB - 1)) * TSZ);
                     step(t + d * i, Pb[i], Sb[i]);
                 }
             }
