@@ -329,7 +329,10 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
     }
     __syncthreads();                                   // (the wave's own X_t stores have left before it reads them back)
     // ------------------------------------------------------------ backward sweep + gradient, :65-92
-    const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
+    // Hermitian states (X_t, L_t stay Hermitian under the sandwich) AND Hermitian control operators: with Y = X L,
+    // [X, L'] = Y - Y' and tr(B Y') = conj(tr(B Y)), so Im tr(B [X, L']) = 2 Im tr(B Y) -- the second product is not formed
+    const bool herm2 = SAND && p.herm_states != 0 && p.herm_ctrl != 0;
+    const double gs = SAND ? (herm2 ? -2.0 * p.dt : -p.dt) : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
     GT L = gt_load(ops + (size_t)(2 + 2 * K) * TSZ, tile, lane);                // Xt
     GT Pt = gt_load(Pk + (size_t)(N - 1) * TSZ, tile, lane);
     GT X = gt_load(Xk + (size_t)(N - 1) * TSZ, tile, lane);
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
         grid_put<NT, false>(img1, L, I, J, lane);
         grid_barrier();
         GT R = grid_mma<NT, false, true>(img0, img1, I, J, lane);               // X L'
-        if (SAND) {
+        if (SAND && !herm2) {
             grid_barrier();
             grid_put<NT, true>(img0, X, I, J, lane);
             grid_put<NT, true>(img1, L, I, J, lane);

@@ -441,7 +441,9 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
             pull(p.tp_a + (kw * p.tp_groups + blockIdx.z / p.tp_gsize) * TSZ);
         pull(p.tp_r + (kw * C + blockIdx.z) * TSZ);
     }
-    const double gs = SAND ? -p.dt : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
+    // (Hermitian states and control operators: Im tr(B [X, L']) = 2 Im tr(B X L) -- see chain_tile_split_kernel)
+    const bool herm2 = SAND && p.herm_states != 0 && p.herm_ctrl != 0;
+    const double gs = SAND ? (herm2 ? -2.0 * p.dt : -p.dt) : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
     double z_keep_r = 0.0, z_keep_i = 0.0;
     tload(Pm, Pk + (size_t)(t_hi - 1) * TSZ, lane);
     tload(X, Xk + (size_t)(t_hi - 1) * TSZ, lane);
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
         tprod<NT, false, true>(
             R, [&](int I, int Kt, int kb, double &r, double &i) { r = XA.re[I][Kt][kb]; i = XA.im[I][Kt][kb]; },
             [&](int Kt, int J, int kb, double &r, double &i) { r = LA.re[J][Kt][kb]; i = LA.im[J][Kt][kb]; });
-        if (SAND) {
+        if (SAND && !herm2) {
             tmul_tn<NT, true, false>(Y, L, X);                     // L' X
 #pragma unroll
             for (int I = 0; I < NT; ++I)
@@ -763,6 +765,7 @@ __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TilePara
             ad4[c] = s_addr[c * 64 + lane];
         }
     }
+    double *s_g = reinterpret_cast<double *>(s_img);               // one slice's K gradient entries on their way out
     // gradient entries of one slice from X_t, L_t (costate after pulling back through slice t)
     auto emit = [&](int t, const TMat<1> &X, const TMat<1> &L) {
         if (SPARSE && !z_known) {
@@ -831,7 +834,11 @@ __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TilePara
             // vector instructions, instead of being hoisted out of the slice loop)
             int lane_here = lane;
             asm volatile("" : "+v"(lane_here));
-            sparse_traces<NT, SAND>(R, s_M, s_coef, s_addr, K, z_keep_r, z_keep_i, gs, out + (size_t)t * K, lane_here, true, p.sp_nz);
+            // the K entries go to LDS (the wave's conversion image is idle here) and from there to HBM by ALL lanes (lanes
+            // beyond K repeat entry K - 1): the store sits behind no branch
+            sparse_traces<NT, SAND>(R, s_M, s_coef, s_addr, K, z_keep_r, z_keep_i, gs, s_g, lane_here, true, p.sp_nz);
+            const int idx = min(lane, K - 1);                      // (K <= 16 with lists)
+            out[(size_t)t * K + idx] = s_g[idx];
         } else {
             for (int c0 = 0; c0 < K || c0 == 0; c0 += 4) {
                 double v[2 + 8];
@@ -860,13 +867,17 @@ __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TilePara
                     const double wr = v[2 + 2 * cc], wi = v[3 + 2 * cc];
                     const double im = SAND ? wi : fma(wr, v[1], wi * v[0]);
                     if (c < K && lane == 0)
-                        out[c + (size_t)t * K] = gs * im;
+                        s_g[c] = gs * im;                          // (to LDS; stored below by all lanes, no branch round it)
                 }
                 if (t == N - 1) {
                     z_keep_r = v[0];
                     z_keep_i = v[1];
                 }
             }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const int idx = min(lane, K - 1);                      // (K <= 64: the launcher keeps larger K off this kernel)
+            out[(size_t)t * K + idx] = s_g[idx];
         }
         ST_MARK(8)
     };
@@ -1470,7 +1481,7 @@ bool tile_chain_is_split(const TileParams &p, bool keepl)
     // restores a limit for comparisons)
     static const long e_max = std::getenv("GRAPE_SPLIT_MAX_E") ? std::atol(std::getenv("GRAPE_SPLIT_MAX_E")) : (1L << 40);
     return tile_count(p.n) == 1 && !p.pack2 && !keepl && !p.unitary && !p.thin && (p.E_plan ? p.E_plan : p.E) < e_max && p.N >= 4 &&
-           p.tp_chunks < 2 && !tile_chain_env("1w");
+           p.tp_chunks < 2 && p.K <= 64 && !tile_chain_env("1w");
 }
 
 // rank-one chain: is the forward vector pass fused into the expm kernel for this launch?  (0 no, 1 yes, 2 ablation:

@@ -109,7 +109,7 @@ for i in range(cases):
     T = float(rng.uniform(0.3, 2.0))
     what = (f"case {i}: n={n} K={K} N={N} E={E} {sys_type} v{variant} herm={herm} sparse={sparse} states={states} flag={flag} "
             f"shared_ctrl={shared_ctrl} action={os.environ.get('GRAPE_ACTION', '-')} whole={os.environ.get('GRAPE_ACT_WHOLE', '-')} dpp={os.environ.get('GRAPE_THIN_DPP', '-')} dppc={os.environ.get('GRAPE_DPP_CHUNKS', '-')}")
-    exact = rng.random() < 0.15 and N <= 33 and n <= 32 and states not in ("rect", "vec")      # (the C oracle has no exact gradient for n x m states)
+    exact = rng.random() < 0.15 and N <= 33 and n <= 64 and states not in ("rect", "vec")      # (the C oracle has no exact gradient for n x m states)
     if chunk_budget:
         nt = (n + 15) // 16
         # one member's share of one workspace array: n <= 4 S x chunks <= N + 512 slices' worth of n x n matrices; tiles: N dumps
