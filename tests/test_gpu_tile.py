@@ -154,6 +154,20 @@ def test_two_wave_chain_meets_anywhere_on_the_time_axis(qoc, oracle, monkeypatch
         assert np.max(np.abs(G - res[0])) <= 1e-10 * max(1.0, np.max(np.abs(res[0])))
 
 
+def test_many_controls_keep_the_one_wave_chain(qoc, oracle, monkeypatch):
+    """K = 70 dense control operators on 12 x 12 mixed states: beyond what the two-wave chain stores per slice in one instruction
+    (K <= 64), the general flow stays with chain_tile_kernel -- same numbers"""
+    monkeypatch.setenv("GRAPE_NO_TP", "1")
+    w = _random_problem(qoc, 12, 70, 6, 2, "StateTransfer", seed=21, hermitian=False, mixed=True)
+    w.B *= 0.1
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    with _engine(qoc, w) as eng:
+        F, G = eng.eval(w.x)
+        names = eng.kernel_names()
+    assert any("chain_tile_kernel" in k for k in names) and not any("chain_tile_split_kernel" in k for k in names), names
+    assert_parity(F, G, F_ref, G_ref, w.n, what="K = 70")
+
+
 @pytest.mark.parametrize("chain", ["chunked", "sequential"])
 def test_c5_five_qubit_parity(qoc, oracle, monkeypatch, chain):
     """BASELINE config 5 at parity size: 32x32 UnitaryGate, K=6, N=2000 (2 members): the chunked time axis small
