@@ -1043,12 +1043,18 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             const size_t lo = (size_t)c->sub_lo[i];
             const int rc = grape_set_operators(c->sub[i], A + lo * nn2, B + lo * Kc * nn2, Xi + lo * nm2,
                                                Xt + lo * nm2, wts + lo);
-            if (rc) return fail(c, rc, c->sub[i]->err);
+            if (rc) {
+                c->ops_set = false;                              // (some shards hold the new operators, some the old ones)
+                return fail(c, rc, c->sub[i]->err);
+            }
         }
         c->ops_set = true;
         c->evaluated = false;
         return GRAPE_OK;
     }
+    // an upload that fails half way (allocation of a re-planned workspace, a copy) leaves the context NOT READY -- never with
+    // the previous upload's flags over freed or partly rewritten buffers
+    c->ops_set = false;
     DeviceGuard guard;
     HIP_TRY(c, hipSetDevice(c->device));
     // ordered behind the last evaluation BEFORE any device buffer is touched (the sparse lists, vectors and hoisted
