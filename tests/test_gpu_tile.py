@@ -154,6 +154,20 @@ def test_two_wave_chain_meets_anywhere_on_the_time_axis(qoc, oracle, monkeypatch
         assert np.max(np.abs(G - res[0])) <= 1e-10 * max(1.0, np.max(np.abs(res[0])))
 
 
+def test_two_wave_chain_on_ensembles_beyond_the_resident_wave_slots(qoc, oracle, monkeypatch):
+    """2304 full-rank 16 x 16 members (more workgroups than the device holds at once: they queue): every member against the oracle"""
+    monkeypatch.setenv("GRAPE_NO_THIN", "1")
+    w = qoc.workloads.config("C4", E=2304, N=8)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, per_member=True)
+    with _engine(qoc, w) as eng:
+        F, G = eng.eval(w.x)
+        foms, grads = eng.member_results()
+        assert any("chain_tile_split_kernel" in k for k in eng.kernel_names()), eng.kernel_names()
+    assert_parity(F, G, F_ref, G_ref, w.n, what="E = 2304")
+    worst = max(np.abs(grads[k] - grads_ref[k]).max() / max(np.abs(grads_ref[k]).max(), 1e-30) for k in range(w.E))
+    assert worst <= 1e-10 and np.abs(foms - foms_ref).max() <= 1e-10, (worst, np.abs(foms - foms_ref).max())
+
+
 def test_many_controls_keep_the_one_wave_chain(qoc, oracle, monkeypatch):
     """K = 70 dense control operators on 12 x 12 mixed states: beyond what the two-wave chain stores per slice in one instruction
     (K <= 64), the general flow stays with chain_tile_kernel -- same numbers"""
