@@ -134,7 +134,13 @@ def action_steps(local):
     return float((np.minimum(deg, 24) * pieces).sum())
 
 
-def tile_kernel_models(local, info):
+def _hermitian(M):
+    import numpy as np
+    M = np.asarray(M)
+    return M.shape[-1] == M.shape[-2] and bool(np.allclose(M, np.conj(np.swapaxes(M, -1, -2)), rtol=0.0, atol=1e-13))
+
+
+def tile_kernel_models(local, info, names=()):
     """Work of the two halves of a tile-family (n = 5..32) evaluation AS RUN: matrix-core flops
     = v_mfma_f64_16x16x4 instructions x 2048 (a complex tile product is 12 of them: three real products), HBM bytes =
     the padded D-layout dumps each kernel writes / reads.  Squarings (data dependent, none at the BASELINE configs with
@@ -177,9 +183,20 @@ def tile_kernel_models(local, info):
         chain = {"name": "unitary chain (M_t = P' M P, forward product P^T V)", "flops": units * N * 3 * prod,
                  "bytes": units * N * tsz * 2}
     else:
-        q = 6 if sand else 3
-        chain = {"name": "dense chain (general flow: forward states stored)", "flops": units * N * q * prod,
-                 "bytes": units * N * tsz * 4}
+        # general flow.  Hermitian states + Hermitian control operators under the sandwich: Im tr(B [X, L]) = 2 Im tr(B X L),
+        # five products per slice instead of six (every general-flow chain kernel); chain_tile_split_kernel (n <= 16) also
+        # stores Hermitian states in 3/4 of their slot and, with member-invariant controls, forms the propagators itself --
+        # no expm kernel: P_t written once, read once
+        herm = sand and _hermitian(local.Xi) and _hermitian(local.Xt)
+        q = (5 if herm and _hermitian(local.B) else 6) if sand else 3
+        split = any(k.startswith("chain_tile_split_kernel") for k in names)
+        state_b = 2 * (0.75 if (split and herm) else 1.0)
+        chain = {"name": "dense chain (general flow: states stored)", "flops": units * N * q * prod,
+                 "bytes": units * N * tsz * (2 + state_b)}
+        if split and not any(k.startswith(("prop_", "grid_prop")) for k in names):
+            chain = {"name": "two-wave chain forming its own propagators (general flow)",
+                     "flops": units * N * (3 + q) * prod, "bytes": units * N * tsz * (2 + state_b)}
+            return None, chain
     return expm, chain
 
 
@@ -209,11 +226,13 @@ def roofline(local, info, samples, evals_per_s, n_gpus, traffic, profile=None, n
     if info.get("kernel_family") == 1:            # n > 4: FP64 matrix-core kernels
         # priced PER KERNEL on the flow actually run (the rank-one / unitary / chunked flows do less work than model S,
         # so model-S flops over their run time can exceed the peak: kept below as model_s_equivalent only)
-        expm, chain = tile_kernel_models(local, info)
+        expm, chain = tile_kernel_models(local, info, names)
         t_first = float(first_ms.mean()) * 1e-3 if first_ms.size else 0.0
         parts = []
         k_first, k_rest = split_kernels(list(names))
         for part, t, launched in ((expm, t_first, k_first), (chain, max(sec - t_first, 0.0), k_rest)):
+            if part is None:                                   # (the chain forms the propagators: one part, the whole launch list)
+                continue
             tf = part["flops"] / t / 1e12 if t > 0 else 0.0
             gb = part["bytes"] / t / 1e9 if t > 0 else 0.0
             fm, fh = tf / FP64_PEAK_TFLOPS, gb / HBM_PEAK_GBS

@@ -134,6 +134,7 @@ struct TileParams {
     int32_t unitary;      // every generator Hermitian: chain kernel carries M_t = P' M P, no stored states
     int32_t herm_states;  // every Xi, Xt Hermitian (density operators): [X, L'] = Y - Y' with one product
     int32_t split_at;     // set by the launcher: first slice of the second wave (chain_tile_split_kernel)
+    int32_t split_expm;   // set by the launcher: chain_tile_split_kernel forms P_t itself in its phase 1 (no expm kernel ran)
     int32_t n_x;          // control arrays evaluated by this launch (batched evaluation); x is (K, N, n_x)
     int32_t thin;         // rank-one states: 1 = sweep_thin.hip's matrix-vector chain (the prop kernel then stores P_t
                           // TRANSPOSED for odd t; `states` holds the forward pass's vector records, N + 1 per member);

@@ -619,7 +619,12 @@ GRAPE_DEV void hunpack(TMat<1> &m, const HState &h, double2 *__restrict__ img, i
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
 }
-template <int SAND, int SPARSE = 0, int HERM = 0>
+// EXPM (member-invariant control operators, TileParams.split_expm): phase 1 FORMS the propagators it needs instead of
+// reading them -- G_t = A'_k + Gc_t from the pre-pass's control sum (shared by all members: served by L2 / Infinity Cache),
+// the degree-8 Taylor polynomial in three products + squarings exactly as prop_hoist1_kernel evaluates it -- and stores P_t
+// for the other wave's phase 2.  No expm kernel runs: every P_t is written once and read once (18 -> 14 KB of HBM traffic
+// per member and slice), and the expm's products fill the matrix pipe of the phase that waits for HBM.
+template <int SAND, int SPARSE = 0, int HERM = 0, bool EXPM = false>
 __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TileParams p)
 {
     constexpr int NT = 1, TSZ = 256, PARTS = 2;
@@ -669,6 +674,7 @@ __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TilePara
     }
     const size_t kw = (size_t)blockIdx.y * p.E + k;                // workspace row: (control array, member)
     const double2 *__restrict__ Pk = p.props + kw * N * TSZ;
+    double2 *__restrict__ Pw = p.props + kw * N * TSZ;             // (EXPM: phase 1 writes them)
     double2 *__restrict__ Sk = p.states + kw * N * TSZ;            // slot t: X_t (t < Nh) or L_t (t >= Nh)
     double *__restrict__ out = p.member_out + kw * ((size_t)K * N + 1);
     constexpr int RG = 4, RB = 3;                                  // ring sizes of phase 1 / phase 2 (which keeps more matrices live)
@@ -711,10 +717,69 @@ __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TilePara
 
     // ------------------------------------------------------------ phase 1
     {
-        TMat<1> Pb[RG];
+        TMat<1> Pb[RG];                                            // ring: P_t -- or, EXPM, the control sums Gc_t
+        TMat<1> Ah;                                                // EXPM: A'_k = (-i dt) A_k
+        double nA = 0.0;
+        const double2 *__restrict__ src = EXPM ? p.gc + (size_t)blockIdx.y * N * TSZ : Pk;
+        const double *__restrict__ gcn = p.gcn + (size_t)blockIdx.y * N;
+        if constexpr (EXPM) {
+            tload(Ah, p.ha + (size_t)k * TSZ, lane);
+            nA = p.ha_norm[k];
+        }
         const int a = fwd ? 0 : N - 1, cnt = fwd ? Nh : N - Nh, last = a + d * (cnt - 1);
         auto clampt = [&](int t) { return fwd ? min(t, last) : max(t, last); };
-        auto step = [&](int t, const TMat<1> &Pt) {
+        // P_t = exp(G_t), G_t = A'_k + Gc_t: the constants and their arrangement are prop_hoist1_kernel's
+        //   A4' = A2 (A2 + c1 G),  A8' = (A4' + c3 A2)(x4 I + x5 G + x6 A2 + c7 A4'),  P = x2 A8' + (I + G + y2 A2)
+        auto expm_t = [&](TMat<1> &Pt, const TMat<1> &Gc, int t) {
+            constexpr double c1 = kX1 / kX2, c3 = kX3 / kX2, c7 = kX7 * kX2;
+            TMat<1> G, A2, T, A4;
+            TOp<1> OA;
+            G.re[0][0] = Ah.re[0][0] + Gc.re[0][0];
+            G.im[0][0] = Ah.im[0][0] + Gc.im[0][0];
+            const int sq = p.s_forced >= 0 ? p.s_forced : squarings_from_ratio(nA + gcn[t]);       // (bounds are stored / theta8)
+            if (sq > 0) {
+                const double sc = ldexp(1.0, -sq);
+                G.re[0][0] *= sc;
+                G.im[0][0] *= sc;
+            }
+            to_a_layout(OA, G, s_img, lane);
+            tmul_an<NT, false, false>(A2, OA, G);                  // A2 = G G
+            T.re[0][0] = c1 * G.re[0][0] + A2.re[0][0];
+            T.im[0][0] = c1 * G.im[0][0] + A2.im[0][0];
+            to_a_layout(OA, A2, s_img, lane);
+            tmul_an<NT, false, false>(A4, OA, T);                  // A4'
+            TMat<1> U;
+            U.re[0][0] = c3 * A2.re[0][0] + A4.re[0][0];
+            U.im[0][0] = c3 * A2.im[0][0] + A4.im[0][0];
+            T.re[0][0] = c7 * A4.re[0][0] + (kX6 * A2.re[0][0] + kX5 * G.re[0][0]);
+            T.im[0][0] = c7 * A4.im[0][0] + (kX6 * A2.im[0][0] + kX5 * G.im[0][0]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * r + (lane >> 4) == (lane & 15))
+                    T.re[0][0][r] += kX4;
+            to_a_layout(OA, U, s_img, lane);
+            tmul_an<NT, false, false>(Pt, OA, T);                  // A8'
+            Pt.re[0][0] = kX2 * Pt.re[0][0] + (kY2 * A2.re[0][0] + G.re[0][0]);
+            Pt.im[0][0] = kX2 * Pt.im[0][0] + (kY2 * A2.im[0][0] + G.im[0][0]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * r + (lane >> 4) == (lane & 15))
+                    Pt.re[0][0][r] += 1.0;
+            for (int i = 0; i < sq; ++i) {                         // undo the scaling
+                to_a_layout(OA, Pt, s_img, lane);
+                tmul_an<NT, false, false>(T, OA, Pt);
+                Pt = T;
+            }
+        };
+        auto step = [&](int t, const TMat<1> &In) {
+            TMat<1> Pl;
+            if constexpr (EXPM) {
+                expm_t(Pl, In, t);
+                tstore(Pw + (size_t)t * TSZ, Pl, lane);            // for the other wave's phase 2
+                ST_DEP(Pl.im[0][0][3])
+                ST_MARK(0)
+            }
+            const TMat<1> &Pt = EXPM ? Pl : In;
             if (fwd) {
                 if (!(GRAPE_SPLIT_ABL & 1)) sstore(Sk + (size_t)t * TSZ, C);            // X_t
                 ST_MARK(9)
@@ -731,17 +796,17 @@ __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TilePara
         int t = a, left = cnt;
         ST_BEGIN();
         for (; left % RG; --left, t += d) {                        // the first (cnt mod RG) slices one at a time
-            tload(Pb[0], Pk + (size_t)t * TSZ, lane);
+            tload(Pb[0], src + (size_t)t * TSZ, lane);
             step(t, Pb[0]);
         }
         if (left > 0) {
 #pragma unroll
             for (int i = 0; i < RG - 1; ++i)
-                tload(Pb[i], Pk + (size_t)clampt(t + d * i) * TSZ, lane);
+                tload(Pb[i], src + (size_t)clampt(t + d * i) * TSZ, lane);
             for (; left > 0; left -= RG, t += d * RG) {
 #pragma unroll
                 for (int i = 0; i < RG; ++i) {
-                    tload(Pb[(i + RG - 1) % RG], Pk + (size_t)clampt(t + d * (i + RG - 1)) * TSZ, lane);   // (clamped: re-reads the last slice)
+                    tload(Pb[(i + RG - 1) % RG], src + (size_t)clampt(t + d * (i + RG - 1)) * TSZ, lane);   // (clamped: re-reads the last slice)
                     step(t + d * i, Pb[i]);
                 }
             }
@@ -1484,6 +1549,14 @@ bool tile_chain_is_split(const TileParams &p, bool keepl)
            p.tp_chunks < 2 && p.K <= 64 && !tile_chain_env("1w");
 }
 
+// the two-wave chain with member-invariant control operators forms the propagators itself (chain_tile_split_kernel<.., EXPM>):
+// launch_nt then runs ctrl_sum_kernel only.  GRAPE_SPLIT_EXPM=0 keeps prop_hoist1_kernel + the chain that reads P_t.
+static bool split_forms_props(const TileParams &p, bool keepl)
+{
+    static const bool off = std::getenv("GRAPE_SPLIT_EXPM") && std::getenv("GRAPE_SPLIT_EXPM")[0] == '0';
+    return !off && p.hoist == 1 && tile_chain_is_split(p, keepl);
+}
+
 // rank-one chain: is the forward vector pass fused into the expm kernel for this launch?  (0 no, 1 yes, 2 ablation:
 // the fused kernel's grid without the hand-over.)  One workgroup then walks a member's N slices, so a member takes at
 // least N x (one propagator / 4 waves) -- 1.6 ms at C4's N = 1000 however small the ensemble; it pays from half a
@@ -1540,7 +1613,9 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         // per propagator as prop_hoist2_kernel, but operand sums formed in registers and k-contiguous ds_read_b128 pairs instead
         // of a third LDS plane: 85.5 against 96-97 ms at C5, matrix pipe 0.72 against 0.64.  GRAPE_HOIST2=1 keeps prop_hoist2.
         const bool keep_hoist2 = std::getenv("GRAPE_HOIST2") != nullptr;
-        if (hoisted && NT == 2 && p.hoist == 1 && !keep_hoist2 && (long)p.E * p.n_x >= (long)(p.cus > 0 ? p.cus : 256)) {
+        if (NT == 1 && split_forms_props(p, keepl)) {              // chain_tile_split_kernel<.., EXPM>: only the control sums
+            e = launch_ctrl_sum(1, q, stream);
+        } else if (hoisted && NT == 2 && p.hoist == 1 && !keep_hoist2 && (long)p.E * p.n_x >= (long)(p.cus > 0 ? p.cus : 256)) {
             e = launch_grid_prop(2, q, stream);
         } else if (hoisted) {                                      // member-invariant controls: prop_hoist.hip
             e = launch_prop_hoist(NT, q, stream);
@@ -1591,6 +1666,7 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         if (n0 < 0) n0 = 0;                                        // (N = 1: wave 1 owns the slice's costate, wave 0 its gradient)
         if (n0 > p.N - 1) n0 = p.N - 1;                            // (wave 0 always ends at t = N - 1: it writes the figure of merit)
         q.split_at = n0;
+        q.split_expm = split_forms_props(p, keepl) ? 1 : 0;
         constexpr int parts = 2;
         const size_t bt_b = sizeof(double2) * (size_t)p.K * 256;
         const size_t img_b = sizeof(double2) * (size_t)parts * (kTileImage + 1);
@@ -1599,13 +1675,15 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         const dim3 blk(64 * parts);
         const int hm = !sandwich || !p.herm_states ? 0 : (p.herm_ctrl ? 2 : 1);      // (see HERM at the kernel)
         const bool lists4 = p.sparse && p.K == 4 && p.sp_nz == 64 && !std::getenv("GRAPE_SPLIT_LISTS_LDS");   // SPARSE = 2
-#define GRAPE_SPLIT_GO(SP, LDS)                                                                              \
-    {                                                                                                        \
-        if (!sandwich)    GRAPE_LAUNCH((chain_tile_split_kernel<0, SP, 0>), grid, blk, LDS, stream, q);      \
-        else if (hm == 2) GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, 2>), grid, blk, LDS, stream, q);      \
-        else if (hm == 1) GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, 1>), grid, blk, LDS, stream, q);      \
-        else              GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, 0>), grid, blk, LDS, stream, q);      \
+#define GRAPE_SPLIT_GO2(SP, LDS, EX)                                                                             \
+    {                                                                                                            \
+        if (!sandwich)    GRAPE_LAUNCH((chain_tile_split_kernel<0, SP, 0, EX>), grid, blk, LDS, stream, q);      \
+        else if (hm == 2) GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, 2, EX>), grid, blk, LDS, stream, q);      \
+        else if (hm == 1) GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, 1, EX>), grid, blk, LDS, stream, q);      \
+        else              GRAPE_LAUNCH((chain_tile_split_kernel<1, SP, 0, EX>), grid, blk, LDS, stream, q);      \
     }
+#define GRAPE_SPLIT_GO(SP, LDS) \
+    { if (q.split_expm) GRAPE_SPLIT_GO2(SP, LDS, true) else GRAPE_SPLIT_GO2(SP, LDS, false) }
         if (p.sparse) {
             const size_t lds_sp = img_b + sizeof(double2) * ((size_t)p.K * p.sp_nz + (size_t)parts * 16 * 17) +
                                   sizeof(int32_t) * (size_t)p.K * p.sp_nz;
@@ -1614,6 +1692,7 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         }
         GRAPE_SPLIT_GO(0, lds2)
 #undef GRAPE_SPLIT_GO
+#undef GRAPE_SPLIT_GO2
         return hipGetLastError();
     }
     // unitary flow, small ensembles: the time axis in chunks (chunk_product_kernel / chunk_scan_kernel above), grid.z = chunk

@@ -441,4 +441,18 @@ GRAPE_DEV double wave_max_fast(double v)
     return v;
 }
 
+// squarings from a norm bound already divided by theta8: 0 when v <= 1 (and for NaN: the polynomial propagates it),
+// else 1 + the binary exponent of v (one more than needed when v is an exact power of two) -- scalar integer
+// arithmetic on the bits of v, no FP64 vector instruction
+GRAPE_DEV int squarings_from_ratio(double v)
+{
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    const int e = (hi >> 20) & 0x7ff;
+    if (hi < 0 || e < 1023 || e == 0x7ff)
+        return 0;
+    if (e == 1023 && (hi & 0xfffff) == 0 && __builtin_amdgcn_readfirstlane(__double2loint(v)) == 0)
+        return 0;                                                  // v == 1 exactly
+    return min(e - 1022, 60);
+}
+
 }  // namespace grape

@@ -14,8 +14,8 @@ import quoptimalcontrol_jl_amd as qoc  # noqa: E402
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 w = qoc.workloads.config("C4", E=E)
 os.environ["GRAPE_NO_THIN"] = "1"
-names = ["-", "p1 products (+ conversion)", "barrier wait", "-", "p2 propagate (2 products)", "p2 state arrives", "p2 product X L",
-         "p2 commutator", "p2 traces", "p1 store / P_t arrives"]
+names = ["p1 Gc_t arrives, expm, P_t store", "p1 propagate (2 products)", "barrier wait", "-", "p2 propagate (2 products)", "p2 state arrives",
+         "p2 product X L", "p2 commutator", "p2 traces", "p1 state store (wave 1: + its products)"]
 with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, member_results=True) as eng:
     for _ in range(3):
         eng.eval(w.x)
