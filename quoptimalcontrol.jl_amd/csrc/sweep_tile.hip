@@ -556,12 +556,12 @@ __global__ __launch_bounds__(64) void chain_tile_kernel(const TileParams p)
 //     Y = X L takes both from the registers they are in (no LDS layout conversion);
 //   * [X, L'] = Y - Y', one conversion (to_a_layout of Y IS the D layout of Y^T) instead of a second product -- and with
 //     Hermitian control operators tr(B Y') = conj(tr(B Y)), i.e. Im tr(B [X, L]) = 2 Im tr(B Y): Y' is never formed.
-// HERM / SPARSE are template arguments, and no vector-memory instruction of the slice loops sits behind a branch: at the join
-// the compiler's s_waitcnt pass has to assume the path that issued nothing, i.e. it waits for the YOUNGEST load in flight --
-// the prefetch it has just issued (round 4 found this for `if (t + 1 < N) load`; round 5 for the `if (lane == 0) store` of
-// the gradient entries and the figure of merit, and for run-time `herm` branches).  Every load is issued RG - 1 (RB - 1)
-// slices ahead of its use into a ring of register buffers; the loops are unrolled by the ring size (a buffer is a fixed set
-// of registers; `Pm = Pn` at the end of an iteration is a wait for the load issued one product earlier).  The waves' own
+// HERM / SPARSE are template arguments, and no vector-memory instruction of the slice loops sits behind a branch: at a join
+// the compiler's s_waitcnt pass has to assume the path that issued nothing (round 4 found a wait for the prefetch just
+// issued behind `if (t + 1 < N) load`; a lane-0 store behind a branch costs 0.6-1.9 k cycles per slice against a store by
+// all lanes, tools/ubench/branch_wait.hip).  Every load is issued RG - 1 (RB - 1) slices ahead of its use into a ring of
+// register buffers; the loops are unrolled by the ring size (a buffer is a fixed set of registers; `Pm = Pn` at the end of
+// an iteration, as rounds 2-4 had it, is a wait for the load issued one product earlier).  The waves' own
 // cycle counts (tools/split_stamps.py, profiles/r05_split_stamps.txt) before / after: 23-29 % of a wave's cycles waiting
 // for P_t in pass 1, 3.7 k cycles per slice in the generic list traces.  What is left: phase 1 is bound by HBM (8 KB per
 // slice and wave, half of it stores).
