@@ -163,9 +163,10 @@ typedef struct grape_info {
     int32_t lane_pair;             /* 1: the lane-pair small-n kernel (two lanes per time chunk, two waves per SIMD) */
     int32_t states_stored;         /* 1: grape_get_trajectory can return the forward states (after set_operators);
                                       0: the flow in use rebuilds them on the fly -- ask for GRAPE_FLAG_KEEP_COSTATES */
-    int32_t rank_one_chain;        /* 1 after grape_set_operators found rank-one states in the 9 <= n <= 16 family
-                                      (Xi = v v', Xt = w w' under the sandwich, or n x 1 states): the sweeps run on
-                                      vectors; GRAPE_FLAG_FORCE_GENERAL keeps the dense chain */
+    int32_t rank_one_chain;        /* 1 after grape_set_operators found rank-one states (Xi = v v', Xt = w w' under the
+                                      sandwich, or n x 1 states) where a vector flow exists: n = 9..16; n = 5..8 and 17..32
+                                      with member-invariant controls on large ensembles; n = 33..64 with sparse control
+                                      operators: the sweeps run on vectors; GRAPE_FLAG_FORCE_GENERAL keeps the dense chain */
     int32_t sparse_controls;       /* 1: every control operator has at most 64 non-zeros (Pauli-type controls; up to 256 --
                                       sums of a few Pauli strings, global drives -- where the longer lists pay) and the
                                       kernels that support it read (coefficient, position) lists instead of dense
