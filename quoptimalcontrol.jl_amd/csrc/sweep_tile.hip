@@ -1553,8 +1553,10 @@ bool tile_chain_is_split(const TileParams &p, bool keepl)
 // launch_nt then runs ctrl_sum_kernel only.  GRAPE_SPLIT_EXPM=0 keeps prop_hoist1_kernel + the chain that reads P_t.
 static bool split_forms_props(const TileParams &p, bool keepl)
 {
-    static const bool off = std::getenv("GRAPE_SPLIT_EXPM") && std::getenv("GRAPE_SPLIT_EXPM")[0] == '0';
-    return !off && p.hoist == 1 && tile_chain_is_split(p, keepl);
+    if (p.hoist != 1 || !tile_chain_is_split(p, keepl))
+        return false;
+    const char *e = std::getenv("GRAPE_SPLIT_EXPM");               // (read per launch, as GRAPE_HOIST2 is: tests switch it)
+    return !(e && e[0] == '0');
 }
 
 // rank-one chain: is the forward vector pass fused into the expm kernel for this launch?  (0 no, 1 yes, 2 ablation:

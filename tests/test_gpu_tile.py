@@ -168,6 +168,50 @@ def test_two_wave_chain_on_ensembles_beyond_the_resident_wave_slots(qoc, oracle,
     assert worst <= 1e-10 and np.abs(foms - foms_ref).max() <= 1e-10, (worst, np.abs(foms - foms_ref).max())
 
 
+def test_two_wave_chain_forms_its_propagators_when_the_controls_are_shared(qoc, oracle, monkeypatch):
+    """member-invariant control operators: chain_tile_split_kernel<.., EXPM> builds P_t in its phase 1 from the pre-pass's
+    control sums (no expm kernel in the launch list) and still hands out the propagators; GRAPE_SPLIT_EXPM=0 keeps
+    prop_hoist1_kernel + the chain that reads P_t -- same numbers; members with their own controls never take the fused form.
+    Large generators (squarings) included."""
+    monkeypatch.setenv("GRAPE_NO_TP", "1")
+    monkeypatch.setenv("GRAPE_NO_THIN", "1")
+    for scale, N in ((1.0, 21), (9.0, 6)):
+        w = qoc.workloads.config("C4", E=9, N=N)                        # (the control sum is hoisted from 8 members on)
+        w.A = w.A * scale
+        F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T, per_member=True)
+        res = {}
+        for fused in (True, False):
+            if fused:
+                monkeypatch.delenv("GRAPE_SPLIT_EXPM", raising=False)
+            else:
+                monkeypatch.setenv("GRAPE_SPLIT_EXPM", "0")
+            with _engine(qoc, w, max_batch=2) as eng:
+                F, G = eng.eval(w.x)
+                foms, grads = eng.member_results()
+                names = eng.kernel_names()
+                P = eng.trajectory(w.E - 1, states=False)[0]
+                Fb, Gb = eng.eval_batch(np.array([0.3 * w.x, w.x]))
+            assert any("chain_tile_split_kernel" in k for k in names) and ("prop_hoist1_kernel" in names) == (not fused), names
+            assert "ctrl_sum_kernel" in names
+            for k in range(w.E):
+                assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], w.n, what=f"fused={fused} scale={scale} member {k}")
+            assert_parity(F, G, F_ref, G_ref, w.n, what=f"fused={fused} scale={scale}")
+            assert Fb[1] == F and np.array_equal(Gb[1], G)
+            P_ref = oracle.member_eval(w.sys_type, w.A[-1], w.B[-1], w.Xi[-1], w.Xt[-1], w.x, w.T, trajectory=True)[2]
+            assert np.abs(P - P_ref).max() <= 1e-12 * max(1.0, np.abs(P_ref).max())
+            res[fused] = (F, G)
+        assert abs(res[True][0] - res[False][0]) <= 1e-12 and np.abs(res[True][1] - res[False][1]).max() <= 1e-12 * max(1.0, np.abs(G_ref).max())
+    w = qoc.workloads.config("C4", E=3, N=12)
+    w.B = w.B * np.array([1.0, 1.1, 0.9])[:, None, None, None]         # amplitude-scaled controls per member
+    monkeypatch.delenv("GRAPE_SPLIT_EXPM", raising=False)
+    with _engine(qoc, w) as eng:
+        F, G = eng.eval(w.x)
+        names = eng.kernel_names()
+    assert any(k.startswith("prop_") for k in names) and "ctrl_sum_kernel" not in names, names
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    assert_parity(F, G, F_ref, G_ref, w.n, what="per-member controls")
+
+
 def test_many_controls_keep_the_one_wave_chain(qoc, oracle, monkeypatch):
     """K = 70 dense control operators on 12 x 12 mixed states: beyond what the two-wave chain stores per slice in one instruction
     (K <= 64), the general flow stays with chain_tile_kernel -- same numbers"""
