@@ -1404,6 +1404,10 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // (C4dense, 1024 members: 6.29 ms unchunked, 6.47 .. 6.80 chunked; 256 members 1.96 -> 1.69 with the longer cap).
         // GRAPE_TP_SLOTS=m: m x CUs pairs for every case (tuning).
         long pair_cap = (c->NT == 1 && !thin) ? 32L * c->compute_units : slots, small_cap = (c->NT == 1 && herm && !thin) ? pair_cap : slots;
+        // (round 5, with the two-wave chain rewritten: C4dense-shaped general flow, chunked / two-wave chain, ms per evaluation:
+        // 512 members 2.98 / 3.93, 576: 3.53 / 3.97, 640: 3.91 / 4.10, 704: 4.29 / 4.12, 768: 4.73 / 4.16 -- the chunked flow up
+        // to 2.5 x CUs units)
+        if (general && c->NT == 1) small_cap = 5L * c->compute_units;
         if (const char *e = std::getenv("GRAPE_TP_SLOTS")) pair_cap = small_cap = std::max(1L, std::atol(e)) * c->compute_units;
         const bool small = c->family == 1 && !c->grid && 2 * units <= (thin ? slots : small_cap) && !env_on("GRAPE_NO_TP") && !may_chunk(c);
         if (small && !thin && N >= 8) {
