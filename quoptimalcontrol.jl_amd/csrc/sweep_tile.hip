@@ -677,7 +677,13 @@ __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TilePara
     double2 *__restrict__ Pw = p.props + kw * N * TSZ;             // (EXPM: phase 1 writes them)
     double2 *__restrict__ Sk = p.states + kw * N * TSZ;            // slot t: X_t (t < Nh) or L_t (t >= Nh)
     double *__restrict__ out = p.member_out + kw * ((size_t)K * N + 1);
-    constexpr int RG = 4, RB = 3;                                  // ring sizes of phase 1 / phase 2 (which keeps more matrices live)
+#ifndef GRAPE_SPLIT_RG
+#define GRAPE_SPLIT_RG 4
+#endif
+#ifndef GRAPE_SPLIT_RB
+#define GRAPE_SPLIT_RB 3
+#endif
+    constexpr int RG = GRAPE_SPLIT_RG, RB = GRAPE_SPLIT_RB;        // ring sizes of phase 1 / phase 2 (which keeps more matrices live)
     const bool fwd = part == 0;
 
     TMat<1> C, Y;                                                  // this wave's chain: X (wave 0) / L (wave 1)
