@@ -435,11 +435,16 @@ def run_extra_config(qoc, name, dev_index, steps, warmup):
     (src/solve.jl:63-143), latency-bound: the time axis is evaluated in parallel chunks."""
     dense = name.endswith("dense")
     expm = name.endswith("expm")                           # "C4expm": GRAPE_ACTION=0, the MFMA expm + vector chain flow
-    cfg_name = name[:-5] if dense else name[:-4] if expm else name
+    pm = name.endswith("pm")                               # "C4pm": the members' OWN control operators, B_k = (1 + eps_k) B --
+    cfg_name = name[:-5] if dense else name[:-4] if expm else name[:-2] if pm else name     # what EnsembleProblem.B_g is for
     members = 0
     if "x" in cfg_name:                                    # "C5x1": the config's shape with that many members
         cfg_name, members = cfg_name.split("x")[0], int(cfg_name.split("x")[1])
     w = qoc.workloads.config(cfg_name, E=members) if members else qoc.workloads.config(cfg_name)
+    if pm:                                                 # amplitude inhomogeneity (src/problems.jl:33-41, test/setup_tests.jl:31-32)
+        import numpy as np
+        w.B = np.ascontiguousarray(w.B * (1.0 + 0.05 * (np.arange(w.E) / w.E - 0.5))[:, None, None, None])
+        w.name = name
     # latency-bound lines (hundreds of ~0.1 ms steps): HIP events around one evaluation in eight, as in the headline run -- a
     # pair of events costs ~5 us of such a call
     sampled = qoc.engine.FLAG_TIME_SAMPLED if steps >= 100 else 0
@@ -469,8 +474,14 @@ def _run_extra(qoc, name, cfg_name, w, dense, expm, sampled, dev_index, steps, w
         samples = eng.kernel_samples()
         info = eng.info
         names = eng.kernel_names()
+        rows = None
+        try:                                                  # tile / grid families keep the members' rows anyway
+            rows = eng.member_results()
+        except Exception:                                     # noqa: BLE001 -- small family without the flag: a second context below
+            rows = None
     evals = steps / el
-    return {"id": name,
+    parity = spot_parity(qoc, w, rows, dense, dev_index)
+    return {"id": name, "parity": parity,
             "workload": f"{name}: {w.sys_type} {w.n}x{w.n}, K={w.K}, N={w.N}, E={w.E}, host->host grape_eval"
                         + (" (dense chain forced)" if dense else " (GRAPE_ACTION=0: expm + vector chain)" if expm else ""),
             "value": evals, "unit": "gradient-evals/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
@@ -479,7 +490,49 @@ def _run_extra(qoc, name, cfg_name, w, dense, expm, sampled, dev_index, steps, w
                                  committed_mfma(f"{name}_E{w.E}"), names)}
 
 
-def shard_overheads(qoc, cfg_name, dev_index, sizes=(512, 256, 128)):
+def spot_parity(qoc, w, rows, dense, dev_index, spots=4):
+    """The in-line parity leg of an extra config: `spots` members spread over the ensemble (first, last and
+    between), this run's per-member rows against the C oracle, at the 1e-10 bar of tests/conftest.py.  The oracle runs the
+    spot members on separate threads (OpenMP over members): a 64 x 64 member takes it tens of seconds."""
+    import numpy as np
+    from oracle import grape_oracle
+    try:
+        if rows is None:                                       # small family: rows only with GRAPE_FLAG_MEMBER_RESULTS
+            with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, device=dev_index, member_results=True,
+                                 flags=qoc.engine.FLAG_FORCE_GENERAL if dense else 0) as chk:
+                chk.eval(w.x)
+                rows = chk.member_results()
+        foms, grads = rows
+        ks = sorted(set(int(round(i * (w.E - 1) / max(spots - 1, 1))) for i in range(min(spots, w.E))))
+        sel = np.array(ks)
+        t0 = time.perf_counter()
+        _, _, foms_ref, grads_ref = grape_oracle.ensemble_eval(w.sys_type, w.A[sel], w.B[sel], w.Xi[sel], w.Xt[sel], w.wts[sel],
+                                                               w.x, w.T, per_member=True, n_threads=len(ks))
+        gerr = max(float(np.abs(grads[k] - grads_ref[i]).max() / np.abs(grads_ref[i]).max()) for i, k in enumerate(ks))
+        ferr = max(float(abs(foms[k] - foms_ref[i]) / (1e-10 * max(abs(foms_ref[i]), 1e-3 * w.n * w.n))) for i, k in enumerate(ks))
+        return {"members": ks, "max_rel_G": gerr, "max_F_err_over_tol": ferr, "tol": 1e-10,
+                "ok": bool(gerr <= 1e-10 and ferr <= 1.0), "oracle_s": time.perf_counter() - t0}
+    except Exception as exc:                                   # noqa: BLE001 -- a check must not kill the line; it says so instead
+        return {"error": repr(exc)[:120]}
+
+
+def scaling_forecast(shards, allreduce_us=15.0):
+    """What the driver's N = 2 / 4 / 8 runs should show (strong scaling: every GPU a contiguous 1/N of the members, one
+    all-reduce of K N + 1 doubles per step), predicted from the shard steps timed on THIS GPU: evals/s = 1 / (shard step +
+    allowance).  allreduce_us is an allowance, not a measurement: a 16-96 KB all-reduce over xGMI is latency-bound (an 8-rank
+    ring is 14 hops); nobody has timed it on this pool (SCALE has been skipped every round)."""
+    out = {"allreduce_allowance_us": allreduce_us}
+    for cfg, sh in shards.items():
+        if not isinstance(sh, dict) or "error" in sh:
+            continue
+        row = {}
+        for n_gpus, key in zip((2, 4, 8), sorted(sh.keys(), key=lambda s: -int(s[1:]))):
+            row[str(n_gpus)] = 1.0 / (1e-3 * sh[key]["ms_per_step"] + 1e-6 * allreduce_us)
+        out[cfg] = row
+    return out
+
+
+def shard_overheads(qoc, cfg_name, dev_index, sizes=(512, 256, 128), steps=300):
     """What a GPU of an N-GPU strong-scaling run does per step, timed on this one: the config's ensemble cut to the shard
     sizes of 2 / 4 / 8 GPUs, host -> host grape_eval, next to the shard's sweep-kernel time.  fixed_overhead_us = the part
     that does not shrink with the shard (x upload, launches, the reduce, publication, host turnaround): an N-GPU step
@@ -492,11 +545,10 @@ def shard_overheads(qoc, cfg_name, dev_index, sizes=(512, 256, 128)):
                              flags=qoc.engine.FLAG_TIME_KERNELS | qoc.engine.FLAG_TIME_SAMPLED) as eng:   # (an event pair costs ~5 us: every 8th call, as the headline)
             xf = np.ascontiguousarray(w.x.T)
             call = eng.bind_eval(xf, np.empty_like(xf))
-            for _ in range(20):
+            for _ in range(min(20, steps)):
                 call()
             clock_ramp(call, 0.15)
             eng.kernel_time(reset=True)
-            steps = 300
             t0 = time.perf_counter()
             for _ in range(steps):
                 call()
@@ -661,16 +713,33 @@ def compact(out):
     if isinstance(ex.get("shard_fixed_overhead"), dict):
         cx["shard_ms_kernel_us"] = {k: ([_r(v["ms_per_step"]), _r(v["sweep_kernel_us"])] if "ms_per_step" in v else v)
                                     for k, v in ex["shard_fixed_overhead"].items()}
+    if isinstance(ex.get("scaling_forecast"), dict):
+        cx["scaling_forecast"] = {k: ({kk: _r(vv, 4) for kk, vv in v.items()} if isinstance(v, dict) else v)
+                                  for k, v in ex["scaling_forecast"].items()}
     if cx:
         c["extra"] = cx
     if "extra_configs" in out:
         c["extra_configs"] = []
+        c["extra_parity_columns"] = "spot members, max rel G err, max F err / tol, ok (vs the C oracle, tol 1e-10)"
         for e in out["extra_configs"]:
             if "error" in e:
                 c["extra_configs"].append({"id": e.get("workload"), "error": e["error"][:120]})
                 continue
+            par = e.get("parity") or {}
+            cpar = ([len(par["members"]), _r(par["max_rel_G"], 2), _r(par["max_F_err_over_tol"], 2), par["ok"]]
+                    if "members" in par else {"error": par.get("error", "none")})
+            if e["id"].endswith("pm"):                  # per-member controls: the rate, its ratio to the shared-controls line, kernels
+                base = next((b for b in out["extra_configs"] if b.get("id") == e["id"][:-2]), None)
+                base_v = base["value"] if base else (out["value"] if e["id"][:-2] == out["config"]["workload"].split(":")[0] else None)
+                c["extra_configs"].append({"id": e["id"], "value": _r(e["value"], 5), "ms_per_step": _r(e["ms_per_step"], 5),
+                                           "vs_shared_controls": _r(e["value"] / base_v, 3) if base_v else None,
+                                           "kernel": e["roofline"].get("kernel"), "parity": cpar})
+                continue
             c["extra_configs"].append({"id": e["id"], "value": _r(e["value"], 5), "ms_per_step": _r(e["ms_per_step"], 5),
-                                       "steps": e["steps"], "roofline": compact_roofline(e["roofline"])})
+                                       "steps": e["steps"], "roofline": compact_roofline(e["roofline"]), "parity": cpar})
+    for k in ("ranks_seen", "rank_kernel_us"):
+        if k in out:
+            c[k] = out[k] if k == "ranks_seen" else {kk: _r(vv) for kk, vv in out[k].items()}
     c["F"] = out.get("F")
     return c
 
@@ -707,7 +776,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the device-resident loop and the extra configs")
-    ap.add_argument("--extra-configs", default="C4,C5,C4dense,C4expm,C6,C2,C5x1,C4x1")
+    ap.add_argument("--extra-configs", default="C4,C5,C4dense,C4expm,C6,C2,C5x1,C4x1,C3pm,C4pm,C5pm")
     ap.add_argument("--details", default="", help="also write the complete record (every note, per-kernel model, L-BFGS traces) "
                                                   "to this file; the printed line stays compact")
     ap.add_argument("--verbose", action="store_true", help="print the complete record instead of the compact line")
@@ -802,6 +871,12 @@ def main():
     info = sg.local.info if sg.local is not None else {}
     names = sg.local.kernel_names() if sg.local is not None and hasattr(sg.local, "kernel_names") else []
     elapsed = statistics.median(block_s)
+    rank_kernel = None
+    if world > 1:                                  # every rank's own sweep-kernel time (median of its HIP-event samples): min / max over ranks
+        mine = float(np.median(samples[0]) * 1e3) if len(samples[0]) else float("nan")
+        t = torch.tensor([mine, -mine], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        rank_kernel = {"min": float(t[0].item()), "max": float(-t[1].item())}
 
     # ---- the device-resident pipelined loop round 1 reported (x and [G,F] stay in HBM, one sync at the end)
     extra = None
@@ -910,6 +985,10 @@ def main():
         }
         if extra is not None:
             out["extra"] = extra
+        if world > 1 or args.force_dist:
+            out["ranks_seen"] = n_joined           # the communicator's own count (ncclCommCount / the mailbox group), not WORLD_SIZE
+            if rank_kernel:
+                out["rank_kernel_us"] = rank_kernel
         if world == 1 and not args.no_cpu_baseline:
             cb, (foms_ref, grads_ref) = cpu_baseline(w, args.cpu_seconds, args.cpu_sample)
             out["cpu_baseline"] = cb
@@ -937,11 +1016,20 @@ def main():
             out["extra"]["shard_fixed_overhead"] = shard_overheads(qoc, args.config, dev_index)
         except Exception as exc:                   # noqa: BLE001
             out["extra"]["shard_fixed_overhead"] = {"error": repr(exc)}
+        shards = {args.config: out["extra"]["shard_fixed_overhead"]}
+        for cfg, sizes, st in (("C4", (512, 256, 128), 20), ("C5", (2048, 1024, 512), 3)):
+            if cfg == args.config or cfg not in args.extra_configs.split(","):
+                continue
+            try:
+                shards[cfg] = shard_overheads(qoc, cfg, dev_index, sizes, st)
+            except Exception as exc:               # noqa: BLE001
+                shards[cfg] = {"error": repr(exc)}
+        out["extra"]["scaling_forecast"] = scaling_forecast(shards)
     if rank == 0 and world == 1 and not args.no_extra and args.extra_configs:
         out["extra_configs"] = []
         for name in [s for s in args.extra_configs.split(",") if s and s != args.config]:
-            heavy = name in ("C4", "C4dense", "C4expm", "C5", "C6")
-            slow = name in ("C5", "C6")
+            heavy = name in ("C4", "C4dense", "C4expm", "C5", "C6", "C4pm", "C5pm")
+            slow = name in ("C5", "C6", "C5pm")
             try:
                 out["extra_configs"].append(run_extra_config(qoc, name, dev_index, 3 if slow else (20 if heavy else 200),
                                                              1 if slow else (3 if heavy else 20)))

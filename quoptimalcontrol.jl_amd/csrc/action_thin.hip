@@ -1194,7 +1194,7 @@ static hipError_t launch_action_nb(int sandwich, const TileParams &p, hipStream_
                                   : action_thin_kernel)
                          : action_thin2_kernel;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = ensure_dynamic_lds((const void *)kern, lds);
         if (e != hipSuccess)
             return e;
     }

@@ -83,6 +83,9 @@ struct grape_ctx {
     size_t ws_unit = 0;           // double2 elements of one unit's share of a workspace array
     size_t ws_budget = 0;         // bytes the workspace arrays may take: GRAPE_MAX_WORKSPACE_BYTES, else 0.9 x free memory - the rest
     int ws_arrays = 1;            // arrays the current plan was made for (props [+ costates] [+ states])
+    bool ws_invalid = false;      // a re-plan freed props / costates and could not allocate them again: the next
+    bool ws_keep_costates = false; //   grape_set_operators plans and allocates afresh (with this costate wish)
+    int test_fail_replan = 0;     // tests: that allocation fails this many times (GRAPE_TEST_FAIL_REPLAN)
     int ws_B = 1;                 // control arrays the workspace holds: max_batch, or 1 when that does not fit (a batch then runs
                                   // its arrays one behind the other, as it does on a member-chunked workspace)
     uint64_t bytes = 0;
@@ -428,6 +431,32 @@ static void free_all(grape_ctx *c)
     delete c;
 }
 
+namespace grape {
+hipError_t ensure_dynamic_lds(const void *fn, size_t lds)
+{
+    struct Granted { const void *fn; int dev; size_t lds; };
+    static std::mutex mu;
+    static std::vector<Granted> table;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    std::lock_guard<std::mutex> lock(mu);
+    for (Granted &g : table)
+        if (g.fn == fn && g.dev == dev) {
+            if (lds <= g.lds)
+                return hipSuccess;
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess)
+                g.lds = lds;
+            return e;
+        }
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+        table.push_back({fn, dev, lds});
+    return e;
+}
+}  // namespace grape
+
 extern "C" int grape_abi_version(void) { return GRAPE_ABI_VERSION; }
 
 extern "C" const char *grape_last_error(const grape_ctx *ctx)
@@ -481,23 +510,27 @@ static int validate_config(const grape_config *cfg)
 // not depend on where the chunks are cut.  false: not even one granule fits.
 static bool plan_chunk(grape_ctx *c, int arrays)
 {
+    // (every field is committed at the end: a plan that does not fit leaves the context as it was)
     const size_t E = (size_t)c->cfg.n_ensemble, unit_bytes = sizeof(double2) * c->ws_unit * (size_t)arrays;
     const size_t units = c->family == 0 ? E : (size_t)c->EU;
-    c->ws_arrays = arrays;
-    c->ws_B = c->B;
+    int ws_B = c->B, Ec, EUc;
     if (unit_bytes * units * (size_t)c->B <= c->ws_budget) {
-        c->Ec = (int)E;
-        c->EUc = c->EU;
+        Ec = (int)E;
+        EUc = c->EU;
     } else {
-        c->ws_B = 1;
+        ws_B = 1;
         size_t fit = c->ws_budget / unit_bytes;                      // units of one control array
         const size_t gran = c->family == 0 ? (size_t)c->MPB : (c->pack2 ? 1 : 2);
         fit = fit / gran * gran;
         if (fit < gran) return false;
         if (fit > units) fit = units;
-        c->EUc = (int)fit;
-        c->Ec = c->family == 1 && c->pack2 ? (int)std::min(E, 2 * fit) : (int)fit;
+        EUc = (int)fit;
+        Ec = c->family == 1 && c->pack2 ? (int)std::min(E, 2 * fit) : (int)fit;
     }
+    c->ws_arrays = arrays;
+    c->ws_B = ws_B;
+    c->Ec = Ec;
+    c->EUc = EUc;
     c->ws_elems = c->ws_unit * (size_t)(c->family == 0 ? c->Ec : c->EUc);
     return true;
 }
@@ -625,10 +658,14 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
         // workspace budget: what is free now minus what is allocated besides the workspace arrays (operators, rows, staging;
         // twice, for the buffers grape_set_operators adds), 90 % of it.  GRAPE_MAX_WORKSPACE_BYTES overrides (tests).
         size_t free_b = 0, total_b = 0;
-        (void)hipMemGetInfo(&free_b, &total_b);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b == 0) {   // no figure: plan for the whole device and let
+            hipDeviceProp_t pr{};                                            // the allocations below decide
+            free_b = hipGetDeviceProperties(&pr, c->device) == hipSuccess ? pr.totalGlobalMem : ~(size_t)0 >> 1;
+        }
         const size_t rest = 2 * (sizeof(double2) * ops_elems + sizeof(double) * (size_t)E * Q * c->B) + ((size_t)64 << 20);
         c->ws_budget = free_b > rest ? (size_t)(0.9 * (double)(free_b - rest)) : 0;
         if (const char *ev = std::getenv("GRAPE_MAX_WORKSPACE_BYTES")) c->ws_budget = (size_t)std::strtoull(ev, nullptr, 10);
+        if (const char *ev = std::getenv("GRAPE_TEST_FAIL_REPLAN")) c->test_fail_replan = std::atoi(ev);
         // optimistic plan: the propagators (and the costates when asked for); grape_set_operators plans again when the flow
         // it chooses stores the forward states as well
         if (!plan_chunk(c, 1 + (keepl ? 1 : 0))) {
@@ -1653,24 +1690,36 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         // per chunk change, the arrays are allocated afresh (the vector flows' records and the chunked time axis only ever
         // serve ensembles far below any budget).
         const bool full_states = !thin && (!herm || c->exact_w1);
-        const int arrays = 1 + (c->d_costates ? 1 : 0) + (full_states ? 1 : 0);
+        // (ws_invalid: an earlier re-plan freed the arrays and its allocation failed -- plan and allocate again, with the
+        // costate wish it had recorded: the pointers no longer tell)
+        const bool keep = c->ws_invalid ? c->ws_keep_costates : c->d_costates != nullptr;
+        const int arrays = 1 + (keep ? 1 : 0) + (full_states ? 1 : 0);
         const int had = c->Ec, had_B = c->ws_B;
-        if (arrays != c->ws_arrays) {
+        if (arrays != c->ws_arrays || c->ws_invalid) {
             if (!plan_chunk(c, arrays))
                 return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: the workspace of this data flow does not fit the budget of " +
                                                     std::to_string(c->ws_budget) + " bytes even for one workgroup's members");
-            if (c->Ec != had || c->ws_B != had_B) {
-                const size_t old_b = sizeof(double2) * c->ws_unit * (size_t)(c->family == 0 ? had : (c->pack2 ? (had + 1) / 2 : had)) * (size_t)had_B;
+            if (c->Ec != had || c->ws_B != had_B || c->ws_invalid) {
                 const size_t new_b = sizeof(double2) * c->ws_elems * ws_batch(c);
-                (void)hipFree(c->d_props); c->d_props = nullptr;
-                (void)hipFree(c->d_states); c->d_states = nullptr;
-                c->bytes -= c->states_bytes + old_b;
-                c->states_bytes = 0;
-                const bool keep = c->d_costates != nullptr;
-                if (keep) { (void)hipFree(c->d_costates); c->d_costates = nullptr; c->bytes -= old_b; }
+                if (!c->ws_invalid) {
+                    const size_t old_b = sizeof(double2) * c->ws_unit * (size_t)(c->family == 0 ? had : (c->pack2 ? (had + 1) / 2 : had)) * (size_t)had_B;
+                    (void)hipFree(c->d_props); c->d_props = nullptr;
+                    (void)hipFree(c->d_states); c->d_states = nullptr;
+                    c->bytes -= c->states_bytes + old_b;
+                    c->states_bytes = 0;
+                    if (keep) { (void)hipFree(c->d_costates); c->d_costates = nullptr; c->bytes -= old_b; }
+                    c->ws_invalid = true;
+                    c->ws_keep_costates = keep;
+                    c->ops_set = false;                       // no evaluation on freed arrays, whatever happens below
+                }
+                if (c->test_fail_replan > 0) {                // test hook (GRAPE_TEST_FAIL_REPLAN at grape_create)
+                    --c->test_fail_replan;
+                    return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: workspace allocation failed (GRAPE_TEST_FAIL_REPLAN)");
+                }
                 HIP_TRY(c, hipMalloc((void **)&c->d_props, new_b));
                 c->bytes += new_b;
-                if (keep) { HIP_TRY(c, hipMalloc((void **)&c->d_costates, new_b)); c->bytes += new_b; }
+                if (keep && !c->d_costates) { HIP_TRY(c, hipMalloc((void **)&c->d_costates, new_b)); c->bytes += new_b; }
+                c->ws_invalid = false;
             }
         }
         if (chunked(c) && (c->tp_C || c->thin_dpp))
@@ -1910,7 +1959,11 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     const bool exact = c->cfg.gradient == GRAPE_GRADIENT_EXACT;
     if (exact) p.member_out = nullptr;                       // the sweep's first-order rows are not wanted
     // one workgroup holds the whole ensemble (single problems): its row is [G, F], no reduce launch
-    const bool direct = c->family == 0 && c->NB == 1 && n_x == 1 && !exact && c->direct_publish && !done.probe_out;
+    // (done.stage_base: this evaluation is the last array of a batch that runs array by array -- its publication has to
+    // copy out the WHOLE staging buffer, which only the reduce kernels do: no self-closing sweep / fold then)
+    const bool direct = c->family == 0 && c->NB == 1 && n_x == 1 && !exact && c->direct_publish && !done.probe_out &&
+                        !done.stage_base;
+    const bool fold = !done.stage_base && tile_folds_reduce(c, n_x);
     if (direct) {
         p.direct_dst = done.flag && done.host_out ? done.host_out : d_fg;
         p.direct_flag = done.flag;
@@ -1999,7 +2052,7 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
             }
         }
         t.ev_mid = lo == 0 ? emid : nullptr;
-        if (d_fg && tile_folds_reduce(c, n_x)) {
+        if (d_fg && fold) {
             t.fold_fg = d_fg;
             t.fold_wts = c->d_wts;
             t.fold_done = done;
@@ -2020,7 +2073,7 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     if (exact)
         HIP_TRY(c, grape::launch_reduce(c->d_member_out, c->d_wts, c->d_partial, d_fg, p.E, (int)(KN(c) + 1), c->ksplit,
                                         stream, done));
-    else if (direct || tile_folds_reduce(c, n_x))
+    else if (direct || fold)
         ;                                                    // the sweep / forms kernel has written [G, F] (and the flag)
     else if (c->family == 0) {
         if (done.mflags && done.flag && done.host_out && !done.probe_out)
@@ -2035,8 +2088,10 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
             grape::DoneSignal db;
             if (b == n_x - 1 && done.flag) {
                 db = done;
-                db.stage_base = d_fg;
-                db.n_total = (int)(Qs * n_x);
+                if (!db.stage_base) {                        // (set already: the last array of a batch run array by array)
+                    db.stage_base = d_fg;
+                    db.n_total = (int)(Qs * n_x);
+                }
             }
             HIP_TRY(c, grape::launch_reduce(c->d_member_out + (size_t)b * p.E * Qs, c->d_wts, c->d_partial,
                                             d_fg + (size_t)b * Qs, p.E, (int)Qs, c->ksplit, stream, db));

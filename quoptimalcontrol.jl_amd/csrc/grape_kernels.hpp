@@ -97,7 +97,13 @@ struct SweepParams {
     // -- all that exact_pair_kernel needs of the trajectory (no debug flow, no X_t / L_t dumps)
     int32_t dump_w1;
     double *zphi;         // (2 per member and control array) Phi = tr(L' X) = tr M
+    int32_t tune;         // pair kernel, set by its launcher from GRAPE_PAIR_TUNE (tuning experiments; 0 in the product)
 };
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of once per launch: the driver call sits
+// on the host's critical path in front of an evaluation's launches (grape_api.cpp; thread-safe: group contexts launch from one
+// thread per shard).  Returns hipSuccess without a call when `lds` is within what the kernel was already granted there.
+hipError_t ensure_dynamic_lds(const void *fn, size_t lds);
 
 // sandwich == 0: UnitaryGate chain; 1: State/CoherenceTransfer sandwich chain.
 // mode: 0 general flow, 1 general flow + costates stored (debug), 2 unitary flow (all

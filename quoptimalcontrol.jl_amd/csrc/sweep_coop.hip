@@ -507,7 +507,7 @@ hipError_t launch_coop_chain_unitary(int sandwich, const TileParams &q, hipStrea
     const size_t lds = coop_chain_lds(q);
     auto kern = sandwich ? coop_chain_unitary_kernel<1> : coop_chain_unitary_kernel<0>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = ensure_dynamic_lds((const void *)kern, lds);
         if (e != hipSuccess)
             return e;
     }

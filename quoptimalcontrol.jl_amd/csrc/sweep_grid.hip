@@ -905,12 +905,12 @@ static hipError_t launch_grid_exact_nt(int sandwich, const TileParams &p, int ob
     const dim3 grid(p.N, p.E), block(64 * NT * NT);
     hipError_t e;
     if (sandwich) {
-        e = hipFuncSetAttribute((const void *)grid_exact_kernel<NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = ensure_dynamic_lds((const void *)grid_exact_kernel<NT, 1>, lds);
         if (e != hipSuccess)
             return e;
         GRAPE_LAUNCH((grid_exact_kernel<NT, 1>), grid, block, lds, stream, p, objective);
     } else {
-        e = hipFuncSetAttribute((const void *)grid_exact_kernel<NT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = ensure_dynamic_lds((const void *)grid_exact_kernel<NT, 0>, lds);
         if (e != hipSuccess)
             return e;
         GRAPE_LAUNCH((grid_exact_kernel<NT, 0>), grid, block, lds, stream, p, objective);
@@ -943,12 +943,12 @@ static hipError_t launch_grid_prop_nt(const TileParams &p, hipStream_t stream)
         e = launch_ctrl_sum(NT, q, stream);
         if (e != hipSuccess)
             return e;
-        e = hipFuncSetAttribute((const void *)grid_prop_kernel<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+        e = ensure_dynamic_lds((const void *)grid_prop_kernel<NT, true>, lds_p);
         if (e != hipSuccess)
             return e;
         GRAPE_LAUNCH((grid_prop_kernel<NT, true>), pgrid, dim3(64 * NT * NT), lds_p, stream, q);
     } else {
-        e = hipFuncSetAttribute((const void *)grid_prop_kernel<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+        e = ensure_dynamic_lds((const void *)grid_prop_kernel<NT, false>, lds_p);
         if (e != hipSuccess)
             return e;
         GRAPE_LAUNCH((grid_prop_kernel<NT, false>), pgrid, dim3(64 * NT * NT), lds_p, stream, q);
@@ -992,8 +992,7 @@ static hipError_t launch_grid_nt(int sandwich, bool keepl, const TileParams &p, 
     }
 #define GRAPE_GRID_CHAIN(S, KL, SP)                                                                                      \
     {                                                                                                                    \
-        e = hipFuncSetAttribute((const void *)grid_chain_kernel<NT, S, KL, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds_c);                                                                             \
+        e = ensure_dynamic_lds((const void *)grid_chain_kernel<NT, S, KL, SP>, lds_c);                                                                             \
         if (e != hipSuccess)                                                                                             \
             return e;                                                                                                    \
         GRAPE_LAUNCH((grid_chain_kernel<NT, S, KL, SP>), grid, block, lds_c, stream, q);                                 \

@@ -26,6 +26,21 @@
 #ifndef GRAPE_ABL
 #define GRAPE_ABL 0          // diagnostic ablation bitmask (tools/ablate.sh); 0 in the product build
 #endif
+#ifndef GRAPE_PD
+#define GRAPE_PD 2           // unitary backward sweep: 0 = load one slice ahead in front of each step; 1 = products / gradient
+#endif                       // split, the slice after next loaded as soon as the products have released its buffer
+#ifndef GRAPE_PLAYOUT
+#define GRAPE_PLAYOUT 0
+#endif
+#ifndef GRAPE_PD_EARLY
+#define GRAPE_PD_EARLY 2     // GRAPE_PD == 2: slices requested before the scan (0, 1, 2)
+#endif
+#ifndef GRAPE_PD_EARLY_AT
+#define GRAPE_PD_EARLY_AT 0  // where: 0 = straight after phase A, 1 = behind the scan's first barrier
+#endif
+#ifndef GRAPE_MBAR
+#define GRAPE_MBAR 2         // scan barriers: 0 = __syncthreads() (all members of the workgroup), 1 = per-member LDS counters,
+#endif                       // 2 = workgroup barrier that waits for LDS only (not for the P_t stores / prefetches in flight)
 
 namespace grape {
 
@@ -93,6 +108,76 @@ GRAPE_DEV void pstamp(unsigned long long *__restrict__ st, int slot)
         if ((threadIdx.x & 63) == 0)
             st[slot] = t;
     }
+}
+
+// A propagator's own half as the eight 16-byte loads deliver it, loaded OUTSIDE the compiler's s_waitcnt bookkeeping (inline asm):
+// the compiler drains every outstanding load in front of a loop's back edge, i.e. it waits for the prefetch it has just issued,
+// and the backward sweep then exposes one full memory latency per slice (tools: build/abl pd0..pd3 of round 4).  Here the
+// kernel counts itself: pbuf_issue() = 8 loads, pbuf_wait<N>() = "all but the N youngest have landed"; the wait takes the
+// buffer as an in/out operand so that no read of it can move in front of the wait.
+typedef double d2v __attribute__((ext_vector_type(2)));
+struct PBuf {
+    d2v v[8];          // element e = r + 4 jl of the lane's half (PMat<4> order)
+};
+
+// element (r, jl) of a lane of parity q sits (2 ((r >> 1) ^ q) + 8 q) + ((r & 1) + 4 jl) rows of CH*16 bytes into the slice:
+// the first part is the lane's (voff[r >> 1], with the chunk's 16 ch bytes), the second is uniform (sb[(r & 1) + 4 jl])
+GRAPE_DEV void pbuf_issue(PBuf &b, unsigned voff0, unsigned voff1, const double2 *sb0, const double2 *sb1, const double2 *sb4,
+                          const double2 *sb5)
+{
+    asm volatile("global_load_dwordx4 %0, %8, %10\n\t"
+                 "global_load_dwordx4 %1, %8, %11\n\t"
+                 "global_load_dwordx4 %2, %9, %10\n\t"
+                 "global_load_dwordx4 %3, %9, %11\n\t"
+                 "global_load_dwordx4 %4, %8, %12\n\t"
+                 "global_load_dwordx4 %5, %8, %13\n\t"
+                 "global_load_dwordx4 %6, %9, %12\n\t"
+                 "global_load_dwordx4 %7, %9, %13"
+                 : "=&v"(b.v[0]), "=&v"(b.v[1]), "=&v"(b.v[2]), "=&v"(b.v[3]), "=&v"(b.v[4]), "=&v"(b.v[5]), "=&v"(b.v[6]),
+                   "=&v"(b.v[7])
+                 : "v"(voff0), "v"(voff1), "s"(sb0), "s"(sb1), "s"(sb4), "s"(sb5)
+                 : "memory");
+}
+
+template <int YOUNGER>
+GRAPE_DEV void pbuf_wait(PBuf &b)
+{
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]), "+v"(b.v[4]), "+v"(b.v[5]), "+v"(b.v[6]), "+v"(b.v[7])
+                 : "n"(YOUNGER)
+                 : "memory");
+}
+
+GRAPE_DEV void pbuf_to_mat(PMat<4> &m, const PBuf &b)
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        m.re[e] = b.v[e][0];
+        m.im[e] = b.v[e][1];
+    }
+}
+
+// Barrier among the W waves of ONE member (the scan's exchanges never cross members): an LDS counter per member, every wave adds
+// one and polls until `target` arrivals.  Unlike __syncthreads() it neither couples the members of a workgroup nor waits for
+// this wave's global stores (the P_t of phase A are still draining when the scan starts).  LDS operations of a CU execute in
+// order, so a wave that reads the count also sees what the arriving waves wrote before they added.
+GRAPE_DEV void member_barrier(unsigned *cnt, unsigned target)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0)
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+        __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+// workgroup barrier for exchanges through LDS only: the wave's own LDS operations drained, then s_barrier (__syncthreads()
+// also waits for every global store / load in flight)
+GRAPE_DEV void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 template <int N, int SAND>
@@ -173,6 +258,9 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
     constexpr int MAXW = MAXT / 64;
     constexpr bool UNI = (MODE == PMODE_UNITARY);
     constexpr bool KEEPL = (MODE == PMODE_GENERAL_KEEPL);
+    // the backward sweep counts its own propagator loads (PBuf): only where they are the sweep's ONLY vector-memory operations
+    // -- gradient entries staged in LDS (XGLDS), no W_t dump
+    constexpr bool PDASM = (GRAPE_PD == 2) && UNI && N == 4 && !DUMPW && XGLDS;
     // dynamic LDS:  s_tot  2*MAXW*NN double2   wave totals of the two scans (both parity halves)
     //               s_ops  MPB * 2 * PS double2, PS = NM * NE + 8: parity images of the members' operators (the pad puts the
     //                      two parities' images half an LDS row apart: a wave reads BOTH addresses in one instruction)
@@ -200,7 +288,8 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
     const size_t stride = (size_t)CH;
     const int NM = 2 * K + 4;                     // images: A', B'_c, B'_c^T, Xi, Xt, and Xi Xt' (built in the prologue)
 
-    double2 *s_ops_all = s_dyn + 2 * MAXW * NN;
+    unsigned *s_cnt = reinterpret_cast<unsigned *>(s_dyn + 2 * MAXW * NN);      // per-member arrival counters (4 double2 = 16 words)
+    double2 *s_ops_all = s_dyn + 2 * MAXW * NN + 4;
     const int PS = NM * NE + kParityPad;          // stride between the two parity images of a member
     double2 *s_ops = s_ops_all + (size_t)mb * 2 * PS;
     const int SK = S * K;
@@ -215,6 +304,14 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
     double *s_nrm = reinterpret_cast<double *>(s_ops_all + (size_t)p.MPB * 2 * PS) + (size_t)mb * (K + 1);
     const unsigned magic = p.sk_magic;
     auto chunk_of = [&](int q) { return SK == 1 ? q : (int)__umulhi((unsigned)q, magic); };
+    if (threadIdx.x < 16)
+        s_cnt[threadIdx.x] = 0u;
+    if (p.tune & 7) {                                 // diagnostic / tuning: which waves of a SIMD go first (s_setprio)
+        const int sel = p.tune & 7;
+        const bool hi = sel == 1 ? (mb & 1) : sel == 2 ? (mb & 2) : sel == 3 ? (blockIdx.x & 1) : sel == 4 ? ((threadIdx.x >> 6) & 1) : false;
+        if (hi)
+            __builtin_amdgcn_s_setprio(2);
+    }
     {
         const double *__restrict__ xsrc = x_all + (size_t)xi * K * Nsl;
         const int KNs = K * Nsl;
@@ -287,7 +384,10 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
     const double2 *sXX = sXt + NE, *sXX_o = sXt_o + NE;
     double *xg = s_xg + ch * (SK + 1);
     const size_t wbase = (size_t)k * S * NN * stride + ch;
-    double2 *__restrict__ Pw = p.props + wbase;
+    // GRAPE_PLAYOUT 1 (experiment): propagators slice-major over the launch's members -- all waves work on the same slice
+    // index at the same time, and member-major puts their 16 KB blocks 16 S KB apart
+    const size_t pstep = GRAPE_PLAYOUT ? (size_t)p.E * p.n_x * NN * stride : (size_t)NN * stride;
+    double2 *__restrict__ Pw = p.props + (GRAPE_PLAYOUT ? (size_t)k * NN * stride + ch : wbase);
     double2 *__restrict__ Xw = p.states + wbase;
     double *__restrict__ out = p.member_out + (size_t)k * ((size_t)K * Nsl + 1);
     const int t0 = ch * S;
@@ -359,7 +459,7 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
         pexpm_t8<N, UNI>(P, G, p.s_forced, nb);
         __builtin_amdgcn_sched_barrier(0);
         if (!(GRAPE_ABL & 2))
-        pstore_ws(Pw + (size_t)j * NN * stride, stride, P, par);
+        pstore_ws(Pw + (size_t)j * pstep, stride, P, par);
         if (UNI && XGLDS && p.plast_lds && j == S - 1) {          // the backward sweep's first operand stays on chip
 #pragma unroll
             for (int e = 0; e < NE; ++e)
@@ -406,6 +506,30 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
     }
 
     pstamp(st, 1);
+#if GRAPE_PD == 2
+    // backward sweep's propagator ring (see PBuf): addresses, and with GRAPE_PD_EARLY the first one or two slices requested
+    // BEFORE the scan -- HBM is idle during phase B and the sweep then has two slices fewer to wait for
+    PBuf bA, bB;
+    const unsigned pd_rowb = (unsigned)CH * 16u;
+    const unsigned pd_voff0 = (unsigned)(10 * par) * pd_rowb + (unsigned)ch * 16u;
+    const unsigned pd_voff1 = (unsigned)(2 + 6 * par) * pd_rowb + (unsigned)ch * 16u;
+    const double2 *pd_Pk = p.props + (size_t)k * (GRAPE_PLAYOUT ? 1 : S) * NN * stride;   // wave-uniform
+    auto pd_issue = [&](PBuf &b, int jj) {
+        const double2 *s0 = pd_Pk + (size_t)max(jj, 0) * pstep;
+        pbuf_issue(b, pd_voff0, pd_voff1, s0, s0 + CH, s0 + 4 * CH, s0 + 5 * CH);
+    };
+    // (no wait in front: phase A's stores may still be draining; the sweep starts with vmcnt(0), which covers both)
+    auto pd_early = [&]() {
+        if constexpr (PDASM && GRAPE_PD_EARLY >= 1) {
+            const int jm0 = (XGLDS && p.plast_lds) ? S - 2 : S - 1;
+            pd_issue(bA, jm0);
+            if (GRAPE_PD_EARLY >= 2)
+                pd_issue(bB, jm0 - 1);
+        }
+    };
+    if (W == 1 || GRAPE_PD_EARLY_AT == 0)
+        pd_early();
+#endif
     // ---------------------------------------------------------------- phase B
     // Kogge-Stone over the 32 chunks of a wave (shuffle distance 2d lanes keeps the parity), wave totals
     // through LDS.  Unitary flow: M at the chunk end from the inclusive prefix U and the total T;
@@ -430,7 +554,16 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
         if (W > 1) {
             if (cw == 31)
                 pstore_lds(&s_tot[0][wbase_tot + wave][par * NE], inc);
-            __syncthreads();
+            if (GRAPE_MBAR == 1 && UNI)
+                member_barrier(&s_cnt[mb], (unsigned)W);
+            else if (GRAPE_MBAR == 2 && UNI)
+                lds_barrier();
+            else
+                __syncthreads();
+#if GRAPE_PD == 2
+            if (GRAPE_PD_EARLY_AT == 1)                 // every wave of the workgroup has left phase A
+                pd_early();
+#endif
             if (wave > 0) {                          // (wave is uniform: the first wave's prefix is the identity -- nothing to do)
                 PMat<N> pre, wt, wtp;
                 pload_lds(pre, &s_tot[0][wbase_tot][par * NE]);          // total of wave 0
@@ -454,7 +587,12 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
         if (UNI) {
             if (ch == CH - 1)
                 pstore_lds(&s_tot[1][wbase_tot][par * NE], inc);
-            __syncthreads();
+            if (GRAPE_MBAR == 1)
+                member_barrier(&s_cnt[mb], (unsigned)(W > 1 ? 2 * W : W));
+            else if (GRAPE_MBAR == 2)
+                lds_barrier();
+            else
+                __syncthreads();
             PMat<N> T, Tp, C0, xi_m, xi_o, xt_m, xt_o;
             pload_lds(T, &s_tot[1][wbase_tot][par * NE]);
             if (SAND) {
@@ -603,8 +741,8 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
                 PA.re[e] = v.x;
                 PA.im[e] = v.y;
             }
-        } else {
-            pload_ws(PA, Pw + (size_t)(S - 1) * NN * stride, stride, par);
+        } else if (!PDASM) {
+            pload_ws(PA, Pw + (size_t)(S - 1) * pstep, stride, par);
         }
         // (Round 4, ISA: the compiler's s_waitcnt pass waits with vmcnt(0) in front of BOTH steps -- for the prefetch it has
         // just issued -- because the second load sits behind `if (j >= 2)` and PA enters the loop from LDS on one path and
@@ -613,15 +751,136 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
         // sixteen 1 KB loads in flight per wave instead of eight, 128 KB per CU against a 32 KB L1.  The drain is what
         // paces phase D at the rate HBM delivers; left as it was.)
         int j = S - 1;
+#if GRAPE_PD == 1
+        // products and gradient of a slice apart: the products are the last readers of the slice's propagator, so the load of
+        // the slice after next goes out between them -- unconditionally, from a clamped (always valid) address, so that the
+        // compiler's s_waitcnt bookkeeping sees the same history on every path and waits for the OLDER buffer only
+        auto products = [&](int jj, const PMat<N> &P) {
+            if (t0 + jj < Nsl) {
+                fetch_partner(Pp, P);
+                fetch_partner(Mp, M);
+                pmul(tmp, M, Mp, P);
+                pmul_ah_b(M, P, Pp, tmp);            // M_t = P' M_{t+1} P
+            }
+        };
+        auto gradient = [&](int jj) {
+            const int t = t0 + jj;
+            if (t < Nsl) {
+                if (!SAND) {
+                    double tr_r, tr_i;
+                    ptrace(tr_r, tr_i, M);
+                    zr = tr_r;
+                    zi = -tr_i;
+                }
+                pwrite_gradient<N, SAND>(xg + jj * K, sBT, K, M, zr, zi, gs, par);
+                if (t == Nsl - 1 && par == 0)
+                    s_F[mb] = pfigure_of_merit<N, SAND>(zr, zi);
+            }
+        };
+        if (DUMPW) {
+            for (; j >= 0; --j) {
+                if (j < S - 1 || !(XGLDS && p.plast_lds))
+                    pload_ws(PA, Pw + (size_t)j * pstep, stride, par);
+                step(j, PA);
+            }
+        } else {
+            pload_ws(PB, Pw + (size_t)max(j - 1, 0) * NN * stride, stride, par);
+            for (; j >= 1; j -= 2) {
+                products(j, PA);
+                pload_ws(PA, Pw + (size_t)max(j - 2, 0) * NN * stride, stride, par);
+                gradient(j);
+                products(j - 1, PB);
+                pload_ws(PB, Pw + (size_t)max(j - 3, 0) * NN * stride, stride, par);
+                gradient(j - 1);
+            }
+            if (j == 0) {
+                products(0, PA);
+                gradient(0);
+            }
+        }
+#elif GRAPE_PD == 2
+        if constexpr (PDASM) {
+            auto products = [&](int jj, const PMat<N> &P) {
+                if (t0 + jj < Nsl) {
+                    fetch_partner(Pp, P);
+                    fetch_partner(Mp, M);
+                    pmul(tmp, M, Mp, P);
+                    pmul_ah_b(M, P, Pp, tmp);            // M_t = P' M_{t+1} P
+                }
+            };
+            auto gradient = [&](int jj) {
+                const int t = t0 + jj;
+                if (t < Nsl) {
+                    if (!SAND) {
+                        double tr_r, tr_i;
+                        ptrace(tr_r, tr_i, M);
+                        zr = tr_r;
+                        zi = -tr_i;
+                    }
+                    pwrite_gradient<N, SAND>(xg + jj * K, sBT, K, M, zr, zi, gs, par);
+                    if (t == Nsl - 1 && par == 0)
+                        s_F[mb] = pfigure_of_merit<N, SAND>(zr, zi);
+                }
+            };
+            const bool plast = XGLDS && p.plast_lds;
+            const int jm = plast ? S - 2 : S - 1;                 // the first slice that comes from memory
+            if (GRAPE_PD_EARLY >= 1) {
+                pbuf_wait<0>(bA);                                 // issued before the scan: long landed
+                if (GRAPE_PD_EARLY >= 2)
+                    pbuf_wait<0>(bB);
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // phase A's stores are long done: the count starts at zero
+                pd_issue(bA, jm);
+            }
+            if (GRAPE_PD_EARLY < 2)
+                pd_issue(bB, jm - 1);
+            if (plast) {
+                products(j, PA);
+                gradient(j);
+            }
+            // slice jm in bA, slice jm - 1 in bB (landed or in flight); clamped loads once the slices run out
+            for (j = jm; j >= 1; j -= 2) {
+                pbuf_wait<8>(bA);
+                pbuf_to_mat(PA, bA);
+                products(j, PA);
+                pd_issue(bA, j - 2);
+                gradient(j);
+                pbuf_wait<8>(bB);
+                pbuf_to_mat(PB, bB);
+                products(j - 1, PB);
+                pd_issue(bB, j - 3);
+                gradient(j - 1);
+            }
+            if (j == 0) {
+                pbuf_wait<8>(bA);
+                pbuf_to_mat(PA, bA);
+                products(0, PA);
+                gradient(0);
+            }
+            pbuf_wait<0>(bA);                                     // the clamped extra loads land before their registers are reused
+            pbuf_wait<0>(bB);
+        } else {
+            for (; j >= 1; j -= 2) {
+                pload_ws(PB, Pw + (size_t)(j - 1) * pstep, stride, par);
+                step(j, PA);
+                if (j >= 2)
+                    pload_ws(PA, Pw + (size_t)(j - 2) * pstep, stride, par);
+                step(j - 1, PB);
+            }
+            if (j == 0)
+                step(0, PA);
+        }
+#else
         for (; j >= 1; j -= 2) {
-            if (!(GRAPE_ABL & 8)) pload_ws(PB, Pw + (size_t)(j - 1) * NN * stride, stride, par);
+            if (!(GRAPE_ABL & 8)) pload_ws(PB, Pw + (size_t)(j - 1) * pstep, stride, par);
             step(j, PA);
             if (j >= 2 && !(GRAPE_ABL & 8))
-                pload_ws(PA, Pw + (size_t)(j - 2) * NN * stride, stride, par);
+                pload_ws(PA, Pw + (size_t)(j - 2) * pstep, stride, par);
             step(j - 1, PB);
         }
         if (j == 0)
             step(0, PA);
+#endif
     } else {
         pstamp(st, 2);
         // ------------------------------------------------------------ phase C (debug flow only)
@@ -632,8 +891,8 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
                 if (t < Nsl) {
                     pstore_ws(Xw + (size_t)j * NN * stride, stride, X, par);
                     if (j + 1 < S) {
-                        pload_ws(Po, Pw + (size_t)j * NN * stride, stride, par);
-                        pload_ws(Pp, Pw + (size_t)j * NN * stride, stride, 1 - par);
+                        pload_ws(Po, Pw + (size_t)j * pstep, stride, par);
+                        pload_ws(Pp, Pw + (size_t)j * pstep, stride, 1 - par);
                         if (SAND) {
                             fetch_partner(Xp, X);
                             pmul_a_bh(tmp, X, Xp, Po, Pp);       // X P'
@@ -653,8 +912,8 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
         for (int j = S - 1; j >= 0; --j) {
             const int t = t0 + j;
             if (t < Nsl) {
-                pload_ws(Po, Pw + (size_t)j * NN * stride, stride, par);
-                pload_ws(Pp, Pw + (size_t)j * NN * stride, stride, 1 - par);
+                pload_ws(Po, Pw + (size_t)j * pstep, stride, par);
+                pload_ws(Pp, Pw + (size_t)j * pstep, stride, 1 - par);
                 if (SAND) {
                     fetch_partner(Lp, Lc);
                     pmul(tmp, Lc, Lp, Po);           // L P
@@ -758,28 +1017,13 @@ int sweep_pair_max_waves(int n)
 size_t sweep_pair_lds_bytes(int n, int MPB, int LT, int S, int K, bool xg_in_lds, bool plast)
 {
     const int maxt = n == 2 ? PairTraits<2>::MAXT : PairTraits<4>::MAXT;
-    size_t b = sizeof(double2) * (2 * (size_t)(maxt / 64) * n * n);
+    size_t b = sizeof(double2) * (2 * (size_t)(maxt / 64) * n * n + 4);
     b += sizeof(double2) * ((size_t)MPB * 2 * ((2 * K + 4) * (n * (n / 2)) + kParityPad) + ((size_t)MPB * (K + 1) + 1) / 2);
     if (xg_in_lds)
         b += sizeof(double) * ((size_t)MPB * (LT / 2) * ((size_t)S * K + 1) + ((MPB + 1) & ~1));
     if (plast)
         b += sizeof(double2) * (size_t)MPB * LT * (n * (n / 2));
     return b;
-}
-
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device) instead of once per launch: the
-// call sits on the host's critical path in front of every evaluation's first launch
-static hipError_t ensure_dynamic_lds(const void *fn, size_t lds, int (&have)[16])
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16)
-        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if ((int)lds <= have[dev])
-        return hipSuccess;
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess)
-        have[dev] = (int)lds;
-    return e;
 }
 
 template <int N, int SAND, int MODE, bool XGLDS>
@@ -792,6 +1036,10 @@ static hipError_t plaunch_one(const SweepParams &p0, hipStream_t stream)
     if (lds > 160 * 1024)
         return hipErrorInvalidConfiguration;
     p.plast_lds = 0;
+    {
+        static const int tune_env = [] { const char *e = getenv("GRAPE_PAIR_TUNE"); return e ? atoi(e) : 0; }();
+        p.tune = tune_env;
+    }
     if (MODE == PMODE_UNITARY && XGLDS && p.S > 1) {         // room for the chunks' last propagators?
         const size_t with = sweep_pair_lds_bytes(N, p.MPB, p.LT, p.S, p.K, true, true);
         if (with <= 160 * 1024) {
@@ -803,8 +1051,7 @@ static hipError_t plaunch_one(const SweepParams &p0, hipStream_t stream)
         if (p.dump_w1) {
             auto kern_w = sweep_pair_kernel<N, SAND, MODE, MAXT, XGLDS, true>;
             if (lds > 64 * 1024) {
-                static int have_w[16] = {0};
-                hipError_t e = ensure_dynamic_lds((const void *)kern_w, lds, have_w);
+                hipError_t e = ensure_dynamic_lds((const void *)kern_w, lds);
                 if (e != hipSuccess)
                     return e;
             }
@@ -816,8 +1063,7 @@ static hipError_t plaunch_one(const SweepParams &p0, hipStream_t stream)
         return hipErrorInvalidConfiguration;
     auto kern = sweep_pair_kernel<N, SAND, MODE, MAXT, XGLDS>;
     if (lds > 64 * 1024) {
-        static int have[16] = {0};
-        hipError_t e = ensure_dynamic_lds((const void *)kern, lds, have);
+        hipError_t e = ensure_dynamic_lds((const void *)kern, lds);
         if (e != hipSuccess)
             return e;
     }

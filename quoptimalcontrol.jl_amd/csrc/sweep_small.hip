@@ -585,7 +585,7 @@ static hipError_t launch_one(const SweepParams &p, hipStream_t stream)
         return hipErrorInvalidConfiguration;
     auto kern = sweep_small_kernel<N, SAND, MODE, MAXT, XGLDS>;
     if (lds > 64 * 1024) {                       // above the default dynamic-LDS cap: opt in
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = ensure_dynamic_lds((const void *)kern, lds);
         if (e != hipSuccess)
             return e;
     }

@@ -1576,7 +1576,8 @@ int tile_fuse_forward(const TileParams &p)
         return 0;
     if (sizeof(double2) * (4 * (size_t)kTileImage + (size_t)(p.K + 1) * 256) > 64 * 1024)   // generators not staged
         return 0;
-    const long wgs = (long)p.E * p.n_x, slots = 4L * (p.cus > 0 ? p.cus : 256);
+    // (E_plan: a member-chunked launch takes the whole ensemble's decision -- its results must not depend on the chunk size)
+    const long wgs = (long)(p.E_plan ? p.E_plan : p.E) * p.n_x, slots = 4L * (p.cus > 0 ? p.cus : 256);
     if (std::getenv("GRAPE_FORCE_FUSE") || 2 * wgs >= slots)
         return std::getenv("GRAPE_FUSE_ABL") ? 2 : 1;
     return 0;
@@ -1611,8 +1612,7 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         q.fuse_fwd = (NT == 1 && (q.stage_ops || hoisted)) ? tile_fuse_forward(p) : 0;
         const size_t lds = img_bytes + (q.stage_ops ? ops_bytes : 0) + (q.fuse_fwd ? sizeof(double2) * 33 : 0);
         if (lds > 64 * 1024) {
-            hipError_t ea = hipFuncSetAttribute((const void *)prop_tile_kernel<NT>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t ea = ensure_dynamic_lds((const void *)prop_tile_kernel<NT>, lds);
             if (ea != hipSuccess)
                 return ea;
         }
@@ -1623,7 +1623,8 @@ static hipError_t launch_nt(int sandwich, bool keepl, const TileParams &p, hipSt
         const bool keep_hoist2 = std::getenv("GRAPE_HOIST2") != nullptr;
         if (NT == 1 && split_forms_props(p, keepl)) {              // chain_tile_split_kernel<.., EXPM>: only the control sums
             e = launch_ctrl_sum(1, q, stream);
-        } else if (hoisted && NT == 2 && p.hoist == 1 && !keep_hoist2 && (long)p.E * p.n_x >= (long)(p.cus > 0 ? p.cus : 256)) {
+        } else if (hoisted && NT == 2 && p.hoist == 1 && !keep_hoist2 &&
+                   (long)(p.E_plan ? p.E_plan : p.E) * p.n_x >= (long)(p.cus > 0 ? p.cus : 256)) {
             e = launch_grid_prop(2, q, stream);
         } else if (hoisted) {                                      // member-invariant controls: prop_hoist.hip
             e = launch_prop_hoist(NT, q, stream);

@@ -168,3 +168,70 @@ def test_c5_shaped_general_flow_full_size_on_one_gpu(qoc, oracle):
     for k in (0, info["member_chunk"] - 1, info["member_chunk"], w.E - 1):
         F_ref, g_ref = oracle.member_eval(w.sys_type, w.A[k], w.B[k], w.Xi[k], w.Xt[k], w.x, w.T)
         assert_parity(foms[k], grads[k], F_ref, g_ref, w.n, what=f"C5 general flow, member {k}")
+
+
+@pytest.mark.parametrize("case", ["pair_one_workgroup", "lane_one_workgroup", "tile_single_problem_unitary", "tile_single_problem_vector"])
+def test_batches_array_by_array_on_self_closing_evaluations(qoc, oracle, monkeypatch, case):
+    """a budget below max_batch arrays makes a batch run array by array (ws_B = 1).  Where ONE array's evaluation
+    closes itself -- a single workgroup of the small family publishing directly, a single problem of the tile family folding
+    the reduction into its last kernel -- the last array must still publish the WHOLE batch: every slot of the host buffer
+    equals the one-array evaluation of its controls."""
+    if case == "pair_one_workgroup":
+        w = qoc.workloads.config("C3", E=3, N=40)                   # E <= MPB: NB == 1
+    elif case == "lane_one_workgroup":
+        w = _random_problem(qoc, 3, 2, 2, 33, "UnitaryGate", seed=11, hermitian=True, mixed=True)
+    elif case == "tile_single_problem_unitary":
+        w = _random_problem(qoc, 16, 3, 1, 24, "UnitaryGate", seed=12, hermitian=True, mixed=True)
+        w.A *= 0.3; w.B *= 0.3
+    else:
+        w = qoc.workloads.config("C4", E=1, N=40)
+    rng = np.random.default_rng(5)
+    xs = np.array([w.x, rng.uniform(-1, 1, w.x.shape), rng.uniform(0, 2, w.x.shape), 0.5 * w.x])
+    monkeypatch.delenv("GRAPE_MAX_WORKSPACE_BYTES", raising=False)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, max_batch=4) as eng:
+        Fb0, Gb0 = eng.eval_batch(xs)
+        unit = _ws_unit_bytes(w, eng.info)
+        singles = [eng.eval(x) for x in xs]
+    for b, (F1, G1) in enumerate(singles):
+        assert Fb0[b] == F1 and np.array_equal(Gb0[b], G1), ("unbudgeted", b)
+    # room for every member of ONE array's workspace, not for four arrays
+    monkeypatch.setenv("GRAPE_MAX_WORKSPACE_BYTES", str(int(3.2 * unit * max(w.E, 2))))
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, max_batch=4) as eng:
+        Fb, Gb = eng.eval_batch(xs)
+        Fd, Gd = eng.eval_batch(xs[:2])
+        assert eng.info["member_chunk"] == w.E
+    assert np.array_equal(Fb, Fb0) and np.array_equal(Gb, Gb0)
+    assert np.array_equal(Fd, Fb0[:2]) and np.array_equal(Gd, Gb0[:2])
+    for b in range(len(xs)):
+        F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, xs[b], w.T)
+        assert_parity(Fb[b], Gb[b], F_ref, G_ref, w.n, what=f"array {b}")
+
+
+def test_replan_allocation_failure_is_recoverable(qoc, oracle, monkeypatch):
+    """grape_set_operators re-plans the workspace when the new operators need another data flow (here: Hermitian ->
+    non-Hermitian generators, one more array).  If the allocation behind that plan fails, the context must refuse evaluations
+    and the NEXT grape_set_operators must plan and allocate again instead of skipping the block (null workspace pointers)."""
+    w = qoc.workloads.config("C3", E=40, N=32)
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        unit = _ws_unit_bytes(w, eng.info)
+    A2 = w.A + 0.05j * np.eye(4)[None]                              # non-Hermitian drift: the general flow (P_t and X_t stored)
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, A2, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    monkeypatch.setenv("GRAPE_MAX_WORKSPACE_BYTES", str(int(1.5 * unit * w.E)))
+    monkeypatch.setenv("GRAPE_TEST_FAIL_REPLAN", "1")
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        assert eng.info["member_chunk"] == w.E
+        eng.eval(w.x)
+        with pytest.raises(qoc.GrapeError) as e1:
+            eng.set_operators(A2, w.B, w.Xi, w.Xt, w.wts)
+        assert e1.value.status == -6
+        with pytest.raises(qoc.GrapeError) as e2:
+            eng.eval(w.x)
+        assert e2.value.status == -5
+        eng.set_operators(A2, w.B, w.Xi, w.Xt, w.wts)            # plans and allocates again
+        assert eng.info["member_chunk"] < w.E
+        F, G = eng.eval(w.x)
+        assert_parity(F, G, F_ref, G_ref, w.n, what="after the recovered re-plan")
+        eng.set_operators(w.A, w.B, w.Xi, w.Xt, w.wts)           # and back to the unitary flow
+        F0, G0 = eng.eval(w.x)
+    F0_ref, G0_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    assert_parity(F0, G0, F0_ref, G0_ref, w.n, what="back on the unitary flow")
