@@ -118,11 +118,13 @@ GRAPE_DEV void swap32(double &a, double &b)
 // of pieces from the larger of the two slices' bounds.  Worked out by all lanes at once into the wave's own LDS strip --
 // inside the chain the table search is five dependent scalar-memory round trips per slice (measured: 45 % of the kernel
 // in s_waitcnt)
-GRAPE_DEV void act_make_plan(unsigned short *s_plan, const double *__restrict__ gn, double an, int N, int forced, int lane)
+// gscale: |s_k| of a member whose control operators are member 0's times s_k (1: the plain sum, bit for bit)
+GRAPE_DEV void act_make_plan(unsigned short *s_plan, const double *__restrict__ gn, double an, int N, int forced, int lane,
+                             double gscale = 1.0)
 {
     for (int i0 = 0; i0 < N; i0 += 64) {
         const int i = min(i0 + lane, N - 1);
-        double th = an + fmax(gn[i], gn[N - 1 - i]);
+        double th = fma(gscale, fmax(gn[i], gn[N - 1 - i]), an);
         int pieces = 1;
         if (forced >= 0)
             pieces = 1 << min(forced, 10);
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void action_rows_kernel(const TileParams p)
     __shared__ double s_sum[2 * NB];
     const int t = blockIdx.x, y = blockIdx.y, K = p.K, N = p.N;
     const double *__restrict__ x = p.x + ((size_t)y * N + t) * K;
-    const double2 *__restrict__ Bb = p.act_b;
+    const double2 *__restrict__ Bb = p.act_b_ref ? p.act_b_ref : p.act_b;      // member 0's set of control operators
     double2 *__restrict__ dst = p.act_g + ((size_t)y * N + t) * (PLANAR ? 3 : 2) * NN;
     for (int e = threadIdx.x; e < NN; e += 256) {
         double2 g0, g1;
@@ -448,9 +450,12 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_parts_kernel(const T
     const int offP = (!WHOLE && c) ? 128 : 0, offQ = WHOLE ? 128 : c ? 0 : 256;
     const double *__restrict__ gn = p.act_gn + (size_t)y * N;
     double an = p.act_an[k];
+    const double sk = p.ctrl_scale ? p.ctrl_scale[k] : 1.0;       // B_k = s_k B_0: G = A'_k + s_k Gc_t
+    double sk_abs = fabs(sk);
     if (WHOLE) {                                                  // the wave's two members share the plan: the larger bound
-        const double other = __shfl_xor(an, 32, 64);
+        const double other = __shfl_xor(an, 32, 64), others = __shfl_xor(sk_abs, 32, 64);
         an = (an != an || other != other) ? an + other : fmax(an, other);      // (a NaN bound stays a NaN)
+        sk_abs = (sk_abs != sk_abs || others != others) ? sk_abs + others : fmax(sk_abs, others);
     }
     double2 *__restrict__ rec = (d ? p.wrec : p.states) + kw * (size_t)(N + 1) * 16 + (size_t)r * (N + 1);
     double aP[16], aQ[16];                                        // the member's A'_k (A'_k'), arranged and signed like P, Q
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_parts_kernel(const T
                                                                   //  an unconditional store keeps the compiler's vmcnt exact)
     extern __shared__ unsigned short s_plan_all[];
     unsigned short *s_plan = s_plan_all + (size_t)wave * N;       // this wave's own plan: no workgroup barrier anywhere
-    act_make_plan(s_plan, gn, an, N, p.s_forced, lane);
+    act_make_plan(s_plan, gn, an, N, p.s_forced, lane, sk_abs);
     double sel = c ? xi : xr, sel2 = xi;                          // the component(s) of v this row updates
     // Two register sets take turns: one holds G_t = Gc_t + A' (the products' operands), the other receives the planes of
     // the next slice at the top of slice t and has A' added in place (no third set).  One wave per SIMD issues
@@ -511,8 +516,8 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_parts_kernel(const T
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            nP[j] += aP[j];
-            nQ[j] += aQ[j];
+            nP[j] = fma(sk, nP[j], aP[j]);                        // (s_k = 1: the plain sum, bit for bit)
+            nQ[j] = fma(sk, nQ[j], aQ[j]);
         }
     };
     unsigned plan;
@@ -608,6 +613,7 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_thin2_kernel(const T
     const int off = d * 1024 + (16 * H) * 32 + el;
     const double *__restrict__ gn = p.act_gn + (size_t)y * N;
     const double an = p.act_an[k];
+    const double sk = p.ctrl_scale ? p.ctrl_scale[k] : 1.0;       // B_k = s_k B_0: G = A'_k + s_k Gc_t
     double2 a[16];
     {
         const double2 *__restrict__ Ak = p.act_a + (size_t)k * 2048 + d * 1024 + el * 32 + 16 * H;      // (row-major upload)
@@ -631,7 +637,7 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_thin2_kernel(const T
     const double2 *gp = p.act_g + (size_t)y * N * 2048 + (size_t)(d ? N - 1 : 0) * 2048 + off;
     extern __shared__ unsigned short s_plan_all[];
     unsigned short *s_plan = s_plan_all + (size_t)wave * N;
-    act_make_plan(s_plan, gn, an, N, p.s_forced, lane);           // (both waves of a member: the same plan)
+    act_make_plan(s_plan, gn, an, N, p.s_forced, lane, fabs(sk)); // (both waves of a member: the same plan)
     auto fetch = [&](double2 (&g)[16]) {
 #pragma unroll
         for (int j = 0; j < 16; ++j)
@@ -644,8 +650,8 @@ __global__ __launch_bounds__(64 * kActWaves, 2) void action_thin2_kernel(const T
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            g[j].x += a[j].x;
-            g[j].y += a[j].y;
+            g[j].x = fma(sk, g[j].x, a[j].x);                     // (s_k = 1: the plain sum, bit for bit)
+            g[j].y = fma(sk, g[j].y, a[j].y);
         }
     };
     auto step = [&](const double2 (&g)[16], double inv, bool last) {
@@ -1163,10 +1169,11 @@ static hipError_t launch_forms_nb(int sandwich, const TileParams &p, hipStream_t
 template <int NB>
 static hipError_t launch_action_nb(int sandwich, const TileParams &p, hipStream_t stream)
 {
-    const bool parts = NB == 16 && p.act_shared;
+    const bool hoisted = p.act_shared || p.ctrl_scale;            // one control sum per slice serves every member (x s_k)
+    const bool parts = NB == 16 && hoisted;
     if (parts)
         GRAPE_LAUNCH((action_rows_kernel<NB, true>), dim3(p.N, p.n_x), dim3(256), 0, stream, p);
-    else if (p.act_shared)
+    else if (hoisted)
         GRAPE_LAUNCH((action_rows_kernel<NB, false>), dim3(p.N, p.n_x), dim3(256), 0, stream, p);
     else if (NB != 16 || p.K > kActOwnK)
         return hipErrorInvalidConfiguration;                      // (the host layer keeps such ensembles on the expm flow)

@@ -153,6 +153,8 @@ struct grape_ctx {
     double *d_act_an = nullptr, *d_act_gn = nullptr;
     int act_R = 0;                             // sparse rows of the control operators (0: dense forms kernel)
     bool act_shared = true;                    // one set of control operators for every member
+    bool ctrl_scaled = false;                  // B_{k,c} = s_k B_{0,c} with some s_k != 1 (d_ctrl_scale: s_k per member): the
+    double *d_ctrl_scale = nullptr;            //   hoisted flows' pre-pass runs on member 0's operators, members scale Gc_t
     size_t act_var_bytes = 0;                  // device bytes of the vector flow's operator buffers (re-sized per upload)
     double *d_act_bn = nullptr;                // per-member controls: [E][K] norm bounds
     double2 *d_act_bs = nullptr;
@@ -415,6 +417,7 @@ static void free_all(grape_ctx *c)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     (void)hipFree(c->d_ops); (void)hipFree(c->d_wts); (void)hipFree(c->d_x); (void)hipFree(c->d_fg);
     (void)hipFree(c->d_props); (void)hipFree(c->d_states); (void)hipFree(c->d_costates); (void)hipFree(c->d_zphi);
+    (void)hipFree(c->d_ctrl_scale);
     (void)hipFree(c->d_member_out); (void)hipFree(c->d_partial); (void)hipFree(c->d_stamps); (void)hipFree(c->d_block_out); (void)hipFree(c->d_xg_scratch);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_fg) (void)hipHostFree(c->h_fg);
@@ -1240,9 +1243,23 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     bool ctrl_shared = true;                                 // the members' control operators are identical
     for (size_t k = 1; k < E && ctrl_shared; ++k)
         ctrl_shared = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
+    // ... or member 0's times a scalar per member (B_g(k) = (1 + eps_k) B: amplitude inhomogeneity, src/problems.jl:33-41,
+    // test/setup_tests.jl:31-32): every flow built on a per-slice control sum keeps it and scales it per member
+    std::vector<double> ctrl_scale;
+    c->ctrl_scaled = false;
+    if (!ctrl_shared && c->family == 1 && !c->pack2 && !env_off("GRAPE_CTRL_SCALE") &&
+        grape_host::controls_scaled(B, E, K, nn, ctrl_scale)) {
+        c->ctrl_scaled = true;
+        if (!c->d_ctrl_scale) {
+            HIP_TRY(c, hipMalloc((void **)&c->d_ctrl_scale, sizeof(double) * E));
+            c->bytes += sizeof(double) * E;
+        }
+        HIP_TRY(c, hipMemcpy(c->d_ctrl_scale, ctrl_scale.data(), sizeof(double) * E, hipMemcpyHostToDevice));
+    }
+    const bool ctrl_hoistable = ctrl_shared || c->ctrl_scaled;   // ONE control sum per slice serves every member
     const bool act_forced = act_env && act_env[0] == '1';
     // shared controls, or -- n <= 16 -- the members' own (at most six: a lane keeps its half rows of them in registers)
-    const bool act_ok = (ctrl_shared || (c->NT == 1 && K <= 6)) && !(act_env && act_env[0] == '0') &&
+    const bool act_ok = (ctrl_hoistable || (c->NT == 1 && K <= 6)) && !(act_env && act_env[0] == '0') &&
                         c->cfg.n_slices <= 4096;             // (per-slice plans live in LDS)
     // (n = 33..64: grid_thin_kernel of sweep_grid.hip, sparse control operators only -- decided below the list build)
     bool thin = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT && (!c->grid || c->NT >= 3) &&
@@ -1362,9 +1379,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         bool hz = c->family == 1 && c->cfg.gradient != GRAPE_GRADIENT_EXACT;
         const char *he = std::getenv("GRAPE_HOIST");
         if (he && he[0] == '0') hz = false;
-        bool invariant = hz && !c->pack2;                        // (block-diagonal member pairs, n <= 8: always the in-kernel sum)
-        for (size_t k = 1; k < E && invariant; ++k)
-            invariant = std::memcmp(B + 2 * k * K * nn, B, sizeof(double) * 2 * K * nn) == 0;
+        bool invariant = hz && !c->pack2 && ctrl_hoistable;      // (block-diagonal member pairs, n <= 8: always the in-kernel sum)
         if (c->grid && !invariant) hz = false;                   // sweep_grid.hip: the pre-pass or its own H build, nothing in between
         // (32 x 32: the new kernel is also the four-waves-per-propagator one -- single problems take it too)
         if (hz && invariant && !(he && he[0] == '1') && c->EU < 8 && c->NT == 1) {
@@ -1834,6 +1849,9 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.wrec = c->thin_dpp ? c->d_wrec : c->d_props;
     p.props_t = c->d_props_t;
     p.act_shared = c->act_shared ? 1 : 0;
+    p.ctrl_scale = c->ctrl_scaled ? c->d_ctrl_scale : nullptr;
+    p.ops_ref = c->d_ops;
+    p.act_b_ref = c->d_act_b;
     p.act_bn = c->d_act_bn;
     p.act_bs = c->d_act_bs;
     p.act_bo = c->d_act_bo;
@@ -2044,6 +2062,7 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
             if (t.sp_coef) { t.sp_coef += lu * Kc * c->sp_nz; t.sp_addr += lu * Kc * c->sp_nz; }
             if (t.ha) { t.ha += lu * c->TSZ; t.ha_norm += lu * (c->hoist == 1 ? 1 : 1 + Kc); }
             if (t.act_a) { t.act_a += (size_t)lo * 2 * VV; t.act_an += lo; }
+            if (t.ctrl_scale) t.ctrl_scale += lo;
             if (!c->act_shared && t.act_b) {
                 t.act_bn += (size_t)lo * Kc;
                 t.act_b += (size_t)lo * Kc * 2 * VV;

@@ -3,6 +3,7 @@
 //   factor_rank_one      M = u u' ?  (pure-state density operators, vec(rho) vec(rho)')
 //   build_sparse_lists   (coefficient, position) lists of control operators with few non-zeros
 //   hermitian_to_rounding  M == M' to 4 ulp of its largest entry (all entries finite)
+//   controls_scaled      B_{k,c} = s_k B_{0,c} for every member k and control c?  (amplitude inhomogeneity)
 // All matrices are n x n complex, column-major, interleaved {re, im}.
 #pragma once
 #include <cmath>
@@ -45,6 +46,36 @@ inline bool factor_rank_one(const double *M, int n, double *u)
 }
 
 // M == M' to 4 ulp of its largest entry and free of NaN / Inf?
+// Are the members' control operators member 0's times ONE real scalar per member, B_{k,c} = s_k B_{0,c} -- what
+// EnsembleProblem.B_g produces for amplitude inhomogeneity, B_g(k) = (1 + eps_k) B (src/problems.jl:33-41)?  B: E sets of K
+// operators of nn entries.  s_k comes from the largest entry of member 0 and every entry is then compared AFTER scaling, to 4 ulp
+// of itself (the caller's own product (1 + eps) b is rounded once, s_k b once more); zero patterns must agree exactly.
+// s[k] on return (s[0] = 1).  false: not of that form, or a non-finite entry / factor.
+inline bool controls_scaled(const double *B, size_t E, size_t K, size_t nn, std::vector<double> &s)
+{
+    const size_t len = 2 * K * nn;
+    size_t best = 0;
+    for (size_t e = 0; e < len; ++e) {
+        if (!std::isfinite(B[e])) return false;
+        if (std::fabs(B[e]) > std::fabs(B[best])) best = e;
+    }
+    if (B[best] == 0.0) return false;
+    s.assign(E, 1.0);
+    for (size_t k = 1; k < E; ++k) {
+        const double *Bk = B + k * len;
+        const double sk = Bk[best] / B[best];
+        if (!std::isfinite(sk)) return false;
+        for (size_t e = 0; e < len; ++e) {
+            const double want = sk * B[e], have = Bk[e];
+            if (!std::isfinite(have)) return false;
+            if ((B[e] == 0.0) != (have == 0.0) && sk != 0.0) return false;
+            if (!(std::fabs(have - want) <= 8.9e-16 * std::fabs(have))) return false;
+        }
+        s[k] = sk;
+    }
+    return true;
+}
+
 inline bool hermitian_to_rounding(const double *M, int n)
 {
     double scale = 0.0, dev = 0.0;

@@ -188,6 +188,13 @@ struct TileParams {
     const double *act_an;     // [unit] max(|A'_k|_1, |A'_k|_inf)
     double2 *props_t;         // thin == 2: P_t^T dumps, same indexing as props
     double2 *wrec;            // backward chain's records w_0 .. w_N, element-major (the vector flow: = props; thin == 2: own buffer)
+    // Per-member control operators that are member 0's times a scalar, B_{k,c} = s_k B_{0,c} (amplitude inhomogeneity,
+    // EnsembleProblem.B_g, src/problems.jl:33-41): the hoisted flows keep their pre-pass -- Gc_t from member 0's operators
+    // (ops_ref / act_b_ref: the WHOLE ensemble's first unit, also in a member-chunked launch) -- and a member forms
+    // G = A'_k + s_k Gc_t, |G| <= |A'_k| + |s_k| |Gc_t|.  ctrl_scale: s_k per member of this launch; nullptr: all ones
+    const double *ctrl_scale;
+    const double2 *ops_ref;
+    const double2 *act_b_ref;
     int32_t act_shared;       // 1: one set of control operators for every member (pre-pass forms the control sums); 0: per member
                               //    (n <= 16, K <= 6): act_b / act_bf / act_bs / act_bo carry a leading member index
     const double *act_bn;     // (per-member controls) [unit][K] max(|B'_kc|_1, |B'_kc|_inf)

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64 * NT * NT) void ctrl_sum_kernel(const TileParams
     __shared__ double s_col[NT * NT][16];
     const int lane = threadIdx.x & 63, tile = threadIdx.x >> 6, t = blockIdx.x, z = blockIdx.y;
     const int K = p.K;
-    const double2 *__restrict__ B0 = p.ops + TSZ + tile * 256;     // unit 0: [A | B_1..B_K | ...]
+    const double2 *__restrict__ B0 = (p.ops_ref ? p.ops_ref : p.ops) + TSZ + tile * 256;     // unit 0: [A | B_1..B_K | ...]
     const double *__restrict__ x = p.x + (size_t)z * K * p.N + (size_t)t * K;
     double2 *__restrict__ out = p.gc + ((size_t)z * p.N + t) * TSZ + tile * 256;
     const double dt = p.dt;
@@ -279,6 +279,7 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
     const int K = p.K;
     const int nstride = HOIST ? 1 : 1 + K;                         // ha_norm: [unit] or [unit][|A'|, |B'_1| .. |B'_K|], all / theta8
     const double nA = p.ha_norm[(size_t)k * nstride];
+    const double sk = (HOIST && p.ctrl_scale) ? p.ctrl_scale[k] : 1.0;      // B_k = s_k B_0: G = A'_k + s_k Gc_t
     const double *__restrict__ gcn = p.gcn + (size_t)z * p.N;
     const gcptr gc = uniform_global(p.gc + (size_t)z * p.N * TSZ);
     const gcptr Bk = uniform_global(p.ops + ((size_t)k * (2 * K + 3) + 1) * TSZ);      // !HOIST: this member's B_1 .. B_K dumps
@@ -310,10 +311,10 @@ __global__ __launch_bounds__(64 * kHoistWaves, 4) void prop_hoist1_kernel(const 
         if (HOIST) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                Gre[r] = Are[r] + gnext[r][0];
-                Gim[r] = Aim[r] + gnext[r][1];
+                Gre[r] = fma(sk, gnext[r][0], Are[r]);             // (s_k = 1: the plain sum, bit for bit)
+                Gim[r] = fma(sk, gnext[r][1], Aim[r]);
             }
-            bound = nA + bnext;
+            bound = fma(fabs(sk), bnext, nA);
         } else {
             Gre = Are;
             Gim = Aim;
@@ -595,6 +596,7 @@ __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
     const int K = p.K;
     const int nstride = HOIST ? 1 : 1 + K;
     const double nA = p.ha_norm[(size_t)k * nstride];
+    const double sk = (HOIST && p.ctrl_scale) ? p.ctrl_scale[k] : 1.0;      // B_k = s_k B_0: G = A'_k + s_k Gc_t
     const double *__restrict__ gcn = p.gcn + (size_t)z * p.N;
     const gcptr gc = uniform_global(p.gc + (size_t)z * p.N * TSZ + tile * 256);
     const gcptr Bk = uniform_global(p.ops + ((size_t)k * (2 * K + 3) + 1) * TSZ + tile * 256);   // !HOIST: own tile of B_1 .. B_K
@@ -622,10 +624,10 @@ __global__ __launch_bounds__(256, 3) void prop_hoist2_kernel(const TileParams p)
         if (HOIST) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                G.re[r] = anext[r][0] + gnext[r][0];
-                G.im[r] = anext[r][1] + gnext[r][1];
+                G.re[r] = fma(sk, gnext[r][0], anext[r][0]);       // (s_k = 1: the plain sum, bit for bit)
+                G.im[r] = fma(sk, gnext[r][1], anext[r][1]);
             }
-            bound = nA + bnext;
+            bound = fma(fabs(sk), bnext, nA);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_prop_kernel(const TileParam
     const double dt = p.dt;
     GT Ah, Gc;
     double nA = 0.0;
+    const double sk = (HOIST && p.ctrl_scale) ? p.ctrl_scale[k] : 1.0;      // B_k = s_k B_0: G = A'_k + s_k Gc_t
     if (HOIST) {
         Ah = gt_load(p.ha + (size_t)k * TSZ, tile, lane);
         nA = p.ha_norm[k];
@@ -180,9 +181,12 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_prop_kernel(const TileParam
         GT G;
         int s_h = 0;
         if (HOIST) {
-            G.re = Gc.re + Ah.re;
-            G.im = Gc.im + Ah.im;
-            const double bound = (nA + p.gcn[(size_t)blockIdx.z * p.N + t]) * kTheta8;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                G.re[r] = fma(sk, Gc.re[r], Ah.re[r]);            // (s_k = 1: the plain sum, bit for bit)
+                G.im[r] = fma(sk, Gc.im[r], Ah.im[r]);
+            }
+            const double bound = fma(fabs(sk), p.gcn[(size_t)blockIdx.z * p.N + t], nA) * kTheta8;
             s_h = squarings_for(bound);
             Gc = gt_load(p.gc + ((size_t)blockIdx.z * p.N + min(t + 1, t_hi - 1)) * TSZ, tile, lane);
         } else if (p.variant == 0) {

@@ -728,9 +728,12 @@ __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TilePara
         double nA = 0.0;
         const double2 *__restrict__ src = EXPM ? p.gc + (size_t)blockIdx.y * N * TSZ : Pk;
         const double *__restrict__ gcn = p.gcn + (size_t)blockIdx.y * N;
+        double sk = 1.0;
         if constexpr (EXPM) {
             tload(Ah, p.ha + (size_t)k * TSZ, lane);
             nA = p.ha_norm[k];
+            if (p.ctrl_scale)
+                sk = p.ctrl_scale[k];
         }
         const int a = fwd ? 0 : N - 1, cnt = fwd ? Nh : N - Nh, last = a + d * (cnt - 1);
         auto clampt = [&](int t) { return fwd ? min(t, last) : max(t, last); };
@@ -740,9 +743,12 @@ __global__ __launch_bounds__(128, 2) void chain_tile_split_kernel(const TilePara
             constexpr double c1 = kX1 / kX2, c3 = kX3 / kX2, c7 = kX7 * kX2;
             TMat<1> G, A2, T, A4;
             TOp<1> OA;
-            G.re[0][0] = Ah.re[0][0] + Gc.re[0][0];
-            G.im[0][0] = Ah.im[0][0] + Gc.im[0][0];
-            const int sq = p.s_forced >= 0 ? p.s_forced : squarings_from_ratio(nA + gcn[t]);       // (bounds are stored / theta8)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                G.re[0][0][r] = fma(sk, Gc.re[0][0][r], Ah.re[0][0][r]);   // (B_k = s_k B_0; s_k = 1: the plain sum, bit for bit)
+                G.im[0][0][r] = fma(sk, Gc.im[0][0][r], Ah.im[0][0][r]);
+            }
+            const int sq = p.s_forced >= 0 ? p.s_forced : squarings_from_ratio(fma(fabs(sk), gcn[t], nA));   // (bounds are stored / theta8)
             if (sq > 0) {
                 const double sc = ldexp(1.0, -sq);
                 G.re[0][0] *= sc;

@@ -199,9 +199,13 @@ def test_batches_array_by_array_on_self_closing_evaluations(qoc, oracle, monkeyp
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, max_batch=4) as eng:
         Fb, Gb = eng.eval_batch(xs)
         Fd, Gd = eng.eval_batch(xs[:2])
+        singles_b = [eng.eval(x) for x in xs]
         assert eng.info["member_chunk"] == w.E
-    assert np.array_equal(Fb, Fb0) and np.array_equal(Gb, Gb0)
-    assert np.array_equal(Fd, Fb0[:2]) and np.array_equal(Gd, Gb0[:2])
+    for b, (F1, G1) in enumerate(singles_b):                      # every slot = the one-array evaluation on the same context
+        assert Fb[b] == F1 and np.array_equal(Gb[b], G1), ("array by array", b)
+    assert np.array_equal(Fd, Fb[:2]) and np.array_equal(Gd, Gb[:2])
+    if case != "tile_single_problem_vector":                      # (a budgeted single problem leaves the chunked time axis: another flow)
+        assert np.array_equal(Fb, Fb0) and np.array_equal(Gb, Gb0)
     for b in range(len(xs)):
         F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, xs[b], w.T)
         assert_parity(Fb[b], Gb[b], F_ref, G_ref, w.n, what=f"array {b}")
@@ -235,3 +239,18 @@ def test_replan_allocation_failure_is_recoverable(qoc, oracle, monkeypatch):
         F0, G0 = eng.eval(w.x)
     F0_ref, G0_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
     assert_parity(F0, G0, F0_ref, G0_ref, w.n, what="back on the unitary flow")
+
+
+@pytest.mark.parametrize("n,sys_type,herm", [(16, "UnitaryGate", True), (32, "UnitaryGate", True), (40, "UnitaryGate", True)])
+def test_scaled_controls_on_a_chunked_context(qoc, oracle, monkeypatch, n, sys_type, herm):
+    """B_k = s_k B_0 on a member-chunked workspace: the pre-pass takes the WHOLE ensemble's member 0 and the
+    chunk's members their own s_k, whichever block they fall into -- chunked equals unchunked bit for bit."""
+    w = _random_problem(qoc, n, 3, 10, 22, sys_type, seed=700 + n, hermitian=herm, mixed=True)
+    w.B[:] = w.B[0]
+    w.A *= 0.3
+    w.B *= 0.3
+    w.B *= (1.0 + 0.05 * (np.arange(w.E) / w.E - 0.5))[:, None, None, None]
+    _check_chunked_equals_unchunked(qoc, oracle, monkeypatch, w, 3, env={"GRAPE_NO_TP": "1"})
+    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+        eng.eval(w.x)
+        assert "ctrl_sum_kernel" in eng.kernel_names()

@@ -154,11 +154,12 @@ def test_operators_reupload_switches_between_hoisted_and_per_member(qoc, oracle)
                                                                (32, 6, 12, 3, "UnitaryGate", True, False),
                                                                (24, 2, 9, 2, "StateTransfer", False, False)])
 def test_per_member_controls_run_the_new_kernels_too(qoc, oracle, monkeypatch, n, K, N, E, sys_type, herm_gen, rank_one):
-    """Members with their OWN control operators (amplitude-scaled controls of a robustness ensemble): the round-3 expm
-    kernels form the control sum themselves (no pre-pass); against the oracle and against the round-2 kernel."""
+    """Members with their OWN control operators, genuinely different ones (one control of one member rescaled on its own): the
+    round-3 expm kernels form the control sum themselves (no pre-pass); against the oracle and against the round-2 kernel."""
     sand = sys_type != "UnitaryGate"
     A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sand, herm_gen, seed=n + 7 * N, rank_one=rank_one)
-    B = B * (1.0 + 0.07 * np.arange(E))[:, None, None, None]        # B_k = (1 + eps_k) B
+    B = B * (1.0 + 0.07 * np.arange(E))[:, None, None, None]        # B_k = (1 + eps_k) B ...
+    B[E - 1, 0] *= 1.3                                              # ... and one control that breaks the pattern
     F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 0.9, per_member=True)
     res = {}
     for hoist in (None, "0"):
@@ -177,6 +178,83 @@ def test_per_member_controls_run_the_new_kernels_too(qoc, oracle, monkeypatch, n
         assert_parity(F, G, F_ref, G_ref, n, what=f"ensemble (GRAPE_HOIST={hoist})")
         res[hoist] = (F, G)
     assert np.abs(res[None][1] - res["0"][1]).max() <= 1e-12 * np.abs(res["0"][1]).max() + 1e-15
+
+
+SCALED_CASES = [  # n, K, N, E, sys_type, Hermitian drift, rank-one states, state columns, environment, a kernel the flow must run
+    (16, 4, 37, 9, "CoherenceTransfer", False, True, None, {}, "prop_hoist1_kernel"),              # expm + vector chain
+    (16, 4, 40, 70, "CoherenceTransfer", False, True, None, {"GRAPE_ACTION": "1"}, "action_parts_kernel"),   # vector flow (C4's)
+    (16, 4, 40, 70, "CoherenceTransfer", False, True, None, {"GRAPE_ACTION": "1", "GRAPE_ACT_WHOLE": "1"}, "action_parts_kernel"),
+    (24, 3, 20, 40, "CoherenceTransfer", False, True, None, {"GRAPE_ACTION": "1"}, "action_thin2_kernel"),   # 32 x 32 images
+    (16, 4, 33, 12, "CoherenceTransfer", False, False, None, {"GRAPE_NO_TP": "1"}, "chain_tile_split_kernel"),  # expm inside the two-wave chain
+    (16, 2, 19, 9, "UnitaryGate", True, False, None, {"GRAPE_NO_TP": "1"}, "prop_hoist1_kernel"),      # unitary flow
+    (32, 6, 12, 3, "UnitaryGate", True, False, None, {"GRAPE_NO_TP": "1"}, "prop_hoist2_kernel"),      # four waves per propagator
+    (32, 3, 7, 9, "StateTransfer", False, False, None, {"GRAPE_NO_TP": "1"}, "prop_hoist2_kernel"),
+    (48, 3, 6, 4, "UnitaryGate", True, False, None, {}, "grid_prop_kernel"),                           # n > 32: the grid family
+]
+
+
+@pytest.mark.parametrize("n,K,N,E,sys_type,herm_gen,rank_one,cols,env,kernel", SCALED_CASES)
+def test_scaled_per_member_controls_keep_the_hoisted_flows(qoc, oracle, monkeypatch, n, K, N, E, sys_type, herm_gen, rank_one,
+                                                           cols, env, kernel):
+    """VERDICT r5 #2 -- EnsembleProblem.B_g (src/problems.jl:33-41, applied in src/tools.jl:42-53) exists so that members can
+    differ in their control operators; the case the reference itself writes down is amplitude inhomogeneity, B_g(k) =
+    (1 + eps_k) B.  grape_set_operators detects B_{k,c} = s_k B_{0,c} and the flows built on the per-slice control sum keep
+    it: ctrl_sum_kernel / action_rows_kernel run on member 0's operators, a member forms A'_k + s_k Gc_t.  Every member
+    against the oracle; the kernels asserted; GRAPE_CTRL_SCALE=0 (the per-member build of round 3) agrees to rounding."""
+    sand = sys_type != "UnitaryGate"
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, sand, herm_gen, seed=n + 3 * N + E, rank_one=rank_one, cols=cols)
+    A *= 0.5
+    B = B * (1.0 + 0.05 * (np.arange(E) / E - 0.5))[:, None, None, None]      # bench.py's C4pm / C5pm scaling
+    for kk, v in env.items():
+        monkeypatch.setenv(kk, v)
+    F_ref, G_ref, foms_ref, grads_ref = oracle.ensemble_eval(sys_type, A, B, Xi, Xt, wts, x, 0.9, per_member=True)
+    res = {}
+    for mode in ("scaled", "own"):
+        if mode == "own":
+            monkeypatch.setenv("GRAPE_CTRL_SCALE", "0")
+        else:
+            monkeypatch.delenv("GRAPE_CTRL_SCALE", raising=False)
+        try:
+            eng = qoc.GrapeEngine(sys_type, A, B, Xi, Xt, wts, 0.9, N, member_results=True)
+        except qoc.GrapeError:
+            assert mode == "own"                                    # (a forced vector flow the per-member build does not serve)
+            continue
+        with eng:
+            F, G = eng.eval(x)
+            foms, grads = eng.member_results()
+            F2, G2 = eng.eval(x)
+            names = eng.kernel_names()
+            hoisted = eng.info["hoisted_controls"]
+        assert F == F2 and np.array_equal(G, G2)
+        if mode == "scaled":
+            assert kernel in names, names
+            assert "ctrl_sum_kernel" in names or "action_rows_kernel" in names, names
+            assert hoisted == 1 or "action_rows_kernel" in names
+        else:
+            assert "ctrl_sum_kernel" not in names and "action_rows_kernel" not in names, names
+        for k in range(E):
+            assert_parity(foms[k], grads[k], foms_ref[k], grads_ref[k], n, what=f"member {k} ({mode})")
+        assert_parity(F, G, F_ref, G_ref, n, what=f"ensemble ({mode})")
+        res[mode] = G
+    if "own" in res:
+        assert np.abs(res["scaled"] - res["own"]).max() <= 1e-11 * np.abs(res["own"]).max() + 1e-15
+
+
+def test_scaled_controls_detection_is_exact(qoc, oracle):
+    """B_k = s_k B_0 is decided entry by entry after scaling: a single entry off by 1e-9 keeps the member's own operators; a
+    member-chunked evaluation (workspace budget) still builds the control sum from the WHOLE ensemble's member 0."""
+    n, K, N, E = 16, 3, 14, 10
+    A, B, Xi, Xt, wts, x = _problem(n, K, N, E, True, False, seed=77)
+    Bs = B * (1.0 + 0.1 * np.arange(E))[:, None, None, None]
+    Bo = Bs.copy()
+    Bo[4, 1, 2, 3] *= 1.0 + 1e-9
+    for Bk, want in ((Bs, True), (Bo, False)):
+        with qoc.GrapeEngine("CoherenceTransfer", A, Bk, Xi, Xt, wts, 0.7, N) as eng:
+            F, G = eng.eval(x)
+            names = eng.kernel_names()
+        assert (("ctrl_sum_kernel" in names) or ("action_rows_kernel" in names)) == want, names
+        Fr, Gr = oracle.ensemble_eval("CoherenceTransfer", A, Bk, Xi, Xt, wts, x, 0.7)
+        assert_parity(F, G, Fr, Gr, n, what=f"scaled pattern {want}")
 
 
 @pytest.mark.parametrize("n,sys_type,herm_gen,N,scale", [(32, "UnitaryGate", True, 9, 0.6), (21, "StateTransfer", False, 5, 0.6),
