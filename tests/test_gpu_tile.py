@@ -273,7 +273,9 @@ def test_time_chunks_ragged_and_entry_points(qoc, oracle, monkeypatch, n, sys_ty
 
 @pytest.mark.parametrize("name,E,members,dense", [("C4", 1024, (0, 1, 511, 1023), False), ("C4", 1024, (0, 1023), True),
                                                   ("C4", 1024, (0, 510, 1023), "expm"),
-                                                  ("C5", 1024, (0, 1023), False), ("C5", 4096, (0, 2047, 4095), False)])
+                                                  ("C5", 1024, (0, 1023), False), ("C5", 4096, (0, 2047, 4095), False),
+                                                  ("C6", 256, (0, 127, 255), False),          # 64 x 64, N = 500: the bench's C6 line
+                                                  ("C4", 1024, (0, 700, 1023), "pm"), ("C5", 1024, (0, 1023), "pm")])
 def test_full_size_spot_members(qoc, oracle, name, E, members, dense, monkeypatch):
     """Full BASELINE sizes (C4: E = 1024, N = 1000 -- the vector flow the bench runs, the two-wave dense chain, and the
     MFMA expm + fused vector chain every ensemble with more than six per-member controls takes (GRAPE_ACTION=0); C5:
@@ -283,13 +285,18 @@ def test_full_size_spot_members(qoc, oracle, name, E, members, dense, monkeypatc
     w = qoc.workloads.config(name, E=E)
     if dense == "expm":
         monkeypatch.setenv("GRAPE_ACTION", "0")
+    if dense == "pm":                                      # bench.py's C4pm / C5pm: B_k = (1 + eps_k) B, the hoisted flows x s_k
+        w.B = np.ascontiguousarray(w.B * (1.0 + 0.05 * (np.arange(w.E) / w.E - 0.5))[:, None, None, None])
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N,
                          flags=qoc.engine.FLAG_FORCE_GENERAL if dense is True else 0) as eng:
         F, G = eng.eval(w.x)
         if dense == "expm":
             assert eng.info["expm_action"] == 0 and eng.info["rank_one_chain"] == 1 and eng.info["fused_forward"] == 1
-        elif name == "C4" and not dense:
+        elif name == "C4" and (not dense or dense == "pm"):
             assert eng.info["expm_action"] == 1
+        if dense == "pm":
+            names = eng.kernel_names()
+            assert ("action_rows_kernel" in names and "action_parts_kernel" in names) if name == "C4" else "ctrl_sum_kernel" in names, names
         foms, grads = eng.member_results()
         F2, G2 = eng.eval(w.x)
     assert F == F2 and np.array_equal(G, G2)
