@@ -223,7 +223,40 @@ def roofline(local, info, samples, evals_per_s, n_gpus, traffic, profile=None, n
     alg_bytes, alg_flops = local.algorithmic_bytes, local.algorithmic_flops
     fused = bool(info.get("fused_forward"))
     chunks = int(info.get("time_chunks") or 0)
-    if info.get("kernel_family") == 1:            # n > 4: FP64 matrix-core kernels
+    if info.get("kernel_family") == 2 and local.n >= 17:
+        # size-generic kernel on the matrix cores (sweep_any.hip, n > 64): products of 4 real MFMA products per complex one on
+        # matrices padded to multiples of 16; per slice 3 (Taylor-8) + s squarings + 3 / 6 chain products, s from the kernel's
+        # own rule on the 1-norm bound of G_t (replicated here on a sample of members)
+        n, K, N, E = local.n, local.K, local.N, local.E
+        nt = (n + 15) // 16
+        prod = 4 * nt * nt * (4 * nt) * 2048
+        dt = local.T / N
+        sq = []
+        for k in sorted(set(int(round(i * (E - 1) / 3)) for i in range(4))):
+            H = local.A[k][None] + np.tensordot(local.x.T, local.B[k], 1)           # (N, n, n)
+            nb = dt * (np.abs(H.real) + np.abs(H.imag)).sum(axis=1).max(axis=1)
+            sq.append(np.where(nb > 0.08, np.ceil(np.log2(np.maximum(nb, 1e-300) / 0.08)), 0.0).mean())
+        s_mean = float(np.mean(sq))
+        q = 3 if local.sys_type == "UnitaryGate" else 6
+        t_first = float(first_ms.mean()) * 1e-3 if first_ms.size else 0.0
+        parts = []
+        for nm, fl, t in (("propagators (any_prop_kernel)", E * N * (3 + s_mean) * prod, t_first),
+                          ("chain (any_sweep_kernel: one workgroup per member)", E * N * q * prod, max(sec - t_first, 0.0))):
+            if t <= 0:
+                continue
+            tf = fl / t / 1e12
+            parts.append({"kernel": nm, "what": nm, "avg_us": 1e6 * t, "mfma_flops_per_launch": fl, "hbm_bytes_per_launch": 0.0,
+                          "achieved_TFLOPs": tf, "achieved_GBs": 0.0, "frac_mfma": tf / FP64_PEAK_TFLOPS, "frac_hbm": 0.0, "bound": "mfma"})
+        fl_all = E * N * (3 + s_mean + q) * prod
+        tf_all = fl_all / sec / 1e12 if sec > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": tf_all, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_all / FP64_PEAK_TFLOPS,
+                "traffic": traffic, "kernel": ";".join(names), "kernels": parts, "squarings_per_slice": s_mean,
+                "model_s_equivalent": {"flops_per_launch": alg_flops, "TFLOPs": alg_flops / sec / 1e12 if sec > 0 else 0.0,
+                                       "frac_fp64": alg_flops / sec / 1e12 / FP64_PEAK_TFLOPS if sec > 0 else 0.0,
+                                       "end_to_end_frac": alg_flops * evals_per_s / 1e12 / FP64_PEAK_TFLOPS},
+                "note": "matrix-core flops ISSUED (four real products per complex one, padded tiles) / HIP-event time / 78.6 TF; the "
+                        "chain runs on E compute units only (one workgroup per member, sequential in time)"}
+    elif info.get("kernel_family") == 1:            # n > 4: FP64 matrix-core kernels
         # priced PER KERNEL on the flow actually run (the rank-one / unitary / chunked flows do less work than model S,
         # so model-S flops over their run time can exceed the peak: kept below as model_s_equivalent only)
         expm, chain = tile_kernel_models(local, info, names)
@@ -293,11 +326,11 @@ def roofline(local, info, samples, evals_per_s, n_gpus, traffic, profile=None, n
     roof["frac_model_s"] = ms_eq.get("frac_hbm", ms_eq.get("frac_fp64"))     # SURVEY.md 8d numerator over the same time
     # ... where it means something: a flow that does less than half of model S's work (the vector flow of C4 does ~1/12 of
     # its flops) makes that ratio a multiple of the peak -- printed as null, the flow's own fraction is `frac`
-    if info.get("kernel_family") == 1:
+    if info.get("kernel_family") in (1, 2) and "kernels" in roof:
         done = sum(k.get("mfma_flops_per_launch", k.get("valu_fp64_flops_per_launch", 0.0)) for k in roof.get("kernels", []))
         if done < 0.5 * alg_flops:
             roof["frac_model_s"] = None
-    elif roof.get("bytes_per_launch", alg_bytes) < 0.5 * alg_bytes:
+    elif "kernels" not in roof and roof.get("bytes_per_launch", alg_bytes) < 0.5 * alg_bytes:
         roof["frac_model_s"] = None
     if info.get("kernel_family") != 1 and info.get("lane_pair") and uni:
         ph = committed_phases(local, st["kernel_avg_us"])
@@ -776,7 +809,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the device-resident loop and the extra configs")
-    ap.add_argument("--extra-configs", default="C4,C5,C4dense,C4expm,C6,C2,C5x1,C4x1,C3pm,C4pm,C5pm")
+    ap.add_argument("--extra-configs", default="C4,C5,C4dense,C4expm,C6,C7,C2,C5x1,C4x1,C3pm,C4pm,C5pm")
     ap.add_argument("--details", default="", help="also write the complete record (every note, per-kernel model, L-BFGS traces) "
                                                   "to this file; the printed line stays compact")
     ap.add_argument("--verbose", action="store_true", help="print the complete record instead of the compact line")
@@ -1028,8 +1061,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra and args.extra_configs:
         out["extra_configs"] = []
         for name in [s for s in args.extra_configs.split(",") if s and s != args.config]:
-            heavy = name in ("C4", "C4dense", "C4expm", "C5", "C6", "C4pm", "C5pm")
-            slow = name in ("C5", "C6", "C5pm")
+            heavy = name in ("C4", "C4dense", "C4expm", "C5", "C6", "C7", "C4pm", "C5pm")
+            slow = name in ("C5", "C6", "C7", "C5pm")
             try:
                 out["extra_configs"].append(run_extra_config(qoc, name, dev_index, 3 if slow else (20 if heavy else 200),
                                                              1 if slow else (3 if heavy else 20)))

@@ -61,7 +61,8 @@ struct grape_ctx {
     int NT = 0;                   // tile family: tiles per dimension (padded n = 16 NT)
     size_t TSZ = 0;               // tile family: double2 per matrix dump
     bool pack2 = false;           // tile family, n <= 8: two members per 16x16 tile (block diagonal)
-    double2 *d_scratch = nullptr; // family 2 (sweep_any.hip): 6 matrices per (control array, member of the workspace chunk)
+    double2 *d_scratch = nullptr; // family 2 (sweep_any.hip): 6 matrices per (control array, member of the workspace chunk, propagator block)
+    int any_blocks = 1;           // family 2: workgroups per member of the propagator launch (grape::any_prop_blocks)
     size_t scratch_bytes = 0;
     bool grid = false;            // tile family, n = 33..64 (NT = 3, 4): a workgroup of NT x NT waves per matrix (sweep_grid.hip) -- the
                                   // reference's general flow only; GRAPE_GRID=1 sends smaller sizes there too (cross-checks)
@@ -153,6 +154,7 @@ struct grape_ctx {
     double *d_act_an = nullptr, *d_act_gn = nullptr;
     int act_R = 0;                             // sparse rows of the control operators (0: dense forms kernel)
     bool act_shared = true;                    // one set of control operators for every member
+    bool ctrl_shared = false;                  // the members' control operators are identical (memcmp)
     bool ctrl_scaled = false;                  // B_{k,c} = s_k B_{0,c} with some s_k != 1 (d_ctrl_scale: s_k per member): the
     double *d_ctrl_scale = nullptr;            //   hoisted flows' pre-pass runs on member 0's operators, members scale Gc_t
     size_t act_var_bytes = 0;                  // device bytes of the vector flow's operator buffers (re-sized per upload)
@@ -1257,6 +1259,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         HIP_TRY(c, hipMemcpy(c->d_ctrl_scale, ctrl_scale.data(), sizeof(double) * E, hipMemcpyHostToDevice));
     }
     const bool ctrl_hoistable = ctrl_shared || c->ctrl_scaled;   // ONE control sum per slice serves every member
+    c->ctrl_shared = ctrl_shared;
     const bool act_forced = act_env && act_env[0] == '1';
     // shared controls, or -- n <= 16 -- the members' own (at most six: a lane keeps its half rows of them in registers)
     const bool act_ok = (ctrl_hoistable || (c->NT == 1 && K <= 6)) && !(act_env && act_env[0] == '0') &&
@@ -1741,7 +1744,8 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             return fail(c, GRAPE_ERR_ALLOC, "grape_set_operators: a chunked time axis on a member-chunked workspace (budget too small for this ensemble)");
     }
     if (c->family == 2) {
-        const size_t need = sizeof(double2) * 6 * nn * (size_t)c->Ec * ws_batch(c);
+        c->any_blocks = grape::any_prop_blocks(c->cfg.n, c->cfg.n_slices, (long)c->cfg.n_ensemble * c->B, c->compute_units);
+        const size_t need = sizeof(double2) * 6 * nn * (size_t)c->Ec * ws_batch(c) * (size_t)c->any_blocks;
         if (c->scratch_bytes < need) {
             (void)hipFree(c->d_scratch);
             c->d_scratch = nullptr;
@@ -1969,7 +1973,7 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
         const size_t slot = (size_t)(c->ev_issued % kEventRing);
         e0 = c->ev[3 * slot];
         e1 = c->ev[3 * slot + 2];
-        if (c->family == 1) emid = c->ev[3 * slot + 1];
+        if (c->family == 1 || (c->family == 2 && c->any_blocks > 1)) emid = c->ev[3 * slot + 1];
         c->ev_has_mid[slot] = emid ? 1 : 0;
         c->ev_issued += 1;
         HIP_TRY(c, hipEventRecord(e0, stream));
@@ -2048,6 +2052,9 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
             a.s_forced = c->cfg.expm_squarings;
             a.variant = c->cfg.variant;
             a.dt = c->cfg.duration / c->cfg.n_slices;
+            a.prop_blocks = c->any_blocks;
+            a.ev_mid = lo == 0 ? emid : nullptr;
+            a.shared_b = c->ctrl_shared ? c->d_ops + nn : nullptr;
             HIP_TRY(c, grape::launch_sweep_any(a, stream));
             return GRAPE_OK;
         }

@@ -236,12 +236,22 @@ struct AnyParams {
     const double *x;          // (K, N, n_x)
     double2 *props, *states;  // N matrices per (control array, member)
     double2 *costates;        // nullable (GRAPE_FLAG_KEEP_COSTATES)
-    double2 *scratch;         // 6 matrices per (control array, member)
+    double2 *scratch;         // 6 matrices per (control array, member, propagator block)
     double *member_out;       // rows of K N + 1 doubles; row of (control array z, member k) at (z * E_rows + k)
     int32_t n, K, N, E, E_rows, n_x, sand, s_forced, variant;
     double dt;
+    // Few members (fewer than the device has compute units -- the rule at these sizes): the propagators, which do not depend
+    // on one another, are formed by prop_blocks workgroups per member (blockIdx.z: slices [z spb, (z + 1) spb)) in a launch of
+    // their own (phase 1), the chain -- sequential in time -- by one workgroup per member behind it (phase 2).  prop_blocks <=
+    // 1: one launch does both (phase 0).
+    int32_t prop_blocks, phase;
+    hipEvent_t ev_mid;        // nullable: recorded behind the propagator launch (prop_blocks > 1 only)
+    int32_t abl;              // diagnostic ablation mask (GRAPE_ANY_ABL; wrong results): 1 no MFMAs, 2 no traces, 4 no operand fetch
+    const double2 *shared_b;  // nullable: the members' control operators are identical -- member 0's [B_1..B_K] for everybody
+                              // (K n^2 16 B that stay in L2 instead of E times as much streamed from memory per slice)
 };
 hipError_t launch_sweep_any(const AnyParams &p, hipStream_t stream);
+int any_prop_blocks(int n, int N, long units, int cus);    // how many propagator blocks per member the launcher will use
 
 // n = 33..64 (NT = 3, 4; sweep_grid.hip): a workgroup of NT x NT waves per matrix, the reference's general flow
 hipError_t launch_sweep_grid(int NT, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);

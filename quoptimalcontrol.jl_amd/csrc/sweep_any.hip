@@ -8,12 +8,17 @@
 //     G_t = (-i dt)(A + sum_c x[c,t] B_c) in the reference's association, P_t = exp(G_t) (degree-8 Taylor polynomial in three
 //     products + squarings, theta8 = 0.08: cmat.hpp's constants), forward states stored (src/GRAPE.jl:53-63), costates
 //     pulled back (:65-75), gradient traces (:261-303) and the figure of merit at t = N (:77, :94).
-// A product C = op(A) op(B) is n^2 dot products spread over the threads (thread idx -> element (idx % n, idx / n): the left
-// operand's column is read coalesced, the right operand's entry is a broadcast).  Reductions (norm bound, traces) go through
-// LDS in a fixed order: results are bitwise reproducible.  Operators and workspace are plain column-major n x n ComplexF64
+// A product C = op(A) op(B): n = 1 (and GRAPE_ANY_MFMA=0) n^2 dot products spread over the threads (any_mm); from n = 17 on
+// the FP64 matrix cores (any_mm_mfma, round 6): the workgroup's 16 waves own the 32 x 32 blocks of a 128 x 128 block of C and
+// the operands stream from memory through LDS in panels of 16 k values.  Reductions (norm bound, traces) go through LDS in a
+// fixed order: results are bitwise reproducible.  Operators and workspace are plain column-major n x n ComplexF64
 // per member: ops [A | B_1..B_K | Xi | Xt], props / states / costates N matrices each, scratch 6 matrices.
+#include <algorithm>
+#include <cstdlib>
+
 #include "cmat.hpp"
 #include "grape_kernels.hpp"
+#include "tile.hpp"
 
 namespace grape {
 
@@ -25,7 +30,7 @@ template <bool HA, bool HB>
 __device__ void any_mm(int n, const double2 *__restrict__ A, const double2 *__restrict__ B, double2 *__restrict__ C)
 {
     const int nn = n * n;
-    for (int idx = threadIdx.x; idx < nn; idx += kAnyThreads) {
+    for (int idx = threadIdx.x; idx < nn; idx += (int)blockDim.x) {
         const int i = idx % n, j = idx / n;
         double sr = 0.0, si = 0.0;
         for (int k = 0; k < n; ++k) {
@@ -42,78 +47,317 @@ __device__ void any_mm(int n, const double2 *__restrict__ A, const double2 *__re
     __syncthreads();
 }
 
-// sum over the workgroup of one complex value per thread, in thread order (deterministic); result in every thread
-__device__ double2 any_block_sum(double vr, double vi, double *s_red)
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product on the FP64 matrix cores (round 6; VERDICT r5: "n > 64 is a scalar fallback").  A 128 x 128 ComplexF64 matrix
+// is 256 KB -- half a compute unit's register file, more than its LDS -- so the operands stay in memory and stream through LDS.
+// The workgroup is 512 threads = 8 waves, two per SIMD with 256 registers each (a 16-wave workgroup's 128 registers spilled
+// inside the product loop: 150 us per 128 x 128 product against 64):
+//   * C is walked in 128 x 128 blocks; wave (wi, wj) of the 2 x 4 wave grid accumulates the 64 x 32 block (wi, wj) of it: 4 x 2
+//     tiles of v_mfma_f64_16x16x4, (re, im) accumulators, four real products per complex one;
+//   * per panel of 16 k values every thread fetches four entries of op(A) (128 rows x 16 k) and four of op(B) (16 k x 128
+//     columns), conjugated where the operand is a conjugate transpose, into registers WHILE the previous panel is multiplied,
+//     then writes them to the two LDS images (k-contiguous, [re plane | im plane], row pitch 18 doubles: the 16-byte
+//     fragment reads of 16 rows x 4 lane groups spread over all bank groups), two buffers taking turns -- one barrier per panel;
+//   * fragments: lane (lo, hi) takes k = 4 hi + kb (both operands the same assignment, as sweep_grid.hip), two ds_read_b128
+//     per plane and tile row; the B-side fragment is the MFMA's FIRST operand, so the accumulator holds C TRANSPOSED in the
+//     D layout (row 4 r + hi = column of C, column lo = row of C) and 16 lanes store 256 contiguous bytes of a column of C.
+// Per panel and wave: 128 MFMAs, 24 LDS reads.  C must not alias A or B.  Ends in a workgroup barrier.
+constexpr int kAnyMfmaThreads = 512;
+constexpr int kAnyPitch = 18;                          // doubles per image row: 16 k values + 2
+constexpr int kAnyPlane = 128 * kAnyPitch;             // doubles per plane
+constexpr int kAnyBuf = 4 * kAnyPlane;                 // doubles of one buffer: two images x two planes (73 728 B)
+constexpr size_t kAnyImgBytes = sizeof(double) * 2 * kAnyBuf;        // two buffers: a panel is written while the previous one is read
+
+// EPI: what to do with element (i, j) of the product -- the plain store, or a fused element-wise step (the Taylor combinations
+// of the expm: at n = 128 every separate pass over a matrix is 0.5 - 1 MB through memory for a workgroup that gets ~20 GB/s of
+// the device's bandwidth when all compute units run; the propagator launch was memory-bound with them).  It may read and
+// write other matrices at (i, j) but must not write an OPERAND of this product (later 128-blocks read them again).
+// Two phases, eight elements (one tile row of the wave's block: row i, eight columns) at a time: load(idx) fetches what the step
+// needs at element idx -- all eight issued before any is used (one at a time, every element waited a memory round trip: a
+// 128 x 128 product spent more time in its epilogue than in its matrix instructions) -- then store(idx, i, j, v, loaded).
+struct AnyStore {
+    double2 *__restrict__ C;
+    struct L {};
+    __device__ L load(size_t) const { return L{}; }
+    __device__ void store(size_t idx, int, int, double2 v, const L &) const { C[idx] = v; }
+};
+
+template <bool HA, bool HB, typename EPI>
+__device__ void any_mm_mfma(int n, const double2 *__restrict__ A, const double2 *__restrict__ B, double *__restrict__ img, EPI epi,
+                            int abl = 0)
 {
-    __syncthreads();
-    s_red[threadIdx.x] = vr;
-    s_red[kAnyThreads + threadIdx.x] = vi;
-    __syncthreads();
-    for (int d = kAnyThreads / 2; d >= 1; d >>= 1) {
-        if ((int)threadIdx.x < d) {
-            s_red[threadIdx.x] += s_red[threadIdx.x + d];
-            s_red[kAnyThreads + threadIdx.x] += s_red[kAnyThreads + threadIdx.x + d];
-        }
-        __syncthreads();
+    constexpr int TH = kAnyMfmaThreads, NQ = 1024 / TH;         // k pairs per thread, operand and panel
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 15, hi = lane >> 4;
+    const int wi = wave >> 2, wj = wave & 3;           // rows 64 wi .., columns 32 wj ..
+    const int nsb = (n + 127) >> 7, npan = (n + 15) >> 4;
+    // this thread's entries of a panel: PAIRS of adjacent k values (written to the images as one 16-byte store per plane: with
+    // the 144-byte row pitch the 16 lanes of a store phase hit 16 different bank groups; single 8-byte entries of consecutive
+    // rows collided four ways and the stash took half as long as the products).  Pair e = tid + TH q -> (row / column within the
+    // 128-block, k pair within the panel); rows run fastest over the lanes where the operand is read along its rows.
+    int ar_[NQ], ak_[NQ], br_[NQ], bk_[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = tid + TH * q;
+        ar_[q] = HA ? e >> 3 : e & 127;
+        ak_[q] = 2 * (HA ? e & 7 : e >> 7);
+        br_[q] = HB ? e & 127 : e >> 3;
+        bk_[q] = 2 * (HB ? e >> 7 : e & 7);
     }
-    return make_double2(s_red[0], s_red[kAnyThreads]);
+    for (int bj = 0; bj < nsb; ++bj)
+        for (int bi = 0; bi < nsb; ++bi) {
+            const int i0 = 128 * bi, j0 = 128 * bj;
+            const bool active = i0 + 64 * wi < n && j0 + 32 * wj < n;      // (wave-uniform)
+            d4 cre[4][2], cim[4][2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    cre[a][b] = (d4){0, 0, 0, 0};
+                    cim[a][b] = (d4){0, 0, 0, 0};
+                }
+            double2 ra[NQ][2], rb[NQ][2];
+            auto fetch = [&](int pnl) {
+                const int k0 = 16 * pnl;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        {
+                            const int i = i0 + ar_[q], kk = k0 + ak_[q] + u;
+                            const unsigned at = HA ? (unsigned)kk + (unsigned)i * (unsigned)n : (unsigned)i + (unsigned)kk * (unsigned)n;
+                            double2 v = (i < n && kk < n) ? A[at] : make_double2(0.0, 0.0);
+                            if (HA) v.y = -v.y;
+                            ra[q][u] = v;
+                        }
+                        {
+                            const int j = j0 + br_[q], kk = k0 + bk_[q] + u;
+                            const unsigned at = HB ? (unsigned)j + (unsigned)kk * (unsigned)n : (unsigned)kk + (unsigned)j * (unsigned)n;
+                            double2 v = (j < n && kk < n) ? B[at] : make_double2(0.0, 0.0);
+                            if (HB) v.y = -v.y;
+                            rb[q][u] = v;
+                        }
+                    }
+            };
+            auto stash = [&](int buf) {
+                double *__restrict__ ia = img + buf * kAnyBuf, *__restrict__ ib = ia + 2 * kAnyPlane;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    double *pa = ia + ar_[q] * kAnyPitch + ak_[q], *pb = ib + br_[q] * kAnyPitch + bk_[q];
+                    *reinterpret_cast<double2 *>(pa) = make_double2(ra[q][0].x, ra[q][1].x);
+                    *reinterpret_cast<double2 *>(pa + kAnyPlane) = make_double2(ra[q][0].y, ra[q][1].y);
+                    *reinterpret_cast<double2 *>(pb) = make_double2(rb[q][0].x, rb[q][1].x);
+                    *reinterpret_cast<double2 *>(pb + kAnyPlane) = make_double2(rb[q][0].y, rb[q][1].y);
+                }
+            };
+            // buffer b holds panel p (stashed, behind a barrier), the registers panel p + 1: the stash of p + 1 goes to the OTHER
+            // buffer (last read one iteration ago, in front of that iteration's barrier), the fetch of p + 2 is in flight under
+            // the products of p -- one barrier per panel, and a wave's stash runs under the other waves' products
+            fetch(0);
+            __syncthreads();                           // (the previous block's / product's readers of buffer 0 are done)
+            stash(0);
+            if (npan > 1)
+                fetch(1);
+            __syncthreads();
+            for (int pnl = 0; pnl < npan; ++pnl) {
+                const int buf = pnl & 1;
+                const double *__restrict__ ia = img + buf * kAnyBuf, *__restrict__ ib = ia + 2 * kAnyPlane;
+                if (pnl + 1 < npan)
+                    stash(buf ^ 1);
+                if (pnl + 2 < npan && !(abl & 4))
+                    fetch(pnl + 2);
+                if (active && !(abl & 1)) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {      // two k values of the lane's four per 16-byte read
+                        double2 bre[2], bim[2];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const int rb_ = (32 * wj + 16 * t + lo) * kAnyPitch + 4 * hi + 2 * h;
+                            bre[t] = *reinterpret_cast<const double2 *>(ib + rb_);
+                            bim[t] = *reinterpret_cast<const double2 *>(ib + kAnyPlane + rb_);
+                        }
+#pragma unroll
+                        for (int ti = 0; ti < 4; ++ti) {
+                            const int ra_ = (64 * wi + 16 * ti + lo) * kAnyPitch + 4 * hi + 2 * h;
+                            const double2 are = *reinterpret_cast<const double2 *>(ia + ra_);
+                            const double2 aim = *reinterpret_cast<const double2 *>(ia + kAnyPlane + ra_);
+#pragma unroll
+                            for (int kb = 0; kb < 2; ++kb) {
+                                const double ar = kb ? are.y : are.x, ai = kb ? aim.y : aim.x;
+#pragma unroll
+                                for (int tj = 0; tj < 2; ++tj) {
+                                    const double br = kb ? bre[tj].y : bre[tj].x, bi_ = kb ? bim[tj].y : bim[tj].x;
+                                    cre[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(br, ar, cre[ti][tj], 0, 0, 0);
+                                    cim[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(br, ai, cim[ti][tj], 0, 0, 0);
+                                    cre[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi_, -ai, cre[ti][tj], 0, 0, 0);
+                                    cim[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi_, ar, cim[ti][tj], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();                       // panel p + 1 is stashed, panel p is read
+            }
+            if (active) {
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) {
+                    const int i = i0 + 64 * wi + 16 * ti + lo;
+                    typename EPI::L ld[8];
+                    size_t at[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {      // (tj, r) = (e >> 2, e & 3); out-of-range elements read a valid address
+                        const int j = j0 + 32 * wj + 16 * (e >> 2) + 4 * (e & 3) + hi;
+                        at[e] = (size_t)min(i, n - 1) + (size_t)min(j, n - 1) * n;
+                        ld[e] = epi.load(at[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int j = j0 + 32 * wj + 16 * (e >> 2) + 4 * (e & 3) + hi;
+                        if (i < n && j < n)
+                            epi.store(at[e], i, j, make_double2(cre[ti][e >> 2][e & 3], cim[ti][e >> 2][e & 3]), ld[e]);
+                    }
+                }
+            }
+        }
+    __syncthreads();
 }
 
-__global__ __launch_bounds__(kAnyThreads) void any_sweep_kernel(const AnyParams p)
+__device__ int g_any_abl = 0;                         // (diagnostic: set through AnyParams.abl by thread 0 of every workgroup)
+
+// the product of the kernel below: matrix cores (MFMA, n >= 17 in practice n > 64) or the scalar dot products
+template <bool MFMA, bool HA, bool HB>
+__device__ __forceinline__ void any_prod(int n, const double2 *__restrict__ A, const double2 *__restrict__ B, double2 *__restrict__ C,
+                                         double *__restrict__ img)
 {
-    __shared__ double s_red[2 * kAnyThreads];
+    if constexpr (MFMA)
+        any_mm_mfma<HA, HB>(n, A, B, img, AnyStore{C}, g_any_abl);
+    else
+        any_mm<HA, HB>(n, A, B, C);
+}
+
+// NV sums over the workgroup at once (wave butterflies, then the 16 waves in wave order through LDS: deterministic, three
+// barriers); the results in every thread.  s_red: at least 16 NV + NV doubles.
+template <int NV, int TH>
+__device__ void any_block_sum_n(double (&v)[NV], double *s_red)
+{
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            v[q] += __shfl_xor(v[q], d, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+            s_red[wave * NV + q] = v[q];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NV) {
+        double acc = 0.0;
+        for (int w = 0; w < TH / 64; ++w)
+            acc += s_red[w * NV + threadIdx.x];
+        s_red[(TH / 64) * NV + threadIdx.x] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+        v[q] = s_red[(TH / 64) * NV + q];
+}
+
+template <bool MFMA>
+__global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_sweep_kernel(const AnyParams p)
+{
+    constexpr int TH = MFMA ? kAnyMfmaThreads : kAnyThreads;       // (the matrix-core product wants 256 registers per wave)
+    if (p.abl && threadIdx.x == 0)
+        g_any_abl = p.abl;
+    __shared__ double s_red[2 * TH];
+    extern __shared__ double s_any_img[];              // MFMA: the two operand images of any_mm_mfma
     const int n = p.n, nn = n * n, K = p.K, N = p.N;
     const int k = blockIdx.x, z = blockIdx.y;
     const double2 *__restrict__ ops = p.ops + (size_t)k * (K + 3) * nn;
-    const double2 *__restrict__ opA = ops, *__restrict__ opB = ops + nn, *__restrict__ opXi = ops + (size_t)(1 + K) * nn,
-                  *__restrict__ opXt = opXi + nn;
+    const double2 *__restrict__ opA = ops, *__restrict__ opB = p.shared_b ? p.shared_b : ops + nn,
+                  *__restrict__ opXi = ops + (size_t)(1 + K) * nn, *__restrict__ opXt = opXi + nn;
     const double *__restrict__ x = p.x + (size_t)z * K * N;
     const size_t kw = (size_t)z * p.E + k;
     double2 *__restrict__ Pk = p.props + kw * N * nn, *__restrict__ Xk = p.states + kw * N * nn;
     double2 *__restrict__ Lk = p.costates ? p.costates + kw * N * nn : nullptr;
-    double2 *__restrict__ sc = p.scratch + kw * 6 * nn;
+    const int nblk = p.prop_blocks > 1 ? p.prop_blocks : 1;
+    double2 *__restrict__ sc = p.scratch + (kw * nblk + (p.phase == 1 ? blockIdx.z : 0)) * 6 * nn;
     double2 *G = sc, *A2 = sc + nn, *A4 = sc + 2 * (size_t)nn, *T = sc + 3 * (size_t)nn, *U = sc + 4 * (size_t)nn, *Y = sc + 5 * (size_t)nn;
     double *__restrict__ out = p.member_out + ((size_t)z * p.E_rows + k) * ((size_t)K * N + 1);
     const double dt = p.dt;
 
     // ------------------------------------------------------------ propagators, src/timeevolution.jl:98-110 (:45-57 static)
-    for (int t = 0; t < N; ++t) {
-        for (int idx = threadIdx.x; idx < nn; idx += kAnyThreads) {
-            double hr, hi;
-            if (p.variant == 0) {                      // (0 + B_1 x_1 + ...) + A
-                hr = 0.0;
-                hi = 0.0;
-            } else {                                   // A + B_1 x_1 + ...
-                hr = opA[idx].x;
-                hi = opA[idx].y;
+    const int spb = (N + nblk - 1) / nblk;
+    const int t_lo = p.phase == 1 ? (int)blockIdx.z * spb : 0, t_hi = p.phase == 1 ? min(N, t_lo + spb) : (p.phase == 2 ? 0 : N);
+    for (int t = t_lo; t < t_hi; ++t) {
+        // four elements per thread and pass: the K + 1 operator entries of each are independent loads -- issued one element
+        // and one control at a time (round 5) every load waited for the one before: ~230 memory round trips per thread and
+        // slice, 0.3 ms of the 0.6 ms a 128 x 128 slice took without its products
+        for (int base = threadIdx.x; base < nn; base += 4 * TH) {
+            double hr[4], hi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = min(base + u * TH, nn - 1);
+                if (p.variant == 0) {                  // (0 + B_1 x_1 + ...) + A
+                    hr[u] = 0.0;
+                    hi[u] = 0.0;
+                } else {                               // A + B_1 x_1 + ...
+                    hr[u] = opA[idx].x;
+                    hi[u] = opA[idx].y;
+                }
             }
             for (int c = 0; c < K; ++c) {
                 const double xv = x[c + (size_t)t * K];
-                const double2 b = opB[(size_t)c * nn + idx];
-                hr = fma(b.x, xv, hr);
-                hi = fma(b.y, xv, hi);
+                double2 b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    b[u] = opB[(size_t)c * nn + min(base + u * TH, nn - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    hr[u] = fma(b[u].x, xv, hr[u]);
+                    hi[u] = fma(b[u].y, xv, hi[u]);
+                }
             }
-            if (p.variant == 0) {
-                hr += opA[idx].x;
-                hi += opA[idx].y;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * TH;
+                if (idx < nn) {
+                    if (p.variant == 0) {
+                        hr[u] += opA[idx].x;
+                        hi[u] += opA[idx].y;
+                    }
+                    G[idx] = make_double2(dt * hi[u], -dt * hr[u]);      // (-i dt) H
+                }
             }
-            G[idx] = make_double2(dt * hi, -dt * hr);  // (-i dt) H
         }
         __syncthreads();
-        // |G|_1 bound: max column sum of |re| + |im|
+        // |G|_1 bound: max column sum of |re| + |im|.  A wave per column, its lanes along the rows (coalesced, independent loads),
+        // lane partials summed by a butterfly (fixed order); the maximum over columns needs no order
         double cs = 0.0;
-        for (int j = threadIdx.x; j < n; j += kAnyThreads) {
-            double s = 0.0;
-            for (int i = 0; i < n; ++i)
-                s += fabs(G[i + (size_t)j * n].x) + fabs(G[i + (size_t)j * n].y);
-            cs = fmax(cs, s);
+        {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            for (int j = wave; j < n; j += TH / 64) {
+                double part = 0.0;
+                for (int i = lane; i < n; i += 64) {
+                    const double2 g = G[i + (size_t)j * n];
+                    part += fabs(g.x) + fabs(g.y);
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1)
+                    part += __shfl_xor(part, d, 64);
+                cs = (part != part || cs != cs) ? part + cs : fmax(cs, part);      // (a NaN stays a NaN)
+            }
         }
         __syncthreads();
         s_red[threadIdx.x] = cs;
         __syncthreads();
-        for (int d = kAnyThreads / 2; d >= 1; d >>= 1) {
-            if ((int)threadIdx.x < d)
-                s_red[threadIdx.x] = fmax(s_red[threadIdx.x], s_red[threadIdx.x + d]);
+        for (int d = TH / 2; d >= 1; d >>= 1) {
+            if ((int)threadIdx.x < d) {
+                const double a_ = s_red[threadIdx.x], b_ = s_red[threadIdx.x + d];
+                s_red[threadIdx.x] = (a_ != a_ || b_ != b_) ? a_ + b_ : fmax(a_, b_);
+            }
             __syncthreads();
         }
         const double colmax = s_red[0];
@@ -121,101 +365,149 @@ __global__ __launch_bounds__(kAnyThreads) void any_sweep_kernel(const AnyParams 
         const int s = p.s_forced >= 0 ? p.s_forced : squarings_for(colmax);
         if (s > 0) {
             const double scl = ldexp(1.0, -s);
-            for (int idx = threadIdx.x; idx < nn; idx += kAnyThreads)
+            for (int idx = threadIdx.x; idx < nn; idx += TH)
                 G[idx] = make_double2(G[idx].x * scl, G[idx].y * scl);
             __syncthreads();
         }
-        any_mm<false, false>(n, G, G, A2);
-        for (int idx = threadIdx.x; idx < nn; idx += kAnyThreads)
-            T[idx] = make_double2(fma(kX1, G[idx].x, kX2 * A2[idx].x), fma(kX1, G[idx].y, kX2 * A2[idx].y));
-        __syncthreads();
-        any_mm<false, false>(n, A2, T, A4);
-        for (int idx = threadIdx.x; idx < nn; idx += kAnyThreads) {
-            const bool diag = (idx % n) == (idx / n);
-            U[idx] = make_double2(fma(kX3, A2[idx].x, A4[idx].x), fma(kX3, A2[idx].y, A4[idx].y));
-            T[idx] = make_double2(fma(kX5, G[idx].x, fma(kX6, A2[idx].x, kX7 * A4[idx].x)) + (diag ? kX4 : 0.0),
-                                  fma(kX5, G[idx].y, fma(kX6, A2[idx].y, kX7 * A4[idx].y)));
-        }
-        __syncthreads();
         double2 *P = Pk + (size_t)t * nn;
-        any_mm<false, false>(n, U, T, s > 0 ? Y : P);
         double2 *cur = s > 0 ? Y : P;
-        for (int idx = threadIdx.x; idx < nn; idx += kAnyThreads) {
-            const bool diag = (idx % n) == (idx / n);
-            cur[idx] = make_double2(cur[idx].x + fma(kY2, A2[idx].x, G[idx].x) + (diag ? 1.0 : 0.0),
-                                    cur[idx].y + fma(kY2, A2[idx].y, G[idx].y));
+        if constexpr (MFMA) {
+            // the Taylor combinations ride on the products' epilogues (same operations on the same values as the passes below)
+            struct Epi1 {                              // A2 = G G ; T = x1 G + x2 A2
+                const double2 *G;
+                double2 *A2, *T;
+                struct L { double2 g; };
+                __device__ L load(size_t idx) const { return L{G[idx]}; }
+                __device__ void store(size_t idx, int, int, double2 v, const L &l) const
+                {
+                    A2[idx] = v;
+                    T[idx] = make_double2(fma(kX1, l.g.x, kX2 * v.x), fma(kX1, l.g.y, kX2 * v.y));
+                }
+            };
+            struct Epi2 {                              // A4 = A2 T (not stored) ; U = x3 A2 + A4 ; T2 = x4 I + x5 G + x6 A2 + x7 A4
+                const double2 *G, *A2;
+                double2 *U, *T2;
+                struct L { double2 g, a2; };
+                __device__ L load(size_t idx) const { return L{G[idx], A2[idx]}; }
+                __device__ void store(size_t idx, int i, int j, double2 v, const L &l) const
+                {
+                    U[idx] = make_double2(fma(kX3, l.a2.x, v.x), fma(kX3, l.a2.y, v.y));
+                    T2[idx] = make_double2(fma(kX5, l.g.x, fma(kX6, l.a2.x, kX7 * v.x)) + (i == j ? kX4 : 0.0),
+                                           fma(kX5, l.g.y, fma(kX6, l.a2.y, kX7 * v.y)));
+                }
+            };
+            struct Epi3 {                              // P = A8 + G + y2 A2 + I
+                const double2 *G, *A2;
+                double2 *P;
+                struct L { double2 g, a2; };
+                __device__ L load(size_t idx) const { return L{G[idx], A2[idx]}; }
+                __device__ void store(size_t idx, int i, int j, double2 v, const L &l) const
+                {
+                    P[idx] = make_double2(v.x + fma(kY2, l.a2.x, l.g.x) + (i == j ? 1.0 : 0.0), v.y + fma(kY2, l.a2.y, l.g.y));
+                }
+            };
+            any_mm_mfma<false, false>(n, G, G, s_any_img, Epi1{G, A2, T}, p.abl);
+            any_mm_mfma<false, false>(n, A2, T, s_any_img, Epi2{G, A2, U, A4}, p.abl);        // (T2 in A4's buffer)
+            any_mm_mfma<false, false>(n, U, A4, s_any_img, Epi3{G, A2, cur}, p.abl);
+        } else {
+            any_mm<false, false>(n, G, G, A2);
+            for (int idx = threadIdx.x; idx < nn; idx += TH)
+                T[idx] = make_double2(fma(kX1, G[idx].x, kX2 * A2[idx].x), fma(kX1, G[idx].y, kX2 * A2[idx].y));
+            __syncthreads();
+            any_mm<false, false>(n, A2, T, A4);
+            for (int idx = threadIdx.x; idx < nn; idx += TH) {
+                const bool diag = (idx % n) == (idx / n);
+                U[idx] = make_double2(fma(kX3, A2[idx].x, A4[idx].x), fma(kX3, A2[idx].y, A4[idx].y));
+                T[idx] = make_double2(fma(kX5, G[idx].x, fma(kX6, A2[idx].x, kX7 * A4[idx].x)) + (diag ? kX4 : 0.0),
+                                      fma(kX5, G[idx].y, fma(kX6, A2[idx].y, kX7 * A4[idx].y)));
+            }
+            __syncthreads();
+            any_mm<false, false>(n, U, T, cur);
+            for (int idx = threadIdx.x; idx < nn; idx += TH) {
+                const bool diag = (idx % n) == (idx / n);
+                cur[idx] = make_double2(cur[idx].x + fma(kY2, A2[idx].x, G[idx].x) + (diag ? 1.0 : 0.0),
+                                        cur[idx].y + fma(kY2, A2[idx].y, G[idx].y));
+            }
+            __syncthreads();
         }
-        __syncthreads();
         for (int i = 0; i < s; ++i) {                  // undo the scaling: ping-pong Y <-> U, the last square lands in P
             double2 *dst = (i == s - 1) ? P : (cur == Y ? U : Y);
-            any_mm<false, false>(n, cur, cur, dst);
+            any_prod<MFMA, false, false>(n, cur, cur, dst, s_any_img);
             cur = dst;
         }
     }
+    if (p.phase == 1)
+        return;                                        // (the chain runs in a launch of its own)
     // ------------------------------------------------------------ forward sweep, src/GRAPE.jl:53-63
-    for (int idx = threadIdx.x; idx < nn; idx += kAnyThreads)
+    for (int idx = threadIdx.x; idx < nn; idx += TH)
         Xk[idx] = opXi[idx];
     __syncthreads();
     for (int t = 0; t + 1 < N; ++t) {
         const double2 *P = Pk + (size_t)t * nn;
         if (p.sand) {
-            any_mm<false, true>(n, Xk + (size_t)t * nn, P, Y);                       // X P'       (:245)
-            any_mm<false, false>(n, P, Y, Xk + (size_t)(t + 1) * nn);                // P (X P')   (:246)
+            any_prod<MFMA, false, true>(n, Xk + (size_t)t * nn, P, Y, s_any_img);                       // X P'       (:245)
+            any_prod<MFMA, false, false>(n, P, Y, Xk + (size_t)(t + 1) * nn, s_any_img);                // P (X P')   (:246)
         } else {
-            any_mm<false, false>(n, P, Xk + (size_t)t * nn, Xk + (size_t)(t + 1) * nn);       // :226
+            any_prod<MFMA, false, false>(n, P, Xk + (size_t)t * nn, Xk + (size_t)(t + 1) * nn, s_any_img);       // :226
         }
     }
     // ------------------------------------------------------------ backward sweep + gradient, :65-92
     const double gs = p.sand ? -dt : (p.variant == 0 ? -2.0 * dt : 2.0 * dt);
     double2 *Lc = A2, *Ln = A4;                        // costate at t + 1 / at t (scratch, swapped per slice)
-    for (int idx = threadIdx.x; idx < nn; idx += kAnyThreads)
+    for (int idx = threadIdx.x; idx < nn; idx += TH)
         Lc[idx] = opXt[idx];
     __syncthreads();
     for (int t = N - 1; t >= 0; --t) {
         const double2 *P = Pk + (size_t)t * nn, *X = Xk + (size_t)t * nn;
         if (p.sand) {
-            any_mm<false, false>(n, Lc, P, Y);                                       // L P        (:248)
-            any_mm<true, false>(n, P, Y, Ln);                                        // P' (L P)   (:249)
+            any_prod<MFMA, false, false>(n, Lc, P, Y, s_any_img);                                       // L P        (:248)
+            any_prod<MFMA, true, false>(n, P, Y, Ln, s_any_img);                                        // P' (L P)   (:249)
         } else {
-            any_mm<true, false>(n, P, Lc, Ln);                                       // P' L       (:228)
+            any_prod<MFMA, true, false>(n, P, Lc, Ln, s_any_img);                                       // P' L       (:228)
         }
         if (Lk) {
-            for (int idx = threadIdx.x; idx < nn; idx += kAnyThreads)
+            for (int idx = threadIdx.x; idx < nn; idx += TH)
                 Lk[(size_t)t * nn + idx] = Ln[idx];
         }
-        // z = tr(X' L)
-        double zr_p = 0.0, zi_p = 0.0;
-        for (int idx = threadIdx.x; idx < nn; idx += kAnyThreads) {
-            const double2 a = X[idx], b = Ln[idx];
-            zr_p = fma(a.x, b.x, zr_p);
-            zr_p = fma(a.y, b.y, zr_p);
-            zi_p = fma(a.x, b.y, zi_p);
-            zi_p = fma(-a.y, b.x, zi_p);
-        }
-        const double2 zz = any_block_sum(zr_p, zi_p, s_red);
         // R = X L' [- L' X]
-        any_mm<false, true>(n, X, Ln, T);
+        any_prod<MFMA, false, true>(n, X, Ln, T, s_any_img);
         if (p.sand) {
-            any_mm<true, false>(n, Ln, X, U);
-            for (int idx = threadIdx.x; idx < nn; idx += kAnyThreads)
+            any_prod<MFMA, true, false>(n, Ln, X, U, s_any_img);
+            for (int idx = threadIdx.x; idx < nn; idx += TH)
                 T[idx] = make_double2(T[idx].x - U[idx].x, T[idx].y - U[idx].y);
             __syncthreads();
         }
-        for (int c = 0; c < K; ++c) {                  // w = sum_ij B_c[i][j] R[j][i]
-            const double2 *Bc = opB + (size_t)c * nn;
-            double wr = 0.0, wi = 0.0;
-            for (int idx = threadIdx.x; idx < nn; idx += kAnyThreads) {
+        // z = tr(X' L) and w_c = sum_ij B_c[i][j] R[j][i], four controls per pass over R and per workgroup reduction
+        double2 zz = make_double2(0.0, 0.0);
+        for (int c0 = 0; c0 < K && !(p.abl & 2); c0 += 4) {
+            double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int idx = threadIdx.x; idx < nn; idx += TH) {
                 const int i = idx % n, j = idx / n;
-                const double2 b = Bc[idx], r = T[j + (size_t)i * n];
-                wr = fma(b.x, r.x, wr);
-                wr = fma(-b.y, r.y, wr);
-                wi = fma(b.x, r.y, wi);
-                wi = fma(b.y, r.x, wi);
+                const double2 r = T[j + (size_t)i * n];
+                if (c0 == 0) {
+                    const double2 a = X[idx], b = Ln[idx];
+                    v[0] = fma(a.x, b.x, v[0]);
+                    v[0] = fma(a.y, b.y, v[0]);
+                    v[1] = fma(a.x, b.y, v[1]);
+                    v[1] = fma(-a.y, b.x, v[1]);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                    if (c0 + cc < K) {
+                        const double2 b = opB[(size_t)(c0 + cc) * nn + idx];
+                        v[2 + 2 * cc] = fma(b.x, r.x, v[2 + 2 * cc]);
+                        v[2 + 2 * cc] = fma(-b.y, r.y, v[2 + 2 * cc]);
+                        v[3 + 2 * cc] = fma(b.x, r.y, v[3 + 2 * cc]);
+                        v[3 + 2 * cc] = fma(b.y, r.x, v[3 + 2 * cc]);
+                    }
             }
-            const double2 ww = any_block_sum(wr, wi, s_red);
-            if (threadIdx.x == 0) {
-                const double im = p.sand ? ww.y : fma(ww.x, zz.y, ww.y * zz.x);
-                out[c + (size_t)t * K] = gs * im;
+            any_block_sum_n<10, TH>(v, s_red);
+            if (c0 == 0)
+                zz = make_double2(v[0], v[1]);
+            if ((int)threadIdx.x < 4 && c0 + (int)threadIdx.x < K) {
+                const int cc = threadIdx.x;
+                const double im = p.sand ? v[3 + 2 * cc] : fma(v[2 + 2 * cc], zz.y, v[3 + 2 * cc] * zz.x);
+                out[c0 + cc + (size_t)t * K] = gs * im;
             }
         }
         if (t == N - 1 && threadIdx.x == 0) {          // figure of merit at t = N (:77, :94)
@@ -234,9 +526,52 @@ __global__ __launch_bounds__(kAnyThreads) void any_sweep_kernel(const AnyParams 
     }
 }
 
-hipError_t launch_sweep_any(const AnyParams &p, hipStream_t stream)
+// Propagator blocks per member: about two workgroups per compute unit over the launch, at least 4 slices each (n >= 17 only:
+// below, the kernel is a correctness path).  GRAPE_ANY_BLOCKS=b forces b (tests; 1 = the single launch of round 5).
+int any_prop_blocks(int n, int N, long units, int cus)
 {
-    GRAPE_LAUNCH(any_sweep_kernel, dim3(p.E, p.n_x), dim3(kAnyThreads), 0, stream, p);
+    if (const char *e = std::getenv("GRAPE_ANY_BLOCKS"))
+        return (int)std::max(1L, std::min<long>(std::atol(e), N));
+    if (n < 17 || units >= 2L * cus)
+        return 1;
+    const long want = (2L * cus + units - 1) / units;
+    return (int)std::max(1L, std::min<long>(want, std::max(1, N / 4)));
+}
+
+hipError_t launch_sweep_any(const AnyParams &p0, hipStream_t stream)
+{
+    static const bool mfma_off = [] { const char *e = std::getenv("GRAPE_ANY_MFMA"); return e && e[0] == '0'; }();
+    const bool mfma = p0.n >= 17 && !mfma_off;
+    if (mfma) {
+        const hipError_t e = ensure_dynamic_lds((const void *)any_sweep_kernel<true>, kAnyImgBytes);
+        if (e != hipSuccess)
+            return e;
+    }
+    AnyParams p = p0;
+    if (const char *e = std::getenv("GRAPE_ANY_ABL"))
+        p.abl = std::atoi(e);
+    auto launch = [&](dim3 grid) {
+        if (mfma)
+            GRAPE_LAUNCH_AS(p.phase == 1 ? "any_prop_kernel" : "any_sweep_kernel", any_sweep_kernel<true>, grid, dim3(kAnyMfmaThreads),
+                            kAnyImgBytes, stream, p);
+        else
+            GRAPE_LAUNCH_AS(p.phase == 1 ? "any_prop_kernel" : "any_sweep_kernel", any_sweep_kernel<false>, grid, dim3(kAnyThreads), 0,
+                            stream, p);
+    };
+    if (p.prop_blocks > 1) {
+        p.phase = 1;
+        launch(dim3(p.E, p.n_x, p.prop_blocks));
+        if (p.ev_mid) {
+            const hipError_t e = hipEventRecord(p.ev_mid, stream);
+            if (e != hipSuccess)
+                return e;
+        }
+        p.phase = 2;
+        launch(dim3(p.E, p.n_x));
+    } else {
+        p.phase = 0;
+        launch(dim3(p.E, p.n_x));
+    }
     return hipGetLastError();
 }
 

@@ -1,7 +1,10 @@
 """GPU: the size-generic path (sweep_any.hip) for operator dimensions outside the specialised families -- n = 1 and n > 64.
 `_fom_and_gradient_GRAPE!` (src/GRAPE.jl:25-96) takes matrices of any size; so does grape_create now.  Correct at the 1e-10 bar
-(every member's (F_k, g_k), the ensemble sums, propagators / states / costates to 1e-12), not fast: plain vector FP64, the
-reference's general flow."""
+(every member's (F_k, g_k), the ensemble sums, propagators / states / costates to 1e-12), the reference's general flow.
+Round 6: from n = 17 on its products run on the FP64 matrix cores (any_mm_mfma: 128 x 128 blocks of C, operands streamed
+through LDS in k-panels; sizes that are and are not multiples of 16 / 32 / 128 below) and the propagators of an ensemble
+smaller than the device are formed by several workgroups per member (any_prop_kernel); GRAPE_ANY_MFMA=0 / GRAPE_ANY_BLOCKS=1
+keep round 5's scalar products / single launch -- all three agree."""
 import numpy as np
 import pytest
 
@@ -39,7 +42,7 @@ def _check(qoc, oracle, w, variant=0, **kw):
     return F, G
 
 
-@pytest.mark.parametrize("n", [1, 65, 80, 100])
+@pytest.mark.parametrize("n", [1, 65, 80, 96, 100, 128, 130])
 @pytest.mark.parametrize("sys_type,herm", [("UnitaryGate", True), ("StateTransfer", False), ("CoherenceTransfer", True)])
 @pytest.mark.parametrize("variant", [0, 1])
 def test_any_size_random(qoc, oracle, n, sys_type, herm, variant):
@@ -87,3 +90,26 @@ def test_exact_gradient_is_refused_outside_2_to_32(qoc):
     with pytest.raises(Exception) as ei:
         qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, gradient="exact")
     assert "2 <= n <= 64" in str(ei.value)
+
+
+def test_matrix_core_products_agree_with_the_scalar_ones(qoc, oracle, monkeypatch):
+    """any_mm_mfma against any_mm (GRAPE_ANY_MFMA=0) and the propagator launch against the single launch (GRAPE_ANY_BLOCKS=1)
+    on a size that fills neither the last tile nor the last 32-block (n = 77), with squarings; kernel names asserted."""
+    w = _random_problem(qoc, 77, 3, 9, 3, "StateTransfer", seed=31, hermitian=False, mixed=True)
+    w.A *= 0.15
+    w.B *= 0.15
+    res = {}
+    for tag, env in (("mfma", {}), ("scalar", {"GRAPE_ANY_MFMA": "0"}), ("one_launch", {"GRAPE_ANY_BLOCKS": "1"})):
+        for kk in ("GRAPE_ANY_MFMA", "GRAPE_ANY_BLOCKS"):
+            monkeypatch.delenv(kk, raising=False)
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
+            res[tag] = eng.eval(w.x)
+            names = eng.kernel_names()
+        assert ("any_prop_kernel" in names) == (tag != "one_launch"), names
+    F_ref, G_ref = oracle.ensemble_eval(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.x, w.T)
+    for tag, (F, G) in res.items():
+        assert_parity(F, G, F_ref, G_ref, w.n, what=tag)
+    assert res["mfma"][0] == res["one_launch"][0] and np.array_equal(res["mfma"][1], res["one_launch"][1])      # the same products
+    assert np.abs(res["mfma"][1] - res["scalar"][1]).max() <= 1e-12 * np.abs(res["scalar"][1]).max()
