@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GRAPE_ABI_VERSION 5
+#define GRAPE_ABI_VERSION 6
 
 typedef enum grape_status {
     GRAPE_OK = 0,
@@ -198,6 +198,16 @@ typedef struct grape_info {
                                       many members (src/solve.jl:166-187 is a serial loop with no such limit) -- same
                                       results bit for bit; grape_get_trajectory is not available on such a context */
     int32_t reserved0;
+    /* ---- ABI v6 ---- */
+    uint64_t workspace_budget_bytes; /* what the workspace arrays may take: 0.9 x the device memory free at grape_create minus the
+                                      other buffers, or GRAPE_MAX_WORKSPACE_BYTES -- with member_chunk, what makes a run's
+                                      chunk plan reproducible on another device / another day */
+    int32_t scaled_controls;       /* 1 after grape_set_operators found the members' control operators to be member 0's times one
+                                      real factor per member, B_{k,c} = s_k B_{0,c} (EnsembleProblem.B_g with amplitude
+                                      inhomogeneity, src/problems.jl:33-41): the flows built on the per-slice control sum keep
+                                      it (hoisted_controls = 1) and every member scales it by its s_k */
+    int32_t propagator_blocks;     /* kernel_family 2, n >= 17: workgroups per member of the propagator launch (1: one launch
+                                      forms the propagators and walks the chain) */
 } grape_info;
 
 /* Opaque RCCL bootstrap token (ncclUniqueId), see grape_comm_unique_id / grape_comm_attach. */

@@ -3557,6 +3557,9 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
         info->expm_action = s0->action ? 1 : 0;
         info->prop_chain = s0->thin_dpp ? 1 : 0;
         info->member_chunk = s0->Ec;
+        info->workspace_budget_bytes = s0->ws_budget;
+        info->scaled_controls = s0->ctrl_scaled ? 1 : 0;
+        info->propagator_blocks = s0->family == 2 ? s0->any_blocks : 0;
     }
     return GRAPE_OK;
 }

@@ -28,7 +28,7 @@ FLAG_FORCE_COLLECTIVE = 32
 FLAG_TIME_SAMPLED = 64
 FLAG_GROUP_PEER_SUM = 128
 MAX_DEVICES = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID_ARG", -2: "GRAPE_ERR_UNSUPPORTED",
           -3: "GRAPE_ERR_NO_DEVICE", -4: "GRAPE_ERR_HIP", -5: "GRAPE_ERR_NOT_READY",
@@ -70,7 +70,8 @@ class GrapeInfo(C.Structure):
                 ("states_stored", C.c_int32), ("rank_one_chain", C.c_int32),
                 ("sparse_controls", C.c_int32), ("fused_forward", C.c_int32),
                 ("time_chunks", C.c_int32), ("hoisted_controls", C.c_int32),
-                ("expm_action", C.c_int32), ("prop_chain", C.c_int32), ("member_chunk", C.c_int32), ("reserved0", C.c_int32)]
+                ("expm_action", C.c_int32), ("prop_chain", C.c_int32), ("member_chunk", C.c_int32), ("reserved0", C.c_int32),
+                ("workspace_budget_bytes", C.c_uint64), ("scaled_controls", C.c_int32), ("propagator_blocks", C.c_int32)]
 
 
 class GrapeLbfgsOptions(C.Structure):

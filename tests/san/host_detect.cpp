@@ -59,6 +59,33 @@ int main()
             if (n > 1 && (at / 2) % (size_t)(n + 1) != 0 && grape_host::hermitian_to_rounding(H.data(), n)) { std::printf("perturbed matrix accepted\n"); return 7; }
         }
 
+        {   // scaled control operators: B_k = s_k B_0 is recognised (factors recovered), one perturbed / non-finite entry is not
+            // (a random stream of its own: the checks above keep the sequence they were tuned on)
+            static uint64_t s2 = 0x9E3779B97F4A7C15ull;
+            const uint64_t keep_s = s;
+            s = s2;
+            const size_t Es = 2 + rnd() % 4, Ks = 1 + rnd() % 3, nn = (size_t)n * n, len = 2 * Ks * nn;
+            std::vector<double> Bs(Es * len), fac(Es, 1.0), got;
+            for (size_t e = 0; e < len; ++e) Bs[e] = (rnd() % 4 == 0) ? 0.0 : unif();
+            Bs[0] = 2.0;                                                            // the largest entry (the factor comes from it) ...
+            Bs[1] = 0.5;                                                            // ... and a second non-zero one to perturb
+            for (size_t k = 1; k < Es; ++k) {
+                fac[k] = 1.0 + 0.3 * unif();
+                for (size_t e = 0; e < len; ++e) Bs[k * len + e] = fac[k] * Bs[e];
+            }
+            if (!grape_host::controls_scaled(Bs.data(), Es, Ks, nn, got)) { std::printf("scaled controls rejected\n"); return 8; }
+            for (size_t k = 0; k < Es; ++k)
+                if (std::fabs(got[k] - fac[k]) > 1e-14 * std::fabs(fac[k])) { std::printf("wrong scale factor\n"); return 9; }
+            const size_t at = len * (1 + rnd() % (Es - 1)) + 1 + ((rnd() & 1) ? 0 : rnd() % (len - 1));     // never the reference entry
+            const double keep = Bs[at];
+            Bs[at] = keep == 0.0 ? 1e-9 : keep * (1.0 + 1e-9);
+            if (grape_host::controls_scaled(Bs.data(), Es, Ks, nn, got)) { std::printf("perturbed controls accepted as scaled\n"); return 10; }
+            Bs[at] = (rnd() & 1) ? std::nan("") : INFINITY;
+            if (grape_host::controls_scaled(Bs.data(), Es, Ks, nn, got)) { std::printf("non-finite controls accepted as scaled\n"); return 11; }
+            s2 = s;
+            s = keep_s;
+        }
+
         const size_t E = 1 + rnd() % 3, K = 1 + rnd() % 5;
         const int max_nz = 1 + (int)(rnd() % 64), stride = n + (int)(rnd() % 3);
         std::vector<double> B(2 * E * K * (size_t)n * n, 0.0);
