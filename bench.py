@@ -753,7 +753,7 @@ def compact(out):
         c["extra"] = cx
     if "extra_configs" in out:
         c["extra_configs"] = []
-        c["extra_parity_columns"] = "spot members, max rel G err, max F err / tol, ok (vs the C oracle, tol 1e-10)"
+        c["extra_parity_columns"] = "spot members, max rel G err, max F err/tol, ok (C oracle, 1e-10)"
         for e in out["extra_configs"]:
             if "error" in e:
                 c["extra_configs"].append({"id": e.get("workload"), "error": e["error"][:120]})
@@ -768,8 +768,11 @@ def compact(out):
                                            "vs_shared_controls": _r(e["value"] / base_v, 3) if base_v else None,
                                            "kernel": e["roofline"].get("kernel"), "parity": cpar})
                 continue
+            cr = compact_roofline(e["roofline"])
+            for k in ("bytes_per_launch", "model_s_bytes_per_launch"):      # (the headline's roofline keeps them; the line has 8 KB)
+                cr.pop(k, None)
             c["extra_configs"].append({"id": e["id"], "value": _r(e["value"], 5), "ms_per_step": _r(e["ms_per_step"], 5),
-                                       "steps": e["steps"], "roofline": compact_roofline(e["roofline"]), "parity": cpar})
+                                       "roofline": cr, "parity": cpar})
     for k in ("ranks_seen", "rank_kernel_us"):
         if k in out:
             c[k] = out[k] if k == "ranks_seen" else {kk: _r(vv) for kk, vv in out[k].items()}

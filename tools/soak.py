@@ -25,10 +25,11 @@ n_action = 0
 n_chunked = 0
 n_grid = 0
 n_member_chunked = 0
+n_scaled = 0
 t0 = time.time()
 for i in range(cases):
-    n = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32, 33, 40, 48, 57, 64],
-                       p=[.1, .08, .13, .06, .05, .07, .07, .07, .1, .05, .05, .07, .02, .02, .02, .02, .02]))
+    n = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32, 33, 40, 48, 57, 64, 66, 80, 97],      # (> 64: round 6, matrix-core products)
+                       p=[.1, .08, .13, .06, .05, .07, .07, .07, .1, .05, .05, .07, .02, .02, .02, .02, .014, .002, .002, .002]))
     K = int(rng.integers(1, 9))
     N = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 64, 100, 257])) if n <= 16 else int(rng.choice([1, 2, 5, 9, 20] if n <= 32 else [1, 2, 5, 9]))
     E = int(rng.choice([1, 2, 3, 5, 9, 17])) if n <= 16 else int(rng.choice([1, 2, 3]))
@@ -68,6 +69,9 @@ for i in range(cases):
 
     if shared_ctrl:
         B = np.broadcast_to(B[0], B.shape).copy()
+        if rng.random() < 0.35:                        # round 6: B_k = s_k B_0 (EnsembleProblem.B_g with amplitude inhomogeneity)
+            B = B * (1.0 + 0.2 * rng.uniform(-1, 1, E))[:, None, None, None]
+            n_scaled += 1
         os.environ["GRAPE_HOIST"] = "1"                # (forced for the small ensembles of a soak run; n <= 4 has no such path)
         # rank-one states, n = 9..32: the vector flow of action_thin.hip (forced likewise), or the flows it replaces
         os.environ["GRAPE_ACTION"] = "1" if rng.random() < 0.6 else "0"
@@ -160,5 +164,6 @@ for i in range(cases):
         fails += 1
         print("FAIL", what, "->", repr(exc)[:300], flush=True)
 print(f"soak: {cases} cases, {fails} failures, {n_action} of them through the vector flow, {n_chunked} through the chunked propagator chain, "
-      f"{n_grid} through the n > 32 grid family, {n_member_chunked} member-chunked, {time.time() - t0:.1f} s (seed {seed})")
+      f"{n_grid} with n > 32 (grid family; n > 64: size-generic kernel on the matrix cores), {n_member_chunked} member-chunked, "
+      f"{n_scaled} with scaled per-member controls, {time.time() - t0:.1f} s (seed {seed})")
 sys.exit(1 if fails else 0)
