@@ -469,37 +469,57 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
             for (int idx = threadIdx.x; idx < nn; idx += TH)
                 Lk[(size_t)t * nn + idx] = Ln[idx];
         }
-        // R = X L' [- L' X]
-        any_prod<MFMA, false, true>(n, X, Ln, T, s_any_img);
+        // R = X L' [- L' X] -- formed as its conjugate transpose R' = L X' [- X' L]: the traces below walk B_c and R' with the
+        // same (coalesced) index, sum_ij B_c[i][j] R[j][i] = sum_idx B_c[idx] conj(R'[idx]); R itself was read transposed, 16 bytes
+        // per 128-byte line (12 of C7's 100 ms)
+        any_prod<MFMA, false, true>(n, Ln, X, T, s_any_img);
         if (p.sand) {
-            any_prod<MFMA, true, false>(n, Ln, X, U, s_any_img);
+            any_prod<MFMA, true, false>(n, X, Ln, U, s_any_img);
             for (int idx = threadIdx.x; idx < nn; idx += TH)
                 T[idx] = make_double2(T[idx].x - U[idx].x, T[idx].y - U[idx].y);
             __syncthreads();
         }
-        // z = tr(X' L) and w_c = sum_ij B_c[i][j] R[j][i], four controls per pass over R and per workgroup reduction
+        // z = tr(X' L) and w_c = sum_ij B_c[i][j] R[j][i], four controls per pass over R' and per workgroup reduction; two
+        // elements per thread and step (their loads are independent)
         double2 zz = make_double2(0.0, 0.0);
         for (int c0 = 0; c0 < K && !(p.abl & 2); c0 += 4) {
             double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            for (int idx = threadIdx.x; idx < nn; idx += TH) {
-                const int i = idx % n, j = idx / n;
-                const double2 r = T[j + (size_t)i * n];
-                if (c0 == 0) {
-                    const double2 a = X[idx], b = Ln[idx];
-                    v[0] = fma(a.x, b.x, v[0]);
-                    v[0] = fma(a.y, b.y, v[0]);
-                    v[1] = fma(a.x, b.y, v[1]);
-                    v[1] = fma(-a.y, b.x, v[1]);
+            for (int base = threadIdx.x; base < nn; base += 2 * TH) {
+                double2 rr[2], xa[2], lb[2], bb[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int idx = min(base + u * TH, nn - 1);
+                    rr[u] = T[idx];
+                    if (c0 == 0) {
+                        xa[u] = X[idx];
+                        lb[u] = Ln[idx];
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+                        bb[u][cc] = opB[(size_t)min(c0 + cc, K - 1) * nn + idx];
                 }
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc)
-                    if (c0 + cc < K) {
-                        const double2 b = opB[(size_t)(c0 + cc) * nn + idx];
-                        v[2 + 2 * cc] = fma(b.x, r.x, v[2 + 2 * cc]);
-                        v[2 + 2 * cc] = fma(-b.y, r.y, v[2 + 2 * cc]);
-                        v[3 + 2 * cc] = fma(b.x, r.y, v[3 + 2 * cc]);
-                        v[3 + 2 * cc] = fma(b.y, r.x, v[3 + 2 * cc]);
+                for (int u = 0; u < 2; ++u) {
+                    if (base + u * TH >= nn)
+                        continue;
+                    const double2 r = make_double2(rr[u].x, -rr[u].y);
+                    if (c0 == 0) {
+                        const double2 a = xa[u], b = lb[u];
+                        v[0] = fma(a.x, b.x, v[0]);
+                        v[0] = fma(a.y, b.y, v[0]);
+                        v[1] = fma(a.x, b.y, v[1]);
+                        v[1] = fma(-a.y, b.x, v[1]);
                     }
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+                        if (c0 + cc < K) {
+                            const double2 b = bb[u][cc];
+                            v[2 + 2 * cc] = fma(b.x, r.x, v[2 + 2 * cc]);
+                            v[2 + 2 * cc] = fma(-b.y, r.y, v[2 + 2 * cc]);
+                            v[3 + 2 * cc] = fma(b.x, r.y, v[3 + 2 * cc]);
+                            v[3 + 2 * cc] = fma(b.y, r.x, v[3 + 2 * cc]);
+                        }
+                }
             }
             any_block_sum_n<10, TH>(v, s_red);
             if (c0 == 0)
