@@ -1500,6 +1500,19 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
                 c->tp_S = (int)((N + C - 1) / C);
                 c->tp_C = (int)((N + c->tp_S - 1) / c->tp_S);
             }
+        } else if (c->family == 1 && c->grid && !thin && c->cfg.gradient != GRAPE_GRADIENT_EXACT && N >= 16 &&
+                   2 * units <= (long)c->compute_units && !env_on("GRAPE_NO_TP") && !may_chunk(c)) {
+            // n = 33..64 (round 6; VERDICT r5 #4b): a 16-wave workgroup per member walked all N slices -- one 64 x 64 problem,
+            // N = 500: 10.7 ms, the same as 16 of them.  Chunks of S slices: (S - 1) chunk products + 2 .. 4 C scan products +
+            // 3 .. 6 S chain products in a row instead of 3 .. 6 N: S ~ sqrt(N / 2); at most two (member, chunk) workgroups per CU
+            const long s_lat = std::max(4L, std::lround(std::sqrt((double)N / 2.0)));
+            long C = std::min(2L * c->compute_units / units, (N + s_lat - 1) / s_lat);
+            if (const char *e = std::getenv("GRAPE_TP_CHUNKS")) C = std::atol(e);
+            if (C > N / 2) C = N / 2;
+            if (C >= 2) {
+                c->tp_S = (int)((N + C - 1) / C);
+                c->tp_C = (int)((N + c->tp_S - 1) / c->tp_S);
+            }
         } else if (small && thin && N >= 32 && 4 * units < slots) {      // C4's shape: 128 members 1.18 -> 0.87 ms, 256 members 1.39 -> 1.53
                                                                           // (and from half a device on, the fused forward pass)
             // measured optimum at C4's shape (N = 1000): 16..32 slices per chunk for 1..16 members (tools/single_open.py)
@@ -1516,7 +1529,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         }
         if (c->tp_C) {
             const size_t tsz = (size_t)c->NT * c->NT * 256, rows = (size_t)c->EU * c->B;
-            const size_t dumps = ((general || dpp_small) ? 2 : 1) * (size_t)c->tp_C;     // general flow: [Q_c | Q_c^T] and [R_c | U_c^T]
+            const size_t dumps = ((general || dpp_small || c->grid) ? 2 : 1) * (size_t)c->tp_C;     // general flow: [Q_c | Q_c^T] and [R_c | U_c^T]
             auto ensure = [&](void **ptr, size_t *cap, size_t bytes) -> hipError_t {
                 if (*cap >= bytes)
                     return hipSuccess;
@@ -1536,7 +1549,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
             HIP_TRY(c, ensure((void **)&c->d_tp_z, &c->tp_cap[4], sizeof(double) * rows * 128));
             // unitary flow, many chunks: two-level scan over groups of ~sqrt(C) chunks
             c->tp_G = c->tp_g = 0;
-            if (!thin && c->tp_C >= 16 && !env_on("GRAPE_TP_ONE_LEVEL")) {
+            if (!thin && !c->grid && c->tp_C >= 16 && !env_on("GRAPE_TP_ONE_LEVEL")) {
                 c->tp_g = (int)std::lround(std::ceil(std::sqrt((double)c->tp_C)));
                 c->tp_G = (c->tp_C + c->tp_g - 1) / c->tp_g;
                 HIP_TRY(c, ensure((void **)&c->d_tp_a, &c->tp_cap[5], sizeof(double2) * rows * tsz * (general ? 4 : 2) * c->tp_G));
@@ -1745,7 +1758,52 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     }
     if (c->family == 2) {
         c->any_blocks = grape::any_prop_blocks(c->cfg.n, c->cfg.n_slices, (long)c->cfg.n_ensemble * c->B, c->compute_units);
-        const size_t need = sizeof(double2) * 6 * nn * (size_t)c->Ec * ws_batch(c) * (size_t)c->any_blocks;
+        // (every propagator block owns six scratch matrices: at n = 2048 that is 400 MB per block -- no more blocks than 8 GB,
+        // or a quarter of the workspace budget, pays for)
+        const size_t per_block = sizeof(double2) * 6 * nn * (size_t)c->Ec * ws_batch(c);
+        const size_t cap = std::min<size_t>((size_t)8 << 30, std::max<size_t>(c->ws_budget / 4, per_block));
+        while (c->any_blocks > 1 && per_block * (size_t)c->any_blocks > cap)
+            c->any_blocks = (c->any_blocks + 1) / 2;
+        // Chunked time axis (round 6): the chain of a member is sequential in time and holds ONE workgroup (= one compute unit)
+        // -- with fewer members than compute units the slices are cut into chunks (chunk products -> boundary scan -> a
+        // workgroup per (member, chunk); sweep_any.hip phases 3-5): about one (member, chunk) workgroup per CU, S ~ sqrt(N / 2)
+        // slices or more per chunk ((S - 1) + 2..4 C + 3..6 S dependent products instead of 3..6 N).
+        c->tp_C = c->tp_S = 0;
+        {
+            const long units = (long)c->cfg.n_ensemble * c->B, N = c->cfg.n_slices;
+            if (c->cfg.n >= 17 && N >= 16 && 2 * units <= (long)c->compute_units && !env_on("GRAPE_NO_TP") && !chunked(c) && !may_chunk(c)) {
+                const long s_lat = std::max(4L, std::lround(std::sqrt((double)N / 2.0)));
+                long C = std::min((long)c->compute_units / units, (N + s_lat - 1) / s_lat);
+                if (const char *e = std::getenv("GRAPE_TP_CHUNKS")) C = std::atol(e);
+                if (C > N / 2) C = N / 2;
+                // three more matrices per (member, chunk) + a scratch set each: inside the same cap
+                while (C >= 2 && (per_block + sizeof(double2) * 3 * nn * (size_t)c->Ec * ws_batch(c)) * (size_t)C > cap)
+                    C = (C + 1) / 2;
+                if (C >= 2) {
+                    c->tp_S = (int)((N + C - 1) / C);
+                    c->tp_C = (int)((N + c->tp_S - 1) / c->tp_S);
+                }
+            }
+        }
+        if (c->tp_C) {
+            const size_t bytes = sizeof(double2) * nn * (size_t)c->cfg.n_ensemble * c->B * (size_t)c->tp_C;
+            auto ensure = [&](double2 **ptr, size_t *capb) -> hipError_t {
+                if (*capb >= bytes)
+                    return hipSuccess;
+                (void)hipFree(*ptr);
+                *ptr = nullptr;
+                c->bytes += bytes - *capb;
+                *capb = 0;
+                const hipError_t e = hipMalloc((void **)ptr, bytes);
+                if (e == hipSuccess)
+                    *capb = bytes;
+                return e;
+            };
+            HIP_TRY(c, ensure(&c->d_tp_q, &c->tp_cap[0]));
+            HIP_TRY(c, ensure(&c->d_tp_r, &c->tp_cap[1]));
+            HIP_TRY(c, ensure(&c->d_tp_m, &c->tp_cap[2]));      // (family 2: the states at the chunks' starts)
+        }
+        const size_t need = per_block * (size_t)std::max(c->any_blocks, std::max(1, c->tp_C));
         if (c->scratch_bytes < need) {
             (void)hipFree(c->d_scratch);
             c->d_scratch = nullptr;
@@ -1823,7 +1881,7 @@ static TileParams tile_params(const grape_ctx *c, const double *d_x, int n_x = 1
     p.tp_groups = c->tp_C ? c->tp_G : 0;
     p.tp_gsize = c->tp_g;
     p.tp_a = c->d_tp_a;
-    if (c->tp_C && ((!c->unitary && !c->thin) || c->thin_dpp)) {   // general flow / chunked propagator chain: second halves of the dump buffers
+    if (c->tp_C && ((!c->unitary && !c->thin) || c->thin_dpp || c->grid)) {   // general flow (always: sweep_grid.hip) / chunked propagator chain: second halves of the dump buffers
         const size_t half = (size_t)c->EU * c->B * c->tp_C * c->NT * c->NT * 256;
         p.tp_qt = c->d_tp_q + half;
         p.tp_u = c->d_tp_r + half;
@@ -2055,6 +2113,11 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
             a.prop_blocks = c->any_blocks;
             a.ev_mid = lo == 0 ? emid : nullptr;
             a.shared_b = c->ctrl_shared ? c->d_ops + nn : nullptr;
+            a.tp_chunks = c->tp_C;
+            a.tp_S = c->tp_S;
+            a.tp_q = c->d_tp_q;
+            a.tp_r = c->d_tp_r;
+            a.tp_u = c->d_tp_m;
             HIP_TRY(c, grape::launch_sweep_any(a, stream));
             return GRAPE_OK;
         }

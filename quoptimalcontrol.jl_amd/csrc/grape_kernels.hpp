@@ -152,6 +152,9 @@ struct TileParams {
     // time-parallel unitary chain (small ensembles, sweep_tile.hip): the N slices of a unit are cut into tp_chunks chunks
     // of tp_S slices, one wavefront per chunk; 0 = the sequential chain (one wavefront walks all N slices)
     int32_t tp_chunks, tp_S;
+    int32_t tp_window;    // sweep_grid.hip (round 6): 1 = grid_chain_kernel works on ONE chunk of the time axis per workgroup
+                          // (blockIdx.z), its first state from tp_u, its last costate from tp_r (written by the boundary scan)
+    int32_t tp_scan;      // 1 = this launch IS the boundary scan (the chain kernel on the chunk products): no output rows
     double2 *tp_q;        // [control array][unit][chunk] chunk products Q_c = P_hi-1 ... P_lo (D-layout dumps)
     double2 *tp_r;        // same shape: R_c = Q_C-1 ... Q_c+1, the product of everything after chunk c
     double2 *tp_m;        // [control array][unit]: M_N
@@ -245,6 +248,12 @@ struct AnyParams {
     // their own (phase 1), the chain -- sequential in time -- by one workgroup per member behind it (phase 2).  prop_blocks <=
     // 1: one launch does both (phase 0).
     int32_t prop_blocks, phase;
+    // Chunked time axis (tp_chunks > 1; round 6): phase 3 = chunk products Q_c (workgroup per (member, chunk): blockIdx.z) into
+    // tp_q, phase 4 = boundary scan (the chain on the chunk products: states at the chunks' starts -> tp_u, costates at their
+    // starts -> tp_r, no output rows), phase 5 = the chain on the slices of chunk blockIdx.z.  The scratch matrices are per
+    // (control array, member, max(prop_blocks, tp_chunks)).
+    int32_t tp_chunks, tp_S;
+    double2 *tp_q, *tp_u, *tp_r;
     hipEvent_t ev_mid;        // nullable: recorded behind the propagator launch (prop_blocks > 1 only)
     int32_t abl;              // diagnostic ablation mask (GRAPE_ANY_ABL; wrong results): 1 no MFMAs, 2 no traces, 4 no operand fetch
     const double2 *shared_b;  // nullable: the members' control operators are identical -- member 0's [B_1..B_K] for everybody

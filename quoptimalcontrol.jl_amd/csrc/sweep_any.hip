@@ -282,15 +282,17 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
     const size_t kw = (size_t)z * p.E + k;
     double2 *__restrict__ Pk = p.props + kw * N * nn, *__restrict__ Xk = p.states + kw * N * nn;
     double2 *__restrict__ Lk = p.costates ? p.costates + kw * N * nn : nullptr;
-    const int nblk = p.prop_blocks > 1 ? p.prop_blocks : 1;
-    double2 *__restrict__ sc = p.scratch + (kw * nblk + (p.phase == 1 ? blockIdx.z : 0)) * 6 * nn;
+    const int nprop = p.prop_blocks > 1 ? p.prop_blocks : 1;
+    const int nblk = max(nprop, p.tp_chunks > 1 ? p.tp_chunks : 1);        // scratch sets per (control array, member)
+    const bool zblk = p.phase == 1 || p.phase == 3 || p.phase == 5;
+    double2 *__restrict__ sc = p.scratch + (kw * nblk + (zblk ? blockIdx.z : 0)) * 6 * nn;
     double2 *G = sc, *A2 = sc + nn, *A4 = sc + 2 * (size_t)nn, *T = sc + 3 * (size_t)nn, *U = sc + 4 * (size_t)nn, *Y = sc + 5 * (size_t)nn;
     double *__restrict__ out = p.member_out + ((size_t)z * p.E_rows + k) * ((size_t)K * N + 1);
     const double dt = p.dt;
 
     // ------------------------------------------------------------ propagators, src/timeevolution.jl:98-110 (:45-57 static)
-    const int spb = (N + nblk - 1) / nblk;
-    const int t_lo = p.phase == 1 ? (int)blockIdx.z * spb : 0, t_hi = p.phase == 1 ? min(N, t_lo + spb) : (p.phase == 2 ? 0 : N);
+    const int spb = (N + nprop - 1) / nprop;
+    const int t_lo = p.phase == 1 ? (int)blockIdx.z * spb : 0, t_hi = p.phase == 1 ? min(N, t_lo + spb) : (p.phase == 0 ? N : 0);
     for (int t = t_lo; t < t_hi; ++t) {
         // four elements per thread and pass: the K + 1 operator entries of each are independent loads -- issued one element
         // and one control at a time (round 5) every load waited for the one before: ~230 memory round trips per thread and
@@ -308,17 +310,26 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
                     hi[u] = opA[idx].y;
                 }
             }
-            for (int c = 0; c < K; ++c) {
-                const double xv = x[c + (size_t)t * K];
-                double2 b[4];
+            for (int c0 = 0; c0 < K; c0 += 4) {        // four controls x four elements: sixteen independent loads per step
+                double xv[4];
+                double2 b[4][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    b[u] = opB[(size_t)c * nn + min(base + u * TH, nn - 1)];
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = min(c0 + cc, K - 1);
+                    xv[cc] = c0 + cc < K ? x[c + (size_t)t * K] : 0.0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    hr[u] = fma(b[u].x, xv, hr[u]);
-                    hi[u] = fma(b[u].y, xv, hi[u]);
+                    for (int u = 0; u < 4; ++u)
+                        b[cc][u] = opB[(size_t)c * nn + min(base + u * TH, nn - 1)];
                 }
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                    if (c0 + cc < K) {                 // (controls in their order: the reference's sum)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            hr[u] = fma(b[cc][u].x, xv[cc], hr[u]);
+                            hi[u] = fma(b[cc][u].y, xv[cc], hi[u]);
+                        }
+                    }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -438,11 +449,36 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
     }
     if (p.phase == 1)
         return;                                        // (the chain runs in a launch of its own)
+    if (p.phase == 3) {
+        // chunk product Q_c = P_(hi-1) ... P_lo of chunk c = blockIdx.z (ping-pong between two scratch matrices)
+        const int c = blockIdx.z, lo = c * p.tp_S, hi = min(N, lo + p.tp_S);
+        double2 *Qc = p.tp_q + (kw * p.tp_chunks + c) * nn;
+        const double2 *cur = Pk + (size_t)lo * nn;
+        for (int t = lo + 1; t < hi; ++t) {
+            double2 *dst = (t == hi - 1) ? Qc : (cur == G ? A2 : G);
+            any_prod<MFMA, false, false>(n, Pk + (size_t)t * nn, cur, dst, s_any_img);
+            cur = dst;
+        }
+        if (hi - lo == 1) {
+            for (int idx = threadIdx.x; idx < nn; idx += TH)
+                Qc[idx] = cur[idx];
+        }
+        return;
+    }
+    // The chain.  phase 5: the slices [w_lo, w_hi) of chunk blockIdx.z, first state / last costate from the boundary scan;
+    // phase 4 IS that scan: this code on the chunk products (the launcher hands over N = chunks, props = tp_q, states = tp_u,
+    // costates = tp_r) without output rows.
+    const bool win = p.phase == 5, emit = p.phase != 4;
+    const int CHN = win ? p.tp_chunks : 1, chn = win ? (int)blockIdx.z : 0;
+    const int w_lo = win ? chn * p.tp_S : 0, w_hi = win ? min(N, w_lo + p.tp_S) : N;
     // ------------------------------------------------------------ forward sweep, src/GRAPE.jl:53-63
-    for (int idx = threadIdx.x; idx < nn; idx += TH)
-        Xk[idx] = opXi[idx];
+    {
+        const double2 *X0 = win ? p.tp_u + (kw * CHN + chn) * nn : opXi;
+        for (int idx = threadIdx.x; idx < nn; idx += TH)
+            Xk[(size_t)w_lo * nn + idx] = X0[idx];
+    }
     __syncthreads();
-    for (int t = 0; t + 1 < N; ++t) {
+    for (int t = w_lo; t + 1 < w_hi; ++t) {
         const double2 *P = Pk + (size_t)t * nn;
         if (p.sand) {
             any_prod<MFMA, false, true>(n, Xk + (size_t)t * nn, P, Y, s_any_img);                       // X P'       (:245)
@@ -454,10 +490,13 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
     // ------------------------------------------------------------ backward sweep + gradient, :65-92
     const double gs = p.sand ? -dt : (p.variant == 0 ? -2.0 * dt : 2.0 * dt);
     double2 *Lc = A2, *Ln = A4;                        // costate at t + 1 / at t (scratch, swapped per slice)
-    for (int idx = threadIdx.x; idx < nn; idx += TH)
-        Lc[idx] = opXt[idx];
+    {
+        const double2 *L0 = (win && chn + 1 < CHN) ? p.tp_r + (kw * CHN + chn + 1) * nn : opXt;
+        for (int idx = threadIdx.x; idx < nn; idx += TH)
+            Lc[idx] = L0[idx];
+    }
     __syncthreads();
-    for (int t = N - 1; t >= 0; --t) {
+    for (int t = w_hi - 1; t >= w_lo; --t) {
         const double2 *P = Pk + (size_t)t * nn, *X = Xk + (size_t)t * nn;
         if (p.sand) {
             any_prod<MFMA, false, false>(n, Lc, P, Y, s_any_img);                                       // L P        (:248)
@@ -482,7 +521,7 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
         // z = tr(X' L) and w_c = sum_ij B_c[i][j] R[j][i], four controls per pass over R' and per workgroup reduction; two
         // elements per thread and step (their loads are independent)
         double2 zz = make_double2(0.0, 0.0);
-        for (int c0 = 0; c0 < K && !(p.abl & 2); c0 += 4) {
+        for (int c0 = 0; c0 < K && !(p.abl & 2) && emit; c0 += 4) {
             double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (int base = threadIdx.x; base < nn; base += 2 * TH) {
                 double2 rr[2], xa[2], lb[2], bb[2][4];
@@ -524,13 +563,13 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
             any_block_sum_n<10, TH>(v, s_red);
             if (c0 == 0)
                 zz = make_double2(v[0], v[1]);
-            if ((int)threadIdx.x < 4 && c0 + (int)threadIdx.x < K) {
+            if ((int)threadIdx.x < 4 && c0 + (int)threadIdx.x < K && emit) {
                 const int cc = threadIdx.x;
                 const double im = p.sand ? v[3 + 2 * cc] : fma(v[2 + 2 * cc], zz.y, v[3 + 2 * cc] * zz.x);
                 out[c0 + cc + (size_t)t * K] = gs * im;
             }
         }
-        if (t == N - 1 && threadIdx.x == 0) {          // figure of merit at t = N (:77, :94)
+        if (t == N - 1 && threadIdx.x == 0 && emit) {  // figure of merit at t = N (:77, :94)
             if (p.sand) {
                 const double inv = 1.0 / (double)n;
                 const double ar = zz.x * inv, ai = zz.y * inv;
@@ -558,6 +597,11 @@ int any_prop_blocks(int n, int N, long units, int cus)
     return (int)std::max(1L, std::min<long>(want, std::max(1, N / 4)));
 }
 
+static const char *any_phase_name(int phase)
+{
+    return phase == 1 ? "any_prop_kernel" : phase == 3 ? "any_chunk_product_kernel" : phase == 4 ? "any_scan_kernel" : "any_sweep_kernel";
+}
+
 hipError_t launch_sweep_any(const AnyParams &p0, hipStream_t stream)
 {
     static const bool mfma_off = [] { const char *e = std::getenv("GRAPE_ANY_MFMA"); return e && e[0] == '0'; }();
@@ -572,22 +616,42 @@ hipError_t launch_sweep_any(const AnyParams &p0, hipStream_t stream)
         p.abl = std::atoi(e);
     auto launch = [&](dim3 grid) {
         if (mfma)
-            GRAPE_LAUNCH_AS(p.phase == 1 ? "any_prop_kernel" : "any_sweep_kernel", any_sweep_kernel<true>, grid, dim3(kAnyMfmaThreads),
+            GRAPE_LAUNCH_AS(any_phase_name(p.phase), any_sweep_kernel<true>, grid, dim3(kAnyMfmaThreads),
                             kAnyImgBytes, stream, p);
         else
-            GRAPE_LAUNCH_AS(p.phase == 1 ? "any_prop_kernel" : "any_sweep_kernel", any_sweep_kernel<false>, grid, dim3(kAnyThreads), 0,
+            GRAPE_LAUNCH_AS(any_phase_name(p.phase), any_sweep_kernel<false>, grid, dim3(kAnyThreads), 0,
                             stream, p);
     };
-    if (p.prop_blocks > 1) {
+    const bool tp = p.tp_chunks > 1 && p.tp_q && p.tp_u && p.tp_r;
+    if (p.prop_blocks > 1 || tp) {
         p.phase = 1;
-        launch(dim3(p.E, p.n_x, p.prop_blocks));
+        launch(dim3(p.E, p.n_x, std::max(1, p.prop_blocks)));
         if (p.ev_mid) {
             const hipError_t e = hipEventRecord(p.ev_mid, stream);
             if (e != hipSuccess)
                 return e;
         }
-        p.phase = 2;
-        launch(dim3(p.E, p.n_x));
+        if (tp) {
+            p.phase = 3;
+            launch(dim3(p.E, p.n_x, p.tp_chunks));
+            AnyParams sc = p;                          // the boundary scan: the chain on the chunk products
+            sc.phase = 4;
+            sc.props = p.tp_q;
+            sc.N = p.tp_chunks;
+            sc.states = p.tp_u;
+            sc.costates = p.tp_r;
+            {
+                const AnyParams keep = p;
+                p = sc;
+                launch(dim3(p.E, p.n_x));
+                p = keep;
+            }
+            p.phase = 5;
+            launch(dim3(p.E, p.n_x, p.tp_chunks));
+        } else {
+            p.phase = 2;
+            launch(dim3(p.E, p.n_x));
+        }
     } else {
         p.phase = 0;
         launch(dim3(p.E, p.n_x));

@@ -306,14 +306,23 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
     const double2 *__restrict__ Pk = p.props + kw * N * TSZ;
     double2 *__restrict__ Xk = p.states + kw * N * TSZ;
     double *__restrict__ out = p.member_out + ((size_t)blockIdx.y * p.E_members + k) * ((size_t)K * N + 1);
+    // Chunked time axis (round 6: single problems / ensembles far smaller than the device walked their N slices in ONE
+    // workgroup): this workgroup owns the slices [t_lo, t_hi) of chunk blockIdx.z; the state at t_lo and the costate behind
+    // t_hi - 1 come from the boundary scan -- THIS kernel run on the chunk products Q_c in the place of the propagators
+    // (p.tp_scan: N = number of chunks, states -> tp_u, costates (KEEPL) -> tp_r, no output rows).
+    const bool win = p.tp_window != 0;
+    const int CHN = win ? p.tp_chunks : 1, chn = win ? (int)blockIdx.z : 0;
+    const int t_lo = win ? chn * p.tp_S : 0, t_hi = win ? min(N, t_lo + p.tp_S) : N;
+    const bool emit = p.tp_scan == 0;
 
     // ------------------------------------------------------------ forward sweep, src/GRAPE.jl:53-63
     {
-        GT X = gt_load(ops + (size_t)(1 + 2 * K) * TSZ, tile, lane);            // Xi
-        GT Pt = gt_load(Pk, tile, lane);
-        for (int t = 0; t < N; ++t) {
+        GT X = win ? gt_load(p.tp_u + (kw * CHN + chn) * TSZ, tile, lane)
+                   : gt_load(ops + (size_t)(1 + 2 * K) * TSZ, tile, lane);      // Xi
+        GT Pt = gt_load(Pk + (size_t)t_lo * TSZ, tile, lane);
+        for (int t = t_lo; t < t_hi; ++t) {
             gt_store(Xk + (size_t)t * TSZ, tile, lane, X);
-            if (t + 1 < N) {                           // (the state behind the last slice is never read)
+            if (t + 1 < t_hi) {                        // (the state behind the last slice is never read)
                 grid_barrier();
                 grid_put<NT, false>(img0, Pt, I, J, lane);                      // P plain: the left operand of P X, the right one of . P'
                 grid_put<NT, true>(img1, X, I, J, lane);
@@ -337,9 +346,10 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
     // [X, L'] = Y - Y' and tr(B Y') = conj(tr(B Y)), so Im tr(B [X, L']) = 2 Im tr(B Y) -- the second product is not formed
     const bool herm2 = SAND && p.herm_states != 0 && p.herm_ctrl != 0;
     const double gs = SAND ? (herm2 ? -2.0 * p.dt : -p.dt) : (p.variant == 0 ? -2.0 * p.dt : 2.0 * p.dt);
-    GT L = gt_load(ops + (size_t)(2 + 2 * K) * TSZ, tile, lane);                // Xt
-    GT Pt = gt_load(Pk + (size_t)(N - 1) * TSZ, tile, lane);
-    GT X = gt_load(Xk + (size_t)(N - 1) * TSZ, tile, lane);
+    GT L = (win && chn + 1 < CHN) ? gt_load(p.tp_r + (kw * CHN + chn + 1) * TSZ, tile, lane)
+                                  : gt_load(ops + (size_t)(2 + 2 * K) * TSZ, tile, lane);                // Xt
+    GT Pt = gt_load(Pk + (size_t)(t_hi - 1) * TSZ, tile, lane);
+    GT X = gt_load(Xk + (size_t)(t_hi - 1) * TSZ, tile, lane);
     int buf = 0;
     double2 sp_c[NCW][NEM];
     int sp_a[NCW][NEM];
@@ -356,8 +366,8 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
                 sp_a[ci][e] = on ? p.sp_addr[at] : 0;
             }
     }
-    for (int t = N - 1; t >= 0; --t) {
-        const int tp = max(t - 1, 0);
+    for (int t = t_hi - 1; t >= t_lo; --t) {
+        const int tp = max(t - 1, t_lo);
         grid_barrier();
         grid_put<NT, true>(img0, Pt, I, J, lane);                               // P transposed: P' as a left operand, P as a right one
         grid_put<NT, SAND == 0>(img1, L, I, J, lane);                           // L: left operand of L P (plain) / right operand of P' L (transposed)
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
                         v[3] = img0[PLANE + lane * P + lane];
                     }
                     wave_sum_n(v);
-                    if (lane == 0) {
+                    if (lane == 0 && emit) {
                         const double zr = v[2], zi = -v[3];
                         const double im = SAND ? v[1] : fma(v[0], zi, v[1] * zr);
                         out[c + (size_t)t * K] = gs * im;
@@ -437,7 +447,7 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
                     s_red[2 * wave + 1] = v2[1];
                 }
                 grid_barrier();
-                if (threadIdx.x == 0) {
+                if (threadIdx.x == 0 && emit) {
                     double zr = 0.0, zi = 0.0;
                     for (int w = 0; w < WAVES; ++w) {
                         zr += s_red[2 * w];
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
                     red[wave * kGridRed + q] = v[q];
             }
             grid_barrier();
-            if ((int)threadIdx.x < kGridGroup && c0 + (int)threadIdx.x < K) {
+            if ((int)threadIdx.x < kGridGroup && c0 + (int)threadIdx.x < K && emit) {
                 const int cc = threadIdx.x;
                 double zr = 0.0, zi = 0.0, wr = 0.0, wi = 0.0;
                 for (int w = 0; w < WAVES; ++w) {
@@ -503,6 +513,34 @@ __global__ __launch_bounds__(64 * NT * NT) void grid_chain_kernel(const TilePara
             buf ^= 1;                                   // (two buffers: the next group's writes meet no reader)
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Chunked time axis, step 1: Q_c = P_(hi-1) ... P_lo of chunk c = blockIdx.x of member blockIdx.y (control array blockIdx.z),
+// tp_S - 1 products; the boundary scan and the per-chunk chains are grid_chain_kernel itself (launch_grid_nt).
+template <int NT>
+__global__ __launch_bounds__(64 * NT * NT) void grid_chunk_product_kernel(const TileParams p)
+{
+    using G_ = GridGeom<NT>;
+    constexpr int TSZ = G_::TSZ, PLANE = G_::PLANE;
+    extern __shared__ double s_grid[];
+    double *img0 = s_grid, *img1 = s_grid + 2 * PLANE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, I = wave / NT, J = wave % NT, tile = I * NT + J;
+    const int c = blockIdx.x, k = blockIdx.y, N = p.N;
+    const size_t kw = (size_t)blockIdx.z * p.E + k;
+    const double2 *__restrict__ Pk = p.props + kw * N * TSZ;
+    const int lo = c * p.tp_S, hi = min(N, lo + p.tp_S);
+    GT Q = gt_load(Pk + (size_t)lo * TSZ, tile, lane);
+    GT Pt = gt_load(Pk + (size_t)min(lo + 1, hi - 1) * TSZ, tile, lane);
+    for (int t = lo + 1; t < hi; ++t) {
+        grid_barrier();
+        grid_put<NT, false>(img0, Pt, I, J, lane);
+        grid_put<NT, true>(img1, Q, I, J, lane);
+        grid_barrier();
+        Pt = gt_load(Pk + (size_t)min(t + 1, hi - 1) * TSZ, tile, lane);        // next slice's tile in flight under the products
+        Q = grid_mma<NT, false, false>(img0, img1, I, J, lane);                 // P_t Q
+    }
+    gt_store(p.tp_q + (kw * p.tp_chunks + c) * TSZ, tile, lane, Q);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -994,41 +1032,73 @@ static hipError_t launch_grid_nt(int sandwich, bool keepl, const TileParams &p, 
             return hipGetLastError();
         }
     }
+    // the chain kernel for these parameters on `cgrid` (costates stored or not)
+    auto run_chain = [&](const TileParams &cq, dim3 cgrid, bool kl) -> hipError_t {
+        hipError_t ce = hipSuccess;
 #define GRAPE_GRID_CHAIN(S, KL, SP)                                                                                      \
     {                                                                                                                    \
-        e = ensure_dynamic_lds((const void *)grid_chain_kernel<NT, S, KL, SP>, lds_c);                                                                             \
-        if (e != hipSuccess)                                                                                             \
-            return e;                                                                                                    \
-        GRAPE_LAUNCH((grid_chain_kernel<NT, S, KL, SP>), grid, block, lds_c, stream, q);                                 \
+        ce = ensure_dynamic_lds((const void *)grid_chain_kernel<NT, S, KL, SP>, lds_c);                                  \
+        if (ce != hipSuccess)                                                                                            \
+            return ce;                                                                                                   \
+        GRAPE_LAUNCH((grid_chain_kernel<NT, S, KL, SP>), cgrid, block, lds_c, stream, cq);                               \
     }
-    const int spne = (p.sparse && p.K <= 16 && p.sp_nz <= 256 && NT >= 2) ? (p.sp_nz <= 64 ? 1 : 4) : 0;
-    if constexpr (NT >= 2) {
-        if (spne == 1) {
-            if (sandwich) {
-                if (keepl) GRAPE_GRID_CHAIN(1, true, 1) else GRAPE_GRID_CHAIN(1, false, 1)
-            } else {
-                if (keepl) GRAPE_GRID_CHAIN(0, true, 1) else GRAPE_GRID_CHAIN(0, false, 1)
+        const int spne = (cq.sparse && cq.K <= 16 && cq.sp_nz <= 256 && NT >= 2) ? (cq.sp_nz <= 64 ? 1 : 4) : 0;
+        if constexpr (NT >= 2) {
+            if (spne == 1) {
+                if (sandwich) {
+                    if (kl) GRAPE_GRID_CHAIN(1, true, 1) else GRAPE_GRID_CHAIN(1, false, 1)
+                } else {
+                    if (kl) GRAPE_GRID_CHAIN(0, true, 1) else GRAPE_GRID_CHAIN(0, false, 1)
+                }
+                return hipGetLastError();
             }
-            return hipGetLastError();
         }
-    }
-    if constexpr (NT >= 3) {
-        if (spne == 4) {
-            if (sandwich) {
-                if (keepl) GRAPE_GRID_CHAIN(1, true, 4) else GRAPE_GRID_CHAIN(1, false, 4)
-            } else {
-                if (keepl) GRAPE_GRID_CHAIN(0, true, 4) else GRAPE_GRID_CHAIN(0, false, 4)
+        if constexpr (NT >= 3) {
+            if (spne == 4) {
+                if (sandwich) {
+                    if (kl) GRAPE_GRID_CHAIN(1, true, 4) else GRAPE_GRID_CHAIN(1, false, 4)
+                } else {
+                    if (kl) GRAPE_GRID_CHAIN(0, true, 4) else GRAPE_GRID_CHAIN(0, false, 4)
+                }
+                return hipGetLastError();
             }
-            return hipGetLastError();
         }
-    }
-    if (sandwich) {
-        if (keepl) GRAPE_GRID_CHAIN(1, true, 0) else GRAPE_GRID_CHAIN(1, false, 0)
-    } else {
-        if (keepl) GRAPE_GRID_CHAIN(0, true, 0) else GRAPE_GRID_CHAIN(0, false, 0)
-    }
+        if (sandwich) {
+            if (kl) GRAPE_GRID_CHAIN(1, true, 0) else GRAPE_GRID_CHAIN(1, false, 0)
+        } else {
+            if (kl) GRAPE_GRID_CHAIN(0, true, 0) else GRAPE_GRID_CHAIN(0, false, 0)
+        }
 #undef GRAPE_GRID_CHAIN
-    return hipGetLastError();
+        return hipGetLastError();
+    };
+    if (p.tp_chunks > 1 && p.tp_q && p.tp_u && p.tp_r) {
+        // Chunked time axis (single problems, ensembles far smaller than the device): chunk products -> boundary scan (the chain
+        // kernel on the chunk products: states at the chunks' starts into tp_u, costates at their starts into tp_r) -> one
+        // workgroup per (member, chunk).  Dependent products per evaluation: (tp_S - 1) + 2..4 C + 3..6 tp_S instead of 3..6 N.
+        const size_t lds_q = grid_lds_bytes(NT, false);
+        e = ensure_dynamic_lds((const void *)grid_chunk_product_kernel<NT>, lds_q);
+        if (e != hipSuccess)
+            return e;
+        GRAPE_LAUNCH((grid_chunk_product_kernel<NT>), dim3(p.tp_chunks, p.E, p.n_x), block, lds_q, stream, q);
+        TileParams sc = q;
+        sc.props = q.tp_q;
+        sc.N = q.tp_chunks;
+        sc.states = q.tp_u;
+        sc.costates = q.tp_r;
+        sc.tp_chunks = 0;
+        sc.tp_window = 0;
+        sc.tp_scan = 1;
+        e = run_chain(sc, grid, true);
+        if (e != hipSuccess)
+            return e;
+        TileParams w = q;
+        w.tp_window = 1;
+        w.tp_scan = 0;
+        return run_chain(w, dim3(p.E, p.n_x, p.tp_chunks), keepl);
+    }
+    q.tp_window = 0;
+    q.tp_scan = 0;
+    return run_chain(q, grid, keepl);
 }
 
 hipError_t launch_sweep_grid(int NT, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream)

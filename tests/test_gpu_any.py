@@ -113,3 +113,32 @@ def test_matrix_core_products_agree_with_the_scalar_ones(qoc, oracle, monkeypatc
         assert_parity(F, G, F_ref, G_ref, w.n, what=tag)
     assert res["mfma"][0] == res["one_launch"][0] and np.array_equal(res["mfma"][1], res["one_launch"][1])      # the same products
     assert np.abs(res["mfma"][1] - res["scalar"][1]).max() <= 1e-12 * np.abs(res["scalar"][1]).max()
+
+
+@pytest.mark.parametrize("n,sys_type,herm,variant,N,E", [(70, "UnitaryGate", True, 0, 26, 1), (96, "StateTransfer", False, 1, 20, 2),
+                                                        (130, "CoherenceTransfer", True, 0, 17, 1)])
+def test_chunked_time_axis_beyond_64(qoc, oracle, monkeypatch, n, sys_type, herm, variant, N, E):
+    """Round 6: fewer members than compute units cut the time axis into chunks here too (sweep_any.hip phases 3-5: chunk
+    products, the chain on the chunk products as the boundary scan, a workgroup per (member, chunk)) -- a single 128 x 128
+    problem walked its slices in ONE workgroup on ONE compute unit.  Oracle parity incl. the stored trajectory, agreement with
+    the sequential chain (GRAPE_NO_TP=1), forced chunk counts with a ragged last chunk, bitwise reproducible."""
+    w = _random_problem(qoc, n, 3, N, E, sys_type, seed=60 + n, hermitian=herm, mixed=True)
+    w.A *= 2.0 / n
+    w.B *= 2.0 / n
+    res = {}
+    for tag, env in (("chunked", {}), ("chunks3", {"GRAPE_TP_CHUNKS": "3"}), ("sequential", {"GRAPE_NO_TP": "1"})):
+        for kk in ("GRAPE_TP_CHUNKS", "GRAPE_NO_TP"):
+            monkeypatch.delenv(kk, raising=False)
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        _check(qoc, oracle, w, variant=variant)
+        with _engine(qoc, w, variant=variant) as eng:
+            F1, G1 = eng.eval(w.x)
+            names = eng.kernel_names()
+            chunks = eng.info["time_chunks"]
+        assert ("any_chunk_product_kernel" in names and "any_scan_kernel" in names) == (tag != "sequential"), names
+        assert (chunks >= 2) == (tag != "sequential") and (tag != "chunks3" or chunks == 3)
+        res[tag] = G1
+    scale = np.abs(res["sequential"]).max()
+    assert np.abs(res["chunked"] - res["sequential"]).max() <= 1e-11 * scale
+    assert np.abs(res["chunks3"] - res["sequential"]).max() <= 1e-11 * scale

@@ -31,7 +31,7 @@ for i in range(cases):
     n = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32, 33, 40, 48, 57, 64, 66, 80, 97],      # (> 64: round 6, matrix-core products)
                        p=[.1, .08, .13, .06, .05, .07, .07, .07, .1, .05, .05, .07, .02, .02, .02, .02, .014, .002, .002, .002]))
     K = int(rng.integers(1, 9))
-    N = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 64, 100, 257])) if n <= 16 else int(rng.choice([1, 2, 5, 9, 20] if n <= 32 else [1, 2, 5, 9]))
+    N = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 64, 100, 257])) if n <= 16 else int(rng.choice([1, 2, 5, 9, 20] if n <= 32 else [1, 2, 5, 9, 17, 24]))      # (17, 24: round 6, chunked time axis beyond 32)
     E = int(rng.choice([1, 2, 3, 5, 9, 17])) if n <= 16 else int(rng.choice([1, 2, 3]))
     # a workspace budget of a few members' arrays: the evaluation walks the ensemble in blocks (bitwise the unchunked result,
     # tests/test_gpu_chunked.py; here against the oracle like every other case)
