@@ -297,7 +297,7 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
         // four elements per thread and pass: the K + 1 operator entries of each are independent loads -- issued one element
         // and one control at a time (round 5) every load waited for the one before: ~230 memory round trips per thread and
         // slice, 0.3 ms of the 0.6 ms a 128 x 128 slice took without its products
-        for (int base = threadIdx.x; base < nn; base += 4 * TH) {
+        for (int base = threadIdx.x; base < nn && !(p.abl & 8); base += 4 * TH) {
             double hr[4], hi[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
         double cs = 0.0;
         {
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            for (int j = wave; j < n; j += TH / 64) {
+            for (int j = wave; j < n && !(p.abl & 16); j += TH / 64) {
                 double part = 0.0;
                 for (int i = lane; i < n; i += 64) {
                     const double2 g = G[i + (size_t)j * n];
@@ -382,7 +382,8 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
         }
         double2 *P = Pk + (size_t)t * nn;
         double2 *cur = s > 0 ? Y : P;
-        if constexpr (MFMA) {
+        if (p.abl & 32) {
+        } else if constexpr (MFMA) {
             // the Taylor combinations ride on the products' epilogues (same operations on the same values as the passes below)
             struct Epi1 {                              // A2 = G G ; T = x1 G + x2 A2
                 const double2 *G;
