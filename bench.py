@@ -241,7 +241,7 @@ def roofline(local, info, samples, evals_per_s, n_gpus, traffic, profile=None, n
         t_first = float(first_ms.mean()) * 1e-3 if first_ms.size else 0.0
         parts = []
         for nm, fl, t in (("propagators (any_prop_kernel)", E * N * (3 + s_mean) * prod, t_first),
-                          ("chain (any_sweep_kernel: one workgroup per member)", E * N * q * prod, max(sec - t_first, 0.0))):
+                          ("chain (chunk products, boundary scan, windowed any_sweep_kernel)", E * N * q * prod, max(sec - t_first, 0.0))):
             if t <= 0:
                 continue
             tf = fl / t / 1e12
@@ -575,7 +575,7 @@ def shard_overheads(qoc, cfg_name, dev_index, sizes=(512, 256, 128), steps=300):
     for E in sizes:
         w = qoc.workloads.config(cfg_name, E=E)
         with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, device=dev_index,
-                             flags=qoc.engine.FLAG_TIME_KERNELS | qoc.engine.FLAG_TIME_SAMPLED) as eng:   # (an event pair costs ~5 us: every 8th call, as the headline)
+                             flags=qoc.engine.FLAG_TIME_KERNELS | (qoc.engine.FLAG_TIME_SAMPLED if steps >= 32 else 0)) as eng:   # (an event pair costs ~5 us: every 8th call, as the headline; short runs time every call)
             xf = np.ascontiguousarray(w.x.T)
             call = eng.bind_eval(xf, np.empty_like(xf))
             for _ in range(min(20, steps)):

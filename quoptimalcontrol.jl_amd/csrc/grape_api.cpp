@@ -155,6 +155,9 @@ struct grape_ctx {
     int act_R = 0;                             // sparse rows of the control operators (0: dense forms kernel)
     bool act_shared = true;                    // one set of control operators for every member
     bool ctrl_shared = false;                  // the members' control operators are identical (memcmp)
+    int32_t *d_any_sp_i = nullptr;             // size-generic family, sparse shared controls: [eptr | ectl | cptr | caddr]
+    double2 *d_any_sp_c = nullptr;             //                                              [ecoef | ccoef]
+    size_t any_sp_i_cap = 0, any_sp_c_cap = 0, any_sp_nnz = 0, any_sp_ntouch = 0;   // capacities (elements); non-zeros of the current operators (0: dense), elements they touch
     bool ctrl_scaled = false;                  // B_{k,c} = s_k B_{0,c} with some s_k != 1 (d_ctrl_scale: s_k per member): the
     double *d_ctrl_scale = nullptr;            //   hoisted flows' pre-pass runs on member 0's operators, members scale Gc_t
     size_t act_var_bytes = 0;                  // device bytes of the vector flow's operator buffers (re-sized per upload)
@@ -428,6 +431,7 @@ static void free_all(grape_ctx *c)
     (void)hipFree(c->d_scratch);
     (void)hipFree(c->d_vecs);
     (void)hipFree(c->d_sp_coef); (void)hipFree(c->d_sp_addr);
+    (void)hipFree(c->d_any_sp_i); (void)hipFree(c->d_any_sp_c);
     (void)hipFree(c->d_tp_q); (void)hipFree(c->d_tp_r); (void)hipFree(c->d_tp_m); (void)hipFree(c->d_tp_z); (void)hipFree(c->d_tp_vec); (void)hipFree(c->d_tp_a);
     (void)hipFree(c->d_x_bar);
     (void)hipFree(c->d_ha); (void)hipFree(c->d_ha_norm); (void)hipFree(c->d_gc); (void)hipFree(c->d_gcn);
@@ -1260,6 +1264,44 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     }
     const bool ctrl_hoistable = ctrl_shared || c->ctrl_scaled;   // ONE control sum per slice serves every member
     c->ctrl_shared = ctrl_shared;
+    c->any_sp_nnz = 0;
+    if (c->family == 2 && c->cfg.n >= 17 && ctrl_shared && K >= 1 && !env_on("GRAPE_NO_SPARSE")) {
+        // size-generic family: shared control operators with few non-zeros (all of them together at most n^2 / 4: local drives on
+        // seven qubits have 7 x 128 of 16 384) -- the H build and the gradient traces walk lists, not K dense operators per slice
+        std::vector<int32_t> tidx, tptr, ectl, cptr, caddr;
+        std::vector<double> ecoef, ccoef;
+        const long nnz = grape_host::build_any_sparse(B, K, n, nn / 4, tidx, tptr, ectl, ecoef, cptr, caddr, ccoef);
+        if (nnz > 0) {
+            const size_t nt = tidx.size();
+            const size_t ni = nt + (nt + 1) + (size_t)nnz + (K + 1) + (size_t)nnz, nc = 2 * (size_t)nnz;
+            if (c->any_sp_i_cap < ni) {
+                (void)hipFree(c->d_any_sp_i); c->d_any_sp_i = nullptr;
+                c->bytes -= sizeof(int32_t) * c->any_sp_i_cap;
+                c->any_sp_i_cap = 0;
+                HIP_TRY(c, hipMalloc((void **)&c->d_any_sp_i, sizeof(int32_t) * ni));
+                c->any_sp_i_cap = ni;
+                c->bytes += sizeof(int32_t) * ni;
+            }
+            if (c->any_sp_c_cap < nc) {
+                (void)hipFree(c->d_any_sp_c); c->d_any_sp_c = nullptr;
+                c->bytes -= sizeof(double2) * c->any_sp_c_cap;
+                c->any_sp_c_cap = 0;
+                HIP_TRY(c, hipMalloc((void **)&c->d_any_sp_c, sizeof(double2) * nc));
+                c->any_sp_c_cap = nc;
+                c->bytes += sizeof(double2) * nc;
+            }
+            int32_t *di = c->d_any_sp_i;                     // [tidx | tptr | ectl | cptr | caddr]
+            HIP_TRY(c, hipMemcpy(di, tidx.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(di + nt, tptr.data(), sizeof(int32_t) * (nt + 1), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(di + 2 * nt + 1, ectl.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(di + 2 * nt + 1 + nnz, cptr.data(), sizeof(int32_t) * (K + 1), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(di + 2 * nt + 1 + nnz + (K + 1), caddr.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->d_any_sp_c, ecoef.data(), sizeof(double2) * nnz, hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->d_any_sp_c + nnz, ccoef.data(), sizeof(double2) * nnz, hipMemcpyHostToDevice));
+            c->any_sp_ntouch = nt;
+            c->any_sp_nnz = (size_t)nnz;
+        }
+    }
     const bool act_forced = act_env && act_env[0] == '1';
     // shared controls, or -- n <= 16 -- the members' own (at most six: a lane keeps its half rows of them in registers)
     const bool act_ok = (ctrl_hoistable || (c->NT == 1 && K <= 6)) && !(act_env && act_env[0] == '0') &&
@@ -2113,6 +2155,18 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
             a.prop_blocks = c->any_blocks;
             a.ev_mid = lo == 0 ? emid : nullptr;
             a.shared_b = c->ctrl_shared ? c->d_ops + nn : nullptr;
+            if (c->any_sp_nnz) {
+                const size_t z = c->any_sp_nnz;
+                const size_t nt = c->any_sp_ntouch;
+                a.sp_tidx = c->d_any_sp_i;
+                a.sp_tptr = a.sp_tidx + nt;
+                a.sp_ectl = a.sp_tptr + (nt + 1);
+                a.sp_cptr = a.sp_ectl + z;
+                a.sp_caddr = a.sp_cptr + (Kc + 1);
+                a.sp_ntouch = (int32_t)nt;
+                a.sp_ecoef = c->d_any_sp_c;
+                a.sp_ccoef = a.sp_ecoef + z;
+            }
             a.tp_chunks = c->tp_C;
             a.tp_S = c->tp_S;
             a.tp_q = c->d_tp_q;
@@ -3611,7 +3665,10 @@ extern "C" int grape_get_info(const grape_ctx *c, grape_info *info)
     info->lane_pair = (c->is_group ? c->sub[0]->pair : c->pair) ? 1 : 0;
     info->states_stored = states_stored(c->is_group ? c->sub[0] : c) ? 1 : 0;
     info->rank_one_chain = (c->is_group ? c->sub[0]->thin : c->thin) ? 1 : 0;
-    info->sparse_controls = (c->is_group ? c->sub[0]->sparse_ctrl : c->sparse_ctrl) ? 1 : 0;
+    {
+        const grape_ctx *s0 = c->is_group ? c->sub[0] : c;
+        info->sparse_controls = (s0->sparse_ctrl || s0->any_sp_nnz) ? 1 : 0;
+    }
     {
         const grape_ctx *s0 = c->is_group ? c->sub[0] : c;
         info->fused_forward = (s0->thin && !s0->action && tile_fuse_forward(tile_params(s0, nullptr, 1)) == 1) ? 1 : 0;

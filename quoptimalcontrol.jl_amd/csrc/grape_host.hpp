@@ -4,6 +4,7 @@
 //   build_sparse_lists   (coefficient, position) lists of control operators with few non-zeros
 //   hermitian_to_rounding  M == M' to 4 ulp of its largest entry (all entries finite)
 //   controls_scaled      B_{k,c} = s_k B_{0,c} for every member k and control c?  (amplitude inhomogeneity)
+//   build_any_sparse     shared control operators with few non-zeros, by element and by control (size-generic family)
 // All matrices are n x n complex, column-major, interleaved {re, im}.
 #pragma once
 #include <cmath>
@@ -114,6 +115,64 @@ inline bool build_sparse_lists(const double *B, size_t E, size_t K, int n, int r
             }
     }
     return true;
+}
+
+// Size-generic family (sweep_any.hip), shared control operators with few non-zeros (local Pauli-type drives on >= 7 qubits: n
+// entries of n^2): the non-zeros of member 0's B_1..B_K in two orders, positions = i + j n (column-major, as the kernel's matrices):
+//   by ELEMENT  tidx[m] = the m-th element that any control touches (ascending), tptr[m] .. tptr[m + 1] = its entries (control,
+//               coefficient), controls ascending -- H[e] = A[e] + sum over them of x_c coefficient: the dense sum without its
+//               zero terms, in the same order;
+//   by CONTROL  cptr[c] .. cptr[c + 1] = the (position, coefficient) of B_c's non-zeros, for the gradient traces.
+// Returns the number of non-zeros (0: none at all -- nothing built), or -1 beyond max_total.
+inline long build_any_sparse(const double *B0, size_t K, int n, size_t max_total, std::vector<int32_t> &tidx, std::vector<int32_t> &tptr,
+                             std::vector<int32_t> &ectl, std::vector<double> &ecoef, std::vector<int32_t> &cptr,
+                             std::vector<int32_t> &caddr, std::vector<double> &ccoef)
+{
+    const size_t nn = (size_t)n * n;
+    std::vector<int32_t> cnt(nn, 0);
+    cptr.assign(K + 1, 0);
+    size_t total = 0;
+    for (size_t c = 0; c < K; ++c) {
+        for (size_t e = 0; e < nn; ++e)
+            if (B0[2 * (c * nn + e)] != 0.0 || B0[2 * (c * nn + e) + 1] != 0.0) {
+                ++cnt[e];
+                ++total;
+                if (total > max_total)
+                    return -1;
+            }
+        cptr[c + 1] = (int32_t)total;
+    }
+    tidx.clear();
+    tptr.assign(1, 0);
+    if (total == 0)
+        return 0;
+    std::vector<int32_t> slot(nn, -1);                        // element -> its first entry
+    for (size_t e = 0; e < nn; ++e)
+        if (cnt[e]) {
+            slot[e] = tptr.back();
+            tidx.push_back((int32_t)e);
+            tptr.push_back(tptr.back() + cnt[e]);
+        }
+    ectl.assign(total, 0);
+    ecoef.assign(2 * total, 0.0);
+    caddr.assign(total, 0);
+    ccoef.assign(2 * total, 0.0);
+    size_t q = 0;
+    for (size_t c = 0; c < K; ++c)
+        for (size_t e = 0; e < nn; ++e) {
+            const double re = B0[2 * (c * nn + e)], im = B0[2 * (c * nn + e) + 1];
+            if (re == 0.0 && im == 0.0)
+                continue;
+            const size_t at = (size_t)slot[e]++;          // (controls ascending: c is the outer loop)
+            ectl[at] = (int32_t)c;
+            ecoef[2 * at] = re;
+            ecoef[2 * at + 1] = im;
+            caddr[q] = (int32_t)e;
+            ccoef[2 * q] = re;
+            ccoef[2 * q + 1] = im;
+            ++q;
+        }
+    return (long)total;
 }
 
 }  // namespace grape_host

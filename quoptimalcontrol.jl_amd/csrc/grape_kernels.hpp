@@ -255,9 +255,15 @@ struct AnyParams {
     int32_t tp_chunks, tp_S;
     double2 *tp_q, *tp_u, *tp_r;
     hipEvent_t ev_mid;        // nullable: recorded behind the propagator launch (prop_blocks > 1 only)
-    int32_t abl;              // diagnostic ablation mask (GRAPE_ANY_ABL; wrong results): 1 no MFMAs, 2 no traces, 4 no operand fetch
+    int32_t abl;              // diagnostic ablation mask (GRAPE_ANY_ABL; wrong results): 1 no MFMAs, 2 no traces, 4 no operand fetch,
+                              // 8 no H build, 16 no norm, 32 no Taylor products, 64 no stores of the H build's first pass
     const double2 *shared_b;  // nullable: the members' control operators are identical -- member 0's [B_1..B_K] for everybody
                               // (K n^2 16 B that stay in L2 instead of E times as much streamed from memory per slice)
+    // nullable (all or none): shared control operators with few non-zeros (grape_host::build_any_sparse) -- the H build and the
+    // gradient traces walk these lists instead of K dense n x n operators per slice
+    const int32_t *sp_tidx, *sp_tptr, *sp_ectl, *sp_cptr, *sp_caddr;     // touched elements, their entries; by control
+    const double2 *sp_ecoef, *sp_ccoef;
+    int32_t sp_ntouch;
 };
 hipError_t launch_sweep_any(const AnyParams &p, hipStream_t stream);
 int any_prop_blocks(int n, int N, long units, int cus);    // how many propagator blocks per member the launcher will use

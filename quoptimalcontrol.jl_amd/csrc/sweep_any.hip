@@ -294,84 +294,134 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
     const int spb = (N + nprop - 1) / nprop;
     const int t_lo = p.phase == 1 ? (int)blockIdx.z * spb : 0, t_hi = p.phase == 1 ? min(N, t_lo + spb) : (p.phase == 0 ? N : 0);
     for (int t = t_lo; t < t_hi; ++t) {
-        // four elements per thread and pass: the K + 1 operator entries of each are independent loads -- issued one element
-        // and one control at a time (round 5) every load waited for the one before: ~230 memory round trips per thread and
-        // slice, 0.3 ms of the 0.6 ms a 128 x 128 slice took without its products
-        for (int base = threadIdx.x; base < nn && !(p.abl & 8); base += 4 * TH) {
-            double hr[4], hi[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = min(base + u * TH, nn - 1);
-                if (p.variant == 0) {                  // (0 + B_1 x_1 + ...) + A
-                    hr[u] = 0.0;
-                    hi[u] = 0.0;
-                } else {                               // A + B_1 x_1 + ...
-                    hr[u] = opA[idx].x;
-                    hi[u] = opA[idx].y;
-                }
-            }
-            for (int c0 = 0; c0 < K; c0 += 4) {        // four controls x four elements: sixteen independent loads per step
-                double xv[4];
-                double2 b[4][4];
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const int c = min(c0 + cc, K - 1);
-                    xv[cc] = c0 + cc < K ? x[c + (size_t)t * K] : 0.0;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        b[cc][u] = opB[(size_t)c * nn + min(base + u * TH, nn - 1)];
-                }
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc)
-                    if (c0 + cc < K) {                 // (controls in their order: the reference's sum)
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            hr[u] = fma(b[cc][u].x, xv[cc], hr[u]);
-                            hi[u] = fma(b[cc][u].y, xv[cc], hi[u]);
-                        }
-                    }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * TH;
-                if (idx < nn) {
-                    if (p.variant == 0) {
-                        hr[u] += opA[idx].x;
-                        hi[u] += opA[idx].y;
-                    }
-                    G[idx] = make_double2(dt * hi[u], -dt * hr[u]);      // (-i dt) H
-                }
-            }
-        }
-        __syncthreads();
-        // |G|_1 bound: max column sum of |re| + |im|.  A wave per column, its lanes along the rows (coalesced, independent loads),
-        // lane partials summed by a butterfly (fixed order); the maximum over columns needs no order
+        // G = (-i dt) H and |G|_1 (max column sum of |re| + |im|): a wave per column, its lanes along the rows (coalesced), four
+        // (scalar kernel: two) columns x two rows per step.  Dense control operators: ONE pass, four controls at a time -- 32 independent loads in
+        // flight (issued one element and one control at a time, round 5, every load waited for the one before: ~230 memory
+        // round trips per thread and slice; this launch runs with every compute unit pulling from memory and a round trip costs
+        // microseconds).  Control operators with few non-zeros (sp_tidx): pass 1 writes (-i dt) A, pass 2 -- a thread per touched
+        // element -- re-forms those from A and their entries (controls ascending: the dense sum without its zero terms), pass 3
+        // takes the column sums; three short passes of independent loads instead of K + 1 operators per element.
+        // A column's sum: the lane's rows in their order, then a butterfly -- a fixed order; the maximum needs none.
         double cs = 0.0;
         {
+            constexpr int NW = TH / 64, CU = MFMA ? 4 : 2, UB = 2 * CU;     // (the scalar kernel has 128 registers per lane)
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            for (int j = wave; j < n && !(p.abl & 16); j += TH / 64) {
-                double part = 0.0;
-                for (int i = lane; i < n; i += 64) {
-                    const double2 g = G[i + (size_t)j * n];
-                    part += fabs(g.x) + fabs(g.y);
+            const bool lists = p.sp_tidx != nullptr;
+            for (int pass = 0; pass < (lists ? 2 : 1) && !(p.abl & 8); ++pass) {
+                // pass 0: G (dense: with its column sums); pass 1 (lists): the column sums of the patched G
+                if (pass == 1) {
+                    __syncthreads();
+                    for (int m = threadIdx.x; m < p.sp_ntouch; m += TH) {
+                        const int idx = p.sp_tidx[m], e0 = p.sp_tptr[m], e1 = p.sp_tptr[m + 1];
+                        const double2 a = opA[idx];
+                        double hr = p.variant == 0 ? 0.0 : a.x, hi = p.variant == 0 ? 0.0 : a.y;
+                        for (int e = e0; e < e1; ++e) {
+                            const double2 b = p.sp_ecoef[e];
+                            const double xv = x[p.sp_ectl[e] + (size_t)t * K];
+                            hr = fma(b.x, xv, hr);
+                            hi = fma(b.y, xv, hi);
+                        }
+                        if (p.variant == 0) {
+                            hr += a.x;
+                            hi += a.y;
+                        }
+                        G[idx] = make_double2(dt * hi, -dt * hr);
+                    }
+                    __syncthreads();
                 }
+                for (int j0 = wave; j0 < n; j0 += CU * NW) {
+                    double part[CU];
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1)
-                    part += __shfl_xor(part, d, 64);
-                cs = (part != part || cs != cs) ? part + cs : fmax(cs, part);      // (a NaN stays a NaN)
+                    for (int q = 0; q < CU; ++q)
+                        part[q] = 0.0;
+                    for (int i0 = lane; i0 < n; i0 += 128) {
+                        int idx[UB];
+                        bool ok[UB];
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {     // u = column (u >> 1), row (u & 1)
+                            const int i = i0 + 64 * (u & 1), j = j0 + NW * (u >> 1);
+                            ok[u] = i < n && j < n;
+                            idx[u] = ok[u] ? i + j * n : 0;
+                        }
+                        if (pass == 1) {
+                            double2 g[UB];
+#pragma unroll
+                            for (int u = 0; u < UB; ++u)
+                                g[u] = G[idx[u]];
+#pragma unroll
+                            for (int u = 0; u < UB; ++u)
+                                if (ok[u])
+                                    part[u >> 1] += fabs(g[u].x) + fabs(g[u].y);
+                            continue;
+                        }
+                        double2 a[UB];
+                        double hr[UB], hi[UB];
+#pragma unroll
+                        for (int u = 0; u < UB; ++u)
+                            a[u] = opA[idx[u]];
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            hr[u] = p.variant == 0 ? 0.0 : a[u].x;      // (0 + B_1 x_1 + ...) + A  /  A + B_1 x_1 + ...
+                            hi[u] = p.variant == 0 ? 0.0 : a[u].y;
+                        }
+                        for (int c0 = 0; c0 < K && !lists; c0 += 4) {
+                            double xv[4];
+                            double2 b[4][UB];
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc) {
+                                const int c = min(c0 + cc, K - 1);
+                                xv[cc] = c0 + cc < K ? x[c + (size_t)t * K] : 0.0;
+#pragma unroll
+                                for (int u = 0; u < UB; ++u)
+                                    b[cc][u] = opB[(size_t)c * nn + idx[u]];
+                            }
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc)
+                                if (c0 + cc < K) {         // (controls in their order: the reference's sum)
+#pragma unroll
+                                    for (int u = 0; u < UB; ++u) {
+                                        hr[u] = fma(b[cc][u].x, xv[cc], hr[u]);
+                                        hi[u] = fma(b[cc][u].y, xv[cc], hi[u]);
+                                    }
+                                }
+                        }
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            if (p.variant == 0) {
+                                hr[u] += a[u].x;
+                                hi[u] += a[u].y;
+                            }
+                            const double2 g = make_double2(dt * hi[u], -dt * hr[u]);      // (-i dt) H
+                            if (ok[u]) {
+                                if (!(p.abl & 64))
+                                    G[idx[u]] = g;
+                                part[u >> 1] += fabs(g.x) + fabs(g.y);
+                            }
+                        }
+                    }
+                    if (lists && pass == 0)
+                        continue;
+#pragma unroll
+                    for (int q = 0; q < CU; ++q) {
+                        double pq = part[q];
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1)
+                            pq += __shfl_xor(pq, d, 64);
+                        if (!(p.abl & 16))
+                            cs = (pq != pq || cs != cs) ? pq + cs : fmax(cs, pq);      // (a NaN stays a NaN)
+                    }
+                }
             }
         }
+        __syncthreads();                               // (G is complete; s_red is free)
+        if ((threadIdx.x & 63) == 0)                   // every lane of a wave holds the wave's maximum
+            s_red[threadIdx.x >> 6] = cs;
         __syncthreads();
-        s_red[threadIdx.x] = cs;
-        __syncthreads();
-        for (int d = TH / 2; d >= 1; d >>= 1) {
-            if ((int)threadIdx.x < d) {
-                const double a_ = s_red[threadIdx.x], b_ = s_red[threadIdx.x + d];
-                s_red[threadIdx.x] = (a_ != a_ || b_ != b_) ? a_ + b_ : fmax(a_, b_);
-            }
-            __syncthreads();
+        double colmax = s_red[0];
+        for (int w = 1; w < TH / 64; ++w) {
+            const double b_ = s_red[w];
+            colmax = (colmax != colmax || b_ != b_) ? colmax + b_ : fmax(colmax, b_);
         }
-        const double colmax = s_red[0];
         __syncthreads();
         const int s = p.s_forced >= 0 ? p.s_forced : squarings_for(colmax);
         if (s > 0) {
@@ -522,21 +572,38 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
         // z = tr(X' L) and w_c = sum_ij B_c[i][j] R[j][i], four controls per pass over R' and per workgroup reduction; two
         // elements per thread and step (their loads are independent)
         double2 zz = make_double2(0.0, 0.0);
+        const bool sparse = p.sp_cptr != nullptr;      // B_c's non-zeros from the lists; the dense pass then only forms z
         for (int c0 = 0; c0 < K && !(p.abl & 2) && emit; c0 += 4) {
             double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            for (int base = threadIdx.x; base < nn; base += 2 * TH) {
+            if (sparse) {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    if (c0 + cc >= K)
+                        break;
+                    const int e1 = p.sp_cptr[c0 + cc + 1];
+                    for (int e = p.sp_cptr[c0 + cc] + (int)threadIdx.x; e < e1; e += TH) {
+                        const double2 b = p.sp_ccoef[e], rc = T[p.sp_caddr[e]];
+                        const double2 r = make_double2(rc.x, -rc.y);
+                        v[2 + 2 * cc] = fma(b.x, r.x, v[2 + 2 * cc]);
+                        v[2 + 2 * cc] = fma(-b.y, r.y, v[2 + 2 * cc]);
+                        v[3 + 2 * cc] = fma(b.x, r.y, v[3 + 2 * cc]);
+                        v[3 + 2 * cc] = fma(b.y, r.x, v[3 + 2 * cc]);
+                    }
+                }
+            }
+            for (int base = threadIdx.x; base < nn && (!sparse || c0 == 0); base += 2 * TH) {
                 double2 rr[2], xa[2], lb[2], bb[2][4];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int idx = min(base + u * TH, nn - 1);
-                    rr[u] = T[idx];
+                    rr[u] = sparse ? make_double2(0.0, 0.0) : T[idx];
                     if (c0 == 0) {
                         xa[u] = X[idx];
                         lb[u] = Ln[idx];
                     }
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc)
-                        bb[u][cc] = opB[(size_t)min(c0 + cc, K - 1) * nn + idx];
+                        bb[u][cc] = sparse ? make_double2(0.0, 0.0) : opB[(size_t)min(c0 + cc, K - 1) * nn + idx];
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -552,7 +619,7 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
                     }
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc)
-                        if (c0 + cc < K) {
+                        if (c0 + cc < K && !sparse) {
                             const double2 b = bb[u][cc];
                             v[2 + 2 * cc] = fma(b.x, r.x, v[2 + 2 * cc]);
                             v[2 + 2 * cc] = fma(-b.y, r.y, v[2 + 2 * cc]);

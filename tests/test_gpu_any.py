@@ -142,3 +142,59 @@ def test_chunked_time_axis_beyond_64(qoc, oracle, monkeypatch, n, sys_type, herm
     scale = np.abs(res["sequential"]).max()
     assert np.abs(res["chunked"] - res["sequential"]).max() <= 1e-11 * scale
     assert np.abs(res["chunks3"] - res["sequential"]).max() <= 1e-11 * scale
+
+
+@pytest.mark.parametrize("n,sys_type,herm,variant,E,N", [(66, "UnitaryGate", True, 0, 3, 7), (128, "UnitaryGate", True, 1, 2, 18),
+                                                        (81, "StateTransfer", False, 1, 1, 6), (100, "CoherenceTransfer", True, 0, 2, 5)])
+def test_sparse_shared_controls_beyond_64(qoc, oracle, monkeypatch, n, sys_type, herm, variant, E, N):
+    """Round 6: shared control operators with few non-zeros (local drives on seven qubits and more: n of n^2 entries) -- the H
+    build and the gradient traces of sweep_any.hip walk lists (grape_host::build_any_sparse: by element for H, by control for
+    the traces) instead of K dense n x n operators per slice.  Oracle parity per member incl. the trajectory, `sparse_controls`
+    reported, agreement with the dense walk (GRAPE_NO_SPARSE=1) to rounding; an operator set beyond the density bound and
+    per-member operators keep the dense walk."""
+    rng = np.random.default_rng(500 + n)
+    K = 5
+    w = _random_problem(qoc, n, K, N, E, sys_type, seed=70 + n, hermitian=herm, mixed=True)
+    w.A *= 2.0 / n
+    B = np.zeros((K, n, n), dtype=complex)
+    for c in range(K):                                       # c = 0: diagonal; others: a few off-diagonals (Hermitian where asked),
+        if c == 0:                                           # two controls sharing positions, one with a single entry
+            B[c][np.arange(n), np.arange(n)] = rng.standard_normal(n)
+            continue
+        cnt = 1 if c == 4 else n
+        ii, jj = rng.integers(0, n, cnt), rng.integers(0, n, cnt)
+        if c == 3:
+            ii, jj = np.nonzero(B[2])[0][:cnt], np.nonzero(B[2])[1][:cnt]
+        v = rng.standard_normal(len(ii)) + 1j * rng.standard_normal(len(ii))
+        B[c][ii, jj] = v
+        if herm:
+            B[c] = (B[c] + B[c].conj().T) / 2
+    w.B = np.broadcast_to(B * 0.3, (E,) + B.shape).copy()
+    res = {}
+    for tag, env in (("lists", {}), ("dense", {"GRAPE_NO_SPARSE": "1"})):
+        monkeypatch.delenv("GRAPE_NO_SPARSE", raising=False)
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        _check(qoc, oracle, w, variant=variant)
+        with _engine(qoc, w, variant=variant) as eng:
+            res[tag] = eng.eval(w.x)
+            assert eng.info["sparse_controls"] == (1 if tag == "lists" else 0)
+    monkeypatch.delenv("GRAPE_NO_SPARSE", raising=False)
+    assert abs(res["lists"][0] - res["dense"][0]) <= 1e-12 * max(1.0, abs(res["dense"][0]))
+    assert np.abs(res["lists"][1] - res["dense"][1]).max() <= 1e-12 * np.abs(res["dense"][1]).max()
+    # beyond the density bound (all operators together > n^2 / 4 non-zeros), and per-member operators: the dense walk
+    w2 = _random_problem(qoc, n, 2, N, max(E, 2), sys_type, seed=71 + n, hermitian=herm, mixed=True)
+    w2.A *= 2.0 / n
+    w2.B *= 2.0 / n
+    w2.B[:] = w2.B[0]
+    with _engine(qoc, w2, variant=variant) as eng:
+        eng.eval(w2.x)
+        assert eng.info["sparse_controls"] == 0
+    w3 = _random_problem(qoc, n, K, N, max(E, 2), sys_type, seed=72 + n, hermitian=herm, mixed=True)
+    w3.A *= 2.0 / n
+    w3.B = np.broadcast_to(B * 0.3, (max(E, 2),) + B.shape).copy()
+    w3.B[1] *= 1.25
+    with _engine(qoc, w3, variant=variant) as eng:
+        eng.eval(w3.x)
+        assert eng.info["sparse_controls"] == 0
+    _check(qoc, oracle, w3, variant=variant)

@@ -19,12 +19,15 @@ stats C4_E1024 GRAPE_X=0 --config C4 --steps 40 --warmup 5
 stats C5_E4096 GRAPE_X=0 --config C5 --steps 2 --warmup 1
 stats C6_E256 GRAPE_X=0 --config C6 --steps 3 --warmup 1
 stats C7_E64 GRAPE_X=0 --config C7 --steps 5 --warmup 1
+stats C6x1 GRAPE_X=0 --config C6x1 --steps 50 --warmup 5
+stats C7x1 GRAPE_X=0 --config C7x1 --steps 10 --warmup 2
 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C3" > "$OUT/pmc_C3.log" 2>&1
 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C7" --config C7 --steps 3 --warmup 1 > "$OUT/pmc_C7.log" 2>&1
 cd "$ROOT"
 python3 tools/phase_profile.py --config C3 > "$OUT/C3_phase_stamps.json" 2> /dev/null
 python3 -m pytest tests/test_gpu_perf_gate.py -q -s 2>&1 | grep -E "perf gate|passed|failed" > "$OUT/perf_gate.txt"
 python3 tools/anysize_time.py > "$OUT/anysize_time.txt" 2>&1
+python3 tools/single_big_time.py > "$OUT/single_big_time.txt" 2>&1
 for seed in 61 62 63 64; do python3 tools/soak.py 1500 $seed 2>&1 | tail -1; done > "$OUT/soak.txt"
 python3 tools/soak_api.py 400 6 2>&1 | tail -1 >> "$OUT/soak.txt"
 python3 tools/parity_report.py > "$OUT/parity.json" 2> "$OUT/parity.log"
