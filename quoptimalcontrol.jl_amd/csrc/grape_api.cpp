@@ -1265,7 +1265,7 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
     const bool ctrl_hoistable = ctrl_shared || c->ctrl_scaled;   // ONE control sum per slice serves every member
     c->ctrl_shared = ctrl_shared;
     c->any_sp_nnz = 0;
-    if (c->family == 2 && c->cfg.n >= 17 && ctrl_shared && K >= 1 && !env_on("GRAPE_NO_SPARSE")) {
+    if (c->family == 2 && c->cfg.n >= 17 && ctrl_shared && K >= 1 && K <= 256 && !env_on("GRAPE_NO_SPARSE")) {
         // size-generic family: shared control operators with few non-zeros (all of them together at most n^2 / 4: local drives on
         // seven qubits have 7 x 128 of 16 384) -- the H build and the gradient traces walk lists, not K dense operators per slice
         std::vector<int32_t> tidx, tptr, ectl, cptr, caddr;

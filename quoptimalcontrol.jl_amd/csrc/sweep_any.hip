@@ -15,6 +15,8 @@
 // per member: ops [A | B_1..B_K | Xi | Xt], props / states / costates N matrices each, scratch 6 matrices.
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 #include "cmat.hpp"
 #include "grape_kernels.hpp"
@@ -68,6 +70,17 @@ constexpr int kAnyPlane = 128 * kAnyPitch;             // doubles per plane
 constexpr int kAnyBuf = 4 * kAnyPlane;                 // doubles of one buffer: two images x two planes (73 728 B)
 constexpr size_t kAnyImgBytes = sizeof(double) * 2 * kAnyBuf;        // two buffers: a panel is written while the previous one is read
 
+// Diagnostic time stamps (GRAPE_ANY_STAMPS=1: the launcher prints where workgroup (0, 0, 0) of the propagator launch and of the
+// windowed chain spend their time, 100 MHz clock): tag << 56 | time, written by thread 0 of that workgroup only.
+__device__ unsigned long long *g_any_stamps = nullptr;
+__device__ int g_any_stamp_n = 0;
+constexpr int kAnyStampCap = 8192;
+__device__ __forceinline__ void any_stamp(int tag)
+{
+    if (g_any_stamps && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && g_any_stamp_n < kAnyStampCap)
+        g_any_stamps[g_any_stamp_n++] = ((unsigned long long)tag << 56) | (__builtin_amdgcn_s_memrealtime() & 0x00ffffffffffffffull);
+}
+
 // EPI: what to do with element (i, j) of the product -- the plain store, or a fused element-wise step (the Taylor combinations
 // of the expm: at n = 128 every separate pass over a matrix is 0.5 - 1 MB through memory for a workgroup that gets ~20 GB/s of
 // the device's bandwidth when all compute units run; the propagator launch was memory-bound with them).  It may read and
@@ -82,12 +95,29 @@ struct AnyStore {
     __device__ void store(size_t idx, int, int, double2 v, const L &) const { C[idx] = v; }
 };
 
+#ifndef GRAPE_ANY_NOINLINE
+#define GRAPE_ANY_NOINLINE 0
+#endif
 template <bool HA, bool HB, typename EPI>
+#if GRAPE_ANY_NOINLINE
+__device__ __attribute__((noinline)) void any_mm_mfma(int n, const double2 *__restrict__ A, const double2 *__restrict__ B, double *__restrict__ img, EPI epi,
+                            int abl = 0)
+#elif GRAPE_ANY_NOINLINE == 2
 __device__ void any_mm_mfma(int n, const double2 *__restrict__ A, const double2 *__restrict__ B, double *__restrict__ img, EPI epi,
                             int abl = 0)
+#else
+__device__ __forceinline__ void any_mm_mfma(int n, const double2 *__restrict__ A, const double2 *__restrict__ B, double *__restrict__ img,
+                                            EPI epi, int abl = 0)
+#endif
 {
     constexpr int TH = kAnyMfmaThreads, NQ = 1024 / TH;         // k pairs per thread, operand and panel
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 15, hi = lane >> 4;
+    // (the thread index through an opaque move: everything below that depends only on it -- operand and result offsets of all
+    // ten inlined products -- is otherwise hoisted out of the caller's slice loop, kept alive across the 128 accumulators of
+    // every product, i.e. spilled, and reloaded from scratch memory one waited load at a time: 13-25 us in front of each
+    // product at n = 128; recomputing it is ~50 vector instructions)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6, lo = lane & 15, hi = lane >> 4;
     const int wi = wave >> 2, wj = wave & 3;           // rows 64 wi .., columns 32 wj ..
     const int nsb = (n + 127) >> 7, npan = (n + 15) >> 4;
     // this thread's entries of a panel: PAIRS of adjacent k values (written to the images as one 16-byte store per plane: with
@@ -152,12 +182,14 @@ __device__ void any_mm_mfma(int n, const double2 *__restrict__ A, const double2 
             // buffer b holds panel p (stashed, behind a barrier), the registers panel p + 1: the stash of p + 1 goes to the OTHER
             // buffer (last read one iteration ago, in front of that iteration's barrier), the fetch of p + 2 is in flight under
             // the products of p -- one barrier per panel, and a wave's stash runs under the other waves' products
+            any_stamp(10);
             fetch(0);
             __syncthreads();                           // (the previous block's / product's readers of buffer 0 are done)
             stash(0);
             if (npan > 1)
                 fetch(1);
             __syncthreads();
+            any_stamp(11);
             for (int pnl = 0; pnl < npan; ++pnl) {
                 const int buf = pnl & 1;
                 const double *__restrict__ ia = img + buf * kAnyBuf, *__restrict__ ib = ia + 2 * kAnyPlane;
@@ -197,6 +229,7 @@ __device__ void any_mm_mfma(int n, const double2 *__restrict__ A, const double2 
                 }
                 __syncthreads();                       // panel p + 1 is stashed, panel p is read
             }
+            any_stamp(12);
             if (active) {
 #pragma unroll
                 for (int ti = 0; ti < 4; ++ti) {
@@ -219,6 +252,7 @@ __device__ void any_mm_mfma(int n, const double2 *__restrict__ A, const double2 
             }
         }
     __syncthreads();
+    any_stamp(13);
 }
 
 __device__ int g_any_abl = 0;                         // (diagnostic: set through AnyParams.abl by thread 0 of every workgroup)
@@ -265,9 +299,14 @@ __device__ void any_block_sum_n(double (&v)[NV], double *s_red)
         v[q] = s_red[(TH / 64) * NV + q];
 }
 
-template <bool MFMA>
+// PART: which launches this instantiation serves -- 0 all phases (the single launch, phase 0), 1 the propagators (phase 1), 2 the
+// chain (phases 2, 4, 5), 3 the chunk products (phase 3).  One kernel for everything carried ten product sites and every
+// phase's uniform state through each of them: 250 spilled scalar registers, kept in vector registers that were themselves
+// spilled to scratch memory -- each scalar came back through a waited scratch load, 13-25 us in front of every product at n = 128.
+template <bool MFMA, int PART>
 __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_sweep_kernel(const AnyParams p)
 {
+    constexpr bool DO_PROPS = PART == 0 || PART == 1, DO_CHAIN = PART == 0 || PART == 2, DO_CPROD = PART == 3;
     constexpr int TH = MFMA ? kAnyMfmaThreads : kAnyThreads;       // (the matrix-core product wants 256 registers per wave)
     if (p.abl && threadIdx.x == 0)
         g_any_abl = p.abl;
@@ -293,6 +332,7 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
     // ------------------------------------------------------------ propagators, src/timeevolution.jl:98-110 (:45-57 static)
     const int spb = (N + nprop - 1) / nprop;
     const int t_lo = p.phase == 1 ? (int)blockIdx.z * spb : 0, t_hi = p.phase == 1 ? min(N, t_lo + spb) : (p.phase == 0 ? N : 0);
+    if constexpr (DO_PROPS)
     for (int t = t_lo; t < t_hi; ++t) {
         // G = (-i dt) H and |G|_1 (max column sum of |re| + |im|): a wave per column, its lanes along the rows (coalesced), four
         // (scalar kernel: two) columns x two rows per step.  Dense control operators: ONE pass, four controls at a time -- 32 independent loads in
@@ -302,6 +342,7 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
         // element -- re-forms those from A and their entries (controls ascending: the dense sum without its zero terms), pass 3
         // takes the column sums; three short passes of independent loads instead of K + 1 operators per element.
         // A column's sum: the lane's rows in their order, then a butterfly -- a fixed order; the maximum needs none.
+        any_stamp(1);
         double cs = 0.0;
         {
             constexpr int NW = TH / 64, CU = MFMA ? 4 : 2, UB = 2 * CU;     // (the scalar kernel has 128 registers per lane)
@@ -309,8 +350,24 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
             const bool lists = p.sp_tidx != nullptr;
             for (int pass = 0; pass < (lists ? 2 : 1) && !(p.abl & 8); ++pass) {
                 // pass 0: G (dense: with its column sums); pass 1 (lists): the column sums of the patched G
+                if (lists && pass == 0) {              // (-i dt) A, sixteen elements per lane in flight
+                    constexpr int SB = MFMA ? 16 : 8;
+                    for (int base = threadIdx.x; base < nn; base += SB * TH) {
+                        double2 a[SB];
+#pragma unroll
+                        for (int u = 0; u < SB; ++u)
+                            a[u] = opA[min(base + u * TH, nn - 1)];
+#pragma unroll
+                        for (int u = 0; u < SB; ++u)
+                            if (base + u * TH < nn && !(p.abl & 64))
+                                G[base + u * TH] = make_double2(dt * a[u].y, -dt * a[u].x);
+                    }
+                    any_stamp(2);
+                    continue;
+                }
                 if (pass == 1) {
                     __syncthreads();
+                    any_stamp(3);
                     for (int m = threadIdx.x; m < p.sp_ntouch; m += TH) {
                         const int idx = p.sp_tidx[m], e0 = p.sp_tptr[m], e1 = p.sp_tptr[m + 1];
                         const double2 a = opA[idx];
@@ -328,6 +385,7 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
                         G[idx] = make_double2(dt * hi, -dt * hr);
                     }
                     __syncthreads();
+                    any_stamp(4);
                 }
                 for (int j0 = wave; j0 < n; j0 += CU * NW) {
                     double part[CU];
@@ -399,8 +457,6 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
                             }
                         }
                     }
-                    if (lists && pass == 0)
-                        continue;
 #pragma unroll
                     for (int q = 0; q < CU; ++q) {
                         double pq = part[q];
@@ -413,6 +469,7 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
                 }
             }
         }
+        any_stamp(5);
         __syncthreads();                               // (G is complete; s_red is free)
         if ((threadIdx.x & 63) == 0)                   // every lane of a wave holds the wave's maximum
             s_red[threadIdx.x >> 6] = cs;
@@ -423,9 +480,13 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
             colmax = (colmax != colmax || b_ != b_) ? colmax + b_ : fmax(colmax, b_);
         }
         __syncthreads();
+        any_stamp(6);
         const int s = p.s_forced >= 0 ? p.s_forced : squarings_for(colmax);
-        if (s > 0) {
-            const double scl = ldexp(1.0, -s);
+        // G / 2^s: the scalar kernel scales G in memory; the matrix-core kernel leaves it as it is and scales where G is read
+        // (products of powers of two are exact: (G / 2^s)(G / 2^s) = (G G) / 4^s bit for bit -- the pass over G and its barrier
+        // were 20 us per 128 x 128 slice)
+        const double scl = ldexp(1.0, -s);
+        if (s > 0 && !MFMA) {
             for (int idx = threadIdx.x; idx < nn; idx += TH)
                 G[idx] = make_double2(G[idx].x * scl, G[idx].y * scl);
             __syncthreads();
@@ -435,42 +496,48 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
         if (p.abl & 32) {
         } else if constexpr (MFMA) {
             // the Taylor combinations ride on the products' epilogues (same operations on the same values as the passes below)
-            struct Epi1 {                              // A2 = G G ; T = x1 G + x2 A2
+            struct Epi1 {                              // (G here: G / 2^s)  A2 = G G ; T = x1 G + x2 A2
                 const double2 *G;
                 double2 *A2, *T;
+                double scl, scl2;
                 struct L { double2 g; };
                 __device__ L load(size_t idx) const { return L{G[idx]}; }
                 __device__ void store(size_t idx, int, int, double2 v, const L &l) const
                 {
+                    v = make_double2(v.x * scl2, v.y * scl2);
                     A2[idx] = v;
-                    T[idx] = make_double2(fma(kX1, l.g.x, kX2 * v.x), fma(kX1, l.g.y, kX2 * v.y));
+                    T[idx] = make_double2(fma(kX1, l.g.x * scl, kX2 * v.x), fma(kX1, l.g.y * scl, kX2 * v.y));
                 }
             };
             struct Epi2 {                              // A4 = A2 T (not stored) ; U = x3 A2 + A4 ; T2 = x4 I + x5 G + x6 A2 + x7 A4
                 const double2 *G, *A2;
                 double2 *U, *T2;
+                double scl;
                 struct L { double2 g, a2; };
                 __device__ L load(size_t idx) const { return L{G[idx], A2[idx]}; }
                 __device__ void store(size_t idx, int i, int j, double2 v, const L &l) const
                 {
+                    const double gx = l.g.x * scl, gy = l.g.y * scl;
                     U[idx] = make_double2(fma(kX3, l.a2.x, v.x), fma(kX3, l.a2.y, v.y));
-                    T2[idx] = make_double2(fma(kX5, l.g.x, fma(kX6, l.a2.x, kX7 * v.x)) + (i == j ? kX4 : 0.0),
-                                           fma(kX5, l.g.y, fma(kX6, l.a2.y, kX7 * v.y)));
+                    T2[idx] = make_double2(fma(kX5, gx, fma(kX6, l.a2.x, kX7 * v.x)) + (i == j ? kX4 : 0.0),
+                                           fma(kX5, gy, fma(kX6, l.a2.y, kX7 * v.y)));
                 }
             };
             struct Epi3 {                              // P = A8 + G + y2 A2 + I
                 const double2 *G, *A2;
                 double2 *P;
+                double scl;
                 struct L { double2 g, a2; };
                 __device__ L load(size_t idx) const { return L{G[idx], A2[idx]}; }
                 __device__ void store(size_t idx, int i, int j, double2 v, const L &l) const
                 {
-                    P[idx] = make_double2(v.x + fma(kY2, l.a2.x, l.g.x) + (i == j ? 1.0 : 0.0), v.y + fma(kY2, l.a2.y, l.g.y));
+                    P[idx] = make_double2(v.x + fma(kY2, l.a2.x, l.g.x * scl) + (i == j ? 1.0 : 0.0),
+                                          v.y + fma(kY2, l.a2.y, l.g.y * scl));
                 }
             };
-            any_mm_mfma<false, false>(n, G, G, s_any_img, Epi1{G, A2, T}, p.abl);
-            any_mm_mfma<false, false>(n, A2, T, s_any_img, Epi2{G, A2, U, A4}, p.abl);        // (T2 in A4's buffer)
-            any_mm_mfma<false, false>(n, U, A4, s_any_img, Epi3{G, A2, cur}, p.abl);
+            any_mm_mfma<false, false>(n, G, G, s_any_img, Epi1{G, A2, T, scl, scl * scl}, p.abl);
+            any_mm_mfma<false, false>(n, A2, T, s_any_img, Epi2{G, A2, U, A4, scl}, p.abl);   // (T2 in A4's buffer)
+            any_mm_mfma<false, false>(n, U, A4, s_any_img, Epi3{G, A2, cur, scl}, p.abl);
         } else {
             any_mm<false, false>(n, G, G, A2);
             for (int idx = threadIdx.x; idx < nn; idx += TH)
@@ -498,9 +565,9 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
             cur = dst;
         }
     }
-    if (p.phase == 1)
+    if constexpr (PART == 1)
         return;                                        // (the chain runs in a launch of its own)
-    if (p.phase == 3) {
+    if constexpr (DO_CPROD) {
         // chunk product Q_c = P_(hi-1) ... P_lo of chunk c = blockIdx.z (ping-pong between two scratch matrices)
         const int c = blockIdx.z, lo = c * p.tp_S, hi = min(N, lo + p.tp_S);
         double2 *Qc = p.tp_q + (kw * p.tp_chunks + c) * nn;
@@ -516,6 +583,7 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
         }
         return;
     }
+    if constexpr (DO_CHAIN) {
     // The chain.  phase 5: the slices [w_lo, w_hi) of chunk blockIdx.z, first state / last costate from the boundary scan;
     // phase 4 IS that scan: this code on the chunk products (the launcher hands over N = chunks, props = tp_q, states = tp_u,
     // costates = tp_r) without output rows.
@@ -547,6 +615,8 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
             Lc[idx] = L0[idx];
     }
     __syncthreads();
+    double2 zz = make_double2(0.0, 0.0);               // tr(X' L), formed once per sweep (see below)
+    bool have_z = false;
     for (int t = w_hi - 1; t >= w_lo; --t) {
         const double2 *P = Pk + (size_t)t * nn, *X = Xk + (size_t)t * nn;
         if (p.sand) {
@@ -569,48 +639,95 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
                 T[idx] = make_double2(T[idx].x - U[idx].x, T[idx].y - U[idx].y);
             __syncthreads();
         }
-        // z = tr(X' L) and w_c = sum_ij B_c[i][j] R[j][i], four controls per pass over R' and per workgroup reduction; two
-        // elements per thread and step (their loads are independent)
-        double2 zz = make_double2(0.0, 0.0);
+        // w_c = sum_ij B_c[i][j] R[j][i], four controls per pass over R' and per workgroup reduction, EU elements per thread and
+        // step (their loads are independent) -- or from the controls' lists -- and z = tr(X' L).  z is the same number at every
+        // slice (X_t+1 = P X_t, L_t = P' L_t+1: the trace is cyclic; the reference re-forms it per slice, src/GRAPE.jl:70, which
+        // agrees to rounding): this sweep forms it at its first slice -- the two extra passes over X_t and L_t were 50 of the
+        // 65 us a slice's traces took at n = 128 -- and, for sandwich problems (whose gradient does not contain it), at t = N - 1.
+        any_stamp(20);
+        constexpr int EU = MFMA ? 4 : 2;
         const bool sparse = p.sp_cptr != nullptr;      // B_c's non-zeros from the lists; the dense pass then only forms z
-        for (int c0 = 0; c0 < K && !(p.abl & 2) && emit; c0 += 4) {
-            double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (sparse) {
+        const bool need_z = emit && (p.sand ? t == N - 1 : !have_z);
+        if (sparse && emit && !(p.abl & 2)) {
+            // the controls' lists: wave w takes the controls w, w + 8, ...; its lanes stride the list, a butterfly sums them (fixed
+            // order), lane 0 leaves the pair in LDS -- all controls at once, two barriers (one control after the other through
+            // the workgroup reduction: 22 us per slice for seven lists of 128 entries)
+            if (need_z) {
+                double v2[2] = {0.0, 0.0};
+                constexpr int ZU = MFMA ? 8 : 2;
+                for (int base = threadIdx.x; base < nn; base += ZU * TH) {
+                    double2 xa[ZU], lb[ZU];
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    if (c0 + cc >= K)
-                        break;
-                    const int e1 = p.sp_cptr[c0 + cc + 1];
-                    for (int e = p.sp_cptr[c0 + cc] + (int)threadIdx.x; e < e1; e += TH) {
-                        const double2 b = p.sp_ccoef[e], rc = T[p.sp_caddr[e]];
-                        const double2 r = make_double2(rc.x, -rc.y);
-                        v[2 + 2 * cc] = fma(b.x, r.x, v[2 + 2 * cc]);
-                        v[2 + 2 * cc] = fma(-b.y, r.y, v[2 + 2 * cc]);
-                        v[3 + 2 * cc] = fma(b.x, r.y, v[3 + 2 * cc]);
-                        v[3 + 2 * cc] = fma(b.y, r.x, v[3 + 2 * cc]);
+                    for (int u = 0; u < ZU; ++u) {
+                        const int idx = min(base + u * TH, nn - 1);
+                        xa[u] = X[idx];
+                        lb[u] = Ln[idx];
                     }
+#pragma unroll
+                    for (int u = 0; u < ZU; ++u)
+                        if (base + u * TH < nn) {
+                            v2[0] = fma(xa[u].x, lb[u].x, v2[0]);
+                            v2[0] = fma(xa[u].y, lb[u].y, v2[0]);
+                            v2[1] = fma(xa[u].x, lb[u].y, v2[1]);
+                            v2[1] = fma(-xa[u].y, lb[u].x, v2[1]);
+                        }
+                }
+                any_block_sum_n<2, TH>(v2, s_red);
+                zz = make_double2(v2[0], v2[1]);
+                have_z = true;
+                __syncthreads();                       // (s_red is written again below)
+            }
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            for (int c = wave; c < K; c += TH / 64) {
+                double wr = 0.0, wi = 0.0;
+                const int e1 = p.sp_cptr[c + 1];
+                for (int e = p.sp_cptr[c] + lane; e < e1; e += 64) {
+                    const double2 b = p.sp_ccoef[e], rc = T[p.sp_caddr[e]];
+                    const double2 r = make_double2(rc.x, -rc.y);
+                    wr = fma(b.x, r.x, wr);
+                    wr = fma(-b.y, r.y, wr);
+                    wi = fma(b.x, r.y, wi);
+                    wi = fma(b.y, r.x, wi);
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    wr += __shfl_xor(wr, d, 64);
+                    wi += __shfl_xor(wi, d, 64);
+                }
+                if (lane == 0) {
+                    s_red[2 * c] = wr;
+                    s_red[2 * c + 1] = wi;
                 }
             }
-            for (int base = threadIdx.x; base < nn && (!sparse || c0 == 0); base += 2 * TH) {
-                double2 rr[2], xa[2], lb[2], bb[2][4];
+            __syncthreads();
+            for (int c = threadIdx.x; c < K; c += TH) {
+                const double im = p.sand ? s_red[2 * c + 1] : fma(s_red[2 * c], zz.y, s_red[2 * c + 1] * zz.x);
+                out[c + (size_t)t * K] = gs * im;
+            }
+        }
+        for (int c0 = 0; c0 < K && !(p.abl & 2) && emit && !sparse; c0 += 4) {
+            double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const bool zpass = c0 == 0 && need_z;
+            for (int base = threadIdx.x; base < nn; base += EU * TH) {
+                double2 rr[EU], xa[EU], lb[EU], bb[EU][4];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < EU; ++u) {
                     const int idx = min(base + u * TH, nn - 1);
-                    rr[u] = sparse ? make_double2(0.0, 0.0) : T[idx];
-                    if (c0 == 0) {
+                    rr[u] = T[idx];
+                    if (zpass) {
                         xa[u] = X[idx];
                         lb[u] = Ln[idx];
                     }
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc)
-                        bb[u][cc] = sparse ? make_double2(0.0, 0.0) : opB[(size_t)min(c0 + cc, K - 1) * nn + idx];
+                        bb[u][cc] = opB[(size_t)min(c0 + cc, K - 1) * nn + idx];
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < EU; ++u) {
                     if (base + u * TH >= nn)
                         continue;
                     const double2 r = make_double2(rr[u].x, -rr[u].y);
-                    if (c0 == 0) {
+                    if (zpass) {
                         const double2 a = xa[u], b = lb[u];
                         v[0] = fma(a.x, b.x, v[0]);
                         v[0] = fma(a.y, b.y, v[0]);
@@ -619,7 +736,7 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
                     }
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc)
-                        if (c0 + cc < K && !sparse) {
+                        if (c0 + cc < K) {
                             const double2 b = bb[u][cc];
                             v[2 + 2 * cc] = fma(b.x, r.x, v[2 + 2 * cc]);
                             v[2 + 2 * cc] = fma(-b.y, r.y, v[2 + 2 * cc]);
@@ -629,14 +746,17 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
                 }
             }
             any_block_sum_n<10, TH>(v, s_red);
-            if (c0 == 0)
+            if (zpass) {
                 zz = make_double2(v[0], v[1]);
+                have_z = true;
+            }
             if ((int)threadIdx.x < 4 && c0 + (int)threadIdx.x < K && emit) {
                 const int cc = threadIdx.x;
                 const double im = p.sand ? v[3 + 2 * cc] : fma(v[2 + 2 * cc], zz.y, v[3 + 2 * cc] * zz.x);
                 out[c0 + cc + (size_t)t * K] = gs * im;
             }
         }
+        any_stamp(21);
         if (t == N - 1 && threadIdx.x == 0 && emit) {  // figure of merit at t = N (:77, :94)
             if (p.sand) {
                 const double inv = 1.0 / (double)n;
@@ -650,6 +770,7 @@ __global__ __launch_bounds__(MFMA ? kAnyMfmaThreads : kAnyThreads) void any_swee
         double2 *tmp = Lc;
         Lc = Ln;
         Ln = tmp;
+    }
     }
 }
 
@@ -675,20 +796,71 @@ hipError_t launch_sweep_any(const AnyParams &p0, hipStream_t stream)
     static const bool mfma_off = [] { const char *e = std::getenv("GRAPE_ANY_MFMA"); return e && e[0] == '0'; }();
     const bool mfma = p0.n >= 17 && !mfma_off;
     if (mfma) {
-        const hipError_t e = ensure_dynamic_lds((const void *)any_sweep_kernel<true>, kAnyImgBytes);
-        if (e != hipSuccess)
-            return e;
+        for (const void *f : {(const void *)any_sweep_kernel<true, 0>, (const void *)any_sweep_kernel<true, 1>,
+                              (const void *)any_sweep_kernel<true, 2>, (const void *)any_sweep_kernel<true, 3>}) {
+            const hipError_t e = ensure_dynamic_lds(f, kAnyImgBytes);
+            if (e != hipSuccess)
+                return e;
+        }
     }
     AnyParams p = p0;
     if (const char *e = std::getenv("GRAPE_ANY_ABL"))
         p.abl = std::atoi(e);
+    unsigned long long *d_stamps = nullptr;
+    if (std::getenv("GRAPE_ANY_STAMPS")) {             // (diagnostic: synchronises, prints, frees)
+        const int zero = 0;
+        if (hipMalloc((void **)&d_stamps, sizeof(unsigned long long) * kAnyStampCap) == hipSuccess) {
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_any_stamps), &d_stamps, sizeof(d_stamps));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_any_stamp_n), &zero, sizeof(zero));
+        }
+    }
+    struct StampDump {
+        unsigned long long *d;
+        hipStream_t st;
+        ~StampDump()
+        {
+            if (!d)
+                return;
+            (void)hipStreamSynchronize(st);
+            int cnt = 0;
+            (void)hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_any_stamp_n), sizeof(cnt));
+            std::vector<unsigned long long> h((size_t)std::max(cnt, 0));
+            if (cnt > 0)
+                (void)hipMemcpy(h.data(), d, sizeof(unsigned long long) * cnt, hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "[any stamps] %d stamps (tag: us since the previous one)\n", cnt);
+            const int show = std::getenv("GRAPE_ANY_STAMPS_N") ? std::atoi(std::getenv("GRAPE_ANY_STAMPS_N")) : 120;
+            for (int i = 1; i < cnt; ++i) {
+                const double us = (double)((h[i] & 0x00ffffffffffffffull) - (h[i - 1] & 0x00ffffffffffffffull)) * 0.01;
+                if (i < show || i >= cnt - show)
+                    std::fprintf(stderr, "%d:%.1f ", (int)(h[i] >> 56), us);
+                if (i == show && cnt > 2 * show)
+                    std::fprintf(stderr, "\n ... \n");
+            }
+            std::fprintf(stderr, "\n");
+            unsigned long long *null = nullptr;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_any_stamps), &null, sizeof(null));
+            (void)hipFree(d);
+        }
+    } stamp_dump{d_stamps, stream};
     auto launch = [&](dim3 grid) {
-        if (mfma)
-            GRAPE_LAUNCH_AS(any_phase_name(p.phase), any_sweep_kernel<true>, grid, dim3(kAnyMfmaThreads),
-                            kAnyImgBytes, stream, p);
+        const int part = p.phase == 0 ? 0 : p.phase == 1 ? 1 : p.phase == 3 ? 3 : 2;
+#define GRAPE_ANY_LAUNCH(PART)                                                                                              \
+    do {                                                                                                                    \
+        if (mfma)                                                                                                           \
+            GRAPE_LAUNCH_AS(any_phase_name(p.phase), (any_sweep_kernel<true, PART>), grid, dim3(kAnyMfmaThreads),           \
+                            kAnyImgBytes, stream, p);                                                                       \
+        else                                                                                                                \
+            GRAPE_LAUNCH_AS(any_phase_name(p.phase), (any_sweep_kernel<false, PART>), grid, dim3(kAnyThreads), 0, stream, p); \
+    } while (0)
+        if (part == 0)
+            GRAPE_ANY_LAUNCH(0);
+        else if (part == 1)
+            GRAPE_ANY_LAUNCH(1);
+        else if (part == 3)
+            GRAPE_ANY_LAUNCH(3);
         else
-            GRAPE_LAUNCH_AS(any_phase_name(p.phase), any_sweep_kernel<false>, grid, dim3(kAnyThreads), 0,
-                            stream, p);
+            GRAPE_ANY_LAUNCH(2);
+#undef GRAPE_ANY_LAUNCH
     };
     const bool tp = p.tp_chunks > 1 && p.tp_q && p.tp_u && p.tp_r;
     if (p.prop_blocks > 1 || tp) {
