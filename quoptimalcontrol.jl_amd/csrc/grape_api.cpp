@@ -154,7 +154,6 @@ struct grape_ctx {
     double *d_act_an = nullptr, *d_act_gn = nullptr;
     int act_R = 0;                             // sparse rows of the control operators (0: dense forms kernel)
     bool act_shared = true;                    // one set of control operators for every member
-    bool vec4 = false;                         // family 2 plumbing, sweep_vec4.hip's kernel (n = 4, states 4 x 1, left multiplication)
     bool ctrl_shared = false;                  // the members' control operators are identical (memcmp)
     int32_t *d_any_sp_i = nullptr;             // size-generic family, sparse shared controls: [eptr | ectl | cptr | caddr]
     double2 *d_any_sp_c = nullptr;             //                                              [ecoef | ccoef]
@@ -604,21 +603,6 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
     // ensemble alone cannot fill it.
     const int N = cfg->n_slices, E = cfg->n_ensemble;
     c->family = wmax > 0 ? 0 : (nt > 0 ? 1 : 2);              // 2: n = 1 or n > 64 -- the size-generic kernel (sweep_any.hip)
-    // n = 4, states 4 x 1 under left multiplication (vec(rho) of one qubit under a Liouvillian, test/liou.jl:38-48), first-order
-    // gradient: the sequential vector chain of sweep_vec4.hip behind the size-generic family's plumbing (plain column-major
-    // operators, N propagators and N states per member, member rows + reduce) -- on request only, GRAPE_VEC4=1: measured at
-    // E = 1024, N = 1000 it takes 0.24 ms where the lane-pair kernel on the zero-padded states takes 0.26 (dissipative
-    // generator, general flow) and 0.135 (Hermitian generator -- the reference's own case --, unitary flow), and which of the
-    // two a problem is is not known before its operators arrive.
-    {
-        const char *ev = std::getenv("GRAPE_VEC4");
-        if (ev && ev[0] == '1' && grape::sweep_vec4_serves(cfg->n, cfg->n_controls) && c->m == 1 &&
-            cfg->sys_type == GRAPE_UNITARY_GATE && cfg->gradient != GRAPE_GRADIENT_EXACT &&
-            !(cfg->flags & (GRAPE_FLAG_KEEP_COSTATES | GRAPE_FLAG_PHASE_STAMPS | GRAPE_FLAG_FORCE_GENERAL))) {
-            c->family = 2;
-            c->vec4 = true;
-        }
-    }
     c->B = cfg->max_batch > 1 ? cfg->max_batch : 1;
     c->NT = nt;
     c->TSZ = (size_t)nt * nt * 256;
@@ -1895,8 +1879,6 @@ extern "C" int grape_set_operators(grape_ctx *c, const double *A, const double *
         c->states_bytes = 0;
         HIP_TRY(c, hipMalloc((void **)&c->d_states, full));
         c->states_bytes = full;
-        if (c->vec4)                                         // (the kernel writes column 0 of every X_t = [v_t 0 0 0])
-            HIP_TRY(c, hipMemset(c->d_states, 0, full));
     }
     HIP_TRY(c, hipMemcpy(c->d_ops, packed.data(), sizeof(double) * packed.size(), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_wts, wts, sizeof(double) * E, hipMemcpyHostToDevice));
@@ -2079,6 +2061,10 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
     p.dt = c->cfg.duration / c->cfg.n_slices;                 // src/GRAPE.jl:42
     p.dump_w1 = c->exact_w1 ? 1 : 0;
     p.zphi = c->d_zphi;
+    // n x 1 states under left multiplication at n = 4 (vec(rho) of one qubit under a Liouvillian with a dissipator: the general
+    // flow): the lane-pair kernel sweeps back on vectors (GRAPE_PAIR_VEC=0: on the padded matrices, as round 5)
+    p.vec = (c->family == 0 && c->pair && c->cfg.n == 4 && c->m == 1 && c->cfg.sys_type == GRAPE_UNITARY_GATE &&
+             c->cfg.gradient != GRAPE_GRADIENT_EXACT && !env_off("GRAPE_PAIR_VEC")) ? 1 : 0;
     bool timed = (c->cfg.flags & GRAPE_FLAG_TIME_KERNELS) != 0;
     if (timed && (c->cfg.flags & GRAPE_FLAG_TIME_SAMPLED) && (c->launches++ & 7) != 0)
         timed = false;
@@ -2190,10 +2176,7 @@ static int enqueue_eval(grape_ctx *c, const double *d_x, double *d_fg, hipStream
             a.tp_q = c->d_tp_q;
             a.tp_r = c->d_tp_r;
             a.tp_u = c->d_tp_m;
-            if (c->vec4)
-                HIP_TRY(c, grape::launch_sweep_vec4(a, stream));
-            else
-                HIP_TRY(c, grape::launch_sweep_any(a, stream));
+            HIP_TRY(c, grape::launch_sweep_any(a, stream));
             return GRAPE_OK;
         }
         TileParams t = tile_params(c, d_x, n_x);

@@ -98,6 +98,8 @@ struct SweepParams {
     int32_t dump_w1;
     double *zphi;         // (2 per member and control array) Phi = tr(L' X) = tr M
     int32_t tune;         // pair kernel, set by its launcher from GRAPE_PAIR_TUNE (tuning experiments; 0 in the product)
+    int32_t vec;          // pair kernel, general flow, left multiplication, n = 4: the states are n x 1 (column 0 of the padded
+                          // matrices) -- the sweep back runs on vectors and phase A stores no in-chunk prefixes
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of once per launch: the driver call sits
@@ -267,10 +269,6 @@ struct AnyParams {
 };
 hipError_t launch_sweep_any(const AnyParams &p, hipStream_t stream);
 int any_prop_blocks(int n, int N, long units, int cus);    // how many propagator blocks per member the launcher will use
-// n = 4, states 4 x 1, left multiplication (sweep_vec4.hip): the same parameters, a sequential vector chain hidden under the
-// propagators' Taylor series; the host zeroes `states` once (the kernel writes column 0 of every X_t)
-bool sweep_vec4_serves(int n, int K);
-hipError_t launch_sweep_vec4(const AnyParams &p, hipStream_t stream);
 
 // n = 33..64 (NT = 3, 4; sweep_grid.hip): a workgroup of NT x NT waves per matrix, the reference's general flow
 hipError_t launch_sweep_grid(int NT, int sandwich, bool keep_costates, const TileParams &p, hipStream_t stream);

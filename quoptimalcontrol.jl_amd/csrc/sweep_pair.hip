@@ -248,7 +248,10 @@ GRAPE_DEV void pwrite_gradient(double *out, const double2 *s_bt, int K, const PM
     }
 }
 
-template <int N, int SAND, int MODE, int MAXT, bool XGLDS, bool DUMPW = false>
+// VEC (general flow, left multiplication, n = 4, at most kVecSlices slices per lane): the states are n x 1 -- column 0 of the
+// zero-padded matrices -- and the sweep back runs on VECTORS (phase D, below); phase A then stores no in-chunk prefixes.
+constexpr int kVecSlices = 16;
+template <int N, int SAND, int MODE, int MAXT, bool XGLDS, bool DUMPW = false, bool VEC = false>
 __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restrict__ ops_all,
                                                           const double *__restrict__ x_all,
                                                           const double *__restrict__ wts_all,
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
             fetch_partner(Ppar, P);
             pmul(Qout, P, Ppar, Qin);
         }
-        if (MODE == PMODE_GENERAL)                    // in-chunk prefix product, read back in phase D
+        if (MODE == PMODE_GENERAL && !VEC)            // in-chunk prefix product, read back in phase D
             pstore_ws(Xw + (size_t)j * NN * stride, stride, Qout, par);
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -907,6 +910,127 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
         }
 
         pstamp(st, 3);
+        // ------------------------------------------------------------ phase D, general flow on n x 1 states (VEC)
+        // X_t = [x_t 0 0 0], L_t = [w_t 0 0 0]: the chunk's states by a forward pass x_j+1 = P_j x_j from the chunk-start state the
+        // scan delivered (kept in registers: 16 slices x 2 entries per lane), then w_j = P_j' w_j+1 backward with the gradient
+        // g[c,t] = gs Re(z w_t' B'_c x_t), z = x_t' w_t -- matrix-vector products on the lane's OWN columns of P_j (one 128-byte
+        // half per lane and pass: no partner half, no prefixes).  Per slice 3 x 256 B of workspace traffic instead of 4 x 256 B
+        // and ~36 complex FMAs per lane instead of three 4 x 4 products.  Own-block-first order as everywhere (cmatp.hpp): a
+        // lane's half of a vector = the entries of ITS index block, the partner's half arrives through DPP.
+        if constexpr (VEC) {
+            static_assert(N == 4 && !SAND && MODE == PMODE_GENERAL, "the vector sweep serves left multiplication at n = 4");
+            constexpr int SV = kVecSlices;
+            double xr[SV + 1][2], xi_[SV + 1][2];
+            {   // column 0 of the padded matrices lives in lane 0 of the pair: rows 0, 1 are its own block, rows 2, 3 lane 1's
+                const double a2 = pair_swap(Xs.re[2]), b2 = pair_swap(Xs.im[2]), a3 = pair_swap(Xs.re[3]), b3 = pair_swap(Xs.im[3]);
+                xr[0][0] = par ? a2 : Xs.re[0];
+                xi_[0][0] = par ? b2 : Xs.im[0];
+                xr[0][1] = par ? a3 : Xs.re[1];
+                xi_[0][1] = par ? b3 : Xs.im[1];
+            }
+            double wr[2], wi[2];
+            {
+                const double a2 = pair_swap(Le.re[2]), b2 = pair_swap(Le.im[2]), a3 = pair_swap(Le.re[3]), b3 = pair_swap(Le.im[3]);
+                wr[0] = par ? a2 : Le.re[0];
+                wi[0] = par ? b2 : Le.im[0];
+                wr[1] = par ? a3 : Le.re[1];
+                wi[1] = par ? b3 : Le.im[1];
+            }
+            PMat<N> Pj;
+            // forward pass: the states at the slices of this chunk
+#pragma unroll
+            for (int j = 0; j < SV; ++j) {
+                if (j < S && t0 + j < Nsl) {
+                    pload_ws(Pj, Pw + (size_t)j * pstep, stride, par);
+                    double yr[4], yi[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {          // y_loc[r] = P_loc[r, 0] x_own[0] + P_loc[r, 1] x_own[1]
+                        yr[r] = Pj.re[r] * xr[j][0];
+                        yr[r] = fma(-Pj.im[r], xi_[j][0], yr[r]);
+                        yr[r] = fma(Pj.re[r + 4], xr[j][1], yr[r]);
+                        yr[r] = fma(-Pj.im[r + 4], xi_[j][1], yr[r]);
+                        yi[r] = Pj.re[r] * xi_[j][0];
+                        yi[r] = fma(Pj.im[r], xr[j][0], yi[r]);
+                        yi[r] = fma(Pj.re[r + 4], xi_[j][1], yi[r]);
+                        yi[r] = fma(Pj.im[r + 4], xr[j][1], yi[r]);
+                    }
+                    // my rows 2, 3 are the partner's block: trade them for the partner's contribution to mine
+                    xr[j + 1][0] = yr[0] + pair_swap(yr[2]);
+                    xi_[j + 1][0] = yi[0] + pair_swap(yi[2]);
+                    xr[j + 1][1] = yr[1] + pair_swap(yr[3]);
+                    xi_[j + 1][1] = yi[1] + pair_swap(yi[3]);
+                } else {
+                    xr[j + 1][0] = xr[j][0];
+                    xi_[j + 1][0] = xi_[j][0];
+                    xr[j + 1][1] = xr[j][1];
+                    xi_[j + 1][1] = xi_[j][1];
+                }
+            }
+            // backward pass + gradient
+#pragma unroll
+            for (int j = SV - 1; j >= 0; --j) {
+                if (j < S && t0 + j < Nsl) {
+                    const int t = t0 + j;
+                    pload_ws(Pj, Pw + (size_t)j * pstep, stride, par);
+                    double lr[4], li[4];                   // w in my local row order: own block, then the partner's
+                    lr[0] = wr[0]; li[0] = wi[0]; lr[1] = wr[1]; li[1] = wi[1];
+                    lr[2] = pair_swap(wr[0]); li[2] = pair_swap(wi[0]); lr[3] = pair_swap(wr[1]); li[3] = pair_swap(wi[1]);
+#pragma unroll
+                    for (int jl = 0; jl < 2; ++jl) {       // (P' w)[own column jl] = sum_r conj(P_loc[r, jl]) w_loc[r]
+                        double ar = 0.0, ai = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            ar = fma(Pj.re[r + 4 * jl], lr[r], ar);
+                            ar = fma(Pj.im[r + 4 * jl], li[r], ar);
+                            ai = fma(Pj.re[r + 4 * jl], li[r], ai);
+                            ai = fma(-Pj.im[r + 4 * jl], lr[r], ai);
+                        }
+                        wr[jl] = ar;
+                        wi[jl] = ai;
+                    }
+                    // z = x_t' w_t (own halves + the partner's)
+                    double zr_ = xr[j][0] * wr[0];
+                    zr_ = fma(xi_[j][0], wi[0], zr_);
+                    zr_ = fma(xr[j][1], wr[1], zr_);
+                    zr_ = fma(xi_[j][1], wi[1], zr_);
+                    double zi_ = xr[j][0] * wi[0];
+                    zi_ = fma(-xi_[j][0], wr[0], zi_);
+                    zi_ = fma(xr[j][1], wi[1], zi_);
+                    zi_ = fma(-xi_[j][1], wr[1], zi_);
+                    zr_ += pair_swap(zr_);
+                    zi_ += pair_swap(zi_);
+                    // w_t in local row order again (it has just changed)
+                    lr[0] = wr[0]; li[0] = wi[0]; lr[1] = wr[1]; li[1] = wi[1];
+                    lr[2] = pair_swap(wr[0]); li[2] = pair_swap(wi[0]); lr[3] = pair_swap(wr[1]); li[3] = pair_swap(wi[1]);
+                    for (int c = 0; c < K; ++c) {          // a = w' B'_c x over my columns, pair sum; g = gs Re(z a)
+                        const double2 *bc = sB + (size_t)c * NE;
+                        double ar = 0.0, ai = 0.0;
+#pragma unroll
+                        for (int jl = 0; jl < 2; ++jl) {
+                            double ur = 0.0, ui = 0.0;     // u = sum_r conj(w_loc[r]) B'_loc[r, jl]
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const double2 b = bc[r + 4 * jl];
+                                ur = fma(lr[r], b.x, ur);
+                                ur = fma(li[r], b.y, ur);
+                                ui = fma(lr[r], b.y, ui);
+                                ui = fma(-li[r], b.x, ui);
+                            }
+                            ar = fma(ur, xr[j][jl], ar);
+                            ar = fma(-ui, xi_[j][jl], ar);
+                            ai = fma(ur, xi_[j][jl], ai);
+                            ai = fma(ui, xr[j][jl], ai);
+                        }
+                        ar += pair_swap(ar);
+                        ai += pair_swap(ai);
+                        if (par == 0)
+                            xg[j * K + c] = gs * fma(zr_, ar, -zi_ * ai);
+                    }
+                    if (t == Nsl - 1 && par == 0)
+                        s_F[mb] = pfigure_of_merit<N, SAND>(zr_, zi_);
+                }
+            }
+        } else {
         // ------------------------------------------------------------ phase D, general flow
         PMat<N> Lc = Le, Po, Pp, X, Xp, M, tmp, Lp;
         for (int j = S - 1; j >= 0; --j) {
@@ -958,6 +1082,7 @@ __global__ __launch_bounds__(MAXT) void sweep_pair_kernel(const double2 *__restr
                 if (t == Nsl - 1 && par == 0)
                     s_F[mb] = pfigure_of_merit<N, SAND>(zr, zi);
             }
+        }
         }
     }
     // results: LDS -> HBM, lane-contiguous.  (1) this member's unweighted row, (2) the block's weighted partial sum
@@ -1061,6 +1186,18 @@ static hipError_t plaunch_one(const SweepParams &p0, hipStream_t stream)
     }
     if (p.dump_w1)
         return hipErrorInvalidConfiguration;
+    if constexpr (N == 4 && SAND == 0 && MODE == PMODE_GENERAL && XGLDS) {
+        if (p.vec && p.S <= kVecSlices) {                    // n x 1 states: the sweep back on vectors
+            auto kern_v = sweep_pair_kernel<N, SAND, MODE, MAXT, XGLDS, false, true>;
+            if (lds > 64 * 1024) {
+                hipError_t e = ensure_dynamic_lds((const void *)kern_v, lds);
+                if (e != hipSuccess)
+                    return e;
+            }
+            GRAPE_LAUNCH_AS("sweep_pair_vec_kernel", kern_v, grid, block, lds, stream, p.ops, p.x, p.wts, p);
+            return hipGetLastError();
+        }
+    }
     auto kern = sweep_pair_kernel<N, SAND, MODE, MAXT, XGLDS>;
     if (lds > 64 * 1024) {
         hipError_t e = ensure_dynamic_lds((const void *)kern, lds);

@@ -11,8 +11,6 @@ hipError_t launch_sweep_tile(int, int, bool, const TileParams &, hipStream_t) { 
 hipError_t launch_sweep_grid(int, int, bool, const TileParams &, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_grid_prop(int, const TileParams &, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_sweep_any(const AnyParams &, hipStream_t) { return hipErrorNoDevice; }
-hipError_t launch_sweep_vec4(const AnyParams &, hipStream_t) { return hipErrorNoDevice; }
-bool sweep_vec4_serves(int n, int K) { return n == 4 && K >= 1 && K <= 8; }
 int any_prop_blocks(int n, int N, long units, int cus) { return (n < 17 || units >= 2L * cus) ? 1 : (int)std::max(1L, std::min<long>((2L * cus + units - 1) / units, std::max(1, N / 4))); }
 int reduce_rows_mflags(int Q, int n_x) { const long long g = (long long)((Q + 31) / 32) * n_x; return g >= 1 && g <= kMaxMflags ? (int)g : 0; }
 hipError_t launch_reduce(const double *, const double *, double *, double *, int, int, int, hipStream_t, DoneSignal) { return hipErrorNoDevice; }
