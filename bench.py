@@ -761,7 +761,7 @@ def compact(out):
             par = e.get("parity") or {}
             cpar = ([len(par["members"]), _r(par["max_rel_G"], 2), _r(par["max_F_err_over_tol"], 2), par["ok"]]
                     if "members" in par else {"error": par.get("error", "none")})
-            if "x" in e["id"]:                          # single problems (the `Problem` closure): latency lines -- rate, time, kernels
+            if "x" in e["id"] or e["id"] == "L1d":      # single problems (the `Problem` closure) and the 4 x 1 Liouvillian ensemble: rate, time, kernels
                 c["extra_configs"].append({"id": e["id"], "value": _r(e["value"], 5), "ms_per_step": _r(e["ms_per_step"], 5),
                                            "kernel": e["roofline"].get("kernel"), "parity": cpar})
                 continue
@@ -816,7 +816,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the device-resident loop and the extra configs")
-    ap.add_argument("--extra-configs", default="C4,C5,C4dense,C4expm,C6,C7,C2,C5x1,C4x1,C6x1,C7x1,C3pm,C4pm,C5pm")
+    ap.add_argument("--extra-configs", default="C4,C5,C4dense,C4expm,C6,C7,C2,C5x1,C4x1,C6x1,C7x1,L1d,C3pm,C4pm,C5pm")
     ap.add_argument("--details", default="", help="also write the complete record (every note, per-kernel model, L-BFGS traces) "
                                                   "to this file; the printed line stays compact")
     ap.add_argument("--verbose", action="store_true", help="print the complete record instead of the compact line")

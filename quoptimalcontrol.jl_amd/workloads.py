@@ -298,6 +298,13 @@ def config(name, E=None, N=None, **extra):
         kw.setdefault("N", 200)
         kw.setdefault("T", 1.0)
         return five_qubit_unitary(nq=7, **kw)
+    if name == "L1d":                                  # vec(rho) of one qubit under a DISSIPATIVE Liouvillian: 4 x 1 states, left
+        kw.setdefault("E", 1024)                       # multiplication, non-Hermitian generator (test/liou.jl:38-48 + a dissipator;
+        kw.setdefault("N", 1000)                       # VERDICT r5 Missing #1: the lane-pair kernel's vector sweep)
+        kw.setdefault("T", 5.0)
+        w = liouville_vec(nq=1, dissipative=True, **kw)
+        w.name = "L1d"
+        return w
     raise KeyError(name)
 
 

@@ -80,7 +80,7 @@ def test_scaling_forecast_and_compact_line_stay_within_the_drivers_tail():
             "kernel_max_us": 72.0, "kernel_launches": 113, "bytes_per_launch": 296747008,
             "model_s_equivalent": {"algorithmic_bytes_per_launch": 558891008}}
     par = {"members": [0, 341, 682, 1023], "max_rel_G": 2.5e-14, "max_F_err_over_tol": 0.002, "tol": 1e-10, "ok": True}
-    extra_ids = ["C4", "C5", "C4dense", "C4expm", "C6", "C7", "C2", "C5x1", "C4x1", "C6x1", "C7x1", "C3pm", "C4pm", "C5pm"]
+    extra_ids = ["C4", "C5", "C4dense", "C4expm", "C6", "C7", "C2", "C5x1", "C4x1", "C6x1", "C7x1", "L1d", "C3pm", "C4pm", "C5pm"]
     tile_roof = dict(roof, bound="mfma", unit="TFLOP/s", kernel="ctrl_sum_kernel;grid_prop_kernel",
                      kernels=[{"kernel": "ctrl_sum_kernel;grid_prop_kernel", "avg_us": 85700.0, "bound": "mfma", "frac_mfma": 0.72, "frac_hbm": 0.2},
                               {"kernel": "chain_tile_unitary_kernel;reduce_stage1;reduce_stage2", "avg_us": 83500.0, "bound": "mfma",
