@@ -19,8 +19,9 @@ stats C4_E1024 GRAPE_X=0 --config C4 --steps 40 --warmup 5
 stats C5_E4096 GRAPE_X=0 --config C5 --steps 2 --warmup 1
 stats C6_E256 GRAPE_X=0 --config C6 --steps 3 --warmup 1
 stats C7_E64 GRAPE_X=0 --config C7 --steps 5 --warmup 1
-stats C6x1 GRAPE_X=0 --config C6x1 --steps 50 --warmup 5
-stats C7x1 GRAPE_X=0 --config C7x1 --steps 10 --warmup 2
+stats C6x1 GRAPE_X=0 --config C6 --ensemble 1 --steps 50 --warmup 5
+stats C7x1 GRAPE_X=0 --config C7 --ensemble 1 --steps 10 --warmup 2
+stats L1d GRAPE_X=0 --config L1d --steps 200 --warmup 20
 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C3" > "$OUT/pmc_C3.log" 2>&1
 bash "$ROOT/tools/prof_pmc.sh" "$OUT/pmc_C7" --config C7 --steps 3 --warmup 1 > "$OUT/pmc_C7.log" 2>&1
 cd "$ROOT"
