@@ -83,8 +83,9 @@ def test_vector_sweep_against_the_mpmath_fixtures(qoc, monkeypatch, name):
 
 def test_vector_sweep_at_size_batches_lbfgs_and_the_fallback(qoc, oracle, monkeypatch):
     """E = 600, N = 130 (150 workgroups, chunks of 3 slices with a ragged tail): spot members against the oracle, batches,
-    L-BFGS; the Hermitian Liouvillian keeps the unitary flow; N = 2200 at E = 1024 needs 35 slices per lane -- beyond the vector
-    sweep's registers: the matrix sweep serves it."""
+    L-BFGS; the Hermitian Liouvillian keeps the unitary flow; N = 2200 at E = 1024 gets eight waves per member (grape_create keeps
+    lane pairs at 16 slices or fewer) and stays with the vector sweep; N = 4200 needs 17 slices per lane even then -- beyond the
+    vector sweep's registers: the matrix sweep serves it."""
     monkeypatch.delenv("GRAPE_PAIR_VEC", raising=False)
     w = qoc.workloads.liouville_vec(nq=1, E=600, N=130, T=2.0, dissipative=True)
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, member_results=True, max_batch=3) as eng:
@@ -105,13 +106,15 @@ def test_vector_sweep_at_size_batches_lbfgs_and_the_fallback(qoc, oracle, monkey
     with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N) as eng:
         eng.eval(w.x)
         assert "sweep_pair_vec_kernel" not in eng.kernel_names() and eng.info["unitary_flow"] == 1
-    w = qoc.workloads.liouville_vec(nq=1, E=1024, N=2200, T=2.0, dissipative=True)
-    with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, member_results=True) as eng:
-        eng.eval(w.x)
-        foms, grads = eng.member_results()
-        assert eng.info["slices_per_lane"] > 16 and "sweep_pair_vec_kernel" not in eng.kernel_names()
-    f_ref, g_ref = oracle.member_eval(w.sys_type, w.A[7], w.B[7], w.Xi[7], w.Xt[7], w.x, w.T)
-    assert_parity(foms[7], grads[7], f_ref, g_ref, 4, what="fallback member 7")
+    for N, vec in ((2200, True), (4200, False)):
+        w = qoc.workloads.liouville_vec(nq=1, E=1024, N=N, T=2.0, dissipative=True)
+        with qoc.GrapeEngine(w.sys_type, w.A, w.B, w.Xi, w.Xt, w.wts, w.T, w.N, member_results=True) as eng:
+            eng.eval(w.x)
+            foms, grads = eng.member_results()
+            assert (eng.info["slices_per_lane"] <= 16) == vec and ("sweep_pair_vec_kernel" in eng.kernel_names()) == vec
+            assert eng.info["waves_per_member"] == 8
+        f_ref, g_ref = oracle.member_eval(w.sys_type, w.A[7], w.B[7], w.Xi[7], w.Xt[7], w.x, w.T)
+        assert_parity(foms[7], grads[7], f_ref, g_ref, 4, what=f"N = {N} member 7")
 
 
 def test_vector_sweep_leaves_other_contexts_alone(qoc, monkeypatch):
