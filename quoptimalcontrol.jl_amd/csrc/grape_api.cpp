@@ -625,11 +625,12 @@ static int create_shard(const grape_config *cfg, int dev, grape_ctx **out)
         if (W > wneed) W = wneed;
         if (W > 8) W = 8;        // the wave totals of the scan combine sequentially: beyond 8 waves per member that
                                  // costs more than the shorter chunks save (single qubit, N = 1000: 15.2 vs 18.1 us)
-        // Lane pairs (n = 4): no more than 16 slices per pair.  An ensemble that fills the device alone got W = 1 whatever N was
-        // -- E = 4096, N = 2000: 63 slices per pair, the x / g staging no longer fits LDS, 2.01 ms; with W = 4 (16 slices) 1.13 ms;
-        // E = 2048 / 4096 at N = 1000: 0.346 / 0.645 -> 0.312 / 0.592 ms with W = 2; E = 1024, N = 2000: 0.352 -> 0.309 with W = 4
-        // (round 6, tools/w_sweep.py).  It also keeps n x 1 problems inside the vector sweep's 16 slices per lane.
-        if (c->pair && cfg->n == 4)
+        // No more than 16 slices per lane (pair).  An ensemble that fills the device alone got W = 1 whatever N was -- n = 4,
+        // E = 4096, N = 2000: 63 slices per pair, the x / g staging no longer fits LDS, 2.01 ms; with W = 4 (16 slices) 1.13 ms;
+        // E = 2048 / 4096 at N = 1000: 0.346 / 0.645 -> 0.312 / 0.592 ms with W = 2; E = 1024, N = 2000: 0.352 -> 0.309 with W = 4;
+        // n = 2 / 3, E = 4096, N = 4000: 1.07 / 1.86 -> 0.59 / 1.12 ms with W = 4 (round 6, tools/w_sweep.py, profiles/r06_w_sweep.txt).
+        // It also keeps n x 1 problems at n = 4 inside the vector sweep's 16 slices per lane.
+        if (c->family == 0)
             while (W < 8 && 2 * W <= wmax && (N + cpw * W - 1) / (cpw * W) > 16)
                 W *= 2;
     }
