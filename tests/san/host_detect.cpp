@@ -112,6 +112,43 @@ int main()
             }
         }
         (sp ? sparse_yes : sparse_no)++;
+        {   // the size-generic family's lists (build_any_sparse): by touched element and by control, both reproduce member 0's
+            // operators exactly, the entries of an element ascend in their control, the element list ascends
+            std::vector<int32_t> tidx, tptr, ectl, cptr, caddr;
+            std::vector<double> ecoef, ccoef;
+            const size_t cap = rnd() % (2 * (size_t)n * n + 2);
+            const long nnz = grape_host::build_any_sparse(B.data(), K, n, cap, tidx, tptr, ectl, ecoef, cptr, caddr, ccoef);
+            size_t truth = 0;
+            for (size_t q = 0; q < K * (size_t)n * n; ++q)
+                truth += (B[2 * q] != 0.0 || B[2 * q + 1] != 0.0) ? 1 : 0;
+            if (truth > cap) {
+                if (nnz != -1) { std::printf("any-sparse: over the bound but accepted\n"); return 12; }
+            } else {
+                if (nnz != (long)truth) { std::printf("any-sparse: wrong count\n"); return 13; }
+                if (nnz > 0) {
+                    if (tptr.size() != tidx.size() + 1 || cptr.size() != K + 1 || ectl.size() != truth || caddr.size() != truth ||
+                        ecoef.size() != 2 * truth || ccoef.size() != 2 * truth || (size_t)tptr.back() != truth || (size_t)cptr[K] != truth)
+                        { std::printf("any-sparse: sizes\n"); return 14; }
+                    std::vector<double> R1(2 * K * (size_t)n * n, 0.0), R2(R1);
+                    for (size_t m = 0; m < tidx.size(); ++m) {
+                        if (m && tidx[m] <= tidx[m - 1]) { std::printf("any-sparse: element order\n"); return 15; }
+                        for (int e = tptr[m]; e < tptr[m + 1]; ++e) {
+                            if (e > tptr[m] && ectl[e] <= ectl[e - 1]) { std::printf("any-sparse: control order\n"); return 16; }
+                            R1[2 * ((size_t)ectl[e] * n * n + tidx[m])] = ecoef[2 * e];
+                            R1[2 * ((size_t)ectl[e] * n * n + tidx[m]) + 1] = ecoef[2 * e + 1];
+                        }
+                    }
+                    for (size_t c = 0; c < K; ++c)
+                        for (int e = cptr[c]; e < cptr[c + 1]; ++e) {
+                            if (caddr[e] < 0 || caddr[e] >= n * n) { std::printf("any-sparse: position\n"); return 17; }
+                            R2[2 * (c * n * n + caddr[e])] = ccoef[2 * e];
+                            R2[2 * (c * n * n + caddr[e]) + 1] = ccoef[2 * e + 1];
+                        }
+                    for (size_t q = 0; q < R1.size(); ++q)
+                        if (R1[q] != B[q] || R2[q] != B[q]) { std::printf("any-sparse: lists do not reproduce B\n"); return 18; }
+                }
+            }
+        }
     }
     std::printf("host detect ok: rank-one %ld / not %ld, sparse %ld / dense %ld\n", yes, no, sparse_yes, sparse_no);
     return 0;
